@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/ from the reference tree.
+
+Run ONCE in the build container (where /root/reference is mounted); the GPU box never
+sees /root/reference, so everything the tests need is written here as small .npz files.
+
+Sources (all under /root/reference):
+  * tests/test_pca.py:34-59          -> pca_toy.npz          (A_list, A_pca, A_svd)
+  * tests/test_neighbors.py:23-48    -> neighbors_toy.npz    (X, distances_euclidean,
+                                                              connectivities_umap, transitions*)
+  * src/scanpy/datasets/10x_pbmc68k_reduced.zarr.zip
+                                      -> pbmc68k_reduced.npz (X, counts CSR, stored
+                                         distances / connectivities CSR, X_pca, louvain codes)
+
+The reference cannot be imported here (needs Python >= 3.12), so the literal arrays are
+pulled out of the test modules with `ast`, and the zarr-v3 store is decoded by hand
+(zip member -> `sharding_indexed` shard -> trailing (offset,nbytes) index -> zstd chunk).
+"""
+from __future__ import annotations
+
+import ast
+import json
+import sys
+import zipfile
+from pathlib import Path
+
+import numpy as np
+
+REF = Path("/root/reference")
+OUT = Path(__file__).resolve().parent
+
+
+def literal_arrays(pyfile: Path, names: set[str]) -> dict[str, np.ndarray]:
+    """Evaluate top-level `name = <literal or np.array(literal)>` assignments."""
+    tree = ast.parse(pyfile.read_text())
+    out = {}
+    for node in tree.body:
+        if not isinstance(node, ast.Assign) or len(node.targets) != 1:
+            continue
+        tgt = node.targets[0]
+        if not isinstance(tgt, ast.Name) or tgt.id not in names:
+            continue
+        val = node.value
+        if isinstance(val, ast.Call):  # np.array([...])
+            val = val.args[0]
+        out[tgt.id] = np.array(ast.literal_eval(val), dtype=np.float64)
+    missing = names - out.keys()
+    if missing:
+        raise SystemExit(f"{pyfile}: did not find {sorted(missing)}")
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# minimal zarr-v3 reader: regular chunk grid of shard files, each holding a C-ordered grid of
+# inner chunks; inner codecs bytes(little)+zstd; shard index at the end =
+# n_inner x (offset u64, nbytes u64) + crc32c
+# --------------------------------------------------------------------------------------
+def _zstd_decompress(buf: bytes, nbytes: int) -> bytes:
+    import pyarrow as pa
+
+    return pa.Codec("zstd").decompress(buf, decompressed_size=nbytes).to_pybytes()
+
+
+def read_zarr_array(z: zipfile.ZipFile, path: str) -> np.ndarray:
+    meta = json.loads(z.read(f"{path}/zarr.json"))
+    shape = tuple(meta["shape"])
+    dtype = np.dtype(meta["data_type"])
+    chunk = tuple(meta["chunk_grid"]["configuration"]["chunk_shape"])
+    (codec,) = meta["codecs"]
+    assert codec["name"] == "sharding_indexed", codec["name"]
+    inner = tuple(codec["configuration"]["chunk_shape"])
+    assert [c["name"] for c in codec["configuration"]["codecs"]] == ["bytes", "zstd"]
+    assert codec["configuration"]["index_location"] == "end"
+    out = np.full(shape, meta["fill_value"], dtype=dtype)
+    grid = [-(-s // c) for s, c in zip(shape, chunk)]
+    per_shard = [c // i for c, i in zip(chunk, inner)]  # inner chunks per shard, per axis
+    n_inner = int(np.prod(per_shard))
+    inner_bytes = int(np.prod(inner)) * dtype.itemsize
+    for sidx in np.ndindex(*grid):
+        key = f"{path}/c/" + "/".join(map(str, sidx))
+        raw = z.read(key)
+        index = np.frombuffer(raw[-(16 * n_inner + 4) : -4], dtype="<u8").reshape(n_inner, 2)
+        for flat, iidx in enumerate(np.ndindex(*per_shard)):
+            off, nb = index[flat]
+            if off == np.iinfo(np.uint64).max:  # empty inner chunk -> fill value
+                continue
+            buf = _zstd_decompress(raw[int(off) : int(off + nb)], inner_bytes)
+            block = np.frombuffer(buf, dtype=dtype.newbyteorder("<")).reshape(inner)
+            lo = [s * c + i * ic for s, c, i, ic in zip(sidx, chunk, iidx, inner)]
+            sl = tuple(slice(l, min(l + ic, s)) for l, ic, s in zip(lo, inner, shape))
+            if any(s.start >= s.stop for s in sl):
+                continue
+            out[sl] = block[tuple(slice(0, s.stop - s.start) for s in sl)]
+    return out
+
+
+def read_csr(z: zipfile.ZipFile, path: str) -> dict[str, np.ndarray]:
+    meta = json.loads(z.read(f"{path}/zarr.json"))
+    assert meta["attributes"]["encoding-type"] == "csr_matrix"
+    return dict(
+        data=read_zarr_array(z, f"{path}/data"),
+        indices=read_zarr_array(z, f"{path}/indices"),
+        indptr=read_zarr_array(z, f"{path}/indptr"),
+        shape=np.array(meta["attributes"]["shape"], dtype=np.int64),
+    )
+
+
+def main() -> None:
+    if not REF.exists():
+        raise SystemExit("/root/reference not present: fixtures can only be regenerated in the build container")
+
+    pca = literal_arrays(REF / "tests/test_pca.py", {"A_list", "A_pca", "A_svd"})
+    np.savez(OUT / "pca_toy.npz", **pca)
+
+    nb_names = {
+        "X",
+        "distances_euclidean",
+        "distances_euclidean_all",
+        "connectivities_umap",
+        "transitions_sym_umap",
+        "transitions_umap",
+    }
+    nb = literal_arrays(REF / "tests/test_neighbors.py", nb_names)
+    nb["n_neighbors"] = np.array(3)  # tests/test_neighbors.py:24 (includes the point itself)
+    np.savez(OUT / "neighbors_toy.npz", **nb)
+
+    z = zipfile.ZipFile(REF / "src/scanpy/datasets/10x_pbmc68k_reduced.zarr.zip")
+    fx = {}
+    fx["X"] = read_zarr_array(z, "X")
+    for name, path in [("counts", "layers/counts"), ("distances", "obsp/distances"), ("connectivities", "obsp/connectivities")]:
+        for k, v in read_csr(z, path).items():
+            fx[f"{name}_{k}"] = v
+    fx["X_pca"] = read_zarr_array(z, "obsm/X_pca")
+    fx["louvain_codes"] = read_zarr_array(z, "obs/louvain/codes")
+    fx["bulk_labels_codes"] = read_zarr_array(z, "obs/bulk_labels/codes")
+    fx["highly_variable"] = read_zarr_array(z, "var/highly_variable")
+    fx["n_neighbors"] = read_zarr_array(z, "uns/neighbors/params/n_neighbors")
+    np.savez_compressed(OUT / "pbmc68k_reduced.npz", **fx)
+    for f in ("pca_toy.npz", "neighbors_toy.npz", "pbmc68k_reduced.npz"):
+        print(f, (OUT / f).stat().st_size, "bytes")
+
+
+if __name__ == "__main__":
+    sys.exit(main())
