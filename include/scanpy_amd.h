@@ -1,0 +1,163 @@
+/*
+ * scanpy_amd.h -- C ABI of libscanpy_amd.so (MI355X / gfx950 kernels for the
+ * sc.pp.pca -> sc.pp.neighbors -> sc.tl.leiden path).
+ *
+ * The reference (scverse/scanpy) is pure Python and has no FFI of its own; the entry
+ * points below are the native boundary a binding for that path would call.  Each one
+ * cites the reference code whose arithmetic it replaces (paths relative to the scanpy
+ * source tree).  Conventions:
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *   - the caller owns all buffers (inputs, outputs, workspace); the library allocates
+ *     nothing that outlives a call and never frees caller memory;
+ *   - `stream` is a hipStream_t; work is enqueued on it.  Calls that must report a
+ *     data-dependent size (`*_host` outputs) synchronise that stream before returning;
+ *   - return value: 0 on success, a negative SCAMD_E* code otherwise, with a
+ *     human-readable message available from scamd_last_error() (thread-local);
+ *   - no C++ exceptions cross the boundary; one host thread per device.
+ *   - row-major everywhere; CSR = (indptr int64[n+1], indices int32[nnz], data f32[nnz]).
+ */
+#ifndef SCANPY_AMD_H
+#define SCANPY_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* scamd_stream_t; /* == hipStream_t */
+
+#define SCAMD_OK 0
+#define SCAMD_EINVAL (-1)     /* bad argument */
+#define SCAMD_EWORKSPACE (-2) /* workspace too small */
+#define SCAMD_EHIP (-3)       /* HIP runtime error */
+#define SCAMD_EUNSUPPORTED (-4)
+#define SCAMD_ECAPACITY (-5)  /* caller-provided output capacity too small */
+
+#define SCAMD_ABI_VERSION 1
+
+int scamd_abi_version(void);
+const char* scamd_last_error(void);
+/* Number of HIP devices visible (0 on a CPU-only host); never fails. */
+int scamd_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * kNN -- exact brute-force Euclidean k-nearest-neighbours of a row range of X against all of X.
+ * Replaces sklearn KNeighborsTransformer(algorithm='brute') as called at
+ * src/scanpy/neighbors/__init__.py:754-768 (reference `transformer='sklearn'` path) together with
+ * the self-column handling of src/scanpy/neighbors/_common.py:74-98 and the in-place diagonal
+ * zeroing at neighbors/__init__.py:644.
+ *
+ *   x        [n, d] float32, row stride ld_x (elements)
+ *   queries  rows q_begin .. q_begin+n_query-1 of x (a rank's row shard; the whole matrix on 1 GPU)
+ *   k        columns to return.  Column 0 is the query itself with distance exactly 0, columns
+ *            1..k-1 its k-1 nearest OTHER rows ordered by (distance, index) -- i.e. what the
+ *            reference feeds to the connectivity step for n_neighbors = k.
+ *   out_idx  [n_query, k] int32   (-1 where fewer than k-1 other rows exist)
+ *   out_dist [n_query, k] float64 Euclidean distance, sqrt of the float64 sum of squared
+ *            float64 differences of the float32 inputs (+inf for missing entries)
+ *   n_fallback_host  (optional, host) number of queries whose candidate list could not be
+ *            certified by the float32 MFMA pass and were recomputed by the float64 scan.
+ *   cert_scale  1.0 normally; >1 widens the certification margin (tests use a huge value to force
+ *            every query through the float64 fallback scan).
+ * Exactness: pass 1 (FP32 MFMA, ||c||^2 - 2 q.c) keeps KP > k candidates per query; pass 2 re-ranks
+ * them in float64; a query is accepted only if its k-th exact distance is provably below every
+ * rejected candidate given the float32 rounding bound, otherwise pass 3 rescans it in float64.
+ * ---------------------------------------------------------------------------------------- */
+size_t scamd_knn_workspace_bytes(int64_t n, int d, int64_t n_query, int k);
+int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x,
+                     int64_t q_begin, int64_t n_query, int k,
+                     int32_t* out_idx, double* out_dist,
+                     double cert_scale, int64_t* n_fallback_host,
+                     void* workspace, size_t workspace_bytes, scamd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fuzzy simplicial set -- umap connectivities from a kNN result.
+ * Replaces umap.umap_.fuzzy_simplicial_set(..., set_op_mix_ratio=1, local_connectivity=1) as called
+ * at src/scanpy/neighbors/_connectivity.py:103-138 (smooth_knn_dist + compute_membership_strengths
+ * + W + W^T - W o W^T, zeros eliminated, CSR with sorted column indices).
+ *
+ *   knn_idx  [n, k] int32, column 0 = the row itself; knn_dist [n, k] float32
+ *   out_indptr [n+1] int64; out_indices/out_data: capacity `cap` entries (2*n*(k-1) always suffices)
+ *   out_sigma, out_rho [n] float32 (optional, may be NULL)
+ *   nnz_host  (host) number of stored entries written
+ * ---------------------------------------------------------------------------------------- */
+size_t scamd_fuzzy_workspace_bytes(int64_t n, int k);
+int scamd_fuzzy_simplicial_set_f32(const int32_t* knn_idx, const float* knn_dist, int64_t n, int k,
+                                   int64_t* out_indptr, int32_t* out_indices, float* out_data,
+                                   int64_t cap, float* out_sigma, float* out_rho, int64_t* nnz_host,
+                                   void* workspace, size_t workspace_bytes, scamd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * PCA building blocks on a CSR float32 matrix (n rows = cells, g columns = genes).
+ * Together they replace sklearn PCA(svd_solver='arpack')._fit_truncated on sparse input
+ * (sklearn/decomposition/_pca.py:704-793 as called at src/scanpy/preprocessing/_pca/__init__.py:
+ * 287-308): mean_variance_axis, the implicitly centred operator X - 1 mu^T
+ * (sklearn/utils/sparsefuncs.py:718-742; in-repo restatement _pca/_compat.py:43-56) applied to
+ * blocks of vectors, and the Gram-matrix alternative of _pca/_kernels.py:14-58.
+ * ---------------------------------------------------------------------------------------- */
+/* per-row sum and sum of squares in float64 (fixed summation order).  Applied to the CSC copy
+ * (rows = genes) it yields the column statistics of mean_variance_axis. */
+int scamd_csr_row_stats_f32(const int64_t* indptr, const float* data, int64_t n_rows,
+                            double* row_sum, double* row_sumsq, scamd_stream_t stream);
+/* Deterministic (stable) CSR -> CSC: t_indptr int64[g+1], t_indices int32[nnz] (row ids, ascending
+ * within a column), t_data f32[nnz]. */
+size_t scamd_csr_transpose_workspace_bytes(int64_t n, int64_t g, int64_t nnz);
+int scamd_csr_transpose_f32(const int64_t* indptr, const int32_t* indices, const float* data,
+                            int64_t n, int64_t g, int64_t nnz,
+                            int64_t* t_indptr, int32_t* t_indices, float* t_data,
+                            void* workspace, size_t workspace_bytes, scamd_stream_t stream);
+/* Y[n, l] (float32) = A[n, g] * B[g, l] - 1 * shift[l]^T   (shift may be NULL).
+ * A is CSR; B row-major float32 with leading dimension l; 1 <= l <= 128. */
+int scamd_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, const float* data,
+                       int64_t n, int64_t g, const float* b, int l, const float* shift,
+                       float* y, scamd_stream_t stream);
+/* W[n_rows, l] (float64) = A * B with float64 accumulation of float32 products in a fixed order
+ * (A = the CSC copy viewed as a g x n CSR, B = Y[n, l] float32: W = X^T Y); optional rank-1
+ * correction W -= scale[n_rows] * colsum[l]^T (scale = column means, colsum = 1^T Y; both float64,
+ * both NULL to skip). */
+size_t scamd_spmm_f64acc_workspace_bytes(int64_t n_rows, int64_t nnz, int l);
+int scamd_spmm_csr_f32_f64acc(const int64_t* indptr, const int32_t* indices, const float* data,
+                              int64_t n_rows, int64_t nnz, const float* b, int l,
+                              const double* scale, const double* colsum, double* w,
+                              void* workspace, size_t workspace_bytes, scamd_stream_t stream);
+/* colsum[l] (float64) = 1^T Y for Y [n, l] float32, fixed summation order. */
+size_t scamd_colsum_workspace_bytes(int l);
+int scamd_colsum_f32_f64(const float* y, int64_t n, int l, double* colsum,
+                         void* workspace, size_t workspace_bytes, scamd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Leiden community detection on a symmetric weighted CSR graph.
+ * Replaces leidenalg.find_partition(g, RBConfigurationVertexPartition, weights, n_iterations,
+ * resolution_parameter, seed) / igraph Graph.community_leiden(objective_function='modularity')
+ * as called at src/scanpy/tools/_leiden.py:167-196 (graph built by
+ * src/scanpy/_utils/__init__.py:278-304).  Objective:
+ *   Q = 1/(2m) sum_ij (A_ij - resolution * k_i k_j / (2m)) delta(c_i, c_j).
+ *   membership [n] int32: consecutive ids, renumbered by decreasing community size
+ *   modularity_host, n_communities_host: host outputs
+ *   n_iterations < 0: iterate until an iteration changes nothing.
+ * ---------------------------------------------------------------------------------------- */
+size_t scamd_leiden_workspace_bytes(int64_t n, int64_t nnz);
+int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indices, const float* weights,
+                         int64_t n, int64_t nnz, double resolution, int n_iterations,
+                         double beta, uint64_t seed,
+                         int32_t* membership, double* modularity_host, int32_t* n_communities_host,
+                         void* workspace, size_t workspace_bytes, scamd_stream_t stream);
+/* Modularity of a given membership (replaces igraph Graph.modularity as used by
+ * src/scanpy/metrics/_metrics.py:202-214). */
+int scamd_modularity_csr_f32(const int64_t* indptr, const int32_t* indices, const float* weights,
+                             int64_t n, const int32_t* membership, double resolution,
+                             double* modularity_host, void* workspace, size_t workspace_bytes,
+                             scamd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Self tests / micro benchmarks (device).  scamd_selftest_mfma_layout checks the
+ * v_mfma_f32_32x32x2_f32 operand/result lane mapping the kNN kernel relies on; returns 0 if OK.
+ * ---------------------------------------------------------------------------------------- */
+int scamd_selftest_mfma_layout(scamd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCANPY_AMD_H */

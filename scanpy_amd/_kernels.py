@@ -1,0 +1,126 @@
+"""Thin torch-tensor wrappers over the C ABI (include/scanpy_amd.h).  No arithmetic happens here."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._device import ptr, require_gpu, stream_ptr, workspace_pool
+
+
+def _ws(nbytes: int, dev: torch.device):
+    buf = workspace_pool.get(nbytes, dev)
+    return buf, C.c_size_t(buf.numel())
+
+
+def mfma_selftest() -> None:
+    require_gpu()
+    _lib.check(_lib.load().scamd_selftest_mfma_layout(stream_ptr()), "mfma selftest")
+
+
+def knn(x: torch.Tensor, k: int, *, q_begin: int = 0, n_query: int | None = None, cert_scale: float = 1.0):
+    """x [n, d] float32 (device).  -> (idx int32 [nq, k], dist float64 [nq, k], n_fallback)."""
+    dev = require_gpu()
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.is_cuda
+    x = x.contiguous()
+    n, d = x.shape
+    nq = n - q_begin if n_query is None else n_query
+    idx = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    dist = torch.empty((nq, k), dtype=torch.float64, device=dev)
+    need = lib.scamd_knn_workspace_bytes(n, d, nq, k)
+    if need == 0 and nq > 0:
+        raise _lib.ScamdError(f"knn: unsupported shape d={d} (max 128) / k={k} (max 120)")
+    ws, wsz = _ws(need, dev)
+    nfb = C.c_int64(0)
+    rc = lib.scamd_knn_l2_f32(ptr(x), n, d, x.stride(0), q_begin, nq, k, ptr(idx), ptr(dist),
+                              float(cert_scale), C.byref(nfb), ptr(ws), wsz, stream_ptr())
+    _lib.check(rc, "scamd_knn_l2_f32")
+    return idx, dist, int(nfb.value)
+
+
+def fuzzy_simplicial_set(knn_idx: torch.Tensor, knn_dist: torch.Tensor):
+    """-> (indptr int64 [n+1], indices int32 [nnz], data float32 [nnz], sigma [n], rho [n])."""
+    dev = require_gpu()
+    lib = _lib.load()
+    n, k = knn_idx.shape
+    knn_idx = knn_idx.to(torch.int32).contiguous()
+    knn_dist = knn_dist.to(torch.float32).contiguous()
+    cap = 2 * n * (k - 1)
+    indptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    indices = torch.empty(cap, dtype=torch.int32, device=dev)
+    data = torch.empty(cap, dtype=torch.float32, device=dev)
+    sigma = torch.empty(n, dtype=torch.float32, device=dev)
+    rho = torch.empty(n, dtype=torch.float32, device=dev)
+    ws, wsz = _ws(lib.scamd_fuzzy_workspace_bytes(n, k), dev)
+    nnz = C.c_int64(0)
+    rc = lib.scamd_fuzzy_simplicial_set_f32(ptr(knn_idx), ptr(knn_dist), n, k, ptr(indptr), ptr(indices), ptr(data),
+                                            cap, ptr(sigma), ptr(rho), C.byref(nnz), ptr(ws), wsz, stream_ptr())
+    _lib.check(rc, "scamd_fuzzy_simplicial_set_f32")
+    m = int(nnz.value)
+    return indptr, indices[:m], data[:m], sigma, rho
+
+
+def csr_transpose(indptr: torch.Tensor, indices: torch.Tensor, data: torch.Tensor, n: int, g: int):
+    dev = require_gpu()
+    lib = _lib.load()
+    nnz = data.numel()
+    t_indptr = torch.empty(g + 1, dtype=torch.int64, device=dev)
+    t_indices = torch.empty(nnz, dtype=torch.int32, device=dev)
+    t_data = torch.empty(nnz, dtype=torch.float32, device=dev)
+    ws, wsz = _ws(lib.scamd_csr_transpose_workspace_bytes(n, g, nnz), dev)
+    rc = lib.scamd_csr_transpose_f32(ptr(indptr), ptr(indices), ptr(data), n, g, nnz, ptr(t_indptr), ptr(t_indices),
+                                     ptr(t_data), ptr(ws), wsz, stream_ptr())
+    _lib.check(rc, "scamd_csr_transpose_f32")
+    return t_indptr, t_indices, t_data
+
+
+def csr_row_stats(indptr: torch.Tensor, data: torch.Tensor, n_rows: int):
+    dev = require_gpu()
+    s = torch.empty(n_rows, dtype=torch.float64, device=dev)
+    q = torch.empty(n_rows, dtype=torch.float64, device=dev)
+    _lib.check(_lib.load().scamd_csr_row_stats_f32(ptr(indptr), ptr(data), n_rows, ptr(s), ptr(q), stream_ptr()),
+               "scamd_csr_row_stats_f32")
+    return s, q
+
+
+def spmm(indptr, indices, data, n: int, g: int, b: torch.Tensor, shift: torch.Tensor | None = None) -> torch.Tensor:
+    """Y[n, l] = A B - 1 shift^T, float32."""
+    dev = require_gpu()
+    b = b.to(torch.float32).contiguous()
+    assert b.shape[0] == g
+    l = b.shape[1]
+    y = torch.empty((n, l), dtype=torch.float32, device=dev)
+    if shift is not None:
+        shift = shift.to(torch.float32).contiguous()
+    _lib.check(_lib.load().scamd_spmm_csr_f32(ptr(indptr), ptr(indices), ptr(data), n, g, ptr(b), l, ptr(shift),
+                                              ptr(y), stream_ptr()), "scamd_spmm_csr_f32")
+    return y
+
+
+def spmm_f64acc(indptr, indices, data, n_rows: int, b: torch.Tensor, scale: torch.Tensor | None = None,
+                colsum: torch.Tensor | None = None) -> torch.Tensor:
+    """W[n_rows, l] float64 = A B (float64 accumulation) - scale colsum^T."""
+    dev = require_gpu()
+    lib = _lib.load()
+    assert b.dtype == torch.float32 and b.is_contiguous()
+    l = b.shape[1]
+    nnz = data.numel()
+    w = torch.empty((n_rows, l), dtype=torch.float64, device=dev)
+    ws, wsz = _ws(lib.scamd_spmm_f64acc_workspace_bytes(n_rows, nnz, l), dev)
+    rc = lib.scamd_spmm_csr_f32_f64acc(ptr(indptr), ptr(indices), ptr(data), n_rows, nnz, ptr(b), l, ptr(scale),
+                                       ptr(colsum), ptr(w), ptr(ws), wsz, stream_ptr())
+    _lib.check(rc, "scamd_spmm_csr_f32_f64acc")
+    return w
+
+
+def colsum(y: torch.Tensor) -> torch.Tensor:
+    dev = require_gpu()
+    lib = _lib.load()
+    assert y.dtype == torch.float32 and y.is_contiguous()
+    n, l = y.shape
+    out = torch.empty(l, dtype=torch.float64, device=dev)
+    ws, wsz = _ws(lib.scamd_colsum_workspace_bytes(l), dev)
+    _lib.check(lib.scamd_colsum_f32_f64(ptr(y), n, l, ptr(out), ptr(ws), wsz, stream_ptr()), "scamd_colsum_f32_f64")
+    return out

@@ -1,0 +1,64 @@
+"""ctypes binding of libscanpy_amd.so (the C ABI declared in include/scanpy_amd.h).
+
+The product path has NO CPU fallback: if the shared library is missing or no GPU is visible the
+calls raise.  `load()` only dlopens (works on a CPU-only host, used by the symbol-export test).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from functools import lru_cache
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "_lib" / "libscanpy_amd.so"
+
+_i64, _i32, _f64, _sz, _vp, _u64 = C.c_int64, C.c_int, C.c_double, C.c_size_t, C.c_void_p, C.c_uint64
+
+# name -> (restype, argtypes); must list every symbol of include/scanpy_amd.h
+SIGNATURES = {
+    "scamd_abi_version": (_i32, []),
+    "scamd_last_error": (C.c_char_p, []),
+    "scamd_device_count": (_i32, []),
+    "scamd_knn_workspace_bytes": (_sz, [_i64, _i32, _i64, _i32]),
+    "scamd_knn_l2_f32": (_i32, [_vp, _i64, _i32, _i64, _i64, _i64, _i32, _vp, _vp, _f64, C.POINTER(_i64), _vp, _sz, _vp]),
+    "scamd_fuzzy_workspace_bytes": (_sz, [_i64, _i32]),
+    "scamd_fuzzy_simplicial_set_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp, C.POINTER(_i64), _vp, _sz, _vp]),
+    "scamd_csr_row_stats_f32": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "scamd_csr_transpose_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "scamd_csr_transpose_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "scamd_spmm_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp]),
+    "scamd_spmm_f64acc_workspace_bytes": (_sz, [_i64, _i64, _i32]),
+    "scamd_spmm_csr_f32_f64acc": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "scamd_colsum_workspace_bytes": (_sz, [_i32]),
+    "scamd_colsum_f32_f64": (_i32, [_vp, _i64, _i32, _vp, _vp, _sz, _vp]),
+    "scamd_leiden_workspace_bytes": (_sz, [_i64, _i64]),
+    "scamd_leiden_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _f64, _i32, _f64, _u64, _vp, C.POINTER(_f64), C.POINTER(_i32), _vp, _sz, _vp]),
+    "scamd_modularity_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _f64, C.POINTER(_f64), _vp, _sz, _vp]),
+    "scamd_selftest_mfma_layout": (_i32, [_vp]),
+}
+
+
+class ScamdError(RuntimeError):
+    pass
+
+
+@lru_cache(maxsize=1)
+def load() -> C.CDLL:
+    if not LIB_PATH.exists():
+        raise ScamdError(
+            f"{LIB_PATH} not found: build it with `python -m scanpy_amd._build` "
+            "(scanpy_amd has no CPU fallback for the pca/neighbors/leiden kernels)"
+        )
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.scamd_abi_version() != 1:
+        raise ScamdError("libscanpy_amd.so ABI version mismatch; rebuild")
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().scamd_last_error().decode(errors="replace")
+        raise ScamdError(f"{what or 'libscanpy_amd'} failed (code {rc}): {msg}")

@@ -1,0 +1,597 @@
+// Exact brute-force Euclidean kNN for gfx950 (MI355X).
+//
+// Replaces sklearn KNeighborsTransformer(algorithm='brute') as called by the reference at
+// src/scanpy/neighbors/__init__.py:754-768 plus the self-column conventions of
+// src/scanpy/neighbors/_common.py:74-98.  Three passes:
+//
+//   1. knn_select_kernel   FP32 MFMA (v_mfma_f32_32x32x2_f32): s(q,c) = ||c||^2 - 2 q.c for a
+//      32-query x 32-candidate tile per instruction chain; every wave owns 32 queries (their
+//      -2q fragments stay in VGPRs for the whole sweep) and streams ALL candidates through an
+//      LDS-staged, double-buffered tile shared by the block's waves.  A per-query threshold
+//      (current KP-th best) filters the 16 results each lane holds; survivors are inserted into a
+//      KP-slot list in LDS.  KP > k, so the list is a superset of the answer unless float32
+//      rounding interferes -- which pass 2 proves or disproves.
+//   2. knn_rerank_kernel   float64 (q-c)^2 re-evaluation of the KP candidates, ordering by
+//      (distance, index), explicit self column, and a certificate: the k-th exact distance must
+//      lie below the final threshold by more than the float32 error bound of pass 1.
+//   3. knn_fallback_kernel float64 scan of all rows for the (rare) uncertified queries.
+//
+// Roofline: pass 1 is FP32-MFMA bound (2*n_query*n*2H flop); passes 2/3 are negligible.
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace scamd {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int FALLBACK_CAP = 2048;    // collected rows per uncertified query
+constexpr int FALLBACK_CHUNK = 1024;  // uncertified queries processed per launch
+
+// ------------------------------------------------------------------------------------------------
+// pack: zero-padded [n_pad][DP] copy, float32 squared norms (rounded once from float64), max norm
+// ------------------------------------------------------------------------------------------------
+__global__ void knn_pack_kernel(const float* __restrict__ x, int64_t n, int d, int64_t ld, int DP,
+                                int64_t n_pad, float* __restrict__ xp, float* __restrict__ cn,
+                                unsigned int* __restrict__ cmax_bits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  float wmax = 0.f;
+  for (int64_t r = wave; r < n_pad; r += nwaves) {
+    double s = 0.0;
+    for (int c = lane; c < DP; c += 64) {
+      float v = (r < n && c < d) ? x[r * ld + c] : 0.f;
+      xp[r * DP + c] = v;
+      s += (double)v * (double)v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    float nf = (r < n) ? (float)s : INFINITY;  // pad rows can never be selected
+    if (lane == 0) cn[r] = nf;
+    if (r < n) wmax = fmaxf(wmax, nf);
+  }
+  if (lane == 0 && wmax > 0.f) atomicMax(cmax_bits, __float_as_uint(wmax));
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 1
+// ------------------------------------------------------------------------------------------------
+template <int H, int TC, int NW, int KP>
+struct SelectCfg {
+  static constexpr int DP = 2 * H;
+  static constexpr int DPL = DP + 1;  // odd row stride -> conflict-free ds_read_b32 fragments
+  static constexpr int QB = NW * 32;
+  static constexpr int NT = NW * 64;
+  static constexpr int TILE_F4 = TC * DP / 4;
+  static constexpr int F4_PER_THREAD = (TILE_F4 + NT - 1) / NT;
+  static constexpr size_t LDS_BYTES = (size_t)(2 * TC * DPL + 2 * TC + 2 * KP * QB + 2 * QB) * 4;
+};
+
+template <int H, int TC, int NW, int KP>
+__global__ __launch_bounds__(NW * 64) void knn_select_kernel(const float* __restrict__ xp,
+                                                             const float* __restrict__ cn,
+                                                             int n_tiles, int64_t n_pad,
+                                                             int64_t q_begin,
+                                                             int* __restrict__ cand_idx,
+                                                             float* __restrict__ cand_tau) {
+  using C = SelectCfg<H, TC, NW, KP>;
+  constexpr int DP = C::DP, DPL = C::DPL, QB = C::QB, NT = C::NT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tile = smem;                   // [2][TC][DPL]
+  float* tnorm = tile + 2 * TC * DPL;   // [2][TC]
+  float* ld = tnorm + 2 * TC;           // [KP][QB] candidate keys s = ||c||^2 - 2 q.c
+  int* li = (int*)(ld + KP * QB);       // [KP][QB] candidate row ids
+  float* lmax = (float*)(li + KP * QB); // [QB] current threshold (max key in the list)
+  int* lpos = (int*)(lmax + QB);        // [QB] slot holding that max
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ql = wave * 32 + l31;
+
+  // B operand: lane l holds query (l&31), dims [half*H, half*H+H), pre-scaled by -2.
+  float bq[H];
+  {
+    int64_t qrow = q_begin + (int64_t)blockIdx.x * QB + ql;
+    if (qrow > n_pad - 1) qrow = n_pad - 1;  // padded query slot: results are never read
+    const float* qp = xp + qrow * DP + half * H;
+#pragma unroll
+    for (int s = 0; s < H; ++s) bq[s] = -2.0f * qp[s];
+  }
+
+  for (int e = tid; e < KP * QB; e += NT) {
+    ld[e] = INFINITY;
+    li[e] = -1;
+  }
+  if (tid < QB) {
+    lmax[tid] = INFINITY;
+    lpos[tid] = 0;
+  }
+
+  float4 stage[C::F4_PER_THREAD];
+  float nstage = 0.f;
+  auto gload = [&](int t) {
+    const float4* src = reinterpret_cast<const float4*>(xp + (int64_t)t * TC * DP);
+#pragma unroll
+    for (int i = 0; i < C::F4_PER_THREAD; ++i) {
+      int e = tid + i * NT;
+      if (e < C::TILE_F4) stage[i] = src[e];
+    }
+    if (tid < TC) nstage = cn[(int64_t)t * TC + tid];
+  };
+  auto lstore = [&](int b) {
+    float* dst = tile + b * TC * DPL;
+#pragma unroll
+    for (int i = 0; i < C::F4_PER_THREAD; ++i) {
+      int e = tid + i * NT;
+      if (e < C::TILE_F4) {
+        int f = e * 4;
+        float v[4] = {stage[i].x, stage[i].y, stage[i].z, stage[i].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          int ff = f + c;
+          int row = ff / DP, col = ff - row * DP;
+          dst[row * DPL + col] = v[c];
+        }
+      }
+    }
+    if (tid < TC) tnorm[b * TC + tid] = nstage;
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  volatile float* vld = ld;
+  volatile int* vli = li;
+  volatile float* vlmax = lmax;
+  volatile int* vlpos = lpos;
+
+  float thr = INFINITY;
+  for (int t = 0; t < n_tiles; ++t) {
+    const int b = t & 1;
+    if (t + 1 < n_tiles) gload(t + 1);
+    const float* tb = tile + b * TC * DPL;
+    const float* nb = tnorm + b * TC;
+#pragma unroll
+    for (int sub = 0; sub < TC / 32; ++sub) {
+      // A operand: lane l holds candidate (l&31) of this 32-row sub-tile, same dim slice as B.
+      float a[H];
+      const float* ap = tb + (sub * 32 + l31) * DPL + half * H;
+#pragma unroll
+      for (int s = 0; s < H; ++s) a[s] = ap[s];
+      // C-in = ||c||^2 of the candidate each accumulator register belongs to:
+      // register r of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+      f32x16 acc;
+#pragma unroll
+      for (int a4 = 0; a4 < 4; ++a4) {
+        float4 v = *reinterpret_cast<const float4*>(nb + sub * 32 + 8 * a4 + 4 * half);
+        acc[4 * a4 + 0] = v.x;
+        acc[4 * a4 + 1] = v.y;
+        acc[4 * a4 + 2] = v.z;
+        acc[4 * a4 + 3] = v.w;
+      }
+#pragma unroll
+      for (int s = 0; s < H; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bq[s], acc, 0, 0, 0);
+
+      float m01 = fminf(fminf(acc[0], acc[1]), fminf(acc[2], acc[3]));
+      float m23 = fminf(fminf(acc[4], acc[5]), fminf(acc[6], acc[7]));
+      float m45 = fminf(fminf(acc[8], acc[9]), fminf(acc[10], acc[11]));
+      float m67 = fminf(fminf(acc[12], acc[13]), fminf(acc[14], acc[15]));
+      float m = fminf(fminf(m01, m23), fminf(m45, m67));
+      if (__any(m < thr)) {
+        // Rare path.  Lanes l and l+32 share a query: run the halves one after the other so the
+        // list of a query is only ever touched by one lane at a time (LDS ops of a wave retire
+        // in order; `volatile` keeps the compiler from reordering them).
+        const int cbase = t * TC + sub * 32 + 4 * half;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          if (half == hh) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float v = acc[r];
+              if (v < vlmax[ql]) {
+                int p = vlpos[ql];
+                vld[p * QB + ql] = v;
+                vli[p * QB + ql] = cbase + (r & 3) + 8 * (r >> 2);
+                float mx = -INFINITY;
+                int mp = 0;
+                for (int u = 0; u < KP; ++u) {
+                  float xv = vld[u * QB + ql];
+                  if (xv > mx) {
+                    mx = xv;
+                    mp = u;
+                  }
+                }
+                vlmax[ql] = mx;
+                vlpos[ql] = mp;
+              }
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        thr = vlmax[ql];
+      }
+    }
+    if (t + 1 < n_tiles) lstore(b ^ 1);
+    __syncthreads();
+  }
+
+  for (int e = tid; e < KP * QB; e += NT) {
+    int q = e / KP, u = e - q * KP;
+    cand_idx[((int64_t)blockIdx.x * QB + q) * KP + u] = li[u * QB + q];
+  }
+  if (tid < QB) cand_tau[(int64_t)blockIdx.x * QB + tid] = lmax[tid];
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 2: exact float64 re-rank + certificate.  One wave per query, 4 queries per block.
+// ------------------------------------------------------------------------------------------------
+__device__ inline bool key_less(double da, int ia, double db, int ib) {
+  return da < db || (da == db && ia < ib);
+}
+
+template <int KP>
+__global__ __launch_bounds__(256) void knn_rerank_kernel(
+    const float* __restrict__ x, int64_t n, int d, int64_t ld, int64_t q_begin, int64_t n_query,
+    int k, const int* __restrict__ cand_idx, const float* __restrict__ cand_tau,
+    const unsigned int* __restrict__ cmax_bits, double cert_scale, int32_t* __restrict__ out_idx,
+    double* __restrict__ out_dist, double* __restrict__ kth_d2, int* __restrict__ flag_list,
+    int* __restrict__ n_flag) {
+  constexpr int PER = (KP + 63) / 64;
+  __shared__ float qs[4][128];
+  __shared__ double sd[4][KP];
+  __shared__ int si[4][KP];
+  __shared__ double skth[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t qi = (int64_t)blockIdx.x * 4 + w;
+  if (qi >= n_query) return;  // whole wave exits together (no block-level sync below)
+  const int64_t q = q_begin + qi;
+  for (int c = lane; c < d; c += 64) qs[w][c] = x[q * ld + c];
+  if (lane == 0) skth[w] = INFINITY;
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+
+  double qn = 0.0;
+  for (int c = 0; c < d; ++c) qn += (double)qs[w][c] * (double)qs[w][c];
+
+  double myd[PER];
+  int myi[PER];
+#pragma unroll
+  for (int p = 0; p < PER; ++p) {
+    int u = lane + p * 64;
+    myd[p] = INFINITY;
+    myi[p] = -1;
+    if (u < KP) {
+      int idx = cand_idx[qi * KP + u];
+      if (idx >= 0 && idx < n && idx != q) {
+        const float* cp = x + (int64_t)idx * ld;
+        double s = 0.0;
+        for (int c = 0; c < d; ++c) {
+          double df = (double)qs[w][c] - (double)cp[c];
+          s = fma(df, df, s);
+        }
+        myd[p] = s;
+        myi[p] = idx;
+      }
+      // NaN distances sort last and are reported as missing
+      if (!(myd[p] == myd[p])) {
+        myd[p] = INFINITY;
+        myi[p] = -1;
+      }
+      sd[w][u] = myd[p];
+      si[w][u] = myi[p];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+
+  const int kk = k - 1;  // neighbours besides self
+  if (lane == 0) {
+    out_idx[qi * k] = (int32_t)q;
+    out_dist[qi * k] = 0.0;
+  }
+#pragma unroll
+  for (int p = 0; p < PER; ++p) {
+    int u = lane + p * 64;
+    if (u < KP) {
+      int rank = 0;
+      for (int v = 0; v < KP; ++v) {
+        double dv = sd[w][v];
+        int iv = si[w][v];
+        // missing entries (idx -1, +inf) order after everything, ties among them by slot
+        bool less = (iv >= 0) ? (myi[p] < 0 || key_less(dv, iv, myd[p], myi[p]))
+                              : (myi[p] < 0 && v < u);
+        rank += less ? 1 : 0;
+      }
+      if (rank < kk) {
+        out_idx[qi * k + 1 + rank] = myi[p];
+        out_dist[qi * k + 1 + rank] = (myi[p] >= 0) ? sqrt(myd[p]) : INFINITY;
+        if (rank == kk - 1) skth[w] = myd[p];
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+  if (lane == 0) {
+    double dk = (kk > 0) ? skth[w] : 0.0;
+    double tau = (double)cand_tau[qi];
+    double cmax = (double)__uint_as_float(*cmax_bits);
+    // |s_float32 - s_exact| <= (2H+2) u (||c||^2 + 2 ||q|| ||c||), u = 2^-24; 2H+2 <= 130.
+    double eps = cert_scale * 130.0 * 5.9604644775390625e-08 * (cmax + 2.0 * sqrt(qn * cmax));
+    bool certified = (tau == INFINITY) || ((dk - qn) + eps < tau);
+    kth_d2[qi] = dk;
+    if (!certified) {
+      int slot = atomicAdd(n_flag, 1);
+      flag_list[slot] = (int)qi;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 3: float64 scan for uncertified queries.  One 256-thread block per query.  Collects every
+// row with exact d^2 <= bound (the k-th exact distance among the candidates, an upper bound of the
+// true k-th distance), then rank-sorts the collection.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void knn_fallback_kernel(
+    const float* __restrict__ x, int64_t n, int d, int64_t ld, int64_t q_begin, int k,
+    const int* __restrict__ flag_list, int flag_begin, int flag_count,
+    const double* __restrict__ kth_d2, int32_t* __restrict__ out_idx, double* __restrict__ out_dist,
+    double* __restrict__ scratch_d, int* __restrict__ scratch_i, int* __restrict__ overflow) {
+  __shared__ float qs[128];
+  __shared__ int cnt;
+  const int fb = blockIdx.x;
+  if (fb >= flag_count) return;
+  const int64_t qi = flag_list[flag_begin + fb];
+  const int64_t q = q_begin + qi;
+  double* bd = scratch_d + (int64_t)fb * FALLBACK_CAP;
+  int* bi = scratch_i + (int64_t)fb * FALLBACK_CAP;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) qs[c] = x[q * ld + c];
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  const double bound = kth_d2[qi];
+  for (int64_t r = threadIdx.x; r < n; r += blockDim.x) {
+    if (r == q) continue;
+    const float* cp = x + r * ld;
+    double s = 0.0;
+    for (int c = 0; c < d; ++c) {
+      double df = (double)qs[c] - (double)cp[c];
+      s = fma(df, df, s);
+    }
+    if (s <= bound) {
+      int slot = atomicAdd(&cnt, 1);
+      if (slot < FALLBACK_CAP) {
+        bd[slot] = s;
+        bi[slot] = (int)r;
+      }
+    }
+  }
+  __syncthreads();
+  int m = cnt;
+  if (m > FALLBACK_CAP) {
+    if (threadIdx.x == 0) atomicAdd(overflow, 1);
+    m = FALLBACK_CAP;
+  }
+  __threadfence_block();
+  const int kk = k - 1;
+  for (int u = threadIdx.x; u < m; u += blockDim.x) {
+    double du = bd[u];
+    int iu = bi[u];
+    int rank = 0;
+    for (int v = 0; v < m; ++v) rank += key_less(bd[v], bi[v], du, iu) ? 1 : 0;
+    if (rank < kk) {
+      out_idx[qi * k + 1 + rank] = iu;
+      out_dist[qi * k + 1 + rank] = sqrt(du);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct KnnPlan {
+  int H, TC, NW, KP;
+  int64_t n_pad, nq_pad;
+};
+
+static bool knn_plan(int64_t n, int d, int64_t n_query, int k, KnnPlan* p) {
+  if (d <= 16) p->H = 8;
+  else if (d <= 32) p->H = 16;
+  else if (d <= 50) p->H = 25;
+  else if (d <= 64) p->H = 32;
+  else if (d <= 128) p->H = 64;
+  else return false;
+  p->TC = (p->H == 64) ? 64 : 128;
+  if (k <= 24) { p->KP = 32; p->NW = 8; }
+  else if (k <= 56) { p->KP = 64; p->NW = 4; }
+  else if (k <= 120) { p->KP = 128; p->NW = 2; }
+  else return false;
+  const int QB = p->NW * 32;
+  p->nq_pad = (n_query + QB - 1) / QB * QB;
+  p->n_pad = (n + 255) / 256 * 256;
+  return true;
+}
+
+struct KnnBuffers {
+  float* xp; float* cn; unsigned int* cmax; int* cand_idx; float* cand_tau; double* kth_d2;
+  int* flag_list; int* counters; double* scratch_d; int* scratch_i;
+};
+
+static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffers* b) {
+  b->xp = ws.take<float>((size_t)p.n_pad * 2 * p.H);
+  b->cn = ws.take<float>((size_t)p.n_pad);
+  b->cmax = ws.take<unsigned int>(4);
+  b->cand_idx = ws.take<int>((size_t)p.nq_pad * p.KP);
+  b->cand_tau = ws.take<float>((size_t)p.nq_pad);
+  b->kth_d2 = ws.take<double>((size_t)n_query);
+  b->flag_list = ws.take<int>((size_t)n_query);
+  b->counters = ws.take<int>(4);
+  b->scratch_d = ws.take<double>((size_t)FALLBACK_CHUNK * FALLBACK_CAP);
+  b->scratch_i = ws.take<int>((size_t)FALLBACK_CHUNK * FALLBACK_CAP);
+}
+
+template <int H, int TC, int NW, int KP>
+static int launch_select(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, hipStream_t s) {
+  using C = SelectCfg<H, TC, NW, KP>;
+  auto kern = knn_select_kernel<H, TC, NW, KP>;
+  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+  const int n_tiles = (int)(p.n_pad / TC);
+  const int grid = (int)(p.nq_pad / C::QB);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, b.xp, b.cn, n_tiles, p.n_pad,
+                     q_begin, b.cand_idx, b.cand_tau);
+  SCAMD_LAUNCH_CHECK();
+  return SCAMD_OK;
+}
+
+template <int H, int TC>
+static int dispatch_kp(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, hipStream_t s) {
+  switch (p.KP) {
+    case 32: return launch_select<H, TC, 8, 32>(p, b, q_begin, s);
+    case 64: return launch_select<H, TC, 4, 64>(p, b, q_begin, s);
+    default: return launch_select<H, TC, 2, 128>(p, b, q_begin, s);
+  }
+}
+
+static int dispatch_select(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, hipStream_t s) {
+  switch (p.H) {
+    case 8: return dispatch_kp<8, 128>(p, b, q_begin, s);
+    case 16: return dispatch_kp<16, 128>(p, b, q_begin, s);
+    case 25: return dispatch_kp<25, 128>(p, b, q_begin, s);
+    case 32: return dispatch_kp<32, 128>(p, b, q_begin, s);
+    default: return dispatch_kp<64, 64>(p, b, q_begin, s);
+  }
+}
+
+}  // namespace scamd
+
+using namespace scamd;
+
+extern "C" size_t scamd_knn_workspace_bytes(int64_t n, int d, int64_t n_query, int k) {
+  KnnPlan p;
+  if (!knn_plan(n, d, n_query, k, &p)) return 0;
+  Workspace ws(nullptr, 0);
+  KnnBuffers b;
+  knn_carve(ws, p, n_query, &b);
+  return ws.used();
+}
+
+extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, int64_t q_begin,
+                                int64_t n_query, int k, int32_t* out_idx, double* out_dist,
+                                double cert_scale, int64_t* n_fallback_host, void* workspace,
+                                size_t workspace_bytes, scamd_stream_t stream) {
+  SCAMD_REQUIRE(x && out_idx && out_dist, SCAMD_EINVAL, "knn: null pointer");
+  SCAMD_REQUIRE(n >= 1 && d >= 1 && ld_x >= d, SCAMD_EINVAL, "knn: bad shape n=%lld d=%d ld=%lld",
+                (long long)n, d, (long long)ld_x);
+  SCAMD_REQUIRE(n < (int64_t)1 << 31, SCAMD_EUNSUPPORTED, "knn: n=%lld exceeds int32 row ids", (long long)n);
+  SCAMD_REQUIRE(q_begin >= 0 && n_query >= 0 && q_begin + n_query <= n, SCAMD_EINVAL,
+                "knn: query range [%lld, %lld) outside [0, %lld)", (long long)q_begin,
+                (long long)(q_begin + n_query), (long long)n);
+  SCAMD_REQUIRE(k >= 1, SCAMD_EINVAL, "knn: k=%d", k);
+  KnnPlan p;
+  SCAMD_REQUIRE(knn_plan(n, d, n_query, k, &p), SCAMD_EUNSUPPORTED,
+                "knn: unsupported d=%d (max 128) or k=%d (max 120)", d, k);
+  if (n_fallback_host) *n_fallback_host = 0;
+  if (n_query == 0) return SCAMD_OK;
+  Workspace ws(workspace, workspace_bytes);
+  KnnBuffers b;
+  knn_carve(ws, p, n_query, &b);
+  SCAMD_REQUIRE(workspace && ws.ok, SCAMD_EWORKSPACE, "knn: workspace %zu < required %zu",
+                workspace_bytes, ws.used());
+  hipStream_t s = stream;
+
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.cmax, 0, 16, s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, 16, s));
+  {
+    int blocks = (int)std::min<int64_t>((p.n_pad + 3) / 4, 256 * 16);
+    hipLaunchKernelGGL(knn_pack_kernel, dim3(blocks), dim3(256), 0, s, x, n, d, ld_x, 2 * p.H,
+                       p.n_pad, b.xp, b.cn, b.cmax);
+    SCAMD_LAUNCH_CHECK();
+  }
+  int rc = dispatch_select(p, b, q_begin, s);
+  if (rc != SCAMD_OK) return rc;
+  {
+    int blocks = (int)((n_query + 3) / 4);
+#define RERANK(KP_)                                                                              \
+  hipLaunchKernelGGL(knn_rerank_kernel<KP_>, dim3(blocks), dim3(256), 0, s, x, n, d, ld_x, q_begin, \
+                     n_query, k, b.cand_idx, b.cand_tau, b.cmax, cert_scale, out_idx, out_dist,  \
+                     b.kth_d2, b.flag_list, b.counters)
+    if (p.KP == 32) RERANK(32);
+    else if (p.KP == 64) RERANK(64);
+    else RERANK(128);
+#undef RERANK
+    SCAMD_LAUNCH_CHECK();
+  }
+  int h_counters[4] = {0, 0, 0, 0};
+  SCAMD_HIP_CHECK(hipMemcpyAsync(h_counters, b.counters, 16, hipMemcpyDeviceToHost, s));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+  const int n_flag = h_counters[0];
+  if (n_fallback_host) *n_fallback_host = n_flag;
+  for (int begin = 0; begin < n_flag; begin += FALLBACK_CHUNK) {
+    int count = std::min(FALLBACK_CHUNK, n_flag - begin);
+    hipLaunchKernelGGL(knn_fallback_kernel, dim3(count), dim3(256), 0, s, x, n, d, ld_x, q_begin, k,
+                       b.flag_list, begin, count, b.kth_d2, out_idx, out_dist, b.scratch_d,
+                       b.scratch_i, b.counters + 1);
+    SCAMD_LAUNCH_CHECK();
+  }
+  if (n_flag > 0) {
+    SCAMD_HIP_CHECK(hipMemcpyAsync(h_counters, b.counters, 16, hipMemcpyDeviceToHost, s));
+    SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+    SCAMD_REQUIRE(h_counters[1] == 0, SCAMD_EUNSUPPORTED,
+                  "knn: %d queries have more than %d rows tied within their k-th distance",
+                  h_counters[1], FALLBACK_CAP);
+  }
+  return SCAMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA layout self test: D = A(32x2) * B(2x32) + C with asymmetric integer-valued operands.
+// ------------------------------------------------------------------------------------------------
+namespace scamd {
+__global__ void mfma_layout_kernel(int* mismatches) {
+  const int lane = threadIdx.x & 63;
+  const int i = lane & 31, kk = lane >> 5;
+  // A[i][k] = i + 100*k + 1 ; B[k][j] = 3*j + 7*k + 2 ; C[i][j] = 1000*i + j
+  float a = (float)(i + 100 * kk + 1);
+  float bval = (float)(3 * i + 7 * kk + 2);  // lane holds B[k=kk][j=i]
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+    acc[r] = (float)(1000 * row + i);
+  }
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bval, acc, 0, 0, 0);
+  int bad = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+    int col = i;
+    float expect = (float)(1000 * row + col);
+    for (int k2 = 0; k2 < 2; ++k2) expect += (float)(row + 100 * k2 + 1) * (float)(3 * col + 7 * k2 + 2);
+    if (acc[r] != expect) ++bad;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+}  // namespace scamd
+
+extern "C" int scamd_selftest_mfma_layout(scamd_stream_t stream) {
+  int* d_bad = nullptr;
+  SCAMD_HIP_CHECK(hipMalloc(&d_bad, sizeof(int)));
+  SCAMD_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(int), stream));
+  hipLaunchKernelGGL(scamd::mfma_layout_kernel, dim3(1), dim3(64), 0, stream, d_bad);
+  int h_bad = -1;
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(d_bad);
+  if (e != hipSuccess) {
+    scamd::set_error("mfma selftest: %s", hipGetErrorString(e));
+    return SCAMD_EHIP;
+  }
+  if (h_bad != 0) {
+    scamd::set_error("mfma selftest: %d mismatching accumulator entries", h_bad);
+    return SCAMD_EUNSUPPORTED;
+  }
+  return SCAMD_OK;
+}

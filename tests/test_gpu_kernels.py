@@ -1,0 +1,231 @@
+"""GPU parity tests of the individual C-ABI kernels against the CPU oracle (run with -m gpu)."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+from helpers import knn_sets_equal_mod_ties
+from oracle import connectivities as oc
+from oracle import knn as oknn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    import torch
+
+    from scanpy_amd import _kernels
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return _kernels
+
+
+def _dev(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_mfma_layout(K):
+    K.mfma_selftest()
+
+
+def _check_knn(K, x, k, **kw):
+    idx, dist, nfb = K.knn(_dev(x), k, **kw)
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    n = x.shape[0]
+    oi, od, _ = oknn.knn_sklearn(x, k)
+    # column 0: self with exact zero
+    assert (idx[:, 0] == np.arange(n)).all()
+    assert (dist[:, 0] == 0).all()
+    # exact float64 truth for the distances of whatever we returned
+    x64 = x.astype(np.float64)
+    true_d = np.sqrt(((x64[:, None, :] - x64[idx]) ** 2).sum(-1))
+    np.testing.assert_allclose(dist, true_d, rtol=1e-12, atol=0)
+    assert (np.diff(dist[:, 1:], axis=1) >= 0).all(), "neighbours must be sorted by distance"
+    bad, differ = knn_sets_equal_mod_ties(idx[:, 1:], dist[:, 1:], oi[:, 1:], od[:, 1:])
+    assert bad == 0, f"{bad} rows differ from the sklearn oracle beyond ties ({differ} incl. ties)"
+    np.testing.assert_allclose(dist[:, 1:], od[:, 1:], rtol=2e-6, atol=2e-6 * np.abs(x).max())
+    return idx, dist, nfb
+
+
+def test_knn_toy_golden(K, neighbors_toy):
+    x = neighbors_toy["X"].astype(np.float32)
+    idx, dist, _ = K.knn(_dev(x), 3)
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    d = oknn.sparse_from_indices_distances(idx, dist, keep_self=False)
+    np.testing.assert_allclose(d.toarray(), neighbors_toy["distances_euclidean"], rtol=1e-6)
+
+
+@pytest.mark.parametrize(
+    ("n", "d", "k"),
+    [(1000, 50, 15), (5000, 10, 30), (3000, 64, 15), (2000, 100, 15), (777, 3, 5), (4000, 50, 100), (300, 128, 15), (2500, 33, 24)],
+)
+def test_knn_vs_sklearn(K, n, d, k):
+    rng = np.random.default_rng(n + d + k)
+    centers = rng.standard_normal((8, d)).astype(np.float32) * 3
+    x = (centers[rng.integers(0, 8, n)] + rng.standard_normal((n, d))).astype(np.float32)
+    _check_knn(K, x, k)
+
+
+def test_knn_large_offset_norms(K):
+    """Points far from the origin: float32 expansion loses digits, certificate/fallback must cope."""
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((3000, 50)) + 300.0).astype(np.float32)
+    _, _, nfb = _check_knn(K, x, 15)
+    print("fallback queries:", nfb)
+
+
+def test_knn_duplicates(K):
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((500, 20)).astype(np.float32)
+    x = np.vstack([x, x[:100], x[:50]])  # exact duplicates (and triplicates)
+    idx, dist, _ = K.knn(_dev(x), 10)
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    x64 = x.astype(np.float64)
+    true_d = np.sqrt(((x64[:, None, :] - x64[idx]) ** 2).sum(-1))
+    np.testing.assert_allclose(dist, true_d, rtol=1e-12)
+    ei, ed = oknn.knn_exact_f64(x, np.arange(len(x)), 11)
+    # drop self from the exact list (self may not be first among duplicates)
+    for r in range(len(x)):
+        keep = ei[r] != r
+        er = ed[r][keep][:9] if keep.sum() >= 9 else ed[r][1:10]
+        np.testing.assert_allclose(dist[r, 1:], er, rtol=1e-12, atol=1e-12)
+
+
+def test_knn_forced_fallback_matches(K):
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((1500, 50)).astype(np.float32)
+    i1, d1, n1 = K.knn(_dev(x), 15)
+    i2, d2, n2 = K.knn(_dev(x), 15, cert_scale=1e30)
+    assert n2 == 1500 and n1 < 1500
+    np.testing.assert_array_equal(i1.cpu().numpy(), i2.cpu().numpy())
+    np.testing.assert_array_equal(d1.cpu().numpy(), d2.cpu().numpy())
+
+
+def test_knn_query_shard(K):
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal((2100, 50)).astype(np.float32)
+    i_all, d_all, _ = K.knn(_dev(x), 15)
+    i_s, d_s, _ = K.knn(_dev(x), 15, q_begin=700, n_query=900)
+    np.testing.assert_array_equal(i_all[700:1600].cpu().numpy(), i_s.cpu().numpy())
+    np.testing.assert_array_equal(d_all[700:1600].cpu().numpy(), d_s.cpu().numpy())
+
+
+def test_knn_tiny(K):
+    x = np.array([[0.0, 0.0], [1.0, 0.0]], dtype=np.float32)
+    idx, dist, _ = K.knn(_dev(x), 3)
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    assert idx[0].tolist() == [0, 1, -1] and idx[1].tolist() == [1, 0, -1]
+    assert dist[0, 1] == 1.0 and np.isinf(dist[0, 2])
+
+
+# ---------------------------------------------------------------------------------------------------
+def _fuzzy_vs_oracle(K, idx, dist, k, atol=2e-6):
+    n = idx.shape[0]
+    indptr, indices, data, sigma, rho = K.fuzzy_simplicial_set(_dev(idx.astype(np.int32)), _dev(dist.astype(np.float32)))
+    got = sparse.csr_matrix((data.cpu().numpy(), indices.cpu().numpy(), indptr.cpu().numpy()), shape=(n, n))
+    ref, rs, rr = oc.fuzzy_simplicial_set(idx, dist, n, k)
+    assert got.has_canonical_format or (got.sort_indices() is None)
+    np.testing.assert_array_equal(rho.cpu().numpy(), rr)
+    np.testing.assert_allclose(sigma.cpu().numpy(), rs, rtol=1e-6)
+    assert (np.diff(got.indices.astype(np.int64))[np.setdiff1d(np.arange(got.nnz - 1), got.indptr[1:-1] - 1)] > 0).all(), "sorted columns"
+    assert got.nnz == ref.nnz, (got.nnz, ref.nnz)
+    np.testing.assert_array_equal(got.indptr, ref.indptr)
+    np.testing.assert_array_equal(got.indices, ref.indices)
+    np.testing.assert_allclose(got.data, ref.data, rtol=0, atol=atol)
+    assert abs(got - got.T).max() == 0, "connectivities must be exactly symmetric"
+    return got
+
+
+def test_fuzzy_toy_golden(K, neighbors_toy):
+    x = neighbors_toy["X"]
+    idx, dist, _ = oknn.knn_sklearn(x, 3)
+    got = _fuzzy_vs_oracle(K, idx, dist, 3)
+    np.testing.assert_allclose(got.toarray(), neighbors_toy["connectivities_umap"], rtol=1e-5, atol=1e-6)
+
+
+def test_fuzzy_fixture_golden(K, pbmc68k):
+    d = pbmc68k["distances"]
+    k = pbmc68k["n_neighbors"]
+    idx, dist = oknn.indices_distances_from_sparse(d, k)
+    order = np.argsort(dist, axis=1, kind="stable")
+    idx, dist = np.take_along_axis(idx, order, 1), np.take_along_axis(dist, order, 1)
+    got = _fuzzy_vs_oracle(K, idx, dist, k)
+    ref = pbmc68k["connectivities"].copy()
+    ref.sort_indices()
+    np.testing.assert_array_equal(got.indices, ref.indices)
+    np.testing.assert_allclose(got.data, ref.data, atol=1e-5)
+
+
+@pytest.mark.parametrize(("n", "k"), [(20000, 15), (3000, 30), (500, 5)])
+def test_fuzzy_synthetic(K, n, k):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((n, 20)).astype(np.float32)
+    x[: n // 50] = x[n // 50 : 2 * (n // 50)]  # some exact duplicates -> zero distances
+    idx, dist, _ = K.knn(_dev(x), k)
+    _fuzzy_vs_oracle(K, idx.cpu().numpy(), dist.cpu().numpy(), k)
+
+
+# ---------------------------------------------------------------------------------------------------
+def _rand_csr(n, g, density, seed):
+    rng = np.random.default_rng(seed)
+    m = sparse.random(n, g, density=density, format="csr", dtype=np.float32, random_state=rng,
+                      data_rvs=lambda s: np.log1p(np.exp(rng.standard_normal(s))).astype(np.float32))
+    m.sort_indices()
+    return m
+
+
+def _csr_dev(m):
+    return _dev(m.indptr.astype(np.int64)), _dev(m.indices.astype(np.int32)), _dev(m.data.astype(np.float32))
+
+
+@pytest.mark.parametrize(("n", "g", "density"), [(5000, 2000, 0.05), (1234, 77, 0.3), (20000, 500, 0.02), (3, 5, 0.9)])
+def test_csr_transpose_and_stats(K, n, g, density):
+    m = _rand_csr(n, g, density, n + g)
+    ip, ix, dv = _csr_dev(m)
+    t_ip, t_ix, t_dv = K.csr_transpose(ip, ix, dv, n, g)
+    ref = m.tocsc()
+    ref.sort_indices()
+    np.testing.assert_array_equal(t_ip.cpu().numpy(), ref.indptr)
+    np.testing.assert_array_equal(t_ix.cpu().numpy(), ref.indices)
+    np.testing.assert_array_equal(t_dv.cpu().numpy(), ref.data)
+    s, q = K.csr_row_stats(t_ip, t_dv, g)
+    d64 = m.astype(np.float64)
+    np.testing.assert_allclose(s.cpu().numpy(), np.asarray(d64.sum(0)).ravel(), rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(q.cpu().numpy(), np.asarray(d64.multiply(d64).sum(0)).ravel(), rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize(("n", "g", "l"), [(5000, 2000, 64), (1000, 300, 50), (2000, 100, 128), (700, 765, 7)])
+def test_spmm(K, n, g, l):
+    m = _rand_csr(n, g, 0.05, n + l)
+    rng = np.random.default_rng(l)
+    b = rng.standard_normal((g, l)).astype(np.float32)
+    shift = rng.standard_normal(l).astype(np.float32)
+    ip, ix, dv = _csr_dev(m)
+    y = K.spmm(ip, ix, dv, n, g, _dev(b), _dev(shift)).cpu().numpy()
+    ref = m.astype(np.float64) @ b.astype(np.float64) - shift.astype(np.float64)[None, :]
+    np.testing.assert_allclose(y, ref, rtol=2e-5, atol=2e-5)
+    # transposed product with float64 accumulation on the CSC copy
+    t_ip, t_ix, t_dv = K.csr_transpose(ip, ix, dv, n, g)
+    yd = _dev(y.astype(np.float32))
+    cs = K.colsum(yd)
+    np.testing.assert_allclose(cs.cpu().numpy(), y.astype(np.float64).sum(0), rtol=1e-12, atol=1e-9)
+    mu = rng.standard_normal(g)
+    w = K.spmm_f64acc(t_ip, t_ix, t_dv, g, yd, _dev(mu), cs).cpu().numpy()
+    ref_w = m.astype(np.float64).T @ y.astype(np.float64) - np.outer(mu, y.astype(np.float64).sum(0))
+    np.testing.assert_allclose(w, ref_w, rtol=1e-11, atol=1e-9)
+
+
+def test_spmm_long_rows(K):
+    """Rows longer than one segment (the CSC copy of a tall matrix)."""
+    m = _rand_csr(50, 30000, 0.4, 3)  # 12k entries per row
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal((30000, 64)).astype(np.float32)
+    ip, ix, dv = _csr_dev(m)
+    w = K.spmm_f64acc(ip, ix, dv, 50, _dev(b)).cpu().numpy()
+    np.testing.assert_allclose(w, m.astype(np.float64) @ b.astype(np.float64), rtol=1e-12, atol=1e-10)
+    y = K.spmm(ip, ix, dv, 50, 30000, _dev(b)).cpu().numpy()
+    np.testing.assert_allclose(y, m.astype(np.float64) @ b.astype(np.float64), rtol=1e-4, atol=1e-3)
