@@ -147,7 +147,7 @@ int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indices, const fl
 /* Modularity of a given membership (replaces igraph Graph.modularity as used by
  * src/scanpy/metrics/_metrics.py:202-214). */
 int scamd_modularity_csr_f32(const int64_t* indptr, const int32_t* indices, const float* weights,
-                             int64_t n, const int32_t* membership, double resolution,
+                             int64_t n, int64_t nnz, const int32_t* membership, double resolution,
                              double* modularity_host, void* workspace, size_t workspace_bytes,
                              scamd_stream_t stream);
 

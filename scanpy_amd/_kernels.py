@@ -124,3 +124,40 @@ def colsum(y: torch.Tensor) -> torch.Tensor:
     ws, wsz = _ws(lib.scamd_colsum_workspace_bytes(l), dev)
     _lib.check(lib.scamd_colsum_f32_f64(ptr(y), n, l, ptr(out), ptr(ws), wsz, stream_ptr()), "scamd_colsum_f32_f64")
     return out
+
+
+def leiden(indptr: torch.Tensor, indices: torch.Tensor, weights: torch.Tensor, n: int, *, resolution: float = 1.0,
+           n_iterations: int = -1, beta: float = 0.01, seed: int = 0):
+    """Symmetric CSR graph on device -> (membership int32 [n] on device, modularity, n_communities)."""
+    dev = require_gpu()
+    lib = _lib.load()
+    indptr = indptr.to(torch.int64).contiguous()
+    indices = indices.to(torch.int32).contiguous()
+    weights = weights.to(torch.float32).contiguous()
+    nnz = weights.numel()
+    memb = torch.empty(n, dtype=torch.int32, device=dev)
+    ws, wsz = _ws(lib.scamd_leiden_workspace_bytes(n, nnz), dev)
+    q = C.c_double(0.0)
+    nc = C.c_int32(0)
+    rc = lib.scamd_leiden_csr_f32(ptr(indptr), ptr(indices), ptr(weights), n, nnz, float(resolution),
+                                  int(n_iterations), float(beta), int(seed) & (2**64 - 1), ptr(memb), C.byref(q),
+                                  C.byref(nc), ptr(ws), wsz, stream_ptr())
+    _lib.check(rc, "scamd_leiden_csr_f32")
+    return memb, float(q.value), int(nc.value)
+
+
+def modularity(indptr: torch.Tensor, indices: torch.Tensor, weights: torch.Tensor, n: int, membership: torch.Tensor,
+               *, resolution: float = 1.0) -> float:
+    dev = require_gpu()
+    lib = _lib.load()
+    indptr = indptr.to(torch.int64).contiguous()
+    indices = indices.to(torch.int32).contiguous()
+    weights = weights.to(torch.float32).contiguous()
+    membership = membership.to(torch.int32).contiguous()
+    nnz = weights.numel()
+    ws, wsz = _ws(lib.scamd_leiden_workspace_bytes(n, nnz), dev)
+    q = C.c_double(0.0)
+    rc = lib.scamd_modularity_csr_f32(ptr(indptr), ptr(indices), ptr(weights), n, nnz, ptr(membership),
+                                      float(resolution), C.byref(q), ptr(ws), wsz, stream_ptr())
+    _lib.check(rc, "scamd_modularity_csr_f32")
+    return float(q.value)

@@ -80,7 +80,7 @@ __global__ void fss_sigma_kernel(const int* __restrict__ idx, const float* __res
     float df = __fsub_rn(di[j], rho);
     if (t == (int)i || t < 0) val = 0.f;
     else if (df <= 0.f || sigma == 0.f) val = 1.f;
-    else val = expf(-__fdiv_rn(df, sigma));
+    else val = (float)exp(-(double)__fdiv_rn(df, sigma));  // correctly rounded, keeps float32 subnormals
     w[i * k + j] = val;
     cnt += (val > 0.f) ? 1 : 0;
   }

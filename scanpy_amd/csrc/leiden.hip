@@ -1,14 +1,946 @@
-// placeholder until the Leiden kernels land (first GPU bring-up run only)
+// Leiden community detection on gfx950: wave-per-vertex label moves over the CSR neighbour graph.
+//
+// Replaces leidenalg.find_partition(RBConfigurationVertexPartition) / igraph community_leiden
+// (objective 'modularity') as called at src/scanpy/tools/_leiden.py:167-196 on the graph built by
+// src/scanpy/_utils/__init__.py:278-304.  Same three phases as Traag et al. 2019,
+// re-designed for a GPU:
+//   1. local moving   -- synchronous rounds; one wave per vertex accumulates the weight towards each
+//                        neighbouring community (all-pairs readlane compare, no hash table) and picks
+//                        the best move from a snapshot of the community totals; moves towards
+//                        lower/higher-priority communities alternate by round so that swaps cannot
+//                        oscillate; only vertices next to a change stay active (the queue of the
+//                        sequential algorithm).
+//   2. refinement     -- inside each community singletons merge into well-connected sub-communities
+//                        with the largest non-negative gain (beta -> 0 limit of the randomised rule);
+//                        a per-round mover/non-mover hash bit makes simultaneous merges chain-free.
+//   3. aggregation    -- coarse edges are combined in an open-addressing hash table with 64-bit
+//                        integer atomics, then rank-sorted per row.
+// ALL weight sums are 64-bit fixed point (weight * 2^32): integer addition is associative, so atomic
+// accumulation order cannot change any result -- labels are bitwise reproducible run to run.
+// Memory-latency / gather bound: per round ~E*(4+8+4) B of edge data + n*24 B of vertex data.
 #include "common.h"
-using namespace scamd;
-extern "C" size_t scamd_leiden_workspace_bytes(int64_t n, int64_t nnz) { return 0; }
-extern "C" int scamd_leiden_csr_f32(const int64_t*, const int32_t*, const float*, int64_t, int64_t, double, int,
-                                    double, uint64_t, int32_t*, double*, int32_t*, void*, size_t, scamd_stream_t) {
-  set_error("leiden: not built yet");
-  return SCAMD_EUNSUPPORTED;
+#include "scan.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace scamd {
+
+constexpr double WSCALE = 4294967296.0;  // 2^32
+constexpr int MAX_LM_ROUNDS = 128;
+constexpr int MAX_RF_ROUNDS = 48;
+constexpr int RF_QUIET_ROUNDS = 3;
+constexpr int MAX_LEVELS = 64;
+constexpr int MAX_OUTER_ITERS = 32;
+constexpr unsigned long long HEMPTY = ~0ull;
+
+__device__ __forceinline__ unsigned int hash32(unsigned int x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
 }
-extern "C" int scamd_modularity_csr_f32(const int64_t*, const int32_t*, const float*, int64_t, const int32_t*, double,
-                                        double*, void*, size_t, scamd_stream_t) {
-  set_error("modularity: not built yet");
-  return SCAMD_EUNSUPPORTED;
+__device__ __forceinline__ unsigned int prio(int c, unsigned int seed) { return hash32((unsigned int)c ^ seed); }
+
+__device__ __forceinline__ long long readlane_i64(long long v, int l) {
+  int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), l);
+  int hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// ---- small utility kernels -----------------------------------------------------------------------
+__global__ void ld_quantize_kernel(const float* __restrict__ w, int64_t nnz, long long* __restrict__ wq) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < nnz) {
+    double v = (double)w[e];
+    wq[e] = (v > 0.0) ? (long long)llrint(v * WSCALE) : 0ll;
+  }
+}
+
+// one wave per row: k[v] = sum of row
+__global__ void ld_strength_kernel(const int64_t* __restrict__ indptr, const long long* __restrict__ wq, int n,
+                                   long long* __restrict__ k, unsigned long long* __restrict__ total) {
+  const int lane = threadIdx.x & 63;
+  const int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (v >= n) return;
+  long long s = 0;
+  for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) s += wq[e];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) {
+    k[v] = s;
+    atomicAdd(total, (unsigned long long)s);
+  }
+}
+
+__global__ void ld_iota_kernel(int* __restrict__ a, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = i;
+}
+
+__global__ void ld_fill_u8_kernel(unsigned char* __restrict__ a, int n, unsigned char v) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = v;
+}
+
+// Ktot[c] = sum k[v], csize[c] = #members   (both zeroed by the caller)
+__global__ void ld_totals_kernel(const int* __restrict__ comm, const long long* __restrict__ k, int n,
+                                 unsigned long long* __restrict__ Ktot, int* __restrict__ csize) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n) {
+    atomicAdd(&Ktot[comm[v]], (unsigned long long)k[v]);
+    atomicAdd(&csize[comm[v]], 1);
+  }
+}
+
+// ---- wave-wide argmax helper ---------------------------------------------------------------------
+struct Cand {
+  double val;
+  int c;
+  unsigned int pr;
+};
+__device__ __forceinline__ bool cand_better(const Cand& a, const Cand& b) {  // is a better than b
+  if (a.c < 0) return false;
+  if (b.c < 0) return true;
+  if (a.val != b.val) return a.val > b.val;
+  if (a.pr != b.pr) return a.pr < b.pr;
+  return a.c < b.c;
+}
+__device__ __forceinline__ Cand wave_best(Cand x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    Cand y;
+    y.val = __shfl_xor(x.val, o);
+    y.c = __shfl_xor(x.c, o);
+    y.pr = (unsigned int)__shfl_xor((int)x.pr, o);
+    if (cand_better(y, x)) x = y;
+  }
+  return x;
+}
+
+// ---- phase 1: local moving -------------------------------------------------------------------------
+// counters: [0] moved, [1] blocked (wanted to move, direction not allowed this round)
+__global__ __launch_bounds__(256) void ld_move_kernel(
+    int n, const int64_t* __restrict__ indptr, const int* __restrict__ indices, const long long* __restrict__ wq,
+    const long long* __restrict__ k, const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot,
+    const int* __restrict__ csize, const unsigned char* __restrict__ active, double g /* gamma / 2m */,
+    int round, unsigned int seed, int* __restrict__ comm_next, unsigned char* __restrict__ active_next,
+    int* __restrict__ counters) {
+  const int lane = threadIdx.x & 63;
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= n) return;
+  const int a = comm[v];
+  if (!active[v]) {
+    if (lane == 0) comm_next[v] = a;
+    return;
+  }
+  const double kv = (double)k[v];
+  const int64_t beg = indptr[v];
+  const int deg = (int)(indptr[v + 1] - beg);
+  const double Ka_wo = (double)(long long)(Ktot[a] - (unsigned long long)k[v]);  // own community without v
+  Cand best;
+  best.val = 0.0;
+  best.c = -1;
+  best.pr = 0;
+  long long w_own = 0;
+  for (int cb = 0; cb < deg; cb += 64) {
+    const int e = cb + lane;
+    int u = (e < deg) ? indices[beg + e] : -1;
+    const int c = (u >= 0 && u != v) ? comm[u] : -1;
+    long long sum = 0;
+    for (int db = 0; db < deg; db += 64) {
+      const int e2 = db + lane;
+      int c2 = -1;
+      long long w2 = 0;
+      if (e2 < deg) {
+        const int u2 = indices[beg + e2];
+        if (u2 != v) {
+          c2 = (db == cb) ? c : comm[u2];
+          w2 = wq[beg + e2];
+        }
+      }
+      const int cnt = min(64, deg - db);
+      for (int t = 0; t < cnt; ++t) {
+        const int ct = __builtin_amdgcn_readlane(c2, t);
+        const long long wt = readlane_i64(w2, t);
+        if (ct == c) sum += wt;
+      }
+    }
+    if (c >= 0) {
+      if (c == a) {
+        w_own = sum;
+      } else {
+        Cand x;
+        x.val = (double)sum - g * kv * (double)(long long)Ktot[c];
+        x.c = c;
+        x.pr = prio(c, seed);
+        if (cand_better(x, best)) best = x;
+      }
+    }
+  }
+  best = wave_best(best);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) w_own = max(w_own, __shfl_xor(w_own, o));
+  const double stay = (double)w_own - g * kv * Ka_wo;
+  int target = a;
+  bool wants = false, allowed = true;
+  if (best.c >= 0 && best.val > stay) {
+    wants = true;
+    target = best.c;
+    const unsigned int pa = prio(a, seed), pb = best.pr;
+    allowed = (round & 1) ? (pb > pa || (pb == pa && target > a)) : (pb < pa || (pb == pa && target < a));
+  } else if (stay < 0.0 && Ka_wo > 0.0 && csize[v] == 0) {
+    // leaving for an empty community (id = own vertex id, free at the snapshot) beats staying
+    wants = true;
+    target = v;
+  }
+  const bool moves = wants && allowed;
+  if (lane == 0) {
+    comm_next[v] = moves ? target : a;
+    if (moves) atomicAdd(&counters[0], 1);
+    else if (wants) atomicAdd(&counters[1], 1);
+    if (wants) active_next[v] = 1;
+  }
+  if (moves) {
+    for (int e = lane; e < deg; e += 64) active_next[indices[beg + e]] = 1;
+  }
+}
+
+// ---- phase 2: refinement ---------------------------------------------------------------------------
+// a_in[v] = w(v, C(v) - v): weight from v to the rest of its (phase-1) community
+__global__ __launch_bounds__(256) void ld_within_kernel(int n, const int64_t* __restrict__ indptr,
+                                                        const int* __restrict__ indices,
+                                                        const long long* __restrict__ wq, const int* __restrict__ comm,
+                                                        long long* __restrict__ a_in) {
+  const int lane = threadIdx.x & 63;
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= n) return;
+  const int a = comm[v];
+  long long s = 0;
+  for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) {
+    const int u = indices[e];
+    if (u != v && comm[u] == a) s += wq[e];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) a_in[v] = s;
+}
+
+// Eref[r] += w(v, C - r) for every v in refined community r   (Eref zeroed by the caller)
+__global__ __launch_bounds__(256) void ld_cut_kernel(int n, const int64_t* __restrict__ indptr,
+                                                     const int* __restrict__ indices, const long long* __restrict__ wq,
+                                                     const int* __restrict__ comm, const int* __restrict__ ref,
+                                                     unsigned long long* __restrict__ Eref) {
+  const int lane = threadIdx.x & 63;
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= n) return;
+  const int a = comm[v], r = ref[v];
+  long long s = 0;
+  for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) {
+    const int u = indices[e];
+    if (u != v && comm[u] == a && ref[u] != r) s += wq[e];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0 && s != 0) atomicAdd(&Eref[r], (unsigned long long)s);
+}
+
+__device__ __forceinline__ bool mover_bit(int v, int round, unsigned int seed) {
+  return (hash32((unsigned int)v * 0x9E3779B1u + (unsigned int)round * 0x85EBCA77u + seed) >> 7) & 1u;
+}
+
+__global__ __launch_bounds__(256) void ld_refine_propose_kernel(
+    int n, const int64_t* __restrict__ indptr, const int* __restrict__ indices, const long long* __restrict__ wq,
+    const long long* __restrict__ k, const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot,
+    const int* __restrict__ ref, const int* __restrict__ refsize, const unsigned long long* __restrict__ Kref,
+    const unsigned long long* __restrict__ Eref, const long long* __restrict__ a_in, double g, int round,
+    unsigned int seed, int* __restrict__ target) {
+  const int lane = threadIdx.x & 63;
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= n) return;
+  int tgt = -1;
+  const int rv = ref[v];
+  const double kv = (double)k[v];
+  const int a = comm[v];
+  const double KC = (double)(long long)Ktot[a];
+  bool eligible = (refsize[rv] == 1) && mover_bit(v, round, seed) &&
+                  ((double)a_in[v] >= g * kv * (KC - kv));  // v well connected inside C
+  if (eligible) {
+    const int64_t beg = indptr[v];
+    const int deg = (int)(indptr[v + 1] - beg);
+    Cand best;
+    best.val = 0.0;
+    best.c = -1;
+    best.pr = 0;
+    for (int cb = 0; cb < deg; cb += 64) {
+      const int e = cb + lane;
+      int u = (e < deg) ? indices[beg + e] : -1;
+      const int c = (u >= 0 && u != v && comm[u] == a) ? ref[u] : -1;
+      long long sum = 0;
+      for (int db = 0; db < deg; db += 64) {
+        const int e2 = db + lane;
+        int c2 = -1;
+        long long w2 = 0;
+        if (e2 < deg) {
+          const int u2 = indices[beg + e2];
+          if (u2 != v && comm[u2] == a) {
+            c2 = (db == cb) ? c : ref[u2];
+            w2 = wq[beg + e2];
+          }
+        }
+        const int cnt = min(64, deg - db);
+        for (int t = 0; t < cnt; ++t) {
+          const int ct = __builtin_amdgcn_readlane(c2, t);
+          const long long wt = readlane_i64(w2, t);
+          if (ct == c) sum += wt;
+        }
+      }
+      if (c >= 0 && c != rv) {
+        const double Kr = (double)(long long)Kref[c];
+        const bool single = refsize[c] == 1;
+        const bool ok_target = (!single || !mover_bit(c, round, seed)) &&
+                               ((double)(long long)Eref[c] >= g * Kr * (KC - Kr));  // target well connected
+        const double gain = (double)sum - g * kv * Kr;
+        if (ok_target && gain >= 0.0) {
+          Cand x;
+          x.val = gain;
+          x.c = c;
+          x.pr = prio(c, seed);
+          if (cand_better(x, best)) best = x;
+        }
+      }
+    }
+    best = wave_best(best);
+    tgt = best.c;
+  }
+  if (lane == 0) target[v] = tgt;
+}
+
+__global__ void ld_refine_apply_kernel(int n, const int* __restrict__ target, const long long* __restrict__ k,
+                                       int* __restrict__ ref, int* __restrict__ refsize,
+                                       unsigned long long* __restrict__ Kref, int* __restrict__ counters) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  const int t = target[v];
+  if (t < 0) return;
+  // v is a singleton (ref[v] == v) joining t; t's members do not move this round
+  ref[v] = t;
+  atomicAdd(&refsize[t], 1);
+  atomicAdd(&Kref[t], (unsigned long long)k[v]);
+  refsize[v] = 0;
+  Kref[v] = 0;
+  atomicAdd(&counters[0], 1);
+}
+
+__global__ void ld_refine_init_kernel(int n, const long long* __restrict__ k, int* __restrict__ ref,
+                                      int* __restrict__ refsize, unsigned long long* __restrict__ Kref) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n) {
+    ref[v] = v;
+    refsize[v] = 1;
+    Kref[v] = (unsigned long long)k[v];
+  }
+}
+
+// ---- phase 3: aggregation --------------------------------------------------------------------------
+__global__ void ld_flag_kernel(int n, const int* __restrict__ size, int* __restrict__ flag) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n) flag[v] = size[v] > 0 ? 1 : 0;
+}
+
+// coarse id of every node + representative coarse id of its phase-1 community
+__global__ void ld_coarse_ids_kernel(int n, const int* __restrict__ ref, const int64_t* __restrict__ newid_of_ref,
+                                     const int* __restrict__ comm, int* __restrict__ cid, int* __restrict__ rep) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n) {
+    const int c = (int)newid_of_ref[ref[v]];
+    cid[v] = c;
+    atomicMin(&rep[comm[v]], c);
+  }
+}
+__global__ void ld_coarse_comm_kernel(int n, const int* __restrict__ cid, const int* __restrict__ comm,
+                                      const int* __restrict__ rep, int* __restrict__ comm_new) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n) comm_new[cid[v]] = rep[comm[v]];
+}
+__global__ void ld_remap_kernel(int n_orig, const int* __restrict__ cid, int* __restrict__ node_of) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_orig) node_of[i] = cid[node_of[i]];
+}
+
+__device__ __forceinline__ unsigned long long hash64(unsigned long long x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+
+// one wave per node; every stored entry (v,u,w) adds w to table[(cid[v], cid[u])]
+__global__ __launch_bounds__(256) void ld_hash_insert_kernel(int n, const int64_t* __restrict__ indptr,
+                                                             const int* __restrict__ indices,
+                                                             const long long* __restrict__ wq,
+                                                             const int* __restrict__ cid,
+                                                             unsigned long long* __restrict__ keys,
+                                                             unsigned long long* __restrict__ vals,
+                                                             unsigned long long mask) {
+  const int lane = threadIdx.x & 63;
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= n) return;
+  const unsigned long long src = (unsigned long long)(unsigned int)cid[v] << 32;
+  for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) {
+    const unsigned long long key = src | (unsigned int)cid[indices[e]];
+    unsigned long long slot = hash64(key) & mask;
+    for (;;) {
+      unsigned long long prev = atomicCAS(&keys[slot], HEMPTY, key);
+      if (prev == HEMPTY || prev == key) {
+        atomicAdd(&vals[slot], (unsigned long long)wq[e]);
+        break;
+      }
+      slot = (slot + 1) & mask;
+    }
+  }
+}
+
+__global__ void ld_hash_count_kernel(const unsigned long long* __restrict__ keys, unsigned long long size,
+                                     int* __restrict__ rowcnt) {
+  unsigned long long s = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < size && keys[s] != HEMPTY) atomicAdd(&rowcnt[(int)(keys[s] >> 32)], 1);
+}
+
+__global__ void ld_hash_fill_kernel(const unsigned long long* __restrict__ keys,
+                                    const unsigned long long* __restrict__ vals, unsigned long long size,
+                                    const int64_t* __restrict__ indptr, int* __restrict__ cursor,
+                                    int* __restrict__ tmp_col, long long* __restrict__ tmp_w) {
+  unsigned long long s = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= size) return;
+  const unsigned long long key = keys[s];
+  if (key == HEMPTY) return;
+  const int src = (int)(key >> 32);
+  const int64_t p = indptr[src] + atomicAdd(&cursor[src], 1);
+  tmp_col[p] = (int)(key & 0xffffffffull);
+  tmp_w[p] = (long long)vals[s];
+}
+
+// one wave per row: rank sort by column (columns unique within a row)
+__global__ __launch_bounds__(256) void ld_sortrows_kernel(int n, const int64_t* __restrict__ indptr,
+                                                          const int* __restrict__ tmp_col,
+                                                          const long long* __restrict__ tmp_w,
+                                                          int* __restrict__ out_col, long long* __restrict__ out_w) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int64_t base = indptr[row];
+  const int len = (int)(indptr[row + 1] - base);
+  for (int cb = 0; cb < len; cb += 64) {
+    const int e = cb + lane;
+    const int c = (e < len) ? tmp_col[base + e] : 0x7fffffff;
+    int rank = 0;
+    for (int db = 0; db < len; db += 64) {
+      const int e2 = db + lane;
+      const int c2 = (e2 < len) ? tmp_col[base + e2] : 0x7fffffff;
+      const int cnt = min(64, len - db);
+      for (int t = 0; t < cnt; ++t) rank += (__builtin_amdgcn_readlane(c2, t) < c) ? 1 : 0;
+    }
+    if (e < len) {
+      out_col[base + rank] = c;
+      out_w[base + rank] = tmp_w[base + e];
+    }
+  }
+}
+
+// ---- quality ---------------------------------------------------------------------------------------
+// internal[0] += sum over stored entries inside a community (self loops included)
+__global__ __launch_bounds__(256) void ld_internal_kernel(int n, const int64_t* __restrict__ indptr,
+                                                          const int* __restrict__ indices,
+                                                          const long long* __restrict__ wq, const int* __restrict__ comm,
+                                                          unsigned long long* __restrict__ internal) {
+  const int lane = threadIdx.x & 63;
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  long long s = 0;
+  if (v < n) {
+    const int a = comm[v];
+    for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64)
+      if (comm[indices[e]] == a) s += wq[e];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0 && s != 0) atomicAdd(internal, (unsigned long long)s);
+}
+
+// sumsq[0] = sum_c (Ktot[c] / 2m)^2 in a fixed order (single block)
+__global__ __launch_bounds__(1024) void ld_sumsq_kernel(int n, const unsigned long long* __restrict__ Ktot,
+                                                        double m2, double* __restrict__ out) {
+  __shared__ double sh[1024];
+  double s = 0.0;
+  for (int c = threadIdx.x; c < n; c += 1024) {
+    double f = (double)(long long)Ktot[c] / m2;
+    s += f * f;
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+// ---- final renumbering by decreasing size ------------------------------------------------------------
+__global__ void ld_minmember_kernel(int n, const int* __restrict__ memb, int* __restrict__ minmember,
+                                    int* __restrict__ size) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n) {
+    atomicMin(&minmember[memb[v]], v);
+    atomicAdd(&size[memb[v]], 1);
+  }
+}
+// compact list of non-empty communities: key = (~size << 32) | minmember  (ascending = size desc)
+__global__ void ld_commkeys_kernel(int n, const int* __restrict__ size, const int* __restrict__ minmember,
+                                   const int64_t* __restrict__ pos, unsigned long long* __restrict__ keys,
+                                   int* __restrict__ ids) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n && size[c] > 0) {
+    const int64_t p = pos[c];
+    keys[p] = ((unsigned long long)(~(unsigned int)size[c]) << 32) | (unsigned int)minmember[c];
+    ids[p] = c;
+  }
+}
+__global__ void ld_rank_kernel(int nc, const unsigned long long* __restrict__ keys, const int* __restrict__ ids,
+                               int* __restrict__ newlabel /* indexed by old community id */) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nc) return;
+  const unsigned long long ki = keys[i];
+  int rank = 0;
+  for (int j = 0; j < nc; ++j) rank += keys[j] < ki ? 1 : 0;
+  newlabel[ids[i]] = rank;
+}
+__global__ void ld_compact_label_kernel(int nc, const int* __restrict__ ids, int* __restrict__ newlabel) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nc) newlabel[ids[i]] = i;
+}
+__global__ void ld_relabel_kernel(int n, const int* __restrict__ newlabel, int* __restrict__ memb) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n) memb[v] = newlabel[memb[v]];
+}
+__global__ void ld_gather_kernel(int n, const int* __restrict__ comm, const int* __restrict__ node_of,
+                                 int* __restrict__ out) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n) out[v] = comm[node_of[v]];
+}
+
+// ---- host orchestration --------------------------------------------------------------------------
+struct LevelGraph {
+  int n = 0;
+  int64_t nnz = 0;
+  const int64_t* indptr = nullptr;
+  const int* indices = nullptr;
+  const long long* wq = nullptr;
+  const long long* k = nullptr;
+};
+
+struct CoarseBuf {
+  int64_t* indptr; int* indices; long long* wq; long long* k;
+};
+
+struct LeidenBuffers {
+  long long* wq0; long long* k0;
+  CoarseBuf cb[2];
+  int* comm; int* comm_next; int* csize; unsigned long long* Ktot;
+  unsigned char* active; unsigned char* active_next;
+  int* ref; int* target; int* refsize; unsigned long long* Kref; unsigned long long* Eref; long long* a_in;
+  int* flag; int64_t* newid; int64_t* scan_tmp; int* cid; int* rep; int* comm_tmp;
+  int* node_of; int* memb; int* memb_best;
+  unsigned long long* hkeys; unsigned long long* hvals; unsigned long long hsize;
+  int* rowcnt; int* cursor; int* tmp_col; long long* tmp_w;
+  int* counters; unsigned long long* total; double* dscratch;
+  unsigned long long* ckeys; int* cids; int* newlabel; int* minmember;
+};
+
+static unsigned long long next_pow2(unsigned long long x) {
+  unsigned long long p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b) {
+  const size_t N = (size_t)n, E = (size_t)std::max<int64_t>(nnz, 1);
+  b->wq0 = ws.take<long long>(E);
+  b->k0 = ws.take<long long>(N);
+  for (int i = 0; i < 2; ++i) {
+    b->cb[i].indptr = ws.take<int64_t>(N + 1);
+    b->cb[i].indices = ws.take<int>(E);
+    b->cb[i].wq = ws.take<long long>(E);
+    b->cb[i].k = ws.take<long long>(N);
+  }
+  b->comm = ws.take<int>(N);
+  b->comm_next = ws.take<int>(N);
+  b->csize = ws.take<int>(N);
+  b->Ktot = ws.take<unsigned long long>(N);
+  b->active = ws.take<unsigned char>(N);
+  b->active_next = ws.take<unsigned char>(N);
+  b->ref = ws.take<int>(N);
+  b->target = ws.take<int>(N);
+  b->refsize = ws.take<int>(N);
+  b->Kref = ws.take<unsigned long long>(N);
+  b->Eref = ws.take<unsigned long long>(N);
+  b->a_in = ws.take<long long>(N);
+  b->flag = ws.take<int>(N);
+  b->newid = ws.take<int64_t>(N + 1);
+  b->scan_tmp = ws.take<int64_t>((size_t)scan_num_blocks(n) + 2);
+  b->cid = ws.take<int>(N);
+  b->rep = ws.take<int>(N);
+  b->comm_tmp = ws.take<int>(N);
+  b->node_of = ws.take<int>(N);
+  b->memb = ws.take<int>(N);
+  b->memb_best = ws.take<int>(N);
+  b->hsize = next_pow2(2 * (unsigned long long)E + 16);
+  b->hkeys = ws.take<unsigned long long>((size_t)b->hsize);
+  b->hvals = ws.take<unsigned long long>((size_t)b->hsize);
+  b->rowcnt = ws.take<int>(N);
+  b->cursor = ws.take<int>(N);
+  b->tmp_col = ws.take<int>(E);
+  b->tmp_w = ws.take<long long>(E);
+  b->counters = ws.take<int>(8);
+  b->total = ws.take<unsigned long long>(4);
+  b->dscratch = ws.take<double>(4);
+  b->ckeys = ws.take<unsigned long long>(N);
+  b->cids = ws.take<int>(N);
+  b->newlabel = ws.take<int>(N);
+  b->minmember = ws.take<int>(N);
+}
+
+#define GRID1(n) dim3((unsigned)ceil_div((n), 256)), dim3(256)
+#define GRIDW(n) dim3((unsigned)ceil_div((n), 4)), dim3(256)
+
+struct LeidenCtx {
+  hipStream_t s;
+  LeidenBuffers b;
+  double gamma;
+  double m2;  // total (quantised) weight = sum of strengths
+  unsigned int seed;
+};
+
+static int read_counters(LeidenCtx& cx, int* h, int cnt) {
+  SCAMD_HIP_CHECK(hipMemcpyAsync(h, cx.b.counters, sizeof(int) * cnt, hipMemcpyDeviceToHost, cx.s));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  return SCAMD_OK;
+}
+
+static int compute_totals(LeidenCtx& cx, const LevelGraph& g, const int* comm) {
+  SCAMD_HIP_CHECK(hipMemsetAsync(cx.b.Ktot, 0, sizeof(unsigned long long) * g.n, cx.s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(cx.b.csize, 0, sizeof(int) * g.n, cx.s));
+  hipLaunchKernelGGL(ld_totals_kernel, GRID1(g.n), 0, cx.s, comm, g.k, g.n, cx.b.Ktot, cx.b.csize);
+  SCAMD_LAUNCH_CHECK();
+  return SCAMD_OK;
+}
+
+// modularity of `comm` on level graph g (needs Ktot up to date)
+static int quality(LeidenCtx& cx, const LevelGraph& g, const int* comm, double* q) {
+  SCAMD_HIP_CHECK(hipMemsetAsync(cx.b.total + 1, 0, sizeof(unsigned long long), cx.s));
+  hipLaunchKernelGGL(ld_internal_kernel, GRIDW(g.n), 0, cx.s, g.n, g.indptr, g.indices, g.wq, comm, cx.b.total + 1);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ld_sumsq_kernel, dim3(1), dim3(1024), 0, cx.s, g.n, cx.b.Ktot, cx.m2, cx.b.dscratch);
+  SCAMD_LAUNCH_CHECK();
+  unsigned long long internal = 0;
+  double sumsq = 0;
+  SCAMD_HIP_CHECK(hipMemcpyAsync(&internal, cx.b.total + 1, sizeof(internal), hipMemcpyDeviceToHost, cx.s));
+  SCAMD_HIP_CHECK(hipMemcpyAsync(&sumsq, cx.b.dscratch, sizeof(double), hipMemcpyDeviceToHost, cx.s));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  *q = (double)(long long)internal / cx.m2 - cx.gamma * sumsq;
+  return SCAMD_OK;
+}
+
+static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
+  LeidenBuffers& b = cx.b;
+  hipLaunchKernelGGL(ld_fill_u8_kernel, GRID1(g.n), 0, cx.s, b.active, g.n, (unsigned char)1);
+  SCAMD_LAUNCH_CHECK();
+  const double gg = cx.gamma / cx.m2;
+  *total_moves = 0;
+  int quiet = 0;
+  for (int round = 0; round < MAX_LM_ROUNDS; ++round) {
+    int rc = compute_totals(cx, g, b.comm);
+    if (rc != SCAMD_OK) return rc;
+    SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
+    SCAMD_HIP_CHECK(hipMemsetAsync(b.active_next, 0, g.n, cx.s));
+    hipLaunchKernelGGL(ld_move_kernel, GRIDW(g.n), 0, cx.s, g.n, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
+                       b.csize, b.active, gg, round, cx.seed, b.comm_next, b.active_next, b.counters);
+    SCAMD_LAUNCH_CHECK();
+    int h[2];
+    rc = read_counters(cx, h, 2);
+    if (rc != SCAMD_OK) return rc;
+    std::swap(b.comm, b.comm_next);
+    std::swap(b.active, b.active_next);
+    *total_moves += h[0];
+    if (h[0] == 0 && h[1] == 0) break;
+    // moves blocked by the direction rule get their chance in the next (opposite) round
+    quiet = (h[0] == 0) ? quiet + 1 : 0;
+    if (quiet >= 2) break;
+  }
+  return compute_totals(cx, g, b.comm);
+}
+
+static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
+  LeidenBuffers& b = cx.b;
+  const double gg = cx.gamma / cx.m2;
+  hipLaunchKernelGGL(ld_refine_init_kernel, GRID1(g.n), 0, cx.s, g.n, g.k, b.ref, b.refsize, b.Kref);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ld_within_kernel, GRIDW(g.n), 0, cx.s, g.n, g.indptr, g.indices, g.wq, b.comm, b.a_in);
+  SCAMD_LAUNCH_CHECK();
+  *n_merged = 0;
+  int quiet = 0;
+  for (int round = 0; round < MAX_RF_ROUNDS; ++round) {
+    SCAMD_HIP_CHECK(hipMemsetAsync(b.Eref, 0, sizeof(unsigned long long) * g.n, cx.s));
+    hipLaunchKernelGGL(ld_cut_kernel, GRIDW(g.n), 0, cx.s, g.n, g.indptr, g.indices, g.wq, b.comm, b.ref, b.Eref);
+    SCAMD_LAUNCH_CHECK();
+    SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
+    hipLaunchKernelGGL(ld_refine_propose_kernel, GRIDW(g.n), 0, cx.s, g.n, g.indptr, g.indices, g.wq, g.k, b.comm,
+                       b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, b.a_in, gg, round, cx.seed, b.target);
+    SCAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ld_refine_apply_kernel, GRID1(g.n), 0, cx.s, g.n, b.target, g.k, b.ref, b.refsize, b.Kref,
+                       b.counters);
+    SCAMD_LAUNCH_CHECK();
+    int h[1];
+    int rc = read_counters(cx, h, 1);
+    if (rc != SCAMD_OK) return rc;
+    *n_merged += h[0];
+    quiet = (h[0] == 0) ? quiet + 1 : 0;
+    if (quiet >= RF_QUIET_ROUNDS) break;
+  }
+  return SCAMD_OK;
+}
+
+// builds the coarse graph of `g` under b.ref into cb[dst]; updates b.comm (coarse phase-1 partition)
+// and b.node_of.  Returns the new node count in *n_new (== g.n means nothing merged: no graph built).
+static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, LevelGraph* out, int* n_new) {
+  LeidenBuffers& b = cx.b;
+  hipLaunchKernelGGL(ld_flag_kernel, GRID1(g.n), 0, cx.s, g.n, b.refsize, b.flag);
+  SCAMD_LAUNCH_CHECK();
+  int rc = exclusive_scan_i32_i64(b.flag, g.n, b.newid, b.scan_tmp, cx.s);
+  if (rc != SCAMD_OK) return rc;
+  int64_t nn = 0;
+  SCAMD_HIP_CHECK(hipMemcpyAsync(&nn, b.newid + g.n, sizeof(int64_t), hipMemcpyDeviceToHost, cx.s));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  *n_new = (int)nn;
+  if (nn == g.n) return SCAMD_OK;
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.rep, 0x7f, sizeof(int) * g.n, cx.s));
+  hipLaunchKernelGGL(ld_coarse_ids_kernel, GRID1(g.n), 0, cx.s, g.n, b.ref, b.newid, b.comm, b.cid, b.rep);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ld_coarse_comm_kernel, GRID1(g.n), 0, cx.s, g.n, b.cid, b.comm, b.rep, b.comm_tmp);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ld_remap_kernel, GRID1(n_orig), 0, cx.s, n_orig, b.cid, b.node_of);
+  SCAMD_LAUNCH_CHECK();
+  // hash-combine the coarse edges
+  const unsigned long long hsize = std::min<unsigned long long>(b.hsize, next_pow2(2 * (unsigned long long)g.nnz + 16));
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.hkeys, 0xff, sizeof(unsigned long long) * hsize, cx.s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.hvals, 0, sizeof(unsigned long long) * hsize, cx.s));
+  hipLaunchKernelGGL(ld_hash_insert_kernel, GRIDW(g.n), 0, cx.s, g.n, g.indptr, g.indices, g.wq, b.cid, b.hkeys,
+                     b.hvals, hsize - 1);
+  SCAMD_LAUNCH_CHECK();
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.rowcnt, 0, sizeof(int) * nn, cx.s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.cursor, 0, sizeof(int) * nn, cx.s));
+  const unsigned hblocks = (unsigned)((hsize + 255) / 256);
+  hipLaunchKernelGGL(ld_hash_count_kernel, dim3(hblocks), dim3(256), 0, cx.s, b.hkeys, hsize, b.rowcnt);
+  SCAMD_LAUNCH_CHECK();
+  CoarseBuf& cb = b.cb[dst];
+  rc = exclusive_scan_i32_i64(b.rowcnt, nn, cb.indptr, b.scan_tmp, cx.s);
+  if (rc != SCAMD_OK) return rc;
+  hipLaunchKernelGGL(ld_hash_fill_kernel, dim3(hblocks), dim3(256), 0, cx.s, b.hkeys, b.hvals, hsize, cb.indptr,
+                     b.cursor, b.tmp_col, b.tmp_w);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ld_sortrows_kernel, GRIDW(nn), 0, cx.s, (int)nn, cb.indptr, b.tmp_col, b.tmp_w, cb.indices,
+                     cb.wq);
+  SCAMD_LAUNCH_CHECK();
+  int64_t nnz_new = 0;
+  SCAMD_HIP_CHECK(hipMemcpyAsync(&nnz_new, cb.indptr + nn, sizeof(int64_t), hipMemcpyDeviceToHost, cx.s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.total + 2, 0, sizeof(unsigned long long), cx.s));
+  hipLaunchKernelGGL(ld_strength_kernel, GRIDW(nn), 0, cx.s, cb.indptr, cb.wq, (int)nn, cb.k, b.total + 2);
+  SCAMD_LAUNCH_CHECK();
+  SCAMD_HIP_CHECK(hipMemcpyAsync(b.comm, b.comm_tmp, sizeof(int) * nn, hipMemcpyDeviceToDevice, cx.s));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  out->n = (int)nn;
+  out->nnz = nnz_new;
+  out->indptr = cb.indptr;
+  out->indices = cb.indices;
+  out->wq = cb.wq;
+  out->k = cb.k;
+  return SCAMD_OK;
+}
+
+// one Leiden iteration starting from the level-0 partition in b.memb; result back into b.memb
+static int leiden_iteration(LeidenCtx& cx, const LevelGraph& g0) {
+  LeidenBuffers& b = cx.b;
+  SCAMD_HIP_CHECK(hipMemcpyAsync(b.comm, b.memb, sizeof(int) * g0.n, hipMemcpyDeviceToDevice, cx.s));
+  hipLaunchKernelGGL(ld_iota_kernel, GRID1(g0.n), 0, cx.s, b.node_of, g0.n);
+  SCAMD_LAUNCH_CHECK();
+  LevelGraph g = g0;
+  for (int level = 0; level < MAX_LEVELS; ++level) {
+    int moves = 0;
+    int rc = local_moving(cx, g, &moves);
+    if (rc != SCAMD_OK) return rc;
+    int merged = 0;
+    rc = refinement(cx, g, &merged);
+    if (rc != SCAMD_OK) return rc;
+    if (merged == 0) break;
+    LevelGraph gn;
+    int n_new = 0;
+    rc = aggregate(cx, g, g0.n, level & 1, &gn, &n_new);
+    if (rc != SCAMD_OK) return rc;
+    if (n_new == g.n) break;
+    g = gn;
+  }
+  hipLaunchKernelGGL(ld_gather_kernel, GRID1(g0.n), 0, cx.s, g0.n, b.comm, b.node_of, b.memb);
+  SCAMD_LAUNCH_CHECK();
+  return SCAMD_OK;
+}
+
+// relabel b.memb (values < n) to consecutive ids ordered by (size desc, first member asc)
+static int renumber(LeidenCtx& cx, int n, int* n_comm) {
+  LeidenBuffers& b = cx.b;
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.minmember, 0x7f, sizeof(int) * n, cx.s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.csize, 0, sizeof(int) * n, cx.s));
+  hipLaunchKernelGGL(ld_minmember_kernel, GRID1(n), 0, cx.s, n, b.memb, b.minmember, b.csize);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ld_flag_kernel, GRID1(n), 0, cx.s, n, b.csize, b.flag);
+  SCAMD_LAUNCH_CHECK();
+  int rc = exclusive_scan_i32_i64(b.flag, n, b.newid, b.scan_tmp, cx.s);
+  if (rc != SCAMD_OK) return rc;
+  int64_t nc = 0;
+  SCAMD_HIP_CHECK(hipMemcpyAsync(&nc, b.newid + n, sizeof(int64_t), hipMemcpyDeviceToHost, cx.s));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  hipLaunchKernelGGL(ld_commkeys_kernel, GRID1(n), 0, cx.s, n, b.csize, b.minmember, b.newid, b.ckeys, b.cids);
+  SCAMD_LAUNCH_CHECK();
+  if (nc <= 131072) {
+    hipLaunchKernelGGL(ld_rank_kernel, GRID1(nc), 0, cx.s, (int)nc, b.ckeys, b.cids, b.newlabel);
+  } else {
+    // degenerate partitions (hundreds of thousands of communities): consecutive ids by first member only
+    hipLaunchKernelGGL(ld_compact_label_kernel, GRID1(nc), 0, cx.s, (int)nc, b.cids, b.newlabel);
+  }
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ld_relabel_kernel, GRID1(n), 0, cx.s, n, b.newlabel, b.memb);
+  SCAMD_LAUNCH_CHECK();
+  *n_comm = (int)nc;
+  return SCAMD_OK;
+}
+
+static int setup_level0(LeidenCtx& cx, const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n,
+                        int64_t nnz, LevelGraph* g0) {
+  LeidenBuffers& b = cx.b;
+  if (nnz > 0) {
+    hipLaunchKernelGGL(ld_quantize_kernel, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, cx.s, weights, nnz, b.wq0);
+    SCAMD_LAUNCH_CHECK();
+  }
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.total, 0, sizeof(unsigned long long) * 4, cx.s));
+  hipLaunchKernelGGL(ld_strength_kernel, GRIDW(n), 0, cx.s, indptr, b.wq0, (int)n, b.k0, b.total);
+  SCAMD_LAUNCH_CHECK();
+  unsigned long long tot = 0;
+  SCAMD_HIP_CHECK(hipMemcpyAsync(&tot, b.total, sizeof(tot), hipMemcpyDeviceToHost, cx.s));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  cx.m2 = (double)tot;
+  g0->n = (int)n;
+  g0->nnz = nnz;
+  g0->indptr = indptr;
+  g0->indices = indices;
+  g0->wq = b.wq0;
+  g0->k = b.k0;
+  return SCAMD_OK;
+}
+
+}  // namespace scamd
+
+using namespace scamd;
+
+extern "C" size_t scamd_leiden_workspace_bytes(int64_t n, int64_t nnz) {
+  if (n <= 0 || nnz < 0) return 0;
+  Workspace ws(nullptr, 0);
+  LeidenBuffers b;
+  leiden_carve(ws, n, nnz, &b);
+  return ws.used();
+}
+
+extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n,
+                                    int64_t nnz, double resolution, int n_iterations, double beta, uint64_t seed,
+                                    int32_t* membership, double* modularity_host, int32_t* n_communities_host,
+                                    void* workspace, size_t workspace_bytes, scamd_stream_t stream) {
+  (void)beta;  // the refinement takes the beta -> 0 (greedy) limit of the randomised merge rule
+  SCAMD_REQUIRE(indptr && membership && (nnz == 0 || (indices && weights)), SCAMD_EINVAL, "leiden: null pointer");
+  SCAMD_REQUIRE(n >= 1 && n < ((int64_t)1 << 31) && nnz >= 0, SCAMD_EINVAL, "leiden: bad shape n=%lld nnz=%lld",
+                (long long)n, (long long)nnz);
+  SCAMD_REQUIRE(resolution >= 0.0, SCAMD_EINVAL, "leiden: negative resolution");
+  LeidenCtx cx;
+  cx.s = stream;
+  cx.gamma = resolution;
+  cx.seed = (unsigned int)(seed ^ (seed >> 32)) * 0x9E3779B1u + 0x632BE5ABu;
+  Workspace ws(workspace, workspace_bytes);
+  leiden_carve(ws, n, nnz, &cx.b);
+  SCAMD_REQUIRE(workspace && ws.ok, SCAMD_EWORKSPACE, "leiden: workspace %zu < required %zu", workspace_bytes,
+                ws.used());
+  LevelGraph g0;
+  int rc = setup_level0(cx, indptr, indices, weights, n, nnz, &g0);
+  if (rc != SCAMD_OK) return rc;
+  LeidenBuffers& b = cx.b;
+  hipLaunchKernelGGL(ld_iota_kernel, GRID1(n), 0, cx.s, b.memb, (int)n);
+  SCAMD_LAUNCH_CHECK();
+  double q_best = 0.0;
+  if (cx.m2 > 0.0) {
+    rc = compute_totals(cx, g0, b.memb);
+    if (rc == SCAMD_OK) rc = quality(cx, g0, b.memb, &q_best);
+    if (rc != SCAMD_OK) return rc;
+    SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb_best, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+    const int max_iter = n_iterations < 0 ? MAX_OUTER_ITERS : n_iterations;
+    for (int it = 0; it < max_iter; ++it) {
+      rc = leiden_iteration(cx, g0);
+      if (rc != SCAMD_OK) return rc;
+      double q = 0.0;
+      rc = compute_totals(cx, g0, b.memb);
+      if (rc == SCAMD_OK) rc = quality(cx, g0, b.memb, &q);
+      if (rc != SCAMD_OK) return rc;
+      const bool improved = q > q_best + 1e-12;
+      if (improved) {
+        q_best = q;
+        SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb_best, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+      } else {
+        // synchronous moves are not monotone: keep the best partition seen
+        SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb, b.memb_best, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+      }
+      if (n_iterations < 0 && !improved) break;
+    }
+  }
+  int nc = 0;
+  rc = renumber(cx, (int)n, &nc);
+  if (rc != SCAMD_OK) return rc;
+  SCAMD_HIP_CHECK(hipMemcpyAsync(membership, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  if (modularity_host) *modularity_host = q_best;
+  if (n_communities_host) *n_communities_host = nc;
+  return SCAMD_OK;
+}
+
+extern "C" int scamd_modularity_csr_f32(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n,
+                                        int64_t nnz, const int32_t* membership, double resolution,
+                                        double* modularity_host, void* workspace, size_t workspace_bytes,
+                                        scamd_stream_t stream) {
+  SCAMD_REQUIRE(indptr && membership && modularity_host && (nnz == 0 || (indices && weights)), SCAMD_EINVAL,
+                "modularity: null pointer");
+  SCAMD_REQUIRE(n >= 1 && n < ((int64_t)1 << 31) && nnz >= 0, SCAMD_EINVAL, "modularity: bad shape");
+  LeidenCtx cx;
+  cx.s = stream;
+  cx.gamma = resolution;
+  cx.seed = 0;
+  Workspace ws(workspace, workspace_bytes);
+  leiden_carve(ws, n, nnz, &cx.b);
+  SCAMD_REQUIRE(workspace && ws.ok, SCAMD_EWORKSPACE, "modularity: workspace %zu < required %zu", workspace_bytes,
+                ws.used());
+  LevelGraph g0;
+  int rc = setup_level0(cx, indptr, indices, weights, n, nnz, &g0);
+  if (rc != SCAMD_OK) return rc;
+  *modularity_host = 0.0;
+  if (cx.m2 <= 0.0) return SCAMD_OK;
+  // membership ids must lie in [0, n)
+  rc = compute_totals(cx, g0, membership);
+  if (rc == SCAMD_OK) rc = quality(cx, g0, membership, modularity_host);
+  return rc;
 }

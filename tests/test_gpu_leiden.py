@@ -1,0 +1,121 @@
+"""GPU Leiden vs the CPU oracle (oracle/leiden.c).  Label parity is UNPINNED in the reference (no golden
+labels; tests/test_clustering.py pins determinism, seed sensitivity, NMI > 0.9 between flavors), so the
+checks are: identical modularity arithmetic, quality at least the oracle's, ARI on planted partitions."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+from scipy import sparse
+from sklearn.metrics import adjusted_rand_score, normalized_mutual_info_score
+
+from oracle import connectivities as oc
+from oracle import knn as oknn
+from oracle import leiden as ol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    from scanpy_amd import _kernels
+
+    return _kernels
+
+
+def _dev(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _graph_dev(adj):
+    adj = sparse.csr_matrix(adj)
+    adj.sort_indices()
+    return _dev(adj.indptr.astype(np.int64)), _dev(adj.indices.astype(np.int32)), _dev(adj.data.astype(np.float32)), adj.shape[0]
+
+
+def _blob_graph(n, n_types, seed, spread=1.0, k=15):
+    from scanpy_amd.datasets import blobs_embedding
+
+    x, lab = blobs_embedding(n, 50, n_types=n_types, spread=spread, seed=seed)
+    idx, dist, _ = oknn.knn_sklearn(x, k, n_jobs=-1)
+    c, _, _ = oc.fuzzy_simplicial_set(idx, dist, n, k)
+    return c, lab
+
+
+def test_modularity_matches_oracle(K, pbmc68k):
+    adj = pbmc68k["connectivities"].astype(np.float32)
+    ip, ix, w, n = _graph_dev(adj)
+    for memb in (pbmc68k["louvain_codes"].astype(np.int32), np.arange(n, dtype=np.int32), np.zeros(n, dtype=np.int32)):
+        for res in (1.0, 0.5, 2.0):
+            q = K.modularity(ip, ix, w, n, _dev(memb), resolution=res)
+            assert abs(q - ol.modularity(adj, memb, resolution=res)) < 1e-8
+
+
+def test_leiden_fixture_quality_and_determinism(K, pbmc68k):
+    adj = pbmc68k["connectivities"].astype(np.float32)
+    ip, ix, w, n = _graph_dev(adj)
+    m0, q0, nc0 = K.leiden(ip, ix, w, n, seed=0)
+    m0 = m0.cpu().numpy()
+    _, q_oracle = ol.leiden(adj, seed=0)
+    print("gpu Q", q0, "n_comm", nc0, "oracle Q", q_oracle)
+    assert abs(q0 - ol.modularity(adj, m0)) < 1e-8, "reported modularity must be that of the labels"
+    assert q0 > q_oracle - 0.01
+    assert m0.min() == 0 and m0.max() == nc0 - 1
+    sizes = np.bincount(m0)
+    assert (np.diff(sizes) <= 0).all(), "ids ordered by decreasing size"
+    m1, q1, _ = K.leiden(ip, ix, w, n, seed=0)
+    np.testing.assert_array_equal(m0, m1.cpu().numpy())
+    assert q0 == q1
+    mo, _ = ol.leiden(adj, seed=0)
+    nmi = normalized_mutual_info_score(mo, m0)
+    print("NMI vs oracle", nmi, "ARI", adjusted_rand_score(mo, m0))
+    assert nmi > 0.9  # the reference's own cross-implementation bar (tests/test_clustering.py:130-163)
+
+
+def test_leiden_seed_changes_labels(K, pbmc68k):
+    adj = pbmc68k["connectivities"].astype(np.float32)
+    ip, ix, w, n = _graph_dev(adj)
+    labels = [K.leiden(ip, ix, w, n, seed=s)[0].cpu().numpy() for s in (0, 1, 2, 3)]
+    assert any((labels[0] != l).any() for l in labels[1:])
+
+
+@pytest.mark.parametrize(("n", "n_types"), [(5000, 8), (20000, 32), (60000, 64)])
+def test_leiden_planted(K, n, n_types):
+    adj, truth = _blob_graph(n, n_types, seed=n)
+    ip, ix, w, _ = _graph_dev(adj)
+    m, q, nc = K.leiden(ip, ix, w, n)
+    m = m.cpu().numpy()
+    mo, qo = ol.leiden(adj)
+    ari_truth, ari_oracle = adjusted_rand_score(truth, m), adjusted_rand_score(mo, m)
+    print(f"n={n}: gpu Q={q:.6f} nc={nc}; oracle Q={qo:.6f} nc={mo.max() + 1}; ARI truth={ari_truth:.4f} oracle={ari_oracle:.4f}")
+    assert ari_oracle >= 0.99
+    assert ari_truth >= 0.99
+    assert q >= qo - 1e-6
+
+
+def test_leiden_resolution_and_iterations(K):
+    adj, _ = _blob_graph(8000, 16, seed=3)
+    ip, ix, w, n = _graph_dev(adj)
+    for res in (0.3, 1.0, 3.0):
+        m, q, nc = K.leiden(ip, ix, w, n, resolution=res)
+        mo, qo = ol.leiden(adj, resolution=res)
+        print(f"res={res}: gpu Q={q:.5f} nc={nc} oracle Q={qo:.5f} nc={mo.max() + 1}")
+        assert abs(q - ol.modularity(adj, m.cpu().numpy(), resolution=res)) < 1e-8
+        assert q >= qo - 0.01
+    m2, q2, _ = K.leiden(ip, ix, w, n, n_iterations=2)
+    assert q2 > 0.5
+
+
+def test_leiden_disconnected_and_isolated(K):
+    # two cliques + three isolated vertices
+    a = np.zeros((11, 11), dtype=np.float32)
+    a[:4, :4] = 1
+    a[4:8, 4:8] = 1
+    np.fill_diagonal(a, 0)
+    adj = sparse.csr_matrix(a)
+    ip, ix, w, n = _graph_dev(adj)
+    m, q, nc = K.leiden(ip, ix, w, n)
+    m = m.cpu().numpy()
+    assert nc == 5 and len(set(m[:4])) == 1 and len(set(m[4:8])) == 1 and m[0] != m[4]
+    assert len(set(m[8:])) == 3
