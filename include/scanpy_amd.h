@@ -71,6 +71,9 @@ int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x,
                      int32_t* out_idx, double* out_dist,
                      double cert_scale, int64_t* n_fallback_host,
                      void* workspace, size_t workspace_bytes, scamd_stream_t stream);
+/* Duration (ms, HIP events on `stream`) of the FP32-MFMA selection kernel of the calling thread's most
+ * recent scamd_knn_l2_f32 call; -1 if none.  Used by bench.py for the roofline figure. */
+float scamd_knn_last_select_ms(void);
 
 /* ------------------------------------------------------------------------------------------
  * Fuzzy simplicial set -- umap connectivities from a kNN result.

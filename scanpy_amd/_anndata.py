@@ -1,0 +1,83 @@
+"""A minimal AnnData-shaped container, used when the `anndata` package is not installed.
+
+The path only touches X / layers / obs / var / obsm / varm / obsp / uns, `n_obs`, `n_vars`, `shape`,
+`copy()` and column subsetting `adata[:, mask]` (src/scanpy/preprocessing/_pca/__init__.py:232).
+A real `anndata.AnnData` is accepted everywhere this class is.
+"""
+from __future__ import annotations
+
+import copy as _copy
+
+import numpy as np
+import pandas as pd
+from scipy import sparse
+
+
+class AnnData:
+    def __init__(self, X=None, obs=None, var=None, *, obsm=None, varm=None, obsp=None, uns=None, layers=None):
+        if X is not None and not sparse.issparse(X):
+            X = np.asarray(X)
+        self.X = X
+        n_obs, n_vars = X.shape if X is not None else (len(obs), len(var))
+        self.obs = obs if obs is not None else pd.DataFrame(index=pd.RangeIndex(n_obs).astype(str))
+        self.var = var if var is not None else pd.DataFrame(index=pd.RangeIndex(n_vars).astype(str))
+        self.obsm = dict(obsm or {})
+        self.varm = dict(varm or {})
+        self.obsp = dict(obsp or {})
+        self.uns = dict(uns or {})
+        self.layers = dict(layers or {})
+        self.is_view = False
+
+    @property
+    def n_obs(self) -> int:
+        return len(self.obs)
+
+    @property
+    def n_vars(self) -> int:
+        return len(self.var)
+
+    @property
+    def shape(self):
+        return (self.n_obs, self.n_vars)
+
+    def copy(self) -> "AnnData":
+        return AnnData(
+            None if self.X is None else self.X.copy(),
+            self.obs.copy(),
+            self.var.copy(),
+            obsm={k: v.copy() for k, v in self.obsm.items()},
+            varm={k: v.copy() for k, v in self.varm.items()},
+            obsp={k: v.copy() for k, v in self.obsp.items()},
+            uns=_copy.deepcopy(self.uns),
+            layers={k: v.copy() for k, v in self.layers.items()},
+        )
+
+    def __getitem__(self, index) -> "AnnData":
+        """Only `adata[:, var_mask]` and `adata[obs_mask]` / `adata[obs_mask, :]` are supported."""
+        if not isinstance(index, tuple):
+            index = (index, slice(None))
+        oi, vi = index
+        oi = slice(None) if oi is None else oi
+        X = self.X[oi][:, vi] if self.X is not None else None
+        sub = AnnData(
+            X,
+            self.obs.iloc[oi] if not isinstance(oi, slice) or oi != slice(None) else self.obs,
+            self.var.iloc[vi] if not isinstance(vi, slice) or vi != slice(None) else self.var,
+            obsm={k: v[oi] for k, v in self.obsm.items()},
+            varm={k: v[vi] for k, v in self.varm.items()},
+            uns=self.uns,
+            layers={k: v[oi][:, vi] for k, v in self.layers.items()},
+        )
+        if isinstance(vi, slice) and vi == slice(None):
+            sub.obsp = {k: v[oi][:, oi] for k, v in self.obsp.items()}
+        sub.is_view = True
+        return sub
+
+    def __repr__(self) -> str:
+        return (f"AnnData object with n_obs x n_vars = {self.n_obs} x {self.n_vars}\n    obs: {list(self.obs.columns)}\n"
+                f"    var: {list(self.var.columns)}\n    uns: {list(self.uns)}\n    obsm: {list(self.obsm)}\n"
+                f"    varm: {list(self.varm)}\n    obsp: {list(self.obsp)}")
+
+
+def is_anndata(obj) -> bool:
+    return all(hasattr(obj, a) for a in ("obs", "var", "obsm", "obsp", "uns", "n_obs", "n_vars"))

@@ -1,0 +1,17 @@
+"""The few settings the path reads (src/scanpy/_settings/__init__.py:59-218): N_PCS, n_jobs, verbosity."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+
+@dataclass
+class Settings:
+    N_PCS: int = 50        # _settings/__init__.py:83
+    n_jobs: int = 4        # _settings/__init__.py:132 (unused on the GPU path; kept for API parity)
+    verbosity: int = 1
+    # Default Leiden flavor.  The reference's V1 preset says 'leidenalg' (presets.py:271-277); both flavors
+    # optimise the same objective and map onto the same GPU kernel here.
+    leiden_flavor: str = "leidenalg"
+
+
+settings = Settings()

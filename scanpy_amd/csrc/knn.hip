@@ -468,6 +468,9 @@ static int dispatch_select(const KnnPlan& p, const KnnBuffers& b, int64_t q_begi
 
 using namespace scamd;
 
+static thread_local float g_last_select_ms = -1.f;
+extern "C" float scamd_knn_last_select_ms(void) { return g_last_select_ms; }
+
 extern "C" size_t scamd_knn_workspace_bytes(int64_t n, int d, int64_t n_query, int k) {
   KnnPlan p;
   if (!knn_plan(n, d, n_query, k, &p)) return 0;
@@ -509,8 +512,17 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
                        p.n_pad, b.xp, b.cn, b.cmax);
     SCAMD_LAUNCH_CHECK();
   }
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  SCAMD_HIP_CHECK(hipEventCreate(&ev0));
+  SCAMD_HIP_CHECK(hipEventCreate(&ev1));
+  SCAMD_HIP_CHECK(hipEventRecord(ev0, s));
   int rc = dispatch_select(p, b, q_begin, s);
-  if (rc != SCAMD_OK) return rc;
+  if (rc == SCAMD_OK && hipEventRecord(ev1, s) != hipSuccess) rc = SCAMD_EHIP;
+  if (rc != SCAMD_OK) {
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    return rc;
+  }
   {
     int blocks = (int)((n_query + 3) / 4);
 #define RERANK(KP_)                                                                              \
@@ -526,6 +538,13 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
   int h_counters[4] = {0, 0, 0, 0};
   SCAMD_HIP_CHECK(hipMemcpyAsync(h_counters, b.counters, 16, hipMemcpyDeviceToHost, s));
   SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+  {
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) ms = -1.f;
+    g_last_select_ms = ms;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+  }
   const int n_flag = h_counters[0];
   if (n_fallback_host) *n_fallback_host = n_flag;
   for (int begin = 0; begin < n_flag; begin += FALLBACK_CHUNK) {

@@ -21,7 +21,8 @@ def synthetic_planted(
     boost: float = 2.0,
     size_ratio: float = 8.0,
     seed: int = 0,
-    chunk: int = 200_000,
+    chunk: int = 100_000,
+    row_range: tuple[int, int] | None = None,
 ):
     """-> (X csr float32 [n_obs, n_vars] with sorted int32 indices, labels int32 [n_obs]).
 
@@ -30,6 +31,10 @@ def synthetic_planted(
     stratum a cell of type t expresses the type's programme gene with probability `p_programme`
     (value boosted by `boost`), otherwise a uniformly random gene of the stratum.  Values are
     log1p(lognormal(0, 1)).  Type sizes follow a geometric progression spanning `size_ratio`.
+
+    Rows are generated in independent chunks of `chunk` rows (chunk c uses the stream seeded with
+    (seed, c)), so `row_range=(start, stop)` yields exactly rows start..stop-1 of the full matrix
+    without generating the rest: every rank of a row-sharded run builds only its own block.
     """
     rng = np.random.default_rng(seed)
     r = max(1, int(round(density * n_vars)))
@@ -38,21 +43,34 @@ def synthetic_planted(
         raise ValueError("density too high for the stratified generator")
     weights = size_ratio ** (-np.arange(n_types) / max(1, n_types - 1))
     weights /= weights.sum()
-    labels = rng.choice(n_types, size=n_obs, p=weights).astype(np.int32)
     pref = rng.integers(0, width, size=(n_types, r), dtype=np.int32)
     strata = (np.arange(r, dtype=np.int32) * width)[None, :]
-    indices = np.empty((n_obs, r), dtype=np.int32)
-    data = np.empty((n_obs, r), dtype=np.float32)
-    for s in range(0, n_obs, chunk):
-        e = min(n_obs, s + chunk)
-        m = e - s
-        is_prog = rng.random((m, r), dtype=np.float32) < p_programme
-        rand_gene = rng.integers(0, width, size=(m, r), dtype=np.int32)
-        gene = np.where(is_prog, pref[labels[s:e]], rand_gene)
-        indices[s:e] = strata + gene
-        v = np.exp(rng.standard_normal((m, r), dtype=np.float32))
+    start, stop = (0, n_obs) if row_range is None else row_range
+    if not 0 <= start <= stop <= n_obs:
+        raise ValueError("row_range outside [0, n_obs]")
+    n_out = stop - start
+    labels = np.empty(n_out, dtype=np.int32)
+    indices = np.empty((n_out, r), dtype=np.int32)
+    data = np.empty((n_out, r), dtype=np.float32)
+    for c in range(start // chunk, (max(stop, 1) - 1) // chunk + 1):
+        cs, ce = c * chunk, min(n_obs, (c + 1) * chunk)
+        m = ce - cs
+        crng = np.random.default_rng([seed, c])
+        lab = crng.choice(n_types, size=m, p=weights).astype(np.int32)
+        is_prog = crng.random((m, r), dtype=np.float32) < p_programme
+        rand_gene = crng.integers(0, width, size=(m, r), dtype=np.int32)
+        gene = np.where(is_prog, pref[lab], rand_gene)
+        v = np.exp(crng.standard_normal((m, r), dtype=np.float32))
         v *= np.where(is_prog, np.float32(boost), np.float32(1.0))
-        data[s:e] = np.log1p(v)
+        lo, hi = max(cs, start), min(ce, stop)
+        if lo >= hi:
+            continue
+        src = slice(lo - cs, hi - cs)
+        dst = slice(lo - start, hi - start)
+        labels[dst] = lab[src]
+        indices[dst] = (strata + gene)[src]
+        data[dst] = np.log1p(v)[src]
+    n_obs = n_out
     indptr = np.arange(0, n_obs * r + 1, r, dtype=np.int64)
     if indptr[-1] < 2**31:
         indptr = indptr.astype(np.int32)

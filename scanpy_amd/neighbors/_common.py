@@ -1,0 +1,81 @@
+"""kNN index/distance <-> CSR conventions of the reference (src/scanpy/neighbors/_common.py), host side."""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+from scipy import sparse
+
+
+def has_self_column(indices: np.ndarray) -> bool:
+    """_common.py:17-22: some row lists itself first (`.any()`, duplicates may displace self)."""
+    return bool((indices[:, 0] == np.arange(indices.shape[0])).any())
+
+
+def remove_self_column(indices, distances):
+    """_common.py:25-32."""
+    if not has_self_column(indices):
+        msg = "The first neighbor should be the cell itself."
+        raise AssertionError(msg)
+    return indices[:, 1:], distances[:, 1:]
+
+
+def get_sparse_matrix_from_indices_distances(indices, distances, *, keep_self: bool) -> sparse.csr_matrix:
+    """_common.py:35-61: constant-nnz CSR; duplicates stay as explicitly stored zeros."""
+    if not keep_self:
+        indices, distances = remove_self_column(indices, distances)
+    n, k = indices.shape
+    indptr = np.arange(0, n * k + 1, k)
+    return sparse.csr_matrix((distances.copy().ravel(), indices.copy().ravel(), indptr), shape=(n, n))
+
+
+def get_indices_distances_from_dense_matrix(d: np.ndarray, n_neighbors: int):
+    """_common.py:64-71."""
+    sample_range = np.arange(d.shape[0])[:, None]
+    indices = np.argpartition(d, n_neighbors - 1, axis=1)[:, :n_neighbors]
+    indices = indices[sample_range, np.argsort(d[sample_range, indices])]
+    return indices, d[sample_range, indices]
+
+
+def _ind_dist_shortcut(d: sparse.csr_matrix):
+    """_common.py:126-143."""
+    nnzs = np.diff(d.indptr)
+    if len(nnzs) == 0 or not (nnzs == nnzs[0]).all():
+        warnings.warn("Sparse matrix has no constant number of neighbors per row. "
+                      "Cannot efficiently get indices and distances.", RuntimeWarning, stacklevel=3)
+        return None
+    n_obs, n_neighbors = d.shape[0], int(nnzs[0])
+    return d.indices.reshape(n_obs, n_neighbors), d.data.reshape(n_obs, n_neighbors)
+
+
+def _ind_dist_slow(d: sparse.csr_matrix, n_neighbors: int):
+    """_common.py:101-123."""
+    indices = np.zeros((d.shape[0], n_neighbors), dtype=int)
+    distances = np.zeros((d.shape[0], n_neighbors), dtype=d.dtype)
+    m1 = n_neighbors - 1
+    for i in range(indices.shape[0]):
+        row = d[i]
+        cols, vals = row.indices, row.data  # 'true' and 'spurious' zeros alike
+        indices[i, 0] = i
+        distances[i, 0] = 0
+        if len(cols) > m1:
+            order = np.argsort(vals)[:m1]
+            indices[i, 1:] = cols[order]
+            distances[i, 1:] = vals[order]
+        else:
+            indices[i, 1 : 1 + len(cols)] = cols
+            distances[i, 1 : 1 + len(cols)] = vals
+    return indices, distances
+
+
+def get_indices_distances_from_sparse_matrix(d, n_neighbors: int):
+    """_common.py:74-98: first column = the cell itself, at most n_neighbors columns."""
+    d = sparse.csr_matrix(d)
+    shortcut = _ind_dist_shortcut(d)
+    indices, distances = shortcut if shortcut is not None else _ind_dist_slow(d, n_neighbors)
+    if not has_self_column(indices):  # RAPIDS-style rows lack the self column
+        indices = np.hstack([np.arange(indices.shape[0])[:, None], indices])
+        distances = np.hstack([np.zeros(distances.shape[0])[:, None], distances])
+    if indices.shape[1] > n_neighbors:
+        indices, distances = indices[:, :n_neighbors], distances[:, :n_neighbors]
+    return indices, distances

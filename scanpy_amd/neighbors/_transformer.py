@@ -1,0 +1,85 @@
+"""kNN estimator for the reference's plug-in protocol (`KnnTransformerLike`,
+src/scanpy/neighbors/_types.py:53-64; template src/scanpy/neighbors/_backends/rapids.py:39-101).
+
+`MI355XKNNTransformer(n_neighbors=15)` can be passed as `transformer=` to UNMODIFIED upstream
+`scanpy.pp.neighbors`: `fit_transform(X)` returns a CSR with a constant number of stored entries per
+row.  With `include_self=False` (default) rows hold the n_neighbors-1 nearest OTHER cells (RAPIDS style,
+_common.py:88-91 re-inserts the self column), so `obsp['distances']` equals the reference's default
+result; `include_self=True` gives sklearn-style rows (self first with an explicit 0, n_neighbors+1
+entries).
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy import sparse
+
+
+def knn_search(x, k: int, *, q_begin: int = 0, n_query: int | None = None):
+    """Exact Euclidean kNN on the GPU.  -> (indices int64 [nq, k], distances float64 [nq, k]);
+    column 0 is the row itself with distance exactly 0."""
+    import torch
+
+    from .. import _kernels
+    from .._device import require_gpu
+
+    dev = require_gpu()
+    if sparse.issparse(x):
+        x = x.toarray()
+    xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
+    idx, dist, _ = _kernels.knn(xd, k, q_begin=q_begin, n_query=n_query)
+    return idx.cpu().numpy().astype(np.int64), dist.cpu().numpy()
+
+
+class MI355XKNNTransformer:
+    """sklearn-estimator-shaped exact kNN on MI355X (`fit`, `transform`, `fit_transform`, `get_params`,
+    `set_params`)."""
+
+    def __init__(self, n_neighbors: int = 15, *, metric: str = "euclidean", include_self: bool = False):
+        if metric not in ("euclidean", "l2"):
+            msg = f"metric={metric!r}: the MI355X kNN kernel is Euclidean only"
+            raise ValueError(msg)
+        self.n_neighbors = n_neighbors
+        self.metric = metric
+        self.include_self = include_self
+        self._fit_x = None
+
+    def get_params(self, deep: bool = True) -> dict:
+        return dict(n_neighbors=self.n_neighbors, metric=self.metric, include_self=self.include_self)
+
+    def set_params(self, **params):
+        for k, v in params.items():
+            if k not in ("n_neighbors", "metric", "include_self"):
+                raise ValueError(f"Invalid parameter {k!r}")
+            setattr(self, k, v)
+        return self
+
+    def fit(self, x, y=None):
+        self._fit_x = x
+        return self
+
+    def transform(self, x) -> sparse.csr_matrix:
+        if self._fit_x is None:
+            raise RuntimeError("call fit first")
+        if x is not self._fit_x and (x.shape != self._fit_x.shape or not _same(x, self._fit_x)):
+            msg = "MI355XKNNTransformer only answers queries for the fitted data (fit_transform semantics)"
+            raise NotImplementedError(msg)
+        n = x.shape[0]
+        if self.include_self:  # sklearn style: self + n_neighbors others
+            k = min(self.n_neighbors + 1, n)
+            idx, dist = knn_search(x, k)
+        else:  # RAPIDS style: n_neighbors - 1 others, no self
+            k = min(self.n_neighbors, n)
+            idx, dist = knn_search(x, k)
+            idx, dist = idx[:, 1:], dist[:, 1:]
+        kk = idx.shape[1]
+        indptr = np.arange(0, n * kk + 1, kk)
+        return sparse.csr_matrix((dist.ravel(), idx.ravel(), indptr), shape=(n, n))
+
+    def fit_transform(self, x, y=None) -> sparse.csr_matrix:
+        return self.fit(x).transform(x)
+
+
+def _same(a, b) -> bool:
+    if sparse.issparse(a) or sparse.issparse(b):
+        return (abs(sparse.csr_matrix(a) - sparse.csr_matrix(b))).nnz == 0
+    return bool(np.array_equal(np.asarray(a), np.asarray(b)))

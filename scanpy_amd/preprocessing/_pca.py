@@ -1,0 +1,160 @@
+"""`sc.pp.pca` on MI355X: same signature, defaults, errors and AnnData write-back as the reference
+(src/scanpy/preprocessing/_pca/__init__.py:53-384); the arithmetic runs in `_pca_solver.pca_fit`."""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+from scipy import sparse
+
+from .._anndata import AnnData, is_anndata
+from .._settings import settings
+from .._utils import _UNSET, as_csr_f32, resolve_seed
+
+_DEFAULT_MASK = object()  # Default("adata.var.get('highly_variable')"), _pca/__init__.py:65-67
+
+
+def _check_mask(adata, mask, dim: str):
+    """src/scanpy/get/get.py:607-665 (the slice the path uses)."""
+    if mask is None:
+        return None
+    if isinstance(mask, str):
+        annot = adata.var if dim == "var" else adata.obs
+        if mask not in annot.columns:
+            msg = f"Did not find `adata.{dim}[{mask!r}]`. Either add the mask first to `adata.{dim}`or consider using the mask argument with an array."
+            raise ValueError(msg)
+        mask = annot[mask].to_numpy()
+    else:
+        mask = np.asarray(mask)
+        n = adata.n_vars if dim == "var" else adata.n_obs
+        if len(mask) != n:
+            raise ValueError("The shape of the mask do not match the data.")
+    if mask.dtype != bool:
+        raise ValueError("Mask array must be boolean.")
+    return mask
+
+
+def _get_arr(adata, *, layer=None, obsm=None):
+    """src/scanpy/get/get.py:505-570 (X / layers / obsm)."""
+    if layer is not None and obsm is not None:
+        raise ValueError("Only one of `layer` or `obsm` can be specified.")
+    if layer is not None:
+        return adata.layers[layer]
+    if obsm is not None:
+        return adata.obsm[obsm]
+    return adata.X
+
+
+def pca(  # noqa: PLR0912, PLR0913, PLR0915
+    data,
+    n_comps: int | None = None,
+    *,
+    layer: str | None = None,
+    obsm: str | None = None,
+    zero_center: bool = True,
+    svd_solver: str | None = None,
+    chunked: bool = False,
+    chunk_size: int | None = None,
+    rng=None,
+    random_state=_UNSET,
+    return_info: bool = False,
+    mask_var=_DEFAULT_MASK,
+    dtype="float32",
+    key_added: str | None = None,
+    copy: bool = False,
+):
+    """Principal component analysis (drop-in for `scanpy.pp.pca`, src/scanpy/preprocessing/_pca/__init__.py:53).
+
+    Differences from the reference are confined to HOW the decomposition is computed:
+    `svd_solver` None/'arpack' -> block-Krylov solver converged to ARPACK-level accuracy,
+    'randomized' -> randomized subspace iteration, 'covariance_eigh' -> exact covariance + eigh.
+    `chunked=True` (IncrementalPCA) is not offered on the GPU path.
+    """
+    from ._pca_solver import GpuBackend, pca_fit
+
+    seed, _meta = resolve_seed(rng, random_state)
+    if chunked:
+        msg = "chunked (incremental) PCA is not implemented on the MI355X path; the whole CSR fits in HBM."
+        raise NotImplementedError(msg)
+    if return_anndata := is_anndata(data):
+        adata = data.copy() if copy else data
+    else:
+        adata = AnnData(data)
+
+    # mask handling: _pca/__init__.py:221-232
+    if mask_var is _DEFAULT_MASK:
+        mask_var = "highly_variable" if "highly_variable" in adata.var.columns else None
+    elif mask_var is not None and obsm is not None:
+        msg = "Argument `mask_var` is incompatible with `obsm`."
+        raise ValueError(msg)
+    mask_var_param, mask = mask_var, _check_mask(adata, mask_var, "var")
+
+    x = _get_arr(adata, layer=layer, obsm=obsm)
+    if mask is not None:
+        x = x[:, mask]
+    n_obs, n_vars = x.shape
+
+    if n_comps is None:  # _pca/__init__.py:234-236
+        min_dim = min(n_vars, n_obs)
+        n_comps = min_dim - 1 if min_dim <= settings.N_PCS else settings.N_PCS
+
+    is_sparse = sparse.issparse(x)
+    if svd_solver in {"auto", "randomized"} and not is_sparse:
+        pass  # reference only logs a reproducibility note here (_pca/__init__.py:207-212)
+    if svd_solver is None:
+        svd_solver = "arpack"  # _handle_sklearn_args default for PCA / TruncatedSVD (_pca/__init__.py:439-442)
+    elif svd_solver in {"auto", "full", "tsqr"}:
+        warnings.warn(f"Ignoring svd_solver={svd_solver!r} and using arpack-accuracy block Krylov on the GPU.",
+                      UserWarning, stacklevel=2)
+        svd_solver = "arpack"
+    elif svd_solver == "randomized" and is_sparse and zero_center:
+        # the reference rejects 'randomized' for sparse input with a warning and falls back to arpack
+        # (tests/test_pca.py:236-261); mirror that.
+        warnings.warn("Ignoring svd_solver='randomized' and using arpack, sparse PCA with sklearn < 1.4 only supports ['lobpcg', 'arpack'].",
+                      UserWarning, stacklevel=2)
+        svd_solver = "arpack"
+    elif svd_solver == "lobpcg":
+        warnings.warn("svd_solver='lobpcg' for sparse relies on legacy code and will not be supported in the future. "
+                      "Also the lobpcg solver has been observed to be inaccurate. Please use 'arpack' instead.",
+                      FutureWarning, stacklevel=2)
+        svd_solver = "arpack"
+    elif svd_solver not in {"arpack", "randomized", "covariance_eigh"}:
+        raise ValueError(f"svd_solver={svd_solver!r} is not supported")
+
+    backend = GpuBackend()
+    res = pca_fit(backend.upload(as_csr_f32(x)), n_comps, backend=backend, zero_center=zero_center,
+                  svd_solver=svd_solver, seed=seed)
+    x_pca = res.scores.cpu().numpy()
+    in_dtype = x.dtype if np.issubdtype(x.dtype, np.floating) else np.dtype("float64")
+    components = res.components.astype(in_dtype, copy=False)
+    variance = res.explained_variance.astype(in_dtype, copy=False)
+    variance_ratio = res.explained_variance_ratio.astype(in_dtype, copy=False)
+    if x_pca.dtype.descr != np.dtype(dtype).descr:
+        x_pca = x_pca.astype(dtype)
+
+    if return_anndata:
+        k_obsm, k_varm, k_uns = ("X_pca", "PCs", "pca") if key_added is None else (key_added,) * 3
+        adata.obsm[k_obsm] = x_pca
+        if obsm:
+            pass
+        elif mask is not None:
+            pcs = np.zeros(shape=(adata.n_vars, n_comps))
+            pcs[mask] = components.T
+            adata.varm[k_varm] = pcs
+        else:
+            adata.varm[k_varm] = components.T
+        adata.uns[k_uns] = dict(
+            params=dict(
+                zero_center=zero_center,
+                mask_var=mask_var_param,
+                **(dict(layer=layer) if layer is not None else {}),
+                **(dict(obsm=obsm) if obsm is not None else {}),
+            ),
+            variance=variance,
+            variance_ratio=variance_ratio,
+            **(dict(components=components.T) if obsm is not None else {}),
+        )
+        return adata if copy else None
+    if return_info:
+        return x_pca, components, variance_ratio, variance
+    return x_pca

@@ -1,0 +1,278 @@
+"""Truncated PCA of a row-sharded CSR matrix: block Krylov (block Lanczos) on the implicitly centred operator.
+
+Replaces `sklearn.decomposition.PCA(svd_solver='arpack').fit_transform(csr)` as called at
+src/scanpy/preprocessing/_pca/__init__.py:287-308 (sklearn/decomposition/_pca.py:704-793).  ARPACK
+applies C = (X - 1 mu^T)^T (X - 1 mu^T) to ONE vector per step (two sparse mat-vecs, hundreds of steps,
+all host-bound); here C is applied to a BLOCK of b = 64..128 vectors per pass over the matrix
+(`scamd_spmm_csr_f32` + `scamd_spmm_csr_f32_f64acc`, both HBM/L2 streaming kernels) and the Krylov space
+span{Z, CZ, C^2 Z, ...} is built on the SMALL side (g x b panels, float64, torch.linalg on the device).
+Rayleigh-Ritz on that space converges to the same eigenpairs ARPACK returns; iteration stops on the
+Ritz residual, so accuracy is a tolerance, not a fixed iteration count.
+
+`svd_solver`:
+  'arpack' (default, reference default for sparse input, _pca/__init__.py:439-442)  -> block Krylov to `tol`
+  'randomized'       -> randomized subspace iteration (n_iter power iterations, n_oversamples)
+  'covariance_eigh'  -> C assembled exactly from identity blocks, then a full eigh
+                        (the Gram route of src/scanpy/preprocessing/_pca/_dask.py:28-89, _kernels.py:14-58)
+
+Row sharding (multi-GPU): every rank holds a contiguous block of cells; the only exchanges are
+all-reduces of g x b float64 panels and g-vectors (<= 1 MB), the scores stay sharded.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+
+class NoComm:
+    """Single-process stand-in for the row-shard communicator."""
+
+    world_size = 1
+    rank = 0
+
+    def allreduce_(self, t: torch.Tensor) -> torch.Tensor:
+        return t
+
+
+class TorchDistComm:
+    """Sum all-reduce over torch.distributed (backend 'nccl' == RCCL on ROCm; 'gloo' in CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        self._dist = dist
+        self.group = group
+        self.world_size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def allreduce_(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world_size > 1:
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+class GpuBackend:
+    """The product kernel layer: device CSR handles + the C-ABI SpMM blocks."""
+
+    def __init__(self):
+        from .. import _kernels
+        from .._device import require_gpu
+
+        self.K = _kernels
+        self.device = require_gpu()
+
+    def upload(self, x_csr):
+        ip = torch.from_numpy(np.ascontiguousarray(x_csr.indptr, dtype=np.int64)).to(self.device)
+        ix = torch.from_numpy(np.ascontiguousarray(x_csr.indices, dtype=np.int32)).to(self.device)
+        dv = torch.from_numpy(np.ascontiguousarray(x_csr.data, dtype=np.float32)).to(self.device)
+        return (ip, ix, dv, x_csr.shape[0], x_csr.shape[1])
+
+    def transpose(self, a):
+        ip, ix, dv, n, g = a
+        t_ip, t_ix, t_dv = self.K.csr_transpose(ip, ix, dv, n, g)
+        return (t_ip, t_ix, t_dv, g, n)
+
+    def row_stats(self, a):
+        ip, _, dv, n, _ = a
+        return self.K.csr_row_stats(ip, dv, n)
+
+    def spmm(self, a, b, shift):
+        ip, ix, dv, n, g = a
+        return self.K.spmm(ip, ix, dv, n, g, b, shift)
+
+    def spmm_f64acc(self, a, b):
+        ip, ix, dv, n, _ = a
+        return self.K.spmm_f64acc(ip, ix, dv, n, b)
+
+    def colsum(self, y):
+        return self.K.colsum(y)
+
+
+@dataclass
+class PCAResult:
+    scores: torch.Tensor            # [n_local, k] float32 (device), this rank's rows of X_pca
+    components: np.ndarray          # [k, g] float64 (host) -- rows are unit-norm loadings
+    explained_variance: np.ndarray  # [k]
+    explained_variance_ratio: np.ndarray
+    singular_values: np.ndarray
+    mean: np.ndarray | None         # [g] float64
+    n_samples: int
+    info: dict = field(default_factory=dict)
+
+
+def _sign_flip(v: torch.Tensor) -> torch.Tensor:
+    """svd_flip(u_based_decision=False): largest-|.| loading of every component positive
+    (sklearn/utils/extmath.py:895-953 as used at sklearn/decomposition/_pca.py:751-753)."""
+    idx = v.abs().argmax(dim=0)
+    sgn = torch.sign(v[idx, torch.arange(v.shape[1], device=v.device)])
+    sgn[sgn == 0] = 1
+    return v * sgn[None, :]
+
+
+def _orth(w: torch.Tensor, ref_scale: float | None = None, rel_tol: float = 1e-10):
+    """Thin QR with rank truncation: keeps the directions whose R diagonal exceeds rel_tol * ref_scale
+    (ref_scale defaults to the largest diagonal entry)."""
+    if w.shape[1] == 0:
+        return w
+    q, r = torch.linalg.qr(w, mode="reduced")
+    d = torch.diagonal(r).abs()
+    ref = float(d.max()) if ref_scale is None else ref_scale
+    keep = d > rel_tol * max(ref, 1e-300)
+    return q[:, keep]
+
+
+def _rayleigh_ritz(kall: torch.Tensor, ckall: torch.Tensor, k: int):
+    """Generalised Rayleigh-Ritz for C on span(kall); kall need not be exactly orthonormal (it holds the
+    float32-rounded panels that were actually applied).  Returns (lambda desc [k'], V [g,k'], C V)."""
+    gm = kall.T @ kall
+    t = kall.T @ ckall
+    t = 0.5 * (t + t.T)
+    lch = torch.linalg.cholesky(gm)
+    t2 = torch.linalg.solve_triangular(lch, t, upper=False)
+    t2 = torch.linalg.solve_triangular(lch, t2.T, upper=False).T
+    t2 = 0.5 * (t2 + t2.T)
+    lam, y = torch.linalg.eigh(t2)
+    lam, y = lam.flip(0)[:k], y.flip(1)[:, :k]
+    y = torch.linalg.solve_triangular(lch.T, y, upper=True)
+    return lam, kall @ y, ckall @ y
+
+
+def pca_fit(a, n_comps: int, *, backend=None, comm=None, zero_center: bool = True, svd_solver: str = "arpack",
+            seed: int = 0, tol: float = 2e-8, max_blocks: int = 24, block_size: int | None = None,
+            n_oversamples: int = 10, n_iter: int | str = "auto") -> PCAResult:
+    """`a` = backend handle of this rank's CSR rows (from `backend.upload`)."""
+    backend = backend or GpuBackend()
+    comm = comm or NoComm()
+    n_local, g = a[3], a[4]
+    at = backend.transpose(a)
+    s, q = backend.row_stats(at)
+    dev = s.device
+    nt = torch.tensor([float(n_local)], dtype=torch.float64, device=dev)
+    comm.allreduce_(s)
+    comm.allreduce_(q)
+    comm.allreduce_(nt)
+    n = int(round(float(nt.item())))
+    if not 1 <= n_comps <= min(n, g):
+        raise ValueError(f"n_components={n_comps!r} must be between 1 and min(n_samples, n_features)={min(n, g)!r} "
+                         f"with svd_solver='{svd_solver}'")
+    if svd_solver == "arpack" and n_comps == min(n, g):
+        raise ValueError(f"n_components={n_comps!r} must be strictly less than min(n_samples, n_features)="
+                         f"{min(n, g)!r} with svd_solver='arpack'")
+    mean = s / n
+    var = torch.clamp(q / n - mean * mean, min=0.0)  # population variance per gene (mean_variance_axis)
+    mu = mean if zero_center else None
+    n_apply = 0
+
+    def apply_c(z64: torch.Tensor):
+        """C @ fl32(z) with C = Xc^T Xc (Xc = X - 1 mu^T, or X when not centring)."""
+        nonlocal n_apply
+        n_apply += 1
+        zf = z64.to(torch.float32).contiguous()
+        z_used = zf.to(torch.float64)
+        shift = (mu @ z_used).to(torch.float32) if mu is not None else None
+        y = backend.spmm(a, zf, shift)
+        w = backend.spmm_f64acc(at, y)
+        comm.allreduce_(w)
+        if mu is not None:
+            cs = backend.colsum(y)
+            comm.allreduce_(cs)
+            w = w - torch.outer(mu, cs)
+        return z_used, w
+
+    rng = np.random.default_rng(seed)
+    info = {"solver": svd_solver}
+
+    if svd_solver == "covariance_eigh":
+        cols = []
+        eye = torch.eye(g, dtype=torch.float64, device=dev)
+        for j in range(0, g, 128):
+            _, w = apply_c(eye[:, j:j + 128])
+            cols.append(w)
+        cmat = torch.cat(cols, dim=1)
+        cmat = 0.5 * (cmat + cmat.T)
+        lam, v = torch.linalg.eigh(cmat)
+        lam, v = lam.flip(0)[:n_comps], v.flip(1)[:, :n_comps]
+    elif svd_solver == "randomized":
+        b = min(g, n, n_comps + n_oversamples, 128)
+        if n_iter == "auto":
+            n_iter = 7 if n_comps < 0.1 * min(n, g) else 4
+        z = _orth(torch.from_numpy(rng.standard_normal((g, b))).to(dev))
+        for _ in range(int(n_iter)):
+            _, w = apply_c(z)
+            z = _orth(w)
+        zu, w = apply_c(z)
+        lam, v, _ = _rayleigh_ritz(zu, w, n_comps)
+    elif svd_solver in ("arpack", "auto", "lobpcg"):
+        rank_max = g  # dimension of the space the Krylov blocks live in
+        b = block_size or (64 if n_comps <= 56 else 128)
+        b = min(b, rank_max, 128)
+        z = _orth(torch.from_numpy(rng.standard_normal((g, b))).to(dev))
+        ks, cks = [], []
+        lam = v = None
+        resid = float("inf")
+        rr_dim = -1
+        for blk in range(max_blocks):
+            zu, w = apply_c(z)
+            ks.append(zu)
+            cks.append(w)
+            kall, ckall = torch.cat(ks, dim=1), torch.cat(cks, dim=1)
+            m = kall.shape[1]
+            full = m >= rank_max
+            if m >= n_comps and (blk >= 2 or full):
+                lam, v, cv = _rayleigh_ritz(kall, ckall, n_comps)
+                rr_dim = m
+                r = cv - v * lam[None, :]
+                resid = float((torch.linalg.norm(r, dim=0) / lam[0].clamp_min(1e-300)).max())
+                if resid < tol or full:
+                    break
+            if full:
+                break
+            # next block: the new directions of C K, orthogonalised (twice) against everything so far
+            wt = w
+            gram = kall.T @ kall
+            for _ in range(2):
+                wt = wt - kall @ torch.linalg.solve(gram, kall.T @ wt)
+            scale = float(torch.linalg.norm(w, dim=0).max())
+            z = _orth(wt, ref_scale=scale)[:, : rank_max - m]
+            if z.shape[1] == 0:  # invariant subspace: the Krylov space is exhausted (rank-deficient input)
+                break
+        if rr_dim != kall.shape[1]:
+            lam, v, cv = _rayleigh_ritz(kall, ckall, n_comps)
+            r = cv - v * lam[None, :]
+            resid = float((torch.linalg.norm(r, dim=0) / lam[0].clamp_min(1e-300)).max())
+        if v.shape[1] < n_comps:  # rank < n_comps: complete with null-space directions (zero variance)
+            extra = torch.from_numpy(rng.standard_normal((g, n_comps - v.shape[1]))).to(dev)
+            for _ in range(2):
+                extra = extra - v @ (v.T @ extra)
+            v = torch.cat([v, _orth(extra)], dim=1)
+            lam = torch.cat([lam, torch.zeros(n_comps - lam.shape[0], dtype=lam.dtype, device=dev)])
+        info.update(n_blocks=len(ks), block_size=b, residual=resid)
+    else:
+        raise ValueError(f"svd_solver={svd_solver!r} is not supported on the MI355X path "
+                         "(use 'arpack', 'randomized' or 'covariance_eigh')")
+
+    lam = torch.clamp(lam, min=0.0)
+    v = _sign_flip(v)
+    vf = v.to(torch.float32).contiguous()
+    shift = (mu @ vf.to(torch.float64)).to(torch.float32) if mu is not None else None
+    scores = backend.spmm(a, vf, shift)
+    info["n_operator_applications"] = n_apply
+    if zero_center:
+        ev = lam / (n - 1)
+        total_var = var.sum() * n / (n - 1)
+    else:
+        # TruncatedSVD semantics (sklearn/decomposition/_truncated_svd.py): variance of the scores
+        ev = torch.clamp(lam / n - (mean @ v) ** 2, min=0.0)
+        total_var = var.sum()
+    return PCAResult(
+        scores=scores,
+        components=v.T.contiguous().cpu().numpy(),
+        explained_variance=ev.cpu().numpy(),
+        explained_variance_ratio=(ev / total_var).cpu().numpy(),
+        singular_values=torch.sqrt(lam).cpu().numpy(),
+        mean=mean.cpu().numpy() if zero_center else None,
+        n_samples=n,
+        info=info,
+    )

@@ -1,0 +1,151 @@
+"""`sc.tl.leiden` on MI355X (src/scanpy/tools/_leiden.py:55-228): same signature, flavor validation,
+`restrict_to` semantics and write-back; the optimiser is `scamd_leiden_csr_f32`."""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+import pandas as pd
+from scipy import sparse
+
+from .._anndata import is_anndata
+from .._settings import settings
+from .._utils import _UNSET, choose_graph, natsorted_str, resolve_seed
+
+_DEFAULT = object()
+
+
+def _validate_flavor(flavor, *, partition_type, directed):
+    """src/scanpy/tools/_leiden.py:231-268."""
+    if was_default := (flavor is None or flavor is _DEFAULT):
+        flavor = settings.leiden_flavor
+    if flavor == "igraph":
+        if directed:
+            msg = "Cannot use igraph’s leiden implementation with a directed graph."
+            raise ValueError(msg)
+        if partition_type is not None:
+            msg = "Do not pass in partition_type argument when using igraph."
+            raise ValueError(msg)
+    elif flavor == "leidenalg":
+        if partition_type is not None:
+            msg = "partition_type is a leidenalg class; the MI355X kernel optimises RBConfiguration modularity only."
+            raise NotImplementedError(msg)
+        if was_default:
+            msg = ("In the future, the default backend for leiden will be igraph instead of leidenalg. "
+                   "To achieve the future defaults please pass: `flavor='igraph'` and `n_iterations=2`. "
+                   "`directed` must also be `False` to work with igraph’s implementation.")
+            warnings.warn(msg, FutureWarning, stacklevel=3)
+    else:
+        msg = f"flavor must be either 'igraph' or 'leidenalg', but {flavor!r} was passed."
+        raise ValueError(msg)
+    return flavor
+
+
+def restrict_adjacency(adata, restrict_key, *, restrict_categories, adjacency):
+    """src/scanpy/tools/_utils_clustering.py:33-50."""
+    if not isinstance(restrict_categories[0], str):
+        msg = "You need to use strings to label categories, e.g. '1' instead of 1."
+        raise ValueError(msg)
+    for c in restrict_categories:
+        if c not in adata.obs[restrict_key].cat.categories:
+            msg = f"{c!r} is not a valid category for {restrict_key!r}"
+            raise ValueError(msg)
+    restrict_indices = adata.obs[restrict_key].isin(restrict_categories).to_numpy()
+    adjacency = adjacency[restrict_indices, :]
+    adjacency = adjacency[:, restrict_indices]
+    return adjacency, restrict_indices
+
+
+def rename_groups(adata, restrict_key, *, key_added, restrict_categories, restrict_indices, groups):
+    """src/scanpy/tools/_utils_clustering.py:16-30."""
+    key_added = f"{restrict_key}_R" if key_added is None else key_added
+    all_groups = adata.obs[restrict_key].astype("U")
+    prefix = f"{'-'.join(restrict_categories)},"
+    new_groups = [prefix + g for g in groups.astype("U")]
+    all_groups.iloc[restrict_indices] = new_groups
+    return all_groups
+
+
+def leiden_partition(adjacency, *, resolution=1.0, n_iterations=-1, seed=0, use_weights=True, beta=0.01):
+    """Symmetric adjacency (scipy sparse) -> (membership int32 [n], modularity)."""
+    import torch
+
+    from .. import _kernels
+    from .._device import require_gpu
+
+    dev = require_gpu()
+    adj = sparse.csr_matrix(adjacency)
+    if not adj.has_sorted_indices:
+        adj = adj.sorted_indices()
+    n = adj.shape[0]
+    indptr = torch.from_numpy(np.ascontiguousarray(adj.indptr, dtype=np.int64)).to(dev)
+    indices = torch.from_numpy(np.ascontiguousarray(adj.indices, dtype=np.int32)).to(dev)
+    w = adj.data if use_weights else np.ones_like(adj.data)
+    weights = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).to(dev)
+    memb, q, _ = _kernels.leiden(indptr, indices, weights, n, resolution=float(resolution),
+                                 n_iterations=int(n_iterations), beta=beta, seed=int(seed))
+    return memb.cpu().numpy(), q
+
+
+def leiden(  # noqa: PLR0913
+    adata,
+    resolution: float = 1,
+    *,
+    restrict_to=None,
+    rng=None,
+    random_state=_UNSET,
+    key_added: str = "leiden",
+    adjacency=None,
+    directed: bool | None = None,
+    use_weights: bool = True,
+    n_iterations: int = -1,
+    partition_type=None,
+    neighbors_key: str | None = None,
+    obsp: str | None = None,
+    copy: bool = False,
+    flavor=_DEFAULT,
+    **clustering_args,
+):
+    """Cluster cells with the Leiden algorithm (drop-in for `scanpy.tl.leiden`, src/scanpy/tools/_leiden.py:55).
+
+    Both reference flavors optimise the same objective on the symmetric connectivities
+    (RBConfiguration modularity with `resolution`) and are served by the same GPU
+    optimiser.  Writes `.obs[key_added]` (categorical of str, naturally sorted categories, ids by
+    decreasing community size) and `.uns[key_added] = {params, modularity}`."""
+    if not is_anndata(adata):
+        raise TypeError("leiden() expects an AnnData-like object")
+    flavor = _validate_flavor(flavor, partition_type=partition_type, directed=directed)
+    seed, meta_random_state = resolve_seed(rng, random_state)
+    unknown = set(clustering_args) - {"objective_function", "weights", "beta", "initial_membership", "node_weights"}
+    if unknown:
+        raise TypeError(f"leiden() got unexpected clustering arguments {sorted(unknown)}")
+    if clustering_args.get("objective_function", "modularity").lower() != "modularity":
+        raise NotImplementedError("only objective_function='modularity' is built on the MI355X path")
+    if clustering_args.get("initial_membership") is not None or clustering_args.get("node_weights") is not None:
+        raise NotImplementedError("initial_membership / node_weights are not supported on the MI355X path")
+    if resolution is None:
+        raise NotImplementedError("resolution=None (partition types without a resolution) is not supported")
+    adata = adata.copy() if copy else adata
+    if adjacency is None:
+        adjacency = choose_graph(adata, obsp, neighbors_key)
+    if restrict_to is not None:
+        restrict_key, restrict_categories = restrict_to
+        adjacency, restrict_indices = restrict_adjacency(
+            adata, restrict_key, restrict_categories=restrict_categories, adjacency=adjacency)
+    groups, modularity = leiden_partition(adjacency, resolution=resolution, n_iterations=n_iterations, seed=seed,
+                                          use_weights=use_weights, beta=clustering_args.get("beta", 0.01))
+    if restrict_to is not None:
+        if key_added == "leiden":
+            key_added += "_R"
+        groups = rename_groups(adata, key_added=key_added, restrict_key=restrict_key,
+                               restrict_categories=restrict_categories, restrict_indices=restrict_indices,
+                               groups=groups)
+    groups = np.asarray(groups)
+    adata.obs[key_added] = pd.Categorical(
+        values=groups.astype("U"),
+        categories=natsorted_str(list(map(str, np.unique(groups)))),
+    )
+    adata.uns[key_added] = {}
+    adata.uns[key_added]["params"] = dict(resolution=resolution, n_iterations=n_iterations, **meta_random_state)
+    adata.uns[key_added]["modularity"] = modularity
+    return adata if copy else None

@@ -1,0 +1,297 @@
+"""End-to-end parity of the drop-in API (sc.pp.pca -> sc.pp.neighbors -> sc.tl.leiden) on the GPU against the
+CPU oracle and the reference's golden vectors.  Mirrors tests/test_pca.py, tests/test_neighbors.py,
+tests/test_neighbors_key_added.py and tests/test_clustering.py of the reference where they touch the path."""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+import pandas as pd
+import pytest
+from scipy import sparse
+from sklearn.metrics import adjusted_rand_score
+
+from helpers import knn_sets_equal_mod_ties
+from oracle import connectivities as oc
+from oracle import knn as oknn
+from oracle import leiden as ol
+from oracle import pca as opca
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sc():
+    import scanpy_amd
+
+    return scanpy_amd
+
+
+# ---------------------------------------------------------------------------------------- pca ------
+@pytest.mark.parametrize("fmt", ["csr", "dense"])
+def test_pca_transform_golden(sc, pca_toy, fmt):
+    """tests/test_pca.py:225-233."""
+    a = pca_toy["A_list"].astype("float32")
+    adata = sc.AnnData(sparse.csr_matrix(a) if fmt == "csr" else a)
+    sc.pp.pca(adata, n_comps=4, zero_center=True, dtype="float64")
+    assert np.linalg.norm(np.abs(pca_toy["A_pca"][:, :4]) - np.abs(adata.obsm["X_pca"])) < 2e-05
+    assert adata.obsm["X_pca"].dtype == np.float64
+    assert adata.varm["PCs"].shape == (5, 4)
+    assert set(adata.uns["pca"]) == {"params", "variance", "variance_ratio"}
+    assert adata.uns["pca"]["params"] == {"zero_center": True, "mask_var": None}
+
+
+def test_pca_no_zero_center_golden(sc, pca_toy):
+    """tests/test_pca.py:264-274."""
+    adata = sc.AnnData(sparse.csr_matrix(pca_toy["A_list"].astype("float32")))
+    sc.pp.pca(adata, n_comps=4, zero_center=False, dtype="float64", random_state=14)
+    assert np.linalg.norm(np.abs(pca_toy["A_svd"][:, :4]) - np.abs(adata.obsm["X_pca"])) < 2e-05
+
+
+def test_pca_randomized_sparse_warns(sc, pca_toy):
+    """tests/test_pca.py:236-261: sparse + 'randomized' warns and still gives the exact answer."""
+    adata = sc.AnnData(sparse.csr_matrix(pca_toy["A_list"].astype("float32")))
+    with pytest.warns(UserWarning, match=r"Ignoring.*'randomized"):
+        sc.pp.pca(adata, n_comps=4, svd_solver="randomized", dtype="float64", random_state=14)
+    assert np.linalg.norm(np.abs(pca_toy["A_pca"][:, :4]) - np.abs(adata.obsm["X_pca"])) < 2e-05
+
+
+def test_pca_shapes_and_errors(sc, pca_toy):
+    """tests/test_pca.py:277-296."""
+    adata = sc.AnnData(sparse.csr_matrix(pca_toy["A_list"].astype("float32")))
+    sc.pp.pca(adata)
+    assert adata.obsm["X_pca"].shape == (6, 4)  # min_dim - 1
+    with pytest.raises(ValueError, match=r"n_components=100 must be between 1 and.*6"):
+        sc.pp.pca(adata, n_comps=100)
+    x = sc.pp.pca(pca_toy["A_list"].astype("float32"), n_comps=3)
+    assert isinstance(x, np.ndarray) and x.shape == (6, 3) and x.dtype == np.float32
+    out = sc.pp.pca(pca_toy["A_list"].astype("float32"), n_comps=3, return_info=True)
+    assert len(out) == 4 and out[1].shape == (3, 5)
+
+
+def test_pca_synthetic_vs_reference(sc):
+    """north_star gate: loadings within 1e-4 up to sign vs reference Scanpy (= sklearn arpack)."""
+    from scanpy_amd.datasets import synthetic_planted
+
+    x, _ = synthetic_planted(20000, 2000, seed=0)
+    adata = sc.AnnData(x)
+    sc.pp.pca(adata)
+    ref = opca.pca_reference(x, 50)
+    pcs = adata.varm["PCs"]
+    assert pcs.shape == (2000, 50) and adata.obsm["X_pca"].shape == (20000, 50)
+    err = np.abs(np.abs(pcs.T) - np.abs(ref["components"])).max()
+    print("max |loading| diff vs sklearn arpack:", err)
+    assert err < 1e-4
+    np.testing.assert_allclose(adata.uns["pca"]["variance"], ref["variance"], rtol=1e-4)
+    np.testing.assert_allclose(adata.uns["pca"]["variance_ratio"], ref["variance_ratio"], rtol=1e-4)
+    sgn = np.sign((pcs.T * ref["components"]).sum(1))
+    assert np.abs(adata.obsm["X_pca"] * sgn[None, :] - ref["X_pca"]).max() < 2e-3
+    assert (sgn > 0).all(), "same svd_flip sign convention as sklearn"
+
+
+def test_pca_real_counts_layer_and_mask(sc, pbmc68k):
+    """Real CSR input (bundled counts layer) + mask_var semantics (tests/test_pca.py:461-506)."""
+    counts = pbmc68k["counts"].astype(np.float32)
+    x = counts.copy()
+    x.data = np.log1p(x.data)
+    var = pd.DataFrame({"highly_variable": pbmc68k["highly_variable"]}, index=[f"g{i}" for i in range(x.shape[1])])
+    adata = sc.AnnData(x, var=var)
+    sc.pp.pca(adata, n_comps=30)
+    mask = pbmc68k["highly_variable"]
+    assert adata.uns["pca"]["params"]["mask_var"] == "highly_variable"
+    assert (adata.varm["PCs"][~mask] == 0).all() and adata.varm["PCs"].shape == (x.shape[1], 30)
+    ref = opca.pca_reference(x[:, mask], 30)
+    err = np.abs(np.abs(adata.varm["PCs"][mask].T) - np.abs(ref["components"]))
+    # trailing components of real data can be nearly degenerate: compare the well separated ones strictly
+    gaps = -np.diff(ref["variance"]) / ref["variance"][:-1]
+    ok = np.concatenate([[True], gaps[:-1] > 1e-2]) & np.concatenate([gaps > 1e-2, [False]])
+    print("components compared strictly:", ok.sum(), "max err", err[ok].max())
+    assert err[ok].max() < 1e-4
+    np.testing.assert_allclose(adata.uns["pca"]["variance"], ref["variance"], rtol=1e-4)
+    # explicit mask argument equals the subset run
+    ad2 = sc.AnnData(x)
+    sc.pp.pca(ad2, n_comps=30, mask_var=mask)
+    np.testing.assert_array_equal(ad2.obsm["X_pca"], adata.obsm["X_pca"])
+    with pytest.raises(ValueError, match="incompatible with `obsm`"):
+        sc.pp.pca(ad2, mask_var=mask, obsm="X_pca")
+
+
+def test_pca_reproducible(sc, pbmc68k):
+    """tests/test_pca.py:333-354."""
+    x = pbmc68k["counts"].astype(np.float32)
+    a = sc.pp.pca(x, n_comps=10, random_state=42)
+    b = sc.pp.pca(x, n_comps=10, random_state=42)
+    np.testing.assert_array_equal(a, b)
+
+
+def test_pca_key_added_and_copy(sc, pca_toy):
+    adata = sc.AnnData(sparse.csr_matrix(pca_toy["A_list"].astype("float32")))
+    out = sc.pp.pca(adata, n_comps=3, key_added="mypca", copy=True)
+    assert "mypca" in out.obsm and "mypca" in out.varm and "mypca" in out.uns
+    assert not adata.obsm and not adata.uns
+
+
+# ------------------------------------------------------------------------------------ neighbors ----
+def test_neighbors_toy_golden(sc, neighbors_toy):
+    """tests/test_neighbors.py:151-226 (distances_euclidean, connectivities_umap)."""
+    adata = sc.AnnData(neighbors_toy["X"].astype(np.float32))
+    sc.pp.neighbors(adata, n_neighbors=int(neighbors_toy["n_neighbors"]))
+    np.testing.assert_allclose(adata.obsp["distances"].toarray(), neighbors_toy["distances_euclidean"], rtol=1e-6)
+    np.testing.assert_allclose(adata.obsp["connectivities"].toarray(), neighbors_toy["connectivities_umap"], rtol=1e-5, atol=1e-6)
+    u = adata.uns["neighbors"]
+    assert u["connectivities_key"] == "connectivities" and u["distances_key"] == "distances"
+    assert u["params"] == {"n_neighbors": 3, "method": "umap", "random_state": 0, "metric": "euclidean"}
+
+
+def test_neighbors_fixture_vs_oracle(sc, pbmc68k):
+    x = pbmc68k["X_pca"]
+    adata = sc.AnnData(pbmc68k["X"], obsm={"X_pca": x})
+    sc.pp.neighbors(adata, n_neighbors=10)
+    oi, od, odist = oknn.knn_sklearn(x, 10)
+    d = adata.obsp["distances"]
+    assert d.nnz == 700 * 9 and (np.diff(d.indptr) == 9).all()
+    gi, gd = d.indices.reshape(700, 9), d.data.reshape(700, 9)
+    bad, _ = knn_sets_equal_mod_ties(gi, gd, oi[:, 1:], od[:, 1:])
+    assert bad == 0
+    np.testing.assert_allclose(gd, od[:, 1:], rtol=2e-6, atol=1e-5)
+    oc_ref, _, _ = oc.fuzzy_simplicial_set(oi, od, 700, 10)
+    c = adata.obsp["connectivities"]
+    assert abs(c - oc_ref).max() < 5e-6 and c.nnz == oc_ref.nnz
+
+
+def test_neighbors_key_added_use_rep_n_pcs(sc, pbmc68k):
+    """tests/test_neighbors_key_added.py:35-50 + params recording."""
+    adata = sc.AnnData(pbmc68k["X"], obsm={"X_pca": pbmc68k["X_pca"]})
+    sc.pp.neighbors(adata, n_neighbors=5, n_pcs=20, key_added="nb", random_state=3)
+    assert "nb_distances" in adata.obsp and "nb_connectivities" in adata.obsp
+    assert adata.uns["nb"]["params"] == {"n_neighbors": 5, "method": "umap", "random_state": 3, "metric": "euclidean", "n_pcs": 20}
+    oi, od, _ = oknn.knn_sklearn(pbmc68k["X_pca"][:, :20], 5)
+    gi = adata.obsp["nb_distances"].indices.reshape(700, 4)
+    bad, _ = knn_sets_equal_mod_ties(gi, adata.obsp["nb_distances"].data.reshape(700, 4), oi[:, 1:], od[:, 1:])
+    assert bad == 0
+    with pytest.raises(ValueError, match="Did not find"):
+        sc.pp.neighbors(adata, use_rep="nope")
+
+
+def test_neighbors_transformer_plugin_route(sc, pbmc68k):
+    """The estimator route of neighbors/_types.py:53-64 gives the same slots as the built-in search."""
+    x = pbmc68k["X_pca"]
+    a = sc.AnnData(pbmc68k["X"], obsm={"X_pca": x})
+    b = sc.AnnData(pbmc68k["X"], obsm={"X_pca": x})
+    sc.pp.neighbors(a, n_neighbors=12)
+    sc.pp.neighbors(b, transformer=sc.MI355XKNNTransformer(n_neighbors=12))
+    assert abs(a.obsp["distances"] - b.obsp["distances"]).max() == 0
+    assert abs(a.obsp["connectivities"] - b.obsp["connectivities"]).max() == 0
+    t = sc.MI355XKNNTransformer(n_neighbors=12, include_self=True).fit_transform(x)
+    assert t.nnz == 700 * 13 and (t.indices.reshape(700, 13)[:, 0] == np.arange(700)).all()
+
+
+def test_neighbors_precomputed_distances(sc, pbmc68k):
+    """tests/test_neighbors.py:275-296: recomputing connectivities from stored distances."""
+    adata = sc.AnnData(pbmc68k["X"], obsm={"X_pca": pbmc68k["X_pca"]})
+    sc.pp.neighbors(adata, n_neighbors=10)
+    ad2 = sc.AnnData(pbmc68k["X"])
+    sc.pp.neighbors(ad2, n_neighbors=10, distances=adata.obsp["distances"])
+    assert abs(ad2.obsp["connectivities"] - adata.obsp["connectivities"]).max() < 1e-6
+    with pytest.warns(UserWarning, match="ignored if `distances` is given"):
+        sc.pp.neighbors(ad2, n_neighbors=10, distances=adata.obsp["distances"], n_pcs=5)
+
+
+def test_neighbors_auto_pca_fallback(sc, pbmc68k):
+    """tests/test_neighbors_key_added.py:53-61: missing X_pca -> warning + pca."""
+    adata = sc.AnnData(pbmc68k["X"])
+    with pytest.warns(UserWarning, match="Falling back to preprocessing with `sc.pp.pca`"):
+        sc.pp.neighbors(adata, n_neighbors=5)
+    assert adata.obsm["X_pca"].shape == (700, 50)
+
+
+# --------------------------------------------------------------------------------------- leiden ----
+def _graph_adata(sc, pbmc68k):
+    adata = sc.AnnData(pbmc68k["X"], obsm={"X_pca": pbmc68k["X_pca"]})
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sc.pp.neighbors(adata, n_neighbors=10)
+    return adata
+
+
+def test_leiden_basic_and_params(sc, pbmc68k):
+    """tests/test_clustering.py:36-102."""
+    adata = _graph_adata(sc, pbmc68k)
+    with pytest.warns(FutureWarning, match="default backend for leiden will be igraph"):
+        sc.tl.leiden(adata)
+    lab = adata.obs["leiden"]
+    assert isinstance(lab.dtype, pd.CategoricalDtype) and list(lab.cat.categories) == [str(i) for i in range(len(lab.cat.categories))]
+    assert adata.uns["leiden"]["params"] == {"resolution": 1, "n_iterations": -1, "random_state": 0}
+    q = adata.uns["leiden"]["modularity"]
+    codes = lab.cat.codes.to_numpy()
+    assert abs(q - ol.modularity(adata.obsp["connectivities"], lab.astype(int).to_numpy())) < 1e-6
+    mo, qo = ol.leiden(adata.obsp["connectivities"])
+    print("Q gpu/oracle", q, qo, "ARI", adjusted_rand_score(mo, codes))
+    assert q > qo - 0.01
+    # same seed => identical, flavor igraph accepted, rng style drops random_state from params
+    ad2 = _graph_adata(sc, pbmc68k)
+    sc.tl.leiden(ad2, flavor="igraph", n_iterations=2, random_state=0, key_added="l2")
+    sc.tl.leiden(ad2, flavor="igraph", n_iterations=2, random_state=0, key_added="l3")
+    assert (ad2.obs["l2"] == ad2.obs["l3"]).all() and ad2.uns["l2"]["modularity"] == ad2.uns["l3"]["modularity"]
+    sc.tl.leiden(ad2, flavor="igraph", rng=5, key_added="l4")
+    assert "random_state" not in ad2.uns["l4"]["params"]
+
+
+def test_leiden_errors(sc, pbmc68k):
+    """tests/test_clustering.py:105-127."""
+    adata = _graph_adata(sc, pbmc68k)
+    with pytest.raises(ValueError, match=r"flavor must be either"):
+        sc.tl.leiden(adata, flavor="foo")
+    with pytest.raises(ValueError, match=r"Cannot use igraph"):
+        sc.tl.leiden(adata, flavor="igraph", directed=True)
+    with pytest.raises(ValueError, match=r"Do not pass in partition_type"):
+        sc.tl.leiden(adata, flavor="igraph", partition_type=object)
+    with pytest.raises(ValueError, match="run `pp.neighbors` first"):
+        sc.tl.leiden(sc.AnnData(pbmc68k["X"]), flavor="igraph")
+
+
+def test_leiden_restrict_to_and_keys(sc, pbmc68k):
+    """tests/test_clustering.py:177-242."""
+    adata = _graph_adata(sc, pbmc68k)
+    adata.obs["bulk"] = pd.Categorical(pbmc68k["bulk_labels_codes"].astype(str))
+    cats = list(adata.obs["bulk"].cat.categories[:2])
+    sc.tl.leiden(adata, flavor="igraph", restrict_to=("bulk", cats), resolution=0.5)
+    assert "leiden_R" in adata.obs
+    sub = adata.obs["bulk"].isin(cats).to_numpy()
+    assert (adata.obs["leiden_R"][~sub].astype(str) == adata.obs["bulk"][~sub].astype(str)).all()
+    assert all(v.startswith("-".join(cats) + ",") for v in adata.obs["leiden_R"][sub].astype(str))
+    with pytest.raises(ValueError, match="not a valid category"):
+        sc.tl.leiden(adata, flavor="igraph", restrict_to=("bulk", ["nope"]))
+    sc.tl.leiden(adata, flavor="igraph", obsp="connectivities", key_added="viaobsp")
+    sc.tl.leiden(adata, flavor="igraph", neighbors_key="neighbors", key_added="viakey")
+    assert (adata.obs["viaobsp"] == adata.obs["viakey"]).all()
+    with pytest.raises(ValueError, match="can't specify both"):
+        sc.tl.leiden(adata, flavor="igraph", obsp="connectivities", neighbors_key="neighbors")
+
+
+# ------------------------------------------------------------------------------------- pipeline ----
+def test_full_pipeline_planted_ari(sc):
+    """north_star gates on one AnnData: PCA loadings 1e-4, kNN sets equal, Leiden ARI >= 0.99 vs the CPU chain."""
+    from scanpy_amd.datasets import synthetic_planted
+
+    x, truth = synthetic_planted(30000, 2000, seed=1)
+    adata = sc.AnnData(x)
+    sc.pp.pca(adata)
+    sc.pp.neighbors(adata)
+    sc.tl.leiden(adata, flavor="igraph")
+    gpu = adata.obs["leiden"].cat.codes.to_numpy()
+    # CPU reference chain on the same input
+    ref = opca.pca_reference(x, 50)
+    assert np.abs(np.abs(adata.varm["PCs"].T) - np.abs(ref["components"])).max() < 1e-4
+    # kNN parity is defined on the SAME embedding: feed ours to the oracle
+    oi, od, _ = oknn.knn_sklearn(adata.obsm["X_pca"], 15, n_jobs=-1)
+    d = adata.obsp["distances"]
+    bad, differ = knn_sets_equal_mod_ties(d.indices.reshape(-1, 14), d.data.reshape(-1, 14), oi[:, 1:], od[:, 1:])
+    assert bad == 0, (bad, differ)
+    # CPU chain end to end (its own PCA -> kNN -> graph -> Leiden)
+    ci, cd, _ = oknn.knn_sklearn(ref["X_pca"].astype(np.float32), 15, n_jobs=-1)
+    cg, _, _ = oc.fuzzy_simplicial_set(ci, cd, x.shape[0], 15)
+    cpu, _ = ol.leiden(cg)
+    ari = adjusted_rand_score(cpu, gpu)
+    print("ARI gpu-vs-cpu-chain", ari, "ARI vs truth", adjusted_rand_score(truth, gpu), "n clusters", gpu.max() + 1)
+    assert ari >= 0.99

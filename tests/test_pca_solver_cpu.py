@@ -1,0 +1,88 @@
+"""Host-side PCA solver logic (block Krylov / randomized / covariance_eigh) against the oracle, on CPU,
+with the kernel layer replaced by tests/stub_backend.py."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+from oracle import pca as opca
+from scanpy_amd.datasets import synthetic_planted
+from scanpy_amd.preprocessing._pca_solver import pca_fit
+from stub_backend import CpuStubBackend
+
+
+def _fit(x, k, **kw):
+    be = CpuStubBackend()
+    return pca_fit(be.upload(sparse.csr_matrix(x)), k, backend=be, **kw)
+
+
+@pytest.mark.parametrize("solver", ["arpack", "covariance_eigh"])
+def test_golden_A(pca_toy, solver):
+    """tests/test_pca.py:225-233: ||abs(A_pca[:, :4]) - abs(X_pca)|| < 2e-5."""
+    res = _fit(pca_toy["A_list"].astype(np.float32), 4, svd_solver=solver)
+    assert np.linalg.norm(np.abs(pca_toy["A_pca"][:, :4]) - np.abs(res.scores.numpy())) < 2e-5
+
+
+def test_golden_A_no_center(pca_toy):
+    """tests/test_pca.py:264-274 (TruncatedSVD path, golden A_svd)."""
+    res = _fit(pca_toy["A_list"].astype(np.float32), 4, zero_center=False)
+    assert np.linalg.norm(np.abs(pca_toy["A_svd"][:, :4]) - np.abs(res.scores.numpy())) < 2e-5
+    ref = opca.pca_reference(sparse.csr_matrix(pca_toy["A_list"].astype(np.float32)), 4, zero_center=False)
+    np.testing.assert_allclose(res.explained_variance, ref["variance"], rtol=1e-4)
+    np.testing.assert_allclose(res.explained_variance_ratio, ref["variance_ratio"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("solver", ["arpack", "covariance_eigh"])
+def test_synthetic_vs_reference(solver):
+    x, _ = synthetic_planted(4000, 600, n_types=24, seed=1)
+    res = _fit(x, 20, svd_solver=solver)
+    ref = opca.pca_reference(x, 20)
+    tru = opca.pca_dense_f64(x, 20)
+    # loadings within 1e-4 up to sign (sign rule is the same, so compare directly, then up to sign)
+    err = np.abs(np.abs(res.components) - np.abs(ref["components"])).max()
+    err_truth = np.abs(res.components - tru["components"]).max()
+    print(solver, "loadings err vs sklearn", err, "vs f64 truth", err_truth, res.info)
+    assert err < 1e-4 and err_truth < 1e-5
+    np.testing.assert_allclose(res.explained_variance, tru["variance"], rtol=1e-6)
+    np.testing.assert_allclose(res.explained_variance_ratio, tru["variance_ratio"], rtol=1e-6)
+    np.testing.assert_allclose(res.explained_variance, ref["variance"], rtol=2e-5)
+    assert np.abs(np.abs(res.scores.numpy()) - np.abs(ref["X_pca"])).max() < 5e-4
+    np.testing.assert_allclose(res.mean, ref["mean"], rtol=1e-6, atol=1e-8)
+
+
+def test_randomized_close():
+    x, _ = synthetic_planted(3000, 400, n_types=12, seed=2)
+    res = _fit(x, 10, svd_solver="randomized")
+    tru = opca.pca_dense_f64(x, 10)
+    np.testing.assert_allclose(res.explained_variance, tru["variance"], rtol=1e-3)
+
+
+def test_rank_deficient_and_wide():
+    rng = np.random.default_rng(0)
+    x = sparse.random(30, 200, density=0.2, random_state=rng, format="csr", dtype=np.float32)
+    res = _fit(x, 20)
+    tru = opca.pca_dense_f64(x, 20)
+    np.testing.assert_allclose(res.explained_variance, tru["variance"], rtol=1e-6, atol=1e-9)
+    # rank <= 29 after centring: asking for the maximum arpack allows
+    res = _fit(x, 29)
+    assert res.components.shape == (29, 200)
+    np.testing.assert_allclose(res.components @ res.components.T, np.eye(29), atol=1e-8)
+
+
+def test_errors():
+    x = sparse.random(10, 8, density=0.5, format="csr", dtype=np.float32, random_state=1)
+    with pytest.raises(ValueError, match="must be between 1 and"):
+        _fit(x, 9)
+    with pytest.raises(ValueError, match="strictly less"):
+        _fit(x, 8)
+    with pytest.raises(ValueError, match="not supported"):
+        _fit(x, 2, svd_solver="full")
+
+
+def test_reproducible_and_seed():
+    x, _ = synthetic_planted(2000, 300, n_types=10, seed=3)
+    a = _fit(x, 10, seed=0)
+    b = _fit(x, 10, seed=0)
+    np.testing.assert_array_equal(a.components, b.components)
+    np.testing.assert_array_equal(a.scores.numpy(), b.scores.numpy())
