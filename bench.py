@@ -40,7 +40,7 @@ def parse_args():
     ap.add_argument("--n-comps", type=int, default=50)
     ap.add_argument("--n-neighbors", type=int, default=15)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=40_000, help="cells in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=200_000, help="cells in the CPU-baseline sample (0 = skip)")
     return ap.parse_args()
 
 

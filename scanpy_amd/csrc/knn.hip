@@ -61,7 +61,11 @@ __global__ void knn_pack_kernel(const float* __restrict__ x, int64_t n, int d, i
 template <int H, int TC, int NW, int KP>
 struct SelectCfg {
   static constexpr int DP = 2 * H;
-  static constexpr int DPL = DP + 1;  // odd row stride -> conflict-free ds_read_b32 fragments
+  // LDS row = [dims 0..H-1 | pad | dims H..2H-1 | pad]: each half starts 16-B aligned so a lane reads its
+  // fragment with HP/4 ds_read_b128; row stride = 4 (mod 8) dwords keeps those reads bank-conflict free
+  // (16-lane groups, 64 banks: stride*l mod 64 must hit 16 distinct 4-dword slots).
+  static constexpr int HP = (H + 3) / 4 * 4;
+  static constexpr int DPL = (2 * HP) % 8 == 4 ? 2 * HP : 2 * HP + 4;
   static constexpr int QB = NW * 32;
   static constexpr int NT = NW * 64;
   static constexpr int TILE_F4 = TC * DP / 4;
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(NW * 64) void knn_select_kernel(const float* __rest
                                                              int* __restrict__ cand_idx,
                                                              float* __restrict__ cand_tau) {
   using C = SelectCfg<H, TC, NW, KP>;
-  constexpr int DP = C::DP, DPL = C::DPL, QB = C::QB, NT = C::NT;
+  constexpr int DP = C::DP, DPL = C::DPL, HP = C::HP, QB = C::QB, NT = C::NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tile = smem;                   // [2][TC][DPL]
   float* tnorm = tile + 2 * TC * DPL;   // [2][TC]
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(NW * 64) void knn_select_kernel(const float* __rest
         for (int c = 0; c < 4; ++c) {
           int ff = f + c;
           int row = ff / DP, col = ff - row * DP;
-          dst[row * DPL + col] = v[c];
+          dst[row * DPL + (col < H ? col : col - H + HP)] = v[c];
         }
       }
     }
@@ -143,37 +147,56 @@ __global__ __launch_bounds__(NW * 64) void knn_select_kernel(const float* __rest
   lstore(0);
   __syncthreads();
 
-  volatile float* vld = ld;
-  volatile int* vli = li;
-  volatile float* vlmax = lmax;
-  volatile int* vlpos = lpos;
+  // A operand (lane l: candidate (l&31) of a 32-row sub-tile, same dim slice as B) and the C-in
+  // registers (||c||^2 of the candidate each accumulator register belongs to: register r of lane l is
+  // D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]) of one sub-tile.
+  auto load_frag = [&](const float* tb, const float* nb, int sub, float (&a)[HP], f32x16& c0) {
+    const float4* ap = reinterpret_cast<const float4*>(tb + (sub * 32 + l31) * DPL + half * HP);
+#pragma unroll
+    for (int s4 = 0; s4 < HP / 4; ++s4) {
+      float4 v = ap[s4];
+      a[4 * s4 + 0] = v.x;
+      a[4 * s4 + 1] = v.y;
+      a[4 * s4 + 2] = v.z;
+      a[4 * s4 + 3] = v.w;
+    }
+#pragma unroll
+    for (int a4 = 0; a4 < 4; ++a4) {
+      float4 v = *reinterpret_cast<const float4*>(nb + sub * 32 + 8 * a4 + 4 * half);
+      c0[4 * a4 + 0] = v.x;
+      c0[4 * a4 + 1] = v.y;
+      c0[4 * a4 + 2] = v.z;
+      c0[4 * a4 + 3] = v.w;
+    }
+  };
 
+  constexpr int NSUB = TC / 32;
+  constexpr bool PF = H <= 32;
   float thr = INFINITY;
   for (int t = 0; t < n_tiles; ++t) {
     const int b = t & 1;
     if (t + 1 < n_tiles) gload(t + 1);
     const float* tb = tile + b * TC * DPL;
     const float* nb = tnorm + b * TC;
+    float a_cur[HP];
+    f32x16 c_cur;
+    if (PF) load_frag(tb, nb, 0, a_cur, c_cur);
 #pragma unroll
-    for (int sub = 0; sub < TC / 32; ++sub) {
-      // A operand: lane l holds candidate (l&31) of this 32-row sub-tile, same dim slice as B.
-      float a[H];
-      const float* ap = tb + (sub * 32 + l31) * DPL + half * H;
-#pragma unroll
-      for (int s = 0; s < H; ++s) a[s] = ap[s];
-      // C-in = ||c||^2 of the candidate each accumulator register belongs to:
-      // register r of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
-      f32x16 acc;
-#pragma unroll
-      for (int a4 = 0; a4 < 4; ++a4) {
-        float4 v = *reinterpret_cast<const float4*>(nb + sub * 32 + 8 * a4 + 4 * half);
-        acc[4 * a4 + 0] = v.x;
-        acc[4 * a4 + 1] = v.y;
-        acc[4 * a4 + 2] = v.z;
-        acc[4 * a4 + 3] = v.w;
+    for (int sub = 0; sub < NSUB; ++sub) {
+      // software pipeline (PF): the next sub-tile's fragments are in flight while this one's MFMA chain
+      // runs; without it (d > 64, register budget) the fragments are fetched right before their chain
+      float a_nxt[PF ? HP : 1];
+      f32x16 c_nxt;
+      if constexpr (PF) {
+        if (sub + 1 < NSUB) load_frag(tb, nb, sub + 1, a_nxt, c_nxt);
+      } else {
+        load_frag(tb, nb, sub, a_cur, c_cur);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 acc = c_cur;
 #pragma unroll
-      for (int s = 0; s < H; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bq[s], acc, 0, 0, 0);
+      for (int s = 0; s < H; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s], bq[s], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
 
       float m01 = fminf(fminf(acc[0], acc[1]), fminf(acc[2], acc[3]));
       float m23 = fminf(fminf(acc[4], acc[5]), fminf(acc[6], acc[7]));
@@ -181,37 +204,51 @@ __global__ __launch_bounds__(NW * 64) void knn_select_kernel(const float* __rest
       float m67 = fminf(fminf(acc[12], acc[13]), fminf(acc[14], acc[15]));
       float m = fminf(fminf(m01, m23), fminf(m45, m67));
       if (__any(m < thr)) {
-        // Rare path.  Lanes l and l+32 share a query: run the halves one after the other so the
-        // list of a query is only ever touched by one lane at a time (LDS ops of a wave retire
-        // in order; `volatile` keeps the compiler from reordering them).
+        // Rare path.  Lanes l and l+32 share a query: run the halves one after the other so the list
+        // of a query is only ever touched by one lane at a time (the LDS ops of a wave retire in
+        // order, and every access goes through the same LDS arrays so the compiler keeps their order).
         const int cbase = t * TC + sub * 32 + 4 * half;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           if (half == hh) {
+            float lthr = lmax[ql];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              float v = acc[r];
-              if (v < vlmax[ql]) {
-                int p = vlpos[ql];
-                vld[p * QB + ql] = v;
-                vli[p * QB + ql] = cbase + (r & 3) + 8 * (r >> 2);
+              const float v = acc[r];
+              if (v < lthr) {
+                const int p = lpos[ql];
+                ld[p * QB + ql] = v;
+                li[p * QB + ql] = cbase + (r & 3) + 8 * (r >> 2);
                 float mx = -INFINITY;
                 int mp = 0;
-                for (int u = 0; u < KP; ++u) {
-                  float xv = vld[u * QB + ql];
-                  if (xv > mx) {
-                    mx = xv;
-                    mp = u;
+#pragma unroll 1
+                for (int u0 = 0; u0 < KP; u0 += 32) {
+                  float vals[32];
+#pragma unroll
+                  for (int u = 0; u < 32; ++u) vals[u] = ld[(u0 + u) * QB + ql];
+#pragma unroll
+                  for (int u = 0; u < 32; ++u) {
+                    const bool gt = vals[u] > mx;
+                    mx = gt ? vals[u] : mx;
+                    mp = gt ? (u0 + u) : mp;
                   }
                 }
-                vlmax[ql] = mx;
-                vlpos[ql] = mp;
+                lmax[ql] = mx;
+                lpos[ql] = mp;
+                lthr = mx;
               }
             }
           }
           __builtin_amdgcn_wave_barrier();
         }
-        thr = vlmax[ql];
+        thr = lmax[ql];
+      }
+      if constexpr (PF) {
+        if (sub + 1 < NSUB) {
+#pragma unroll
+          for (int s = 0; s < HP; ++s) a_cur[s] = a_nxt[s];
+          c_cur = c_nxt;
+        }
       }
     }
     if (t + 1 < n_tiles) lstore(b ^ 1);

@@ -61,7 +61,7 @@ __global__ void ld_quantize_kernel(const float* __restrict__ w, int64_t nnz, lon
 
 // one wave per row: k[v] = sum of row
 __global__ void ld_strength_kernel(const int64_t* __restrict__ indptr, const long long* __restrict__ wq, int n,
-                                   long long* __restrict__ k, unsigned long long* __restrict__ total) {
+                                   long long* __restrict__ k) {
   const int lane = threadIdx.x & 63;
   const int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (v >= n) return;
@@ -69,10 +69,17 @@ __global__ void ld_strength_kernel(const int64_t* __restrict__ indptr, const lon
   for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) s += wq[e];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if (lane == 0) {
-    k[v] = s;
-    atomicAdd(total, (unsigned long long)s);
-  }
+  if (lane == 0) k[v] = s;
+}
+
+// total += sum a[0..n)  (grid-stride, one atomic per wave; integer => order independent)
+__global__ __launch_bounds__(256) void ld_sum_kernel(const long long* __restrict__ a, int n,
+                                                     unsigned long long* __restrict__ total) {
+  long long s = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s += a[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0 && s != 0) atomicAdd(total, (unsigned long long)s);
 }
 
 __global__ void ld_iota_kernel(int* __restrict__ a, int n) {
@@ -121,21 +128,27 @@ __device__ __forceinline__ Cand wave_best(Cand x) {
 }
 
 // ---- phase 1: local moving -------------------------------------------------------------------------
-// counters: [0] moved, [1] blocked (wanted to move, direction not allowed this round)
+// append u to the next round's active list once (flag = 0/1 per vertex, cleared every round)
+__device__ __forceinline__ void push_active(int u, int* __restrict__ flag, int* __restrict__ list,
+                                            int* __restrict__ count) {
+  if (atomicExch(&flag[u], 1) == 0) list[atomicAdd(count, 1)] = u;
+}
+
+// One wave per ACTIVE vertex (list[0..n_act)).  Reads the snapshot (comm, Ktot, csize), writes the next
+// state (comm_next, Ktot_next, csize_next: copies of the snapshot updated with integer atomics).
+// counters: [0] moved, [1] blocked (wanted to move, direction not allowed this round), [2] next list length
 __global__ __launch_bounds__(256) void ld_move_kernel(
-    int n, const int64_t* __restrict__ indptr, const int* __restrict__ indices, const long long* __restrict__ wq,
-    const long long* __restrict__ k, const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot,
-    const int* __restrict__ csize, const unsigned char* __restrict__ active, double g /* gamma / 2m */,
-    int round, unsigned int seed, int* __restrict__ comm_next, unsigned char* __restrict__ active_next,
+    int n_act, const int* __restrict__ list, const int64_t* __restrict__ indptr, const int* __restrict__ indices,
+    const long long* __restrict__ wq, const long long* __restrict__ k, const int* __restrict__ comm,
+    const unsigned long long* __restrict__ Ktot, const int* __restrict__ csize, double g /* gamma / 2m */,
+    int round, unsigned int seed, int* __restrict__ comm_next, unsigned long long* __restrict__ Ktot_next,
+    int* __restrict__ csize_next, int* __restrict__ flag_next, int* __restrict__ list_next,
     int* __restrict__ counters) {
   const int lane = threadIdx.x & 63;
-  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (v >= n) return;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n_act) return;
+  const int v = list[w];
   const int a = comm[v];
-  if (!active[v]) {
-    if (lane == 0) comm_next[v] = a;
-    return;
-  }
   const double kv = (double)k[v];
   const int64_t beg = indptr[v];
   const int deg = (int)(indptr[v + 1] - beg);
@@ -198,13 +211,21 @@ __global__ __launch_bounds__(256) void ld_move_kernel(
   }
   const bool moves = wants && allowed;
   if (lane == 0) {
-    comm_next[v] = moves ? target : a;
-    if (moves) atomicAdd(&counters[0], 1);
-    else if (wants) atomicAdd(&counters[1], 1);
-    if (wants) active_next[v] = 1;
+    if (moves) {
+      comm_next[v] = target;
+      const unsigned long long kq = (unsigned long long)k[v];
+      atomicAdd(&Ktot_next[target], kq);
+      atomicAdd(&Ktot_next[a], 0ull - kq);
+      atomicAdd(&csize_next[target], 1);
+      atomicSub(&csize_next[a], 1);
+      atomicAdd(&counters[0], 1);
+    } else if (wants) {
+      atomicAdd(&counters[1], 1);
+    }
+    if (wants) push_active(v, flag_next, list_next, &counters[2]);
   }
   if (moves) {
-    for (int e = lane; e < deg; e += 64) active_next[indices[beg + e]] = 1;
+    for (int e = lane; e < deg; e += 64) push_active(indices[beg + e], flag_next, list_next, &counters[2]);
   }
 }
 
@@ -228,14 +249,43 @@ __global__ __launch_bounds__(256) void ld_within_kernel(int n, const int64_t* __
   if (lane == 0) a_in[v] = s;
 }
 
-// Eref[r] += w(v, C - r) for every v in refined community r   (Eref zeroed by the caller)
-__global__ __launch_bounds__(256) void ld_cut_kernel(int n, const int64_t* __restrict__ indptr,
+// candidates of the refinement: vertices that are well connected inside their community
+// (w(v, C - v) >= gamma k_v (K_C - k_v) / 2m); all of them start as singletons.  counters[2] = list length
+__global__ void ld_refine_candidates_kernel(int n, const long long* __restrict__ k, const int* __restrict__ comm,
+                                            const unsigned long long* __restrict__ Ktot,
+                                            const long long* __restrict__ a_in, double g, int* __restrict__ list,
+                                            int* __restrict__ counters) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  const double kv = (double)k[v];
+  const double KC = (double)(long long)Ktot[comm[v]];
+  if ((double)a_in[v] >= g * kv * (KC - kv)) list[atomicAdd(&counters[2], 1)] = v;
+}
+
+// vertices whose refined community received members this round (their w(r, C - r) must be recomputed);
+// the founder (ref[v] == v) zeroes the accumulator.  counters[3] = list length
+__global__ void ld_touched_members_kernel(int n, const int* __restrict__ ref, const int* __restrict__ touched,
+                                          unsigned long long* __restrict__ Eref, int* __restrict__ rlist,
+                                          int* __restrict__ counters) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  const int r = ref[v];
+  if (touched[r]) {
+    if (r == v) Eref[v] = 0;
+    rlist[atomicAdd(&counters[3], 1)] = v;
+  }
+}
+
+// Eref[r] += w(v, C - r) for the listed members v of refined community r
+__global__ __launch_bounds__(256) void ld_cut_kernel(int n_list, const int* __restrict__ rlist,
+                                                     const int64_t* __restrict__ indptr,
                                                      const int* __restrict__ indices, const long long* __restrict__ wq,
                                                      const int* __restrict__ comm, const int* __restrict__ ref,
                                                      unsigned long long* __restrict__ Eref) {
   const int lane = threadIdx.x & 63;
-  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (v >= n) return;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n_list) return;
+  const int v = rlist[w];
   const int a = comm[v], r = ref[v];
   long long s = 0;
   for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) {
@@ -251,23 +301,25 @@ __device__ __forceinline__ bool mover_bit(int v, int round, unsigned int seed) {
   return (hash32((unsigned int)v * 0x9E3779B1u + (unsigned int)round * 0x85EBCA77u + seed) >> 7) & 1u;
 }
 
+// One wave per candidate.  target[v] = refined community to join, -1 = none this round (stay a
+// candidate), -2 = no longer a singleton (somebody joined it): drop from the candidate list.
 __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
-    int n, const int64_t* __restrict__ indptr, const int* __restrict__ indices, const long long* __restrict__ wq,
-    const long long* __restrict__ k, const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot,
-    const int* __restrict__ ref, const int* __restrict__ refsize, const unsigned long long* __restrict__ Kref,
-    const unsigned long long* __restrict__ Eref, const long long* __restrict__ a_in, double g, int round,
+    int n_cand, const int* __restrict__ list, const int64_t* __restrict__ indptr, const int* __restrict__ indices,
+    const long long* __restrict__ wq, const long long* __restrict__ k, const int* __restrict__ comm,
+    const unsigned long long* __restrict__ Ktot, const int* __restrict__ ref, const int* __restrict__ refsize,
+    const unsigned long long* __restrict__ Kref, const unsigned long long* __restrict__ Eref, double g, int round,
     unsigned int seed, int* __restrict__ target) {
   const int lane = threadIdx.x & 63;
-  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (v >= n) return;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n_cand) return;
+  const int v = list[w];
   int tgt = -1;
-  const int rv = ref[v];
-  const double kv = (double)k[v];
-  const int a = comm[v];
-  const double KC = (double)(long long)Ktot[a];
-  bool eligible = (refsize[rv] == 1) && mover_bit(v, round, seed) &&
-                  ((double)a_in[v] >= g * kv * (KC - kv));  // v well connected inside C
-  if (eligible) {
+  if (refsize[v] != 1 || ref[v] != v) {
+    tgt = -2;
+  } else if (mover_bit(v, round, seed)) {
+    const double kv = (double)k[v];
+    const int a = comm[v];
+    const double KC = (double)(long long)Ktot[a];
     const int64_t beg = indptr[v];
     const int deg = (int)(indptr[v + 1] - beg);
     Cand best;
@@ -297,7 +349,7 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
           if (ct == c) sum += wt;
         }
       }
-      if (c >= 0 && c != rv) {
+      if (c >= 0 && c != v) {
         const double Kr = (double)(long long)Kref[c];
         const bool single = refsize[c] == 1;
         const bool ok_target = (!single || !mover_bit(c, round, seed)) &&
@@ -318,29 +370,39 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
   if (lane == 0) target[v] = tgt;
 }
 
-__global__ void ld_refine_apply_kernel(int n, const int* __restrict__ target, const long long* __restrict__ k,
-                                       int* __restrict__ ref, int* __restrict__ refsize,
-                                       unsigned long long* __restrict__ Kref, int* __restrict__ counters) {
-  int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= n) return;
+// counters: [0] merges, [2] next candidate list length
+__global__ void ld_refine_apply_kernel(int n_cand, const int* __restrict__ list, const int* __restrict__ target,
+                                       const long long* __restrict__ k, int* __restrict__ ref,
+                                       int* __restrict__ refsize, unsigned long long* __restrict__ Kref,
+                                       int* __restrict__ touched, int* __restrict__ list_next,
+                                       int* __restrict__ counters) {
+  int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_cand) return;
+  const int v = list[w];
   const int t = target[v];
-  if (t < 0) return;
-  // v is a singleton (ref[v] == v) joining t; t's members do not move this round
-  ref[v] = t;
-  atomicAdd(&refsize[t], 1);
-  atomicAdd(&Kref[t], (unsigned long long)k[v]);
-  refsize[v] = 0;
-  Kref[v] = 0;
-  atomicAdd(&counters[0], 1);
+  if (t >= 0) {
+    // v is a singleton (ref[v] == v) joining t; t's members do not move this round
+    ref[v] = t;
+    atomicAdd(&refsize[t], 1);
+    atomicAdd(&Kref[t], (unsigned long long)k[v]);
+    refsize[v] = 0;
+    Kref[v] = 0;
+    touched[t] = 1;
+    atomicAdd(&counters[0], 1);
+  } else if (t == -1) {
+    list_next[atomicAdd(&counters[2], 1)] = v;
+  }
 }
 
-__global__ void ld_refine_init_kernel(int n, const long long* __restrict__ k, int* __restrict__ ref,
-                                      int* __restrict__ refsize, unsigned long long* __restrict__ Kref) {
+__global__ void ld_refine_init_kernel(int n, const long long* __restrict__ k, const long long* __restrict__ a_in,
+                                      int* __restrict__ ref, int* __restrict__ refsize,
+                                      unsigned long long* __restrict__ Kref, unsigned long long* __restrict__ Eref) {
   int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v < n) {
     ref[v] = v;
     refsize[v] = 1;
     Kref[v] = (unsigned long long)k[v];
+    Eref[v] = (unsigned long long)a_in[v];  // singleton: w(v, C - v)
   }
 }
 
@@ -459,9 +521,8 @@ __global__ __launch_bounds__(256) void ld_internal_kernel(int n, const int64_t* 
                                                           const long long* __restrict__ wq, const int* __restrict__ comm,
                                                           unsigned long long* __restrict__ internal) {
   const int lane = threadIdx.x & 63;
-  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
   long long s = 0;
-  if (v < n) {
+  for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < n; v += gridDim.x * 4) {
     const int a = comm[v];
     for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64)
       if (comm[indices[e]] == a) s += wq[e];
@@ -549,8 +610,8 @@ struct CoarseBuf {
 struct LeidenBuffers {
   long long* wq0; long long* k0;
   CoarseBuf cb[2];
-  int* comm; int* comm_next; int* csize; unsigned long long* Ktot;
-  unsigned char* active; unsigned char* active_next;
+  int* comm; int* comm_next; int* csize; int* csize_next; unsigned long long* Ktot; unsigned long long* Ktot_next;
+  int* list_a; int* list_b; int* rlist; int* touched;
   int* ref; int* target; int* refsize; unsigned long long* Kref; unsigned long long* Eref; long long* a_in;
   int* flag; int64_t* newid; int64_t* scan_tmp; int* cid; int* rep; int* comm_tmp;
   int* node_of; int* memb; int* memb_best;
@@ -579,9 +640,13 @@ static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b
   b->comm = ws.take<int>(N);
   b->comm_next = ws.take<int>(N);
   b->csize = ws.take<int>(N);
+  b->csize_next = ws.take<int>(N);
   b->Ktot = ws.take<unsigned long long>(N);
-  b->active = ws.take<unsigned char>(N);
-  b->active_next = ws.take<unsigned char>(N);
+  b->Ktot_next = ws.take<unsigned long long>(N);
+  b->list_a = ws.take<int>(N);
+  b->list_b = ws.take<int>(N);
+  b->rlist = ws.take<int>(N);
+  b->touched = ws.take<int>(N);
   b->ref = ws.take<int>(N);
   b->target = ws.take<int>(N);
   b->refsize = ws.take<int>(N);
@@ -641,7 +706,8 @@ static int compute_totals(LeidenCtx& cx, const LevelGraph& g, const int* comm) {
 // modularity of `comm` on level graph g (needs Ktot up to date)
 static int quality(LeidenCtx& cx, const LevelGraph& g, const int* comm, double* q) {
   SCAMD_HIP_CHECK(hipMemsetAsync(cx.b.total + 1, 0, sizeof(unsigned long long), cx.s));
-  hipLaunchKernelGGL(ld_internal_kernel, GRIDW(g.n), 0, cx.s, g.n, g.indptr, g.indices, g.wq, comm, cx.b.total + 1);
+  hipLaunchKernelGGL(ld_internal_kernel, dim3((unsigned)std::min(2048, ceil_div(g.n, 4))), dim3(256), 0, cx.s, g.n, g.indptr, g.indices, g.wq,
+                     comm, cx.b.total + 1);
   SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(ld_sumsq_kernel, dim3(1), dim3(1024), 0, cx.s, g.n, cx.b.Ktot, cx.m2, cx.b.dscratch);
   SCAMD_LAUNCH_CHECK();
@@ -656,58 +722,89 @@ static int quality(LeidenCtx& cx, const LevelGraph& g, const int* comm, double* 
 
 static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
   LeidenBuffers& b = cx.b;
-  hipLaunchKernelGGL(ld_fill_u8_kernel, GRID1(g.n), 0, cx.s, b.active, g.n, (unsigned char)1);
-  SCAMD_LAUNCH_CHECK();
   const double gg = cx.gamma / cx.m2;
   *total_moves = 0;
+  int rc = compute_totals(cx, g, b.comm);
+  if (rc != SCAMD_OK) return rc;
+  hipLaunchKernelGGL(ld_iota_kernel, GRID1(g.n), 0, cx.s, b.list_a, g.n);
+  SCAMD_LAUNCH_CHECK();
+  int n_act = g.n;
   int quiet = 0;
-  for (int round = 0; round < MAX_LM_ROUNDS; ++round) {
-    int rc = compute_totals(cx, g, b.comm);
-    if (rc != SCAMD_OK) return rc;
+  const size_t n = (size_t)g.n;
+  for (int round = 0; round < MAX_LM_ROUNDS && n_act > 0; ++round) {
+    SCAMD_HIP_CHECK(hipMemcpyAsync(b.comm_next, b.comm, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+    SCAMD_HIP_CHECK(hipMemcpyAsync(b.Ktot_next, b.Ktot, sizeof(unsigned long long) * n, hipMemcpyDeviceToDevice, cx.s));
+    SCAMD_HIP_CHECK(hipMemcpyAsync(b.csize_next, b.csize, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+    SCAMD_HIP_CHECK(hipMemsetAsync(b.flag, 0, sizeof(int) * n, cx.s));
     SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
-    SCAMD_HIP_CHECK(hipMemsetAsync(b.active_next, 0, g.n, cx.s));
-    hipLaunchKernelGGL(ld_move_kernel, GRIDW(g.n), 0, cx.s, g.n, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
-                       b.csize, b.active, gg, round, cx.seed, b.comm_next, b.active_next, b.counters);
+    hipLaunchKernelGGL(ld_move_kernel, GRIDW(n_act), 0, cx.s, n_act, b.list_a, g.indptr, g.indices, g.wq, g.k, b.comm,
+                       b.Ktot, b.csize, gg, round, cx.seed, b.comm_next, b.Ktot_next, b.csize_next, b.flag, b.list_b,
+                       b.counters);
     SCAMD_LAUNCH_CHECK();
-    int h[2];
-    rc = read_counters(cx, h, 2);
+    int h[3];
+    rc = read_counters(cx, h, 3);
     if (rc != SCAMD_OK) return rc;
     std::swap(b.comm, b.comm_next);
-    std::swap(b.active, b.active_next);
+    std::swap(b.Ktot, b.Ktot_next);
+    std::swap(b.csize, b.csize_next);
+    std::swap(b.list_a, b.list_b);
+    n_act = h[2];
     *total_moves += h[0];
-    if (h[0] == 0 && h[1] == 0) break;
     // moves blocked by the direction rule get their chance in the next (opposite) round
     quiet = (h[0] == 0) ? quiet + 1 : 0;
     if (quiet >= 2) break;
   }
-  return compute_totals(cx, g, b.comm);
+  return SCAMD_OK;
 }
 
 static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
   LeidenBuffers& b = cx.b;
   const double gg = cx.gamma / cx.m2;
-  hipLaunchKernelGGL(ld_refine_init_kernel, GRID1(g.n), 0, cx.s, g.n, g.k, b.ref, b.refsize, b.Kref);
-  SCAMD_LAUNCH_CHECK();
+  const size_t n = (size_t)g.n;
   hipLaunchKernelGGL(ld_within_kernel, GRIDW(g.n), 0, cx.s, g.n, g.indptr, g.indices, g.wq, b.comm, b.a_in);
   SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ld_refine_init_kernel, GRID1(g.n), 0, cx.s, g.n, g.k, b.a_in, b.ref, b.refsize, b.Kref, b.Eref);
+  SCAMD_LAUNCH_CHECK();
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.touched, 0, sizeof(int) * n, cx.s));
+  hipLaunchKernelGGL(ld_refine_candidates_kernel, GRID1(g.n), 0, cx.s, g.n, g.k, b.comm, b.Ktot, b.a_in, gg, b.list_a,
+                     b.counters);
+  SCAMD_LAUNCH_CHECK();
+  int h[4];
+  int rc = read_counters(cx, h, 4);
+  if (rc != SCAMD_OK) return rc;
+  int n_cand = h[2];
   *n_merged = 0;
   int quiet = 0;
-  for (int round = 0; round < MAX_RF_ROUNDS; ++round) {
-    SCAMD_HIP_CHECK(hipMemsetAsync(b.Eref, 0, sizeof(unsigned long long) * g.n, cx.s));
-    hipLaunchKernelGGL(ld_cut_kernel, GRIDW(g.n), 0, cx.s, g.n, g.indptr, g.indices, g.wq, b.comm, b.ref, b.Eref);
-    SCAMD_LAUNCH_CHECK();
+  for (int round = 0; round < MAX_RF_ROUNDS && n_cand > 0; ++round) {
     SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
-    hipLaunchKernelGGL(ld_refine_propose_kernel, GRIDW(g.n), 0, cx.s, g.n, g.indptr, g.indices, g.wq, g.k, b.comm,
-                       b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, b.a_in, gg, round, cx.seed, b.target);
+    hipLaunchKernelGGL(ld_refine_propose_kernel, GRIDW(n_cand), 0, cx.s, n_cand, b.list_a, g.indptr, g.indices, g.wq,
+                       g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, gg, round, cx.seed, b.target);
     SCAMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ld_refine_apply_kernel, GRID1(g.n), 0, cx.s, g.n, b.target, g.k, b.ref, b.refsize, b.Kref,
-                       b.counters);
+    hipLaunchKernelGGL(ld_refine_apply_kernel, GRID1(n_cand), 0, cx.s, n_cand, b.list_a, b.target, g.k, b.ref,
+                       b.refsize, b.Kref, b.touched, b.list_b, b.counters);
     SCAMD_LAUNCH_CHECK();
-    int h[1];
-    int rc = read_counters(cx, h, 1);
+    rc = read_counters(cx, h, 4);
     if (rc != SCAMD_OK) return rc;
-    *n_merged += h[0];
-    quiet = (h[0] == 0) ? quiet + 1 : 0;
+    const int merges = h[0];
+    std::swap(b.list_a, b.list_b);
+    n_cand = h[2];
+    *n_merged += merges;
+    if (merges > 0) {
+      // recompute w(r, C - r) of the communities that grew
+      hipLaunchKernelGGL(ld_touched_members_kernel, GRID1(g.n), 0, cx.s, g.n, b.ref, b.touched, b.Eref, b.rlist,
+                         b.counters);
+      SCAMD_LAUNCH_CHECK();
+      rc = read_counters(cx, h, 4);
+      if (rc != SCAMD_OK) return rc;
+      if (h[3] > 0) {
+        hipLaunchKernelGGL(ld_cut_kernel, GRIDW(h[3]), 0, cx.s, h[3], b.rlist, g.indptr, g.indices, g.wq, b.comm,
+                           b.ref, b.Eref);
+        SCAMD_LAUNCH_CHECK();
+      }
+      SCAMD_HIP_CHECK(hipMemsetAsync(b.touched, 0, sizeof(int) * n, cx.s));
+    }
+    quiet = (merges == 0) ? quiet + 1 : 0;
     if (quiet >= RF_QUIET_ROUNDS) break;
   }
   return SCAMD_OK;
@@ -756,8 +853,7 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   SCAMD_LAUNCH_CHECK();
   int64_t nnz_new = 0;
   SCAMD_HIP_CHECK(hipMemcpyAsync(&nnz_new, cb.indptr + nn, sizeof(int64_t), hipMemcpyDeviceToHost, cx.s));
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.total + 2, 0, sizeof(unsigned long long), cx.s));
-  hipLaunchKernelGGL(ld_strength_kernel, GRIDW(nn), 0, cx.s, cb.indptr, cb.wq, (int)nn, cb.k, b.total + 2);
+  hipLaunchKernelGGL(ld_strength_kernel, GRIDW(nn), 0, cx.s, cb.indptr, cb.wq, (int)nn, cb.k);
   SCAMD_LAUNCH_CHECK();
   SCAMD_HIP_CHECK(hipMemcpyAsync(b.comm, b.comm_tmp, sizeof(int) * nn, hipMemcpyDeviceToDevice, cx.s));
   SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
@@ -834,7 +930,9 @@ static int setup_level0(LeidenCtx& cx, const int64_t* indptr, const int32_t* ind
     SCAMD_LAUNCH_CHECK();
   }
   SCAMD_HIP_CHECK(hipMemsetAsync(b.total, 0, sizeof(unsigned long long) * 4, cx.s));
-  hipLaunchKernelGGL(ld_strength_kernel, GRIDW(n), 0, cx.s, indptr, b.wq0, (int)n, b.k0, b.total);
+  hipLaunchKernelGGL(ld_strength_kernel, GRIDW(n), 0, cx.s, indptr, b.wq0, (int)n, b.k0);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ld_sum_kernel, dim3(256), dim3(256), 0, cx.s, b.k0, (int)n, b.total);
   SCAMD_LAUNCH_CHECK();
   unsigned long long tot = 0;
   SCAMD_HIP_CHECK(hipMemcpyAsync(&tot, b.total, sizeof(tot), hipMemcpyDeviceToHost, cx.s));

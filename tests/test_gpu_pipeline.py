@@ -58,10 +58,14 @@ def test_pca_randomized_sparse_warns(sc, pca_toy):
 
 def test_pca_shapes_and_errors(sc, pca_toy):
     """tests/test_pca.py:277-296."""
-    adata = sc.AnnData(sparse.csr_matrix(pca_toy["A_list"].astype("float32")))
+    rng = np.random.default_rng(0)
+    adata = sc.AnnData(rng.standard_normal((30, 20)).astype(np.float32))
     sc.pp.pca(adata)
-    assert adata.obsm["X_pca"].shape == (6, 4)  # min_dim - 1
-    with pytest.raises(ValueError, match=r"n_components=100 must be between 1 and.*6"):
+    assert adata.obsm["X_pca"].shape == (30, 19)  # min_dim - 1
+    adata = sc.AnnData(rng.standard_normal((20, 30)).astype(np.float32))
+    sc.pp.pca(adata)
+    assert adata.obsm["X_pca"].shape == (20, 19)
+    with pytest.raises(ValueError, match=r"n_components=100 must be between 1 and.*20 with svd_solver='arpack'"):
         sc.pp.pca(adata, n_comps=100)
     x = sc.pp.pca(pca_toy["A_list"].astype("float32"), n_comps=3)
     assert isinstance(x, np.ndarray) and x.shape == (6, 3) and x.dtype == np.float32
@@ -104,7 +108,9 @@ def test_pca_real_counts_layer_and_mask(sc, pbmc68k):
     err = np.abs(np.abs(adata.varm["PCs"][mask].T) - np.abs(ref["components"]))
     # trailing components of real data can be nearly degenerate: compare the well separated ones strictly
     gaps = -np.diff(ref["variance"]) / ref["variance"][:-1]
-    ok = np.concatenate([[True], gaps[:-1] > 1e-2]) & np.concatenate([gaps > 1e-2, [False]])
+    sep = gaps > 1e-2  # sep[i]: component i is separated from component i+1
+    ok = np.concatenate([[True], sep[:-1]]) & sep  # both neighbours separated (components 0..28)
+    err = err[:-1]
     print("components compared strictly:", ok.sum(), "max err", err[ok].max())
     assert err[ok].max() < 1e-4
     np.testing.assert_allclose(adata.uns["pca"]["variance"], ref["variance"], rtol=1e-4)
