@@ -177,7 +177,7 @@ def main() -> None:
                 "parallelism": f"cells row-sharded x{world}; leiden on rank 0",
             },
             "roofline": {
-                "kernel": "knn_select_kernel<25,128,8,32> (v_mfma_f32_32x32x2_f32)",
+                "kernel": "knn_select_reg_kernel<25> (v_mfma_f32_32x32x2_f32)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": peak,

@@ -21,10 +21,14 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+
+static thread_local float g_last_select_ms = -1.f;
 
 namespace scamd {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int FALLBACK_CAP = 2048;    // collected rows per uncertified query
 constexpr int FALLBACK_CHUNK = 1024;  // uncertified queries processed per launch
@@ -263,6 +267,268 @@ __global__ __launch_bounds__(NW * 64) void knn_select_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// pass 1, register-list variant (k <= 24 -> KP = 32, d <= 64): the default path.
+//
+// Roles are transposed w.r.t. knn_select_kernel: the wave's 32 QUERIES are the A operand (rows of D),
+// the 32 candidates of a sub-tile are the B operand (columns of D).  Accumulator register r of lane l is
+// score(query i(r, l>>5), candidate l&31) with i(r, h) = (r&3) + 8*(r>>2) + 4*h, so
+//   * the KP = 32 best (score, row id) pairs of query i(r, h) live in registers key[r] / idx[r] of the 32
+//     lanes of half h, sorted ascending along the lane index -- no LDS list, no per-lane serial scan;
+//   * the filter is 16 v_cmp (acc[r] < thr[r], thr[r] = key[r] of the half's last lane) or-ed on the scalar
+//     unit, issued in the shadow of the NEXT sub-tile's MFMA chain (two accumulator sets alternate);
+//   * a survivor is inserted with one lane-shift (ds_bpermute) + select per register, both halves at once.
+// Candidates are streamed as a verbatim image of the LDS tile (row = [dims 0..H-1, ||c||^2, 0.. | dims
+// H..2H-1, ||c||^2, 0.. | pad], stride DPL dwords = 4 mod 8 so the b128 fragment reads are conflict free)
+// by LDS-DMA (global_load_lds_dwordx4), double buffered, one barrier per 128-candidate tile.  LDS holds only
+// the two tiles (60 KB), registers stay below 256, so two 4-wave blocks share a CU and cover each other's
+// barrier and insertion stalls.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float readlane_f32(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+template <int H>
+struct RegCfg {
+  static constexpr int HP = (H + 1 + 3) / 4 * 4;  // dims of one half + the norm slot, rounded up to 4
+  static constexpr int DPL = (2 * HP) % 8 == 4 ? 2 * HP : 2 * HP + 4;
+  static constexpr int TC = 128, NW = 4, QB = 128, NT = 256, KP = 32;
+  static constexpr int TILE_BYTES = TC * DPL * 4;
+  static constexpr int TILE_KB = TILE_BYTES / 1024;
+  static constexpr size_t LDS_BYTES = 2 * (size_t)TILE_BYTES;
+  static_assert(TILE_BYTES % 1024 == 0, "tile must be a whole number of 1 KiB LDS-DMA pieces");
+};
+
+// packed image of x for the register-list kernel: [n_pad][DPL] float32 (layout above); rows >= n get
+// ||c||^2 = +inf so that they can never be selected.
+__global__ void knn_pack_image_kernel(const float* __restrict__ x, int64_t n, int d, int64_t ld, int H, int HP,
+                                      int DPL, int64_t n_pad, float* __restrict__ xp,
+                                      unsigned int* __restrict__ cmax_bits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  float wmax = 0.f;
+  for (int64_t r = wave; r < n_pad; r += nwaves) {
+    double s = 0.0;
+    for (int c = lane; c < d; c += 64) {
+      double v = (r < n) ? (double)x[r * ld + c] : 0.0;
+      s += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float nf = (r < n) ? (float)s : INFINITY;
+    for (int c = lane; c < DPL; c += 64) {
+      const int hh = c / HP, cc = c - hh * HP;  // hh == 2: trailing pad
+      float v = 0.f;
+      if (hh < 2) {
+        const int dim = hh * H + cc;
+        if (cc < H) v = (r < n && dim < d) ? x[r * ld + dim] : 0.f;
+        else if (cc == H) v = nf;
+      }
+      xp[r * DPL + c] = v;
+    }
+    if (r < n) wmax = fmaxf(wmax, nf);
+  }
+  if (lane == 0 && wmax > 0.f) atomicMax(cmax_bits, __float_as_uint(wmax));
+}
+
+// MODE bit 0: 1 = stage tiles through registers (global_load_dwordx4 -> ds_write_b128) instead of LDS-DMA
+//      bit 1: 1 = never insert (timing experiments only: results are garbage)
+template <int H, int MODE>
+__global__ __launch_bounds__(256, 2) void knn_select_reg_kernel(const float* __restrict__ xp, int n_tiles,
+                                                                int64_t n_pad, int64_t q_begin,
+                                                                int thr_rank, int* __restrict__ cand_idx,
+                                                                float* __restrict__ cand_tau) {
+  using C = RegCfg<H>;
+  constexpr int HP = C::HP, DPL = C::DPL, TC = C::TC;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int thr_lane = thr_rank - 1;
+
+  // A operand: lane l holds query (l&31), dims [half*H, half*H+H), pre-scaled by -2
+  float aq[H];
+  {
+    int64_t qrow = q_begin + (int64_t)blockIdx.x * C::QB + wave * 32 + l31;
+    if (qrow > n_pad - 1) qrow = n_pad - 1;  // padded query slot: results are never read
+    const float* qp = xp + qrow * DPL + half * HP;
+#pragma unroll
+    for (int s = 0; s < H; ++s) aq[s] = -2.0f * qp[s];
+  }
+  float key[16], thr[16];
+  int idx[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    key[r] = INFINITY;
+    thr[r] = INFINITY;
+    idx[r] = -1;
+  }
+
+  auto dma = [&](int t, int buf) {
+    const char* src = reinterpret_cast<const char*>(xp) + (int64_t)t * C::TILE_BYTES + lane * 16;
+    char* dst = reinterpret_cast<char*>(smem) + buf * C::TILE_BYTES;
+    for (int i = wave; i < C::TILE_KB; i += C::NW)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+  };
+  // B operand of sub-tile g (global sub-tile counter: tile g>>2, rows (g&3)*32 ..): lane l holds candidate
+  // (l&31), the same dim slice as A, then the norm
+  auto load_b = [&](int g, float (&b)[HP]) {
+    const float* tb = smem + ((g >> 2) & 1) * TC * DPL;
+    const float4* p = reinterpret_cast<const float4*>(tb + ((g & 3) * 32 + l31) * DPL + half * HP);
+#pragma unroll
+    for (int s4 = 0; s4 < HP / 4; ++s4) {
+      const float4 v = p[s4];
+      b[4 * s4 + 0] = v.x;
+      b[4 * s4 + 1] = v.y;
+      b[4 * s4 + 2] = v.z;
+      b[4 * s4 + 3] = v.w;
+    }
+  };
+  // insert the survivors of a sub-tile (scores acc + cn, cn = ||c||^2 of the lane's candidate, first row id
+  // cbase); m[r] = the filter's ballot for register r.  The threshold of a query is the thr_rank-th smallest
+  // key of its list (lane thr_rank-1 of its half): a tighter threshold than the list's last entry means fewer
+  // survivors, and everything below the threshold is still guaranteed to be in the list.
+  auto insert = [&](const f32x16& acc, float cn, int cbase, const unsigned long long (&m)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (m[r]) {
+        const float sc = acc[r] + cn;
+        unsigned int lo = (unsigned int)m[r], hi = (unsigned int)(m[r] >> 32);
+        while (lo | hi) {
+          const int slo = lo ? __builtin_ctz(lo) : 0, shi = hi ? __builtin_ctz(hi) : 0;
+          const float vlo = lo ? readlane_f32(sc, slo) : INFINITY;
+          const float vhi = hi ? readlane_f32(sc, 32 + shi) : INFINITY;
+          const float v = half ? vhi : vlo;
+          const int ci = cbase + (half ? shi : slo);
+          const float upk = __shfl_up(key[r], 1, 32);
+          const int upi = __shfl_up(idx[r], 1, 32);
+          const bool gt = key[r] > v;
+          const bool first = (l31 == 0) || !(upk > v);
+          key[r] = gt ? (first ? v : upk) : key[r];
+          idx[r] = gt ? (first ? ci : upi) : idx[r];
+          lo &= lo - 1;
+          hi &= hi - 1;
+        }
+        const float t0 = readlane_f32(key[r], thr_lane), t1 = readlane_f32(key[r], 32 + thr_lane);
+        thr[r] = half ? t1 : t0;
+      }
+    }
+  };
+  // One pipeline step = ONE scheduling region: the MFMA chain of sub-tile g (acc_cur = -2 q.c, C starts at 0)
+  // with, in the shadow of the MFMAs, the fragment reads of sub-tile g+1 and the filter of the previous
+  // sub-tile (acc_prev + cn_prev < thr).  Nothing but the branch to the (rare) insertion sits between two
+  // chains.  (On gfx950 the f32 MFMA shares the SIMD's FMA lanes with the VALU: every filler instruction
+  // costs ~3 cycles of matrix throughput, so the filter is kept at 2 VALU per score register.)
+  const int n_sub = n_tiles * 4;
+  int dummy = 0;
+  auto step = [&](int g, float (&b_cur)[HP], f32x16& acc_cur, const f32x16& acc_prev, float cn_prev,
+                  float (&b_nxt)[HP]) {
+    load_b(min(g + 1, n_sub - 1), b_nxt);  // (the clamp re-reads the last sub-tile: no branch in the region)
+    unsigned long long m[16];
+    f32x16 zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+    acc_cur = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[0], b_cur[0], zero, 0, 0, 0);
+#pragma unroll
+    for (int s = 1; s < H; ++s) {
+      acc_cur = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s], b_cur[s], acc_cur, 0, 0, 0);
+      if (s - 1 < 16) m[s - 1] = __ballot((acc_prev[s - 1] + cn_prev) < thr[s - 1]);
+    }
+#pragma unroll
+    for (int s = H - 1; s < 16; ++s) m[s] = __ballot((acc_prev[s] + cn_prev) < thr[s]);
+    unsigned long long any = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) any |= m[r];
+    // pin the interleave: 1 MFMA, then up to 2 VALU + 1 SALU + 1 LDS read in its shadow
+#pragma unroll
+    for (int s = 0; s < H; ++s) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);
+    }
+    if constexpr ((MODE & 2) == 0) {
+      if (any) insert(acc_prev, cn_prev, (g - 1) * 32, m);
+    } else {
+      dummy += (int)(any & 1);  // keeps the scores live; no insertion
+    }
+  };
+
+  constexpr bool REGSTAGE = (MODE & 1) != 0;
+  constexpr int NP = (C::TILE_KB + C::NW - 1) / C::NW;
+  f32x4 st[NP];
+  auto gload = [&](int t) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xp) + (int64_t)t * C::TILE_BYTES) + lane;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      // every wave issues NP loads; out-of-range piece ids are clamped (a duplicate copy of the last piece)
+      // so that no load sits behind a branch (hipcc would wait vmcnt(0) after each conditional load)
+      const int i = min(wave + C::NW * j, C::TILE_KB - 1);
+      st[j] = src[i * 64];
+    }
+  };
+  auto lstore = [&](int buf) {
+    f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + buf * C::TILE_BYTES) + lane;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int i = min(wave + C::NW * j, C::TILE_KB - 1);
+      dst[i * 64] = st[j];
+    }
+  };
+  if constexpr (REGSTAGE) {
+    gload(0);
+    lstore(0);
+    if (n_tiles > 1) gload(1);
+  } else {
+    dma(0, 0);
+    if (n_tiles > 1) dma(1, 1);
+  }
+  __syncthreads();
+  float bA[HP], bB[HP];
+  f32x16 accA, accB;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accB[r] = INFINITY;  // "previous" scores of the first step: nothing passes
+  load_b(0, bA);
+  float cnA = 0.f, cnB = 0.f;  // ||c||^2 of the lane's candidate in the sub-tile whose scores are in accA / accB
+  for (int t = 0; t < n_tiles; ++t) {
+    const int g = 4 * t;
+    cnA = bA[H];
+    step(g + 0, bA, accA, accB, cnB, bB);
+    cnB = bB[H];
+    step(g + 1, bB, accB, accA, cnA, bA);
+    cnA = bA[H];
+    step(g + 2, bA, accA, accB, cnB, bB);
+    cnB = bB[H];
+    if constexpr (REGSTAGE) {
+      if (t + 1 < n_tiles) lstore((t + 1) & 1);  // buffer of tile t-1: free since the previous barrier
+      if constexpr ((MODE & 4) == 0) __syncthreads();  // (MODE & 4: racy timing experiment)
+      if (t + 2 < n_tiles) gload(t + 2);
+    } else {
+      __syncthreads();
+      if (t + 2 < n_tiles) dma(t + 2, t & 1);
+    }
+    step(g + 3, bB, accB, accA, cnA, bA);
+  }
+  {
+    unsigned long long m[16], any = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      m[r] = __ballot((accB[r] + cnB) < thr[r]);
+      any |= m[r];
+    }
+    if (any) insert(accB, cnB, (n_sub - 1) * 32, m);
+  }
+
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t q = (int64_t)blockIdx.x * C::QB + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    cand_idx[q * C::KP + l31] = idx[r] + ((MODE & 2) ? dummy : 0);
+    if (l31 == thr_lane) cand_tau[q] = key[r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // pass 2: exact float64 re-rank + certificate.  One wave per query, 4 queries per block.
 // ------------------------------------------------------------------------------------------------
 __device__ inline bool key_less(double da, int ia, double db, int ib) {
@@ -429,8 +695,16 @@ __global__ __launch_bounds__(256) void knn_fallback_kernel(
 // ------------------------------------------------------------------------------------------------
 struct KnnPlan {
   int H, TC, NW, KP;
+  bool reg;       // register-list kernel (knn_select_reg_kernel) instead of the LDS-list kernel
+  int thr_rank;   // register-list kernel: rank (1..32) of the list entry used as the filter threshold
+  int row_dwords; // row stride of the packed copy
   int64_t n_pad, nq_pad;
 };
+
+template <int H>
+static void reg_plan(KnnPlan* p) {
+  p->row_dwords = RegCfg<H>::DPL;
+}
 
 static bool knn_plan(int64_t n, int d, int64_t n_query, int k, KnnPlan* p) {
   if (d <= 16) p->H = 8;
@@ -444,6 +718,30 @@ static bool knn_plan(int64_t n, int d, int64_t n_query, int k, KnnPlan* p) {
   else if (k <= 56) { p->KP = 64; p->NW = 4; }
   else if (k <= 120) { p->KP = 128; p->NW = 2; }
   else return false;
+  static const bool legacy = [] {
+    const char* e = getenv("SCAMD_KNN_LEGACY");
+    return e && e[0] == '1';
+  }();
+  p->reg = (p->KP == 32 && p->H <= 32 && !legacy);
+  {
+    // k columns = self + k-1 others must be certified below the threshold: keep a margin of 6 ranks
+    static const int margin = [] {
+      const char* e = getenv("SCAMD_KNN_THR_MARGIN");
+      return e ? atoi(e) : 6;
+    }();
+    p->thr_rank = std::min(32, std::max(1, k + margin));
+  }
+  p->row_dwords = 2 * p->H;
+  if (p->reg) {
+    p->NW = 4;
+    p->TC = 128;
+    switch (p->H) {
+      case 8: reg_plan<8>(p); break;
+      case 16: reg_plan<16>(p); break;
+      case 25: reg_plan<25>(p); break;
+      default: reg_plan<32>(p); break;
+    }
+  }
   const int QB = p->NW * 32;
   p->nq_pad = (n_query + QB - 1) / QB * QB;
   p->n_pad = (n + 255) / 256 * 256;
@@ -456,7 +754,7 @@ struct KnnBuffers {
 };
 
 static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffers* b) {
-  b->xp = ws.take<float>((size_t)p.n_pad * 2 * p.H);
+  b->xp = ws.take<float>((size_t)p.n_pad * p.row_dwords);
   b->cn = ws.take<float>((size_t)p.n_pad);
   b->cmax = ws.take<unsigned int>(4);
   b->cand_idx = ws.take<int>((size_t)p.nq_pad * p.KP);
@@ -491,7 +789,48 @@ static int dispatch_kp(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, h
   }
 }
 
+static int knn_mode() {
+  static const int mode = [] {
+    const char* e = getenv("SCAMD_KNN_MODE");
+    return e ? atoi(e) : 1;
+  }();
+  return mode;
+}
+
+template <int H, int MODE>
+static int launch_select_reg_mode(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, hipStream_t s) {
+  using C = RegCfg<H>;
+  auto kern = knn_select_reg_kernel<H, MODE>;
+  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+  const int n_tiles = (int)(p.n_pad / C::TC);
+  const int grid = (int)(p.nq_pad / C::QB);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, b.xp, n_tiles, p.n_pad, q_begin,
+                     p.thr_rank, b.cand_idx, b.cand_tau);
+  SCAMD_LAUNCH_CHECK();
+  return SCAMD_OK;
+}
+
+template <int H>
+static int launch_select_reg(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, hipStream_t s) {
+  switch (knn_mode()) {
+    case 0: return launch_select_reg_mode<H, 0>(p, b, q_begin, s);
+    case 2: return launch_select_reg_mode<H, 2>(p, b, q_begin, s);
+    case 3: return launch_select_reg_mode<H, 3>(p, b, q_begin, s);
+    case 7: return launch_select_reg_mode<H, 7>(p, b, q_begin, s);
+    default: return launch_select_reg_mode<H, 1>(p, b, q_begin, s);
+  }
+}
+
 static int dispatch_select(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, hipStream_t s) {
+  if (p.reg) {
+    switch (p.H) {
+      case 8: return launch_select_reg<8>(p, b, q_begin, s);
+      case 16: return launch_select_reg<16>(p, b, q_begin, s);
+      case 25: return launch_select_reg<25>(p, b, q_begin, s);
+      default: return launch_select_reg<32>(p, b, q_begin, s);
+    }
+  }
   switch (p.H) {
     case 8: return dispatch_kp<8, 128>(p, b, q_begin, s);
     case 16: return dispatch_kp<16, 128>(p, b, q_begin, s);
@@ -505,7 +844,6 @@ static int dispatch_select(const KnnPlan& p, const KnnBuffers& b, int64_t q_begi
 
 using namespace scamd;
 
-static thread_local float g_last_select_ms = -1.f;
 extern "C" float scamd_knn_last_select_ms(void) { return g_last_select_ms; }
 
 extern "C" size_t scamd_knn_workspace_bytes(int64_t n, int d, int64_t n_query, int k) {
@@ -545,8 +883,14 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
   SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, 16, s));
   {
     int blocks = (int)std::min<int64_t>((p.n_pad + 3) / 4, 256 * 16);
-    hipLaunchKernelGGL(knn_pack_kernel, dim3(blocks), dim3(256), 0, s, x, n, d, ld_x, 2 * p.H,
-                       p.n_pad, b.xp, b.cn, b.cmax);
+    if (p.reg) {
+      const int HP = (p.H + 1 + 3) / 4 * 4;
+      hipLaunchKernelGGL(knn_pack_image_kernel, dim3(blocks), dim3(256), 0, s, x, n, d, ld_x, p.H, HP,
+                         p.row_dwords, p.n_pad, b.xp, b.cmax);
+    } else {
+      hipLaunchKernelGGL(knn_pack_kernel, dim3(blocks), dim3(256), 0, s, x, n, d, ld_x, 2 * p.H,
+                         p.n_pad, b.xp, b.cn, b.cmax);
+    }
     SCAMD_LAUNCH_CHECK();
   }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -559,6 +903,15 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
     return rc;
+  }
+  if (p.reg && (knn_mode() & 2)) {  // timing experiment: the candidate lists are garbage, skip passes 2/3
+    SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) ms = -1.f;
+    g_last_select_ms = ms;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    return SCAMD_OK;
   }
   {
     int blocks = (int)((n_query + 3) / 4);
