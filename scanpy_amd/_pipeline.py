@@ -59,14 +59,23 @@ class _Timer:
 
 
 def _all_gather_rows(t: torch.Tensor, comm, counts: list[int]) -> torch.Tensor:
-    """Concatenate every rank's row block (blocks may differ in length by one)."""
+    """Concatenate every rank's row block.  Blocks may differ in length by one row (shard_bounds); RCCL/gloo
+    all-gather needs equal-sized contributions, so every block is padded to the longest one, gathered into one
+    [world * max_rows, ...] buffer with a single collective, and the padding rows are dropped afterwards."""
     if comm.world_size == 1:
         return t
     import torch.distributed as dist
 
-    parts = [torch.empty((c, *t.shape[1:]), dtype=t.dtype, device=t.device) for c in counts]
-    dist.all_gather(parts, t.contiguous(), group=getattr(comm, "group", None))
-    return torch.cat(parts, dim=0)
+    mx = max(counts)
+    t = t.contiguous()
+    if t.shape[0] < mx:
+        pad = torch.zeros((mx - t.shape[0], *t.shape[1:]), dtype=t.dtype, device=t.device)
+        t = torch.cat([t, pad], dim=0)
+    buf = torch.empty((comm.world_size * mx, *t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(buf, t, group=getattr(comm, "group", None))
+    if all(c == mx for c in counts):
+        return buf
+    return torch.cat([buf[r * mx: r * mx + c] for r, c in enumerate(counts)], dim=0)
 
 
 def shard_bounds(n_total: int, world_size: int, rank: int) -> tuple[int, int]:

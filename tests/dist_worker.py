@@ -1,0 +1,90 @@
+"""Worker for the world_size-2 gloo tests (TEST INFRASTRUCTURE): runs the row-sharded host logic of the path on CPU.
+
+The kernel layer is replaced by CPU stand-ins built from the oracle (tests may use the oracle as a checker; the
+product never does): `CpuStubBackend` for the PCA data passes, sklearn brute kNN / oracle fuzzy set / oracle Leiden
+for the `_kernels` entry points `run_path` calls.  What is exercised is the product's sharding and collective
+logic: shard_bounds, the float64 all-reduces of the PCA panels, the all-gather of embedding rows and kNN lists,
+Leiden on rank 0 and the label broadcast."""
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (str(ROOT), str(ROOT / "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _patch_kernels():
+    """CPU stand-ins with the signatures of scanpy_amd._kernels.{knn, fuzzy_simplicial_set, leiden}."""
+    from oracle import connectivities as oc
+    from oracle import knn as oknn
+    from oracle import leiden as ol
+    from scanpy_amd import _kernels
+
+    def knn(x, k, *, q_begin=0, n_query=None, cert_scale=1.0):
+        xn = x.numpy()
+        n = xn.shape[0]
+        nq = n - q_begin if n_query is None else n_query
+        idx, dist, _ = oknn.knn_sklearn(xn, k)
+        sl = slice(q_begin, q_begin + nq)
+        return (torch.from_numpy(idx[sl].astype(np.int32)), torch.from_numpy(dist[sl].astype(np.float64)), 0)
+
+    def fuzzy_simplicial_set(knn_idx, knn_dist):
+        n, k = knn_idx.shape
+        conn, sig, rho = oc.fuzzy_simplicial_set(knn_idx.numpy(), knn_dist.numpy().astype(np.float32), n, k)
+        return (torch.from_numpy(conn.indptr.astype(np.int64)), torch.from_numpy(conn.indices.astype(np.int32)),
+                torch.from_numpy(conn.data.astype(np.float32)), torch.from_numpy(sig), torch.from_numpy(rho))
+
+    def leiden(indptr, indices, weights, n, *, resolution=1.0, n_iterations=-1, beta=0.01, seed=0):
+        from scipy import sparse
+
+        adj = sparse.csr_matrix((weights.numpy(), indices.numpy(), indptr.numpy()), shape=(n, n))
+        memb, q = ol.leiden(adj, resolution=resolution, n_iterations=n_iterations, seed=seed)
+        return torch.from_numpy(memb.astype(np.int32)), q, int(memb.max()) + 1
+
+    _kernels.knn = knn
+    _kernels.fuzzy_simplicial_set = fuzzy_simplicial_set
+    _kernels.leiden = leiden
+
+
+def run(rank: int, world: int, init_file: str, out_dir: str, n: int, g: int, n_comps: int, mode: str):
+    import torch.distributed as dist
+
+    from scanpy_amd._pipeline import run_path, shard_bounds
+    from scanpy_amd.datasets import synthetic_planted
+    from scanpy_amd.preprocessing._pca_solver import NoComm, TorchDistComm, pca_fit
+    from stub_backend import CpuStubBackend
+
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+        comm = TorchDistComm()
+    else:
+        comm = NoComm()
+    lo, hi = shard_bounds(n, world, rank)
+    x, _ = synthetic_planted(n, g, n_types=12, seed=5, row_range=(lo, hi))
+    be = CpuStubBackend()
+    out = {}
+    if mode == "pca":
+        res = pca_fit(be.upload(x), n_comps, backend=be, comm=comm)
+        out = dict(scores=res.scores.numpy(), components=res.components, variance=res.explained_variance,
+                   ratio=res.explained_variance_ratio, mean=res.mean, lo=lo, hi=hi)
+    else:
+        _patch_kernels()
+        res = run_path(be.upload(x), n, comm=comm, backend=be, n_comps=n_comps, n_neighbors=10)
+        out = dict(scores=res.x_pca.numpy(), knn_idx=res.knn_indices.numpy(), knn_dist=res.knn_distances.numpy(),
+                   labels=res.labels.numpy(), q=res.modularity, nc=res.n_communities, lo=lo, hi=hi,
+                   has_graph=res.conn_indptr is not None)
+    np.savez(Path(out_dir) / f"rank{rank}_of{world}.npz", **out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    a = sys.argv[1:]
+    run(int(a[0]), int(a[1]), a[2], a[3], int(a[4]), int(a[5]), int(a[6]), a[7])
