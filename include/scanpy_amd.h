@@ -125,6 +125,18 @@ int scamd_spmm_csr_f32_f64acc(const int64_t* indptr, const int32_t* indices, con
                               int64_t n_rows, int64_t nnz, const float* b, int l,
                               const double* scale, const double* colsum, double* w,
                               void* workspace, size_t workspace_bytes, scamd_stream_t stream);
+/* Exact Gram matrix and column sums of a CSR float32 matrix in 64-bit fixed point (the covariance route of
+ * src/scanpy/preprocessing/_pca/_kernels.py:14-58 + _pca/_dask.py:28-132, and the engine of the default PCA solve):
+ *   gram[i * ld_gram + j] = round-to-nearest-per-product sum_r x_ri * x_rj * 2^scale_bits   (int64, symmetric,
+ *                           [g_pad x ld_gram], g_pad = g rounded up to 128, padding rows/columns zero)
+ *   colsum[j]             = sum_r round(x_rj * 2^scale_bits)                                 (int64 [g_pad])
+ * Integer accumulation is order independent: the result is bitwise reproducible and additive over row shards
+ * (ranks all-reduce the int64 arrays).  Two-phase use: call with gram == NULL and absmax_host != NULL to get
+ * max|x| (host float) and derive scale_bits <= 62 - log2(n_total * absmax^2); then call with the outputs. */
+size_t scamd_csr_gram_workspace_bytes(int64_t n, int64_t g);
+int scamd_csr_gram_f32(const int64_t* indptr, const int32_t* indices, const float* data, int64_t n, int64_t g,
+                       int64_t nnz, int scale_bits, int64_t* gram, int64_t ld_gram, int64_t* colsum,
+                       float* absmax_host, void* workspace, size_t workspace_bytes, scamd_stream_t stream);
 /* colsum[l] (float64) = 1^T Y for Y [n, l] float32, fixed summation order. */
 size_t scamd_colsum_workspace_bytes(int l);
 int scamd_colsum_f32_f64(const float* y, int64_t n, int l, double* colsum,

@@ -85,6 +85,32 @@ def csr_row_stats(indptr: torch.Tensor, data: torch.Tensor, n_rows: int):
     return s, q
 
 
+def csr_absmax(indptr, indices, data, n: int, g: int) -> float:
+    """max |x| over the stored entries (phase 1 of the Gram computation)."""
+    dev = require_gpu()
+    lib = _lib.load()
+    ws, wsz = _ws(lib.scamd_csr_gram_workspace_bytes(n, g), dev)
+    mx = C.c_float(0.0)
+    rc = lib.scamd_csr_gram_f32(ptr(indptr), ptr(indices), ptr(data), n, g, data.numel(), 0, None, 0, None,
+                                C.byref(mx), ptr(ws), wsz, stream_ptr())
+    _lib.check(rc, "scamd_csr_gram_f32 (absmax)")
+    return float(mx.value)
+
+
+def csr_gram(indptr, indices, data, n: int, g: int, scale_bits: int):
+    """-> (gram int64 [g_pad, g_pad], colsum int64 [g_pad]) in fixed point (x 2^scale_bits), g_pad = ceil128(g)."""
+    dev = require_gpu()
+    lib = _lib.load()
+    gp = (g + 127) // 128 * 128
+    gram = torch.empty((gp, gp), dtype=torch.int64, device=dev)
+    colsum = torch.empty(gp, dtype=torch.int64, device=dev)
+    ws, wsz = _ws(lib.scamd_csr_gram_workspace_bytes(n, g), dev)
+    rc = lib.scamd_csr_gram_f32(ptr(indptr), ptr(indices), ptr(data), n, g, data.numel(), int(scale_bits), ptr(gram),
+                                gp, ptr(colsum), None, ptr(ws), wsz, stream_ptr())
+    _lib.check(rc, "scamd_csr_gram_f32")
+    return gram, colsum
+
+
 def spmm(indptr, indices, data, n: int, g: int, b: torch.Tensor, shift: torch.Tensor | None = None) -> torch.Tensor:
     """Y[n, l] = A B - 1 shift^T, float32."""
     dev = require_gpu()

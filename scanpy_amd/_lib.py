@@ -29,6 +29,8 @@ SIGNATURES = {
     "scamd_spmm_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp]),
     "scamd_spmm_f64acc_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "scamd_spmm_csr_f32_f64acc": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "scamd_csr_gram_workspace_bytes": (_sz, [_i64, _i64]),
+    "scamd_csr_gram_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, C.POINTER(C.c_float), _vp, _sz, _vp]),
     "scamd_colsum_workspace_bytes": (_sz, [_i32]),
     "scamd_colsum_f32_f64": (_i32, [_vp, _i64, _i32, _vp, _vp, _sz, _vp]),
     "scamd_leiden_workspace_bytes": (_sz, [_i64, _i64]),

@@ -10,10 +10,12 @@ Rayleigh-Ritz on that space converges to the same eigenpairs ARPACK returns; ite
 Ritz residual, so accuracy is a tolerance, not a fixed iteration count.
 
 `svd_solver`:
-  'arpack' (default, reference default for sparse input, _pca/__init__.py:439-442)  -> block Krylov to `tol`
+  'arpack' (default, reference default for sparse input, _pca/__init__.py:439-442) and 'covariance_eigh'
+                     -> covariance route when g <= 8192: exact fixed-point Gram matrix in ONE pass over the CSR
+                        (`scamd_csr_gram_f32`; the route of _pca/_dask.py:28-89, _kernels.py:14-58) + a dense
+                        float64 eigen-solve (Chebyshev-filtered subspace iteration, all GEMMs) converged to `tol`;
+                        otherwise (or with `block_size=` given) block Krylov on the CSR operator to `tol`
   'randomized'       -> randomized subspace iteration (n_iter power iterations, n_oversamples)
-  'covariance_eigh'  -> C assembled exactly from identity blocks, then a full eigh
-                        (the Gram route of src/scanpy/preprocessing/_pca/_dask.py:28-89, _kernels.py:14-58)
 
 Row sharding (multi-GPU): every rank holds a contiguous block of cells; the only exchanges are
 all-reduces of g x b float64 panels and g-vectors (<= 1 MB), the scores stay sharded.
@@ -35,6 +37,9 @@ class NoComm:
     def allreduce_(self, t: torch.Tensor) -> torch.Tensor:
         return t
 
+    def allreduce_max_(self, t: torch.Tensor) -> torch.Tensor:
+        return t
+
 
 class TorchDistComm:
     """Sum all-reduce over torch.distributed (backend 'nccl' == RCCL on ROCm; 'gloo' in CPU tests)."""
@@ -50,6 +55,11 @@ class TorchDistComm:
     def allreduce_(self, t: torch.Tensor) -> torch.Tensor:
         if self.world_size > 1:
             self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def allreduce_max_(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world_size > 1:
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self.group)
         return t
 
 
@@ -88,6 +98,16 @@ class GpuBackend:
 
     def colsum(self, y):
         return self.K.colsum(y)
+
+    def absmax(self, a) -> float:
+        ip, ix, dv, n, g = a
+        return self.K.csr_absmax(ip, ix, dv, n, g)
+
+    def gram(self, a, scale_bits: int):
+        """-> (G int64 [g, g], colsum int64 [g]): fixed point X^T X and 1^T X (x 2^scale_bits)."""
+        ip, ix, dv, n, g = a
+        gram, cs = self.K.csr_gram(ip, ix, dv, n, g, scale_bits)
+        return gram[:g, :g], cs[:g]
 
 
 @dataclass
@@ -139,6 +159,141 @@ def _rayleigh_ritz(kall: torch.Tensor, ckall: torch.Tensor, k: int):
     return lam, kall @ y, ckall @ y
 
 
+GRAM_MAX_GENES = 8192  # G is g x g float64 (512 MB at the limit); beyond it the block Krylov route is used
+
+
+def _cholqr2(y: torch.Tensor) -> torch.Tensor:
+    """Orthonormal basis of span(y) by two rounds of Cholesky QR on column-normalised y (GEMM-shaped; falls back to
+    Householder QR when the Gram matrix is numerically singular)."""
+    y = y / torch.linalg.norm(y, dim=0, keepdim=True).clamp_min(1e-300)
+    try:
+        for _ in range(2):
+            l = torch.linalg.cholesky(y.T @ y)
+            y = torch.linalg.solve_triangular(l, y.T, upper=False).T
+        return y
+    except RuntimeError:  # torch.linalg.LinAlgError is a RuntimeError
+        return torch.linalg.qr(y, mode="reduced")[0]
+
+
+def _dense_topk_eigh(amat: torch.Tensor, k: int, rng: np.random.Generator, tol: float, info: dict):
+    """Top-k eigenpairs (descending) of the symmetric PSD g x g float64 matrix `amat` on the device.
+
+    Small problems: one full eigh.  Otherwise Chebyshev-filtered subspace iteration (Zhou & Saad): the block is the
+    current Ritz basis, the filter damps [0, smallest Ritz value] -- every step is a g x g x b GEMM, the only
+    non-GEMM work is a b x b eigh per outer iteration.  Stops on the Ritz residual of the k wanted pairs."""
+    g = amat.shape[0]
+    b = min(g, (max(k + 64, 2 * k) + 15) // 16 * 16)
+    if g <= 384 or 2 * b > g:
+        lam, v = torch.linalg.eigh(amat)
+        info.update(dense_solver="eigh", residual=0.0)
+        return lam.flip(0)[:k], v.flip(1)[:, :k]
+    dev = amat.device
+
+    def rr(z):
+        az = amat @ z
+        t = z.T @ az
+        theta, y = torch.linalg.eigh(0.5 * (t + t.T))
+        theta, y = theta.flip(0), y.flip(1)
+        return theta, z @ y, az @ y
+
+    z = _cholqr2(torch.from_numpy(rng.standard_normal((g, b))).to(dev))
+    z = _cholqr2(amat @ _cholqr2(amat @ z))
+    theta, v, av = rr(z)
+    resid, n_gemm, outer = float("inf"), 3, 0
+    for outer in range(1, 25):
+        r = av[:, :k] - v[:, :k] * theta[None, :k]
+        resid = float((torch.linalg.norm(r, dim=0) / theta[0].clamp_min(1e-300)).max())
+        if resid < tol:
+            break
+        # scaled Chebyshev filter on [0, c], c = smallest Ritz value of the block (<= lambda_b)
+        c = float(theta[-1].clamp_min(0.0))
+        top = float(theta[0])
+        if not top > c > 0.0:  # rank-deficient block (c == 0): plain power steps keep it simple and safe
+            z = _cholqr2(amat @ (amat @ v))
+            n_gemm += 2
+            theta, v, av = rr(z)
+            n_gemm += 1
+            continue
+        m = 8 if outer == 1 else 16
+        e, center = 0.5 * c, 0.5 * c
+        sigma = e / (top - center)
+        sigma1 = sigma
+        y_prev = v
+        y = (av - center * v) * (sigma1 / e)
+        for _ in range(2, m + 1):
+            sigma2 = 1.0 / (2.0 / sigma1 - sigma)
+            y_new = (amat @ y - center * y) * (2.0 * sigma2 / e) - (sigma * sigma2) * y_prev
+            y_prev, y, sigma = y, y_new, sigma2
+        n_gemm += m - 1
+        theta, v, av = rr(_cholqr2(y))
+        n_gemm += 1
+    info.update(dense_solver="chebyshev_subspace", residual=resid, n_outer=outer, n_gemm=n_gemm, block_size=b)
+    return theta[:k], v[:, :k]
+
+
+def _pca_fit_gram(a, n_comps: int, backend, comm, zero_center: bool, seed: int, tol: float) -> "PCAResult | None":
+    """Covariance route: exact fixed-point Gram matrix (one pass over the CSR, `scamd_csr_gram_f32`), all-reduced
+    over the row shards as int64 (so the model is bitwise identical for any number of ranks), then a dense
+    float64 eigen-solve.  Returns None when the route does not apply (too many genes / overflow risk)."""
+    n_local, g = a[3], a[4]
+    if g > GRAM_MAX_GENES or not hasattr(backend, "gram"):
+        return None
+    dev = backend.device
+    meta = torch.tensor([float(n_local), backend.absmax(a)], dtype=torch.float64, device=dev)
+    nt = meta[:1].clone()
+    mx = meta[1:].clone()
+    comm.allreduce_(nt)
+    comm.allreduce_max_(mx)
+    n = int(round(float(nt.item())))
+    absmax = float(mx.item())
+    if not 1 <= n_comps <= min(n, g):
+        raise ValueError(f"n_components={n_comps!r} must be between 1 and min(n_samples, n_features)={min(n, g)!r} "
+                         "with svd_solver='arpack'")
+    if n_comps == min(n, g):
+        raise ValueError(f"n_components={n_comps!r} must be strictly less than min(n_samples, n_features)="
+                         f"{min(n, g)!r} with svd_solver='arpack'")
+    bound = max(n * absmax * absmax, 1e-300)
+    scale_bits = int(np.floor(62.0 - np.log2(bound)))
+    if scale_bits < 8:  # too little resolution left: the float64 Krylov route handles such data
+        return None
+    scale_bits = min(scale_bits, 40)
+    gq, cq = backend.gram(a, scale_bits)
+    comm.allreduce_(gq)
+    comm.allreduce_(cq)
+    inv = 2.0 ** -scale_bits
+    gmat = gq.to(torch.float64) * inv
+    colsum = cq.to(torch.float64) * inv
+    mean = colsum / n
+    var = torch.clamp(torch.diagonal(gmat) / n - mean * mean, min=0.0)
+    amat = gmat - n * torch.outer(mean, mean) if zero_center else gmat
+    amat = 0.5 * (amat + amat.T)
+    info = {"solver": "gram", "scale_bits": scale_bits}
+    rng = np.random.default_rng(seed)
+    lam, v = _dense_topk_eigh(amat, n_comps, rng, tol, info)
+    lam = torch.clamp(lam, min=0.0)
+    v = _sign_flip(v)
+    vf = v.to(torch.float32).contiguous()
+    shift = (mean @ vf.to(torch.float64)).to(torch.float32) if zero_center else None
+    scores = backend.spmm(a, vf, shift)
+    info["n_operator_applications"] = 1
+    if zero_center:
+        ev = lam / (n - 1)
+        total_var = var.sum() * n / (n - 1)
+    else:
+        ev = torch.clamp(lam / n - (mean @ v) ** 2, min=0.0)
+        total_var = var.sum()
+    return PCAResult(
+        scores=scores,
+        components=v.T.contiguous().cpu().numpy(),
+        explained_variance=ev.cpu().numpy(),
+        explained_variance_ratio=(ev / total_var).cpu().numpy(),
+        singular_values=torch.sqrt(lam).cpu().numpy(),
+        mean=mean.cpu().numpy() if zero_center else None,
+        n_samples=n,
+        info=info,
+    )
+
+
 def pca_fit(a, n_comps: int, *, backend=None, comm=None, zero_center: bool = True, svd_solver: str = "arpack",
             seed: int = 0, tol: float = 2e-8, max_blocks: int = 24, block_size: int | None = None,
             n_oversamples: int = 10, n_iter: int | str = "auto") -> PCAResult:
@@ -146,6 +301,10 @@ def pca_fit(a, n_comps: int, *, backend=None, comm=None, zero_center: bool = Tru
     backend = backend or GpuBackend()
     comm = comm or NoComm()
     n_local, g = a[3], a[4]
+    if svd_solver in ("arpack", "auto", "covariance_eigh") and block_size is None:
+        res = _pca_fit_gram(a, n_comps, backend, comm, zero_center, seed, tol)
+        if res is not None:
+            return res
     at = backend.transpose(a)
     s, q = backend.row_stats(at)
     dev = s.device

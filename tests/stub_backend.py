@@ -41,3 +41,22 @@ class CpuStubBackend:
 
     def colsum(self, y):
         return torch.from_numpy(y.numpy().astype(np.float64).sum(axis=0))
+
+    def absmax(self, a) -> float:
+        return float(np.abs(a[0].data).max()) if a[0].nnz else 0.0
+
+    def gram(self, a, scale_bits: int):
+        """Mimics scamd_csr_gram_f32: per-product rounding to 2^-scale_bits, int64 accumulation."""
+        x = a[0].astype(np.float64).tocsr()
+        g = x.shape[1]
+        sc = 2.0 ** scale_bits
+        gram = np.zeros((g, g), dtype=np.int64)
+        for r0 in range(0, x.shape[0], 2048):
+            blk = x[r0:r0 + 2048].toarray()
+            # exact products, rounded once each, then summed as integers
+            for row in blk:
+                nz = np.flatnonzero(row)
+                v = row[nz]
+                gram[np.ix_(nz, nz)] += np.rint(np.outer(v, v) * sc).astype(np.int64)
+        colsum = np.asarray(np.rint(x.multiply(sc).toarray()).sum(axis=0)).ravel().astype(np.int64)
+        return torch.from_numpy(gram), torch.from_numpy(colsum)

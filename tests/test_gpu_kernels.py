@@ -229,3 +229,37 @@ def test_spmm_long_rows(K):
     np.testing.assert_allclose(w, m.astype(np.float64) @ b.astype(np.float64), rtol=1e-12, atol=1e-10)
     y = K.spmm(ip, ix, dv, 50, 30000, _dev(b)).cpu().numpy()
     np.testing.assert_allclose(y, m.astype(np.float64) @ b.astype(np.float64), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize(("n", "g", "density"), [(5000, 2000, 0.05), (1234, 77, 0.3), (3000, 300, 0.2), (3, 5, 0.9), (9000, 513, 0.02)])
+def test_csr_gram_bit_exact(K, n, g, density):
+    """scamd_csr_gram_f32: integer (fixed point) Gram matrix and column sums, bit-exact against numpy int64."""
+    import torch
+    from scipy import sparse
+
+    rng = np.random.default_rng(n + g)
+    x = sparse.random(n, g, density=density, random_state=rng, format="csr", dtype=np.float32)
+    x.data = np.log1p(np.exp(rng.standard_normal(x.nnz))).astype(np.float32)
+    x.sort_indices()
+    ip = torch.from_numpy(x.indptr.astype(np.int64)).cuda()
+    ix = torch.from_numpy(x.indices.astype(np.int32)).cuda()
+    dv = torch.from_numpy(x.data).cuda()
+    mx = K.csr_absmax(ip, ix, dv, n, g)
+    assert mx == float(np.abs(x.data).max())
+    sb = 30
+    gq, cq = K.csr_gram(ip, ix, dv, n, g, sb)
+    gq, cq = gq.cpu().numpy(), cq.cpu().numpy()
+    gp = (g + 127) // 128 * 128
+    assert gq.shape == (gp, gp) and (gq[g:] == 0).all() and (gq[:, g:] == 0).all() and (cq[g:] == 0).all()
+    sc = 2.0 ** sb
+    ref = np.zeros((g, g), dtype=np.int64)
+    xd = x.astype(np.float64).toarray()
+    for row in xd:
+        nz = np.flatnonzero(row)
+        ref[np.ix_(nz, nz)] += np.rint(np.outer(row[nz], row[nz] * sc)).astype(np.int64)
+    np.testing.assert_array_equal(gq[:g, :g], ref)
+    np.testing.assert_array_equal(cq[:g], np.rint(xd * sc).astype(np.int64).sum(axis=0))
+    # determinism: the accumulation order is arbitrary, the integers are not
+    gq2, _ = K.csr_gram(ip, ix, dv, n, g, sb)
+    np.testing.assert_array_equal(gq2.cpu().numpy(), gq)

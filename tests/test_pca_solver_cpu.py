@@ -86,3 +86,35 @@ def test_reproducible_and_seed():
     b = _fit(x, 10, seed=0)
     np.testing.assert_array_equal(a.components, b.components)
     np.testing.assert_array_equal(a.scores.numpy(), b.scores.numpy())
+
+
+def test_gram_route_matches_krylov_route():
+    """Default (covariance/Gram + Chebyshev subspace) and block Krylov on the CSR operator agree to 1e-7."""
+    x, _ = synthetic_planted(3000, 700, n_types=30, seed=4)
+    a = _fit(x, 25)
+    b = _fit(x, 25, block_size=64)
+    assert a.info["solver"] == "gram" and a.info["dense_solver"] == "chebyshev_subspace", a.info
+    assert b.info["solver"] == "arpack"
+    assert np.abs(a.components - b.components).max() < 1e-7
+    np.testing.assert_allclose(a.explained_variance, b.explained_variance, rtol=1e-9)
+    assert a.info["residual"] < 2e-8
+
+
+def test_dense_topk_flat_tail():
+    """Chebyshev-filtered subspace iteration on a spectrum with a nearly flat unwanted tail and on a rank-deficient
+    matrix (smallest Ritz value 0)."""
+    import torch
+
+    from scanpy_amd.preprocessing._pca_solver import _dense_topk_eigh
+
+    rng = np.random.default_rng(0)
+    g, k = 640, 20
+    q, _ = np.linalg.qr(rng.standard_normal((g, g)))
+    for lam in (np.concatenate([np.linspace(5, 1.2, k), np.linspace(1.0, 0.9, g - k)]),
+                np.concatenate([np.linspace(5, 1.2, 60), np.zeros(g - 60)])):
+        amat = torch.from_numpy((q * lam) @ q.T)
+        info = {}
+        got_l, got_v = _dense_topk_eigh(amat, k, np.random.default_rng(1), 2e-8, info)
+        np.testing.assert_allclose(got_l.numpy(), lam[:k], rtol=1e-10)
+        err = np.abs(np.abs(got_v.numpy().T @ q[:, :k]) - np.eye(k)).max()
+        assert err < 1e-6, (err, info)
