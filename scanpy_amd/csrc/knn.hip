@@ -269,19 +269,27 @@ __global__ __launch_bounds__(NW * 64) void knn_select_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------------
 // pass 1, register-list variant (k <= 24 -> KP = 32, d <= 64): the default path.
 //
-// Roles are transposed w.r.t. knn_select_kernel: the wave's 32 QUERIES are the A operand (rows of D),
-// the 32 candidates of a sub-tile are the B operand (columns of D).  Accumulator register r of lane l is
-// score(query i(r, l>>5), candidate l&31) with i(r, h) = (r&3) + 8*(r>>2) + 4*h, so
-//   * the KP = 32 best (score, row id) pairs of query i(r, h) live in registers key[r] / idx[r] of the 32
-//     lanes of half h, sorted ascending along the lane index -- no LDS list, no per-lane serial scan;
-//   * the filter is 16 v_cmp (acc[r] < thr[r], thr[r] = key[r] of the half's last lane) or-ed on the scalar
-//     unit, issued in the shadow of the NEXT sub-tile's MFMA chain (two accumulator sets alternate);
-//   * a survivor is inserted with one lane-shift (ds_bpermute) + select per register, both halves at once.
-// Candidates are streamed as a verbatim image of the LDS tile (row = [dims 0..H-1, ||c||^2, 0.. | dims
-// H..2H-1, ||c||^2, 0.. | pad], stride DPL dwords = 4 mod 8 so the b128 fragment reads are conflict free)
-// by LDS-DMA (global_load_lds_dwordx4), double buffered, one barrier per 128-candidate tile.  LDS holds only
-// the two tiles (60 KB), registers stay below 256, so two 4-wave blocks share a CU and cover each other's
-// barrier and insertion stalls.
+// Roles are transposed w.r.t. knn_select_kernel: the wave's 32 QUERIES are the A operand (rows of D), the 32
+// candidates of a sub-tile are the B operand (columns of D).  Accumulator register r of lane l belongs to
+// (query i(r, l>>5), candidate l&31) with i(r, h) = (r&3) + 8*(r>>2) + 4*h.
+//   * The KP = 32 best (score, row id) pairs of query i(r, h) live in registers key[r] / idx[r] of the 32 lanes
+//     of half h, sorted ascending along the lane index -- no LDS list, no per-lane serial scan.  A survivor is
+//     inserted with one lane shift (ds_bpermute) + select per register, both halves at once.
+//   * The filter costs 9 VALU per sub-tile: one extra MFMA k-pair (A = [-thr_i | 1], B = [1 | ||c_j||^2]) makes
+//     the accumulator hold score - thr_i, so "some score beats its query's threshold" is the OR of 16 sign bits.
+//     (On gfx950 the f32 MFMA shares the SIMD's FMA lanes with the VALU: every VALU instruction beside the chain
+//     costs ~5 cycles of matrix throughput -- 16 adds + 16 compares + 16 scalar ORs cost 16 %, one more MFMA 4 %.)
+//     thr_i is the thr_rank-th smallest key of query i, thr_rank = k + margin <= 32: a tighter threshold than
+//     the list's last entry means fewer survivors; everything below it is still guaranteed to be in the list.
+//   * One scheduling region per sub-tile: the MFMA chain of sub-tile g, the fragment reads of g+1 and the
+//     filter of g-1 are interleaved 1 MFMA : 1 LDS read : <= 2 VALU (sched_group_barrier); only the branch to the
+//     rare insertion sits between two chains.
+// Candidates are streamed as a verbatim image of the LDS tile (row = [dims 0..H-1, 1.0, 0.. | dims H..2H-1,
+// ||c||^2, 0.. | pad], stride DPL dwords = 4 mod 8 so the b128 fragment reads are conflict free), staged
+// global_load_dwordx4 -> ds_write_b128, double buffered, one barrier per 128-candidate tile.  (An LDS-DMA
+// variant measured the same: hipcc puts a vmcnt(0) in front of every ds_read that follows an LDS-DMA.)  LDS holds
+// only the two tiles (60 KB) and the kernel needs < 256 VGPRs, so two 4-wave blocks share a CU and cover each
+// other's barrier and insertion stalls.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float readlane_f32(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
@@ -289,13 +297,13 @@ __device__ __forceinline__ float readlane_f32(float v, int l) {
 
 template <int H>
 struct RegCfg {
-  static constexpr int HP = (H + 1 + 3) / 4 * 4;  // dims of one half + the norm slot, rounded up to 4
+  static constexpr int HP = (H + 1 + 3) / 4 * 4;  // dims of one half + the extra k slot, rounded up to 4
   static constexpr int DPL = (2 * HP) % 8 == 4 ? 2 * HP : 2 * HP + 4;
   static constexpr int TC = 128, NW = 4, QB = 128, NT = 256, KP = 32;
   static constexpr int TILE_BYTES = TC * DPL * 4;
   static constexpr int TILE_KB = TILE_BYTES / 1024;
   static constexpr size_t LDS_BYTES = 2 * (size_t)TILE_BYTES;
-  static_assert(TILE_BYTES % 1024 == 0, "tile must be a whole number of 1 KiB LDS-DMA pieces");
+  static_assert(TILE_BYTES % 1024 == 0, "tile must be a whole number of 1 KiB pieces");
 };
 
 // packed image of x for the register-list kernel: [n_pad][DPL] float32 (layout above); rows >= n get
@@ -322,7 +330,7 @@ __global__ void knn_pack_image_kernel(const float* __restrict__ x, int64_t n, in
       if (hh < 2) {
         const int dim = hh * H + cc;
         if (cc < H) v = (r < n && dim < d) ? x[r * ld + dim] : 0.f;
-        else if (cc == H) v = nf;
+        else if (cc == H) v = (hh == 0) ? 1.0f : nf;  // B operand of the extra k-pair: [1 | ||c||^2]
       }
       xp[r * DPL + c] = v;
     }
@@ -331,9 +339,8 @@ __global__ void knn_pack_image_kernel(const float* __restrict__ x, int64_t n, in
   if (lane == 0 && wmax > 0.f) atomicMax(cmax_bits, __float_as_uint(wmax));
 }
 
-// MODE bit 0: 1 = stage tiles through registers (global_load_dwordx4 -> ds_write_b128) instead of LDS-DMA
-//      bit 1: 1 = never insert (timing experiments only: results are garbage)
-template <int H, int MODE>
+// NOINSERT = true: timing experiment only (the lists stay empty, results are garbage)
+template <int H, bool NOINSERT>
 __global__ __launch_bounds__(256, 2) void knn_select_reg_kernel(const float* __restrict__ xp, int n_tiles,
                                                                 int64_t n_pad, int64_t q_begin,
                                                                 int thr_rank, int* __restrict__ cand_idx,
@@ -355,24 +362,19 @@ __global__ __launch_bounds__(256, 2) void knn_select_reg_kernel(const float* __r
 #pragma unroll
     for (int s = 0; s < H; ++s) aq[s] = -2.0f * qp[s];
   }
-  float key[16], thr[16];
+  // A operand of the extra k-pair: lanes 0..31 hold -thr of query (l&31), lanes 32..63 hold 1.0.
+  // Until the lists are filled (sub-tile 0) the "threshold" is 0, i.e. the accumulator is the plain score.
+  float athr = half ? 1.0f : 0.0f;
+  float key[16];
   int idx[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     key[r] = INFINITY;
-    thr[r] = INFINITY;
     idx[r] = -1;
   }
 
-  auto dma = [&](int t, int buf) {
-    const char* src = reinterpret_cast<const char*>(xp) + (int64_t)t * C::TILE_BYTES + lane * 16;
-    char* dst = reinterpret_cast<char*>(smem) + buf * C::TILE_BYTES;
-    for (int i = wave; i < C::TILE_KB; i += C::NW)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
-                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
-  };
   // B operand of sub-tile g (global sub-tile counter: tile g>>2, rows (g&3)*32 ..): lane l holds candidate
-  // (l&31), the same dim slice as A, then the norm
+  // (l&31), the same dim slice as A, then the extra k slot
   auto load_b = [&](int g, float (&b)[HP]) {
     const float* tb = smem + ((g >> 2) & 1) * TC * DPL;
     const float4* p = reinterpret_cast<const float4*>(tb + ((g & 3) * 32 + l31) * DPL + half * HP);
@@ -385,24 +387,27 @@ __global__ __launch_bounds__(256, 2) void knn_select_reg_kernel(const float* __r
       b[4 * s4 + 3] = v.w;
     }
   };
-  // insert the survivors of a sub-tile (scores acc + cn, cn = ||c||^2 of the lane's candidate, first row id
-  // cbase); m[r] = the filter's ballot for register r.  The threshold of a query is the thr_rank-th smallest
-  // key of its list (lane thr_rank-1 of its half): a tighter threshold than the list's last entry means fewer
-  // survivors, and everything below the threshold is still guaranteed to be in the list.
-  auto insert = [&](const f32x16& acc, float cn, int cbase, const unsigned long long (&m)[16]) {
+  // Insert the survivors of a sub-tile.  acc[r] = score - (threshold its chain used); that threshold is lane
+  // i(r,h) of `athr_used` (negated).  all = true (first sub-tile): every finite score is inserted.
+  auto insert = [&](const f32x16& acc, float athr_used, int cbase, bool all) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      if (m[r]) {
-        const float sc = acc[r] + cn;
-        unsigned int lo = (unsigned int)m[r], hi = (unsigned int)(m[r] >> 32);
+      const unsigned long long m = all ? __ballot(acc[r] < INFINITY) : __ballot(acc[r] < 0.f);
+      if (m) {
+        const int i0 = (r & 3) + 8 * (r >> 2), i1 = i0 + 4;
+        const float tu0 = -readlane_f32(athr_used, i0), tu1 = -readlane_f32(athr_used, i1);
+        const float sc = acc[r] + (half ? tu1 : tu0);  // the float32 score again (+- 1 ulp)
+        unsigned int lo = (unsigned int)m, hi = (unsigned int)(m >> 32);
         while (lo | hi) {
           const int slo = lo ? __builtin_ctz(lo) : 0, shi = hi ? __builtin_ctz(hi) : 0;
           const float vlo = lo ? readlane_f32(sc, slo) : INFINITY;
           const float vhi = hi ? readlane_f32(sc, 32 + shi) : INFINITY;
           const float v = half ? vhi : vlo;
           const int ci = cbase + (half ? shi : slo);
-          const float upk = __shfl_up(key[r], 1, 32);
-          const int upi = __shfl_up(idx[r], 1, 32);
+          // lane l-1's entry by DPP wave_shr:1 (one VALU op, no LDS round trip); lane 32 receives lane 31's
+          // value, which `first` ignores
+          const float upk = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(key[r]), 0x138, 0xf, 0xf, false));
+          const int upi = __builtin_amdgcn_update_dpp(0, idx[r], 0x138, 0xf, 0xf, false);
           const bool gt = key[r] > v;
           const bool first = (l31 == 0) || !(upk > v);
           key[r] = gt ? (first ? v : upk) : key[r];
@@ -410,121 +415,116 @@ __global__ __launch_bounds__(256, 2) void knn_select_reg_kernel(const float* __r
           lo &= lo - 1;
           hi &= hi - 1;
         }
+        // new thresholds of the two queries this register belongs to -> their lanes of the A operand
         const float t0 = readlane_f32(key[r], thr_lane), t1 = readlane_f32(key[r], 32 + thr_lane);
-        thr[r] = half ? t1 : t0;
+        athr = (lane == i0) ? -t0 : ((lane == i1) ? -t1 : athr);
       }
     }
   };
-  // One pipeline step = ONE scheduling region: the MFMA chain of sub-tile g (acc_cur = -2 q.c, C starts at 0)
-  // with, in the shadow of the MFMAs, the fragment reads of sub-tile g+1 and the filter of the previous
-  // sub-tile (acc_prev + cn_prev < thr).  Nothing but the branch to the (rare) insertion sits between two
-  // chains.  (On gfx950 the f32 MFMA shares the SIMD's FMA lanes with the VALU: every filler instruction
-  // costs ~3 cycles of matrix throughput, so the filter is kept at 2 VALU per score register.)
   const int n_sub = n_tiles * 4;
-  int dummy = 0;
-  auto step = [&](int g, float (&b_cur)[HP], f32x16& acc_cur, const f32x16& acc_prev, float cn_prev,
-                  float (&b_nxt)[HP]) {
+  // One pipeline step = ONE scheduling region: chain of sub-tile g into acc_cur (with the thresholds in athr),
+  // fragment reads of sub-tile g+1, sign test of the previous sub-tile's accumulator.
+  auto step = [&](int g, float (&b_cur)[HP], f32x16& acc_cur, float& athr_cur, const f32x16& acc_prev,
+                  float athr_prev, float (&b_nxt)[HP]) {
     load_b(min(g + 1, n_sub - 1), b_nxt);  // (the clamp re-reads the last sub-tile: no branch in the region)
-    unsigned long long m[16];
     f32x16 zero;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+    athr_cur = athr;
     acc_cur = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[0], b_cur[0], zero, 0, 0, 0);
 #pragma unroll
-    for (int s = 1; s < H; ++s) {
-      acc_cur = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s], b_cur[s], acc_cur, 0, 0, 0);
-      if (s - 1 < 16) m[s - 1] = __ballot((acc_prev[s - 1] + cn_prev) < thr[s - 1]);
-    }
+    for (int s = 1; s < H; ++s) acc_cur = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s], b_cur[s], acc_cur, 0, 0, 0);
+    acc_cur = __builtin_amdgcn_mfma_f32_32x32x2f32(athr_cur, b_cur[H], acc_cur, 0, 0, 0);
+    // sign test: OR of the 16 accumulators of the previous sub-tile (3-input ORs)
+    const int o0 = __float_as_int(acc_prev[0]) | __float_as_int(acc_prev[1]) | __float_as_int(acc_prev[2]);
+    const int o1 = __float_as_int(acc_prev[3]) | __float_as_int(acc_prev[4]) | __float_as_int(acc_prev[5]);
+    const int o2 = __float_as_int(acc_prev[6]) | __float_as_int(acc_prev[7]) | __float_as_int(acc_prev[8]);
+    const int o3 = __float_as_int(acc_prev[9]) | __float_as_int(acc_prev[10]) | __float_as_int(acc_prev[11]);
+    const int o4 = __float_as_int(acc_prev[12]) | __float_as_int(acc_prev[13]) | __float_as_int(acc_prev[14]);
+    const int o5 = (o0 | o1 | o2) | (o3 | o4 | __float_as_int(acc_prev[15]));
+    const bool hit = __any(o5 < 0);
+    // pin the interleave: 1 MFMA, then 1 LDS read + up to 2 VALU in its shadow
 #pragma unroll
-    for (int s = H - 1; s < 16; ++s) m[s] = __ballot((acc_prev[s] + cn_prev) < thr[s]);
-    unsigned long long any = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) any |= m[r];
-    // pin the interleave: 1 MFMA, then up to 2 VALU + 1 SALU + 1 LDS read in its shadow
-#pragma unroll
-    for (int s = 0; s < H; ++s) {
+    for (int s = 0; s <= H; ++s) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);
     }
-    if constexpr ((MODE & 2) == 0) {
-      if (any) insert(acc_prev, cn_prev, (g - 1) * 32, m);
+    if constexpr (!NOINSERT) {
+      if (hit) insert(acc_prev, athr_prev, (g - 1) * 32, false);
     } else {
-      dummy += (int)(any & 1);  // keeps the scores live; no insertion
+      if (hit) athr += 0.0f;  // keeps the test live
     }
   };
 
-  constexpr bool REGSTAGE = (MODE & 1) != 0;
+  // staging registers: every wave moves NP 1-KiB pieces per tile; out-of-range piece ids are clamped (a duplicate
+  // copy of the last piece) so that no load sits behind a branch (hipcc waits vmcnt(0) after a conditional load)
   constexpr int NP = (C::TILE_KB + C::NW - 1) / C::NW;
   f32x4 st[NP];
   auto gload = [&](int t) {
     const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xp) + (int64_t)t * C::TILE_BYTES) + lane;
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      // every wave issues NP loads; out-of-range piece ids are clamped (a duplicate copy of the last piece)
-      // so that no load sits behind a branch (hipcc would wait vmcnt(0) after each conditional load)
-      const int i = min(wave + C::NW * j, C::TILE_KB - 1);
-      st[j] = src[i * 64];
-    }
+    for (int j = 0; j < NP; ++j) st[j] = src[min(wave + C::NW * j, C::TILE_KB - 1) * 64];
   };
   auto lstore = [&](int buf) {
     f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + buf * C::TILE_BYTES) + lane;
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      const int i = min(wave + C::NW * j, C::TILE_KB - 1);
-      dst[i * 64] = st[j];
-    }
+    for (int j = 0; j < NP; ++j) dst[min(wave + C::NW * j, C::TILE_KB - 1) * 64] = st[j];
   };
-  if constexpr (REGSTAGE) {
-    gload(0);
-    lstore(0);
-    if (n_tiles > 1) gload(1);
-  } else {
-    dma(0, 0);
-    if (n_tiles > 1) dma(1, 1);
-  }
+  gload(0);
+  lstore(0);
+  if (n_tiles > 1) gload(1);
   __syncthreads();
+
   float bA[HP], bB[HP];
   f32x16 accA, accB;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) accB[r] = INFINITY;  // "previous" scores of the first step: nothing passes
+  float athrA = athr, athrB = athr;
   load_b(0, bA);
-  float cnA = 0.f, cnB = 0.f;  // ||c||^2 of the lane's candidate in the sub-tile whose scores are in accA / accB
-  for (int t = 0; t < n_tiles; ++t) {
-    const int g = 4 * t;
-    cnA = bA[H];
-    step(g + 0, bA, accA, accB, cnB, bB);
-    cnB = bB[H];
-    step(g + 1, bB, accB, accA, cnA, bA);
-    cnA = bA[H];
-    step(g + 2, bA, accA, accB, cnB, bB);
-    cnB = bB[H];
-    if constexpr (REGSTAGE) {
-      if (t + 1 < n_tiles) lstore((t + 1) & 1);  // buffer of tile t-1: free since the previous barrier
-      if constexpr ((MODE & 4) == 0) __syncthreads();  // (MODE & 4: racy timing experiment)
-      if (t + 2 < n_tiles) gload(t + 2);
-    } else {
-      __syncthreads();
-      if (t + 2 < n_tiles) dma(t + 2, t & 1);
-    }
-    step(g + 3, bB, accB, accA, cnA, bA);
-  }
+  // sub-tile 0: plain scores (threshold 0), every finite one is inserted; afterwards all thresholds are finite
+  // whenever the data holds at least thr_rank rows
   {
-    unsigned long long m[16], any = 0;
+    f32x16 zero;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      m[r] = __ballot((accB[r] + cnB) < thr[r]);
-      any |= m[r];
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+    accB = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[0], bA[0], zero, 0, 0, 0);
+#pragma unroll
+    for (int s = 1; s < H; ++s) accB = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s], bA[s], accB, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_f32_32x32x2f32(athr, bA[H], accB, 0, 0, 0);
+    if constexpr (!NOINSERT) insert(accB, athr, 0, true);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accB[r] = INFINITY;  // "previous" scores of the first pipeline step: no hit
+  }
+  // sub-tile 0 is done: prefetch sub-tile 1; accA plays "previous scores" for the first pipeline step
+  load_b(1 < n_sub ? 1 : 0, bB);
+  accA = accB;
+  athrA = athrB;
+  // half-tile loop: h = 2t (sub-tiles 4t, 4t+1) and h = 2t+1 (sub-tiles 4t+2 | barrier | 4t+3); the body is two
+  // pipeline steps with the roles of the A/B register sets fixed, so the insertion code exists twice only
+  for (int h = 0; h < 2 * n_tiles; ++h) {
+    const int g = 2 * h;
+    if (h > 0) step(g, bA, accA, athrA, accB, athrB, bB);
+    if (h & 1) {
+      const int t = h >> 1;
+      if (t + 1 < n_tiles) lstore((t + 1) & 1);  // buffer of tile t-1: free since the previous barrier
+      // every wave has completed its reads of tile t except sub-tile 3 (already in bB): after the barrier tile
+      // t+1 is visible and the staging registers are free for tile t+2
+      if (!(NOINSERT && thr_rank == 31)) __syncthreads();  // (timing experiment: no barrier)
+      if (t + 2 < n_tiles) gload(t + 2);
     }
-    if (any) insert(accB, cnB, (n_sub - 1) * 32, m);
+    step(g + 1, bB, accB, athrB, accA, athrA, bA);
+  }
+  if constexpr (!NOINSERT) {
+    bool neg = false;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) neg |= accB[r] < 0.f;
+    if (__any(neg)) insert(accB, athrB, (n_sub - 1) * 32, false);
   }
 
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int64_t q = (int64_t)blockIdx.x * C::QB + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    cand_idx[q * C::KP + l31] = idx[r] + ((MODE & 2) ? dummy : 0);
-    if (l31 == thr_lane) cand_tau[q] = key[r];
+    cand_idx[q * C::KP + l31] = idx[r];
+    if (l31 == thr_lane) cand_tau[q] = NOINSERT ? key[r] + athr : key[r];
   }
 }
 
@@ -789,18 +789,18 @@ static int dispatch_kp(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, h
   }
 }
 
-static int knn_mode() {
-  static const int mode = [] {
-    const char* e = getenv("SCAMD_KNN_MODE");
-    return e ? atoi(e) : 1;
+static bool knn_noinsert() {  // SCAMD_KNN_NOINSERT=1: timing experiment (garbage results, passes 2/3 skipped)
+  static const bool v = [] {
+    const char* e = getenv("SCAMD_KNN_NOINSERT");
+    return e && e[0] == '1';
   }();
-  return mode;
+  return v;
 }
 
-template <int H, int MODE>
+template <int H, bool NOINSERT>
 static int launch_select_reg_mode(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, hipStream_t s) {
   using C = RegCfg<H>;
-  auto kern = knn_select_reg_kernel<H, MODE>;
+  auto kern = knn_select_reg_kernel<H, NOINSERT>;
   SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
   const int n_tiles = (int)(p.n_pad / C::TC);
@@ -813,13 +813,8 @@ static int launch_select_reg_mode(const KnnPlan& p, const KnnBuffers& b, int64_t
 
 template <int H>
 static int launch_select_reg(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, hipStream_t s) {
-  switch (knn_mode()) {
-    case 0: return launch_select_reg_mode<H, 0>(p, b, q_begin, s);
-    case 2: return launch_select_reg_mode<H, 2>(p, b, q_begin, s);
-    case 3: return launch_select_reg_mode<H, 3>(p, b, q_begin, s);
-    case 7: return launch_select_reg_mode<H, 7>(p, b, q_begin, s);
-    default: return launch_select_reg_mode<H, 1>(p, b, q_begin, s);
-  }
+  return knn_noinsert() ? launch_select_reg_mode<H, true>(p, b, q_begin, s)
+                        : launch_select_reg_mode<H, false>(p, b, q_begin, s);
 }
 
 static int dispatch_select(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, hipStream_t s) {
@@ -904,7 +899,7 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
     (void)hipEventDestroy(ev1);
     return rc;
   }
-  if (p.reg && (knn_mode() & 2)) {  // timing experiment: the candidate lists are garbage, skip passes 2/3
+  if (p.reg && knn_noinsert()) {  // timing experiment: the candidate lists are garbage, skip passes 2/3
     SCAMD_HIP_CHECK(hipStreamSynchronize(s));
     float ms = -1.f;
     if (hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) ms = -1.f;
