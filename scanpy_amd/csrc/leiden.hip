@@ -93,13 +93,55 @@ __global__ void ld_fill_u8_kernel(unsigned char* __restrict__ a, int n, unsigned
   if (i < n) a[i] = v;
 }
 
+// ---- block-local pre-aggregation of per-community reductions ---------------------------------------
+// Late in the optimisation a million vertices reduce into a few dozen communities: a global atomic per vertex
+// serialises on those few L2 lines (~12 ns each).  Every 1024-thread block first combines its vertices in an LDS
+// hash table (open addressing, <= 8 probes; a vertex that finds no slot goes to global memory directly) and then
+// issues one global atomic per distinct community it saw.  All reductions are integer (+, min): order free.
+constexpr int BH_SLOTS = 2048;
+constexpr int BH_EMPTY = -1;
+
+__device__ __forceinline__ int bh_find_slot(int* keys, int c) {
+  unsigned int slot = hash32((unsigned int)c) & (BH_SLOTS - 1);
+  for (int probe = 0; probe < 8; ++probe) {
+    const int prev = atomicCAS(&keys[slot], BH_EMPTY, c);
+    if (prev == BH_EMPTY || prev == c) return (int)slot;
+    slot = (slot + 1) & (BH_SLOTS - 1);
+  }
+  return -1;
+}
+
 // Ktot[c] = sum k[v], csize[c] = #members   (both zeroed by the caller)
-__global__ void ld_totals_kernel(const int* __restrict__ comm, const long long* __restrict__ k, int n,
-                                 unsigned long long* __restrict__ Ktot, int* __restrict__ csize) {
-  int v = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(1024) void ld_totals_kernel(const int* __restrict__ comm, const long long* __restrict__ k, int n,
+                                                         unsigned long long* __restrict__ Ktot, int* __restrict__ csize) {
+  __shared__ int keys[BH_SLOTS];
+  __shared__ unsigned long long ksum[BH_SLOTS];
+  __shared__ int cnt[BH_SLOTS];
+  for (int i = threadIdx.x; i < BH_SLOTS; i += 1024) {
+    keys[i] = BH_EMPTY;
+    ksum[i] = 0ull;
+    cnt[i] = 0;
+  }
+  __syncthreads();
+  const int v = blockIdx.x * 1024 + threadIdx.x;
   if (v < n) {
-    atomicAdd(&Ktot[comm[v]], (unsigned long long)k[v]);
-    atomicAdd(&csize[comm[v]], 1);
+    const int c = comm[v];
+    const int slot = bh_find_slot(keys, c);
+    if (slot >= 0) {
+      atomicAdd(&ksum[slot], (unsigned long long)k[v]);
+      atomicAdd(&cnt[slot], 1);
+    } else {
+      atomicAdd(&Ktot[c], (unsigned long long)k[v]);
+      atomicAdd(&csize[c], 1);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < BH_SLOTS; i += 1024) {
+    const int c = keys[i];
+    if (c != BH_EMPTY) {
+      atomicAdd(&Ktot[c], ksum[i]);
+      atomicAdd(&csize[c], cnt[i]);
+    }
   }
 }
 
@@ -466,15 +508,30 @@ __global__ void ld_flag_kernel(int n, const int* __restrict__ size, int* __restr
   if (v < n) flag[v] = size[v] > 0 ? 1 : 0;
 }
 
-// coarse id of every node + representative coarse id of its phase-1 community
-__global__ void ld_coarse_ids_kernel(int n, const int* __restrict__ ref, const int64_t* __restrict__ newid_of_ref,
-                                     const int* __restrict__ comm, int* __restrict__ cid, int* __restrict__ rep) {
-  int v = blockIdx.x * blockDim.x + threadIdx.x;
+// coarse id of every node + representative coarse id of its phase-1 community (min over its members)
+__global__ __launch_bounds__(1024) void ld_coarse_ids_kernel(int n, const int* __restrict__ ref,
+                                                             const int64_t* __restrict__ newid_of_ref,
+                                                             const int* __restrict__ comm, int* __restrict__ cid,
+                                                             int* __restrict__ rep) {
+  __shared__ int keys[BH_SLOTS];
+  __shared__ int mn[BH_SLOTS];
+  for (int i = threadIdx.x; i < BH_SLOTS; i += 1024) {
+    keys[i] = BH_EMPTY;
+    mn[i] = 0x7fffffff;
+  }
+  __syncthreads();
+  const int v = blockIdx.x * 1024 + threadIdx.x;
   if (v < n) {
     const int c = (int)newid_of_ref[ref[v]];
     cid[v] = c;
-    atomicMin(&rep[comm[v]], c);
+    const int cm = comm[v];
+    const int slot = bh_find_slot(keys, cm);
+    if (slot >= 0) atomicMin(&mn[slot], c);
+    else atomicMin(&rep[cm], c);
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < BH_SLOTS; i += 1024)
+    if (keys[i] != BH_EMPTY) atomicMin(&rep[keys[i]], mn[i]);
 }
 __global__ void ld_coarse_comm_kernel(int n, const int* __restrict__ cid, const int* __restrict__ comm,
                                       const int* __restrict__ rep, int* __restrict__ comm_new) {
@@ -605,13 +662,35 @@ __global__ __launch_bounds__(1024) void ld_sumsq_kernel(int n, const unsigned lo
 }
 
 // ---- final renumbering by decreasing size ------------------------------------------------------------
-__global__ void ld_minmember_kernel(int n, const int* __restrict__ memb, int* __restrict__ minmember,
-                                    int* __restrict__ size) {
-  int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v < n) {
-    atomicMin(&minmember[memb[v]], v);
-    atomicAdd(&size[memb[v]], 1);
+__global__ __launch_bounds__(1024) void ld_minmember_kernel(int n, const int* __restrict__ memb,
+                                                            int* __restrict__ minmember, int* __restrict__ size) {
+  __shared__ int keys[BH_SLOTS];
+  __shared__ int mn[BH_SLOTS];
+  __shared__ int cnt[BH_SLOTS];
+  for (int i = threadIdx.x; i < BH_SLOTS; i += 1024) {
+    keys[i] = BH_EMPTY;
+    mn[i] = 0x7fffffff;
+    cnt[i] = 0;
   }
+  __syncthreads();
+  const int v = blockIdx.x * 1024 + threadIdx.x;
+  if (v < n) {
+    const int c = memb[v];
+    const int slot = bh_find_slot(keys, c);
+    if (slot >= 0) {
+      atomicMin(&mn[slot], v);
+      atomicAdd(&cnt[slot], 1);
+    } else {
+      atomicMin(&minmember[c], v);
+      atomicAdd(&size[c], 1);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < BH_SLOTS; i += 1024)
+    if (keys[i] != BH_EMPTY) {
+      atomicMin(&minmember[keys[i]], mn[i]);
+      atomicAdd(&size[keys[i]], cnt[i]);
+    }
 }
 // compact list of non-empty communities: key = (~size << 32) | minmember  (ascending = size desc)
 __global__ void ld_commkeys_kernel(int n, const int* __restrict__ size, const int* __restrict__ minmember,
@@ -734,6 +813,7 @@ static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b
 
 #define GRID1(n) dim3((unsigned)ceil_div((n), 256)), dim3(256)
 #define GRIDW(n) dim3((unsigned)ceil_div((n), 4)), dim3(256)
+#define GRIDK(n) dim3((unsigned)ceil_div((n), 1024)), dim3(1024)
 
 struct LeidenCtx {
   hipStream_t s;
@@ -761,7 +841,7 @@ static int read_counters(LeidenCtx& cx, int* h, int cnt) {
 static int compute_totals(LeidenCtx& cx, const LevelGraph& g, const int* comm) {
   SCAMD_HIP_CHECK(hipMemsetAsync(cx.b.Ktot, 0, sizeof(unsigned long long) * g.n, cx.s));
   SCAMD_HIP_CHECK(hipMemsetAsync(cx.b.csize, 0, sizeof(int) * g.n, cx.s));
-  hipLaunchKernelGGL(ld_totals_kernel, GRID1(g.n), 0, cx.s, comm, g.k, g.n, cx.b.Ktot, cx.b.csize);
+  hipLaunchKernelGGL(ld_totals_kernel, GRIDK(g.n), 0, cx.s, comm, g.k, g.n, cx.b.Ktot, cx.b.csize);
   SCAMD_LAUNCH_CHECK();
   return SCAMD_OK;
 }
@@ -892,7 +972,7 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   *n_new = (int)nn;
   if (nn == g.n) return SCAMD_OK;
   SCAMD_HIP_CHECK(hipMemsetAsync(b.rep, 0x7f, sizeof(int) * g.n, cx.s));
-  hipLaunchKernelGGL(ld_coarse_ids_kernel, GRID1(g.n), 0, cx.s, g.n, b.ref, b.newid, b.comm, b.cid, b.rep);
+  hipLaunchKernelGGL(ld_coarse_ids_kernel, GRIDK(g.n), 0, cx.s, g.n, b.ref, b.newid, b.comm, b.cid, b.rep);
   SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(ld_coarse_comm_kernel, GRID1(g.n), 0, cx.s, g.n, b.cid, b.comm, b.rep, b.comm_tmp);
   SCAMD_LAUNCH_CHECK();
@@ -966,7 +1046,7 @@ static int renumber(LeidenCtx& cx, int n, int* n_comm) {
   LeidenBuffers& b = cx.b;
   SCAMD_HIP_CHECK(hipMemsetAsync(b.minmember, 0x7f, sizeof(int) * n, cx.s));
   SCAMD_HIP_CHECK(hipMemsetAsync(b.csize, 0, sizeof(int) * n, cx.s));
-  hipLaunchKernelGGL(ld_minmember_kernel, GRID1(n), 0, cx.s, n, b.memb, b.minmember, b.csize);
+  hipLaunchKernelGGL(ld_minmember_kernel, GRIDK(n), 0, cx.s, n, b.memb, b.minmember, b.csize);
   SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(ld_flag_kernel, GRID1(n), 0, cx.s, n, b.csize, b.flag);
   SCAMD_LAUNCH_CHECK();
