@@ -14,7 +14,7 @@
 //   2. knn_rerank_kernel   float64 (q-c)^2 re-evaluation of the KP candidates, ordering by
 //      (distance, index), explicit self column, and a certificate: the k-th exact distance must
 //      lie below the final threshold by more than the float32 error bound of pass 1.
-//   3. knn_fallback_kernel float64 scan of all rows for the (rare) uncertified queries.
+//   3. knn_fallback_scan/rank_kernel  float64 scan of all rows for the (rare) uncertified queries.
 //
 // Roofline: pass 1 is FP32-MFMA bound (2*n_query*n*2H flop); passes 2/3 are negligible.
 #include "common.h"
@@ -633,28 +633,30 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass 3: float64 scan for uncertified queries.  One 256-thread block per query.  Collects every
-// row with exact d^2 <= bound (the k-th exact distance among the candidates, an upper bound of the
-// true k-th distance), then rank-sorts the collection.
+// pass 3: float64 scan for uncertified queries, two kernels.
+//   scan: grid (row chunks, queries): every block scans one chunk of the rows and appends each row whose exact d^2
+//         is <= bound (the k-th exact distance among the candidates, an upper bound of the true k-th distance)
+//         to the query's collection (one global counter per query; order irrelevant, the rank step sorts);
+//   rank: one block per query rank-sorts the collection by (distance, index) and writes the k-1 best.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void knn_fallback_kernel(
-    const float* __restrict__ x, int64_t n, int d, int64_t ld, int64_t q_begin, int k,
-    const int* __restrict__ flag_list, int flag_begin, int flag_count,
-    const double* __restrict__ kth_d2, int32_t* __restrict__ out_idx, double* __restrict__ out_dist,
-    double* __restrict__ scratch_d, int* __restrict__ scratch_i, int* __restrict__ overflow) {
+constexpr int FALLBACK_ROW_CHUNKS = 128;
+
+__global__ __launch_bounds__(256) void knn_fallback_scan_kernel(
+    const float* __restrict__ x, int64_t n, int d, int64_t ld, int64_t q_begin,
+    const int* __restrict__ flag_list, int flag_begin, const double* __restrict__ kth_d2,
+    double* __restrict__ scratch_d, int* __restrict__ scratch_i, int* __restrict__ counts) {
   __shared__ float qs[128];
-  __shared__ int cnt;
-  const int fb = blockIdx.x;
-  if (fb >= flag_count) return;
+  const int fb = blockIdx.y;
   const int64_t qi = flag_list[flag_begin + fb];
   const int64_t q = q_begin + qi;
   double* bd = scratch_d + (int64_t)fb * FALLBACK_CAP;
   int* bi = scratch_i + (int64_t)fb * FALLBACK_CAP;
   for (int c = threadIdx.x; c < d; c += blockDim.x) qs[c] = x[q * ld + c];
-  if (threadIdx.x == 0) cnt = 0;
   __syncthreads();
   const double bound = kth_d2[qi];
-  for (int64_t r = threadIdx.x; r < n; r += blockDim.x) {
+  const int64_t rows_per_chunk = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk, r1 = std::min<int64_t>(n, r0 + rows_per_chunk);
+  for (int64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
     if (r == q) continue;
     const float* cp = x + r * ld;
     double s = 0.0;
@@ -663,20 +665,28 @@ __global__ __launch_bounds__(256) void knn_fallback_kernel(
       s = fma(df, df, s);
     }
     if (s <= bound) {
-      int slot = atomicAdd(&cnt, 1);
+      int slot = atomicAdd(&counts[fb], 1);
       if (slot < FALLBACK_CAP) {
         bd[slot] = s;
         bi[slot] = (int)r;
       }
     }
   }
-  __syncthreads();
-  int m = cnt;
+}
+
+__global__ __launch_bounds__(256) void knn_fallback_rank_kernel(
+    int k, const int* __restrict__ flag_list, int flag_begin, const double* __restrict__ scratch_d,
+    const int* __restrict__ scratch_i, const int* __restrict__ counts, int32_t* __restrict__ out_idx,
+    double* __restrict__ out_dist, int* __restrict__ overflow) {
+  const int fb = blockIdx.x;
+  const int64_t qi = flag_list[flag_begin + fb];
+  const double* bd = scratch_d + (int64_t)fb * FALLBACK_CAP;
+  const int* bi = scratch_i + (int64_t)fb * FALLBACK_CAP;
+  int m = counts[fb];
   if (m > FALLBACK_CAP) {
     if (threadIdx.x == 0) atomicAdd(overflow, 1);
     m = FALLBACK_CAP;
   }
-  __threadfence_block();
   const int kk = k - 1;
   for (int u = threadIdx.x; u < m; u += blockDim.x) {
     double du = bd[u];
@@ -750,7 +760,7 @@ static bool knn_plan(int64_t n, int d, int64_t n_query, int k, KnnPlan* p) {
 
 struct KnnBuffers {
   float* xp; float* cn; unsigned int* cmax; int* cand_idx; float* cand_tau; double* kth_d2;
-  int* flag_list; int* counters; double* scratch_d; int* scratch_i;
+  int* flag_list; int* counters; double* scratch_d; int* scratch_i; int* fb_counts;
 };
 
 static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffers* b) {
@@ -764,6 +774,7 @@ static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffe
   b->counters = ws.take<int>(4);
   b->scratch_d = ws.take<double>((size_t)FALLBACK_CHUNK * FALLBACK_CAP);
   b->scratch_i = ws.take<int>((size_t)FALLBACK_CHUNK * FALLBACK_CAP);
+  b->fb_counts = ws.take<int>((size_t)FALLBACK_CHUNK);
 }
 
 template <int H, int TC, int NW, int KP>
@@ -934,9 +945,13 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
   if (n_fallback_host) *n_fallback_host = n_flag;
   for (int begin = 0; begin < n_flag; begin += FALLBACK_CHUNK) {
     int count = std::min(FALLBACK_CHUNK, n_flag - begin);
-    hipLaunchKernelGGL(knn_fallback_kernel, dim3(count), dim3(256), 0, s, x, n, d, ld_x, q_begin, k,
-                       b.flag_list, begin, count, b.kth_d2, out_idx, out_dist, b.scratch_d,
-                       b.scratch_i, b.counters + 1);
+    SCAMD_HIP_CHECK(hipMemsetAsync(b.fb_counts, 0, sizeof(int) * count, s));
+    const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(FALLBACK_ROW_CHUNKS, n / 2048));
+    hipLaunchKernelGGL(knn_fallback_scan_kernel, dim3(chunks, count), dim3(256), 0, s, x, n, d, ld_x, q_begin,
+                       b.flag_list, begin, b.kth_d2, b.scratch_d, b.scratch_i, b.fb_counts);
+    SCAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(knn_fallback_rank_kernel, dim3(count), dim3(256), 0, s, k, b.flag_list, begin, b.scratch_d,
+                       b.scratch_i, b.fb_counts, out_idx, out_dist, b.counters + 1);
     SCAMD_LAUNCH_CHECK();
   }
   if (n_flag > 0) {
