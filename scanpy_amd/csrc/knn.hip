@@ -286,20 +286,22 @@ __global__ __launch_bounds__(NW * 64) void knn_select_kernel(const float* __rest
 //     rare insertion sits between two chains.
 // Candidates are streamed as a verbatim image of the LDS tile (row = [dims 0..H-1, 1.0, 0.. | dims H..2H-1,
 // ||c||^2, 0.. | pad], stride DPL dwords = 4 mod 8 so the b128 fragment reads are conflict free), staged
-// global_load_dwordx4 -> ds_write_b128, double buffered, one barrier per 128-candidate tile.  (An LDS-DMA
+// global_load_dwordx4 -> ds_write_b128, double buffered, one barrier per 64-candidate tile.  (An LDS-DMA
 // variant measured the same: hipcc puts a vmcnt(0) in front of every ds_read that follows an LDS-DMA.)  LDS holds
-// only the two tiles (60 KB) and the kernel needs < 256 VGPRs, so two 4-wave blocks share a CU and cover each
-// other's barrier and insertion stalls.
+// only the two tiles (30 KB) and the kernel fits 168 VGPRs, so three 4-wave blocks share a CU and cover each
+// other's barrier and insertion stalls.  (Tried and dropped: wave-private sub-tiles without any barrier, 4x the
+// L2->LDS traffic, 973 vs 828 ms; splitting the last partial round of the grid over candidate segments, no gain:
+// a partially filled round already runs its blocks up to 3x faster.)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float readlane_f32(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-template <int H>
+template <int H, int TC_ = 64>
 struct RegCfg {
   static constexpr int HP = (H + 1 + 3) / 4 * 4;  // dims of one half + the extra k slot, rounded up to 4
   static constexpr int DPL = (2 * HP) % 8 == 4 ? 2 * HP : 2 * HP + 4;
-  static constexpr int TC = 128, NW = 4, QB = 128, NT = 256, KP = 32;
+  static constexpr int TC = TC_, SUBS = TC_ / 32, NW = 4, QB = 128, NT = 256, KP = 32;
   static constexpr int TILE_BYTES = TC * DPL * 4;
   static constexpr int TILE_KB = TILE_BYTES / 1024;
   static constexpr size_t LDS_BYTES = 2 * (size_t)TILE_BYTES;
@@ -340,13 +342,14 @@ __global__ void knn_pack_image_kernel(const float* __restrict__ x, int64_t n, in
 }
 
 // NOINSERT = true: timing experiment only (the lists stay empty, results are garbage)
-template <int H, bool NOINSERT>
-__global__ __launch_bounds__(256, 2) void knn_select_reg_kernel(const float* __restrict__ xp, int n_tiles,
-                                                                int64_t n_pad, int64_t q_begin,
-                                                                int thr_rank, int* __restrict__ cand_idx,
-                                                                float* __restrict__ cand_tau) {
-  using C = RegCfg<H>;
-  constexpr int HP = C::HP, DPL = C::DPL, TC = C::TC;
+// TC_ = candidates per LDS tile, WPS = resident blocks per CU (= waves per SIMD) the register budget is cut for
+template <int H, bool NOINSERT, int TC_, int WPS>
+__global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* __restrict__ xp, int n_tiles,
+                                                                  int64_t n_pad, int64_t q_begin,
+                                                                  int thr_rank, int* __restrict__ cand_idx,
+                                                                  float* __restrict__ cand_tau) {
+  using C = RegCfg<H, TC_>;
+  constexpr int HP = C::HP, DPL = C::DPL, TC = C::TC, SUBS = C::SUBS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -376,8 +379,8 @@ __global__ __launch_bounds__(256, 2) void knn_select_reg_kernel(const float* __r
   // B operand of sub-tile g (global sub-tile counter: tile g>>2, rows (g&3)*32 ..): lane l holds candidate
   // (l&31), the same dim slice as A, then the extra k slot
   auto load_b = [&](int g, float (&b)[HP]) {
-    const float* tb = smem + ((g >> 2) & 1) * TC * DPL;
-    const float4* p = reinterpret_cast<const float4*>(tb + ((g & 3) * 32 + l31) * DPL + half * HP);
+    const float* tb = smem + ((g / SUBS) & 1) * TC * DPL;
+    const float4* p = reinterpret_cast<const float4*>(tb + ((g % SUBS) * 32 + l31) * DPL + half * HP);
 #pragma unroll
     for (int s4 = 0; s4 < HP / 4; ++s4) {
       const float4 v = p[s4];
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void knn_select_reg_kernel(const float* __r
       }
     }
   };
-  const int n_sub = n_tiles * 4;
+  const int n_sub = n_tiles * SUBS;
   // One pipeline step = ONE scheduling region: chain of sub-tile g into acc_cur (with the thresholds in athr),
   // fragment reads of sub-tile g+1, sign test of the previous sub-tile's accumulator.
   auto step = [&](int g, float (&b_cur)[HP], f32x16& acc_cur, float& athr_cur, const f32x16& acc_prev,
@@ -500,11 +503,12 @@ __global__ __launch_bounds__(256, 2) void knn_select_reg_kernel(const float* __r
   athrA = athrB;
   // half-tile loop: h = 2t (sub-tiles 4t, 4t+1) and h = 2t+1 (sub-tiles 4t+2 | barrier | 4t+3); the body is two
   // pipeline steps with the roles of the A/B register sets fixed, so the insertion code exists twice only
-  for (int h = 0; h < 2 * n_tiles; ++h) {
+  constexpr int HPT = SUBS / 2;  // loop iterations (two sub-tiles each) per tile
+  for (int h = 0; h < HPT * n_tiles; ++h) {
     const int g = 2 * h;
     if (h > 0) step(g, bA, accA, athrA, accB, athrB, bB);
-    if (h & 1) {
-      const int t = h >> 1;
+    if ((h % HPT) == HPT - 1) {
+      const int t = h / HPT;
       if (t + 1 < n_tiles) lstore((t + 1) & 1);  // buffer of tile t-1: free since the previous barrier
       // every wave has completed its reads of tile t except sub-tile 3 (already in bB): after the barrier tile
       // t+1 is visible and the staging registers are free for tile t+2
@@ -808,10 +812,10 @@ static bool knn_noinsert() {  // SCAMD_KNN_NOINSERT=1: timing experiment (garbag
   return v;
 }
 
-template <int H, bool NOINSERT>
+template <int H, bool NOINSERT, int TC_, int WPS>
 static int launch_select_reg_mode(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, hipStream_t s) {
-  using C = RegCfg<H>;
-  auto kern = knn_select_reg_kernel<H, NOINSERT>;
+  using C = RegCfg<H, TC_>;
+  auto kern = knn_select_reg_kernel<H, NOINSERT, TC_, WPS>;
   SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
   const int n_tiles = (int)(p.n_pad / C::TC);
@@ -824,8 +828,15 @@ static int launch_select_reg_mode(const KnnPlan& p, const KnnBuffers& b, int64_t
 
 template <int H>
 static int launch_select_reg(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, hipStream_t s) {
-  return knn_noinsert() ? launch_select_reg_mode<H, true>(p, b, q_begin, s)
-                        : launch_select_reg_mode<H, false>(p, b, q_begin, s);
+  // 64-candidate tiles (30 KB of LDS per block) and <= 168 VGPRs: three 4-wave blocks share a CU and cover each
+  // other's barrier / insertion stalls (measured 812 vs 831 ms at 1M against 128-candidate tiles, two blocks)
+  static const bool big_tiles = [] {
+    const char* e = getenv("SCAMD_KNN_BIG_TILES");
+    return e && e[0] == '1';
+  }();
+  if (knn_noinsert()) return launch_select_reg_mode<H, true, 64, 3>(p, b, q_begin, s);
+  if (big_tiles) return launch_select_reg_mode<H, false, 128, 2>(p, b, q_begin, s);
+  return launch_select_reg_mode<H, false, 64, 3>(p, b, q_begin, s);
 }
 
 static int dispatch_select(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, hipStream_t s) {
