@@ -170,6 +170,92 @@ __device__ __forceinline__ Cand wave_best(Cand x) {
   return x;
 }
 
+// ---- per-wave LDS hash: weight towards each distinct neighbouring group --------------------------------
+// A vertex with <= WH_MAX_DEG neighbours accumulates sum_w per distinct group id (community / refined community)
+// in a 128-slot open-addressing table private to its wave: O(deg) LDS atomics instead of the O(deg^2) all-pairs
+// readlane compare (which remains the path for the few high-degree coarse vertices).  Integer adds: the sums do
+// not depend on the order of insertion; the table is read back two slots per lane.
+constexpr int WH_SLOTS = 128;
+constexpr int WH_MAX_DEG = 96;
+constexpr int WH_EMPTY = -1;
+
+struct WaveHash {
+  int* keys;                 // [WH_SLOTS]
+  unsigned long long* vals;  // [WH_SLOTS]
+  __device__ __forceinline__ void clear(int lane) {
+    keys[lane] = WH_EMPTY;
+    keys[lane + 64] = WH_EMPTY;
+    vals[lane] = 0ull;
+    vals[lane + 64] = 0ull;
+  }
+  __device__ __forceinline__ void add(int c, long long w) {
+    unsigned int slot = hash32((unsigned int)c) & (WH_SLOTS - 1);
+    for (;;) {
+      const int prev = atomicCAS(&keys[slot], WH_EMPTY, c);
+      if (prev == WH_EMPTY || prev == c) break;
+      slot = (slot + 1) & (WH_SLOTS - 1);
+    }
+    atomicAdd(&vals[slot], (unsigned long long)w);
+  }
+  __device__ __forceinline__ int key(int slot) const { return __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  __device__ __forceinline__ long long val(int slot) const {
+    return (long long)__hip_atomic_load(&vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+};
+
+// ---- high-degree vertices: one workgroup per vertex, 8192-slot LDS table ---------------------------------
+// kNN graphs have hubs (in-degree in the thousands) and aggregated graphs are dense: the wave-per-vertex kernels
+// hand every vertex with more than WH_MAX_DEG neighbours to these block-per-vertex kernels (hub list filled
+// through counters[4]) instead of letting ONE wave grind through an O(deg^2) compare while the grid waits.
+constexpr int BHUB_SLOTS = 8192;
+constexpr int BHUB_MAX_DEG = 6000;  // beyond it (table load > 0.73) the all-pairs wave path is used
+
+struct BlockHash {
+  int* keys;
+  unsigned long long* vals;
+  int nslots;  // power of two >= 2 * deg (256 .. BHUB_SLOTS): clearing and scanning cost O(deg), not O(table)
+  __device__ __forceinline__ void size_for(int deg) {
+    int s = 256;
+    while (s < 2 * deg && s < BHUB_SLOTS) s <<= 1;
+    nslots = s;
+  }
+  __device__ __forceinline__ void clear() {
+    for (int i = threadIdx.x; i < nslots; i += blockDim.x) {
+      keys[i] = WH_EMPTY;
+      vals[i] = 0ull;
+    }
+  }
+  __device__ __forceinline__ void add(int c, long long w) {
+    unsigned int slot = hash32((unsigned int)c) & (nslots - 1);
+    for (;;) {
+      const int prev = atomicCAS(&keys[slot], WH_EMPTY, c);
+      if (prev == WH_EMPTY || prev == c) break;
+      slot = (slot + 1) & (nslots - 1);
+    }
+    atomicAdd(&vals[slot], (unsigned long long)w);
+  }
+};
+
+// block-wide argmax of candidates (+ max of w_own); result valid in thread 0
+__device__ __forceinline__ Cand block_best(Cand x, long long& w_own, Cand* sh_c, long long* sh_w) {
+  x = wave_best(x);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) w_own = max(w_own, __shfl_xor(w_own, o));
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sh_c[wv] = x;
+    sh_w[wv] = w_own;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) {
+      if (cand_better(sh_c[i], x)) x = sh_c[i];
+      w_own = max(w_own, sh_w[i]);
+    }
+  }
+  return x;
+}
+
 // ---- phase 1: local moving -------------------------------------------------------------------------
 // Round = decide (one wave per ACTIVE vertex, reads the state only) -> apply (one thread per active vertex,
 // mutates the state, flags the vertices to revisit) -> compact (flags -> next active list + counters).  No
@@ -182,21 +268,52 @@ __global__ __launch_bounds__(256) void ld_move_kernel(
     int n_act, const int* __restrict__ list, const int64_t* __restrict__ indptr, const int* __restrict__ indices,
     const long long* __restrict__ wq, const long long* __restrict__ k, const int* __restrict__ comm,
     const unsigned long long* __restrict__ Ktot, const int* __restrict__ csize, double g /* gamma / 2m */,
-    int round, unsigned int seed, int* __restrict__ decision) {
+    int round, unsigned int seed, int* __restrict__ decision, int* __restrict__ hub_list,
+    int* __restrict__ counters) {
   const int lane = threadIdx.x & 63;
   const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (w >= n_act) return;
   const int v = list[w];
-  const int a = comm[v];
-  const double kv = (double)k[v];
   const int64_t beg = indptr[v];
   const int deg = (int)(indptr[v + 1] - beg);
+  if (deg > WH_MAX_DEG && deg <= BHUB_MAX_DEG) {  // hub: decided by ld_move_hub_kernel
+    if (lane == 0) hub_list[atomicAdd(&counters[4], 1)] = w;
+    return;
+  }
+  const int a = comm[v];
+  const double kv = (double)k[v];
   const double Ka_wo = (double)(long long)(Ktot[a] - (unsigned long long)k[v]);  // own community without v
   Cand best;
   best.val = 0.0;
   best.c = -1;
   best.pr = 0;
   long long w_own = 0;
+  if (deg <= WH_MAX_DEG) {
+    __shared__ int hkeys[4][WH_SLOTS];
+    __shared__ unsigned long long hvals[4][WH_SLOTS];
+    WaveHash wh{hkeys[threadIdx.x >> 6], hvals[threadIdx.x >> 6]};
+    wh.clear(lane);
+    for (int e = lane; e < deg; e += 64) {
+      const int u = indices[beg + e];
+      if (u != v) wh.add(comm[u], wq[beg + e]);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = wh.key(lane + 64 * h);
+      if (c != WH_EMPTY) {
+        const long long sum = wh.val(lane + 64 * h);
+        if (c == a) {
+          w_own = sum;
+        } else {
+          Cand x;
+          x.val = (double)sum - g * kv * (double)(long long)Ktot[c];
+          x.c = c;
+          x.pr = prio(c, seed);
+          if (cand_better(x, best)) best = x;
+        }
+      }
+    }
+  } else
   for (int cb = 0; cb < deg; cb += 64) {
     const int e = cb + lane;
     int u = (e < deg) ? indices[beg + e] : -1;
@@ -249,6 +366,73 @@ __global__ __launch_bounds__(256) void ld_move_kernel(
     target = v;
   }
   if (lane == 0) decision[w] = (wants && allowed) ? target : (wants ? -2 : -1);
+}
+
+// Hub vertices of the active list (positions in hub_list[0 .. counters[4])): one workgroup each.
+__global__ __launch_bounds__(256) void ld_move_hub_kernel(
+    const int* __restrict__ hub_list, const int* __restrict__ counters, const int* __restrict__ list,
+    const int64_t* __restrict__ indptr, const int* __restrict__ indices, const long long* __restrict__ wq,
+    const long long* __restrict__ k, const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot,
+    const int* __restrict__ csize, double g, int round, unsigned int seed, int* __restrict__ decision) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long hub_smem[];
+  BlockHash bh{reinterpret_cast<int*>(hub_smem + BHUB_SLOTS), hub_smem, BHUB_SLOTS};
+  __shared__ Cand sh_c[4];
+  __shared__ long long sh_w[4];
+  const int n_hub = counters[4];
+  for (int i = blockIdx.x; i < n_hub; i += gridDim.x) {
+    const int w = hub_list[i];
+    const int v = list[w];
+    const int a = comm[v];
+    const double kv = (double)k[v];
+    const int64_t beg = indptr[v];
+    const int deg = (int)(indptr[v + 1] - beg);
+    const double Ka_wo = (double)(long long)(Ktot[a] - (unsigned long long)k[v]);
+    bh.size_for(deg);
+    bh.clear();
+    __syncthreads();
+    for (int e = threadIdx.x; e < deg; e += blockDim.x) {
+      const int u = indices[beg + e];
+      if (u != v) bh.add(comm[u], wq[beg + e]);
+    }
+    __syncthreads();
+    Cand best;
+    best.val = 0.0;
+    best.c = -1;
+    best.pr = 0;
+    long long w_own = 0;
+    for (int sl = threadIdx.x; sl < bh.nslots; sl += blockDim.x) {
+      const int c = bh.keys[sl];
+      if (c != WH_EMPTY) {
+        const long long sum = (long long)bh.vals[sl];
+        if (c == a) {
+          w_own = sum;
+        } else {
+          Cand x;
+          x.val = (double)sum - g * kv * (double)(long long)Ktot[c];
+          x.c = c;
+          x.pr = prio(c, seed);
+          if (cand_better(x, best)) best = x;
+        }
+      }
+    }
+    best = block_best(best, w_own, sh_c, sh_w);
+    if (threadIdx.x == 0) {
+      const double stay = (double)w_own - g * kv * Ka_wo;
+      int target = a;
+      bool wants = false, allowed = true;
+      if (best.c >= 0 && best.val > stay) {
+        wants = true;
+        target = best.c;
+        const unsigned int pa = prio(a, seed), pb = best.pr;
+        allowed = (round & 1) ? (pb > pa || (pb == pa && target > a)) : (pb < pa || (pb == pa && target < a));
+      } else if (stay < 0.0 && Ka_wo > 0.0 && csize[v] == 0) {
+        wants = true;
+        target = v;
+      }
+      decision[w] = (wants && allowed) ? target : (wants ? -2 : -1);
+    }
+    __syncthreads();
+  }
 }
 
 // One thread per active vertex: apply the decided moves in place (integer atomics on the community totals) and
@@ -404,7 +588,7 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
     const long long* __restrict__ wq, const long long* __restrict__ k, const int* __restrict__ comm,
     const unsigned long long* __restrict__ Ktot, const int* __restrict__ ref, const int* __restrict__ refsize,
     const unsigned long long* __restrict__ Kref, const unsigned long long* __restrict__ Eref, double g, int round,
-    unsigned int seed, int* __restrict__ target) {
+    unsigned int seed, int* __restrict__ target, int* __restrict__ hub_list, int* __restrict__ counters) {
   const int lane = threadIdx.x & 63;
   const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (w >= n_cand) return;
@@ -418,10 +602,43 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
     const double KC = (double)(long long)Ktot[a];
     const int64_t beg = indptr[v];
     const int deg = (int)(indptr[v + 1] - beg);
+    if (deg > WH_MAX_DEG && deg <= BHUB_MAX_DEG) {  // hub: proposed by ld_refine_propose_hub_kernel
+      if (lane == 0) hub_list[atomicAdd(&counters[4], 1)] = v;
+      return;
+    }
     Cand best;
     best.val = 0.0;
     best.c = -1;
     best.pr = 0;
+    if (deg <= WH_MAX_DEG) {
+      __shared__ int hkeys[4][WH_SLOTS];
+      __shared__ unsigned long long hvals[4][WH_SLOTS];
+      WaveHash wh{hkeys[threadIdx.x >> 6], hvals[threadIdx.x >> 6]};
+      wh.clear(lane);
+      for (int e = lane; e < deg; e += 64) {
+        const int u = indices[beg + e];
+        if (u != v && comm[u] == a) wh.add(ref[u], wq[beg + e]);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = wh.key(lane + 64 * h);
+        if (c != WH_EMPTY && c != v) {
+          const long long sum = wh.val(lane + 64 * h);
+          const double Kr = (double)(long long)Kref[c];
+          const bool single = refsize[c] == 1;
+          const bool ok_target = (!single || !mover_bit(c, round, seed)) &&
+                                 ((double)(long long)Eref[c] >= g * Kr * (KC - Kr));  // target well connected
+          const double gain = (double)sum - g * kv * Kr;
+          if (ok_target && gain >= 0.0) {
+            Cand x;
+            x.val = gain;
+            x.c = c;
+            x.pr = prio(c, seed);
+            if (cand_better(x, best)) best = x;
+          }
+        }
+      }
+    } else
     for (int cb = 0; cb < deg; cb += 64) {
       const int e = cb + lane;
       int u = (e < deg) ? indices[beg + e] : -1;
@@ -464,6 +681,62 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
     tgt = best.c;
   }
   if (lane == 0) target[v] = tgt;
+}
+
+// Hub candidates (vertex ids in hub_list[0 .. counters[4])): one workgroup each; same rule as the wave kernel.
+__global__ __launch_bounds__(256) void ld_refine_propose_hub_kernel(
+    const int* __restrict__ hub_list, const int* __restrict__ counters, const int64_t* __restrict__ indptr,
+    const int* __restrict__ indices, const long long* __restrict__ wq, const long long* __restrict__ k,
+    const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot, const int* __restrict__ ref,
+    const int* __restrict__ refsize, const unsigned long long* __restrict__ Kref,
+    const unsigned long long* __restrict__ Eref, double g, int round, unsigned int seed, int* __restrict__ target) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long hub_smem[];
+  BlockHash bh{reinterpret_cast<int*>(hub_smem + BHUB_SLOTS), hub_smem, BHUB_SLOTS};
+  __shared__ Cand sh_c[4];
+  __shared__ long long sh_w[4];
+  const int n_hub = counters[4];
+  for (int i = blockIdx.x; i < n_hub; i += gridDim.x) {
+    const int v = hub_list[i];
+    const double kv = (double)k[v];
+    const int a = comm[v];
+    const double KC = (double)(long long)Ktot[a];
+    const int64_t beg = indptr[v];
+    const int deg = (int)(indptr[v + 1] - beg);
+    bh.size_for(deg);
+    bh.clear();
+    __syncthreads();
+    for (int e = threadIdx.x; e < deg; e += blockDim.x) {
+      const int u = indices[beg + e];
+      if (u != v && comm[u] == a) bh.add(ref[u], wq[beg + e]);
+    }
+    __syncthreads();
+    Cand best;
+    best.val = 0.0;
+    best.c = -1;
+    best.pr = 0;
+    long long dummy = 0;
+    for (int sl = threadIdx.x; sl < bh.nslots; sl += blockDim.x) {
+      const int c = bh.keys[sl];
+      if (c != WH_EMPTY && c != v) {
+        const long long sum = (long long)bh.vals[sl];
+        const double Kr = (double)(long long)Kref[c];
+        const bool single = refsize[c] == 1;
+        const bool ok_target = (!single || !mover_bit(c, round, seed)) &&
+                               ((double)(long long)Eref[c] >= g * Kr * (KC - Kr));
+        const double gain = (double)sum - g * kv * Kr;
+        if (ok_target && gain >= 0.0) {
+          Cand x;
+          x.val = gain;
+          x.c = c;
+          x.pr = prio(c, seed);
+          if (cand_better(x, best)) best = x;
+        }
+      }
+    }
+    best = block_best(best, dummy, sh_c, sh_w);
+    if (threadIdx.x == 0) target[v] = best.c;
+    __syncthreads();
+  }
 }
 
 // counters: [0] merges, [2] next candidate list length
@@ -744,7 +1017,7 @@ struct LeidenBuffers {
   long long* wq0; long long* k0;
   CoarseBuf cb[2];
   int* comm; int* comm_next; int* csize; int* csize_next; unsigned long long* Ktot; unsigned long long* Ktot_next;
-  int* list_a; int* list_b; int* rlist; int* touched;
+  int* list_a; int* list_b; int* rlist; int* touched; int* hub_list;
   int* ref; int* target; int* refsize; unsigned long long* Kref; unsigned long long* Eref; long long* a_in;
   int* flag; int64_t* newid; int64_t* scan_tmp; int* cid; int* rep; int* comm_tmp;
   int* node_of; int* memb; int* memb_best;
@@ -779,6 +1052,7 @@ static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b
   b->list_a = ws.take<int>(N);
   b->list_b = ws.take<int>(N);
   b->rlist = ws.take<int>(N);
+  b->hub_list = ws.take<int>(N);
   b->touched = ws.take<int>(N);
   b->ref = ws.take<int>(N);
   b->target = ws.take<int>(N);
@@ -814,6 +1088,8 @@ static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b
 #define GRID1(n) dim3((unsigned)ceil_div((n), 256)), dim3(256)
 #define GRIDW(n) dim3((unsigned)ceil_div((n), 4)), dim3(256)
 #define GRIDK(n) dim3((unsigned)ceil_div((n), 1024)), dim3(1024)
+constexpr int HUB_GRID = 512;
+constexpr size_t HUB_LDS = (size_t)BHUB_SLOTS * 12;
 
 struct LeidenCtx {
   hipStream_t s;
@@ -878,7 +1154,10 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
   for (int round = 0; round < MAX_LM_ROUNDS && n_act > 0; ++round) {
     SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
     hipLaunchKernelGGL(ld_move_kernel, GRIDW(n_act), 0, cx.s, n_act, b.list_a, g.indptr, g.indices, g.wq, g.k, b.comm,
-                       b.Ktot, b.csize, gg, round, cx.seed, b.target);
+                       b.Ktot, b.csize, gg, round, cx.seed, b.target, b.hub_list, b.counters);
+    SCAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ld_move_hub_kernel, dim3(HUB_GRID), dim3(256), HUB_LDS, cx.s, b.hub_list, b.counters, b.list_a,
+                       g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg, round, cx.seed, b.target);
     SCAMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(ld_apply_kernel, GRID1(n_act), 0, cx.s, n_act, b.list_a, b.target, g.indptr, g.indices, g.k,
                        b.comm, b.Ktot, b.csize, b.flag, b.counters);
@@ -926,7 +1205,12 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
   for (int round = 0; round < MAX_RF_ROUNDS && n_cand > 0; ++round) {
     SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
     hipLaunchKernelGGL(ld_refine_propose_kernel, GRIDW(n_cand), 0, cx.s, n_cand, b.list_a, g.indptr, g.indices, g.wq,
-                       g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, gg, round, cx.seed, b.target);
+                       g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, gg, round, cx.seed, b.target, b.hub_list,
+                       b.counters);
+    SCAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ld_refine_propose_hub_kernel, dim3(HUB_GRID), dim3(256), HUB_LDS, cx.s, b.hub_list, b.counters,
+                       g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, gg, round,
+                       cx.seed, b.target);
     SCAMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(ld_refine_apply_kernel, GRID1(n_cand), 0, cx.s, n_cand, b.list_a, b.target, g.k, b.ref,
                        b.refsize, b.Kref, b.touched, b.list_b, b.counters);
@@ -1125,6 +1409,10 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
   leiden_carve(ws, n, nnz, &cx.b);
   SCAMD_REQUIRE(workspace && ws.ok, SCAMD_EWORKSPACE, "leiden: workspace %zu < required %zu", workspace_bytes,
                 ws.used());
+  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ld_move_hub_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)HUB_LDS));
+  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ld_refine_propose_hub_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)HUB_LDS));
   LevelGraph g0;
   int rc = setup_level0(cx, indptr, indices, weights, n, nnz, &g0);
   if (rc != SCAMD_OK) return rc;
