@@ -79,6 +79,16 @@ def cpu_baseline(n_sample: int, n_vars: int, n_comps: int, k: int, seed: int) ->
     }
 
 
+def _profiled_traffic():
+    """HBM-side bytes per launch of the roofline kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE are separate profiling runs, they cannot be taken inside this process); None if not profiled."""
+    f = ROOT / "profiles" / "knn_select_traffic.json"
+    try:
+        return json.loads(f.read_text())["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main() -> None:
     args = parse_args()
     import torch
@@ -169,7 +179,7 @@ def main() -> None:
             "data": "synthetic",
             "config": {
                 "workload": (f"synthetic planted log-normal CSR {n} cells x {args.n_vars} genes (~5% nnz), PCA {args.n_comps} "
-                             f"(block Krylov, arpack accuracy) + exact brute-force kNN k={args.n_neighbors} + umap "
+                             f"(exact Gram + dense eigensolve, arpack accuracy) + exact brute-force kNN k={args.n_neighbors} + umap "
                              "connectivities + Leiden res=1.0 n_iterations=-1 (BASELINE configs[2])"),
                 "n_obs": n,
                 "n_vars": args.n_vars,
@@ -183,7 +193,7 @@ def main() -> None:
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": (achieved / peak) if achieved else None,
-                "traffic": None,
+                "traffic": _profiled_traffic(),
                 "launch_ms": sel,
                 "algorithmic_flop_per_launch": flops,
             },
