@@ -107,7 +107,8 @@ class GpuBackend:
         """-> (G int64 [g, g], colsum int64 [g]): fixed point X^T X and 1^T X (x 2^scale_bits)."""
         ip, ix, dv, n, g = a
         gram, cs = self.K.csr_gram(ip, ix, dv, n, g, scale_bits)
-        return gram[:g, :g], cs[:g]
+        # contiguous: the row shards all-reduce these tensors in place
+        return gram[:g, :g].contiguous(), cs[:g].contiguous()
 
 
 @dataclass

@@ -61,7 +61,8 @@ def test_knn_toy_golden(K, neighbors_toy):
 
 @pytest.mark.parametrize(
     ("n", "d", "k"),
-    [(1000, 50, 15), (5000, 10, 30), (3000, 64, 15), (2000, 100, 15), (777, 3, 5), (4000, 50, 100), (300, 128, 15), (2500, 33, 24)],
+    [(1000, 50, 15), (5000, 10, 30), (3000, 64, 15), (2000, 100, 15), (777, 3, 5), (4000, 50, 100), (300, 128, 15), (2500, 33, 24),
+     (2000, 20, 15), (1500, 30, 10), (60000, 50, 15), (130, 50, 15), (33, 8, 4)],
 )
 def test_knn_vs_sklearn(K, n, d, k):
     rng = np.random.default_rng(n + d + k)
@@ -112,6 +113,39 @@ def test_knn_query_shard(K):
     i_s, d_s, _ = K.knn(_dev(x), 15, q_begin=700, n_query=900)
     np.testing.assert_array_equal(i_all[700:1600].cpu().numpy(), i_s.cpu().numpy())
     np.testing.assert_array_equal(d_all[700:1600].cpu().numpy(), d_s.cpu().numpy())
+
+
+def test_knn_full_size_sampled_exact(K):
+    """BASELINE size (1M x 50, k = 15): the GPU result of 1500 sampled queries equals a float64 brute force over all
+    1M rows computed on the host; every row is its own first neighbour; distances ascend."""
+    import torch
+
+    from scanpy_amd.datasets import blobs_embedding
+
+    n, k = 1_000_000, 15
+    x, _ = blobs_embedding(n, 50, seed=3)
+    idx, dist, nfb = K.knn(_dev(x), k)
+    assert nfb < n // 1000
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    assert (idx[:, 0] == np.arange(n)).all() and (dist[:, 0] == 0).all()
+    assert (np.diff(dist, axis=1) >= 0).all()
+    rng = np.random.default_rng(0)
+    qs = np.sort(rng.choice(n, 1500, replace=False))
+    x64 = x.astype(np.float64)
+    xn = (x64 * x64).sum(1)
+    for s in range(0, len(qs), 250):
+        q = qs[s : s + 250]
+        d2 = xn[q][:, None] + xn[None, :] - 2.0 * (x64[q] @ x64.T)
+        d2[np.arange(len(q)), q] = -1.0  # self first
+        part = np.argpartition(d2, k, axis=1)[:, : k + 4]
+        exact = ((x64[q][:, None, :] - x64[part]) ** 2).sum(-1)
+        exact[part == q[:, None]] = -1.0
+        order = np.lexsort((part, exact), axis=1)[:, :k]
+        ref_idx = np.take_along_axis(part, order, axis=1)
+        ref_d = np.sqrt(np.maximum(np.take_along_axis(exact, order, axis=1), 0.0))
+        same = (np.sort(idx[q], axis=1) == np.sort(ref_idx, axis=1)).all(axis=1)
+        assert same.mean() > 0.999, same.mean()  # (the rest: ties at the k-th distance)
+        np.testing.assert_allclose(dist[q][same][:, 1:], ref_d[same][:, 1:], rtol=1e-9)
 
 
 def test_knn_tiny(K):

@@ -301,3 +301,23 @@ def test_full_pipeline_planted_ari(sc):
     ari = adjusted_rand_score(cpu, gpu)
     print("ARI gpu-vs-cpu-chain", ari, "ARI vs truth", adjusted_rand_score(truth, gpu), "n clusters", gpu.max() + 1)
     assert ari >= 0.99
+
+
+def test_pca_sparse_equals_dense_and_integer_input(sc, pbmc68k):
+    """tests/test_pca.py:306-330 (implicit centring of sparse input == explicit centring of dense input, atol 1e-6)
+    and integer counts as input (promoted like the reference: float64 components)."""
+    counts = pbmc68k["counts"][:300]
+    xs = counts.astype(np.float32)
+    xs.data = np.log1p(xs.data)
+    a_sparse = sc.AnnData(xs.copy())
+    a_dense = sc.AnnData(xs.toarray())
+    sc.pp.pca(a_sparse, n_comps=20)
+    sc.pp.pca(a_dense, n_comps=20)
+    np.testing.assert_allclose(a_sparse.obsm["X_pca"], a_dense.obsm["X_pca"], atol=1e-6)
+    np.testing.assert_allclose(a_sparse.varm["PCs"], a_dense.varm["PCs"], atol=1e-6)
+    np.testing.assert_allclose(a_sparse.uns["pca"]["variance"], a_dense.uns["pca"]["variance"], rtol=1e-6)
+    a_int = sc.AnnData(counts.astype(np.int32))
+    sc.pp.pca(a_int, n_comps=10)
+    assert a_int.obsm["X_pca"].dtype == np.float32 and a_int.varm["PCs"].dtype == np.float64
+    ref = opca.pca_reference(counts.astype(np.float32), 10)
+    assert np.abs(np.abs(a_int.varm["PCs"].T) - np.abs(ref["components"])).max() < 1e-4
