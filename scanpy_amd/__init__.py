@@ -7,11 +7,12 @@ Same function signatures and AnnData slots as scverse/scanpy for that path; the 
 hand-written HIP kernels for gfx950 behind the C ABI of include/scanpy_amd.h.  There is no CPU
 fallback: without the built library or without a GPU the calls raise.
 """
+from . import metrics
 from . import preprocessing as pp
 from . import tools as tl
 from ._anndata import AnnData
 from ._settings import settings
 from .neighbors import MI355XKNNTransformer, Neighbors
 
-__all__ = ["pp", "tl", "AnnData", "settings", "Neighbors", "MI355XKNNTransformer"]
+__all__ = ["pp", "tl", "metrics", "AnnData", "settings", "Neighbors", "MI355XKNNTransformer"]
 __version__ = "0.1.0"
