@@ -175,25 +175,27 @@ __device__ __forceinline__ Cand wave_best(Cand x) {
 // in a 128-slot open-addressing table private to its wave: O(deg) LDS atomics instead of the O(deg^2) all-pairs
 // readlane compare (which remains the path for the few high-degree coarse vertices).  Integer adds: the sums do
 // not depend on the order of insertion; the table is read back two slots per lane.
-constexpr int WH_SLOTS = 128;
-constexpr int WH_MAX_DEG = 96;
+constexpr int WH_SLOTS = 512;    // per wave (6 KB); a vertex uses the first 128 / 256 / 512 of them
+constexpr int WH_MAX_DEG = 384;
 constexpr int WH_EMPTY = -1;
 
 struct WaveHash {
   int* keys;                 // [WH_SLOTS]
   unsigned long long* vals;  // [WH_SLOTS]
+  int nslots;                // power of two >= 1.33 * deg
+  __device__ __forceinline__ void size_for(int deg) { nslots = deg <= 96 ? 128 : (deg <= 192 ? 256 : 512); }
   __device__ __forceinline__ void clear(int lane) {
-    keys[lane] = WH_EMPTY;
-    keys[lane + 64] = WH_EMPTY;
-    vals[lane] = 0ull;
-    vals[lane + 64] = 0ull;
+    for (int i = lane; i < nslots; i += 64) {
+      keys[i] = WH_EMPTY;
+      vals[i] = 0ull;
+    }
   }
   __device__ __forceinline__ void add(int c, long long w) {
-    unsigned int slot = hash32((unsigned int)c) & (WH_SLOTS - 1);
+    unsigned int slot = hash32((unsigned int)c) & (nslots - 1);
     for (;;) {
       const int prev = atomicCAS(&keys[slot], WH_EMPTY, c);
       if (prev == WH_EMPTY || prev == c) break;
-      slot = (slot + 1) & (WH_SLOTS - 1);
+      slot = (slot + 1) & (nslots - 1);
     }
     atomicAdd(&vals[slot], (unsigned long long)w);
   }
@@ -291,17 +293,17 @@ __global__ __launch_bounds__(256) void ld_move_kernel(
   if (deg <= WH_MAX_DEG) {
     __shared__ int hkeys[4][WH_SLOTS];
     __shared__ unsigned long long hvals[4][WH_SLOTS];
-    WaveHash wh{hkeys[threadIdx.x >> 6], hvals[threadIdx.x >> 6]};
+    WaveHash wh{hkeys[threadIdx.x >> 6], hvals[threadIdx.x >> 6], WH_SLOTS};
+    wh.size_for(deg);
     wh.clear(lane);
     for (int e = lane; e < deg; e += 64) {
       const int u = indices[beg + e];
       if (u != v) wh.add(comm[u], wq[beg + e]);
     }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int c = wh.key(lane + 64 * h);
+    for (int sl = lane; sl < wh.nslots; sl += 64) {
+      const int c = wh.key(sl);
       if (c != WH_EMPTY) {
-        const long long sum = wh.val(lane + 64 * h);
+        const long long sum = wh.val(sl);
         if (c == a) {
           w_own = sum;
         } else {
@@ -613,17 +615,17 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
     if (deg <= WH_MAX_DEG) {
       __shared__ int hkeys[4][WH_SLOTS];
       __shared__ unsigned long long hvals[4][WH_SLOTS];
-      WaveHash wh{hkeys[threadIdx.x >> 6], hvals[threadIdx.x >> 6]};
+      WaveHash wh{hkeys[threadIdx.x >> 6], hvals[threadIdx.x >> 6], WH_SLOTS};
+      wh.size_for(deg);
       wh.clear(lane);
       for (int e = lane; e < deg; e += 64) {
         const int u = indices[beg + e];
         if (u != v && comm[u] == a) wh.add(ref[u], wq[beg + e]);
       }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int c = wh.key(lane + 64 * h);
+      for (int sl = lane; sl < wh.nslots; sl += 64) {
+        const int c = wh.key(sl);
         if (c != WH_EMPTY && c != v) {
-          const long long sum = wh.val(lane + 64 * h);
+          const long long sum = wh.val(sl);
           const double Kr = (double)(long long)Kref[c];
           const bool single = refsize[c] == 1;
           const bool ok_target = (!single || !mover_bit(c, round, seed)) &&
@@ -871,33 +873,6 @@ __global__ void ld_hash_fill_kernel(const unsigned long long* __restrict__ keys,
   tmp_w[p] = (long long)vals[s];
 }
 
-// one wave per row: rank sort by column (columns unique within a row)
-__global__ __launch_bounds__(256) void ld_sortrows_kernel(int n, const int64_t* __restrict__ indptr,
-                                                          const int* __restrict__ tmp_col,
-                                                          const long long* __restrict__ tmp_w,
-                                                          int* __restrict__ out_col, long long* __restrict__ out_w) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= n) return;
-  const int64_t base = indptr[row];
-  const int len = (int)(indptr[row + 1] - base);
-  for (int cb = 0; cb < len; cb += 64) {
-    const int e = cb + lane;
-    const int c = (e < len) ? tmp_col[base + e] : 0x7fffffff;
-    int rank = 0;
-    for (int db = 0; db < len; db += 64) {
-      const int e2 = db + lane;
-      const int c2 = (e2 < len) ? tmp_col[base + e2] : 0x7fffffff;
-      const int cnt = min(64, len - db);
-      for (int t = 0; t < cnt; ++t) rank += (__builtin_amdgcn_readlane(c2, t) < c) ? 1 : 0;
-    }
-    if (e < len) {
-      out_col[base + rank] = c;
-      out_w[base + rank] = tmp_w[base + e];
-    }
-  }
-}
-
 // ---- quality ---------------------------------------------------------------------------------------
 // internal[0] += sum over stored entries inside a community (self loops included)
 __global__ __launch_bounds__(256) void ld_internal_kernel(int n, const int64_t* __restrict__ indptr,
@@ -1022,7 +997,7 @@ struct LeidenBuffers {
   int* flag; int64_t* newid; int64_t* scan_tmp; int* cid; int* rep; int* comm_tmp;
   int* node_of; int* memb; int* memb_best;
   unsigned long long* hkeys; unsigned long long* hvals; unsigned long long hsize;
-  int* rowcnt; int* cursor; int* tmp_col; long long* tmp_w;
+  int* rowcnt; int* cursor;
   int* counters; unsigned long long* total; double* dscratch;
   unsigned long long* ckeys; int* cids; int* newlabel; int* minmember;
 };
@@ -1074,8 +1049,6 @@ static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b
   b->hvals = ws.take<unsigned long long>((size_t)b->hsize);
   b->rowcnt = ws.take<int>(N);
   b->cursor = ws.take<int>(N);
-  b->tmp_col = ws.take<int>(E);
-  b->tmp_w = ws.take<long long>(E);
   b->counters = ws.take<int>(8);
   b->total = ws.take<unsigned long long>(4);
   b->dscratch = ws.take<double>(4);
@@ -1277,11 +1250,10 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   CoarseBuf& cb = b.cb[dst];
   rc = exclusive_scan_i32_i64(b.rowcnt, nn, cb.indptr, b.scan_tmp, cx.s);
   if (rc != SCAMD_OK) return rc;
+  // rows are filled in arrival order: nothing downstream depends on the order of a row's entries (all sums are
+  // integer, every choice is an argmax under a total order), so the coarse rows are not sorted
   hipLaunchKernelGGL(ld_hash_fill_kernel, dim3(hblocks), dim3(256), 0, cx.s, b.hkeys, b.hvals, hsize, cb.indptr,
-                     b.cursor, b.tmp_col, b.tmp_w);
-  SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ld_sortrows_kernel, GRIDW(nn), 0, cx.s, (int)nn, cb.indptr, b.tmp_col, b.tmp_w, cb.indices,
-                     cb.wq);
+                     b.cursor, cb.indices, cb.wq);
   SCAMD_LAUNCH_CHECK();
   int64_t nnz_new = 0;
   SCAMD_HIP_CHECK(hipMemcpyAsync(&nnz_new, cb.indptr + nn, sizeof(int64_t), hipMemcpyDeviceToHost, cx.s));
