@@ -74,6 +74,9 @@ int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x,
 /* Duration (ms, HIP events on `stream`) of the FP32-MFMA selection kernel of the calling thread's most
  * recent scamd_knn_l2_f32 call; -1 if none.  Used by bench.py for the roofline figure. */
 float scamd_knn_last_select_ms(void);
+/* (query, candidate) pairs that call's selection kernel evaluated: n_query * n for the brute-force sweep, fewer when
+ * the cell-pruned search (n >= 65536) could skip far cells; -1 if none.  Executed flop = 2 * d * pairs. */
+double scamd_knn_last_select_pairs(void);
 
 /* ------------------------------------------------------------------------------------------
  * Fuzzy simplicial set -- umap connectivities from a kNN result.

@@ -21,6 +21,7 @@ SIGNATURES = {
     "scamd_knn_workspace_bytes": (_sz, [_i64, _i32, _i64, _i32]),
     "scamd_knn_l2_f32": (_i32, [_vp, _i64, _i32, _i64, _i64, _i64, _i32, _vp, _vp, _f64, C.POINTER(_i64), _vp, _sz, _vp]),
     "scamd_knn_last_select_ms": (C.c_float, []),
+    "scamd_knn_last_select_pairs": (_f64, []),
     "scamd_fuzzy_workspace_bytes": (_sz, [_i64, _i32]),
     "scamd_fuzzy_simplicial_set_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp, C.POINTER(_i64), _vp, _sz, _vp]),
     "scamd_csr_row_stats_f32": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),

@@ -22,8 +22,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <vector>
 
 static thread_local float g_last_select_ms = -1.f;
+static thread_local double g_last_select_pairs = -1.0;
 
 namespace scamd {
 
@@ -341,16 +343,34 @@ __global__ void knn_pack_image_kernel(const float* __restrict__ x, int64_t n, in
   if (lane == 0 && wmax > 0.f) atomicMax(cmax_bits, __float_as_uint(wmax));
 }
 
-// NOINSERT = true: timing experiment only (the lists stay empty, results are garbage)
+// Cell-pruned ("exact IVF") mode: rows are grouped by a coarse quantiser into cells, every cell padded to whole
+// tiles in the candidate image and to whole 128-query blocks in the query list.  A block (all its queries in one
+// cell a) visits the cells in order of increasing lower bound LB(a,b) = |c_a - c_b| - r_a - r_b on any distance
+// between a member of a and a member of b, and stops at the first cell whose bound exceeds every query's current
+// threshold distance: all remaining cells are farther still.  The answer is the exact kNN (pass 2 certifies it).
+struct IvfArgs {
+  const int* qpos;          // [n_blocks * 128] image row of every query slot (-1 = padding)
+  const int* block_cell;    // [n_blocks]
+  const int* cell_tile0;    // [n_cells] first tile of the cell in the image
+  const int* cell_ntiles;   // [n_cells]
+  const float* centers;     // [n_cells][dc]
+  const float* radius;      // [n_cells] (already inflated for rounding)
+  const int* perm;          // [n_image_rows] original row id of an image row (-1 = padding)
+  unsigned long long* pairs; // (query, candidate) pairs evaluated, for the roofline figure
+  int n_cells, dc;          // dc = stride of `centers` (>= d)
+  int d;
+};
+
 // TC_ = candidates per LDS tile, WPS = resident blocks per CU (= waves per SIMD) the register budget is cut for
-template <int H, bool NOINSERT, int TC_, int WPS>
-__global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* __restrict__ xp, int n_tiles,
+template <int H, int TC_, int WPS, bool IVF>
+__global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* __restrict__ xp, int n_tiles_all,
                                                                   int64_t n_pad, int64_t q_begin,
                                                                   int thr_rank, int* __restrict__ cand_idx,
-                                                                  float* __restrict__ cand_tau) {
+                                                                  float* __restrict__ cand_tau, IvfArgs iv) {
   using C = RegCfg<H, TC_>;
   constexpr int HP = C::HP, DPL = C::DPL, TC = C::TC, SUBS = C::SUBS;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int IVF_MAX_CELLS = 1024;
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][TC][DPL] (+ IVF: order/lb2/wmax)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
@@ -358,9 +378,17 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
 
   // A operand: lane l holds query (l&31), dims [half*H, half*H+H), pre-scaled by -2
   float aq[H];
-  {
-    int64_t qrow = q_begin + (int64_t)blockIdx.x * C::QB + wave * 32 + l31;
+  int64_t qrow;          // image row of this lane's query
+  bool qvalid = true;
+  if constexpr (IVF) {
+    const int p = iv.qpos[(int64_t)blockIdx.x * C::QB + wave * 32 + l31];
+    qvalid = p >= 0;
+    qrow = qvalid ? p : 0;
+  } else {
+    qrow = q_begin + (int64_t)blockIdx.x * C::QB + wave * 32 + l31;
     if (qrow > n_pad - 1) qrow = n_pad - 1;  // padded query slot: results are never read
+  }
+  {
     const float* qp = xp + qrow * DPL + half * HP;
 #pragma unroll
     for (int s = 0; s < H; ++s) aq[s] = -2.0f * qp[s];
@@ -376,8 +404,9 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     idx[r] = -1;
   }
 
-  // B operand of sub-tile g (global sub-tile counter: tile g>>2, rows (g&3)*32 ..): lane l holds candidate
-  // (l&31), the same dim slice as A, then the extra k slot
+  int n_sub = 0;  // sub-tiles of the current sweep
+  // B operand of sub-tile g of the current sweep: lane l holds candidate (l&31), the same dim slice as A, then
+  // the extra k slot
   auto load_b = [&](int g, float (&b)[HP]) {
     const float* tb = smem + ((g / SUBS) & 1) * TC * DPL;
     const float4* p = reinterpret_cast<const float4*>(tb + ((g % SUBS) * 32 + l31) * DPL + half * HP);
@@ -391,7 +420,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     }
   };
   // Insert the survivors of a sub-tile.  acc[r] = score - (threshold its chain used); that threshold is lane
-  // i(r,h) of `athr_used` (negated).  all = true (first sub-tile): every finite score is inserted.
+  // i(r,h) of `athr_used` (negated).  all = true (very first sub-tile): every finite score is inserted.
   auto insert = [&](const f32x16& acc, float athr_used, int cbase, bool all) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -424,7 +453,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
       }
     }
   };
-  const int n_sub = n_tiles * SUBS;
+  int row0 = 0;  // image row of the current sweep's first candidate
   // One pipeline step = ONE scheduling region: chain of sub-tile g into acc_cur (with the thresholds in athr),
   // fragment reads of sub-tile g+1, sign test of the previous sub-tile's accumulator.
   auto step = [&](int g, float (&b_cur)[HP], f32x16& acc_cur, float& athr_cur, const f32x16& acc_prev,
@@ -453,19 +482,16 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
     }
-    if constexpr (!NOINSERT) {
-      if (hit) insert(acc_prev, athr_prev, (g - 1) * 32, false);
-    } else {
-      if (hit) athr += 0.0f;  // keeps the test live
-    }
+    if (hit) insert(acc_prev, athr_prev, row0 + (g - 1) * 32, false);
   };
 
   // staging registers: every wave moves NP 1-KiB pieces per tile; out-of-range piece ids are clamped (a duplicate
   // copy of the last piece) so that no load sits behind a branch (hipcc waits vmcnt(0) after a conditional load)
   constexpr int NP = (C::TILE_KB + C::NW - 1) / C::NW;
   f32x4 st[NP];
+  int tile0 = 0;  // first tile of the current sweep
   auto gload = [&](int t) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xp) + (int64_t)t * C::TILE_BYTES) + lane;
+    const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xp) + (int64_t)(tile0 + t) * C::TILE_BYTES) + lane;
 #pragma unroll
     for (int j = 0; j < NP; ++j) st[j] = src[min(wave + C::NW * j, C::TILE_KB - 1) * 64];
   };
@@ -474,61 +500,152 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
 #pragma unroll
     for (int j = 0; j < NP; ++j) dst[min(wave + C::NW * j, C::TILE_KB - 1) * 64] = st[j];
   };
-  gload(0);
-  lstore(0);
-  if (n_tiles > 1) gload(1);
-  __syncthreads();
 
-  float bA[HP], bB[HP];
-  f32x16 accA, accB;
-  float athrA = athr, athrB = athr;
-  load_b(0, bA);
-  // sub-tile 0: plain scores (threshold 0), every finite one is inserted; afterwards all thresholds are finite
-  // whenever the data holds at least thr_rank rows
-  {
-    f32x16 zero;
+  // Sweep over `n_tiles` consecutive tiles of the image starting at tile `t0`.  first = the block's very first
+  // sweep: its sub-tile 0 fills the lists (every finite score is inserted).  All four waves call it together; on
+  // entry nobody reads the LDS tiles any more (the caller's barrier / kernel start guarantees it).
+  auto sweep = [&](int t0, int n_tiles, bool first) {
+    tile0 = t0;
+    row0 = t0 * TC;
+    n_sub = n_tiles * SUBS;
+    gload(0);
+    lstore(0);
+    if (n_tiles > 1) gload(1);
+    __syncthreads();
+    float bA[HP], bB[HP];
+    f32x16 accA, accB;
+    float athrA = athr, athrB = athr;
+    load_b(0, bA);
+    if (first) {
+      // sub-tile 0: plain scores (threshold 0), every finite one is inserted; afterwards all thresholds are
+      // finite whenever the sub-tile holds at least thr_rank real rows
+      f32x16 zero;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-    accB = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[0], bA[0], zero, 0, 0, 0);
+      for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+      accB = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[0], bA[0], zero, 0, 0, 0);
 #pragma unroll
-    for (int s = 1; s < H; ++s) accB = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s], bA[s], accB, 0, 0, 0);
-    accB = __builtin_amdgcn_mfma_f32_32x32x2f32(athr, bA[H], accB, 0, 0, 0);
-    if constexpr (!NOINSERT) insert(accB, athr, 0, true);
+      for (int s = 1; s < H; ++s) accB = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s], bA[s], accB, 0, 0, 0);
+      accB = __builtin_amdgcn_mfma_f32_32x32x2f32(athr, bA[H], accB, 0, 0, 0);
+      insert(accB, athr, row0, true);
+      load_b(1 < n_sub ? 1 : 0, bB);  // sub-tile 0 is done: prefetch sub-tile 1
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) accB[r] = INFINITY;  // "previous" scores of the first pipeline step: no hit
-  }
-  // sub-tile 0 is done: prefetch sub-tile 1; accA plays "previous scores" for the first pipeline step
-  load_b(1 < n_sub ? 1 : 0, bB);
-  accA = accB;
-  athrA = athrB;
-  // half-tile loop: h = 2t (sub-tiles 4t, 4t+1) and h = 2t+1 (sub-tiles 4t+2 | barrier | 4t+3); the body is two
-  // pipeline steps with the roles of the A/B register sets fixed, so the insertion code exists twice only
-  constexpr int HPT = SUBS / 2;  // loop iterations (two sub-tiles each) per tile
-  for (int h = 0; h < HPT * n_tiles; ++h) {
-    const int g = 2 * h;
-    if (h > 0) step(g, bA, accA, athrA, accB, athrB, bB);
-    if ((h % HPT) == HPT - 1) {
-      const int t = h / HPT;
-      if (t + 1 < n_tiles) lstore((t + 1) & 1);  // buffer of tile t-1: free since the previous barrier
-      // every wave has completed its reads of tile t except sub-tile 3 (already in bB): after the barrier tile
-      // t+1 is visible and the staging registers are free for tile t+2
-      if (!(NOINSERT && thr_rank == 31)) __syncthreads();  // (timing experiment: no barrier)
-      if (t + 2 < n_tiles) gload(t + 2);
+    accA = accB;
+    athrA = athrB;
+    // half-tile loop (two sub-tiles per iteration, roles of the A/B register sets fixed: the insertion code exists
+    // twice only); the barrier of tile t sits before its last sub-tile, whose fragment is already in registers
+    constexpr int HPT = SUBS / 2;
+    for (int h = 0; h < HPT * n_tiles; ++h) {
+      const int g = 2 * h;
+      if (h > 0 || !first) step(g, bA, accA, athrA, accB, athrB, bB);
+      if ((h % HPT) == HPT - 1) {
+        const int t = h / HPT;
+        if (t + 1 < n_tiles) lstore((t + 1) & 1);  // buffer of tile t-1: free since the previous barrier
+        // every wave has completed its reads of tile t except the last sub-tile (already in bB): after the barrier
+        // tile t+1 is visible and the staging registers are free for tile t+2
+        __syncthreads();
+        if (t + 2 < n_tiles) gload(t + 2);
+      }
+      step(g + 1, bB, accB, athrB, accA, athrA, bA);
     }
-    step(g + 1, bB, accB, athrB, accA, athrA, bA);
-  }
-  if constexpr (!NOINSERT) {
-    bool neg = false;
+    {
+      bool neg = false;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) neg |= accB[r] < 0.f;
-    if (__any(neg)) insert(accB, athrB, (n_sub - 1) * 32, false);
-  }
+      for (int r = 0; r < 16; ++r) neg |= accB[r] < 0.f;
+      if (__any(neg)) insert(accB, athrB, row0 + (n_sub - 1) * 32, false);
+    }
+  };
 
+  if constexpr (!IVF) {
+    sweep(0, n_tiles_all, true);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int64_t q = (int64_t)blockIdx.x * C::QB + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    cand_idx[q * C::KP + l31] = idx[r];
-    if (l31 == thr_lane) cand_tau[q] = NOINSERT ? key[r] + athr : key[r];
+    for (int r = 0; r < 16; ++r) {
+      const int64_t q = (int64_t)blockIdx.x * C::QB + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      cand_idx[q * C::KP + l31] = idx[r];
+      if (l31 == thr_lane) cand_tau[q] = key[r];
+    }
+  } else {
+    // ---- cell order of this block: ascending lower bound, own cell first ----
+    int* order = reinterpret_cast<int*>(smem + 2 * TC * DPL);  // [IVF_MAX_CELLS]
+    float* lb2 = reinterpret_cast<float*>(order + IVF_MAX_CELLS);  // [IVF_MAX_CELLS]
+    float* wmax = lb2 + IVF_MAX_CELLS;                          // [4]
+    const int a = iv.block_cell[blockIdx.x];
+    int npow = 1;
+    while (npow < iv.n_cells) npow <<= 1;
+    const float ra = iv.radius[a];
+    for (int b = tid; b < npow; b += C::NT) {
+      float v = INFINITY;
+      if (b < iv.n_cells && iv.cell_ntiles[b] > 0) {
+        float d2 = 0.f;
+        for (int c = 0; c < iv.d; ++c) {
+          const float df = iv.centers[a * iv.dc + c] - iv.centers[b * iv.dc + c];
+          d2 += df * df;
+        }
+        // lower bound on the distance between any member of a and any member of b, deflated against rounding
+        const float lb = fmaxf(0.f, sqrtf(d2) * (1.0f - 1e-4f) - ra - iv.radius[b]);
+        v = (b == a) ? -1.0f : lb * lb;
+      }
+      lb2[b] = v;
+      order[b] = b;
+    }
+    __syncthreads();
+    for (int kk = 2; kk <= npow; kk <<= 1) {  // bitonic sort by (lb2, cell)
+      for (int j = kk >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < npow; i += C::NT) {
+          const int p = i ^ j;
+          if (p > i) {
+            const bool up = (i & kk) == 0;
+            const float vi = lb2[i], vp = lb2[p];
+            const int oi = order[i], op = order[p];
+            const bool gt = vi > vp || (vi == vp && oi > op);
+            if (gt == up) {
+              lb2[i] = vp;
+              lb2[p] = vi;
+              order[i] = op;
+              order[p] = oi;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // exact threshold distance^2 of a query = thr (score space) + ||q||^2; per wave the max over its real queries
+    const float qn = xp[qrow * DPL + HP + H];  // ||q||^2 sits in the extra k slot of the row's second half
+    bool first = true;
+    for (int ci = 0; ci < iv.n_cells; ++ci) {
+      const float lb = lb2[ci];
+      if (!(lb < INFINITY)) break;  // empty cells sort last
+      if (ci > 0) {
+        float dthr = (half == 0 && qvalid) ? (qn - athr) : -INFINITY;  // athr = -thr on lanes 0..31
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dthr = fmaxf(dthr, __shfl_xor(dthr, o));
+        if (lane == 0) wmax[wave] = dthr;
+        __syncthreads();
+        const float tmax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        __syncthreads();  // wmax is rewritten at the next cell
+        // every remaining cell is at least this far: done once the bound clears every threshold (with slack for
+        // the float32 rounding of thresholds and bounds)
+        if (lb * (1.0f - 1e-3f) > tmax + 1e-3f * fabsf(tmax)) break;
+      }
+      const int b = order[ci];
+      if (tid == 0) atomicAdd(iv.pairs, (unsigned long long)iv.cell_ntiles[b] * TC * C::QB);
+      sweep(iv.cell_tile0[b], iv.cell_ntiles[b], first);
+      first = false;
+      __syncthreads();  // all fragment reads of this cell are done before the next sweep restages the tiles
+    }
+    // results go to the ORIGINAL query / row ids
+    const int qbase = (int64_t)blockIdx.x * C::QB + wave * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qslot = qbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int qp = iv.qpos[qslot];
+      if (qp >= 0) {
+        const int64_t qi = (int64_t)iv.perm[qp] - q_begin;
+        cand_idx[qi * C::KP + l31] = idx[r] >= 0 ? iv.perm[idx[r]] : -1;
+        if (l31 == thr_lane) cand_tau[qi] = key[r];
+      }
+    }
   }
 }
 
@@ -705,6 +822,136 @@ __global__ __launch_bounds__(256) void knn_fallback_rank_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// coarse quantiser of the cell-pruned search: a few Lloyd iterations on a sample, then one assignment of all rows.
+// Quality only affects how much is pruned, never the result.
+// ------------------------------------------------------------------------------------------------
+constexpr double IVF_FIX = 1048576.0;  // 2^20 fixed point of the centroid sums (order-independent atomics)
+
+__global__ void ivf_init_kernel(const float* __restrict__ x, int64_t n, int d, int64_t ld, int n_cells,
+                                float* __restrict__ cent) {
+  const int c = blockIdx.x;
+  const int64_t row = (int64_t)c * (n / n_cells) + (n / n_cells) / 2;
+  for (int j = threadIdx.x; j < d; j += blockDim.x) cent[c * d + j] = x[row * ld + j];
+}
+
+// One thread per sampled row (row = start + j * step, j < count): nearest centroid by (x - c)^2; centroids are
+// staged through LDS in chunks.  accumulate != 0: fixed-point sums / counts of the Lloyd update.  qcounts != NULL:
+// additionally counts the rows of the query range [q0, q1).
+__global__ __launch_bounds__(256) void ivf_assign_kernel(const float* __restrict__ x, int d, int64_t ld, int64_t start,
+                                                         int64_t step, int64_t count, const float* __restrict__ cent,
+                                                         int n_cells, int* __restrict__ labels, int accumulate,
+                                                         long long* __restrict__ sums, int* __restrict__ counts,
+                                                         int64_t q0, int64_t q1, int* __restrict__ qcounts) {
+  constexpr int CH = 64;                        // centroids per LDS chunk
+  extern __shared__ float ivf_smem[];           // [256][d + 1] rows, then [CH][d] centroids
+  float* rows = ivf_smem;
+  float* cc = ivf_smem + 256 * (d + 1);
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = j < count;
+  const int64_t row = valid ? start + j * step : start;
+  for (int c = 0; c < d; ++c) rows[threadIdx.x * (d + 1) + c] = x[row * ld + c];
+  float best = INFINITY;
+  int bi = 0;
+  for (int c0 = 0; c0 < n_cells; c0 += CH) {
+    __syncthreads();
+    const int nc = min(CH, n_cells - c0);
+    for (int e = threadIdx.x; e < nc * d; e += 256) cc[e] = cent[c0 * d + e];
+    __syncthreads();
+    for (int c = 0; c < nc; ++c) {
+      float s = 0.f;
+      for (int t = 0; t < d; ++t) {
+        const float df = rows[threadIdx.x * (d + 1) + t] - cc[c * d + t];
+        s = fmaf(df, df, s);
+      }
+      if (s < best) {
+        best = s;
+        bi = c0 + c;
+      }
+    }
+  }
+  if (!valid) return;
+  labels[j] = bi;
+  if (accumulate) {
+    for (int t = 0; t < d; ++t)
+      atomicAdd(reinterpret_cast<unsigned long long*>(&sums[(int64_t)bi * d + t]),
+                (unsigned long long)llrint((double)rows[threadIdx.x * (d + 1) + t] * IVF_FIX));
+  }
+  if (counts) atomicAdd(&counts[bi], 1);
+  if (qcounts && row >= q0 && row < q1) atomicAdd(&qcounts[bi], 1);
+}
+
+__global__ void ivf_update_kernel(const long long* __restrict__ sums, const int* __restrict__ counts, int n_cells, int d,
+                                  float* __restrict__ cent) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_cells * d) return;
+  const int c = e / d;
+  if (counts[c] > 0) cent[e] = (float)((double)sums[e] / IVF_FIX / (double)counts[c]);
+}
+
+// position of every row in the cell-sorted image (+ of the query rows in the query list); order inside a cell is
+// arbitrary
+__global__ void ivf_scatter_kernel(const int* __restrict__ labels, int64_t n, const int* __restrict__ cell_map,
+                                   const int* __restrict__ row_off, int* __restrict__ row_cur, int64_t q0, int64_t q1,
+                                   const int* __restrict__ slot_off, int* __restrict__ slot_cur, int* __restrict__ perm,
+                                   int* __restrict__ qpos) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = cell_map[labels[i]];
+  const int pos = row_off[c] + atomicAdd(&row_cur[c], 1);
+  perm[pos] = (int)i;
+  if (i >= q0 && i < q1) qpos[slot_off[c] + atomicAdd(&slot_cur[c], 1)] = pos;
+}
+
+// image of the cell-sorted rows (layout of knn_pack_image_kernel); padding rows get ||c||^2 = +inf.  Also the
+// cell radii: max distance of a member to its cell's centre (float32, as uint bits for atomicMax).
+__global__ void ivf_pack_image_kernel(const float* __restrict__ x, int d, int64_t ld, int H, int HP, int DPL,
+                                      int64_t n_img, const int* __restrict__ perm, const int* __restrict__ labels,
+                                      const int* __restrict__ cell_map, const float* __restrict__ cent,
+                                      float* __restrict__ xp, unsigned int* __restrict__ cmax_bits,
+                                      unsigned int* __restrict__ radius_bits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  float wmax = 0.f;
+  for (int64_t r = wave; r < n_img; r += nwaves) {
+    const int src = perm[r];
+    double s = 0.0;
+    float dc2 = 0.f;
+    int cell = 0;
+    if (src >= 0) {
+      cell = cell_map[labels[src]];
+      for (int c = lane; c < d; c += 64) {
+        const float v = x[(int64_t)src * ld + c];
+        s += (double)v * (double)v;
+        const float df = v - cent[cell * d + c];
+        dc2 = fmaf(df, df, dc2);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o);
+      dc2 += __shfl_xor(dc2, o);
+    }
+    const float nf = (src >= 0) ? (float)s : INFINITY;
+    for (int c = lane; c < DPL; c += 64) {
+      const int hh = c / HP, cc = c - hh * HP;
+      float v = 0.f;
+      if (hh < 2) {
+        const int dim = hh * H + cc;
+        if (cc < H) v = (src >= 0 && dim < d) ? x[(int64_t)src * ld + dim] : 0.f;
+        else if (cc == H) v = (hh == 0) ? 1.0f : nf;
+      }
+      xp[r * DPL + c] = v;
+    }
+    if (src >= 0) {
+      wmax = fmaxf(wmax, nf);
+      if (lane == 0) atomicMax(&radius_bits[cell], __float_as_uint(sqrtf(dc2) * 1.0001f + 1e-6f));
+    }
+  }
+  if (lane == 0 && wmax > 0.f) atomicMax(cmax_bits, __float_as_uint(wmax));
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 struct KnnPlan {
@@ -713,6 +960,9 @@ struct KnnPlan {
   int thr_rank;   // register-list kernel: rank (1..32) of the list entry used as the filter threshold
   int row_dwords; // row stride of the packed copy
   int64_t n_pad, nq_pad;
+  bool ivf;       // cell-pruned exact search (register-list kernel only)
+  int n_cells;    // coarse cells
+  int64_t n_img_max, n_slot_max;  // upper bounds of the padded image rows / query slots
 };
 
 template <int H>
@@ -759,12 +1009,32 @@ static bool knn_plan(int64_t n, int d, int64_t n_query, int k, KnnPlan* p) {
   const int QB = p->NW * 32;
   p->nq_pad = (n_query + QB - 1) / QB * QB;
   p->n_pad = (n + 255) / 256 * 256;
+  // cell pruning pays once a sweep is long compared with the per-cell restarts; SCAMD_KNN_IVF=0 forces brute force
+  static const int ivf_env = [] {
+    const char* e = getenv("SCAMD_KNN_IVF");
+    return e ? atoi(e) : -1;
+  }();
+  p->ivf = p->reg && ivf_env != 0 && (n >= 65536 || ivf_env == 1) && n >= 4096;
+  p->n_cells = 0;
+  p->n_img_max = p->n_slot_max = 0;
+  if (p->ivf) {
+    int c = 16;
+    while (c < 1024 && (int64_t)c * 4096 < n) c <<= 1;  // ~4k rows per cell
+    while (c > 1 && (int64_t)c * 256 > n) c >>= 1;
+    p->n_cells = c;
+    p->n_img_max = (n + (int64_t)64 * c + 255) / 256 * 256;
+    p->n_slot_max = n_query + (int64_t)128 * c;
+    p->n_pad = p->n_img_max;
+  }
   return true;
 }
 
 struct KnnBuffers {
   float* xp; float* cn; unsigned int* cmax; int* cand_idx; float* cand_tau; double* kth_d2;
   int* flag_list; int* counters; double* scratch_d; int* scratch_i; int* fb_counts;
+  // cell-pruned search
+  int* labels; int* perm; int* qpos; int* block_cell; float* cent; long long* sums; int* cell_ints;
+  unsigned int* radius_bits;
 };
 
 static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffers* b) {
@@ -779,6 +1049,20 @@ static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffe
   b->scratch_d = ws.take<double>((size_t)FALLBACK_CHUNK * FALLBACK_CAP);
   b->scratch_i = ws.take<int>((size_t)FALLBACK_CHUNK * FALLBACK_CAP);
   b->fb_counts = ws.take<int>((size_t)FALLBACK_CHUNK);
+  b->labels = b->perm = b->qpos = b->block_cell = b->cell_ints = nullptr;
+  b->cent = nullptr;
+  b->sums = nullptr;
+  b->radius_bits = nullptr;
+  if (p.ivf) {
+    b->labels = ws.take<int>((size_t)p.n_pad);  // sample labels, then labels of all rows
+    b->perm = ws.take<int>((size_t)p.n_img_max);
+    b->qpos = ws.take<int>((size_t)p.n_slot_max);
+    b->block_cell = ws.take<int>((size_t)(p.n_slot_max / 128 + 1));
+    b->cent = ws.take<float>((size_t)p.n_cells * 128);
+    b->sums = ws.take<long long>((size_t)p.n_cells * 128);
+    b->cell_ints = ws.take<int>((size_t)p.n_cells * 8);  // counts, qcounts, map, row_off, row_cur, slot_off, slot_cur, tile0/ntiles reuse
+    b->radius_bits = ws.take<unsigned int>((size_t)p.n_cells);
+  }
 }
 
 template <int H, int TC, int NW, int KP>
@@ -804,24 +1088,17 @@ static int dispatch_kp(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, h
   }
 }
 
-static bool knn_noinsert() {  // SCAMD_KNN_NOINSERT=1: timing experiment (garbage results, passes 2/3 skipped)
-  static const bool v = [] {
-    const char* e = getenv("SCAMD_KNN_NOINSERT");
-    return e && e[0] == '1';
-  }();
-  return v;
-}
-
-template <int H, bool NOINSERT, int TC_, int WPS>
+template <int H, int TC_, int WPS>
 static int launch_select_reg_mode(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, hipStream_t s) {
   using C = RegCfg<H, TC_>;
-  auto kern = knn_select_reg_kernel<H, NOINSERT, TC_, WPS>;
+  auto kern = knn_select_reg_kernel<H, TC_, WPS, false>;
   SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
   const int n_tiles = (int)(p.n_pad / C::TC);
   const int grid = (int)(p.nq_pad / C::QB);
+  IvfArgs none{};
   hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, b.xp, n_tiles, p.n_pad, q_begin,
-                     p.thr_rank, b.cand_idx, b.cand_tau);
+                     p.thr_rank, b.cand_idx, b.cand_tau, none);
   SCAMD_LAUNCH_CHECK();
   return SCAMD_OK;
 }
@@ -834,9 +1111,8 @@ static int launch_select_reg(const KnnPlan& p, const KnnBuffers& b, int64_t q_be
     const char* e = getenv("SCAMD_KNN_BIG_TILES");
     return e && e[0] == '1';
   }();
-  if (knn_noinsert()) return launch_select_reg_mode<H, true, 64, 3>(p, b, q_begin, s);
-  if (big_tiles) return launch_select_reg_mode<H, false, 128, 2>(p, b, q_begin, s);
-  return launch_select_reg_mode<H, false, 64, 3>(p, b, q_begin, s);
+  if (big_tiles) return launch_select_reg_mode<H, 128, 2>(p, b, q_begin, s);
+  return launch_select_reg_mode<H, 64, 3>(p, b, q_begin, s);
 }
 
 static int dispatch_select(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, hipStream_t s) {
@@ -857,11 +1133,158 @@ static int dispatch_select(const KnnPlan& p, const KnnBuffers& b, int64_t q_begi
   }
 }
 
+// ---- cell-pruned search: quantiser, cell-sorted image, launch -------------------------------------------
+template <int H>
+static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x, int64_t n, int d, int64_t ld,
+                          int64_t q_begin, int64_t n_query, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+  using C = RegCfg<H, 64>;
+  constexpr int MIN_CELL = 128;
+  const int nc = p.n_cells;
+  int* counts = b.cell_ints;
+  int* qcounts = counts + nc;
+  int* cell_map = qcounts + nc;
+  int* row_off = cell_map + nc;
+  int* row_cur = row_off + nc;
+  int* slot_off = row_cur + nc;
+  int* slot_cur = slot_off + nc;
+  int* tile0 = slot_cur + nc;                     // cell_ints holds 8 * nc ints
+  int* ntiles = reinterpret_cast<int*>(b.sums);  // the sums buffer is free once the quantiser is done
+  // 1. quantiser: Lloyd on a strided sample
+  const size_t lds_assign = ((size_t)256 * (d + 1) + (size_t)64 * d) * sizeof(float);
+  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_assign_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_assign));
+  hipLaunchKernelGGL(ivf_init_kernel, dim3(nc), dim3(64), 0, s, x, n, d, ld, nc, b.cent);
+  SCAMD_LAUNCH_CHECK();
+  const int64_t n_sample = std::min<int64_t>(n, (int64_t)64 * nc);
+  const int64_t step = n / n_sample;
+  for (int it = 0; it < 4; ++it) {
+    SCAMD_HIP_CHECK(hipMemsetAsync(b.sums, 0, sizeof(long long) * nc * d, s));
+    SCAMD_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * nc, s));
+    hipLaunchKernelGGL(ivf_assign_kernel, dim3((unsigned)ceil_div(n_sample, 256)), dim3(256), lds_assign, s, x, d, ld,
+                       (int64_t)0, step, n_sample, b.cent, nc, b.labels, 1, b.sums, counts, (int64_t)0, (int64_t)0,
+                       (int*)nullptr);
+    SCAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ivf_update_kernel, dim3((unsigned)ceil_div((int64_t)nc * d, 256)), dim3(256), 0, s, b.sums,
+                       counts, nc, d, b.cent);
+    SCAMD_LAUNCH_CHECK();
+  }
+  // 2. every row to its cell
+  SCAMD_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * 2 * nc, s));
+  hipLaunchKernelGGL(ivf_assign_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), lds_assign, s, x, d, ld,
+                     (int64_t)0, (int64_t)1, n, b.cent, nc, b.labels, 0, (long long*)nullptr, counts, q_begin,
+                     q_begin + n_query, qcounts);
+  SCAMD_LAUNCH_CHECK();
+  std::vector<int> h_cnt(2 * nc);
+  std::vector<float> h_cent((size_t)nc * d);
+  SCAMD_HIP_CHECK(hipMemcpyAsync(h_cnt.data(), counts, sizeof(int) * 2 * nc, hipMemcpyDeviceToHost, s));
+  SCAMD_HIP_CHECK(hipMemcpyAsync(h_cent.data(), b.cent, sizeof(float) * nc * d, hipMemcpyDeviceToHost, s));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+  // 3. host: fold small cells into their nearest big cell; padded layout of the image and of the query list
+  std::vector<int> h_map(nc), mc(nc, 0), mq(nc, 0);
+  int biggest = 0;
+  for (int c = 1; c < nc; ++c)
+    if (h_cnt[c] > h_cnt[biggest]) biggest = c;
+  for (int c = 0; c < nc; ++c) {
+    int tgt = c;
+    if (h_cnt[c] < MIN_CELL) {
+      tgt = biggest;
+      double bestd = INFINITY;
+      for (int e = 0; e < nc; ++e) {
+        if (h_cnt[e] < MIN_CELL) continue;
+        double dd = 0.0;
+        for (int t = 0; t < d; ++t) {
+          const double df = (double)h_cent[(size_t)c * d + t] - (double)h_cent[(size_t)e * d + t];
+          dd += df * df;
+        }
+        if (dd < bestd) {
+          bestd = dd;
+          tgt = e;
+        }
+      }
+    }
+    h_map[c] = tgt;
+    mc[tgt] += h_cnt[c];
+    mq[tgt] += h_cnt[nc + c];
+  }
+  std::vector<int> h_row_off(nc), h_slot_off(nc), h_tile0(nc), h_ntiles(nc), h_block_cell;
+  int64_t rows = 0, slots = 0;
+  for (int c = 0; c < nc; ++c) {
+    h_row_off[c] = (int)rows;
+    h_tile0[c] = (int)(rows / 64);
+    h_ntiles[c] = (mc[c] + 63) / 64;
+    rows += (int64_t)h_ntiles[c] * 64;
+    h_slot_off[c] = (int)slots;
+    const int nb = (mq[c] + 127) / 128;
+    for (int t = 0; t < nb; ++t) h_block_cell.push_back(c);
+    slots += (int64_t)nb * 128;
+  }
+  const int n_blocks = (int)h_block_cell.size();
+  SCAMD_REQUIRE(rows <= p.n_img_max && slots <= p.n_slot_max, SCAMD_EWORKSPACE, "knn: cell layout exceeds its bound");
+  if (n_blocks == 0) return SCAMD_OK;
+  SCAMD_HIP_CHECK(hipMemcpyAsync(cell_map, h_map.data(), sizeof(int) * nc, hipMemcpyHostToDevice, s));
+  SCAMD_HIP_CHECK(hipMemcpyAsync(row_off, h_row_off.data(), sizeof(int) * nc, hipMemcpyHostToDevice, s));
+  SCAMD_HIP_CHECK(hipMemcpyAsync(slot_off, h_slot_off.data(), sizeof(int) * nc, hipMemcpyHostToDevice, s));
+  SCAMD_HIP_CHECK(hipMemcpyAsync(tile0, h_tile0.data(), sizeof(int) * nc, hipMemcpyHostToDevice, s));
+  SCAMD_HIP_CHECK(hipMemcpyAsync(ntiles, h_ntiles.data(), sizeof(int) * nc, hipMemcpyHostToDevice, s));
+  SCAMD_HIP_CHECK(hipMemcpyAsync(b.block_cell, h_block_cell.data(), sizeof(int) * n_blocks, hipMemcpyHostToDevice, s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(row_cur, 0, sizeof(int) * nc, s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(slot_cur, 0, sizeof(int) * nc, s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.perm, 0xff, sizeof(int) * rows, s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.qpos, 0xff, sizeof(int) * slots, s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.radius_bits, 0, sizeof(unsigned int) * nc, s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 2, 0, 8, s));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(s));  // the host vectors above must outlive their copies
+  // 4. cell-sorted image
+  hipLaunchKernelGGL(ivf_scatter_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, b.labels, n, cell_map, row_off,
+                     row_cur, q_begin, q_begin + n_query, slot_off, slot_cur, b.perm, b.qpos);
+  SCAMD_LAUNCH_CHECK();
+  {
+    const int blocks = (int)std::min<int64_t>((rows + 3) / 4, 256 * 16);
+    hipLaunchKernelGGL(ivf_pack_image_kernel, dim3(blocks), dim3(256), 0, s, x, d, ld, H, C::HP, C::DPL, rows, b.perm,
+                       b.labels, cell_map, b.cent, b.xp, b.cmax, b.radius_bits);
+    SCAMD_LAUNCH_CHECK();
+  }
+  // 5. pruned sweep
+  auto kern = knn_select_reg_kernel<H, 64, 3, true>;
+  const size_t lds = C::LDS_BYTES + 1024 * 8 + 64;
+  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+  IvfArgs iv;
+  iv.qpos = b.qpos;
+  iv.block_cell = b.block_cell;
+  iv.cell_tile0 = tile0;
+  iv.cell_ntiles = ntiles;
+  iv.centers = b.cent;
+  iv.radius = reinterpret_cast<const float*>(b.radius_bits);
+  iv.perm = b.perm;
+  iv.pairs = reinterpret_cast<unsigned long long*>(b.counters + 2);
+  iv.n_cells = nc;
+  iv.dc = d;
+  iv.d = d;
+  SCAMD_HIP_CHECK(hipEventRecord(ev0, s));
+  hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(C::NT), lds, s, b.xp, (int)(rows / 64), rows, q_begin, p.thr_rank,
+                     b.cand_idx, b.cand_tau, iv);
+  SCAMD_LAUNCH_CHECK();
+  SCAMD_HIP_CHECK(hipEventRecord(ev1, s));
+  return SCAMD_OK;
+}
+
+static int dispatch_ivf(const KnnPlan& p, const KnnBuffers& b, const float* x, int64_t n, int d, int64_t ld,
+                        int64_t q_begin, int64_t n_query, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+  switch (p.H) {
+    case 8: return run_ivf_select<8>(p, b, x, n, d, ld, q_begin, n_query, s, ev0, ev1);
+    case 16: return run_ivf_select<16>(p, b, x, n, d, ld, q_begin, n_query, s, ev0, ev1);
+    case 25: return run_ivf_select<25>(p, b, x, n, d, ld, q_begin, n_query, s, ev0, ev1);
+    default: return run_ivf_select<32>(p, b, x, n, d, ld, q_begin, n_query, s, ev0, ev1);
+  }
+}
+
 }  // namespace scamd
 
 using namespace scamd;
 
 extern "C" float scamd_knn_last_select_ms(void) { return g_last_select_ms; }
+extern "C" double scamd_knn_last_select_pairs(void) { return g_last_select_pairs; }
 
 extern "C" size_t scamd_knn_workspace_bytes(int64_t n, int d, int64_t n_query, int k) {
   KnnPlan p;
@@ -898,7 +1321,7 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
 
   SCAMD_HIP_CHECK(hipMemsetAsync(b.cmax, 0, 16, s));
   SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, 16, s));
-  {
+  if (!p.ivf) {
     int blocks = (int)std::min<int64_t>((p.n_pad + 3) / 4, 256 * 16);
     if (p.reg) {
       const int HP = (p.H + 1 + 3) / 4 * 4;
@@ -913,22 +1336,18 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   SCAMD_HIP_CHECK(hipEventCreate(&ev0));
   SCAMD_HIP_CHECK(hipEventCreate(&ev1));
-  SCAMD_HIP_CHECK(hipEventRecord(ev0, s));
-  int rc = dispatch_select(p, b, q_begin, s);
-  if (rc == SCAMD_OK && hipEventRecord(ev1, s) != hipSuccess) rc = SCAMD_EHIP;
+  int rc;
+  if (p.ivf) {
+    rc = dispatch_ivf(p, b, x, n, d, ld_x, q_begin, n_query, s, ev0, ev1);
+  } else {
+    SCAMD_HIP_CHECK(hipEventRecord(ev0, s));
+    rc = dispatch_select(p, b, q_begin, s);
+    if (rc == SCAMD_OK && hipEventRecord(ev1, s) != hipSuccess) rc = SCAMD_EHIP;
+  }
   if (rc != SCAMD_OK) {
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
     return rc;
-  }
-  if (p.reg && knn_noinsert()) {  // timing experiment: the candidate lists are garbage, skip passes 2/3
-    SCAMD_HIP_CHECK(hipStreamSynchronize(s));
-    float ms = -1.f;
-    if (hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) ms = -1.f;
-    g_last_select_ms = ms;
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
-    return SCAMD_OK;
   }
   {
     int blocks = (int)((n_query + 3) / 4);
@@ -951,6 +1370,9 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
     g_last_select_ms = ms;
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
+    unsigned long long pairs = 0;
+    memcpy(&pairs, &h_counters[2], 8);
+    g_last_select_pairs = p.ivf ? (double)pairs : (double)n_query * (double)n;
   }
   const int n_flag = h_counters[0];
   if (n_fallback_host) *n_fallback_host = n_flag;
