@@ -12,8 +12,9 @@ i.e. strong scaling of configs[3]).  The CSR shard is resident in HBM before the
 timed region ends with the labels on the device.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      dominant kernel = knn_select_kernel (FP32 MFMA): achieved = 2 * n_query * n * 50 flop / its
-                HIP-event duration (scamd_knn_last_select_ms), peak = 157.3 TFLOP/s (MI355X_MICROARCH.md).
+  roofline      knn_select_reg_kernel (FP32 MFMA): achieved = 2 * 50 flop per evaluated (query, candidate) pair
+                (scamd_knn_last_select_pairs; the exact cell-pruned search skips provably empty cells) / its HIP-event
+                duration (scamd_knn_last_select_ms), peak = 157.3 TFLOP/s (MI355X_MICROARCH.md).
   cpu_baseline  the reference's CPU call chain (sklearn PCA arpack + sklearn brute kNN = reference calls; oracle
                 fuzzy set + oracle Leiden) on a bounded sample of the same matrix, on this box's host cores.
 """
@@ -141,12 +142,13 @@ def main() -> None:
     for _ in range(args.warmup):
         run_path(handle, n, **kw)
     lib = _lib.load()
-    select_ms, stage_acc, res = [], {}, None
+    select_ms, select_pairs, stage_acc, res = [], [], {}, None
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = run_path(handle, n, timing=True, **kw)
         select_ms.append(float(lib.scamd_knn_last_select_ms()))
+        select_pairs.append(float(lib.scamd_knn_last_select_pairs()))
         for kname, v in res.stage_ms.items():
             stage_acc[kname] = stage_acc.get(kname, 0.0) + v
     sync_all()
@@ -161,7 +163,11 @@ def main() -> None:
     if rank == 0:
         sel = sum(select_ms) / max(len(select_ms), 1)
         n_query = hi - lo
-        flops = 2.0 * n_query * n * args.n_comps  # algorithmic: 2 * d flop per (query, candidate) pair
+        pairs = sum(select_pairs) / max(len(select_pairs), 1)  # (query, candidate) pairs the kernel evaluated
+        brute_pairs = float(n_query) * float(n)
+        # algorithmic flop of the launch = 2 * d flop per EVALUATED pair: the exact cell-pruned search skips the
+        # cells that provably hold no neighbour, what it does evaluate runs on the FP32 MFMA pipe
+        flops = 2.0 * pairs * args.n_comps
         achieved = flops / (sel * 1e-3) / 1e12 if sel > 0 else None
         peak = 157.3
         out = {
@@ -179,7 +185,7 @@ def main() -> None:
             "data": "synthetic",
             "config": {
                 "workload": (f"synthetic planted log-normal CSR {n} cells x {args.n_vars} genes (~5% nnz), PCA {args.n_comps} "
-                             f"(exact Gram + dense eigensolve, arpack accuracy) + exact brute-force kNN k={args.n_neighbors} + umap "
+                             f"(exact Gram + dense eigensolve, arpack accuracy) + exact kNN k={args.n_neighbors} (cell-pruned brute force) + umap "
                              "connectivities + Leiden res=1.0 n_iterations=-1 (BASELINE configs[2])"),
                 "n_obs": n,
                 "n_vars": args.n_vars,
@@ -187,15 +193,17 @@ def main() -> None:
                 "parallelism": f"cells row-sharded x{world}; leiden on rank 0",
             },
             "roofline": {
-                "kernel": "knn_select_reg_kernel<25> (v_mfma_f32_32x32x2_f32)",
+                "kernel": "knn_select_reg_kernel<25,64,3> (v_mfma_f32_32x32x2_f32), exact cell-pruned sweep",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": (achieved / peak) if achieved else None,
-                "traffic": _profiled_traffic(),
+                "traffic": None,  # the committed PMC passes (profiles/knn_select_traffic.json) are of the brute-force sweep
                 "launch_ms": sel,
                 "algorithmic_flop_per_launch": flops,
+                "pairs_evaluated_fraction": pairs / brute_pairs if brute_pairs > 0 else None,
+                "brute_force_equivalent_tflops": 2.0 * brute_pairs * args.n_comps / (sel * 1e-3) / 1e12 if sel > 0 else None,
             },
             "stage_ms_per_step": {kname: v / max(args.steps, 1) for kname, v in stage_acc.items()},
             "result": {"n_communities": res.n_communities, "modularity": res.modularity, **res.info},

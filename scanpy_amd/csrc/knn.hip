@@ -834,33 +834,47 @@ __global__ void ivf_init_kernel(const float* __restrict__ x, int64_t n, int d, i
   for (int j = threadIdx.x; j < d; j += blockDim.x) cent[c * d + j] = x[row * ld + j];
 }
 
-// One thread per sampled row (row = start + j * step, j < count): nearest centroid by (x - c)^2; centroids are
-// staged through LDS in chunks.  accumulate != 0: fixed-point sums / counts of the Lloyd update.  qcounts != NULL:
-// additionally counts the rows of the query range [q0, q1).
+// One thread per sampled row (row = start + j * step, j < count), the row in registers: nearest centroid by
+// (x - c)^2 with the centroids staged through LDS in chunks of 64 (broadcast reads).  accumulate != 0: fixed-point
+// sums / counts of the Lloyd update.  qcounts != NULL: additionally counts the rows of the query range [q0, q1).
+template <int H>
 __global__ __launch_bounds__(256) void ivf_assign_kernel(const float* __restrict__ x, int d, int64_t ld, int64_t start,
                                                          int64_t step, int64_t count, const float* __restrict__ cent,
                                                          int n_cells, int* __restrict__ labels, int accumulate,
                                                          long long* __restrict__ sums, int* __restrict__ counts,
                                                          int64_t q0, int64_t q1, int* __restrict__ qcounts) {
-  constexpr int CH = 64;                        // centroids per LDS chunk
-  extern __shared__ float ivf_smem[];           // [256][d + 1] rows, then [CH][d] centroids
-  float* rows = ivf_smem;
-  float* cc = ivf_smem + 256 * (d + 1);
+  constexpr int CH = 64;                  // centroids per LDS chunk
+  constexpr int DP = (2 * H + 3) / 4 * 4;  // dims padded to float4
+  __shared__ __attribute__((aligned(16))) float cc[CH * DP];
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool valid = j < count;
   const int64_t row = valid ? start + j * step : start;
-  for (int c = 0; c < d; ++c) rows[threadIdx.x * (d + 1) + c] = x[row * ld + c];
+  float xr[DP];
+#pragma unroll
+  for (int c = 0; c < DP; ++c) xr[c] = (c < d) ? x[row * ld + c] : 0.f;
   float best = INFINITY;
   int bi = 0;
   for (int c0 = 0; c0 < n_cells; c0 += CH) {
     __syncthreads();
     const int nc = min(CH, n_cells - c0);
-    for (int e = threadIdx.x; e < nc * d; e += 256) cc[e] = cent[c0 * d + e];
+    for (int e = threadIdx.x; e < nc * DP; e += 256) {
+      const int c = e / DP, t = e - c * DP;
+      cc[e] = (t < d) ? cent[(c0 + c) * d + t] : 0.f;
+    }
     __syncthreads();
     for (int c = 0; c < nc; ++c) {
+      const float4* cp = reinterpret_cast<const float4*>(cc + c * DP);
       float s = 0.f;
-      for (int t = 0; t < d; ++t) {
-        const float df = rows[threadIdx.x * (d + 1) + t] - cc[c * d + t];
+#pragma unroll
+      for (int t4 = 0; t4 < DP / 4; ++t4) {
+        const float4 v = cp[t4];
+        float df = xr[4 * t4 + 0] - v.x;
+        s = fmaf(df, df, s);
+        df = xr[4 * t4 + 1] - v.y;
+        s = fmaf(df, df, s);
+        df = xr[4 * t4 + 2] - v.z;
+        s = fmaf(df, df, s);
+        df = xr[4 * t4 + 3] - v.w;
         s = fmaf(df, df, s);
       }
       if (s < best) {
@@ -872,9 +886,11 @@ __global__ __launch_bounds__(256) void ivf_assign_kernel(const float* __restrict
   if (!valid) return;
   labels[j] = bi;
   if (accumulate) {
-    for (int t = 0; t < d; ++t)
-      atomicAdd(reinterpret_cast<unsigned long long*>(&sums[(int64_t)bi * d + t]),
-                (unsigned long long)llrint((double)rows[threadIdx.x * (d + 1) + t] * IVF_FIX));
+#pragma unroll
+    for (int t = 0; t < DP; ++t)
+      if (t < d)
+        atomicAdd(reinterpret_cast<unsigned long long*>(&sums[(int64_t)bi * d + t]),
+                  (unsigned long long)llrint((double)xr[t] * IVF_FIX));
   }
   if (counts) atomicAdd(&counts[bi], 1);
   if (qcounts && row >= q0 && row < q1) atomicAdd(&qcounts[bi], 1);
@@ -1018,8 +1034,12 @@ static bool knn_plan(int64_t n, int d, int64_t n_query, int k, KnnPlan* p) {
   p->n_cells = 0;
   p->n_img_max = p->n_slot_max = 0;
   if (p->ivf) {
+    static const int cell_rows = [] {
+      const char* e = getenv("SCAMD_KNN_CELL_ROWS");
+      return e ? std::max(256, atoi(e)) : 2048;
+    }();
     int c = 16;
-    while (c < 1024 && (int64_t)c * 4096 < n) c <<= 1;  // ~4k rows per cell
+    while (c < 1024 && (int64_t)c * cell_rows < n) c <<= 1;  // ~cell_rows rows per cell
     while (c > 1 && (int64_t)c * 256 > n) c >>= 1;
     p->n_cells = c;
     p->n_img_max = (n + (int64_t)64 * c + 255) / 256 * 256;
@@ -1150,17 +1170,15 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   int* tile0 = slot_cur + nc;                     // cell_ints holds 8 * nc ints
   int* ntiles = reinterpret_cast<int*>(b.sums);  // the sums buffer is free once the quantiser is done
   // 1. quantiser: Lloyd on a strided sample
-  const size_t lds_assign = ((size_t)256 * (d + 1) + (size_t)64 * d) * sizeof(float);
-  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_assign_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_assign));
+  auto assign = ivf_assign_kernel<H>;
   hipLaunchKernelGGL(ivf_init_kernel, dim3(nc), dim3(64), 0, s, x, n, d, ld, nc, b.cent);
   SCAMD_LAUNCH_CHECK();
   const int64_t n_sample = std::min<int64_t>(n, (int64_t)64 * nc);
   const int64_t step = n / n_sample;
-  for (int it = 0; it < 4; ++it) {
+  for (int it = 0; it < 3; ++it) {
     SCAMD_HIP_CHECK(hipMemsetAsync(b.sums, 0, sizeof(long long) * nc * d, s));
     SCAMD_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * nc, s));
-    hipLaunchKernelGGL(ivf_assign_kernel, dim3((unsigned)ceil_div(n_sample, 256)), dim3(256), lds_assign, s, x, d, ld,
+    hipLaunchKernelGGL(assign, dim3((unsigned)ceil_div(n_sample, 256)), dim3(256), 0, s, x, d, ld,
                        (int64_t)0, step, n_sample, b.cent, nc, b.labels, 1, b.sums, counts, (int64_t)0, (int64_t)0,
                        (int*)nullptr);
     SCAMD_LAUNCH_CHECK();
@@ -1170,7 +1188,7 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   }
   // 2. every row to its cell
   SCAMD_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * 2 * nc, s));
-  hipLaunchKernelGGL(ivf_assign_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), lds_assign, s, x, d, ld,
+  hipLaunchKernelGGL(assign, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, x, d, ld,
                      (int64_t)0, (int64_t)1, n, b.cent, nc, b.labels, 0, (long long*)nullptr, counts, q_begin,
                      q_begin + n_query, qcounts);
   SCAMD_LAUNCH_CHECK();
