@@ -83,6 +83,14 @@ __global__ __launch_bounds__(256) void ld_sum_kernel(const long long* __restrict
   if ((threadIdx.x & 63) == 0 && s != 0) atomicAdd(total, (unsigned long long)s);
 }
 
+__global__ void ld_maxdeg_kernel(const int64_t* __restrict__ indptr, int n, int* __restrict__ out) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  int d = (v < n) ? (int)(indptr[v + 1] - indptr[v]) : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) d = max(d, __shfl_xor(d, o));
+  if ((threadIdx.x & 63) == 0 && d > 0) atomicMax(out, d);
+}
+
 __global__ void ld_iota_kernel(int* __restrict__ a, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] = i;
@@ -558,25 +566,27 @@ __global__ void ld_touched_members_kernel(int n, const int* __restrict__ ref, co
   }
 }
 
-// Eref[r] += w(v, C - r) for the listed members v of refined community r
-__global__ __launch_bounds__(256) void ld_cut_kernel(int n_list, const int* __restrict__ rlist,
+// Eref[r] += w(v, C - r) for the listed members v of refined community r (list length = counters[3], read on the
+// device: no host round trip between building the list and using it)
+__global__ __launch_bounds__(256) void ld_cut_kernel(const int* __restrict__ counters, const int* __restrict__ rlist,
                                                      const int64_t* __restrict__ indptr,
                                                      const int* __restrict__ indices, const long long* __restrict__ wq,
                                                      const int* __restrict__ comm, const int* __restrict__ ref,
                                                      unsigned long long* __restrict__ Eref) {
   const int lane = threadIdx.x & 63;
-  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (w >= n_list) return;
-  const int v = rlist[w];
-  const int a = comm[v], r = ref[v];
-  long long s = 0;
-  for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) {
-    const int u = indices[e];
-    if (u != v && comm[u] == a && ref[u] != r) s += wq[e];
-  }
+  const int n_list = counters[3];
+  for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n_list; w += gridDim.x * 4) {
+    const int v = rlist[w];
+    const int a = comm[v], r = ref[v];
+    long long s = 0;
+    for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) {
+      const int u = indices[e];
+      if (u != v && comm[u] == a && ref[u] != r) s += wq[e];
+    }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if (lane == 0 && s != 0) atomicAdd(&Eref[r], (unsigned long long)s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0 && s != 0) atomicAdd(&Eref[r], (unsigned long long)s);
+  }
 }
 
 __device__ __forceinline__ bool mover_bit(int v, int round, unsigned int seed) {
@@ -977,6 +987,7 @@ __global__ void ld_gather_kernel(int n, const int* __restrict__ comm, const int*
 // ---- host orchestration --------------------------------------------------------------------------
 struct LevelGraph {
   int n = 0;
+  int max_deg = 0;  // largest row length: levels without hubs skip the block-per-vertex kernels
   int64_t nnz = 0;
   const int64_t* indptr = nullptr;
   const int* indices = nullptr;
@@ -1129,9 +1140,11 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
     hipLaunchKernelGGL(ld_move_kernel, GRIDW(n_act), 0, cx.s, n_act, b.list_a, g.indptr, g.indices, g.wq, g.k, b.comm,
                        b.Ktot, b.csize, gg, round, cx.seed, b.target, b.hub_list, b.counters);
     SCAMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ld_move_hub_kernel, dim3(HUB_GRID), dim3(256), HUB_LDS, cx.s, b.hub_list, b.counters, b.list_a,
-                       g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg, round, cx.seed, b.target);
-    SCAMD_LAUNCH_CHECK();
+    if (g.max_deg > WH_MAX_DEG) {
+      hipLaunchKernelGGL(ld_move_hub_kernel, dim3(HUB_GRID), dim3(256), HUB_LDS, cx.s, b.hub_list, b.counters, b.list_a,
+                         g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg, round, cx.seed, b.target);
+      SCAMD_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(ld_apply_kernel, GRID1(n_act), 0, cx.s, n_act, b.list_a, b.target, g.indptr, g.indices, g.k,
                        b.comm, b.Ktot, b.csize, b.flag, b.counters);
     SCAMD_LAUNCH_CHECK();
@@ -1181,10 +1194,12 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
                        g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, gg, round, cx.seed, b.target, b.hub_list,
                        b.counters);
     SCAMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ld_refine_propose_hub_kernel, dim3(HUB_GRID), dim3(256), HUB_LDS, cx.s, b.hub_list, b.counters,
-                       g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, gg, round,
-                       cx.seed, b.target);
-    SCAMD_LAUNCH_CHECK();
+    if (g.max_deg > WH_MAX_DEG) {
+      hipLaunchKernelGGL(ld_refine_propose_hub_kernel, dim3(HUB_GRID), dim3(256), HUB_LDS, cx.s, b.hub_list, b.counters,
+                         g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, gg, round,
+                         cx.seed, b.target);
+      SCAMD_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(ld_refine_apply_kernel, GRID1(n_cand), 0, cx.s, n_cand, b.list_a, b.target, g.k, b.ref,
                        b.refsize, b.Kref, b.touched, b.list_b, b.counters);
     SCAMD_LAUNCH_CHECK();
@@ -1199,11 +1214,12 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
       hipLaunchKernelGGL(ld_touched_members_kernel, GRID1(g.n), 0, cx.s, g.n, b.ref, b.touched, b.Eref, b.rlist,
                          b.counters);
       SCAMD_LAUNCH_CHECK();
-      rc = read_counters(cx, h, 4);
-      if (rc != SCAMD_OK) return rc;
-      if (h[3] > 0) {
-        hipLaunchKernelGGL(ld_cut_kernel, GRIDW(h[3]), 0, cx.s, h[3], b.rlist, g.indptr, g.indices, g.wq, b.comm,
-                           b.ref, b.Eref);
+      {
+        // at most as many members as the merged communities can hold: size the grid by the merge count, the kernel
+        // strides over the device-side list length
+        const int blocks = std::min(4096, std::max(64, ceil_div(g.n, 4)));
+        hipLaunchKernelGGL(ld_cut_kernel, dim3(blocks), dim3(256), 0, cx.s, b.counters, b.rlist, g.indptr, g.indices,
+                           g.wq, b.comm, b.ref, b.Eref);
         SCAMD_LAUNCH_CHECK();
       }
       SCAMD_HIP_CHECK(hipMemsetAsync(b.touched, 0, sizeof(int) * n, cx.s));
@@ -1256,12 +1272,18 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
                      b.cursor, cb.indices, cb.wq);
   SCAMD_LAUNCH_CHECK();
   int64_t nnz_new = 0;
+  int max_deg = 0;
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 6, 0, sizeof(int), cx.s));
+  hipLaunchKernelGGL(ld_maxdeg_kernel, GRID1(nn), 0, cx.s, cb.indptr, (int)nn, b.counters + 6);
+  SCAMD_LAUNCH_CHECK();
+  SCAMD_HIP_CHECK(hipMemcpyAsync(&max_deg, b.counters + 6, sizeof(int), hipMemcpyDeviceToHost, cx.s));
   SCAMD_HIP_CHECK(hipMemcpyAsync(&nnz_new, cb.indptr + nn, sizeof(int64_t), hipMemcpyDeviceToHost, cx.s));
   hipLaunchKernelGGL(ld_strength_kernel, GRIDW(nn), 0, cx.s, cb.indptr, cb.wq, (int)nn, cb.k);
   SCAMD_LAUNCH_CHECK();
   SCAMD_HIP_CHECK(hipMemcpyAsync(b.comm, b.comm_tmp, sizeof(int) * nn, hipMemcpyDeviceToDevice, cx.s));
   SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
   out->n = (int)nn;
+  out->max_deg = max_deg;
   out->nnz = nnz_new;
   out->indptr = cb.indptr;
   out->indices = cb.indices;
@@ -1338,10 +1360,16 @@ static int setup_level0(LeidenCtx& cx, const int64_t* indptr, const int32_t* ind
   SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(ld_sum_kernel, dim3(256), dim3(256), 0, cx.s, b.k0, (int)n, b.total);
   SCAMD_LAUNCH_CHECK();
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 6, 0, sizeof(int), cx.s));
+  hipLaunchKernelGGL(ld_maxdeg_kernel, GRID1(n), 0, cx.s, indptr, (int)n, b.counters + 6);
+  SCAMD_LAUNCH_CHECK();
   unsigned long long tot = 0;
+  int max_deg = 0;
   SCAMD_HIP_CHECK(hipMemcpyAsync(&tot, b.total, sizeof(tot), hipMemcpyDeviceToHost, cx.s));
+  SCAMD_HIP_CHECK(hipMemcpyAsync(&max_deg, b.counters + 6, sizeof(int), hipMemcpyDeviceToHost, cx.s));
   SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
   cx.m2 = (double)tot;
+  g0->max_deg = max_deg;
   g0->n = (int)n;
   g0->nnz = nnz;
   g0->indptr = indptr;
