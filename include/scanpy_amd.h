@@ -34,6 +34,7 @@ typedef struct ihipStream_t* scamd_stream_t; /* == hipStream_t */
 #define SCAMD_EHIP (-3)       /* HIP runtime error */
 #define SCAMD_EUNSUPPORTED (-4)
 #define SCAMD_ECAPACITY (-5)  /* caller-provided output capacity too small */
+#define SCAMD_EINTERNAL (-6)  /* internal invariant violated (reported, never hidden) */
 
 #define SCAMD_ABI_VERSION 1
 

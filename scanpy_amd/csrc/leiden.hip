@@ -33,7 +33,6 @@ constexpr int MAX_RF_ROUNDS = 48;
 constexpr int RF_QUIET_ROUNDS = 3;
 constexpr int MAX_LEVELS = 64;
 constexpr int MAX_OUTER_ITERS = 32;
-constexpr unsigned long long HEMPTY = ~0ull;
 
 __device__ __forceinline__ unsigned int hash32(unsigned int x) {
   x ^= x >> 16;
@@ -828,59 +827,175 @@ __global__ void ld_remap_kernel(int n_orig, const int* __restrict__ cid, int* __
   if (i < n_orig) node_of[i] = cid[node_of[i]];
 }
 
-__device__ __forceinline__ unsigned long long hash64(unsigned long long x) {
-  x ^= x >> 33;
-  x *= 0xff51afd7ed558ccdULL;
-  x ^= x >> 33;
-  x *= 0xc4ceb9fe1a85ec53ULL;
-  x ^= x >> 33;
-  return x;
+// Coarse-graph construction, member-grouped: the members of every coarse node are gathered contiguously
+// (counting sort by coarse id), then ONE wave / workgroup per coarse node accumulates its members' rows into an
+// LDS hash keyed by the neighbour's coarse id and emits the combined row.  No global hash table and no global
+// atomics on the edges: the level-0 graph (24M entries) is read once, sequentially per member.
+//   rows land at an upper-bound offset (sum of the members' degrees) in a scratch CSR and are compacted after
+//   the row lengths are scanned.
+constexpr int AGG_MID_SLOTS = 4096;   // workgroup tier for <= 2048 distinct neighbours (48 KB LDS: 3 blocks/CU)
+constexpr int AGG_MID_MAX = 2048;
+constexpr int AGG_BIG_PASS = 4096;    // the 8192-slot tier takes ~4096 distinct keys per pass
+
+__global__ void ld_agg_mcount_kernel(int n, const int* __restrict__ refsize, const int64_t* __restrict__ newid,
+                                     int* __restrict__ mcount) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n && refsize[r] > 0) mcount[(int)newid[r]] = refsize[r];
 }
 
-// one wave per node; every stored entry (v,u,w) adds w to table[(cid[v], cid[u])]
-__global__ __launch_bounds__(256) void ld_hash_insert_kernel(int n, const int64_t* __restrict__ indptr,
-                                                             const int* __restrict__ indices,
-                                                             const long long* __restrict__ wq,
-                                                             const int* __restrict__ cid,
-                                                             unsigned long long* __restrict__ keys,
-                                                             unsigned long long* __restrict__ vals,
-                                                             unsigned long long mask) {
-  const int lane = threadIdx.x & 63;
-  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+__global__ void ld_agg_scatter_kernel(int n, const int* __restrict__ cid, const int64_t* __restrict__ moff,
+                                      int* __restrict__ cursor, const int64_t* __restrict__ indptr,
+                                      int* __restrict__ members, int* __restrict__ mdeg) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= n) return;
-  const unsigned long long src = (unsigned long long)(unsigned int)cid[v] << 32;
-  for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) {
-    const unsigned long long key = src | (unsigned int)cid[indices[e]];
-    unsigned long long slot = hash64(key) & mask;
-    for (;;) {
-      unsigned long long prev = atomicCAS(&keys[slot], HEMPTY, key);
-      if (prev == HEMPTY || prev == key) {
-        atomicAdd(&vals[slot], (unsigned long long)wq[e]);
-        break;
-      }
-      slot = (slot + 1) & mask;
+  const int c = cid[v];
+  const int64_t p = moff[c] + atomicAdd(&cursor[c], 1);
+  members[p] = v;
+  mdeg[p] = (int)(indptr[v + 1] - indptr[v]);
+}
+
+// distinct neighbours of a coarse node are bounded by both its degree sum and the coarse node count
+__device__ __forceinline__ int64_t agg_need(int64_t dsum, int nn) { return dsum < nn ? dsum : (int64_t)nn; }
+
+// one wave per coarse node; nodes needing more than the wave table go to the mid / big lists
+// (counters[4] / counters[5])
+__global__ __launch_bounds__(256) void ld_agg_wave_kernel(
+    int nn, const int64_t* __restrict__ moff, const int64_t* __restrict__ eoff, const int* __restrict__ members,
+    const int64_t* __restrict__ indptr, const int* __restrict__ indices, const long long* __restrict__ wq,
+    const int* __restrict__ cid, int* __restrict__ s_col, long long* __restrict__ s_w, int* __restrict__ rowcnt,
+    int* __restrict__ mid_list, int* __restrict__ big_list, int* __restrict__ counters, int wave_max, int mid_max) {
+  __shared__ int hkeys[4][WH_SLOTS];
+  __shared__ unsigned long long hvals[4][WH_SLOTS];
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= nn) return;
+  const int64_t m0 = moff[c], m1 = moff[c + 1];
+  const int64_t u0 = eoff[m0];
+  const int64_t dsum = eoff[m1] - u0;
+  const int64_t need = agg_need(dsum, nn);
+  if (need > wave_max) {
+    if (lane == 0) {
+      if (need <= mid_max) mid_list[atomicAdd(&counters[4], 1)] = c;
+      else big_list[atomicAdd(&counters[5], 1)] = c;
     }
+    return;
+  }
+  WaveHash wh{hkeys[threadIdx.x >> 6], hvals[threadIdx.x >> 6], WH_SLOTS};
+  wh.size_for((int)need);
+  wh.clear(lane);
+  for (int64_t i = m0; i < m1; ++i) {
+    const int v = members[i];
+    for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) wh.add(cid[indices[e]], wq[e]);
+  }
+  int base = 0;
+  for (int s0 = 0; s0 < wh.nslots; s0 += 64) {
+    const int key = wh.key(s0 + lane);
+    const bool has = key != WH_EMPTY;
+    const unsigned long long m = __ballot(has);
+    if (has) {
+      const int64_t p = u0 + base + __popcll(m & ((1ull << lane) - 1ull));
+      s_col[p] = key;
+      s_w[p] = wh.val(s0 + lane);
+    }
+    base += __popcll(m);
+  }
+  if (lane == 0) rowcnt[c] = base;
+}
+
+// one workgroup per listed coarse node.  SLOTS-entry LDS table; when the node may have more distinct neighbours
+// than pass_keys the keys are split into hash classes and the members' rows are swept once per class.
+template <int SLOTS>
+__global__ __launch_bounds__(256) void ld_agg_block_kernel(
+    const int* __restrict__ list, const int* __restrict__ list_len, int nn, const int64_t* __restrict__ moff,
+    const int64_t* __restrict__ eoff, const int* __restrict__ members, const int64_t* __restrict__ indptr,
+    const int* __restrict__ indices, const long long* __restrict__ wq, const int* __restrict__ cid,
+    int* __restrict__ s_col, long long* __restrict__ s_w, int* __restrict__ rowcnt, int* __restrict__ err,
+    int pass_keys) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long agg_smem[];
+  unsigned long long* vals = agg_smem;
+  int* keys = reinterpret_cast<int*>(agg_smem + SLOTS);
+  __shared__ int sh_cnt;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n_list = *list_len;
+  for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
+    const int c = list[li];
+    const int64_t m0 = moff[c], m1 = moff[c + 1];
+    const int64_t u0 = eoff[m0];
+    const int64_t need = agg_need(eoff[m1] - u0, nn);
+    const unsigned int n_pass = (unsigned int)((need + pass_keys - 1) / pass_keys);
+    int nslots = 256;
+    {
+      const int64_t per_pass = (need + n_pass - 1) / n_pass;
+      while (nslots < 2 * per_pass && nslots < SLOTS) nslots <<= 1;
+      if (n_pass > 1) nslots = SLOTS;
+    }
+    if (threadIdx.x == 0) sh_cnt = 0;
+    for (unsigned int pass = 0; pass < n_pass; ++pass) {
+      for (int i = threadIdx.x; i < nslots; i += 256) {
+        keys[i] = WH_EMPTY;
+        vals[i] = 0ull;
+      }
+      __syncthreads();
+      for (int64_t i = m0 + wv; i < m1; i += 4) {
+        const int v = members[i];
+        for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) {
+          const int key = cid[indices[e]];
+          if (n_pass > 1 && (hash32((unsigned int)key * 0x9E3779B1u + 0x7F4A7C15u) >> 8) % n_pass != pass) continue;
+          unsigned int slot = hash32((unsigned int)key) & (nslots - 1);
+          int tries = 0;
+          for (;;) {
+            const int prev = atomicCAS(&keys[slot], WH_EMPTY, key);
+            if (prev == WH_EMPTY || prev == key) {
+              atomicAdd(&vals[slot], (unsigned long long)wq[e]);
+              break;
+            }
+            slot = (slot + 1) & (nslots - 1);
+            if (++tries > nslots) {  // table full: cannot happen for uniformly hashed classes; reported, not hidden
+              *err = 1;
+              break;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      for (int s0 = 0; s0 < nslots; s0 += 256) {
+        const int sl = s0 + threadIdx.x;
+        const int key = keys[sl];
+        const bool has = key != WH_EMPTY;
+        const unsigned long long m = __ballot(has);
+        int wbase = 0;
+        if (lane == 0 && m) wbase = atomicAdd(&sh_cnt, __popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (has) {
+          const int64_t p = u0 + wbase + __popcll(m & ((1ull << lane) - 1ull));
+          s_col[p] = key;
+          s_w[p] = (long long)vals[sl];
+        }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) rowcnt[c] = sh_cnt;
+    __syncthreads();
   }
 }
 
-__global__ void ld_hash_count_kernel(const unsigned long long* __restrict__ keys, unsigned long long size,
-                                     int* __restrict__ rowcnt) {
-  unsigned long long s = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < size && keys[s] != HEMPTY) atomicAdd(&rowcnt[(int)(keys[s] >> 32)], 1);
-}
-
-__global__ void ld_hash_fill_kernel(const unsigned long long* __restrict__ keys,
-                                    const unsigned long long* __restrict__ vals, unsigned long long size,
-                                    const int64_t* __restrict__ indptr, int* __restrict__ cursor,
-                                    int* __restrict__ tmp_col, long long* __restrict__ tmp_w) {
-  unsigned long long s = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= size) return;
-  const unsigned long long key = keys[s];
-  if (key == HEMPTY) return;
-  const int src = (int)(key >> 32);
-  const int64_t p = indptr[src] + atomicAdd(&cursor[src], 1);
-  tmp_col[p] = (int)(key & 0xffffffffull);
-  tmp_w[p] = (long long)vals[s];
+// scratch rows (upper-bound offsets) -> final CSR rows; one wave per coarse node
+__global__ __launch_bounds__(256) void ld_agg_compact_kernel(int nn, const int64_t* __restrict__ moff,
+                                                             const int64_t* __restrict__ eoff,
+                                                             const int64_t* __restrict__ indptr_new,
+                                                             const int* __restrict__ s_col,
+                                                             const long long* __restrict__ s_w,
+                                                             int* __restrict__ out_col, long long* __restrict__ out_w) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= nn) return;
+  const int64_t u0 = eoff[moff[c]];
+  const int64_t p0 = indptr_new[c];
+  const int cnt = (int)(indptr_new[c + 1] - p0);
+  for (int i = lane; i < cnt; i += 64) {
+    out_col[p0 + i] = s_col[u0 + i];
+    out_w[p0 + i] = s_w[u0 + i];
+  }
 }
 
 // ---- quality ---------------------------------------------------------------------------------------
@@ -1007,7 +1122,8 @@ struct LeidenBuffers {
   int* ref; int* target; int* refsize; unsigned long long* Kref; unsigned long long* Eref; long long* a_in;
   int* flag; int64_t* newid; int64_t* scan_tmp; int* cid; int* rep; int* comm_tmp;
   int* node_of; int* memb; int* memb_best;
-  unsigned long long* hkeys; unsigned long long* hvals; unsigned long long hsize;
+  int* agg_col; long long* agg_w;  // scratch CSR of the coarse-graph build (rows at upper-bound offsets)
+  int* mcount; int64_t* moff; int64_t* eoff; int* members; int* mdeg; int* mid_list; int* big_list;
   int* rowcnt; int* cursor;
   int* counters; unsigned long long* total; double* dscratch;
   unsigned long long* ckeys; int* cids; int* newlabel; int* minmember;
@@ -1055,9 +1171,15 @@ static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b
   b->node_of = ws.take<int>(N);
   b->memb = ws.take<int>(N);
   b->memb_best = ws.take<int>(N);
-  b->hsize = next_pow2(2 * (unsigned long long)E + 16);
-  b->hkeys = ws.take<unsigned long long>((size_t)b->hsize);
-  b->hvals = ws.take<unsigned long long>((size_t)b->hsize);
+  b->agg_col = ws.take<int>(E);
+  b->agg_w = ws.take<long long>(E);
+  b->mcount = ws.take<int>(N);
+  b->moff = ws.take<int64_t>(N + 1);
+  b->eoff = ws.take<int64_t>(N + 1);
+  b->members = ws.take<int>(N);
+  b->mdeg = ws.take<int>(N);
+  b->mid_list = ws.take<int>(N);
+  b->big_list = ws.take<int>(N);
   b->rowcnt = ws.take<int>(N);
   b->cursor = ws.take<int>(N);
   b->counters = ws.take<int>(8);
@@ -1082,6 +1204,11 @@ struct LeidenCtx {
   double m2;  // total (quantised) weight = sum of strengths
   unsigned int seed;
   int lm_stop_permille = 10;  // local moving of a level stops once < 1 % of its vertices move in a round
+  // coarse-row build tiers (distinct-neighbour bounds); the env overrides exist so the tests can push small graphs
+  // through the workgroup and multi-pass tiers
+  int agg_wave_max = WH_MAX_DEG;
+  int agg_mid_max = AGG_MID_MAX;
+  int agg_pass_keys = AGG_BIG_PASS;
 };
 
 static bool leiden_debug() {
@@ -1251,28 +1378,43 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(ld_remap_kernel, GRID1(n_orig), 0, cx.s, n_orig, b.cid, b.node_of);
   SCAMD_LAUNCH_CHECK();
-  // hash-combine the coarse edges
-  const unsigned long long hsize = std::min<unsigned long long>(b.hsize, next_pow2(2 * (unsigned long long)g.nnz + 16));
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.hkeys, 0xff, sizeof(unsigned long long) * hsize, cx.s));
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.hvals, 0, sizeof(unsigned long long) * hsize, cx.s));
-  hipLaunchKernelGGL(ld_hash_insert_kernel, GRIDW(g.n), 0, cx.s, g.n, g.indptr, g.indices, g.wq, b.cid, b.hkeys,
-                     b.hvals, hsize - 1);
-  SCAMD_LAUNCH_CHECK();
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.rowcnt, 0, sizeof(int) * nn, cx.s));
+  // group the members of every coarse node, then combine their rows per coarse node in LDS
   SCAMD_HIP_CHECK(hipMemsetAsync(b.cursor, 0, sizeof(int) * nn, cx.s));
-  const unsigned hblocks = (unsigned)((hsize + 255) / 256);
-  hipLaunchKernelGGL(ld_hash_count_kernel, dim3(hblocks), dim3(256), 0, cx.s, b.hkeys, hsize, b.rowcnt);
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
+  hipLaunchKernelGGL(ld_agg_mcount_kernel, GRID1(g.n), 0, cx.s, g.n, b.refsize, b.newid, b.mcount);
+  SCAMD_LAUNCH_CHECK();
+  rc = exclusive_scan_i32_i64(b.mcount, nn, b.moff, b.scan_tmp, cx.s);
+  if (rc != SCAMD_OK) return rc;
+  hipLaunchKernelGGL(ld_agg_scatter_kernel, GRID1(g.n), 0, cx.s, g.n, b.cid, b.moff, b.cursor, g.indptr, b.members,
+                     b.mdeg);
+  SCAMD_LAUNCH_CHECK();
+  rc = exclusive_scan_i32_i64(b.mdeg, g.n, b.eoff, b.scan_tmp, cx.s);
+  if (rc != SCAMD_OK) return rc;
+  const int inn = (int)nn;
+  hipLaunchKernelGGL(ld_agg_wave_kernel, GRIDW(inn), 0, cx.s, inn, b.moff, b.eoff, b.members, g.indptr, g.indices, g.wq,
+                     b.cid, b.agg_col, b.agg_w, b.rowcnt, b.mid_list, b.big_list, b.counters, cx.agg_wave_max,
+                     cx.agg_mid_max);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL((ld_agg_block_kernel<AGG_MID_SLOTS>), dim3(768), dim3(256), (size_t)AGG_MID_SLOTS * 12, cx.s,
+                     b.mid_list, b.counters + 4, inn, b.moff, b.eoff, b.members, g.indptr, g.indices, g.wq, b.cid,
+                     b.agg_col, b.agg_w, b.rowcnt, b.counters + 7, AGG_MID_MAX);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL((ld_agg_block_kernel<BHUB_SLOTS>), dim3(HUB_GRID), dim3(256), HUB_LDS, cx.s, b.big_list,
+                     b.counters + 5, inn, b.moff, b.eoff, b.members, g.indptr, g.indices, g.wq, b.cid, b.agg_col,
+                     b.agg_w, b.rowcnt, b.counters + 7, cx.agg_pass_keys);
   SCAMD_LAUNCH_CHECK();
   CoarseBuf& cb = b.cb[dst];
   rc = exclusive_scan_i32_i64(b.rowcnt, nn, cb.indptr, b.scan_tmp, cx.s);
   if (rc != SCAMD_OK) return rc;
-  // rows are filled in arrival order: nothing downstream depends on the order of a row's entries (all sums are
-  // integer, every choice is an argmax under a total order), so the coarse rows are not sorted
-  hipLaunchKernelGGL(ld_hash_fill_kernel, dim3(hblocks), dim3(256), 0, cx.s, b.hkeys, b.hvals, hsize, cb.indptr,
-                     b.cursor, cb.indices, cb.wq);
+  // the order of a row's entries is arbitrary: nothing downstream depends on it (all sums are integer, every
+  // choice is an argmax under a total order)
+  hipLaunchKernelGGL(ld_agg_compact_kernel, GRIDW(inn), 0, cx.s, inn, b.moff, b.eoff, cb.indptr, b.agg_col, b.agg_w,
+                     cb.indices, cb.wq);
   SCAMD_LAUNCH_CHECK();
   int64_t nnz_new = 0;
   int max_deg = 0;
+  int agg_err = 0;
+  SCAMD_HIP_CHECK(hipMemcpyAsync(&agg_err, b.counters + 7, sizeof(int), hipMemcpyDeviceToHost, cx.s));
   SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 6, 0, sizeof(int), cx.s));
   hipLaunchKernelGGL(ld_maxdeg_kernel, GRID1(nn), 0, cx.s, cb.indptr, (int)nn, b.counters + 6);
   SCAMD_LAUNCH_CHECK();
@@ -1282,6 +1424,7 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   SCAMD_LAUNCH_CHECK();
   SCAMD_HIP_CHECK(hipMemcpyAsync(b.comm, b.comm_tmp, sizeof(int) * nn, hipMemcpyDeviceToDevice, cx.s));
   SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  SCAMD_REQUIRE(agg_err == 0, SCAMD_EINTERNAL, "leiden: coarse-row table overflow");
   out->n = (int)nn;
   out->max_deg = max_deg;
   out->nnz = nnz_new;
@@ -1405,6 +1548,10 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
   cx.gamma = resolution;
   cx.seed = (unsigned int)(seed ^ (seed >> 32)) * 0x9E3779B1u + 0x632BE5ABu;
   if (const char* e = getenv("SCAMD_LEIDEN_LM_STOP_PERMILLE")) cx.lm_stop_permille = atoi(e);
+  if (const char* e = getenv("SCAMD_LEIDEN_AGG_WAVE_MAX")) cx.agg_wave_max = std::min(atoi(e), (int)WH_MAX_DEG);
+  if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_MAX")) cx.agg_mid_max = std::min(atoi(e), (int)AGG_MID_MAX);
+  if (const char* e = getenv("SCAMD_LEIDEN_AGG_PASS_KEYS"))
+    cx.agg_pass_keys = std::max(16, std::min(atoi(e), (int)AGG_BIG_PASS));
   Workspace ws(workspace, workspace_bytes);
   leiden_carve(ws, n, nnz, &cx.b);
   SCAMD_REQUIRE(workspace && ws.ok, SCAMD_EWORKSPACE, "leiden: workspace %zu < required %zu", workspace_bytes,

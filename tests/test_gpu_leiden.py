@@ -119,3 +119,25 @@ def test_leiden_disconnected_and_isolated(K):
     m = m.cpu().numpy()
     assert nc == 5 and len(set(m[:4])) == 1 and len(set(m[4:8])) == 1 and m[0] != m[4]
     assert len(set(m[8:])) == 3
+
+
+@pytest.mark.parametrize(
+    "env",
+    [
+        {"SCAMD_LEIDEN_AGG_WAVE_MAX": "0"},  # every coarse row through the workgroup tier
+        {"SCAMD_LEIDEN_AGG_WAVE_MAX": "0", "SCAMD_LEIDEN_AGG_MID_MAX": "0"},  # ... through the 8192-slot tier
+        {"SCAMD_LEIDEN_AGG_WAVE_MAX": "0", "SCAMD_LEIDEN_AGG_MID_MAX": "0", "SCAMD_LEIDEN_AGG_PASS_KEYS": "16"},
+    ],
+    ids=["mid", "big", "big-multipass"],
+)
+def test_leiden_coarse_row_tiers_agree(K, monkeypatch, env):
+    """the wave / workgroup / multi-pass builders of the coarse graph produce the same graph, so the partition
+    (deterministic given the seed) is the same through each of them"""
+    adj, _ = _blob_graph(6000, 12, seed=3)
+    ip, ix, w, n = _graph_dev(adj.astype(np.float32))
+    m0, q0, nc0 = K.leiden(ip, ix, w, n, seed=5)
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    m1, q1, nc1 = K.leiden(ip, ix, w, n, seed=5)
+    assert nc0 == nc1 and q0 == q1
+    assert np.array_equal(m0.cpu().numpy(), m1.cpu().numpy())
