@@ -551,41 +551,29 @@ __global__ void ld_refine_candidates_kernel(int n, const long long* __restrict__
   if ((double)a_in[v] >= g * kv * (KC - kv)) list[atomicAdd(&counters[2], 1)] = v;
 }
 
-// vertices whose refined community received members this round (their w(r, C - r) must be recomputed);
-// the founder (ref[v] == v) zeroes the accumulator.  counters[3] = list length
-__global__ void ld_touched_members_kernel(int n, const int* __restrict__ ref, const int* __restrict__ touched,
-                                          unsigned long long* __restrict__ Eref, int* __restrict__ rlist,
-                                          int* __restrict__ counters) {
-  int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= n) return;
-  const int r = ref[v];
-  if (touched[r]) {
-    if (r == v) Eref[v] = 0;
-    rlist[atomicAdd(&counters[3], 1)] = v;
-  }
-}
-
-// Eref[r] += w(v, C - r) for the listed members v of refined community r (list length = counters[3], read on the
-// device: no host round trip between building the list and using it)
-__global__ __launch_bounds__(256) void ld_cut_kernel(const int* __restrict__ counters, const int* __restrict__ rlist,
-                                                     const int64_t* __restrict__ indptr,
-                                                     const int* __restrict__ indices, const long long* __restrict__ wq,
-                                                     const int* __restrict__ comm, const int* __restrict__ ref,
-                                                     unsigned long long* __restrict__ Eref) {
+// Exact incremental update of w(r, C - r) after a round of merges.  For a vertex v that joined t this round
+// (stamp[v] == round), with t_old = the members t had before the round and J = the other joiners of the round:
+//   Eref[t] += w(v, C - v) - 2 w(v, t_old) - w(v, J)
+// (summed over the joiners every {v, v'} in J x J pair is subtracted twice, as the cut of the union requires).
+// One wave per joiner; all integer, so the result equals a from-scratch recomputation bit for bit.
+__global__ __launch_bounds__(256) void ld_refine_cut_update_kernel(
+    int n_join, const int* __restrict__ jlist, const int64_t* __restrict__ indptr, const int* __restrict__ indices,
+    const long long* __restrict__ wq, const int* __restrict__ comm, const int* __restrict__ ref,
+    const int* __restrict__ stamp, const long long* __restrict__ a_in, int round,
+    unsigned long long* __restrict__ Eref) {
   const int lane = threadIdx.x & 63;
-  const int n_list = counters[3];
-  for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n_list; w += gridDim.x * 4) {
-    const int v = rlist[w];
-    const int a = comm[v], r = ref[v];
-    long long s = 0;
-    for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) {
-      const int u = indices[e];
-      if (u != v && comm[u] == a && ref[u] != r) s += wq[e];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0 && s != 0) atomicAdd(&Eref[r], (unsigned long long)s);
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n_join) return;
+  const int v = jlist[w];
+  const int a = comm[v], t = ref[v];
+  long long s = 0;
+  for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) {
+    const int u = indices[e];
+    if (u != v && comm[u] == a && ref[u] == t) s += (stamp[u] == round) ? wq[e] : 2 * wq[e];
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) atomicAdd(&Eref[t], (unsigned long long)(a_in[v] - s));
 }
 
 __device__ __forceinline__ bool mover_bit(int v, int round, unsigned int seed) {
@@ -750,16 +738,27 @@ __global__ __launch_bounds__(256) void ld_refine_propose_hub_kernel(
   }
 }
 
-// counters: [0] merges, [2] next candidate list length
+// counters: [0] merges (= joiner list length), [2] next candidate list length
 __global__ void ld_refine_apply_kernel(int n_cand, const int* __restrict__ list, const int* __restrict__ target,
                                        const long long* __restrict__ k, int* __restrict__ ref,
                                        int* __restrict__ refsize, unsigned long long* __restrict__ Kref,
-                                       int* __restrict__ touched, int* __restrict__ list_next,
+                                       unsigned long long* __restrict__ Eref, int* __restrict__ stamp, int round,
+                                       int* __restrict__ jlist, int* __restrict__ list_next,
                                        int* __restrict__ counters) {
-  int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= n_cand) return;
-  const int v = list[w];
-  const int t = target[v];
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int v = (w < n_cand) ? list[w] : -1;
+  const int t = (v >= 0) ? target[v] : -2;
+  // list appends are aggregated per wave: one returning atomic per wave instead of one per element
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const unsigned long long mj = __ballot(t >= 0), mk = __ballot(t == -1);
+  int bj = 0, bk = 0;
+  if (lane == 0) {
+    if (mj) bj = atomicAdd(&counters[0], __popcll(mj));
+    if (mk) bk = atomicAdd(&counters[2], __popcll(mk));
+  }
+  bj = __shfl(bj, 0);
+  bk = __shfl(bk, 0);
   if (t >= 0) {
     // v is a singleton (ref[v] == v) joining t; t's members do not move this round
     ref[v] = t;
@@ -767,10 +766,11 @@ __global__ void ld_refine_apply_kernel(int n_cand, const int* __restrict__ list,
     atomicAdd(&Kref[t], (unsigned long long)k[v]);
     refsize[v] = 0;
     Kref[v] = 0;
-    touched[t] = 1;
-    atomicAdd(&counters[0], 1);
+    Eref[v] = 0;
+    stamp[v] = round;
+    jlist[bj + __popcll(mj & lt)] = v;
   } else if (t == -1) {
-    list_next[atomicAdd(&counters[2], 1)] = v;
+    list_next[bk + __popcll(mk & lt)] = v;
   }
 }
 
@@ -1016,22 +1016,33 @@ __global__ __launch_bounds__(256) void ld_internal_kernel(int n, const int64_t* 
   if (lane == 0 && s != 0) atomicAdd(internal, (unsigned long long)s);
 }
 
-// sumsq[0] = sum_c (Ktot[c] / 2m)^2 in a fixed order (single block)
-__global__ __launch_bounds__(1024) void ld_sumsq_kernel(int n, const unsigned long long* __restrict__ Ktot,
-                                                        double m2, double* __restrict__ out) {
-  __shared__ double sh[1024];
-  double s = 0.0;
-  for (int c = threadIdx.x; c < n; c += 1024) {
-    double f = (double)(long long)Ktot[c] / m2;
-    s += f * f;
-  }
+// sumsq[0] = sum_c (Ktot[c] / 2m)^2 in a fixed order: SUMSQ_BLOCKS partial sums (fixed ranges, fixed tree), then one
+// block adds the partials
+constexpr int SUMSQ_BLOCKS = 256;
+__device__ __forceinline__ double block_sum_1024(double s, double* sh) {
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int o = 512; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = sh[0];
+  return sh[0];
+}
+__global__ __launch_bounds__(1024) void ld_sumsq_kernel(int n, const unsigned long long* __restrict__ Ktot,
+                                                        double m2, double* __restrict__ part) {
+  __shared__ double sh[1024];
+  double s = 0.0;
+  for (int c = blockIdx.x * 1024 + threadIdx.x; c < n; c += SUMSQ_BLOCKS * 1024) {
+    double f = (double)(long long)Ktot[c] / m2;
+    s += f * f;
+  }
+  s = block_sum_1024(s, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(1024) void ld_sumsq_final_kernel(const double* __restrict__ part, double* __restrict__ out) {
+  __shared__ double sh[1024];
+  double s = block_sum_1024((int)threadIdx.x < SUMSQ_BLOCKS ? part[threadIdx.x] : 0.0, sh);
+  if (threadIdx.x == 0) out[0] = s;
 }
 
 // ---- final renumbering by decreasing size ------------------------------------------------------------
@@ -1184,7 +1195,7 @@ static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b
   b->cursor = ws.take<int>(N);
   b->counters = ws.take<int>(8);
   b->total = ws.take<unsigned long long>(4);
-  b->dscratch = ws.take<double>(4);
+  b->dscratch = ws.take<double>(4 + SUMSQ_BLOCKS);
   b->ckeys = ws.take<unsigned long long>(N);
   b->cids = ws.take<int>(N);
   b->newlabel = ws.take<int>(N);
@@ -1239,7 +1250,9 @@ static int quality(LeidenCtx& cx, const LevelGraph& g, const int* comm, double* 
   hipLaunchKernelGGL(ld_internal_kernel, dim3((unsigned)std::min(2048, ceil_div(g.n, 4))), dim3(256), 0, cx.s, g.n, g.indptr, g.indices, g.wq,
                      comm, cx.b.total + 1);
   SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ld_sumsq_kernel, dim3(1), dim3(1024), 0, cx.s, g.n, cx.b.Ktot, cx.m2, cx.b.dscratch);
+  hipLaunchKernelGGL(ld_sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(1024), 0, cx.s, g.n, cx.b.Ktot, cx.m2, cx.b.dscratch + 4);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ld_sumsq_final_kernel, dim3(1), dim3(1024), 0, cx.s, cx.b.dscratch + 4, cx.b.dscratch);
   SCAMD_LAUNCH_CHECK();
   unsigned long long internal = 0;
   double sumsq = 0;
@@ -1305,7 +1318,7 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
   hipLaunchKernelGGL(ld_refine_init_kernel, GRID1(g.n), 0, cx.s, g.n, g.k, b.a_in, b.ref, b.refsize, b.Kref, b.Eref);
   SCAMD_LAUNCH_CHECK();
   SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.touched, 0, sizeof(int) * n, cx.s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.touched, 0xff, sizeof(int) * n, cx.s));  // join-round stamps: -1 = never
   hipLaunchKernelGGL(ld_refine_candidates_kernel, GRID1(g.n), 0, cx.s, g.n, g.k, b.comm, b.Ktot, b.a_in, gg, b.list_a,
                      b.counters);
   SCAMD_LAUNCH_CHECK();
@@ -1328,7 +1341,7 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
       SCAMD_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(ld_refine_apply_kernel, GRID1(n_cand), 0, cx.s, n_cand, b.list_a, b.target, g.k, b.ref,
-                       b.refsize, b.Kref, b.touched, b.list_b, b.counters);
+                       b.refsize, b.Kref, b.Eref, b.touched, round, b.rlist, b.list_b, b.counters);
     SCAMD_LAUNCH_CHECK();
     rc = read_counters(cx, h, 4);
     if (rc != SCAMD_OK) return rc;
@@ -1337,19 +1350,9 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
     n_cand = h[2];
     *n_merged += merges;
     if (merges > 0) {
-      // recompute w(r, C - r) of the communities that grew
-      hipLaunchKernelGGL(ld_touched_members_kernel, GRID1(g.n), 0, cx.s, g.n, b.ref, b.touched, b.Eref, b.rlist,
-                         b.counters);
+      hipLaunchKernelGGL(ld_refine_cut_update_kernel, GRIDW(merges), 0, cx.s, merges, b.rlist, g.indptr, g.indices,
+                         g.wq, b.comm, b.ref, b.touched, b.a_in, round, b.Eref);
       SCAMD_LAUNCH_CHECK();
-      {
-        // at most as many members as the merged communities can hold: size the grid by the merge count, the kernel
-        // strides over the device-side list length
-        const int blocks = std::min(4096, std::max(64, ceil_div(g.n, 4)));
-        hipLaunchKernelGGL(ld_cut_kernel, dim3(blocks), dim3(256), 0, cx.s, b.counters, b.rlist, g.indptr, g.indices,
-                           g.wq, b.comm, b.ref, b.Eref);
-        SCAMD_LAUNCH_CHECK();
-      }
-      SCAMD_HIP_CHECK(hipMemsetAsync(b.touched, 0, sizeof(int) * n, cx.s));
     }
     if (leiden_debug()) fprintf(stderr, "[leiden] rf n=%d round=%d cand=%d merges=%d\n", g.n, round, n_cand, merges);
     quiet = (merges == 0) ? quiet + 1 : 0;
