@@ -271,110 +271,150 @@ __device__ __forceinline__ Cand block_best(Cand x, long long& w_own, Cand* sh_c,
 // kernel appends to a list through a single global counter: at 1M vertices that serialised on one L2 atomic
 // (~12 ns each, 15 ms for the first round alone).
 
-// One wave per ACTIVE vertex (list[0..n_act)): decision[w] = community to move to, -1 = stay,
+// G lanes per ACTIVE vertex (list[0..n_act)): decision[w] = community to move to, -1 = stay,
 // -2 = wants to move but the direction rule forbids it this round (stays active).
+//   G = 64: one wave per vertex, table of up to 512 slots (deg <= 384); hubs go to hub_list (counters[4]).
+//   G = 16: FOUR vertices per wave, 128 slots each (deg <= 96) -- a kNN graph's rows are ~2k long, and the kernel
+//           is bound by its chain of dependent gathers (list -> indptr -> indices -> comm -> Ktot), so four
+//           vertices per wave put four times as many gathers in flight per wave slot.  Longer rows go to
+//           ovf_list (counters[5]) and are decided by the G = 64 instantiation in indirect mode
+//           (sub_list / sub_count = positions in `list`, grid-strided).
+template <int G>
 __global__ __launch_bounds__(256) void ld_move_kernel(
-    int n_act, const int* __restrict__ list, const int64_t* __restrict__ indptr, const int* __restrict__ indices,
-    const long long* __restrict__ wq, const long long* __restrict__ k, const int* __restrict__ comm,
-    const unsigned long long* __restrict__ Ktot, const int* __restrict__ csize, double g /* gamma / 2m */,
-    int round, unsigned int seed, int* __restrict__ decision, int* __restrict__ hub_list,
-    int* __restrict__ counters) {
-  const int lane = threadIdx.x & 63;
-  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (w >= n_act) return;
-  const int v = list[w];
-  const int64_t beg = indptr[v];
-  const int deg = (int)(indptr[v + 1] - beg);
-  if (deg > WH_MAX_DEG && deg <= BHUB_MAX_DEG) {  // hub: decided by ld_move_hub_kernel
-    if (lane == 0) hub_list[atomicAdd(&counters[4], 1)] = w;
-    return;
-  }
-  const int a = comm[v];
-  const double kv = (double)k[v];
-  const double Ka_wo = (double)(long long)(Ktot[a] - (unsigned long long)k[v]);  // own community without v
-  Cand best;
-  best.val = 0.0;
-  best.c = -1;
-  best.pr = 0;
-  long long w_own = 0;
-  if (deg <= WH_MAX_DEG) {
-    __shared__ int hkeys[4][WH_SLOTS];
-    __shared__ unsigned long long hvals[4][WH_SLOTS];
-    WaveHash wh{hkeys[threadIdx.x >> 6], hvals[threadIdx.x >> 6], WH_SLOTS};
-    wh.size_for(deg);
-    wh.clear(lane);
-    for (int e = lane; e < deg; e += 64) {
-      const int u = indices[beg + e];
-      if (u != v) wh.add(comm[u], wq[beg + e]);
+    int n_act, const int* __restrict__ list, const int* __restrict__ sub_list, const int* __restrict__ sub_count,
+    const int64_t* __restrict__ indptr, const int* __restrict__ indices, const long long* __restrict__ wq,
+    const long long* __restrict__ k, const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot,
+    const int* __restrict__ csize, double g /* gamma / 2m */, int round, unsigned int seed,
+    int* __restrict__ decision, int* __restrict__ ovf_list, int* __restrict__ hub_list, int* __restrict__ counters) {
+  constexpr int GROUPS = 256 / G;            // vertices per workgroup
+  constexpr int GSLOTS = WH_SLOTS * G / 64;  // table slots per vertex
+  constexpr int GMAX = GSLOTS * 3 / 4;       // longest row the table takes
+  __shared__ int hkeys[GROUPS][GSLOTS];
+  __shared__ unsigned long long hvals[GROUPS][GSLOTS];
+  const int sub = threadIdx.x % G;
+  const int grp = threadIdx.x / G;
+  const int n_items = sub_list ? *sub_count : n_act;
+  for (int item = blockIdx.x * GROUPS + grp; item < n_items; item += gridDim.x * GROUPS) {
+    const int w = sub_list ? sub_list[item] : item;
+    const int v = list[w];
+    const int64_t beg = indptr[v];
+    const int deg = (int)(indptr[v + 1] - beg);
+    if (G < 64) {
+      if (deg > GMAX) {  // decided by the wave-per-vertex instantiation
+        if (sub == 0) ovf_list[atomicAdd(&counters[5], 1)] = w;
+        continue;
+      }
+    } else if (deg > WH_MAX_DEG && deg <= BHUB_MAX_DEG) {  // hub: decided by ld_move_hub_kernel
+      if (sub == 0) hub_list[atomicAdd(&counters[4], 1)] = w;
+      continue;
     }
-    for (int sl = lane; sl < wh.nslots; sl += 64) {
-      const int c = wh.key(sl);
-      if (c != WH_EMPTY) {
-        const long long sum = wh.val(sl);
-        if (c == a) {
-          w_own = sum;
-        } else {
-          Cand x;
-          x.val = (double)sum - g * kv * (double)(long long)Ktot[c];
-          x.c = c;
-          x.pr = prio(c, seed);
-          if (cand_better(x, best)) best = x;
+    const int a = comm[v];
+    const double kv = (double)k[v];
+    const double Ka_wo = (double)(long long)(Ktot[a] - (unsigned long long)k[v]);  // own community without v
+    Cand best;
+    best.val = 0.0;
+    best.c = -1;
+    best.pr = 0;
+    long long w_own = 0;
+    if (deg <= GMAX) {
+      int* keys = hkeys[grp];
+      unsigned long long* vals = hvals[grp];
+      const int nslots = (G < 64 || deg <= 96) ? 128 : (deg <= 192 ? 256 : 512);
+      for (int i = sub; i < nslots; i += G) {
+        keys[i] = WH_EMPTY;
+        vals[i] = 0ull;
+      }
+      for (int e = sub; e < deg; e += G) {
+        const int u = indices[beg + e];
+        if (u != v) {
+          const int c = comm[u];
+          unsigned int slot = hash32((unsigned int)c) & (nslots - 1);
+          for (;;) {
+            const int prev = atomicCAS(&keys[slot], WH_EMPTY, c);
+            if (prev == WH_EMPTY || prev == c) break;
+            slot = (slot + 1) & (nslots - 1);
+          }
+          atomicAdd(&vals[slot], (unsigned long long)wq[beg + e]);
+        }
+      }
+      for (int sl = sub; sl < nslots; sl += G) {
+        const int c = __hip_atomic_load(&keys[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (c != WH_EMPTY) {
+          const long long sum = (long long)__hip_atomic_load(&vals[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (c == a) {
+            w_own = sum;
+          } else {
+            Cand x;
+            x.val = (double)sum - g * kv * (double)(long long)Ktot[c];
+            x.c = c;
+            x.pr = prio(c, seed);
+            if (cand_better(x, best)) best = x;
+          }
+        }
+      }
+    } else if (G == 64) {
+      // rows beyond the workgroup tables: all-pairs compare through readlane
+      const int lane = sub;
+      for (int cb = 0; cb < deg; cb += 64) {
+        const int e = cb + lane;
+        int u = (e < deg) ? indices[beg + e] : -1;
+        const int c = (u >= 0 && u != v) ? comm[u] : -1;
+        long long sum = 0;
+        for (int db = 0; db < deg; db += 64) {
+          const int e2 = db + lane;
+          int c2 = -1;
+          long long w2 = 0;
+          if (e2 < deg) {
+            const int u2 = indices[beg + e2];
+            if (u2 != v) {
+              c2 = (db == cb) ? c : comm[u2];
+              w2 = wq[beg + e2];
+            }
+          }
+          const int cnt = min(64, deg - db);
+          for (int t = 0; t < cnt; ++t) {
+            const int ct = __builtin_amdgcn_readlane(c2, t);
+            const long long wt = readlane_i64(w2, t);
+            if (ct == c) sum += wt;
+          }
+        }
+        if (c >= 0) {
+          if (c == a) {
+            w_own = sum;
+          } else {
+            Cand x;
+            x.val = (double)sum - g * kv * (double)(long long)Ktot[c];
+            x.c = c;
+            x.pr = prio(c, seed);
+            if (cand_better(x, best)) best = x;
+          }
         }
       }
     }
-  } else
-  for (int cb = 0; cb < deg; cb += 64) {
-    const int e = cb + lane;
-    int u = (e < deg) ? indices[beg + e] : -1;
-    const int c = (u >= 0 && u != v) ? comm[u] : -1;
-    long long sum = 0;
-    for (int db = 0; db < deg; db += 64) {
-      const int e2 = db + lane;
-      int c2 = -1;
-      long long w2 = 0;
-      if (e2 < deg) {
-        const int u2 = indices[beg + e2];
-        if (u2 != v) {
-          c2 = (db == cb) ? c : comm[u2];
-          w2 = wq[beg + e2];
-        }
-      }
-      const int cnt = min(64, deg - db);
-      for (int t = 0; t < cnt; ++t) {
-        const int ct = __builtin_amdgcn_readlane(c2, t);
-        const long long wt = readlane_i64(w2, t);
-        if (ct == c) sum += wt;
-      }
-    }
-    if (c >= 0) {
-      if (c == a) {
-        w_own = sum;
-      } else {
-        Cand x;
-        x.val = (double)sum - g * kv * (double)(long long)Ktot[c];
-        x.c = c;
-        x.pr = prio(c, seed);
-        if (cand_better(x, best)) best = x;
-      }
-    }
-  }
-  best = wave_best(best);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) w_own = max(w_own, __shfl_xor(w_own, o));
-  const double stay = (double)w_own - g * kv * Ka_wo;
-  int target = a;
-  bool wants = false, allowed = true;
-  if (best.c >= 0 && best.val > stay) {
-    wants = true;
-    target = best.c;
-    const unsigned int pa = prio(a, seed), pb = best.pr;
-    allowed = (round & 1) ? (pb > pa || (pb == pa && target > a)) : (pb < pa || (pb == pa && target < a));
-  } else if (stay < 0.0 && Ka_wo > 0.0 && csize[v] == 0) {
-    // leaving for an empty community (id = own vertex id, free at the snapshot) beats staying
-    wants = true;
-    target = v;
+    for (int o = G / 2; o > 0; o >>= 1) {
+      Cand y;
+      y.val = __shfl_xor(best.val, o);
+      y.c = __shfl_xor(best.c, o);
+      y.pr = (unsigned int)__shfl_xor((int)best.pr, o);
+      if (cand_better(y, best)) best = y;
+      w_own = max(w_own, __shfl_xor(w_own, o));
+    }
+    const double stay = (double)w_own - g * kv * Ka_wo;
+    int target = a;
+    bool wants = false, allowed = true;
+    if (best.c >= 0 && best.val > stay) {
+      wants = true;
+      target = best.c;
+      const unsigned int pa = prio(a, seed), pb = best.pr;
+      allowed = (round & 1) ? (pb > pa || (pb == pa && target > a)) : (pb < pa || (pb == pa && target < a));
+    } else if (stay < 0.0 && Ka_wo > 0.0 && csize[v] == 0) {
+      // leaving for an empty community (id = own vertex id, free at the snapshot) beats staying
+      wants = true;
+      target = v;
+    }
+    if (sub == 0) decision[w] = (wants && allowed) ? target : (wants ? -2 : -1);
   }
-  if (lane == 0) decision[w] = (wants && allowed) ? target : (wants ? -2 : -1);
 }
 
 // Hub vertices of the active list (positions in hub_list[0 .. counters[4])): one workgroup each.
@@ -1263,6 +1303,13 @@ static int quality(LeidenCtx& cx, const LevelGraph& g, const int* comm, double* 
   return SCAMD_OK;
 }
 
+// levels whose rows are short on average (the kNN graph itself) take the four-vertices-per-wave kernels
+constexpr int QUAD_MAX_DEG = WH_SLOTS / 4 * 3 / 4;  // 96: rows the 128-slot quarter-wave table takes
+static bool level_is_short_rowed(const LevelGraph& g) {
+  if (const char* e = getenv("SCAMD_LEIDEN_QUAD")) return atoi(e) != 0;  // tests: force either kernel family
+  return g.n > 0 && g.nnz / g.n <= 40;
+}
+
 static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
   LeidenBuffers& b = cx.b;
   const double gg = cx.gamma / cx.m2;
@@ -1275,11 +1322,27 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
   SCAMD_HIP_CHECK(hipMemsetAsync(b.flag, 0, sizeof(int) * n, cx.s));
   int n_act = g.n;
   int quiet = 0;
+  const bool quad = level_is_short_rowed(g);
   for (int round = 0; round < MAX_LM_ROUNDS && n_act > 0; ++round) {
     SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
-    hipLaunchKernelGGL(ld_move_kernel, GRIDW(n_act), 0, cx.s, n_act, b.list_a, g.indptr, g.indices, g.wq, g.k, b.comm,
-                       b.Ktot, b.csize, gg, round, cx.seed, b.target, b.hub_list, b.counters);
-    SCAMD_LAUNCH_CHECK();
+    if (quad) {
+      hipLaunchKernelGGL(ld_move_kernel<16>, dim3((unsigned)ceil_div(n_act, 16)), dim3(256), 0, cx.s, n_act, b.list_a,
+                         (const int*)nullptr, (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
+                         b.csize, gg, round, cx.seed, b.target, b.mid_list, b.hub_list, b.counters);
+      SCAMD_LAUNCH_CHECK();
+      if (g.max_deg > QUAD_MAX_DEG) {
+        hipLaunchKernelGGL(ld_move_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(n_act, 4))), dim3(256), 0, cx.s,
+                           n_act, b.list_a, (const int*)b.mid_list, (const int*)(b.counters + 5), g.indptr, g.indices,
+                           g.wq, g.k, b.comm, b.Ktot, b.csize, gg, round, cx.seed, b.target, b.mid_list, b.hub_list,
+                           b.counters);
+        SCAMD_LAUNCH_CHECK();
+      }
+    } else {
+      hipLaunchKernelGGL(ld_move_kernel<64>, GRIDW(n_act), 0, cx.s, n_act, b.list_a, (const int*)nullptr,
+                         (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg, round,
+                         cx.seed, b.target, b.mid_list, b.hub_list, b.counters);
+      SCAMD_LAUNCH_CHECK();
+    }
     if (g.max_deg > WH_MAX_DEG) {
       hipLaunchKernelGGL(ld_move_hub_kernel, dim3(HUB_GRID), dim3(256), HUB_LDS, cx.s, b.hub_list, b.counters, b.list_a,
                          g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg, round, cx.seed, b.target);

@@ -141,3 +141,15 @@ def test_leiden_coarse_row_tiers_agree(K, monkeypatch, env):
     m1, q1, nc1 = K.leiden(ip, ix, w, n, seed=5)
     assert nc0 == nc1 and q0 == q1
     assert np.array_equal(m0.cpu().numpy(), m1.cpu().numpy())
+
+
+def test_leiden_quarter_wave_kernels_agree(K, monkeypatch):
+    """four-vertices-per-wave and wave-per-vertex decision kernels implement the same rule: same partition"""
+    adj, _ = _blob_graph(6000, 12, seed=4)
+    ip, ix, w, n = _graph_dev(adj.astype(np.float32))
+    monkeypatch.setenv("SCAMD_LEIDEN_QUAD", "0")
+    m0, q0, nc0 = K.leiden(ip, ix, w, n, seed=7)
+    monkeypatch.setenv("SCAMD_LEIDEN_QUAD", "1")
+    m1, q1, nc1 = K.leiden(ip, ix, w, n, seed=7)
+    assert nc0 == nc1 and q0 == q1
+    assert np.array_equal(m0.cpu().numpy(), m1.cpu().numpy())
