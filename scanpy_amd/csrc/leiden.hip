@@ -31,6 +31,7 @@ constexpr double WSCALE = 4294967296.0;  // 2^32
 constexpr int MAX_LM_ROUNDS = 128;
 constexpr int MAX_RF_ROUNDS = 48;
 constexpr int RF_QUIET_ROUNDS = 3;
+constexpr int RF_BATCH = 4;  // refinement rounds per host round trip
 constexpr int MAX_LEVELS = 64;
 constexpr int MAX_OUTER_ITERS = 32;
 
@@ -600,10 +601,10 @@ __global__ __launch_bounds__(256) void ld_refine_cut_update_kernel(
     int n_join, const int* __restrict__ jlist, const int64_t* __restrict__ indptr, const int* __restrict__ indices,
     const long long* __restrict__ wq, const int* __restrict__ comm, const int* __restrict__ ref,
     const int* __restrict__ stamp, const long long* __restrict__ a_in, int round,
-    unsigned long long* __restrict__ Eref) {
+    unsigned long long* __restrict__ Eref, const int* __restrict__ n_join_dev) {
   const int lane = threadIdx.x & 63;
-  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (w >= n_join) return;
+  n_join = *n_join_dev;
+  for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n_join; w += gridDim.x * 4) {
   const int v = jlist[w];
   const int a = comm[v], t = ref[v];
   long long s = 0;
@@ -614,6 +615,7 @@ __global__ __launch_bounds__(256) void ld_refine_cut_update_kernel(
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if (lane == 0) atomicAdd(&Eref[t], (unsigned long long)(a_in[v] - s));
+  }
 }
 
 __device__ __forceinline__ bool mover_bit(int v, int round, unsigned int seed) {
@@ -627,10 +629,12 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
     const long long* __restrict__ wq, const long long* __restrict__ k, const int* __restrict__ comm,
     const unsigned long long* __restrict__ Ktot, const int* __restrict__ ref, const int* __restrict__ refsize,
     const unsigned long long* __restrict__ Kref, const unsigned long long* __restrict__ Eref, double g, int round,
-    unsigned int seed, int* __restrict__ target, int* __restrict__ hub_list, int* __restrict__ counters) {
+    unsigned int seed, int* __restrict__ target, int* __restrict__ hub_list, int* __restrict__ counters,
+    const int* __restrict__ n_cand_dev, const int* __restrict__ stop) {
   const int lane = threadIdx.x & 63;
-  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (w >= n_cand) return;
+  if (*stop) return;
+  n_cand = *n_cand_dev;  // list length of this round, produced on the device by the previous round
+  for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n_cand; w += gridDim.x * 4) {
   const int v = list[w];
   int tgt = -1;
   if (refsize[v] != 1 || ref[v] != v) {
@@ -643,7 +647,7 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
     const int deg = (int)(indptr[v + 1] - beg);
     if (deg > WH_MAX_DEG && deg <= BHUB_MAX_DEG) {  // hub: proposed by ld_refine_propose_hub_kernel
       if (lane == 0) hub_list[atomicAdd(&counters[4], 1)] = v;
-      return;
+      continue;
     }
     Cand best;
     best.val = 0.0;
@@ -720,6 +724,7 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
     tgt = best.c;
   }
   if (lane == 0) target[v] = tgt;
+  }
 }
 
 // Hub candidates (vertex ids in hub_list[0 .. counters[4])): one workgroup each; same rule as the wave kernel.
@@ -784,9 +789,13 @@ __global__ void ld_refine_apply_kernel(int n_cand, const int* __restrict__ list,
                                        int* __restrict__ refsize, unsigned long long* __restrict__ Kref,
                                        unsigned long long* __restrict__ Eref, int* __restrict__ stamp, int round,
                                        int* __restrict__ jlist, int* __restrict__ list_next,
-                                       int* __restrict__ counters) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+                                       int* __restrict__ counters, const int* __restrict__ n_cand_dev,
+                                       const int* __restrict__ stop) {
   const int lane = threadIdx.x & 63;
+  if (*stop) return;
+  n_cand = *n_cand_dev;
+  for (int w0 = blockIdx.x * blockDim.x; w0 < n_cand; w0 += gridDim.x * blockDim.x) {
+  const int w = w0 + threadIdx.x;
   const int v = (w < n_cand) ? list[w] : -1;
   const int t = (v >= 0) ? target[v] : -2;
   // list appends are aggregated per wave: one returning atomic per wave instead of one per element
@@ -812,6 +821,20 @@ __global__ void ld_refine_apply_kernel(int n_cand, const int* __restrict__ list,
   } else if (t == -1) {
     list_next[bk + __popcll(mk & lt)] = v;
   }
+  }
+}
+
+// round control, one thread: the stop rule of the refinement (RF_QUIET_ROUNDS rounds without a merge, or an empty
+// candidate list) evaluated on the device so that a batch of rounds runs without a host round trip.
+// ctl: [0] stop, [1] quiet rounds, [2] rounds done, [3] total merges
+__global__ void ld_refine_ctl_kernel(const int* __restrict__ counters, int* __restrict__ ctl) {
+  if (ctl[0]) return;
+  const int merges = counters[0];
+  const int quiet = merges == 0 ? ctl[1] + 1 : 0;
+  ctl[1] = quiet;
+  ctl[2] += 1;
+  ctl[3] += merges;
+  if (quiet >= RF_QUIET_ROUNDS || counters[2] == 0) ctl[0] = 1;
 }
 
 __global__ void ld_refine_init_kernel(int n, const long long* __restrict__ k, const long long* __restrict__ a_in,
@@ -1176,7 +1199,7 @@ struct LeidenBuffers {
   int* agg_col; long long* agg_w;  // scratch CSR of the coarse-graph build (rows at upper-bound offsets)
   int* mcount; int64_t* moff; int64_t* eoff; int* members; int* mdeg; int* mid_list; int* big_list;
   int* rowcnt; int* cursor;
-  int* counters; unsigned long long* total; double* dscratch;
+  int* counters; int* rcounters; unsigned long long* total; double* dscratch;
   unsigned long long* ckeys; int* cids; int* newlabel; int* minmember;
 };
 
@@ -1234,6 +1257,7 @@ static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b
   b->rowcnt = ws.take<int>(N);
   b->cursor = ws.take<int>(N);
   b->counters = ws.take<int>(8);
+  b->rcounters = ws.take<int>(8 * MAX_RF_ROUNDS + 8);
   b->total = ws.take<unsigned long long>(4);
   b->dscratch = ws.take<double>(4 + SUMSQ_BLOCKS);
   b->ckeys = ws.take<unsigned long long>(N);
@@ -1388,39 +1412,56 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
   int h[4];
   int rc = read_counters(cx, h, 4);
   if (rc != SCAMD_OK) return rc;
-  int n_cand = h[2];
   *n_merged = 0;
-  int quiet = 0;
-  for (int round = 0; round < MAX_RF_ROUNDS && n_cand > 0; ++round) {
-    SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
-    hipLaunchKernelGGL(ld_refine_propose_kernel, GRIDW(n_cand), 0, cx.s, n_cand, b.list_a, g.indptr, g.indices, g.wq,
-                       g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, gg, round, cx.seed, b.target, b.hub_list,
-                       b.counters);
-    SCAMD_LAUNCH_CHECK();
-    if (g.max_deg > WH_MAX_DEG) {
-      hipLaunchKernelGGL(ld_refine_propose_hub_kernel, dim3(HUB_GRID), dim3(256), HUB_LDS, cx.s, b.hub_list, b.counters,
-                         g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, gg, round,
-                         cx.seed, b.target);
+  // Rounds run in batches of RF_BATCH without a host round trip: list lengths, merge counts and the stop rule
+  // live on the device (one 8-int counter block per round + ld_refine_ctl_kernel); the host only sizes the grids
+  // from the last list length it has seen (lengths never grow) and looks at the stop flag between batches.
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.rcounters, 0, sizeof(int) * (8 * MAX_RF_ROUNDS + 8), cx.s));
+  int* ctl = b.rcounters + 8 * MAX_RF_ROUNDS;
+  const int* n_in = b.counters + 2;  // length of the initial candidate list
+  int ub = h[2];
+  int hctl[4] = {0, 0, 0, 0};
+  int round = 0;
+  while (round < MAX_RF_ROUNDS && ub > 0) {
+    const int batch = std::min(RF_BATCH, MAX_RF_ROUNDS - round);
+    const int first = round;
+    const unsigned wgrid = (unsigned)std::min(32768, ceil_div(ub, 4));
+    const unsigned tgrid = (unsigned)std::min(32768, ceil_div(ub, 256));
+    int* rcnt = nullptr;
+    for (int i = 0; i < batch; ++i, ++round) {
+      rcnt = b.rcounters + 8 * round;
+      hipLaunchKernelGGL(ld_refine_propose_kernel, dim3(wgrid), dim3(256), 0, cx.s, ub, b.list_a, g.indptr, g.indices,
+                         g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, gg, round, cx.seed, b.target,
+                         b.hub_list, rcnt, n_in, (const int*)ctl);
       SCAMD_LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(ld_refine_apply_kernel, GRID1(n_cand), 0, cx.s, n_cand, b.list_a, b.target, g.k, b.ref,
-                       b.refsize, b.Kref, b.Eref, b.touched, round, b.rlist, b.list_b, b.counters);
-    SCAMD_LAUNCH_CHECK();
-    rc = read_counters(cx, h, 4);
-    if (rc != SCAMD_OK) return rc;
-    const int merges = h[0];
-    std::swap(b.list_a, b.list_b);
-    n_cand = h[2];
-    *n_merged += merges;
-    if (merges > 0) {
-      hipLaunchKernelGGL(ld_refine_cut_update_kernel, GRIDW(merges), 0, cx.s, merges, b.rlist, g.indptr, g.indices,
-                         g.wq, b.comm, b.ref, b.touched, b.a_in, round, b.Eref);
+      if (g.max_deg > WH_MAX_DEG) {
+        hipLaunchKernelGGL(ld_refine_propose_hub_kernel, dim3(HUB_GRID), dim3(256), HUB_LDS, cx.s, b.hub_list, rcnt,
+                           g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, gg, round,
+                           cx.seed, b.target);
+        SCAMD_LAUNCH_CHECK();
+      }
+      hipLaunchKernelGGL(ld_refine_apply_kernel, dim3(tgrid), dim3(256), 0, cx.s, ub, b.list_a, b.target, g.k, b.ref,
+                         b.refsize, b.Kref, b.Eref, b.touched, round, b.rlist, b.list_b, rcnt, n_in, (const int*)ctl);
       SCAMD_LAUNCH_CHECK();
+      hipLaunchKernelGGL(ld_refine_cut_update_kernel, dim3(wgrid), dim3(256), 0, cx.s, ub, b.rlist, g.indptr, g.indices,
+                         g.wq, b.comm, b.ref, b.touched, b.a_in, round, b.Eref, (const int*)rcnt);
+      SCAMD_LAUNCH_CHECK();
+      hipLaunchKernelGGL(ld_refine_ctl_kernel, dim3(1), dim3(1), 0, cx.s, (const int*)rcnt, ctl);
+      SCAMD_LAUNCH_CHECK();
+      std::swap(b.list_a, b.list_b);
+      n_in = rcnt + 2;
     }
-    if (leiden_debug()) fprintf(stderr, "[leiden] rf n=%d round=%d cand=%d merges=%d\n", g.n, round, n_cand, merges);
-    quiet = (merges == 0) ? quiet + 1 : 0;
-    if (quiet >= RF_QUIET_ROUNDS) break;
+    int hr[8 * RF_BATCH];
+    SCAMD_HIP_CHECK(hipMemcpyAsync(hctl, ctl, sizeof(int) * 4, hipMemcpyDeviceToHost, cx.s));
+    SCAMD_HIP_CHECK(hipMemcpyAsync(hr, b.rcounters + 8 * first, sizeof(int) * 8 * batch, hipMemcpyDeviceToHost, cx.s));
+    SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+    if (leiden_debug())
+      for (int i = 0; i < batch && first + i < hctl[2]; ++i)
+        fprintf(stderr, "[leiden] rf n=%d round=%d cand=%d merges=%d\n", g.n, first + i, hr[8 * i + 2], hr[8 * i]);
+    if (hctl[0]) break;
+    ub = hr[8 * (batch - 1) + 2];
   }
+  *n_merged = hctl[3];
   return SCAMD_OK;
 }
 
