@@ -80,12 +80,14 @@ def cpu_baseline(n_sample: int, n_vars: int, n_comps: int, k: int, seed: int) ->
     }
 
 
-def _profiled_traffic():
+def _profiled_traffic(mode: str):
     """HBM-side bytes per launch of the roofline kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE are separate profiling runs, they cannot be taken inside this process); None if not profiled."""
+    WRITE_SIZE are separate profiling runs, they cannot be taken inside this process); None if the committed passes
+    are of a different sweep mode than the one that ran (or absent)."""
     f = ROOT / "profiles" / "knn_select_traffic.json"
     try:
-        return json.loads(f.read_text())["bytes_per_launch"]
+        d = json.loads(f.read_text())
+        return d["bytes_per_launch"] if d.get("mode") == mode else None
     except (OSError, KeyError, ValueError):
         return None
 
@@ -199,7 +201,7 @@ def main() -> None:
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": (achieved / peak) if achieved else None,
-                "traffic": None,  # the committed PMC passes (profiles/knn_select_traffic.json) are of the brute-force sweep
+                "traffic": _profiled_traffic("ivf" if 0 < pairs < brute_pairs else "brute"),
                 "launch_ms": sel,
                 "algorithmic_flop_per_launch": flops,
                 "pairs_evaluated_fraction": pairs / brute_pairs if brute_pairs > 0 else None,

@@ -23,11 +23,34 @@ for P in "$PMC1" "$PMC2" "FETCH_SIZE" "WRITE_SIZE"; do
 done
 cd $R
 python - <<PY
-import csv, glob, collections
+import csv, glob, collections, json
+# the roofline kernel = the knn_select_reg_kernel dispatch with the largest grid of the pass
+tot = {}
 for f in sorted(glob.glob("$OUT/knn_pmc*.csv")):
+    rows = [r for r in csv.DictReader(open(f)) if "knn_select_reg" in r.get("Kernel_Name", "")]
+    if not rows:
+        continue
+    gmax = max(int(r["Grid_Size"]) for r in rows)
     acc = collections.defaultdict(float)
-    for row in csv.DictReader(open(f)):
-        if "knn_select" in row.get("Kernel_Name", ""):
-            acc[row["Counter_Name"]] += float(row["Counter_Value"])
-    print(f, dict(acc))
+    name = ""
+    for r in rows:
+        if int(r["Grid_Size"]) == gmax:
+            acc[r["Counter_Name"]] += float(r["Counter_Value"])
+            name = r["Kernel_Name"]
+    print(f, gmax, dict(acc))
+    tot.update(acc)
+    tot["kernel"] = name[:160]
+if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
+    out = {
+        "kernel": tot["kernel"],
+        "mode": "ivf",
+        "FETCH_SIZE_KB": tot["FETCH_SIZE"],
+        "WRITE_SIZE_KB": tot["WRITE_SIZE"],
+        "bytes_per_launch": 2.0 * tot["FETCH_SIZE"] * 1024 + tot["WRITE_SIZE"] * 1024,
+        "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/knn_only.py 1000000 (cell-pruned sweep, "
+                "summed over the dispatch's rows = all XCDs); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports "
+                "1/2 of wide coalesced reads); counts L2-side fabric requests incl. Infinity-Cache hits",
+    }
+    json.dump(out, open("$OUT/knn_select_traffic.json", "w"), indent=1)
+    print(out)
 PY
