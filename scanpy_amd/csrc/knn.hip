@@ -405,6 +405,11 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
   }
 
   int n_sub = 0;  // sub-tiles of the current sweep
+  // cell-pruned mode: `minima` = the pre-pass over the own cell (key[r] collects, per lane, the smallest score of the
+  // candidates j = lane (mod 32): 32 distinct candidates per query); athr_floor = the threshold derived from it,
+  // which the list threshold can only tighten (same lane layout as athr)
+  bool minima = false;
+  float athr_floor = half ? 1.0f : -INFINITY;
   // B operand of sub-tile g of the current sweep: lane l holds candidate (l&31), the same dim slice as A, then
   // the extra k slot
   auto load_b = [&](int g, float (&b)[HP]) {
@@ -450,6 +455,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
         // new thresholds of the two queries this register belongs to -> their lanes of the A operand
         const float t0 = readlane_f32(key[r], thr_lane), t1 = readlane_f32(key[r], 32 + thr_lane);
         athr = (lane == i0) ? -t0 : ((lane == i1) ? -t1 : athr);
+        if constexpr (IVF) athr = fmaxf(athr, athr_floor);  // -thr = max(-t, -thr_floor); 1.0 stays 1.0 on lanes >= 32
       }
     }
   };
@@ -481,6 +487,13 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+    }
+    if constexpr (IVF) {
+      if (minima) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) key[r] = fminf(key[r], acc_prev[r]);
+        return;
+      }
     }
     if (hit) insert(acc_prev, athr_prev, row0 + (g - 1) * 32, false);
   };
@@ -516,7 +529,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     f32x16 accA, accB;
     float athrA = athr, athrB = athr;
     load_b(0, bA);
-    if (first) {
+    if (!IVF && first) {
       // sub-tile 0: plain scores (threshold 0), every finite one is inserted; afterwards all thresholds are
       // finite whenever the sub-tile holds at least thr_rank real rows
       f32x16 zero;
@@ -538,7 +551,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     constexpr int HPT = SUBS / 2;
     for (int h = 0; h < HPT * n_tiles; ++h) {
       const int g = 2 * h;
-      if (h > 0 || !first) step(g, bA, accA, athrA, accB, athrB, bB);
+      if (IVF || h > 0 || !first) step(g, bA, accA, athrA, accB, athrB, bB);
       if ((h % HPT) == HPT - 1) {
         const int t = h / HPT;
         if (t + 1 < n_tiles) lstore((t + 1) & 1);  // buffer of tile t-1: free since the previous barrier
@@ -553,7 +566,12 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
       bool neg = false;
 #pragma unroll
       for (int r = 0; r < 16; ++r) neg |= accB[r] < 0.f;
-      if (__any(neg)) insert(accB, athrB, row0 + (n_sub - 1) * 32, false);
+      if (IVF && minima) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) key[r] = fminf(key[r], accB[r]);
+      } else if (__any(neg)) {
+        insert(accB, athrB, row0 + (n_sub - 1) * 32, false);
+      }
     }
   };
 
@@ -612,6 +630,41 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     }
     // exact threshold distance^2 of a query = thr (score space) + ||q||^2; per wave the max over its real queries
     const float qn = xp[qrow * DPL + HP + H];  // ||q||^2 sits in the extra k slot of the row's second half
+    // ---- pre-pass: a tight starting threshold from the own cell ----
+    // A streaming top-k list with threshold "current thr_rank-th best" inserts ~thr_rank*(1 + ln(N/thr_rank))
+    // candidates per query, most of them while the list warms up; each insertion costs ~30 VALU on the lanes the
+    // MFMA chain needs.  The pre-pass sweeps the own cell once with threshold 0 (acc = plain score) and only
+    // keeps lane-wise minima (16 v_min per sub-tile, no branches): 32 distinct candidates per query, whose
+    // thr_rank-th smallest bounds the final threshold from above (~ the 34th nearest of the cell for rank 21).
+    // The real sweep then starts with that threshold: about half as many insertions in total.
+    {
+      minima = true;
+      const int pre_tiles = min(iv.cell_ntiles[a], 48);
+      if (tid == 0) atomicAdd(iv.pairs, (unsigned long long)pre_tiles * TC * C::QB);  // evaluated pairs, counted
+      sweep(iv.cell_tile0[a], pre_tiles, false);
+      minima = false;
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float x = key[r];
+        // bitonic sort along the 32 lanes of each half (ascending in l31)
+#pragma unroll
+        for (int kk = 2; kk <= 32; kk <<= 1) {
+#pragma unroll
+          for (int j = kk >> 1; j > 0; j >>= 1) {
+            const float y = __shfl_xor(x, j);
+            const bool up = (l31 & kk) == 0;
+            const bool lower = (l31 & j) == 0;
+            x = (lower == up) ? fminf(x, y) : fmaxf(x, y);
+          }
+        }
+        const int i0 = (r & 3) + 8 * (r >> 2), i1 = i0 + 4;
+        const float t0 = readlane_f32(x, thr_lane), t1 = readlane_f32(x, 32 + thr_lane);
+        athr = (lane == i0) ? -t0 : ((lane == i1) ? -t1 : athr);
+        key[r] = INFINITY;
+      }
+      athr_floor = athr;
+    }
     bool first = true;
     for (int ci = 0; ci < iv.n_cells; ++ci) {
       const float lb = lb2[ci];
@@ -643,7 +696,10 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
       if (qp >= 0) {
         const int64_t qi = (int64_t)iv.perm[qp] - q_begin;
         cand_idx[qi * C::KP + l31] = idx[r] >= 0 ? iv.perm[idx[r]] : -1;
-        if (l31 == thr_lane) cand_tau[qi] = key[r];
+        // final threshold = min(list entry, pre-pass threshold): everything below it is in the list
+        const int i0 = (r & 3) + 8 * (r >> 2), i1 = i0 + 4;
+        const float tf0 = -readlane_f32(athr, i0), tf1 = -readlane_f32(athr, i1);
+        if (l31 == thr_lane) cand_tau[qi] = half ? tf1 : tf0;
       }
     }
   }

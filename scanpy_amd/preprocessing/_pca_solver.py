@@ -164,16 +164,30 @@ GRAM_MAX_GENES = 8192  # G is g x g float64 (512 MB at the limit); beyond it the
 
 
 def _cholqr2(y: torch.Tensor) -> torch.Tensor:
-    """Orthonormal basis of span(y) by two rounds of Cholesky QR on column-normalised y (GEMM-shaped; falls back to
-    Householder QR when the Gram matrix is numerically singular)."""
+    """Orthonormal basis of span(y) by Cholesky QR on column-normalised y (GEMM-shaped: Gram matrix, b x b Cholesky,
+    triangular solve).  Two plain rounds when the block is well conditioned; a Chebyshev-filtered block is not
+    (kappa ~ 1e9: every column leans towards the dominant eigenvectors), so a failed first factorisation switches to
+    shifted CholeskyQR3 (Fukaya et al. 2020: one round with G + sI, s ~ 11(mn + n(n+1)) u |Y|^2, brings kappa down
+    to ~sqrt(s) kappa, then two plain rounds) -- still GEMM-shaped, ~4x cheaper than Householder QR on the device.
+    Householder QR remains the last resort for a numerically rank-deficient block."""
     y = y / torch.linalg.norm(y, dim=0, keepdim=True).clamp_min(1e-300)
-    try:
-        for _ in range(2):
-            l = torch.linalg.cholesky(y.T @ y)
-            y = torch.linalg.solve_triangular(l, y.T, upper=False).T
-        return y
-    except RuntimeError:  # torch.linalg.LinAlgError is a RuntimeError
+    m, n = y.shape
+    gm = y.T @ y
+    l, bad = torch.linalg.cholesky_ex(gm)
+    if int(bad) != 0:
+        shift = 11.0 * (m * n + n * (n + 1)) * torch.finfo(y.dtype).eps * float(n)  # |Y|_2^2 <= n (unit columns)
+        l, bad = torch.linalg.cholesky_ex(gm + shift * torch.eye(n, dtype=y.dtype, device=y.device))
+        if int(bad) != 0:
+            return torch.linalg.qr(y, mode="reduced")[0]
+        y = torch.linalg.solve_triangular(l, y.T, upper=False).T
+        l, bad = torch.linalg.cholesky_ex(y.T @ y)
+        if int(bad) != 0:
+            return torch.linalg.qr(y, mode="reduced")[0]
+    y = torch.linalg.solve_triangular(l, y.T, upper=False).T
+    l, bad = torch.linalg.cholesky_ex(y.T @ y)
+    if int(bad) != 0:
         return torch.linalg.qr(y, mode="reduced")[0]
+    return torch.linalg.solve_triangular(l, y.T, upper=False).T
 
 
 def _dense_topk_eigh(amat: torch.Tensor, k: int, rng: np.random.Generator, tol: float, info: dict):

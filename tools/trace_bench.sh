@@ -23,5 +23,20 @@ for i, r in enumerate(rows):
         out.write("%d,%s,%s,%.1f,%.1f\n" % (i, short[:50], r.get("Grid_Size", r.get("Grid_Size_X", "?")), (int(r["Start_Timestamp"]) - t0) / 1e3,
                                             (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
 out.close()
+# everything in front of the first kNN kernel = the PCA stage (all kernels, unfiltered)
+pca = open("$R/$OUT/trace_pca.csv", "w")
+pca.write("i,name,grid,start_us,dur_us\n")
+started = False
+for i, r in enumerate(rows):
+    name = r["Kernel_Name"]
+    short = name.split("(")[0].replace("scamd::", "").replace("void ", "")
+    if "gram_absmax" in short:
+        started = True
+    if "ivf_" in short or "knn_" in short:
+        break
+    if started:
+        pca.write("%d,%s,%s,%.1f,%.1f\n" % (i, short[:60], r.get("Grid_Size", "?"), (int(r["Start_Timestamp"]) - t0) / 1e3,
+                                            (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+pca.close()
 PY
 wc -l $R/$OUT/trace_filtered.csv
