@@ -827,7 +827,13 @@ __global__ void ld_refine_apply_kernel(int n_cand, const int* __restrict__ list,
 // round control, one thread: the stop rule of the refinement (RF_QUIET_ROUNDS rounds without a merge, or an empty
 // candidate list) evaluated on the device so that a batch of rounds runs without a host round trip.
 // ctl: [0] stop, [1] quiet rounds, [2] rounds done, [3] total merges
-__global__ void ld_refine_ctl_kernel(const int* __restrict__ counters, int* __restrict__ ctl) {
+// The merge counts of successive rounds fall geometrically (each round pairs about half of the remaining
+// singleton/target couples: 323k, 179k, 89k, ... at 1M vertices); once a round merges fewer than stop_ppm
+// millionths of the level's vertices the rest is left to the next level, where those singletons are ordinary
+// coarse nodes of their community (leidenalg's refinement visits every vertex exactly once, it does not iterate
+// to a fixed point either).
+__global__ void ld_refine_ctl_kernel(const int* __restrict__ counters, int* __restrict__ ctl, int n_level,
+                                     int stop_ppm) {
   if (ctl[0]) return;
   const int merges = counters[0];
   const int quiet = merges == 0 ? ctl[1] + 1 : 0;
@@ -835,6 +841,7 @@ __global__ void ld_refine_ctl_kernel(const int* __restrict__ counters, int* __re
   ctl[2] += 1;
   ctl[3] += merges;
   if (quiet >= RF_QUIET_ROUNDS || counters[2] == 0) ctl[0] = 1;
+  if (merges > 0 && (long long)merges * 1000000ll < (long long)n_level * stop_ppm) ctl[0] = 1;
 }
 
 __global__ void ld_refine_init_kernel(int n, const long long* __restrict__ k, const long long* __restrict__ a_in,
@@ -1279,6 +1286,7 @@ struct LeidenCtx {
   double m2;  // total (quantised) weight = sum of strengths
   unsigned int seed;
   int lm_stop_permille = 10;  // local moving of a level stops once < 1 % of its vertices move in a round
+  int rf_stop_ppm = 500;      // refinement stops once a round merges < 0.05 % of the level's vertices
   // coarse-row build tiers (distinct-neighbour bounds); the env overrides exist so the tests can push small graphs
   // through the workgroup and multi-pass tiers
   int agg_wave_max = WH_MAX_DEG;
@@ -1446,7 +1454,7 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
       hipLaunchKernelGGL(ld_refine_cut_update_kernel, dim3(wgrid), dim3(256), 0, cx.s, ub, b.rlist, g.indptr, g.indices,
                          g.wq, b.comm, b.ref, b.touched, b.a_in, round, b.Eref, (const int*)rcnt);
       SCAMD_LAUNCH_CHECK();
-      hipLaunchKernelGGL(ld_refine_ctl_kernel, dim3(1), dim3(1), 0, cx.s, (const int*)rcnt, ctl);
+      hipLaunchKernelGGL(ld_refine_ctl_kernel, dim3(1), dim3(1), 0, cx.s, (const int*)rcnt, ctl, g.n, cx.rf_stop_ppm);
       SCAMD_LAUNCH_CHECK();
       std::swap(b.list_a, b.list_b);
       n_in = rcnt + 2;
@@ -1655,6 +1663,7 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
   cx.gamma = resolution;
   cx.seed = (unsigned int)(seed ^ (seed >> 32)) * 0x9E3779B1u + 0x632BE5ABu;
   if (const char* e = getenv("SCAMD_LEIDEN_LM_STOP_PERMILLE")) cx.lm_stop_permille = atoi(e);
+  if (const char* e = getenv("SCAMD_LEIDEN_RF_STOP_PPM")) cx.rf_stop_ppm = atoi(e);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_WAVE_MAX")) cx.agg_wave_max = std::min(atoi(e), (int)WH_MAX_DEG);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_MAX")) cx.agg_mid_max = std::min(atoi(e), (int)AGG_MID_MAX);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_PASS_KEYS"))
