@@ -34,8 +34,27 @@ def pbmc68k():
     f = dict(np.load(GOLDEN / "pbmc68k_reduced.npz"))
     out = {k: f[k] for k in ("X", "X_pca", "louvain_codes", "bulk_labels_codes", "highly_variable")}
     out["n_neighbors"] = int(f["n_neighbors"][0])
+    out["obs_n_counts"] = f["obs_n_counts"]
     for name in ("counts", "distances", "connectivities"):
         out[name] = sparse.csr_matrix(
             (f[f"{name}_data"], f[f"{name}_indices"], f[f"{name}_indptr"]), shape=tuple(f[f"{name}_shape"])
         )
+    # `.raw.X` of sc.datasets.pbmc68k_reduced() (src/scanpy/datasets/_datasets.py:407-425): counts normalised by the
+    # stored size factors, log1p, rounded to 3 digits, one documented tie-break
+    size = out["obs_n_counts"].astype(np.float32) / np.float32(1e4)
+    raw = out["counts"].astype(np.float32)
+    raw.data /= np.repeat(size, np.diff(raw.indptr))
+    raw.data = np.round(np.log1p(raw.data), 3)
+    raw[357, 715] = 4.019
+    out["raw_X"] = raw.tocsr()
     return out
+
+
+@pytest.fixture(scope="session")
+def hvg_golden():
+    return dict(np.load(GOLDEN / "hvg_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def scale_toy():
+    return dict(np.load(GOLDEN / "scale_toy.npz"))

@@ -9,8 +9,12 @@ Sources (all under /root/reference):
   * tests/test_neighbors.py:23-48    -> neighbors_toy.npz    (X, distances_euclidean,
                                                               connectivities_umap, transitions*)
   * src/scanpy/datasets/10x_pbmc68k_reduced.zarr.zip
-                                      -> pbmc68k_reduced.npz (X, counts CSR, stored
+                                      -> pbmc68k_reduced.npz (X, counts CSR, obs n_counts, stored
                                          distances / connectivities CSR, X_pca, louvain codes)
+  * tests/_scripts/seurat_hvg.csv, tests/_scripts/cell_ranger_hvg.csv
+                                      -> hvg_golden.npz       (the Seurat / Cell Ranger outputs that
+                                         tests/test_highly_variable_genes.py:367-422 compares against)
+  * tests/test_scaling.py:13-72       -> scale_toy.npz        (X_original, X_scaled_*, X_centered_*, mask cases)
 
 The reference cannot be imported here (needs Python >= 3.12), so the literal arrays are
 pulled out of the test modules with `ast`, and the zarr-v3 store is decoded by hand
@@ -135,8 +139,24 @@ def main() -> None:
     fx["bulk_labels_codes"] = read_zarr_array(z, "obs/bulk_labels/codes")
     fx["highly_variable"] = read_zarr_array(z, "var/highly_variable")
     fx["n_neighbors"] = read_zarr_array(z, "uns/neighbors/params/n_neighbors")
+    fx["obs_n_counts"] = read_zarr_array(z, "obs/n_counts")
     np.savez_compressed(OUT / "pbmc68k_reduced.npz", **fx)
-    for f in ("pca_toy.npz", "neighbors_toy.npz", "pbmc68k_reduced.npz"):
+
+    import pandas as pd
+
+    hvg = {}
+    for tag, f in (("seurat", "seurat_hvg.csv"), ("cell_ranger", "cell_ranger_hvg.csv")):
+        df = pd.read_csv(REF / "tests/_scripts" / f, index_col=0)
+        for col in ("means", "dispersions", "dispersions_norm"):
+            hvg[f"{tag}_{col}"] = df[col].to_numpy(dtype=np.float64)
+        hvg[f"{tag}_highly_variable"] = df["highly_variable"].to_numpy(dtype=bool)
+    np.savez_compressed(OUT / "hvg_golden.npz", **hvg)
+
+    sc_names = {"X_original", "X_scaled_original", "X_centered_original", "X_scaled_original_clipped", "X_for_mask",
+                "X_scaled_for_mask", "X_centered_for_mask", "X_scaled_for_mask_clipped"}
+    np.savez(OUT / "scale_toy.npz", **literal_arrays(REF / "tests/test_scaling.py", sc_names))
+
+    for f in ("pca_toy.npz", "neighbors_toy.npz", "pbmc68k_reduced.npz", "hvg_golden.npz", "scale_toy.npz"):
         print(f, (OUT / f).stat().st_size, "bytes")
 
 
