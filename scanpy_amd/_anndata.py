@@ -40,6 +40,19 @@ class AnnData:
     def shape(self):
         return (self.n_obs, self.n_vars)
 
+    @property
+    def var_names(self):
+        return self.var.index
+
+    @property
+    def obs_names(self):
+        return self.obs.index
+
+    def _inplace_subset_var(self, index) -> None:
+        """anndata's `AnnData._inplace_subset_var` (used by `highly_variable_genes(subset=True)`)."""
+        sub = self[:, np.asarray(index)]
+        self.X, self.var, self.varm, self.layers = sub.X, sub.var.copy(), sub.varm, sub.layers
+
     def copy(self) -> "AnnData":
         return AnnData(
             None if self.X is None else self.X.copy(),

@@ -1,0 +1,89 @@
+"""`sc.pp.normalize_total` on MI355X: signature, errors, warnings and write-back of the reference
+(src/scanpy/preprocessing/_normalization.py:127-327); the sweeps over the matrix are HIP kernels
+(`scamd_pp_row_sums_f32`, `scamd_pp_count_high_f32`, `scamd_pp_row_divide_f32`)."""
+from __future__ import annotations
+
+import logging
+import warnings
+
+import numpy as np
+from scipy import sparse
+
+from .._anndata import is_anndata
+from . import _csr_device
+from ._pca import _get_arr
+
+
+_log = logging.getLogger("scanpy_amd")  # the reference logs through scanpy.logging (`logg.info`)
+
+
+def _set_obs_rep(adata, val, *, layer=None, obsm=None) -> None:
+    """src/scanpy/get/get.py:573-604"""
+    if layer is not None:
+        adata.layers[layer] = val
+    elif obsm is not None:
+        adata.obsm[obsm] = val
+    else:
+        adata.X = val
+
+
+def _compute_nnz_median(counts: np.ndarray):
+    """`_normalization.py:20-26`"""
+    return np.median(counts[counts > 0])
+
+
+def normalize_total(  # noqa: PLR0912
+    adata,
+    *,
+    target_sum: float | None = None,
+    exclude_highly_expressed: bool = False,
+    max_fraction: float = 0.05,
+    key_added: str | None = None,
+    layer: str | None = None,
+    obsm: str | None = None,
+    inplace: bool = True,
+    copy: bool = False,
+):
+    """Normalize counts per cell (drop-in for `scanpy.pp.normalize_total`, `_normalization.py:127`).
+
+    Returns `None` (in place), the copied AnnData (`copy=True`) or `dict(X=..., norm_factor=...)`
+    (`inplace=False`), exactly as the reference."""
+    if not is_anndata(adata):
+        raise TypeError("normalize_total expects an AnnData object")
+    if copy:
+        if not inplace:
+            raise ValueError("`copy=True` cannot be used with `inplace=False`.")
+        adata = adata.copy()
+    if max_fraction < 0 or max_fraction > 1:
+        raise ValueError("Choose max_fraction between 0 and 1.")
+    x = _get_arr(adata, layer=layer, obsm=obsm)
+    be = _csr_device.default_backend()
+    m = be.upload(x)  # CSC -> CSR like the reference (`:266-267`); integers -> float32 (`:271-272`)
+    counts = be.row_sums(m)
+    gene_subset = None
+    if exclude_highly_expressed:
+        per_col = be.count_high(m, counts, max_fraction)
+        gene_subset = per_col == 0
+        counts = be.row_sums(m, col_skip=per_col)
+    if target_sum is None:
+        target_sum = _compute_nnz_median(counts)
+    factor = counts / target_sum  # float32 / python float -> float32, as in the reference
+    if exclude_highly_expressed:
+        _log.info("The following highly-expressed genes are not considered during normalization factor computation:\n%s",
+                  list(adata.var_names[~gene_subset]) if hasattr(adata, "var_names") else list(np.flatnonzero(~gene_subset)))
+    be.row_divide_(m, factor)
+    if not np.all(factor > 0):
+        warnings.warn("Some cells have zero counts", UserWarning, stacklevel=2)
+    out = be.download(m)
+    if sparse.issparse(x) and x.format != "csr":
+        out = out.tocsr()
+    dat = dict(X=out, norm_factor=factor)
+    if inplace:
+        if key_added is not None:
+            adata.obs[key_added] = dat["norm_factor"]
+        _set_obs_rep(adata, dat["X"], layer=layer, obsm=obsm)
+    if copy:
+        return adata
+    if not inplace:
+        return dat
+    return None

@@ -60,3 +60,83 @@ class CpuStubBackend:
                 gram[np.ix_(nz, nz)] += np.rint(np.outer(v, v) * sc).astype(np.int64)
         colsum = np.asarray(np.rint(x.multiply(sc).toarray()).sum(axis=0)).ravel().astype(np.int64)
         return torch.from_numpy(gram), torch.from_numpy(colsum)
+
+
+class CpuStubPPBackend:
+    """CPU stand-in for `scanpy_amd.preprocessing._csr_device.GpuPPBackend` (TEST INFRASTRUCTURE): mimics the kernel
+    contracts of csrc/preprocess.hip in numpy so that the host logic of normalize_total / log1p /
+    highly_variable_genes / scale (binning, cut-offs, write-back, errors) runs under pytest without a GPU."""
+
+    def upload(self, x, *, want_csr_rows=True):
+        from scanpy_amd.preprocessing._csr_device import DeviceMatrix, _check_dtype
+
+        if sparse.issparse(x):
+            _check_dtype(x.dtype)
+            if x.format == "csc" and want_csr_rows or x.format not in ("csr", "csc"):
+                x = x.tocsr()
+            x = x.copy()
+            x.sum_duplicates()
+            m = DeviceMatrix(x.format, x.shape, x.indptr.astype(np.int64), x.indices.astype(np.int32),
+                             x.data.astype(np.float32), x)
+        else:
+            x = np.asarray(x)
+            _check_dtype(x.dtype)
+            n, g = x.shape
+            m = DeviceMatrix("dense", x.shape, np.arange(n + 1, dtype=np.int64) * g,
+                             np.tile(np.arange(g, dtype=np.int32), n), x.astype(np.float32).ravel(), x)
+        m.rows = np.repeat(np.arange(len(m.indptr) - 1), np.diff(m.indptr))
+        return m
+
+    def download(self, m):
+        if m.kind == "dense":
+            return m.data.reshape(m.shape).copy()
+        return type(m.host)((m.data.copy(), m.host.indices.copy(), m.host.indptr.copy()), shape=m.shape)
+
+    def row_sums(self, m, col_skip=None):
+        keep = np.ones(m.data.size, bool) if col_skip is None else np.asarray(col_skip)[m.indices] == 0
+        n = len(m.indptr) - 1
+        return np.bincount(m.rows[keep], weights=m.data[keep].astype(np.float64), minlength=n).astype(np.float32)
+
+    def count_high(self, m, row_total, max_fraction):
+        hi = m.data > np.float32(max_fraction) * row_total.astype(np.float32)[m.rows]
+        return np.bincount(m.indices[hi], minlength=m.shape[1]).astype(np.int32)
+
+    def row_divide_(self, m, factor):
+        f = np.asarray(factor, dtype=np.float32)
+        f = np.where(f == 0, np.float32(1), f)
+        m.data = (m.data / f[m.rows]).astype(np.float32)
+
+    def log1p_(self, m, base=None):
+        v = np.log1p(m.data)
+        m.data = (v * np.float32(1.0 / np.log(base))).astype(np.float32) if base is not None else v
+
+    def col_stats(self, m, *, row_mask=None, expm1_scale=None):
+        sel = np.ones(m.data.size, bool) if row_mask is None else np.asarray(row_mask, bool)[m.rows]
+        v = m.data[sel]
+        if expm1_scale is not None:
+            v = np.expm1(v * np.float32(expm1_scale)).astype(np.float32)
+        cols = m.indices[sel]
+        g = m.shape[1]
+        v64 = v.astype(np.float64)
+        return (np.bincount(cols, weights=v64, minlength=g), np.bincount(cols, weights=v64 * v64, minlength=g),
+                np.bincount(cols[v > 0], minlength=g).astype(np.int64))
+
+    def scale_csr_(self, m, std, *, max_value=None, row_mask=None):
+        sel = np.ones(m.data.size, bool) if row_mask is None else np.asarray(row_mask, bool)[m.rows]
+        v = m.data[sel].astype(np.float64) / np.asarray(std)[m.indices[sel]]
+        if max_value is not None:
+            v = np.minimum(v, max_value)
+        m.data[sel] = v.astype(np.float32)
+
+    def scale_dense(self, m, mean, std, *, max_value=None, row_mask=None, out_f64=True):
+        dt = np.float64 if out_f64 else np.float32
+        n, g = m.shape
+        dense = np.zeros((n, g), dtype=np.float64)
+        dense[m.rows, m.indices] = m.data
+        on = np.ones(n, bool) if row_mask is None else np.asarray(row_mask, bool)
+        z = (dense[on] - mean).astype(dt).astype(np.float64) / std
+        if max_value is not None:
+            z = np.clip(z, -max_value, max_value)
+        out = dense.astype(dt)
+        out[on] = z.astype(dt)
+        return out

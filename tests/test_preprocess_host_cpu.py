@@ -1,0 +1,217 @@
+"""Host logic of scanpy_amd.pp.normalize_total / log1p / highly_variable_genes / scale on a CPU stand-in for the
+device passes (tests/stub_backend.CpuStubPPBackend), checked against the oracle and the reference's goldens.
+The same assertions run against the HIP kernels in tests/test_gpu_preprocess.py."""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+import pandas as pd
+import pytest
+from scipy import sparse
+
+import scanpy_amd as sc
+from oracle import preprocess as op
+from scanpy_amd.preprocessing import _csr_device
+from tests.stub_backend import CpuStubPPBackend
+
+
+@pytest.fixture(autouse=True)
+def _stub(monkeypatch):
+    monkeypatch.setattr(_csr_device, "default_backend", lambda: CpuStubPPBackend())
+
+
+def _dense(x):
+    return x.toarray() if sparse.issparse(x) else np.asarray(x)
+
+
+def check_chain_against_goldens(pbmc68k, hvg_golden, typ):
+    """tests/test_highly_variable_genes.py:367-422 through the drop-in functions"""
+    for flavor, params in (("seurat", dict(min_mean=0.0125, max_mean=3, min_disp=0.5)), ("cell_ranger", dict(n_top_genes=100))):
+        adata = sc.AnnData(typ(pbmc68k["raw_X"].copy()))
+        sc.pp.normalize_total(adata, target_sum=1e4)
+        sc.pp.log1p(adata)
+        assert adata.uns["log1p"] == {"base": None}
+        sc.pp.highly_variable_genes(adata, flavor=flavor, **params)
+        assert np.array_equal(adata.var["highly_variable"].to_numpy(), hvg_golden[f"{flavor}_highly_variable"])
+        for col in ("means", "dispersions", "dispersions_norm"):
+            np.testing.assert_allclose(adata.var[col].to_numpy(), hvg_golden[f"{flavor}_{col}"], rtol=2e-5, atol=2e-5)
+        assert adata.uns["hvg"] == {"flavor": flavor} and adata.var["dispersions_norm"].dtype == np.float32
+
+
+def check_normalize_total(typ):
+    for dtype in ("float32", "int64"):
+        x_total = np.array([[1, 0], [3, 0], [5, 6]]).astype(dtype)
+        adata = sc.AnnData(typ(x_total))
+        sc.pp.normalize_total(adata, key_added="n_counts")
+        assert np.allclose(_dense(adata.X).sum(axis=1), 3.0)
+        assert np.allclose(adata.obs["n_counts"], [1 / 3, 1.0, 11 / 3])
+        sc.pp.normalize_total(adata, target_sum=1, key_added="n_counts2")
+        assert np.allclose(_dense(adata.X).sum(axis=1), 1.0)
+        adata = sc.AnnData(typ(np.array([[1, 0, 1], [3, 0, 1], [5, 6, 1]]).astype(dtype)))
+        sc.pp.normalize_total(adata, exclude_highly_expressed=True, max_fraction=0.7)
+        assert np.allclose(_dense(adata.X)[:, 1:3].sum(axis=1), 1.0)
+    a = np.array([[3, 3, 3, 6, 6], [1, 1, 1, 2, 2], [1, 22, 1, 2, 2]], dtype="float32")
+    out = sc.pp.normalize_total(sc.AnnData(typ(a)), target_sum=1, exclude_highly_expressed=True, max_fraction=0.2, inplace=False)
+    assert np.allclose(_dense(out["X"]), [[0.5, 0.5, 0.5, 1, 1], [0.5, 0.5, 0.5, 1, 1], [0.5, 11, 0.5, 1, 1]])
+    # zero-count cells: warning, median over the non-zero sums (tests/test_normalization.py:336-353)
+    adata = sc.AnnData(typ(np.array([[0.0, 0.0], [4.0, 6.0], [8.0, 12.0], [12.0, 18.0]], dtype=np.float32)))
+    with pytest.warns(UserWarning, match="Some cells have zero counts"):
+        sc.pp.normalize_total(adata)
+    assert np.allclose(_dense(adata.X).sum(axis=1)[1:], 20.0)
+    with pytest.raises(ValueError, match="max_fraction"):
+        sc.pp.normalize_total(adata, max_fraction=1.5)
+    with pytest.raises(ValueError, match="copy=True"):
+        sc.pp.normalize_total(adata, copy=True, inplace=False)
+
+
+def check_scale(scale_toy, typ):
+    """tests/test_scaling.py:75-130"""
+    t = scale_toy
+    mask = np.array((0, 0, 1, 1, 1, 0, 0), dtype=bool)
+    for dtype in (np.float32, np.int64):
+        for zero_center in (True, False):
+            for mk, xk, ck, sk in ((None, "X_original", "X_centered_original", "X_scaled_original"),
+                                   (mask, "X_for_mask", "X_centered_for_mask", "X_scaled_for_mask")):
+                adata = sc.AnnData(typ(t[xk].astype(dtype)))
+                if zero_center and typ.__name__ != "array":
+                    with pytest.warns(UserWarning, match=r"zero-center.*densifies"):
+                        sc.pp.scale(adata, zero_center=zero_center, mask_obs=mk)
+                else:
+                    sc.pp.scale(adata, zero_center=zero_center, mask_obs=mk)
+                assert np.allclose(_dense(adata.X), t[ck] if zero_center else t[sk])
+                arr = sc.pp.scale(typ(t[xk].astype(dtype)), zero_center=False, mask_obs=mk, max_value=1)
+                assert np.allclose(_dense(arr), t["X_scaled_original_clipped" if mk is None else "X_scaled_for_mask_clipped"])
+    adata = sc.AnnData(np.array(t["X_for_mask"], dtype="float32"))
+    adata.obs["some cells"] = mask
+    sc.pp.scale(adata, mask_obs="some cells")
+    assert np.array_equal(adata.X, t["X_centered_for_mask"]) and "mean of some cells" in adata.var.columns
+    assert adata.X.dtype == np.float32
+    with pytest.raises(ValueError, match=r"Cannot.*refer.*mask.*without.*anndata"):
+        sc.pp.scale(np.array(t["X_original"], dtype=np.float32), mask_obs="mask")
+
+
+def check_random_against_oracle(typ, seed=0):
+    """normalize -> log1p(base 2) -> HVG (both flavors, top-n and cut-offs, batches) -> scale(max_value) vs the oracle"""
+    rng = np.random.default_rng(seed)
+    n, g = 400, 120
+    lam = rng.gamma(0.3, 4.0, size=g)
+    counts = rng.poisson(lam[None, :] * rng.uniform(0.3, 2.0, size=(n, 1))).astype(np.float32)
+    counts[5] = 0  # an empty cell
+    counts[:, 7] = 0  # an unexpressed gene
+    adata = sc.AnnData(typ(counts))
+    with pytest.warns(UserWarning, match="zero counts"):
+        sc.pp.normalize_total(adata, exclude_highly_expressed=True, max_fraction=0.2)
+    xo, fo, _ = op.normalize_total(sparse.csr_matrix(counts), exclude_highly_expressed=True, max_fraction=0.2)
+    np.testing.assert_allclose(_dense(adata.X), xo.toarray(), rtol=1e-6, atol=1e-7)
+    sc.pp.log1p(adata, base=2)
+    xo = op.log1p(xo, base=2)
+    np.testing.assert_allclose(_dense(adata.X), xo.toarray(), rtol=2e-6, atol=1e-7)
+    for flavor in ("seurat", "cell_ranger"):
+        for kw in (dict(n_top_genes=30), dict(min_mean=0.01, max_mean=5, min_disp=0.2)):
+            with pytest.warns(UserWarning) if False else _nullcontext():
+                df = sc.pp.highly_variable_genes(adata, flavor=flavor, inplace=False, **kw)
+            do = op.highly_variable_genes(xo, flavor=flavor, log1p_base=2, **kw)
+            assert np.array_equal(df["highly_variable"].to_numpy(), do["highly_variable"].to_numpy())
+            for col in ("means", "dispersions", "dispersions_norm"):
+                np.testing.assert_allclose(df[col].to_numpy(), do[col].to_numpy(), rtol=2e-5, atol=2e-5, equal_nan=True)
+    # batches: equals the per-batch oracle combined as `_highly_variable_genes_batched` does
+    adata.obs["batch"] = pd.Categorical(np.where(np.arange(n) % 3 == 0, "a", "b"))
+    df = sc.pp.highly_variable_genes(adata, batch_key="batch", n_top_genes=25, inplace=False)
+    assert int(df["highly_variable"].sum()) == 25 and set(df["highly_variable_nbatches"].unique()) <= {0, 1, 2}
+    per, ambiguous = [], np.zeros(g, dtype=bool)
+    for b in ("a", "b"):
+        rows = (adata.obs["batch"] == b).to_numpy()
+        sub = xo[rows]
+        expressed = np.flatnonzero(np.asarray((sub > 0).sum(axis=0)).ravel() >= 1)
+        d = op.highly_variable_genes(sub[:, expressed], n_top_genes=25, log1p_base=2)
+        hv, mean = np.zeros(g, dtype=bool), np.zeros(g)
+        hv[expressed], mean[expressed] = d["highly_variable"].to_numpy(), d["means"].to_numpy()
+        per.append((hv, mean))
+        # two-gene bins give normalised dispersions of exactly +-1/sqrt(2): several genes tie at the cut-off to the last
+        # ulp, and which side of `>=` they fall on depends on the summation order of the per-gene sums
+        dn = d["dispersions_norm"].to_numpy()
+        cut = np.sort(dn[~np.isnan(dn)])[::-1][24]
+        ambiguous[expressed[np.abs(dn - cut) <= 1e-9 * max(1.0, abs(cut))]] = True
+    nb = per[0][0].astype(int) + per[1][0].astype(int)
+    got = df["highly_variable_nbatches"].to_numpy()
+    assert np.array_equal(got[~ambiguous], nb[~ambiguous]) and np.all(np.abs(got - nb)[ambiguous] <= 1)
+    np.testing.assert_allclose(df["means"].to_numpy(), (per[0][1] + per[1][1]) / 2, rtol=2e-5, atol=2e-6)
+    # scale with clipping, both centring modes
+    for zero_center in (True, False):
+        a2 = sc.AnnData(typ(_dense(adata.X).astype(np.float32)))
+        if zero_center and typ.__name__ != "array":
+            with pytest.warns(UserWarning, match="densifies"):
+                sc.pp.scale(a2, zero_center=zero_center, max_value=3)
+        else:
+            sc.pp.scale(a2, zero_center=zero_center, max_value=3)
+        so, mo, sdo = op.scale(typ(_dense(adata.X).astype(np.float32)), zero_center=zero_center, max_value=3)
+        np.testing.assert_allclose(_dense(a2.X), _dense(so), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(a2.var["mean"], mo, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(a2.var["std"], sdo, rtol=1e-6, atol=1e-9)
+        if zero_center and typ.__name__ != "array":
+            assert a2.X.dtype == np.float64
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+def array(x, dtype=None):
+    """dense ndarray from anything (np.array(csr) would give an object array)"""
+    return np.array(x.toarray() if sparse.issparse(x) else x, dtype=dtype)
+
+
+TYPES = [array, sparse.csr_matrix, sparse.csc_matrix]
+
+
+@pytest.mark.parametrize("typ", TYPES, ids=lambda t: t.__name__)
+def test_chain_goldens(pbmc68k, hvg_golden, typ):
+    check_chain_against_goldens(pbmc68k, hvg_golden, typ)
+
+
+@pytest.mark.parametrize("typ", TYPES, ids=lambda t: t.__name__)
+def test_normalize_total(typ):
+    check_normalize_total(typ)
+
+
+@pytest.mark.parametrize("typ", TYPES, ids=lambda t: t.__name__)
+def test_scale(scale_toy, typ):
+    check_scale(scale_toy, typ)
+
+
+@pytest.mark.parametrize("typ", TYPES, ids=lambda t: t.__name__)
+def test_random_against_oracle(typ):
+    check_random_against_oracle(typ)
+
+
+def test_log1p_warns_when_already_logged_and_keeps_format(caplog):
+    x = sparse.random(20, 9, density=0.4, format="csc", dtype=np.float32, random_state=1)
+    adata = sc.AnnData(x.copy())
+    sc.pp.log1p(adata)
+    assert adata.X.format == "csc" and np.allclose(adata.X.toarray(), np.log1p(x.toarray()), rtol=1e-6)
+    with caplog.at_level(logging.WARNING, logger="scanpy_amd"):
+        sc.pp.log1p(adata)
+    assert "already log-transformed" in caplog.text
+    out = sc.pp.log1p(x.toarray(), base=10)
+    assert np.allclose(out, np.log10(1 + x.toarray()), rtol=2e-6, atol=1e-7)
+    with pytest.raises(NotImplementedError):
+        sc.pp.log1p(adata, chunked=True)
+
+
+def test_hvg_errors_and_subset(pbmc68k):
+    adata = sc.AnnData(pbmc68k["raw_X"].copy())
+    with pytest.raises(ImportError, match="scikit-misc"):
+        sc.pp.highly_variable_genes(adata, flavor="seurat_v3")
+    with pytest.raises(ValueError, match="expects an `AnnData`"):
+        sc.pp.highly_variable_genes(adata.X)
+    with pytest.warns(UserWarning, match="all cutoffs are ignored"):
+        sc.pp.highly_variable_genes(adata, n_top_genes=50, min_mean=0.1)
+    sc.pp.highly_variable_genes(adata, n_top_genes=50, subset=True)
+    assert adata.shape == (700, 50) and adata.var["highly_variable"].all()
+    with pytest.raises(NotImplementedError, match="float32"):
+        sc.pp.log1p(np.ones((3, 3), dtype=np.float64))
