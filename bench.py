@@ -92,6 +92,50 @@ def _profiled_traffic(mode: str):
         return None
 
 
+def upstream_chain(handle, reps: int = 3) -> dict:
+    """SURVEY 8(f).2 rows, measured beside the path (NOT part of `value`): the device passes of
+    normalize_total(1e4) -> log1p -> highly_variable_genes('seurat') statistics -> scale(zero_center=False) on the
+    resident CSR, each against the HBM roofline with its algorithmic bytes (csrc/preprocess.hip header)."""
+    import torch
+
+    from scanpy_amd import _kernels as K
+
+    ip, ix, dt, n, g = handle[:5]
+    nnz = dt.numel()
+    passes = [
+        ("row_sums", 4 * nnz + 8 * (n + 1) + 4 * n),
+        ("row_divide", 8 * nnz + 8 * (n + 1) + 4 * n),
+        ("log1p", 8 * nnz),
+        ("col_stats_expm1", 8 * nnz + 8 * (n + 1) + 24 * g),
+        ("scale_csr", 12 * nnz + 8 * (n + 1) + 8 * g),
+    ]
+    best = [float("inf")] * len(passes)
+    for _ in range(reps):
+        d = dt.clone()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(passes) + 1)]
+        ev[0].record()
+        sums = K.pp_row_sums(ip, ix, d, n)
+        ev[1].record()
+        K.pp_row_divide_(ip, d, n, sums / 1e4)
+        ev[2].record()
+        K.pp_log1p_(d)
+        ev[3].record()
+        s, sq, _ = K.pp_col_stats(ip, ix, d, n, g, expm1_scale=1.0, count_positive=False)
+        ev[4].record()
+        K.pp_scale_csr_(ip, ix, d, n, torch.ones(g, dtype=torch.float64, device=d.device), max_value=10.0)
+        ev[5].record()
+        torch.cuda.synchronize()
+        for i in range(len(passes)):
+            best[i] = min(best[i], ev[i].elapsed_time(ev[i + 1]))
+    out = {"note": "device passes of pp.normalize_total / log1p / highly_variable_genes / scale on the same CSR; "
+                   "best of %d; outside `value`" % reps, "peak_GBps": 8000.0, "passes": {}}
+    for (name, nbytes), ms in zip(passes, best):
+        gbps = nbytes / (ms * 1e-3) / 1e9
+        out["passes"][name] = {"ms": ms, "algorithmic_bytes": nbytes, "GBps": gbps, "frac": gbps / 8000.0}
+    out["total_ms"] = sum(best)
+    return out
+
+
 def main() -> None:
     args = parse_args()
     import torch
@@ -211,6 +255,8 @@ def main() -> None:
             "result": {"n_communities": res.n_communities, "modularity": res.modularity, **res.info},
             "setup_s": {"generate": t_gen, "h2d": t_h2d},
         }
+        if world == 1:
+            out["upstream_chain"] = upstream_chain(handle)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n), args.n_vars, args.n_comps, args.n_neighbors, args.seed)
         print(json.dumps(out), flush=True)

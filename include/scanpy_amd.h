@@ -174,18 +174,21 @@ int scamd_modularity_csr_f32(const int64_t* indptr, const int32_t* indices, cons
  * Upstream normalisation chain: normalize_total -> log1p -> highly_variable_genes -> scale on a
  * CSR float32 matrix resident on the device.  One HBM-bound sweep each; no workspace (the caller owns every output).
  * A dense matrix is passed as a CSR with the full pattern (indptr[i] = i*g, indices = column ids).
+ * nnz = number of stored entries (= indptr[n]); the row-wise kernels size their lanes-per-row from nnz / n.
  * ---------------------------------------------------------------------------------------- */
 /* out[r] = float(sum_j x_rj accumulated in float64): the CSR branch of _normalize_csr
  * (src/scanpy/preprocessing/_normalization.py:40-46).  col_skip != NULL: entries of columns with col_skip[c] != 0
  * are left out (second pass of exclude_highly_expressed, :60-65). */
-int scamd_pp_row_sums_f32(const int64_t* indptr, const int32_t* indices, const float* data, int64_t n,
+int scamd_pp_row_sums_f32(const int64_t* indptr, const int32_t* indices, const float* data, int64_t n, int64_t nnz,
                           const int32_t* col_skip, float* out, scamd_stream_t stream);
 /* col_counts[c] = #{r : x_rc > max_fraction * row_total[r]}  (_normalization.py:47-58); col_counts [g] is zeroed here */
 int scamd_pp_count_high_f32(const int64_t* indptr, const int32_t* indices, const float* data, int64_t n, int64_t g,
-                            const float* row_total, float max_fraction, int32_t* col_counts, scamd_stream_t stream);
+                            int64_t nnz, const float* row_total, float max_fraction, int32_t* col_counts,
+                            scamd_stream_t stream);
 /* x_rj /= factor[r] in float32, factor == 0 treated as 1: axis_mul_or_truediv(x, counts_per_cell, op=truediv,
  * allow_divide_by_zero=False, axis=0) (src/scanpy/_utils/__init__.py:623-659, called at _normalization.py:121-123) */
-int scamd_pp_row_divide_f32(const int64_t* indptr, float* data, int64_t n, const float* factor, scamd_stream_t stream);
+int scamd_pp_row_divide_f32(const int64_t* indptr, float* data, int64_t n, int64_t nnz, const float* factor,
+                            scamd_stream_t stream);
 /* data[i] = log1p(data[i]) (/ log(base) when base > 0; base == 0 means natural log): log1p_array / log1p_sparse
  * (src/scanpy/preprocessing/_simple.py:359-379) */
 int scamd_pp_log1p_f32(float* data, int64_t count, double base, scamd_stream_t stream);
@@ -196,17 +199,18 @@ int scamd_pp_log1p_f32(float* data, int64_t count, double base, scamd_stream_t s
  * filter_genes(min_cells=1) (_highly_variable_genes.py:387-395).  Float64 atomics: sums agree with a sequential
  * float64 sum to ~1e-15 relative, not bitwise. */
 int scamd_pp_col_stats_f32(const int64_t* indptr, const int32_t* indices, const float* data, int64_t n, int64_t g,
-                           const uint8_t* row_mask, int transform, double tscale, double* sum, double* sumsq,
-                           uint64_t* npos, scamd_stream_t stream);
+                           int64_t nnz, const uint8_t* row_mask, int transform, double tscale, double* sum,
+                           double* sumsq, uint64_t* npos /* may be NULL */, scamd_stream_t stream);
 /* zero_center=False: x_rc = min(max_value, x_rc / std[c]) on the masked rows, sparsity kept: scale_and_clip_csr
  * (src/scanpy/preprocessing/_scale.py:280-295) */
-int scamd_pp_scale_csr_f32(const int64_t* indptr, const int32_t* indices, float* data, int64_t n, const double* std_,
-                           double max_value, int has_max, const uint8_t* row_mask, scamd_stream_t stream);
+int scamd_pp_scale_csr_f32(const int64_t* indptr, const int32_t* indices, float* data, int64_t n, int64_t nnz,
+                           const double* std_, double max_value, int has_max, const uint8_t* row_mask,
+                           scamd_stream_t stream);
 /* zero_center=True: dense out[r*g + c] = clip((x_rc - mean[c]) / std[c], +-max_value) for masked rows, x_rc for the
  * others; out is float64 (sparse input: the reference's `x -= mean` yields a float64 matrix) or float32
  * (out_is_f64 == 0, float32 dense input): scale_array (_scale.py:189-216) + clip_array (:53-69) */
 int scamd_pp_scale_dense_f32(const int64_t* indptr, const int32_t* indices, const float* data, int64_t n, int64_t g,
-                             const double* mean, const double* std_, double max_value, int has_max,
+                             int64_t nnz, const double* mean, const double* std_, double max_value, int has_max,
                              const uint8_t* row_mask, void* out, int out_is_f64, scamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

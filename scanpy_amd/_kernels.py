@@ -193,7 +193,7 @@ def modularity(indptr: torch.Tensor, indices: torch.Tensor, weights: torch.Tenso
 def pp_row_sums(indptr, indices, data, n: int, col_skip: torch.Tensor | None = None) -> torch.Tensor:
     dev = require_gpu()
     out = torch.empty(n, dtype=torch.float32, device=dev)
-    rc = _lib.load().scamd_pp_row_sums_f32(ptr(indptr), ptr(indices), ptr(data), n, ptr(col_skip), ptr(out), stream_ptr())
+    rc = _lib.load().scamd_pp_row_sums_f32(ptr(indptr), ptr(indices), ptr(data), n, data.numel(), ptr(col_skip), ptr(out), stream_ptr())
     _lib.check(rc, "scamd_pp_row_sums_f32")
     return out
 
@@ -201,7 +201,7 @@ def pp_row_sums(indptr, indices, data, n: int, col_skip: torch.Tensor | None = N
 def pp_count_high(indptr, indices, data, n: int, g: int, row_total: torch.Tensor, max_fraction: float) -> torch.Tensor:
     dev = require_gpu()
     counts = torch.empty(g, dtype=torch.int32, device=dev)
-    rc = _lib.load().scamd_pp_count_high_f32(ptr(indptr), ptr(indices), ptr(data), n, g, ptr(row_total),
+    rc = _lib.load().scamd_pp_count_high_f32(ptr(indptr), ptr(indices), ptr(data), n, g, data.numel(), ptr(row_total),
                                              float(max_fraction), ptr(counts), stream_ptr())
     _lib.check(rc, "scamd_pp_count_high_f32")
     return counts
@@ -210,7 +210,7 @@ def pp_count_high(indptr, indices, data, n: int, g: int, row_total: torch.Tensor
 def pp_row_divide_(indptr, data, n: int, factor: torch.Tensor) -> None:
     require_gpu()
     assert factor.dtype == torch.float32 and factor.numel() == n
-    _lib.check(_lib.load().scamd_pp_row_divide_f32(ptr(indptr), ptr(data), n, ptr(factor), stream_ptr()),
+    _lib.check(_lib.load().scamd_pp_row_divide_f32(ptr(indptr), ptr(data), n, data.numel(), ptr(factor), stream_ptr()),
                "scamd_pp_row_divide_f32")
 
 
@@ -221,15 +221,17 @@ def pp_log1p_(data: torch.Tensor, base: float | None = None) -> None:
                "scamd_pp_log1p_f32")
 
 
-def pp_col_stats(indptr, indices, data, n: int, g: int, *, row_mask: torch.Tensor | None = None, expm1_scale: float | None = None):
-    """-> (sum float64 [g], sumsq float64 [g], npos int64 [g]) over the masked rows; expm1_scale = s: of expm1(x * s)."""
+def pp_col_stats(indptr, indices, data, n: int, g: int, *, row_mask: torch.Tensor | None = None, expm1_scale: float | None = None,
+                 count_positive: bool = True):
+    """-> (sum float64 [g], sumsq float64 [g], npos int64 [g] or None) over the masked rows; expm1_scale = s: of
+    expm1(x * s)."""
     dev = require_gpu()
     s = torch.empty(g, dtype=torch.float64, device=dev)
     sq = torch.empty(g, dtype=torch.float64, device=dev)
-    npos = torch.empty(g, dtype=torch.int64, device=dev)
+    npos = torch.empty(g, dtype=torch.int64, device=dev) if count_positive else None
     if row_mask is not None:
         assert row_mask.dtype == torch.uint8 and row_mask.numel() == n
-    rc = _lib.load().scamd_pp_col_stats_f32(ptr(indptr), ptr(indices), ptr(data), n, g, ptr(row_mask),
+    rc = _lib.load().scamd_pp_col_stats_f32(ptr(indptr), ptr(indices), ptr(data), n, g, data.numel(), ptr(row_mask),
                                             0 if expm1_scale is None else 1, 1.0 if expm1_scale is None else float(expm1_scale),
                                             ptr(s), ptr(sq), ptr(npos), stream_ptr())
     _lib.check(rc, "scamd_pp_col_stats_f32")
@@ -240,7 +242,7 @@ def pp_scale_csr_(indptr, indices, data, n: int, std: torch.Tensor, *, max_value
                   row_mask: torch.Tensor | None = None) -> None:
     require_gpu()
     assert std.dtype == torch.float64
-    rc = _lib.load().scamd_pp_scale_csr_f32(ptr(indptr), ptr(indices), ptr(data), n, ptr(std),
+    rc = _lib.load().scamd_pp_scale_csr_f32(ptr(indptr), ptr(indices), ptr(data), n, data.numel(), ptr(std),
                                             0.0 if max_value is None else float(max_value), 0 if max_value is None else 1,
                                             ptr(row_mask), stream_ptr())
     _lib.check(rc, "scamd_pp_scale_csr_f32")
@@ -252,7 +254,7 @@ def pp_scale_dense(indptr, indices, data, n: int, g: int, mean: torch.Tensor, st
     dev = require_gpu()
     assert mean.dtype == torch.float64 and std.dtype == torch.float64 and out_dtype in (torch.float32, torch.float64)
     out = torch.empty((n, g), dtype=out_dtype, device=dev)
-    rc = _lib.load().scamd_pp_scale_dense_f32(ptr(indptr), ptr(indices), ptr(data), n, g, ptr(mean), ptr(std),
+    rc = _lib.load().scamd_pp_scale_dense_f32(ptr(indptr), ptr(indices), ptr(data), n, g, data.numel(), ptr(mean), ptr(std),
                                               0.0 if max_value is None else float(max_value), 0 if max_value is None else 1,
                                               ptr(row_mask), ptr(out), 1 if out_dtype == torch.float64 else 0, stream_ptr())
     _lib.check(rc, "scamd_pp_scale_dense_f32")

@@ -10,8 +10,9 @@ from scipy import sparse
 class DeviceMatrix:
     """CSR float32 view of a host matrix on the device.
 
-    kind 'csr' / 'csc': `indptr/indices` describe the compressed axis of the host format (a CSC matrix is uploaded as
-    the CSR of its transpose: element-wise passes do not care, the row/column passes get `transposed=True`);
+    kind 'csr' / 'csc': `indptr/indices` describe the compressed axis of the host format.  'csc' only occurs for the
+    element-wise pass (log1p keeps the storage format); every row/column pass converts CSC -> CSR on upload, as the
+    reference does (`x.tocsr()`, _normalization.py:266-267);
     kind 'dense': full pattern (indptr[i] = i * g, indices = column ids), `data` is the row-major matrix."""
 
     def __init__(self, kind, shape, indptr, indices, data, host):
@@ -98,14 +99,14 @@ class GpuPPBackend:
     def log1p_(self, m: DeviceMatrix, base=None) -> None:
         self.K.pp_log1p_(m.data, base)
 
-    def col_stats(self, m: DeviceMatrix, *, row_mask=None, expm1_scale=None):
-        """-> (sum, sumsq, n_positive) per gene over the masked rows (numpy float64 / int64)."""
+    def col_stats(self, m: DeviceMatrix, *, row_mask=None, expm1_scale=None, count_positive: bool = False):
+        """-> (sum, sumsq, n_positive or None) per gene over the masked rows (numpy float64 / int64)."""
         import torch
 
         mask = None if row_mask is None else torch.from_numpy(np.ascontiguousarray(row_mask, dtype=np.uint8)).to(self.device)
         s, sq, npos = self.K.pp_col_stats(m.indptr, m.indices, m.data, m.n_major, m.shape[1], row_mask=mask,
-                                          expm1_scale=expm1_scale)
-        return s.cpu().numpy(), sq.cpu().numpy(), npos.cpu().numpy()
+                                          expm1_scale=expm1_scale, count_positive=count_positive)
+        return s.cpu().numpy(), sq.cpu().numpy(), None if npos is None else npos.cpu().numpy()
 
     def scale_csr_(self, m: DeviceMatrix, std: np.ndarray, *, max_value=None, row_mask=None) -> None:
         import torch

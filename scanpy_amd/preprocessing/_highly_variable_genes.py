@@ -61,10 +61,10 @@ def _single_batch(be, m, var_names, *, n_rows: int, row_mask, filter_unexpressed
     expm1_scale = None
     if flavor == "seurat":  # counts space: expm1(x * log(base)) (`:402-410`)
         expm1_scale = 1.0 if log1p_base is None else float(np.log(log1p_base))
-    s, sq, npos = be.col_stats(m, row_mask=row_mask, expm1_scale=expm1_scale)
+    # expm1(x) > 0 <=> x > 0: the count of expressing cells rides on the same sweep
+    s, sq, npos = be.col_stats(m, row_mask=row_mask, expm1_scale=expm1_scale, count_positive=filter_unexpressed_genes)
     if filter_unexpressed_genes:  # filter_genes(min_cells=1) (`:387-395`)
-        raw_pos = npos if expm1_scale is None else be.col_stats(m, row_mask=row_mask)[2]
-        filt = raw_pos >= 1
+        filt = npos >= 1
     else:
         filt = np.ones(m.shape[1], dtype=bool)
     mean, var = _csr_device.mean_var_from_sums(s[filt], sq[filt], n_rows, correction=1)

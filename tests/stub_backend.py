@@ -110,7 +110,7 @@ class CpuStubPPBackend:
         v = np.log1p(m.data)
         m.data = (v * np.float32(1.0 / np.log(base))).astype(np.float32) if base is not None else v
 
-    def col_stats(self, m, *, row_mask=None, expm1_scale=None):
+    def col_stats(self, m, *, row_mask=None, expm1_scale=None, count_positive=False):
         sel = np.ones(m.data.size, bool) if row_mask is None else np.asarray(row_mask, bool)[m.rows]
         v = m.data[sel]
         if expm1_scale is not None:
@@ -119,7 +119,7 @@ class CpuStubPPBackend:
         g = m.shape[1]
         v64 = v.astype(np.float64)
         return (np.bincount(cols, weights=v64, minlength=g), np.bincount(cols, weights=v64 * v64, minlength=g),
-                np.bincount(cols[v > 0], minlength=g).astype(np.int64))
+                np.bincount(cols[v > 0], minlength=g).astype(np.int64) if count_positive else None)
 
     def scale_csr_(self, m, std, *, max_value=None, row_mask=None):
         sel = np.ones(m.data.size, bool) if row_mask is None else np.asarray(row_mask, bool)[m.rows]
