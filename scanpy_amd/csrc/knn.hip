@@ -1082,7 +1082,7 @@ static bool knn_plan(int64_t n, int d, int64_t n_query, int k, KnnPlan* p) {
   p->nq_pad = (n_query + QB - 1) / QB * QB;
   p->n_pad = (n + 255) / 256 * 256;
   // cell pruning pays once a sweep is long compared with the per-cell restarts; SCAMD_KNN_IVF=0 forces brute force
-  static const int ivf_env = [] {
+  const int ivf_env = [] {  // read per call: the tests flip it inside one process
     const char* e = getenv("SCAMD_KNN_IVF");
     return e ? atoi(e) : -1;
   }();

@@ -297,3 +297,40 @@ def test_csr_gram_bit_exact(K, n, g, density):
     # determinism: the accumulation order is arbitrary, the integers are not
     gq2, _ = K.csr_gram(ip, ix, dv, n, g, sb)
     np.testing.assert_array_equal(gq2.cpu().numpy(), gq)
+
+
+@pytest.mark.parametrize("d", [50, 20])
+def test_knn_cell_pruned_equals_brute_force(K, monkeypatch, d):
+    """the exact cell-pruned sweep returns what the brute-force sweep returns (bitwise: both end in the same float64
+    re-rank), for all queries and for a shard of queries [q_begin, q_begin + n_query) -- the multi-GPU call pattern"""
+    from scanpy_amd.datasets import blobs_embedding
+
+    n = 12000
+    x, _ = blobs_embedding(n, d, n_types=9, seed=21)
+    xd = _dev(x)
+    monkeypatch.setenv("SCAMD_KNN_IVF", "0")
+    i0, d0, _ = K.knn(xd, 15)
+    monkeypatch.setenv("SCAMD_KNN_IVF", "1")
+    i1, d1, _ = K.knn(xd, 15)
+    np.testing.assert_array_equal(i0.cpu().numpy(), i1.cpu().numpy())
+    np.testing.assert_array_equal(d0.cpu().numpy(), d1.cpu().numpy())
+    for qb, nq in ((0, 1000), (3000, 5000), (11000, 1000), (4097, 129)):
+        i2, d2, _ = K.knn(xd, 15, q_begin=qb, n_query=nq)
+        np.testing.assert_array_equal(i0[qb:qb + nq].cpu().numpy(), i2.cpu().numpy())
+        np.testing.assert_array_equal(d0[qb:qb + nq].cpu().numpy(), d2.cpu().numpy())
+
+
+def test_knn_cell_pruned_query_shards_at_default_size(K):
+    """n >= 65536 takes the cell-pruned sweep by default; two half shards of queries (what two ranks compute) equal
+    the single-call result"""
+    from scanpy_amd.datasets import blobs_embedding
+
+    n = 70000
+    x, _ = blobs_embedding(n, 50, seed=22)
+    xd = _dev(x)
+    i0, d0, _ = K.knn(xd, 15)
+    half = n // 2
+    for qb, nq in ((0, half), (half, n - half)):
+        i1, d1, _ = K.knn(xd, 15, q_begin=qb, n_query=nq)
+        np.testing.assert_array_equal(i0[qb:qb + nq].cpu().numpy(), i1.cpu().numpy())
+        np.testing.assert_array_equal(d0[qb:qb + nq].cpu().numpy(), d1.cpu().numpy())
