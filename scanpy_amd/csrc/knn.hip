@@ -348,6 +348,10 @@ __global__ void knn_pack_image_kernel(const float* __restrict__ x, int64_t n, in
 // cell a) visits the cells in order of increasing lower bound LB(a,b) = |c_a - c_b| - r_a - r_b on any distance
 // between a member of a and a member of b, and stops at the first cell whose bound exceeds every query's current
 // threshold distance: all remaining cells are farther still.  The answer is the exact kNN (pass 2 certifies it).
+// More cells than this did not cut the evaluated pairs at 10M x 50 (isotropic 50-d blobs: the ball bound prunes at the
+// granularity of a blob, not of a cell) and the quantiser grows with the cell count; the order tables are n_cells^2 x 8 B
+constexpr int IVF_MAX_CELLS = 1024;
+
 struct IvfArgs {
   const int* qpos;          // [n_blocks * 128] image row of every query slot (-1 = padding)
   const int* block_cell;    // [n_blocks]
@@ -355,6 +359,8 @@ struct IvfArgs {
   const int* cell_ntiles;   // [n_cells]
   const float* centers;     // [n_cells][dc]
   const float* radius;      // [n_cells] (already inflated for rounding)
+  const int* order;         // [n_cells][n_cells] cells by ascending lower bound from cell a (own cell first)
+  const float* order_lb2;   // [n_cells][n_cells] the squared lower bounds in that order (INF = empty cell)
   const int* perm;          // [n_image_rows] original row id of an image row (-1 = padding)
   unsigned long long* pairs; // (query, candidate) pairs evaluated, for the roofline figure
   int n_cells, dc;          // dc = stride of `centers` (>= d)
@@ -369,8 +375,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
                                                                   float* __restrict__ cand_tau, IvfArgs iv) {
   using C = RegCfg<H, TC_>;
   constexpr int HP = C::HP, DPL = C::DPL, TC = C::TC, SUBS = C::SUBS;
-  constexpr int IVF_MAX_CELLS = 1024;
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][TC][DPL] (+ IVF: order/lb2/wmax)
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][TC][DPL] (+ IVF: wmax[4])
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
@@ -584,50 +589,12 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
       if (l31 == thr_lane) cand_tau[q] = key[r];
     }
   } else {
-    // ---- cell order of this block: ascending lower bound, own cell first ----
-    int* order = reinterpret_cast<int*>(smem + 2 * TC * DPL);  // [IVF_MAX_CELLS]
-    float* lb2 = reinterpret_cast<float*>(order + IVF_MAX_CELLS);  // [IVF_MAX_CELLS]
-    float* wmax = lb2 + IVF_MAX_CELLS;                          // [4]
+    // ---- cell order of this block: row a of the per-cell tables (ascending lower bound, own cell first), built once
+    // per cell by ivf_cell_order_kernel instead of once per block ----
+    float* wmax = smem + 2 * TC * DPL;  // [4]
     const int a = iv.block_cell[blockIdx.x];
-    int npow = 1;
-    while (npow < iv.n_cells) npow <<= 1;
-    const float ra = iv.radius[a];
-    for (int b = tid; b < npow; b += C::NT) {
-      float v = INFINITY;
-      if (b < iv.n_cells && iv.cell_ntiles[b] > 0) {
-        float d2 = 0.f;
-        for (int c = 0; c < iv.d; ++c) {
-          const float df = iv.centers[a * iv.dc + c] - iv.centers[b * iv.dc + c];
-          d2 += df * df;
-        }
-        // lower bound on the distance between any member of a and any member of b, deflated against rounding
-        const float lb = fmaxf(0.f, sqrtf(d2) * (1.0f - 1e-4f) - ra - iv.radius[b]);
-        v = (b == a) ? -1.0f : lb * lb;
-      }
-      lb2[b] = v;
-      order[b] = b;
-    }
-    __syncthreads();
-    for (int kk = 2; kk <= npow; kk <<= 1) {  // bitonic sort by (lb2, cell)
-      for (int j = kk >> 1; j > 0; j >>= 1) {
-        for (int i = tid; i < npow; i += C::NT) {
-          const int p = i ^ j;
-          if (p > i) {
-            const bool up = (i & kk) == 0;
-            const float vi = lb2[i], vp = lb2[p];
-            const int oi = order[i], op = order[p];
-            const bool gt = vi > vp || (vi == vp && oi > op);
-            if (gt == up) {
-              lb2[i] = vp;
-              lb2[p] = vi;
-              order[i] = op;
-              order[p] = oi;
-            }
-          }
-        }
-        __syncthreads();
-      }
-    }
+    const int* order = iv.order + (int64_t)a * iv.n_cells;
+    const float* lb2 = iv.order_lb2 + (int64_t)a * iv.n_cells;
     // exact threshold distance^2 of a query = thr (score space) + ||q||^2; per wave the max over its real queries
     const float qn = xp[qrow * DPL + HP + H];  // ||q||^2 sits in the extra k slot of the row's second half
     // ---- pre-pass: a tight starting threshold from the own cell ----
@@ -702,6 +669,61 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
         if (l31 == thr_lane) cand_tau[qi] = half ? tf1 : tf0;
       }
     }
+  }
+}
+
+// Per-cell sweep order of the cell-pruned search: block a sorts all cells by the lower bound
+// LB(a,b) = max(0, |c_a - c_b| (1 - 1e-4) - r_a - r_b) on the distance between any member of a and any member of b
+// (own cell first, empty cells last with LB = INF) and writes row a of order / order_lb2 (LB squared).
+__global__ __launch_bounds__(256) void ivf_cell_order_kernel(const float* __restrict__ centers, int d,
+                                                             const float* __restrict__ radius,
+                                                             const int* __restrict__ cell_ntiles, int n_cells,
+                                                             int* __restrict__ order_out, float* __restrict__ lb2_out) {
+  extern __shared__ __attribute__((aligned(16))) float co_smem[];
+  int npow = 1;
+  while (npow < n_cells) npow <<= 1;
+  float* lb2 = co_smem;                                 // [npow]
+  int* order = reinterpret_cast<int*>(co_smem + npow);  // [npow]
+  const int a = blockIdx.x, tid = threadIdx.x;
+  const float ra = radius[a];
+  for (int b = tid; b < npow; b += 256) {
+    float v = INFINITY;
+    if (b < n_cells && cell_ntiles[b] > 0) {
+      float d2 = 0.f;
+      for (int c = 0; c < d; ++c) {
+        const float df = centers[a * d + c] - centers[b * d + c];
+        d2 += df * df;
+      }
+      const float lb = fmaxf(0.f, sqrtf(d2) * (1.0f - 1e-4f) - ra - radius[b]);
+      v = (b == a) ? -1.0f : lb * lb;
+    }
+    lb2[b] = v;
+    order[b] = b;
+  }
+  __syncthreads();
+  for (int kk = 2; kk <= npow; kk <<= 1) {  // bitonic sort by (lb2, cell)
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < npow; i += 256) {
+        const int p = i ^ j;
+        if (p > i) {
+          const bool up = (i & kk) == 0;
+          const float vi = lb2[i], vp = lb2[p];
+          const int oi = order[i], op = order[p];
+          const bool gt = vi > vp || (vi == vp && oi > op);
+          if (gt == up) {
+            lb2[i] = vp;
+            lb2[p] = vi;
+            order[i] = op;
+            order[p] = oi;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < n_cells; i += 256) {
+    order_out[(int64_t)a * n_cells + i] = order[i];
+    lb2_out[(int64_t)a * n_cells + i] = lb2[i];
   }
 }
 
@@ -1095,7 +1117,7 @@ static bool knn_plan(int64_t n, int d, int64_t n_query, int k, KnnPlan* p) {
       return e ? std::max(256, atoi(e)) : 2048;
     }();
     int c = 16;
-    while (c < 1024 && (int64_t)c * cell_rows < n) c <<= 1;  // ~cell_rows rows per cell
+    while (c < IVF_MAX_CELLS && (int64_t)c * cell_rows < n) c <<= 1;  // ~cell_rows rows per cell
     while (c > 1 && (int64_t)c * 256 > n) c >>= 1;
     p->n_cells = c;
     p->n_img_max = (n + (int64_t)64 * c + 255) / 256 * 256;
@@ -1110,7 +1132,7 @@ struct KnnBuffers {
   int* flag_list; int* counters; double* scratch_d; int* scratch_i; int* fb_counts;
   // cell-pruned search
   int* labels; int* perm; int* qpos; int* block_cell; float* cent; long long* sums; int* cell_ints;
-  unsigned int* radius_bits;
+  unsigned int* radius_bits; int* cell_order; float* cell_lb2;
 };
 
 static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffers* b) {
@@ -1129,6 +1151,8 @@ static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffe
   b->cent = nullptr;
   b->sums = nullptr;
   b->radius_bits = nullptr;
+  b->cell_order = nullptr;
+  b->cell_lb2 = nullptr;
   if (p.ivf) {
     b->labels = ws.take<int>((size_t)p.n_pad);  // sample labels, then labels of all rows
     b->perm = ws.take<int>((size_t)p.n_img_max);
@@ -1138,6 +1162,8 @@ static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffe
     b->sums = ws.take<long long>((size_t)p.n_cells * 128);
     b->cell_ints = ws.take<int>((size_t)p.n_cells * 8);  // counts, qcounts, map, row_off, row_cur, slot_off, slot_cur, tile0/ntiles reuse
     b->radius_bits = ws.take<unsigned int>((size_t)p.n_cells);
+    b->cell_order = ws.take<int>((size_t)p.n_cells * p.n_cells);
+    b->cell_lb2 = ws.take<float>((size_t)p.n_cells * p.n_cells);
   }
 }
 
@@ -1318,9 +1344,20 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
                        b.labels, cell_map, b.cent, b.xp, b.cmax, b.radius_bits);
     SCAMD_LAUNCH_CHECK();
   }
-  // 5. pruned sweep
+  // 5. sweep order of every cell (needs the radii the pack kernel just produced)
+  {
+    int npow = 1;
+    while (npow < nc) npow <<= 1;
+    const size_t olds = (size_t)npow * 8;
+    SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_cell_order_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)olds));
+    hipLaunchKernelGGL(ivf_cell_order_kernel, dim3(nc), dim3(256), olds, s, b.cent, d,
+                       reinterpret_cast<const float*>(b.radius_bits), ntiles, nc, b.cell_order, b.cell_lb2);
+    SCAMD_LAUNCH_CHECK();
+  }
+  // 6. pruned sweep
   auto kern = knn_select_reg_kernel<H, 64, 3, true>;
-  const size_t lds = C::LDS_BYTES + 1024 * 8 + 64;
+  const size_t lds = C::LDS_BYTES + 64;
   SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
   IvfArgs iv;
@@ -1330,6 +1367,8 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   iv.cell_ntiles = ntiles;
   iv.centers = b.cent;
   iv.radius = reinterpret_cast<const float*>(b.radius_bits);
+  iv.order = b.cell_order;
+  iv.order_lb2 = b.cell_lb2;
   iv.perm = b.perm;
   iv.pairs = reinterpret_cast<unsigned long long*>(b.counters + 2);
   iv.n_cells = nc;

@@ -63,8 +63,24 @@ class Neighbors:
                 self._connectivities = adata.obsp[ck]
             if dk in adata.obsp:
                 self._distances = adata.obsp[dk]
-            self.n_neighbors = info.get("params", {}).get("n_neighbors")
-            self.knn = sparse.issparse(self._distances)
+            self.knn = sparse.issparse(self._distances) or sparse.issparse(self._connectivities)
+            if "params" in info:
+                self.n_neighbors = info["params"]["n_neighbors"]
+            else:  # estimate from the stored graph (neighbors/__init__.py:446-464)
+
+                def count_nonzero(a) -> int:
+                    return a.count_nonzero() if sparse.issparse(a) else int(np.count_nonzero(a))
+
+                if self._connectivities is None:
+                    self.n_neighbors = int(count_nonzero(self._distances) / self._distances.shape[0])
+                else:
+                    self.n_neighbors = int(count_nonzero(self._connectivities) / self._connectivities.shape[0] / 2)
+            self._number_connected_components = 1
+            if sparse.issparse(self._connectivities):  # `:466-472`
+                from scipy.sparse.csgraph import connected_components
+
+                self._connected_components = connected_components(self._connectivities)
+                self._number_connected_components = self._connected_components[0]
 
     @property
     def distances(self):
