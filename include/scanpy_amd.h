@@ -214,6 +214,21 @@ int scamd_pp_scale_dense_f32(const int64_t* indptr, const int32_t* indices, cons
                              const uint8_t* row_mask, void* out, int out_is_f64, scamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * UMAP layout: the SGD of umap-learn's optimize_layout_euclidean, which
+ * simplicial_set_embedding runs for sc.tl.umap (src/scanpy/tools/_umap.py:196-216), in a synchronous, race-free
+ * gather formulation (csrc/umap.hip).  Input: CSR of the pruned symmetric fuzzy graph (indptr [n+1], indices [nnz]),
+ * epochs_per_sample [nnz] (umap_.make_epochs_per_sample: n_epochs * w / max w inverted; <= 0: never sampled),
+ * y [n x dim] float32 row-major = the initial embedding scaled to [0, 10], overwritten with the result.
+ * a, b: curve parameters (find_ab_params); gamma, initial_alpha, negative_sample_rate as in the reference call;
+ * seed drives the counter-based negative sampling.  Deterministic: same inputs -> bitwise the same embedding.
+ * ---------------------------------------------------------------------------------------- */
+size_t scamd_umap_workspace_bytes(int64_t n, int64_t nnz, int dim);
+int scamd_umap_optimize_f32(const int64_t* indptr, const int32_t* indices, const float* epochs_per_sample, int64_t n,
+                            int64_t nnz, int dim, int n_epochs, double a, double b, double gamma,
+                            double initial_alpha, double negative_sample_rate, uint64_t seed, float* y,
+                            void* workspace, size_t workspace_bytes, scamd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Self tests / micro benchmarks (device).  scamd_selftest_mfma_layout checks the
  * v_mfma_f32_32x32x2_f32 operand/result lane mapping the kNN kernel relies on; returns 0 if OK.
  * ---------------------------------------------------------------------------------------- */

@@ -259,3 +259,22 @@ def pp_scale_dense(indptr, indices, data, n: int, g: int, mean: torch.Tensor, st
                                               ptr(row_mask), ptr(out), 1 if out_dtype == torch.float64 else 0, stream_ptr())
     _lib.check(rc, "scamd_pp_scale_dense_f32")
     return out
+
+
+# ---- UMAP layout (csrc/umap.hip) -----------------------------------------------------------------------------------
+def umap_optimize_(indptr, indices, epochs_per_sample, n: int, y: torch.Tensor, *, n_epochs: int, a: float, b: float,
+                   gamma: float = 1.0, initial_alpha: float = 1.0, negative_sample_rate: float = 5.0, seed: int = 0) -> None:
+    """y [n, dim] float32 (device, contiguous): initial embedding in, optimised embedding out."""
+    dev = require_gpu()
+    lib = _lib.load()
+    assert y.dtype == torch.float32 and y.is_contiguous() and y.shape[0] == n
+    assert epochs_per_sample.dtype == torch.float32
+    nnz, dim = int(indices.numel()), int(y.shape[1])
+    need = lib.scamd_umap_workspace_bytes(n, nnz, dim)
+    if need == 0:
+        raise _lib.ScamdError(f"umap: unsupported shape n={n} n_components={dim} (supported: 1..8)")
+    ws, wsz = _ws(need, dev)
+    rc = lib.scamd_umap_optimize_f32(ptr(indptr), ptr(indices), ptr(epochs_per_sample), n, nnz, dim, int(n_epochs),
+                                     float(a), float(b), float(gamma), float(initial_alpha), float(negative_sample_rate),
+                                     int(seed) & (2**64 - 1), ptr(y), ptr(ws), wsz, stream_ptr())
+    _lib.check(rc, "scamd_umap_optimize_f32")

@@ -19,7 +19,6 @@ namespace scamd {
 namespace {
 
 constexpr int PP_BLOCK = 256;
-constexpr int PP_WAVES = PP_BLOCK / 64;
 constexpr int PP_LDS_GENES = 4096;  // column tables up to this many genes live in LDS (80 KB per workgroup)
 
 // Row-wise kernels give G lanes to a row (64 / G rows per wave): a row of a cells x genes matrix holds ~100 entries,

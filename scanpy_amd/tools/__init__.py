@@ -1,3 +1,4 @@
 from ._leiden import leiden
+from ._umap import umap
 
-__all__ = ["leiden"]
+__all__ = ["leiden", "umap"]

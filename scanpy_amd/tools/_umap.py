@@ -1,0 +1,181 @@
+"""`sc.tl.umap` on MI355X: signature, slots and parameter handling of the reference
+(src/scanpy/tools/_umap.py:30-229); the layout optimisation is `scamd_umap_optimize_f32` (csrc/umap.hip).
+
+What the reference delegates to umap-learn's `simplicial_set_embedding` is restated here around the device kernel:
+`find_ab_params`, pruning of rarely sampled edges, `make_epochs_per_sample`, the initial embedding (spectral / random
+/ given coordinates) and its rescaling to [0, 10].  Deviations, all confined to HOW the same objective is optimised:
+  * the SGD is synchronous and race-free (see csrc/umap.hip) and draws negatives with a counter-based hash: the result
+    is bitwise reproducible for a given seed, but it is not the sequence umap-learn's sequential sweep would produce;
+  * `init_pos='spectral'` computes the leading eigenvectors of the symmetric normalised adjacency by block power
+    iteration on the device (SpMM kernel of the PCA stage) instead of ARPACK; a disconnected graph is not laid out
+    component by component -- the block iteration separates the components by itself;
+  * `init_pos='paga'` is outside the path (needs `sc.tl.paga`)."""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+from scipy import sparse
+
+from .._anndata import is_anndata
+from .._utils import _UNSET, choose_graph, resolve_seed
+
+_log = logging.getLogger("scanpy_amd")
+
+
+def find_ab_params(spread: float, min_dist: float):
+    """umap.umap_.find_ab_params: fit 1 / (1 + a x^(2b)) to the offset exponential membership curve."""
+    from scipy.optimize import curve_fit
+
+    def curve(x, a, b):
+        return 1.0 / (1.0 + a * x ** (2 * b))
+
+    xv = np.linspace(0, spread * 3, 300)
+    yv = np.zeros(xv.shape)
+    yv[xv < min_dist] = 1.0
+    yv[xv >= min_dist] = np.exp(-(xv[xv >= min_dist] - min_dist) / spread)
+    params, _ = curve_fit(curve, xv, yv)
+    return params[0], params[1]
+
+
+def _prune_and_schedule(graph, n_epochs: int):
+    """simplicial_set_embedding: drop the entries that would be sampled less than once, then
+    make_epochs_per_sample.  -> CSR (sorted), epochs_per_sample float32 aligned with its data."""
+    g = sparse.coo_matrix(graph).copy()
+    g.sum_duplicates()
+    default_epochs = 500 if g.shape[0] <= 10000 else 200
+    cut = g.data.max() / float(n_epochs if n_epochs > 10 else default_epochs)
+    g.data[g.data < cut] = 0.0
+    g.eliminate_zeros()
+    csr = g.tocsr()
+    csr.sort_indices()
+    w = csr.data.astype(np.float64)
+    eps = -1.0 * np.ones(w.shape[0], dtype=np.float64)
+    n_samples = n_epochs * (w / w.max())
+    eps[n_samples > 0] = float(n_epochs) / n_samples[n_samples > 0]
+    return csr, eps.astype(np.float32)
+
+
+def _spectral_init(indptr, indices, weights, n: int, dim: int, seed: int, *, n_iter: int = 80):
+    """Leading non-trivial eigenvectors of S = D^-1/2 A D^-1/2 (= smallest of the normalised Laplacian, what
+    umap.spectral.spectral_layout asks ARPACK for) by block power iteration on (S + I) / 2 with a Rayleigh-Ritz step.
+    Device tensors in, float64 [n, dim] host array out."""
+    import torch
+
+    from .. import _kernels as K
+
+    dev = weights.device
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), (indptr[1:] - indptr[:-1]))
+    deg = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, rows, weights.to(torch.float64))
+    dis = torch.where(deg > 0, deg.rsqrt(), torch.zeros_like(deg))
+    s_data = (weights.to(torch.float64) * dis[rows] * dis[indices.long()]).to(torch.float32).contiguous()
+    width = dim + 1 + 4  # trivial vector + wanted + a little oversampling
+    from ..preprocessing._pca_solver import _cholqr2  # GEMM-shaped orthonormalisation (Cholesky QR)
+
+    gen = torch.Generator(device="cpu").manual_seed(int(seed) & 0x7FFFFFFF)
+    v = torch.randn((n, width), generator=gen, dtype=torch.float64).to(dev)
+    v[:, 0] = torch.sqrt(deg)  # the known eigenvector of eigenvalue 1
+    v = _cholqr2(v)
+    for _ in range(n_iter):
+        sv = K.spmm(indptr, indices, s_data, n, n, v.to(torch.float32).contiguous()).to(torch.float64)
+        v = _cholqr2(0.5 * (sv + v))
+    sv = K.spmm(indptr, indices, s_data, n, n, v.to(torch.float32).contiguous()).to(torch.float64)
+    t = v.T @ sv
+    theta, y = torch.linalg.eigh(0.5 * (t + t.T))
+    order = torch.argsort(theta, descending=True)
+    vec = v @ y[:, order[1:dim + 1]]  # drop the trivial one
+    return vec.cpu().numpy()
+
+
+def umap_embedding(connectivities, *, n_components=2, n_epochs=None, a, b, gamma=1.0, initial_alpha=1.0,
+                   negative_sample_rate=5, init="spectral", seed=0) -> np.ndarray:
+    """The device part of `simplicial_set_embedding`: symmetric fuzzy graph -> embedding float32 [n, n_components]."""
+    import torch
+
+    from .. import _kernels as K
+    from .._device import require_gpu
+
+    dev = require_gpu()
+    n = connectivities.shape[0]
+    if n_epochs is None:
+        n_epochs = 500 if n <= 10000 else 200
+    csr, eps = _prune_and_schedule(connectivities, n_epochs)
+    indptr = torch.from_numpy(csr.indptr.astype(np.int64)).to(dev)
+    indices = torch.from_numpy(csr.indices.astype(np.int32)).to(dev)
+    rs = np.random.RandomState(seed)
+    if isinstance(init, str) and init == "random":
+        emb = rs.uniform(low=-10.0, high=10.0, size=(n, n_components)).astype(np.float32)
+    elif isinstance(init, str) and init == "spectral":
+        weights = torch.from_numpy(csr.data.astype(np.float32)).to(dev)
+        ini = _spectral_init(indptr, indices, weights, n, n_components, seed)
+        expansion = 10.0 / np.abs(ini).max()
+        emb = (ini * expansion).astype(np.float32) + rs.normal(scale=0.0001, size=[n, n_components]).astype(np.float32)
+    else:
+        emb = np.array(init, dtype=np.float32)
+        if emb.shape != (n, n_components):
+            raise ValueError(f"init_pos has shape {emb.shape}, expected {(n, n_components)}")
+    span = emb.max(0) - emb.min(0)
+    emb = (10.0 * (emb - emb.min(0)) / np.where(span > 0, span, 1.0)).astype(np.float32, order="C")
+    y = torch.from_numpy(emb).to(dev).contiguous()
+    K.umap_optimize_(indptr, indices, torch.from_numpy(eps).to(dev), n, y, n_epochs=n_epochs, a=a, b=b, gamma=gamma,
+                     initial_alpha=initial_alpha, negative_sample_rate=negative_sample_rate, seed=seed)
+    return y.cpu().numpy()
+
+
+def umap(  # noqa: PLR0913
+    adata,
+    *,
+    min_dist: float = 0.5,
+    spread: float = 1.0,
+    n_components: int = 2,
+    maxiter: int | None = None,
+    alpha: float = 1.0,
+    gamma: float = 1.0,
+    negative_sample_rate: int = 5,
+    init_pos="spectral",
+    rng=None,
+    random_state=_UNSET,
+    a: float | None = None,
+    b: float | None = None,
+    method: str = "umap",
+    key_added: str | None = None,
+    neighbors_key: str = "neighbors",
+    copy: bool = False,
+):
+    """Embed the neighborhood graph using UMAP (drop-in for `scanpy.tl.umap`, `_umap.py:30`).
+
+    Writes `obsm['X_umap' | key_added]` and `uns['umap' | key_added]['params'] = {a, b[, random_state]}`."""
+    if not is_anndata(adata):
+        raise TypeError("umap expects an AnnData object")
+    seed, meta = resolve_seed(rng, random_state)
+    adata = adata.copy() if copy else adata
+    key_obsm, key_uns = ("X_umap", "umap") if key_added is None else (key_added, key_added)
+    if neighbors_key is None:  # backwards compat (`:155-156`)
+        neighbors_key = "neighbors"
+    if neighbors_key not in adata.uns:
+        raise ValueError(f"Did not find .uns[{neighbors_key!r}]. Run `sc.pp.neighbors` first.")
+    if method != "umap":
+        raise ValueError(f"Unknown method {method}")
+    neighbors = adata.uns[neighbors_key]
+    connectivities = choose_graph(adata, obsp=None, neighbors_key=neighbors_key)
+    if "params" not in neighbors or neighbors["params"].get("method") != "umap":
+        _log.warning('.obsp["%s"] have not been computed using umap', neighbors.get("connectivities_key", "connectivities"))
+    if a is None or b is None:
+        a, b = find_ab_params(spread, min_dist)
+    adata.uns[key_uns] = dict(params=dict(a=a, b=b, **meta))
+    if isinstance(init_pos, str) and init_pos in adata.obsm:
+        init_coords = adata.obsm[init_pos]
+    elif isinstance(init_pos, str) and init_pos == "paga":
+        raise NotImplementedError("init_pos='paga' needs sc.tl.paga, which is outside the MI355X path")
+    elif isinstance(init_pos, str) and init_pos not in {"spectral", "random"}:
+        raise ValueError(f"init_pos={init_pos!r}: expected 'spectral', 'random', 'paga', a key of adata.obsm or an array")
+    else:
+        init_coords = init_pos
+    if hasattr(init_coords, "dtype"):
+        init_coords = np.asarray(init_coords, dtype=np.float32)  # `check_array(..., dtype=np.float32)`, `:187-188`
+    default_epochs = 500 if connectivities.shape[0] <= 10000 else 200
+    n_epochs = default_epochs if maxiter is None else maxiter
+    adata.obsm[key_obsm] = umap_embedding(connectivities, n_components=n_components, n_epochs=n_epochs, a=a, b=b,
+                                          gamma=gamma, initial_alpha=alpha, negative_sample_rate=negative_sample_rate,
+                                          init=init_coords, seed=seed)
+    return adata if copy else None

@@ -1,0 +1,106 @@
+"""-m gpu: scanpy_amd.tl.umap / scamd_umap_optimize_f32 against the oracle (oracle/umap.py, PARITY UNPINNED: umap-learn is
+not installed and the reference ships no golden embedding -- see the oracle's header).
+  * kernel == the same synchronous scheme on the CPU, element for element, after a few epochs;
+  * full runs: objective (fuzzy cross entropy), trustworthiness and separation of planted clusters on a par with the
+    reference's sequential sweep; bitwise determinism per seed."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+from scipy import sparse
+from sklearn.manifold import trustworthiness
+
+import scanpy_amd as sc
+from oracle import umap as ou
+
+pytestmark = pytest.mark.gpu
+
+
+def _adata(pbmc68k):
+    adata = sc.AnnData(pbmc68k["X"].copy())
+    adata.obsm["X_pca"] = pbmc68k["X_pca"]
+    adata.obsp["connectivities"] = pbmc68k["connectivities"].astype(np.float32)
+    adata.obsp["distances"] = pbmc68k["distances"]
+    adata.uns["neighbors"] = dict(connectivities_key="connectivities", distances_key="distances",
+                                  params=dict(n_neighbors=10, method="umap"))
+    return adata
+
+
+@pytest.mark.parametrize("dim", [2, 3, 5])
+@pytest.mark.parametrize(("n_epochs", "atol"), [(2, 1e-5), (4, 5e-3)])
+def test_kernel_matches_synchronous_oracle(pbmc68k, dim, n_epochs, atol):
+    """Same scheme on the CPU (oracle_umap_synchronous), element for element.  The first epochs (alpha ~ 1, random start)
+    are violently expansive: a 1-ulp difference of powf grows ~20x per epoch (measured 1e-6, 1e-4, 5e-4, 2e-2, 0.6 after
+    2, 3, 4, 6, 8 epochs), so the comparison is made after 2 epochs (ulp level) and after 4."""
+    import torch
+
+    from scanpy_amd import _kernels as K
+
+    g = ou.prune_graph(pbmc68k["connectivities"], n_epochs).tocsr()
+    g.sort_indices()
+    n = g.shape[0]
+    eps = ou.make_epochs_per_sample(g.data, n_epochs).astype(np.float32)
+    a, b = ou.find_ab_params()
+    y0 = np.random.default_rng(dim).uniform(0, 10, size=(n, dim)).astype(np.float32)
+    ref = ou.optimize_layout(g, y0, n_epochs=n_epochs, a=a, b=b, seed=11, scheme="synchronous")
+    dev = torch.device("cuda")
+    y = torch.from_numpy(y0.copy()).to(dev)
+    K.umap_optimize_(torch.from_numpy(g.indptr.astype(np.int64)).to(dev), torch.from_numpy(g.indices.astype(np.int32)).to(dev),
+                     torch.from_numpy(eps).to(dev), n, y, n_epochs=n_epochs, a=a, b=b, seed=11)
+    got = y.cpu().numpy()
+    assert np.abs(got - y0).max() > 0.5  # it moved
+    np.testing.assert_allclose(got, ref, rtol=0, atol=atol)
+
+
+def test_umap_fixture_quality_and_determinism(pbmc68k):
+    adata = _adata(pbmc68k)
+    sc.tl.umap(adata)
+    y = adata.obsm["X_umap"]
+    assert y.shape == (700, 2) and y.dtype == np.float32 and np.isfinite(y).all()
+    a, b = ou.find_ab_params()
+    assert abs(adata.uns["umap"]["params"]["a"] - a) < 1e-9 and adata.uns["umap"]["params"]["random_state"] == 0
+    g = pbmc68k["connectivities"]
+    y_ref = ou.simplicial_set_embedding(g, seed=0, scheme="sequential")
+    ce, ce_ref = ou.fuzzy_cross_entropy(g, y, a, b), ou.fuzzy_cross_entropy(g, y_ref, a, b)
+    assert ce < 1.06 * ce_ref
+    x = pbmc68k["X_pca"]
+    assert trustworthiness(x, y, n_neighbors=15) > trustworthiness(x, y_ref, n_neighbors=15) - 0.02
+    other = _adata(pbmc68k)
+    sc.tl.umap(other)
+    assert np.array_equal(other.obsm["X_umap"], y)  # bitwise reproducible
+    sc.tl.umap(other, random_state=3, key_added="X_alt")
+    assert not np.array_equal(other.obsm["X_alt"], y) and "X_alt" in other.uns
+
+
+def test_umap_init_variants_and_components(pbmc68k):
+    adata = _adata(pbmc68k)
+    sc.tl.umap(adata, init_pos="random", n_components=3, maxiter=50)
+    assert adata.obsm["X_umap"].shape == (700, 3)
+    for dtype in (np.float32, np.float64):  # tests/test_embedding.py:55-66: the init dtype does not matter
+        sc.tl.umap(adata, init_pos=adata.obsm["X_pca"][:, :2].astype(dtype), key_added=f"u_{np.dtype(dtype).name}", maxiter=30)
+    np.testing.assert_array_equal(adata.obsm["u_float32"], adata.obsm["u_float64"])
+    sc.tl.umap(adata, init_pos="u_float32", maxiter=5)
+    conn = adata.obsp["connectivities"].copy()
+    sc.tl.umap(adata, maxiter=5)
+    assert (adata.obsp["connectivities"] != conn).nnz == 0  # tests/test_embedding.py:83-95
+
+
+def test_umap_separates_planted_clusters():
+    from oracle import connectivities as oc
+    from oracle import knn as oknn
+    from scanpy_amd.datasets import blobs_embedding
+    from sklearn.neighbors import NearestNeighbors
+
+    n = 6000
+    x, lab = blobs_embedding(n, 50, n_types=10, seed=5)
+    idx, dist, _ = oknn.knn_sklearn(x, 15, n_jobs=-1)
+    c, _, _ = oc.fuzzy_simplicial_set(idx, dist, n, 15)
+    adata = sc.AnnData(x)
+    adata.obsp["connectivities"] = sparse.csr_matrix(c).astype(np.float32)
+    adata.uns["neighbors"] = dict(connectivities_key="connectivities", distances_key="distances",
+                                  params=dict(n_neighbors=15, method="umap"))
+    sc.tl.umap(adata)
+    y = adata.obsm["X_umap"]
+    nb = NearestNeighbors(n_neighbors=11).fit(y).kneighbors(y, return_distance=False)[:, 1:]
+    purity = (lab[nb] == lab[:, None]).mean()
+    assert purity > 0.97

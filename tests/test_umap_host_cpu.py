@@ -1,0 +1,54 @@
+"""Host-side pieces of scanpy_amd.tl.umap that need no GPU, against the oracle restatement of umap-learn."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+import scanpy_amd as sc
+from oracle import umap as ou
+from scanpy_amd.tools import _umap
+
+
+@pytest.mark.parametrize(("spread", "min_dist"), [(1.0, 0.5), (1.0, 0.1), (2.0, 0.3)])
+def test_find_ab_params(spread, min_dist):
+    a, b = _umap.find_ab_params(spread, min_dist)
+    ao, bo = ou.find_ab_params(spread, min_dist)
+    assert abs(a - ao) < 1e-9 and abs(b - bo) < 1e-9
+    if (spread, min_dist) == (1.0, 0.1):  # umap-learn's documented defaults: a ~ 1.577, b ~ 0.895
+        assert abs(a - 1.577) < 5e-3 and abs(b - 0.895) < 5e-3
+
+
+@pytest.mark.parametrize("n_epochs", [5, 200, 500])
+def test_prune_and_schedule(pbmc68k, n_epochs):
+    g = pbmc68k["connectivities"]
+    csr, eps = _umap._prune_and_schedule(g, n_epochs)
+    go = ou.prune_graph(g, n_epochs).tocsr()
+    go.sort_indices()
+    assert np.array_equal(csr.indptr, go.indptr) and np.array_equal(csr.indices, go.indices)
+    np.testing.assert_allclose(eps, ou.make_epochs_per_sample(go.data, n_epochs), rtol=1e-6)
+    assert (eps >= 1.0).all()  # at most one firing per epoch: the kernel's schedule relies on it
+    assert abs(csr - csr.T).max() == 0  # still symmetric: the mirrored sample has the same schedule
+
+
+def test_errors_without_gpu(pbmc68k):
+    adata = sc.AnnData(pbmc68k["X"].copy())
+    with pytest.raises(ValueError, match="Run `sc.pp.neighbors` first"):
+        sc.tl.umap(adata)
+    adata.obsp["connectivities"] = pbmc68k["connectivities"]
+    adata.uns["neighbors"] = dict(connectivities_key="connectivities", distances_key="distances", params=dict(method="umap"))
+    with pytest.raises(NotImplementedError, match="paga"):
+        sc.tl.umap(adata, init_pos="paga")
+    with pytest.raises(ValueError, match="Unknown method"):
+        sc.tl.umap(adata, method="rapids")
+
+
+def test_oracle_schemes_agree_in_quality(pbmc68k):
+    """the synchronous (Jacobi) scheme the GPU uses optimises the same objective as the reference's sequential sweep"""
+    g = pbmc68k["connectivities"]
+    a, b = ou.find_ab_params()
+    y_seq = ou.simplicial_set_embedding(g, seed=0, scheme="sequential")
+    y_syn = ou.simplicial_set_embedding(g, seed=0, scheme="synchronous")
+    ce_seq, ce_syn = ou.fuzzy_cross_entropy(g, y_seq, a, b), ou.fuzzy_cross_entropy(g, y_syn, a, b)
+    ce_init = ou.fuzzy_cross_entropy(g, ou.initial_embedding(ou.prune_graph(g, 500), 2, "spectral", np.random.RandomState(0)), a, b)
+    assert ce_seq < 0.7 * ce_init and ce_syn < 0.7 * ce_init and abs(ce_syn - ce_seq) < 0.06 * ce_seq
