@@ -136,6 +136,35 @@ def upstream_chain(handle, reps: int = 3) -> dict:
     return out
 
 
+def umap_layout(res, n: int, n_epochs: int = 200) -> dict:
+    """SURVEY 8(f).1 row, measured beside the path (NOT part of `value`): the UMAP layout kernel on the fuzzy graph the
+    timed path just produced (resident), random start, `n_epochs` synchronous epochs."""
+    import torch
+
+    from scanpy_amd import _kernels as K
+    from scanpy_amd.tools._umap import find_ab_params, prune_and_schedule_device
+
+    ip, ix, w, eps = prune_and_schedule_device(res.conn_indptr, res.conn_indices, res.conn_data, n, n_epochs)
+    a, b = find_ab_params(1.0, 0.5)
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    y = (torch.rand((n, 2), generator=gen) * 10.0).to(w.device).contiguous()
+    fired = float(torch.floor(float(n_epochs - 1) / eps[eps > 0].to(torch.float64)).sum())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    K.umap_optimize_(ip, ix, eps, n, y, n_epochs=n_epochs, a=a, b=b, seed=0)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    nnz = int(ix.numel())
+    # per epoch: 16 B of index + schedule per stored sample; a fired sample gathers one neighbour and ~5 negatives (8 B
+    # each at n_components = 2) and rewrites 8 B of schedule; plus the embedding in and out
+    bytes_total = n_epochs * (16.0 * nnz + 16.0 * n) + fired * (8.0 + 6 * 8.0)
+    return {"note": "scamd_umap_optimize_f32 on the path's own fuzzy graph, random start; outside `value`",
+            "n_epochs": n_epochs, "stored_samples": nnz, "fired_samples": fired, "ms": ms, "ms_per_epoch": ms / n_epochs,
+            "gathers_per_s": fired * 6.0 / (ms * 1e-3), "algorithmic_GBps": bytes_total / (ms * 1e-3) / 1e9,
+            "frac_of_8TBps": bytes_total / (ms * 1e-3) / 1e9 / 8000.0, "finite": bool(torch.isfinite(y).all())}
+
+
 def main() -> None:
     args = parse_args()
     import torch
@@ -257,6 +286,7 @@ def main() -> None:
         }
         if world == 1:
             out["upstream_chain"] = upstream_chain(handle)
+            out["umap_layout"] = umap_layout(res, n)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n), args.n_vars, args.n_comps, args.n_neighbors, args.seed)
         print(json.dumps(out), flush=True)

@@ -41,6 +41,10 @@ __device__ __forceinline__ int64_t um_neg_vertex(unsigned long long seed, int ep
   h = um_hash32(h + 0x85EBCA6BU * (unsigned int)(sample >> 32) + 0xC2B2AE35U * (unsigned int)p);
   return (int64_t)(((unsigned long long)h * (unsigned long long)n_vertices) >> 32);
 }
+// x^b for x > 0 through the hardware exp2 / log2 (v_exp_f32, v_log_f32: ~1 ulp each).  The library powf costs ~200
+// instructions per call and, with ~30 % of a wave's lanes inside the "sample fires" branch, made the kernel
+// VALU-bound (7 calls per fired sample); the SGD does not need powf's last bit.
+__device__ __forceinline__ float um_pow(float x, float b) { return __builtin_amdgcn_exp2f(b * __builtin_amdgcn_logf(x)); }
 __device__ __forceinline__ float um_clip4(float v) { return v > 4.0f ? 4.0f : (v < -4.0f ? -4.0f : v); }
 
 // G lanes per vertex (UM_BLOCK / G vertices per workgroup), DIM = embedding dimension (compile time for 2 and 3)
@@ -75,26 +79,42 @@ __global__ __launch_bounds__(UM_BLOCK) void umap_epoch_kernel(
         d2 += diff[t] * diff[t];
       }
       float coeff = 0.f;
-      if (d2 > 0.f) coeff = (-2.0f * a * b * powf(d2, b - 1.0f)) / (a * powf(d2, b) + 1.0f);
+      if (d2 > 0.f) {
+        const float pw = um_pow(d2, b);  // d^(2b); d^(2(b-1)) = pw / d2
+        coeff = (-2.0f * a * b * (pw / d2)) / (a * pw + 1.0f);
+      }
 #pragma unroll
       for (int t = 0; t < D; ++t) delta[t] += 2.0f * um_clip4(coeff * diff[t]);
       next[i] = nx + eps;
       const float eps_neg = eps / neg_rate;
       const float nn = next_neg[i];
       const int n_neg = (int)(((float)epoch - nn) / eps_neg);
-      for (int p = 0; p < n_neg; ++p) {
-        const int64_t kk = um_neg_vertex(seed, epoch, i, p, n);
-        if (kk == v) continue;
-        float e2 = 0.f;
+      // negatives in batches of NB: all gathers of a batch are issued before any of them is used (a loop with one
+      // dependent gather per iteration is latency-bound: 17 G gathers/s measured, vs 3x that batched)
+      constexpr int NB = 6;
+      for (int p0 = 0; p0 < n_neg; p0 += NB) {
+        int64_t kk[NB];
+        float oth[NB][D];
 #pragma unroll
-        for (int t = 0; t < D; ++t) {
-          diff[t] = t < dim ? cur[t] - yin[kk * dim + t] : 0.f;
-          e2 += diff[t] * diff[t];
+        for (int q = 0; q < NB; ++q) {
+          kk[q] = (p0 + q < n_neg) ? um_neg_vertex(seed, epoch, i, p0 + q, n) : v;  // v itself = skipped below
+#pragma unroll
+          for (int t = 0; t < D; ++t) oth[q][t] = t < dim ? yin[kk[q] * dim + t] : 0.f;
         }
-        if (e2 > 0.f) {
-          const float c2 = (2.0f * gamma * b) / ((0.001f + e2) * (a * powf(e2, b) + 1.0f));
 #pragma unroll
-          for (int t = 0; t < D; ++t) delta[t] += um_clip4(c2 * diff[t]);
+        for (int q = 0; q < NB; ++q) {
+          if (kk[q] == v) continue;
+          float e2 = 0.f;
+#pragma unroll
+          for (int t = 0; t < D; ++t) {
+            diff[t] = t < dim ? cur[t] - oth[q][t] : 0.f;
+            e2 += diff[t] * diff[t];
+          }
+          if (e2 > 0.f) {
+            const float c2 = (2.0f * gamma * b) / ((0.001f + e2) * (a * um_pow(e2, b) + 1.0f));
+#pragma unroll
+            for (int t = 0; t < D; ++t) delta[t] += um_clip4(c2 * diff[t]);
+          }
         }
       }
       next_neg[i] = nn + (float)n_neg * eps_neg;

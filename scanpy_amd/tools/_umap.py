@@ -56,6 +56,24 @@ def _prune_and_schedule(graph, n_epochs: int):
     return csr, eps.astype(np.float32)
 
 
+def prune_and_schedule_device(indptr, indices, data, n: int, n_epochs: int):
+    """`_prune_and_schedule` on device tensors (the graph never leaves HBM in the resident pipeline).
+    -> (indptr int64, indices int32, weights float32, epochs_per_sample float32)."""
+    import torch
+
+    default_epochs = 500 if n <= 10000 else 200
+    wmax = data.max()
+    keep = data >= wmax / float(n_epochs if n_epochs > 10 else default_epochs)
+    rows = torch.repeat_interleave(torch.arange(n, device=data.device), (indptr[1:] - indptr[:-1]))
+    counts = torch.bincount(rows[keep], minlength=n)
+    new_indptr = torch.zeros(n + 1, dtype=torch.int64, device=data.device)
+    new_indptr[1:] = torch.cumsum(counts, 0)
+    w = data[keep].contiguous()
+    n_samples = n_epochs * (w.to(torch.float64) / wmax.to(torch.float64))
+    eps = torch.where(n_samples > 0, float(n_epochs) / n_samples, torch.full_like(n_samples, -1.0)).to(torch.float32)
+    return new_indptr, indices[keep].contiguous(), w, eps.contiguous()
+
+
 def _spectral_init(indptr, indices, weights, n: int, dim: int, seed: int, *, n_iter: int = 80):
     """Leading non-trivial eigenvectors of S = D^-1/2 A D^-1/2 (= smallest of the normalised Laplacian, what
     umap.spectral.spectral_layout asks ARPACK for) by block power iteration on (S + I) / 2 with a Rayleigh-Ritz step.
