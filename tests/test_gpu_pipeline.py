@@ -321,3 +321,33 @@ def test_pca_sparse_equals_dense_and_integer_input(sc, pbmc68k):
     assert a_int.obsm["X_pca"].dtype == np.float32 and a_int.varm["PCs"].dtype == np.float64
     ref = opca.pca_reference(counts.astype(np.float32), 10)
     assert np.abs(np.abs(a_int.varm["PCs"].T) - np.abs(ref["components"])).max() < 1e-4
+
+
+def test_counts_to_clusters_to_umap_with_the_dropin_calls():
+    """The whole widened chain through the drop-in functions, as a scanpy script would call them:
+    normalize_total -> log1p -> highly_variable_genes -> scale -> pca -> neighbors -> leiden -> umap."""
+    from sklearn.metrics import adjusted_rand_score
+    from sklearn.neighbors import NearestNeighbors
+
+    import scanpy_amd as sc
+    from scanpy_amd.datasets import synthetic_planted
+
+    x, truth = synthetic_planted(5000, 800, n_types=12, seed=7)
+    x.data = np.expm1(x.data).astype(np.float32)  # back to a counts-like scale
+    adata = sc.AnnData(x)
+    sc.pp.normalize_total(adata, target_sum=1e4)
+    sc.pp.log1p(adata)
+    sc.pp.highly_variable_genes(adata, n_top_genes=400)
+    assert int(adata.var["highly_variable"].sum()) == 400
+    with pytest.warns(UserWarning, match="densifies"):
+        sc.pp.scale(adata, max_value=10)
+    assert adata.X.shape == (5000, 800) and abs(float(adata.X[:, adata.var["highly_variable"].to_numpy()].mean())) < 1e-2  # clipped tails shift it slightly
+    sc.pp.pca(adata, n_comps=30)  # uses var['highly_variable'] as the gene mask, like the reference
+    assert (np.abs(adata.varm["PCs"][~adata.var["highly_variable"].to_numpy()]).sum() == 0)
+    sc.pp.neighbors(adata)
+    sc.tl.leiden(adata)
+    sc.tl.umap(adata)
+    assert adjusted_rand_score(truth, adata.obs["leiden"].cat.codes.to_numpy()) > 0.95
+    y = adata.obsm["X_umap"]
+    nb = NearestNeighbors(n_neighbors=11).fit(y).kneighbors(y, return_distance=False)[:, 1:]
+    assert (truth[nb] == truth[:, None]).mean() > 0.95
