@@ -71,8 +71,14 @@ def _all_gather_rows(t: torch.Tensor, comm, counts: list[int]) -> torch.Tensor:
     if t.shape[0] < mx:
         pad = torch.zeros((mx - t.shape[0], *t.shape[1:]), dtype=t.dtype, device=t.device)
         t = torch.cat([t, pad], dim=0)
-    buf = torch.empty((comm.world_size * mx, *t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(buf, t, group=getattr(comm, "group", None))
+    group = getattr(comm, "group", None)
+    if t.is_cuda and dist.get_backend(group) == "gloo":  # validation runs (several ranks on one GPU): host staging
+        hbuf = torch.empty((comm.world_size * mx, *t.shape[1:]), dtype=t.dtype)
+        dist.all_gather_into_tensor(hbuf, t.cpu(), group=group)
+        buf = hbuf.to(t.device)
+    else:
+        buf = torch.empty((comm.world_size * mx, *t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(buf, t, group=group)
     if all(c == mx for c in counts):
         return buf
     return torch.cat([buf[r * mx: r * mx + c] for r, c in enumerate(counts)], dim=0)
@@ -118,9 +124,16 @@ def run_path(a_handle, n_total: int, *, comm=None, backend=None, n_comps: int = 
     if world > 1:
         import torch.distributed as tdist
 
-        tdist.broadcast(labels, src=0, group=getattr(comm, "group", None))
+        group = getattr(comm, "group", None)
         meta = torch.tensor([q, float(nc)], dtype=torch.float64, device=dev)
-        tdist.broadcast(meta, src=0, group=getattr(comm, "group", None))
+        if labels.is_cuda and tdist.get_backend(group) == "gloo":  # validation runs: host staging
+            hl, hm = labels.cpu(), meta.cpu()
+            tdist.broadcast(hl, src=0, group=group)
+            tdist.broadcast(hm, src=0, group=group)
+            labels, meta = hl.to(dev), hm
+        else:
+            tdist.broadcast(labels, src=0, group=group)
+            tdist.broadcast(meta, src=0, group=group)
         q, nc = float(meta[0]), int(meta[1])
         tm.mark("broadcast")
     info = dict(res.info)

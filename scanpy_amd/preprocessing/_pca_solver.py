@@ -52,15 +52,26 @@ class TorchDistComm:
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
 
-    def allreduce_(self, t: torch.Tensor) -> torch.Tensor:
+    def _host_staged(self, t: torch.Tensor) -> bool:
+        """Device tensors under the gloo backend go through host memory (gloo's CUDA support is partial).  RCCL never
+        takes this branch; it exists so that the sharded GPU path can be validated with several ranks on ONE GPU."""
+        return t.is_cuda and self._dist.get_backend(self.group) == "gloo"
+
+    def _allreduce(self, t: torch.Tensor, op) -> torch.Tensor:
         if self.world_size > 1:
-            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+            if self._host_staged(t):
+                c = t.cpu()
+                self._dist.all_reduce(c, op=op, group=self.group)
+                t.copy_(c)
+            else:
+                self._dist.all_reduce(t, op=op, group=self.group)
         return t
 
+    def allreduce_(self, t: torch.Tensor) -> torch.Tensor:
+        return self._allreduce(t, self._dist.ReduceOp.SUM)
+
     def allreduce_max_(self, t: torch.Tensor) -> torch.Tensor:
-        if self.world_size > 1:
-            self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self.group)
-        return t
+        return self._allreduce(t, self._dist.ReduceOp.MAX)
 
 
 class GpuBackend:
