@@ -92,6 +92,17 @@ def _profiled_traffic(mode: str):
         return None
 
 
+def _baseline_config(n: int, g: int, world: int) -> str:
+    """which BASELINE.json `configs` entry the run corresponds to (the label is informational)"""
+    if (n, g) == (1_000_000, 2000):
+        return "BASELINE configs[2]" if world == 1 else f"BASELINE configs[3] over {world} GPUs"
+    if (n, g) == (100_000, 2000):
+        return "BASELINE configs[1]"
+    if (n, g) == (10_000_000, 4000):
+        return "BASELINE configs[4] sizes, exact kNN, single resolution"
+    return "custom size"
+
+
 def upstream_chain(handle, reps: int = 3) -> dict:
     """SURVEY 8(f).2 rows, measured beside the path (NOT part of `value`): the device passes of
     normalize_total(1e4) -> log1p -> highly_variable_genes('seurat') statistics -> scale(zero_center=False) on the
@@ -246,7 +257,7 @@ def main() -> None:
         achieved = flops / (sel * 1e-3) / 1e12 if sel > 0 else None
         peak = 157.3
         out = {
-            "metric": "cells/sec through pca+neighbors+leiden, 1M x 2k CSR",
+            "metric": "cells/sec through pca+neighbors+leiden, 1M x 2k CSR" if (n, args.n_vars) == (1_000_000, 2000) else f"cells/sec through pca+neighbors+leiden, {n} x {args.n_vars} CSR",
             "value": value,
             "unit": "cells/s",
             "n_gpus": world,
@@ -261,7 +272,7 @@ def main() -> None:
             "config": {
                 "workload": (f"synthetic planted log-normal CSR {n} cells x {args.n_vars} genes (~5% nnz), PCA {args.n_comps} "
                              f"(exact Gram + dense eigensolve, arpack accuracy) + exact kNN k={args.n_neighbors} (cell-pruned brute force) + umap "
-                             "connectivities + Leiden res=1.0 n_iterations=-1 (BASELINE configs[2])"),
+                             "connectivities + Leiden res=1.0 n_iterations=-1 (" + _baseline_config(n, args.n_vars, world) + ")"),
                 "n_obs": n,
                 "n_vars": args.n_vars,
                 "nnz_per_rank": int(nnz_local),
