@@ -41,7 +41,7 @@ def sparse_from_indices_distances(indices, distances, *, keep_self: bool) -> spa
     return sparse.csr_matrix((distances.copy().ravel(), indices.copy().ravel(), indptr), shape=(n, n))
 
 
-def knn_sklearn(x: np.ndarray, n_neighbors: int, *, n_jobs: int | None = None):
+def knn_sklearn(x: np.ndarray, n_neighbors: int, *, n_jobs: int | None = None, metric: str = "euclidean"):
     """Reference shortcut path.  Returns (knn_indices (n,k), knn_distances (n,k), distances CSR k-1/row).
 
     Column 0 is the cell itself with distance exactly 0 (diagonal zeroed in place at
@@ -51,7 +51,7 @@ def knn_sklearn(x: np.ndarray, n_neighbors: int, *, n_jobs: int | None = None):
 
     n = x.shape[0]
     k = min(n - 1, n_neighbors)
-    tr = KNeighborsTransformer(algorithm="brute", n_neighbors=k, metric="euclidean", n_jobs=n_jobs)
+    tr = KNeighborsTransformer(algorithm="brute", n_neighbors=k, metric=metric, n_jobs=n_jobs)
     d = tr.fit_transform(x).tocsr()
     knn_indices, knn_distances = indices_distances_from_sparse(d, n_neighbors)
     knn_distances = knn_distances.copy()

@@ -21,7 +21,7 @@ from ._common import (
     get_indices_distances_from_sparse_matrix,
     get_sparse_matrix_from_indices_distances,
 )
-from ._transformer import MI355XKNNTransformer, knn_search
+from ._transformer import METRICS, MI355XKNNTransformer, knn_search
 
 __all__ = ["neighbors", "Neighbors", "MI355XKNNTransformer"]
 
@@ -116,13 +116,14 @@ class Neighbors:
         self.knn = knn
         x = choose_representation(self._adata, use_rep=use_rep, n_pcs=n_pcs)
         if transformer is None or isinstance(transformer, str):
-            if callable(metric) or metric not in {"euclidean", "l2"}:
-                msg = f"metric={metric!r}: the MI355X kNN kernel is Euclidean only; pass a `transformer` for other metrics."
+            if callable(metric) or metric not in METRICS:
+                msg = (f"metric={metric!r}: the MI355X kNN kernel offers {METRICS}; pass a `transformer` for other "
+                       "metrics.")
                 raise NotImplementedError(msg)
             # built-in exact search: (n, k) arrays straight from the device, self column first with an
             # exact 0 (what the reference gets after zeroing the diagonal, neighbors/__init__.py:639-648)
             k = min(n_neighbors, self._adata.n_obs)
-            knn_indices, knn_distances = knn_search(x, k)
+            knn_indices, knn_distances = knn_search(x, k, metric=metric)
             self._distances = get_sparse_matrix_from_indices_distances(knn_indices, knn_distances, keep_self=False)
         else:  # user-supplied estimator instance: the reference's plug-in route, used as-is (:788, :638)
             self._distances = transformer.fit_transform(x)

@@ -14,19 +14,34 @@ import numpy as np
 from scipy import sparse
 
 
-def knn_search(x, k: int, *, q_begin: int = 0, n_query: int | None = None):
-    """Exact Euclidean kNN on the GPU.  -> (indices int64 [nq, k], distances float64 [nq, k]);
-    column 0 is the row itself with distance exactly 0."""
+METRICS = ("euclidean", "l2", "cosine")
+
+
+def knn_search(x, k: int, *, q_begin: int = 0, n_query: int | None = None, metric: str = "euclidean"):
+    """Exact kNN on the GPU.  -> (indices int64 [nq, k], distances float64 [nq, k]); column 0 is the row itself with
+    distance exactly 0.
+
+    metric 'cosine' (sklearn: 1 - x.y / (|x||y|)): on unit-length rows the Euclidean order IS the cosine order and
+    1 - cos = |x^ - y^|^2 / 2, so the rows are normalised on the device and the Euclidean kernel does the search."""
     import torch
 
     from .. import _kernels
     from .._device import require_gpu
 
+    if metric not in METRICS:
+        raise ValueError(f"metric={metric!r}: the MI355X kNN kernel offers {METRICS}")
     dev = require_gpu()
     if sparse.issparse(x):
         x = x.toarray()
     xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
+    if metric == "cosine":
+        norm = torch.linalg.norm(xd.to(torch.float64), dim=1, keepdim=True)
+        if bool((norm == 0).any()):
+            raise ValueError("metric='cosine' is undefined for all-zero rows")
+        xd = (xd.to(torch.float64) / norm).to(torch.float32).contiguous()
     idx, dist, _ = _kernels.knn(xd, k, q_begin=q_begin, n_query=n_query)
+    if metric == "cosine":
+        dist = 0.5 * dist * dist
     return idx.cpu().numpy().astype(np.int64), dist.cpu().numpy()
 
 
@@ -35,8 +50,8 @@ class MI355XKNNTransformer:
     `set_params`)."""
 
     def __init__(self, n_neighbors: int = 15, *, metric: str = "euclidean", include_self: bool = False):
-        if metric not in ("euclidean", "l2"):
-            msg = f"metric={metric!r}: the MI355X kNN kernel is Euclidean only"
+        if metric not in METRICS:
+            msg = f"metric={metric!r}: the MI355X kNN kernel offers {METRICS}"
             raise ValueError(msg)
         self.n_neighbors = n_neighbors
         self.metric = metric
@@ -66,10 +81,10 @@ class MI355XKNNTransformer:
         n = x.shape[0]
         if self.include_self:  # sklearn style: self + n_neighbors others
             k = min(self.n_neighbors + 1, n)
-            idx, dist = knn_search(x, k)
+            idx, dist = knn_search(x, k, metric=self.metric)
         else:  # RAPIDS style: n_neighbors - 1 others, no self
             k = min(self.n_neighbors, n)
-            idx, dist = knn_search(x, k)
+            idx, dist = knn_search(x, k, metric=self.metric)
             idx, dist = idx[:, 1:], dist[:, 1:]
         kk = idx.shape[1]
         indptr = np.arange(0, n * kk + 1, kk)

@@ -351,3 +351,26 @@ def test_counts_to_clusters_to_umap_with_the_dropin_calls():
     y = adata.obsm["X_umap"]
     nb = NearestNeighbors(n_neighbors=11).fit(y).kneighbors(y, return_distance=False)[:, 1:]
     assert (truth[nb] == truth[:, None]).mean() > 0.95
+
+
+def test_neighbors_cosine_metric(sc, pbmc68k):
+    """metric='cosine' (the reference hands it to sklearn, neighbors/__init__.py:761-768): same neighbour sets and
+    distances as sklearn's brute-force cosine search, through the Euclidean kernel on unit-length rows"""
+    adata = sc.AnnData(pbmc68k["X"].copy())
+    adata.obsm["X_pca"] = pbmc68k["X_pca"]
+    sc.pp.neighbors(adata, n_neighbors=12, metric="cosine")
+    assert adata.uns["neighbors"]["params"]["metric"] == "cosine"
+    oi, od, _ = oknn.knn_sklearn(pbmc68k["X_pca"], 12, metric="cosine")
+    d = adata.obsp["distances"]
+    assert (np.diff(d.indptr) == 11).all()
+    got_i, got_d = d.indices.reshape(-1, 11), d.data.reshape(-1, 11)
+    order = np.argsort(got_d, axis=1, kind="stable")
+    got_i, got_d = np.take_along_axis(got_i, order, 1), np.take_along_axis(got_d, order, 1)
+    bad, _ = knn_sets_equal_mod_ties(got_i, got_d, oi[:, 1:], od[:, 1:], rtol=1e-5, atol=1e-7)
+    assert bad == 0
+    np.testing.assert_allclose(got_d, od[:, 1:], rtol=2e-5, atol=2e-7)
+    tr = sc.MI355XKNNTransformer(n_neighbors=12, metric="cosine")
+    g = tr.fit_transform(pbmc68k["X_pca"])
+    assert abs(g - d).max() < 1e-12
+    with pytest.raises(ValueError, match="all-zero"):
+        sc.MI355XKNNTransformer(metric="cosine").fit_transform(np.zeros((50, 4), dtype=np.float32))
