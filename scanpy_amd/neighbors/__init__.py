@@ -54,7 +54,7 @@ class Neighbors:
         self.n_neighbors = None
         self.knn = None
         self.rp_forest = None
-        self._number_connected_components = None
+        self._cc = None
         key = "neighbors" if neighbors_key is None else neighbors_key
         if key in adata.uns:  # restore an existing graph (neighbors/__init__.py:437-474)
             info = adata.uns[key]
@@ -75,12 +75,25 @@ class Neighbors:
                     self.n_neighbors = int(count_nonzero(self._distances) / self._distances.shape[0])
                 else:
                     self.n_neighbors = int(count_nonzero(self._connectivities) / self._connectivities.shape[0] / 2)
-            self._number_connected_components = 1
-            if sparse.issparse(self._connectivities):  # `:466-472`
-                from scipy.sparse.csgraph import connected_components
+            self._cc = None  # `:466-472`, lazily (see `_connected_components`)
 
-                self._connected_components = connected_components(self._connectivities)
-                self._number_connected_components = self._connected_components[0]
+    @property
+    def _connected_components(self):
+        """(n_components, labels) of the connectivity graph.  The reference computes it eagerly at the end of
+        `compute_neighbors` / on restore (scipy `connected_components`: ~0.3-3 s at 1M cells, more than the GPU spends
+        on the whole path); nothing on this path reads it, so it is computed when first asked for."""
+        if self._cc is None and sparse.issparse(self._connectivities):
+            from scipy.sparse.csgraph import connected_components
+
+            self._cc = connected_components(self._connectivities)
+        return self._cc
+
+    @property
+    def _number_connected_components(self):
+        if self._connectivities is None:
+            return None
+        cc = self._connected_components
+        return 1 if cc is None else cc[0]
 
     @property
     def distances(self):
@@ -131,12 +144,7 @@ class Neighbors:
         self._connectivities = None
         if conn_method == "umap":
             self._connectivities = _connectivities_umap(knn_indices, knn_distances, self._adata.n_obs)
-        self._number_connected_components = 1
-        if sparse.issparse(self._connectivities):
-            from scipy.sparse.csgraph import connected_components
-
-            self._connected_components = connected_components(self._connectivities)
-            self._number_connected_components = self._connected_components[0]
+        self._cc = None  # connected components (neighbors/__init__.py:660-673) are computed on first use
 
 
 def _get_metadata(key_added, **params):

@@ -7,7 +7,7 @@ What the reference delegates to umap-learn's `simplicial_set_embedding` is resta
   * the SGD is synchronous and race-free (see csrc/umap.hip) and draws negatives with a counter-based hash: the result
     is bitwise reproducible for a given seed, but it is not the sequence umap-learn's sequential sweep would produce;
   * `init_pos='spectral'` computes the leading eigenvectors of the symmetric normalised adjacency by block power
-    iteration on the device (SpMM kernel of the PCA stage) instead of ARPACK; a disconnected graph is not laid out
+    iteration (50 steps) on the device (SpMM kernel of the PCA stage) instead of ARPACK; a disconnected graph is not laid out
     component by component -- the block iteration separates the components by itself;
   * `init_pos='paga'` is outside the path (needs `sc.tl.paga`)."""
 from __future__ import annotations
@@ -63,7 +63,7 @@ def prune_and_schedule_device(indptr, indices, data, n: int, n_epochs: int):
 
     default_epochs = 500 if n <= 10000 else 200
     wmax = data.max()
-    keep = data >= wmax / float(n_epochs if n_epochs > 10 else default_epochs)
+    keep = (data >= wmax / float(n_epochs if n_epochs > 10 else default_epochs)) & (data != 0)
     rows = torch.repeat_interleave(torch.arange(n, device=data.device), (indptr[1:] - indptr[:-1]))
     counts = torch.bincount(rows[keep], minlength=n)
     new_indptr = torch.zeros(n + 1, dtype=torch.int64, device=data.device)
@@ -74,7 +74,7 @@ def prune_and_schedule_device(indptr, indices, data, n: int, n_epochs: int):
     return new_indptr, indices[keep].contiguous(), w, eps.contiguous()
 
 
-def _spectral_init(indptr, indices, weights, n: int, dim: int, seed: int, *, n_iter: int = 80):
+def _spectral_init(indptr, indices, weights, n: int, dim: int, seed: int, *, n_iter: int = 50):
     """Leading non-trivial eigenvectors of S = D^-1/2 A D^-1/2 (= smallest of the normalised Laplacian, what
     umap.spectral.spectral_layout asks ARPACK for) by block power iteration on (S + I) / 2 with a Rayleigh-Ritz step.
     Device tensors in, float64 [n, dim] host array out."""
@@ -88,7 +88,27 @@ def _spectral_init(indptr, indices, weights, n: int, dim: int, seed: int, *, n_i
     dis = torch.where(deg > 0, deg.rsqrt(), torch.zeros_like(deg))
     s_data = (weights.to(torch.float64) * dis[rows] * dis[indices.long()]).to(torch.float32).contiguous()
     width = dim + 1 + 4  # trivial vector + wanted + a little oversampling
-    from ..preprocessing._pca_solver import _cholqr2  # GEMM-shaped orthonormalisation (Cholesky QR)
+    def _tall_gram(p, q):
+        """p^T q for very tall, very thin p, q ([n, ~7]): a batched product over 1024 row chunks + a sum.  One GEMM with
+        M = N = 7 and K = 1e6 runs in a single workgroup (tens of ms)."""
+        nn, c = p.shape[0], 1024
+        m = nn // c
+        if m == 0:
+            return p.T @ q
+        head = torch.bmm(p[: m * c].view(c, m, -1).transpose(1, 2), q[: m * c].view(c, m, -1)).sum(dim=0)
+        return head + p[m * c:].T @ q[m * c:]
+
+    def _cholqr2(y):
+        """Cholesky QR, twice, for a very tall and very thin block ([n, ~7]): Q = Y L^-T with the tiny inverse formed
+        explicitly -- rocBLAS trsm with a 7-row triangular factor and a million right-hand sides took 55 ms per call."""
+        y = y / torch.sqrt(torch.diagonal(_tall_gram(y, y))).clamp_min(1e-300)
+        for _ in range(2):
+            l, bad = torch.linalg.cholesky_ex(_tall_gram(y, y))
+            if int(bad) != 0:
+                return torch.linalg.qr(y, mode="reduced")[0]
+            eye = torch.eye(l.shape[0], dtype=l.dtype, device=l.device)
+            y = y @ torch.linalg.solve_triangular(l, eye, upper=False).T
+        return y
 
     gen = torch.Generator(device="cpu").manual_seed(int(seed) & 0x7FFFFFFF)
     v = torch.randn((n, width), generator=gen, dtype=torch.float64).to(dev)
@@ -98,7 +118,7 @@ def _spectral_init(indptr, indices, weights, n: int, dim: int, seed: int, *, n_i
         sv = K.spmm(indptr, indices, s_data, n, n, v.to(torch.float32).contiguous()).to(torch.float64)
         v = _cholqr2(0.5 * (sv + v))
     sv = K.spmm(indptr, indices, s_data, n, n, v.to(torch.float32).contiguous()).to(torch.float64)
-    t = v.T @ sv
+    t = _tall_gram(v, sv)
     theta, y = torch.linalg.eigh(0.5 * (t + t.T))
     order = torch.argsort(theta, descending=True)
     vec = v @ y[:, order[1:dim + 1]]  # drop the trivial one
@@ -117,14 +137,20 @@ def umap_embedding(connectivities, *, n_components=2, n_epochs=None, a, b, gamma
     n = connectivities.shape[0]
     if n_epochs is None:
         n_epochs = 500 if n <= 10000 else 200
-    csr, eps = _prune_and_schedule(connectivities, n_epochs)
-    indptr = torch.from_numpy(csr.indptr.astype(np.int64)).to(dev)
-    indices = torch.from_numpy(csr.indices.astype(np.int32)).to(dev)
+    # the graph goes to the device as it is stored (CSR); pruning and the epoch schedule are computed there
+    # (`prune_and_schedule_device` == `_prune_and_schedule`, which a COO round trip through scipy makes 50x slower than
+    # the whole optimisation at 1M cells)
+    csr = sparse.csr_matrix(connectivities)
+    if not csr.has_canonical_format:
+        csr = csr.copy()
+        csr.sum_duplicates()
+    indptr, indices, weights, eps_t = prune_and_schedule_device(
+        torch.from_numpy(csr.indptr.astype(np.int64)).to(dev), torch.from_numpy(csr.indices.astype(np.int32)).to(dev),
+        torch.from_numpy(np.ascontiguousarray(csr.data, dtype=np.float32)).to(dev), n, n_epochs)
     rs = np.random.RandomState(seed)
     if isinstance(init, str) and init == "random":
         emb = rs.uniform(low=-10.0, high=10.0, size=(n, n_components)).astype(np.float32)
     elif isinstance(init, str) and init == "spectral":
-        weights = torch.from_numpy(csr.data.astype(np.float32)).to(dev)
         ini = _spectral_init(indptr, indices, weights, n, n_components, seed)
         expansion = 10.0 / np.abs(ini).max()
         emb = (ini * expansion).astype(np.float32) + rs.normal(scale=0.0001, size=[n, n_components]).astype(np.float32)
@@ -135,7 +161,7 @@ def umap_embedding(connectivities, *, n_components=2, n_epochs=None, a, b, gamma
     span = emb.max(0) - emb.min(0)
     emb = (10.0 * (emb - emb.min(0)) / np.where(span > 0, span, 1.0)).astype(np.float32, order="C")
     y = torch.from_numpy(emb).to(dev).contiguous()
-    K.umap_optimize_(indptr, indices, torch.from_numpy(eps).to(dev), n, y, n_epochs=n_epochs, a=a, b=b, gamma=gamma,
+    K.umap_optimize_(indptr, indices, eps_t, n, y, n_epochs=n_epochs, a=a, b=b, gamma=gamma,
                      initial_alpha=initial_alpha, negative_sample_rate=negative_sample_rate, seed=seed)
     return y.cpu().numpy()
 

@@ -104,3 +104,20 @@ def test_umap_separates_planted_clusters():
     nb = NearestNeighbors(n_neighbors=11).fit(y).kneighbors(y, return_distance=False)[:, 1:]
     purity = (lab[nb] == lab[:, None]).mean()
     assert purity > 0.97
+
+
+@pytest.mark.parametrize("n_epochs", [5, 200, 500])
+def test_device_pruning_equals_host_pruning(pbmc68k, n_epochs):
+    import torch
+
+    from scanpy_amd.tools import _umap
+
+    g = pbmc68k["connectivities"].astype(np.float32).tocsr()
+    csr, eps = _umap._prune_and_schedule(g, n_epochs)
+    dev = torch.device("cuda")
+    ip, ix, w, eps_d = _umap.prune_and_schedule_device(torch.from_numpy(g.indptr.astype(np.int64)).to(dev),
+                                                       torch.from_numpy(g.indices.astype(np.int32)).to(dev),
+                                                       torch.from_numpy(g.data).to(dev), g.shape[0], n_epochs)
+    assert np.array_equal(ip.cpu().numpy(), csr.indptr) and np.array_equal(ix.cpu().numpy(), csr.indices)
+    np.testing.assert_allclose(eps_d.cpu().numpy(), eps, rtol=1e-6)
+    np.testing.assert_array_equal(w.cpu().numpy(), csr.data)
