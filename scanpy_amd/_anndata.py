@@ -53,6 +53,11 @@ class AnnData:
         sub = self[:, np.asarray(index)]
         self.X, self.var, self.varm, self.layers = sub.X, sub.var.copy(), sub.varm, sub.layers
 
+    def _inplace_subset_obs(self, index) -> None:
+        """anndata's `AnnData._inplace_subset_obs` (used by `filter_cells`)."""
+        sub = self[np.asarray(index)]
+        self.X, self.obs, self.obsm, self.layers, self.obsp = sub.X, sub.obs.copy(), sub.obsm, sub.layers, sub.obsp
+
     def copy(self) -> "AnnData":
         return AnnData(
             None if self.X is None else self.X.copy(),

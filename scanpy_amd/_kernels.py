@@ -198,6 +198,14 @@ def pp_row_sums(indptr, indices, data, n: int, col_skip: torch.Tensor | None = N
     return out
 
 
+def pp_row_count_positive(indptr, data, n: int) -> torch.Tensor:
+    dev = require_gpu()
+    out = torch.empty(n, dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().scamd_pp_row_count_positive_f32(ptr(indptr), ptr(data), n, data.numel(), ptr(out), stream_ptr()),
+               "scamd_pp_row_count_positive_f32")
+    return out
+
+
 def pp_count_high(indptr, indices, data, n: int, g: int, row_total: torch.Tensor, max_fraction: float) -> torch.Tensor:
     dev = require_gpu()
     counts = torch.empty(g, dtype=torch.int32, device=dev)

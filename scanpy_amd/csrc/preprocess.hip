@@ -58,6 +58,22 @@ __global__ __launch_bounds__(PP_BLOCK) void pp_row_sums_kernel(const int64_t* __
   }
 }
 
+// out[r] = number of stored entries of row r that are > 0  (`data > 0` summed along axis 1, filter_cells(min_genes=))
+template <int G>
+__global__ __launch_bounds__(PP_BLOCK) void pp_row_npos_kernel(const int64_t* __restrict__ indptr,
+                                                               const float* __restrict__ data, int64_t n,
+                                                               int32_t* __restrict__ out) {
+  PP_ROW_LOOP(G) {
+    const int64_t e = indptr[r + 1];
+    int c = 0;
+#pragma unroll 4
+    for (int64_t p = indptr[r] + sub; p < e; p += G) c += data[p] > 0.f ? 1 : 0;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (sub == 0) out[r] = c;
+  }
+}
+
 // col_counts[c] += number of entries of column c with value > max_fraction * row_total[row]
 template <int G>
 __global__ __launch_bounds__(PP_BLOCK) void pp_count_high_kernel(const int64_t* __restrict__ indptr,
@@ -277,6 +293,15 @@ extern "C" int scamd_pp_row_sums_f32(const int64_t* indptr, const int32_t* indic
   SCAMD_REQUIRE(!col_skip || indices, SCAMD_EINVAL, "pp_row_sums: col_skip needs indices");
   if (n == 0) return SCAMD_OK;
   PP_DISPATCH_G(lanes_per_row(indptr, n, nnz), pp_row_sums_kernel, indptr, indices, data, n, col_skip, out);
+  SCAMD_LAUNCH_CHECK();
+  return SCAMD_OK;
+}
+
+extern "C" int scamd_pp_row_count_positive_f32(const int64_t* indptr, const float* data, int64_t n, int64_t nnz,
+                                               int32_t* out, scamd_stream_t stream) {
+  SCAMD_REQUIRE(indptr && n >= 0 && nnz >= 0 && (n == 0 || out), SCAMD_EINVAL, "pp_row_count_positive: bad argument");
+  if (n == 0) return SCAMD_OK;
+  PP_DISPATCH_G(lanes_per_row(indptr, n, nnz), pp_row_npos_kernel, indptr, data, n, out);
   SCAMD_LAUNCH_CHECK();
   return SCAMD_OK;
 }

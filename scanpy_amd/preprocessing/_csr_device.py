@@ -84,6 +84,9 @@ class GpuPPBackend:
         skip = None if col_skip is None else torch.from_numpy(np.ascontiguousarray(col_skip, dtype=np.int32)).to(self.device)
         return self.K.pp_row_sums(m.indptr, m.indices, m.data, m.n_major, skip).cpu().numpy()
 
+    def row_count_positive(self, m: DeviceMatrix) -> np.ndarray:
+        return self.K.pp_row_count_positive(m.indptr, m.data, m.n_major).cpu().numpy().astype(np.int64)
+
     def count_high(self, m: DeviceMatrix, row_total: np.ndarray, max_fraction: float) -> np.ndarray:
         import torch
 

@@ -97,6 +97,10 @@ class CpuStubPPBackend:
         n = len(m.indptr) - 1
         return np.bincount(m.rows[keep], weights=m.data[keep].astype(np.float64), minlength=n).astype(np.float32)
 
+    def row_count_positive(self, m):
+        n = len(m.indptr) - 1
+        return np.bincount(m.rows[m.data > 0], minlength=n).astype(np.int64)
+
     def count_high(self, m, row_total, max_fraction):
         hi = m.data > np.float32(max_fraction) * row_total.astype(np.float32)[m.rows]
         return np.bincount(m.indices[hi], minlength=m.shape[1]).astype(np.int32)

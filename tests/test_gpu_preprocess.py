@@ -121,3 +121,8 @@ def test_empty_matrix_and_bad_arguments():
     assert float(s.abs().sum()) == 0 and int(npos.sum()) == 0
     with pytest.raises(_lib.ScamdError, match="base"):
         K.pp_log1p_(torch.ones(4, dtype=torch.float32, device=dev), base=1.0)
+
+
+@pytest.mark.parametrize("typ", TYPES, ids=lambda t: t.__name__)
+def test_filters(typ):
+    host.check_filters(typ)

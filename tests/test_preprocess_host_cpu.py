@@ -215,3 +215,44 @@ def test_hvg_errors_and_subset(pbmc68k):
     assert adata.shape == (700, 50) and adata.var["highly_variable"].all()
     with pytest.raises(NotImplementedError, match="float32"):
         sc.pp.log1p(np.ones((3, 3), dtype=np.float64))
+
+
+def check_filters(typ):
+    """src/scanpy/preprocessing/_simple.py:51-307 semantics against plain numpy"""
+    rng = np.random.default_rng(3)
+    dense = rng.poisson(0.4, size=(300, 40)).astype(np.float32)
+    dense[7] = 0
+    dense[:, 5] = 0
+    for kw, number, keep in (
+        (dict(min_counts=10), dense.sum(axis=1), dense.sum(axis=1) >= 10),
+        (dict(max_counts=20), dense.sum(axis=1), dense.sum(axis=1) <= 20),
+        (dict(min_genes=8), (dense > 0).sum(axis=1), (dense > 0).sum(axis=1) >= 8),
+        (dict(max_genes=15), (dense > 0).sum(axis=1), (dense > 0).sum(axis=1) <= 15),
+    ):
+        subset, num = sc.pp.filter_cells(typ(dense), **kw)
+        assert np.array_equal(subset, keep) and np.allclose(num, number)
+        adata = sc.AnnData(typ(dense))
+        sc.pp.filter_cells(adata, **kw)
+        key = "n_counts" if "counts" in next(iter(kw)) else "n_genes"
+        assert adata.n_obs == int(keep.sum()) and np.allclose(adata.obs[key], number[keep])
+        assert np.allclose(_dense(adata.X), dense[keep])
+    for kw, number, keep in (
+        (dict(min_counts=100), dense.sum(axis=0), dense.sum(axis=0) >= 100),
+        (dict(min_cells=90), (dense > 0).sum(axis=0), (dense > 0).sum(axis=0) >= 90),
+        (dict(max_cells=110), (dense > 0).sum(axis=0), (dense > 0).sum(axis=0) <= 110),
+    ):
+        subset, num = sc.pp.filter_genes(typ(dense), **kw)
+        assert np.array_equal(subset, keep) and np.allclose(num, number)
+        adata = sc.AnnData(typ(dense))
+        sc.pp.filter_genes(adata, **kw)
+        key = "n_counts" if "counts" in next(iter(kw)) else "n_cells"
+        assert adata.n_vars == int(keep.sum()) and np.allclose(adata.var[key], number[keep])
+    with pytest.raises(ValueError, match="exactly one"):
+        sc.pp.filter_cells(typ(dense), min_counts=1, min_genes=1)
+    with pytest.raises(ValueError, match="exactly one"):
+        sc.pp.filter_genes(typ(dense))
+
+
+@pytest.mark.parametrize("typ", TYPES, ids=lambda t: t.__name__)
+def test_filters(typ):
+    check_filters(typ)
