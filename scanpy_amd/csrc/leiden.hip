@@ -974,8 +974,8 @@ __global__ __launch_bounds__(256) void ld_agg_wave_kernel(
 
 // one workgroup per listed coarse node.  SLOTS-entry LDS table; when the node may have more distinct neighbours
 // than pass_keys the keys are split into hash classes and the members' rows are swept once per class.
-template <int SLOTS>
-__global__ __launch_bounds__(256) void ld_agg_block_kernel(
+template <int SLOTS, int THREADS>
+__global__ __launch_bounds__(THREADS) void ld_agg_block_kernel(
     const int* __restrict__ list, const int* __restrict__ list_len, int nn, const int64_t* __restrict__ moff,
     const int64_t* __restrict__ eoff, const int* __restrict__ members, const int64_t* __restrict__ indptr,
     const int* __restrict__ indices, const long long* __restrict__ wq, const int* __restrict__ cid,
@@ -1001,12 +1001,12 @@ __global__ __launch_bounds__(256) void ld_agg_block_kernel(
     }
     if (threadIdx.x == 0) sh_cnt = 0;
     for (unsigned int pass = 0; pass < n_pass; ++pass) {
-      for (int i = threadIdx.x; i < nslots; i += 256) {
+      for (int i = threadIdx.x; i < nslots; i += THREADS) {
         keys[i] = WH_EMPTY;
         vals[i] = 0ull;
       }
       __syncthreads();
-      for (int64_t i = m0 + wv; i < m1; i += 4) {
+      for (int64_t i = m0 + wv; i < m1; i += THREADS / 64) {
         const int v = members[i];
         for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) {
           const int key = cid[indices[e]];
@@ -1028,9 +1028,9 @@ __global__ __launch_bounds__(256) void ld_agg_block_kernel(
         }
       }
       __syncthreads();
-      for (int s0 = 0; s0 < nslots; s0 += 256) {
+      for (int s0 = 0; s0 < nslots; s0 += THREADS) {
         const int sl = s0 + threadIdx.x;
-        const int key = keys[sl];
+        const int key = sl < nslots ? keys[sl] : WH_EMPTY;  // the table in use may be shorter than the workgroup
         const bool has = key != WH_EMPTY;
         const unsigned long long m = __ballot(has);
         int wbase = 0;
@@ -1510,11 +1510,12 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
                      b.cid, b.agg_col, b.agg_w, b.rowcnt, b.mid_list, b.big_list, b.counters, cx.agg_wave_max,
                      cx.agg_mid_max);
   SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL((ld_agg_block_kernel<AGG_MID_SLOTS>), dim3(768), dim3(256), (size_t)AGG_MID_SLOTS * 12, cx.s,
+  // workgroup tiers: 512 threads on the 48 KB tables (3 per CU), 1024 threads on the 96 KB table (1 per CU)
+  hipLaunchKernelGGL((ld_agg_block_kernel<AGG_MID_SLOTS, 512>), dim3(768), dim3(512), (size_t)AGG_MID_SLOTS * 12, cx.s,
                      b.mid_list, b.counters + 4, inn, b.moff, b.eoff, b.members, g.indptr, g.indices, g.wq, b.cid,
                      b.agg_col, b.agg_w, b.rowcnt, b.counters + 7, AGG_MID_MAX);
   SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL((ld_agg_block_kernel<BHUB_SLOTS>), dim3(HUB_GRID), dim3(256), HUB_LDS, cx.s, b.big_list,
+  hipLaunchKernelGGL((ld_agg_block_kernel<BHUB_SLOTS, 1024>), dim3(HUB_GRID), dim3(1024), HUB_LDS, cx.s, b.big_list,
                      b.counters + 5, inn, b.moff, b.eoff, b.members, g.indptr, g.indices, g.wq, b.cid, b.agg_col,
                      b.agg_w, b.rowcnt, b.counters + 7, cx.agg_pass_keys);
   SCAMD_LAUNCH_CHECK();
