@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void ld_move_kernel(
     if (deg <= GMAX) {
       int* keys = hkeys[grp];
       unsigned long long* vals = hvals[grp];
-      const int nslots = (G < 64 || deg <= 96) ? 128 : (deg <= 192 ? 256 : 512);
+      const int nslots = G < 64 ? (deg <= 48 ? 64 : 128) : (deg <= 96 ? 128 : (deg <= 192 ? 256 : 512));
       for (int i = sub; i < nslots; i += G) {
         keys[i] = WH_EMPTY;
         vals[i] = 0ull;
@@ -622,108 +622,145 @@ __device__ __forceinline__ bool mover_bit(int v, int round, unsigned int seed) {
   return (hash32((unsigned int)v * 0x9E3779B1u + (unsigned int)round * 0x85EBCA77u + seed) >> 7) & 1u;
 }
 
-// One wave per candidate.  target[v] = refined community to join, -1 = none this round (stay a
-// candidate), -2 = no longer a singleton (somebody joined it): drop from the candidate list.
+// G lanes per candidate (see ld_move_kernel: G = 16 puts four candidates in a wave on short-rowed levels, rows longer
+// than the 128-slot table go to ovf_list / counters[5] and are proposed by the G = 64 instantiation in indirect mode).
+// target[v] = refined community to join, -1 = none this round (stay a candidate), -2 = no longer a singleton
+// (somebody joined it): drop from the candidate list.
+template <int G>
 __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
-    int n_cand, const int* __restrict__ list, const int64_t* __restrict__ indptr, const int* __restrict__ indices,
-    const long long* __restrict__ wq, const long long* __restrict__ k, const int* __restrict__ comm,
-    const unsigned long long* __restrict__ Ktot, const int* __restrict__ ref, const int* __restrict__ refsize,
-    const unsigned long long* __restrict__ Kref, const unsigned long long* __restrict__ Eref, double g, int round,
-    unsigned int seed, int* __restrict__ target, int* __restrict__ hub_list, int* __restrict__ counters,
+    const int* __restrict__ list, const int* __restrict__ sub_list, const int* __restrict__ sub_count,
+    const int64_t* __restrict__ indptr, const int* __restrict__ indices, const long long* __restrict__ wq,
+    const long long* __restrict__ k, const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot,
+    const int* __restrict__ ref, const int* __restrict__ refsize, const unsigned long long* __restrict__ Kref,
+    const unsigned long long* __restrict__ Eref, double g, int round, unsigned int seed, int* __restrict__ target,
+    int* __restrict__ ovf_list, int* __restrict__ hub_list, int* __restrict__ counters,
     const int* __restrict__ n_cand_dev, const int* __restrict__ stop) {
-  const int lane = threadIdx.x & 63;
+  constexpr int GROUPS = 256 / G;
+  constexpr int GSLOTS = WH_SLOTS * G / 64;
+  constexpr int GMAX = GSLOTS * 3 / 4;
+  __shared__ int hkeys[GROUPS][GSLOTS];
+  __shared__ unsigned long long hvals[GROUPS][GSLOTS];
+  const int sub = threadIdx.x % G;
+  const int grp = threadIdx.x / G;
   if (*stop) return;
-  n_cand = *n_cand_dev;  // list length of this round, produced on the device by the previous round
-  for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n_cand; w += gridDim.x * 4) {
-  const int v = list[w];
-  int tgt = -1;
-  if (refsize[v] != 1 || ref[v] != v) {
-    tgt = -2;
-  } else if (mover_bit(v, round, seed)) {
-    const double kv = (double)k[v];
-    const int a = comm[v];
-    const double KC = (double)(long long)Ktot[a];
-    const int64_t beg = indptr[v];
-    const int deg = (int)(indptr[v + 1] - beg);
-    if (deg > WH_MAX_DEG && deg <= BHUB_MAX_DEG) {  // hub: proposed by ld_refine_propose_hub_kernel
-      if (lane == 0) hub_list[atomicAdd(&counters[4], 1)] = v;
-      continue;
-    }
-    Cand best;
-    best.val = 0.0;
-    best.c = -1;
-    best.pr = 0;
-    if (deg <= WH_MAX_DEG) {
-      __shared__ int hkeys[4][WH_SLOTS];
-      __shared__ unsigned long long hvals[4][WH_SLOTS];
-      WaveHash wh{hkeys[threadIdx.x >> 6], hvals[threadIdx.x >> 6], WH_SLOTS};
-      wh.size_for(deg);
-      wh.clear(lane);
-      for (int e = lane; e < deg; e += 64) {
-        const int u = indices[beg + e];
-        if (u != v && comm[u] == a) wh.add(ref[u], wq[beg + e]);
+  // list length of this round, produced on the device by the previous round (or the overflow count of this one)
+  const int n_items = sub_list ? *sub_count : *n_cand_dev;
+  for (int item = blockIdx.x * GROUPS + grp; item < n_items; item += gridDim.x * GROUPS) {
+    const int w = sub_list ? sub_list[item] : item;
+    const int v = list[w];
+    int tgt = -1;
+    if (refsize[v] != 1 || ref[v] != v) {
+      tgt = -2;
+    } else if (mover_bit(v, round, seed)) {
+      const double kv = (double)k[v];
+      const int a = comm[v];
+      const double KC = (double)(long long)Ktot[a];
+      const int64_t beg = indptr[v];
+      const int deg = (int)(indptr[v + 1] - beg);
+      if (G < 64) {
+        if (deg > GMAX) {  // proposed by the wave-per-candidate instantiation
+          if (sub == 0) ovf_list[atomicAdd(&counters[5], 1)] = w;
+          continue;
+        }
+      } else if (deg > WH_MAX_DEG && deg <= BHUB_MAX_DEG) {  // hub: proposed by ld_refine_propose_hub_kernel
+        if (sub == 0) hub_list[atomicAdd(&counters[4], 1)] = v;
+        continue;
       }
-      for (int sl = lane; sl < wh.nslots; sl += 64) {
-        const int c = wh.key(sl);
-        if (c != WH_EMPTY && c != v) {
-          const long long sum = wh.val(sl);
-          const double Kr = (double)(long long)Kref[c];
-          const bool single = refsize[c] == 1;
-          const bool ok_target = (!single || !mover_bit(c, round, seed)) &&
-                                 ((double)(long long)Eref[c] >= g * Kr * (KC - Kr));  // target well connected
-          const double gain = (double)sum - g * kv * Kr;
-          if (ok_target && gain >= 0.0) {
-            Cand x;
-            x.val = gain;
-            x.c = c;
-            x.pr = prio(c, seed);
-            if (cand_better(x, best)) best = x;
+      Cand best;
+      best.val = 0.0;
+      best.c = -1;
+      best.pr = 0;
+      if (deg <= GMAX) {
+        int* keys = hkeys[grp];
+        unsigned long long* vals = hvals[grp];
+        const int nslots = G < 64 ? (deg <= 48 ? 64 : 128) : (deg <= 96 ? 128 : (deg <= 192 ? 256 : 512));
+        for (int i = sub; i < nslots; i += G) {
+          keys[i] = WH_EMPTY;
+          vals[i] = 0ull;
+        }
+        for (int e = sub; e < deg; e += G) {
+          const int u = indices[beg + e];
+          if (u != v && comm[u] == a) {
+            const int c = ref[u];
+            unsigned int slot = hash32((unsigned int)c) & (nslots - 1);
+            for (;;) {
+              const int prev = atomicCAS(&keys[slot], WH_EMPTY, c);
+              if (prev == WH_EMPTY || prev == c) break;
+              slot = (slot + 1) & (nslots - 1);
+            }
+            atomicAdd(&vals[slot], (unsigned long long)wq[beg + e]);
+          }
+        }
+        for (int sl = sub; sl < nslots; sl += G) {
+          const int c = __hip_atomic_load(&keys[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (c != WH_EMPTY && c != v) {
+            const long long sum = (long long)__hip_atomic_load(&vals[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const double Kr = (double)(long long)Kref[c];
+            const bool single = refsize[c] == 1;
+            const bool ok_target = (!single || !mover_bit(c, round, seed)) &&
+                                   ((double)(long long)Eref[c] >= g * Kr * (KC - Kr));  // target well connected
+            const double gain = (double)sum - g * kv * Kr;
+            if (ok_target && gain >= 0.0) {
+              Cand x;
+              x.val = gain;
+              x.c = c;
+              x.pr = prio(c, seed);
+              if (cand_better(x, best)) best = x;
+            }
+          }
+        }
+      } else if (G == 64) {
+        const int lane = sub;
+        for (int cb = 0; cb < deg; cb += 64) {
+          const int e = cb + lane;
+          int u = (e < deg) ? indices[beg + e] : -1;
+          const int c = (u >= 0 && u != v && comm[u] == a) ? ref[u] : -1;
+          long long sum = 0;
+          for (int db = 0; db < deg; db += 64) {
+            const int e2 = db + lane;
+            int c2 = -1;
+            long long w2 = 0;
+            if (e2 < deg) {
+              const int u2 = indices[beg + e2];
+              if (u2 != v && comm[u2] == a) {
+                c2 = (db == cb) ? c : ref[u2];
+                w2 = wq[beg + e2];
+              }
+            }
+            const int cnt = min(64, deg - db);
+            for (int t = 0; t < cnt; ++t) {
+              const int ct = __builtin_amdgcn_readlane(c2, t);
+              const long long wt = readlane_i64(w2, t);
+              if (ct == c) sum += wt;
+            }
+          }
+          if (c >= 0 && c != v) {
+            const double Kr = (double)(long long)Kref[c];
+            const bool single = refsize[c] == 1;
+            const bool ok_target = (!single || !mover_bit(c, round, seed)) &&
+                                   ((double)(long long)Eref[c] >= g * Kr * (KC - Kr));  // target well connected
+            const double gain = (double)sum - g * kv * Kr;
+            if (ok_target && gain >= 0.0) {
+              Cand x;
+              x.val = gain;
+              x.c = c;
+              x.pr = prio(c, seed);
+              if (cand_better(x, best)) best = x;
+            }
           }
         }
       }
-    } else
-    for (int cb = 0; cb < deg; cb += 64) {
-      const int e = cb + lane;
-      int u = (e < deg) ? indices[beg + e] : -1;
-      const int c = (u >= 0 && u != v && comm[u] == a) ? ref[u] : -1;
-      long long sum = 0;
-      for (int db = 0; db < deg; db += 64) {
-        const int e2 = db + lane;
-        int c2 = -1;
-        long long w2 = 0;
-        if (e2 < deg) {
-          const int u2 = indices[beg + e2];
-          if (u2 != v && comm[u2] == a) {
-            c2 = (db == cb) ? c : ref[u2];
-            w2 = wq[beg + e2];
-          }
-        }
-        const int cnt = min(64, deg - db);
-        for (int t = 0; t < cnt; ++t) {
-          const int ct = __builtin_amdgcn_readlane(c2, t);
-          const long long wt = readlane_i64(w2, t);
-          if (ct == c) sum += wt;
-        }
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) {
+        Cand y;
+        y.val = __shfl_xor(best.val, o);
+        y.c = __shfl_xor(best.c, o);
+        y.pr = (unsigned int)__shfl_xor((int)best.pr, o);
+        if (cand_better(y, best)) best = y;
       }
-      if (c >= 0 && c != v) {
-        const double Kr = (double)(long long)Kref[c];
-        const bool single = refsize[c] == 1;
-        const bool ok_target = (!single || !mover_bit(c, round, seed)) &&
-                               ((double)(long long)Eref[c] >= g * Kr * (KC - Kr));  // target well connected
-        const double gain = (double)sum - g * kv * Kr;
-        if (ok_target && gain >= 0.0) {
-          Cand x;
-          x.val = gain;
-          x.c = c;
-          x.pr = prio(c, seed);
-          if (cand_better(x, best)) best = x;
-        }
-      }
+      tgt = best.c;
     }
-    best = wave_best(best);
-    tgt = best.c;
-  }
-  if (lane == 0) target[v] = tgt;
+    if (sub == 0) target[v] = tgt;
   }
 }
 
@@ -1421,6 +1458,7 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
   int rc = read_counters(cx, h, 4);
   if (rc != SCAMD_OK) return rc;
   *n_merged = 0;
+  const bool quad = level_is_short_rowed(g);
   // Rounds run in batches of RF_BATCH without a host round trip: list lengths, merge counts and the stop rule
   // live on the device (one 8-int counter block per round + ld_refine_ctl_kernel); the host only sizes the grids
   // from the last list length it has seen (lengths never grow) and looks at the stop flag between batches.
@@ -1435,13 +1473,28 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
     const int first = round;
     const unsigned wgrid = (unsigned)std::min(32768, ceil_div(ub, 4));
     const unsigned tgrid = (unsigned)std::min(32768, ceil_div(ub, 256));
+    const unsigned qgrid = (unsigned)std::min(32768, ceil_div(ub, 16));
     int* rcnt = nullptr;
     for (int i = 0; i < batch; ++i, ++round) {
       rcnt = b.rcounters + 8 * round;
-      hipLaunchKernelGGL(ld_refine_propose_kernel, dim3(wgrid), dim3(256), 0, cx.s, ub, b.list_a, g.indptr, g.indices,
-                         g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, gg, round, cx.seed, b.target,
-                         b.hub_list, rcnt, n_in, (const int*)ctl);
-      SCAMD_LAUNCH_CHECK();
+      if (quad) {
+        hipLaunchKernelGGL(ld_refine_propose_kernel<16>, dim3(qgrid), dim3(256), 0, cx.s, b.list_a, (const int*)nullptr,
+                           (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref,
+                           b.Eref, gg, round, cx.seed, b.target, b.mid_list, b.hub_list, rcnt, n_in, (const int*)ctl);
+        SCAMD_LAUNCH_CHECK();
+        if (g.max_deg > QUAD_MAX_DEG) {
+          hipLaunchKernelGGL(ld_refine_propose_kernel<64>, dim3(std::min(wgrid, 2048u)), dim3(256), 0, cx.s, b.list_a,
+                             (const int*)b.mid_list, (const int*)(rcnt + 5), g.indptr, g.indices, g.wq, g.k, b.comm,
+                             b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, gg, round, cx.seed, b.target, b.mid_list,
+                             b.hub_list, rcnt, n_in, (const int*)ctl);
+          SCAMD_LAUNCH_CHECK();
+        }
+      } else {
+        hipLaunchKernelGGL(ld_refine_propose_kernel<64>, dim3(wgrid), dim3(256), 0, cx.s, b.list_a, (const int*)nullptr,
+                           (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref,
+                           b.Eref, gg, round, cx.seed, b.target, b.mid_list, b.hub_list, rcnt, n_in, (const int*)ctl);
+        SCAMD_LAUNCH_CHECK();
+      }
       if (g.max_deg > WH_MAX_DEG) {
         hipLaunchKernelGGL(ld_refine_propose_hub_kernel, dim3(HUB_GRID), dim3(256), HUB_LDS, cx.s, b.hub_list, rcnt,
                            g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, gg, round,
