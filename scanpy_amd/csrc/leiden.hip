@@ -561,22 +561,23 @@ __global__ __launch_bounds__(1024) void ld_compact_kernel(int n, int* __restrict
 
 // ---- phase 2: refinement ---------------------------------------------------------------------------
 // a_in[v] = w(v, C(v) - v): weight from v to the rest of its (phase-1) community
+template <int G>
 __global__ __launch_bounds__(256) void ld_within_kernel(int n, const int64_t* __restrict__ indptr,
                                                         const int* __restrict__ indices,
                                                         const long long* __restrict__ wq, const int* __restrict__ comm,
                                                         long long* __restrict__ a_in) {
-  const int lane = threadIdx.x & 63;
-  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int sub = threadIdx.x % G;
+  const int v = blockIdx.x * (256 / G) + threadIdx.x / G;
   if (v >= n) return;
   const int a = comm[v];
   long long s = 0;
-  for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) {
+  for (int64_t e = indptr[v] + sub; e < indptr[v + 1]; e += G) {
     const int u = indices[e];
     if (u != v && comm[u] == a) s += wq[e];
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if (lane == 0) a_in[v] = s;
+  for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (sub == 0) a_in[v] = s;
 }
 
 // candidates of the refinement: vertices that are well connected inside their community
@@ -597,24 +598,25 @@ __global__ void ld_refine_candidates_kernel(int n, const long long* __restrict__
 //   Eref[t] += w(v, C - v) - 2 w(v, t_old) - w(v, J)
 // (summed over the joiners every {v, v'} in J x J pair is subtracted twice, as the cut of the union requires).
 // One wave per joiner; all integer, so the result equals a from-scratch recomputation bit for bit.
+template <int G>
 __global__ __launch_bounds__(256) void ld_refine_cut_update_kernel(
     int n_join, const int* __restrict__ jlist, const int64_t* __restrict__ indptr, const int* __restrict__ indices,
     const long long* __restrict__ wq, const int* __restrict__ comm, const int* __restrict__ ref,
     const int* __restrict__ stamp, const long long* __restrict__ a_in, int round,
     unsigned long long* __restrict__ Eref, const int* __restrict__ n_join_dev) {
-  const int lane = threadIdx.x & 63;
+  const int sub = threadIdx.x % G;
   n_join = *n_join_dev;
-  for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n_join; w += gridDim.x * 4) {
+  for (int w = blockIdx.x * (256 / G) + threadIdx.x / G; w < n_join; w += gridDim.x * (256 / G)) {
   const int v = jlist[w];
   const int a = comm[v], t = ref[v];
   long long s = 0;
-  for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) {
+  for (int64_t e = indptr[v] + sub; e < indptr[v + 1]; e += G) {
     const int u = indices[e];
     if (u != v && comm[u] == a && ref[u] == t) s += (stamp[u] == round) ? wq[e] : 2 * wq[e];
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if (lane == 0) atomicAdd(&Eref[t], (unsigned long long)(a_in[v] - s));
+  for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (sub == 0) atomicAdd(&Eref[t], (unsigned long long)(a_in[v] - s));
   }
 }
 
@@ -1445,7 +1447,11 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
   LeidenBuffers& b = cx.b;
   const double gg = cx.gamma / cx.m2;
   const size_t n = (size_t)g.n;
-  hipLaunchKernelGGL(ld_within_kernel, GRIDW(g.n), 0, cx.s, g.n, g.indptr, g.indices, g.wq, b.comm, b.a_in);
+  if (level_is_short_rowed(g))
+    hipLaunchKernelGGL(ld_within_kernel<16>, dim3((unsigned)ceil_div(g.n, 16)), dim3(256), 0, cx.s, g.n, g.indptr,
+                       g.indices, g.wq, b.comm, b.a_in);
+  else
+    hipLaunchKernelGGL(ld_within_kernel<64>, GRIDW(g.n), 0, cx.s, g.n, g.indptr, g.indices, g.wq, b.comm, b.a_in);
   SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(ld_refine_init_kernel, GRID1(g.n), 0, cx.s, g.n, g.k, b.a_in, b.ref, b.refsize, b.Kref, b.Eref);
   SCAMD_LAUNCH_CHECK();
@@ -1504,8 +1510,15 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
       hipLaunchKernelGGL(ld_refine_apply_kernel, dim3(tgrid), dim3(256), 0, cx.s, ub, b.list_a, b.target, g.k, b.ref,
                          b.refsize, b.Kref, b.Eref, b.touched, round, b.rlist, b.list_b, rcnt, n_in, (const int*)ctl);
       SCAMD_LAUNCH_CHECK();
-      hipLaunchKernelGGL(ld_refine_cut_update_kernel, dim3(wgrid), dim3(256), 0, cx.s, ub, b.rlist, g.indptr, g.indices,
-                         g.wq, b.comm, b.ref, b.touched, b.a_in, round, b.Eref, (const int*)rcnt);
+      if (quad) {
+        hipLaunchKernelGGL(ld_refine_cut_update_kernel<16>, dim3(qgrid), dim3(256), 0, cx.s, ub, b.rlist, g.indptr, g.indices,
+                           g.wq, b.comm, b.ref, b.touched, b.a_in, round, b.Eref, (const int*)rcnt);
+        SCAMD_LAUNCH_CHECK();
+      } else {
+        hipLaunchKernelGGL(ld_refine_cut_update_kernel<64>, dim3(wgrid), dim3(256), 0, cx.s, ub, b.rlist, g.indptr, g.indices,
+                           g.wq, b.comm, b.ref, b.touched, b.a_in, round, b.Eref, (const int*)rcnt);
+        SCAMD_LAUNCH_CHECK();
+      }
       SCAMD_LAUNCH_CHECK();
       hipLaunchKernelGGL(ld_refine_ctl_kernel, dim3(1), dim3(1), 0, cx.s, (const int*)rcnt, ctl, g.n, cx.rf_stop_ppm);
       SCAMD_LAUNCH_CHECK();
