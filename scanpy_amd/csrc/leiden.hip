@@ -1249,12 +1249,6 @@ struct LeidenBuffers {
   unsigned long long* ckeys; int* cids; int* newlabel; int* minmember;
 };
 
-static unsigned long long next_pow2(unsigned long long x) {
-  unsigned long long p = 1;
-  while (p < x) p <<= 1;
-  return p;
-}
-
 static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b) {
   const size_t N = (size_t)n, E = (size_t)std::max<int64_t>(nnz, 1);
   b->wq0 = ws.take<long long>(E);
