@@ -126,3 +126,8 @@ def test_empty_matrix_and_bad_arguments():
 @pytest.mark.parametrize("typ", TYPES, ids=lambda t: t.__name__)
 def test_filters(typ):
     host.check_filters(typ)
+
+
+@pytest.mark.parametrize("typ", TYPES, ids=lambda t: t.__name__)
+def test_rep_mutation(typ):
+    host.check_rep_mutation(typ)

@@ -256,3 +256,54 @@ def check_filters(typ):
 @pytest.mark.parametrize("typ", TYPES, ids=lambda t: t.__name__)
 def test_filters(typ):
     check_filters(typ)
+
+
+def check_rep_mutation(typ):
+    """`layer=` / `obsm=` transform only the named array and give the same numbers as transforming X
+    (src/testing/scanpy/_helpers/__init__.py:35-63, used by tests/test_normalization.py:77-83 and the log1p / scale tests)"""
+    x = typ(sparse.random(100, 50, format="csr", density=0.2, dtype=np.float32, random_state=0))
+    funcs = (
+        (sc.pp.normalize_total, {}),
+        (sc.pp.log1p, {}),
+        (sc.pp.scale, dict(zero_center=False)),
+    )
+    for func, kw in funcs:
+        def make():
+            a = sc.AnnData(x.copy())
+            a.layers["layer"] = x.copy()
+            a.obsm["obsm"] = x.copy()
+            return a
+
+        with warnings_ignored():
+            out_x = make()
+            func(out_x, **kw)
+            per_field = {}
+            for field in ("layer", "obsm"):
+                a = make()
+                func(a, **{field: field}, **kw)
+                per_field[field] = a
+        for field, a in per_field.items():
+            got = a.layers["layer"] if field == "layer" else a.obsm["obsm"]
+            np.testing.assert_array_equal(_dense(out_x.X), _dense(got))  # same result as on X
+            np.testing.assert_array_equal(_dense(x), _dense(a.X))  # X untouched
+            other = a.obsm["obsm"] if field == "layer" else a.layers["layer"]
+            np.testing.assert_array_equal(_dense(x), _dense(other))  # the other representation untouched
+        np.testing.assert_array_equal(_dense(x), _dense(out_x.layers["layer"]))
+        np.testing.assert_array_equal(_dense(x), _dense(out_x.obsm["obsm"]))
+
+
+class warnings_ignored:
+    def __enter__(self):
+        import warnings
+
+        self._cm = warnings.catch_warnings()
+        self._cm.__enter__()
+        warnings.simplefilter("ignore")
+
+    def __exit__(self, *a):
+        return self._cm.__exit__(*a)
+
+
+@pytest.mark.parametrize("typ", TYPES, ids=lambda t: t.__name__)
+def test_rep_mutation(typ):
+    check_rep_mutation(typ)
