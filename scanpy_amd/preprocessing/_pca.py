@@ -11,6 +11,15 @@ from .._anndata import AnnData, is_anndata
 from .._settings import settings
 from .._utils import _UNSET, as_csr_f32, resolve_seed
 
+def torch_free_bytes() -> int:
+    """free HBM on the current device (0 when there is none: the CPU stand-in of the tests streams every pass)"""
+    import torch
+
+    if not torch.cuda.is_available():
+        return 0
+    return int(torch.cuda.mem_get_info()[0])
+
+
 _DEFAULT_MASK = object()  # Default("adata.var.get('highly_variable')"), _pca/__init__.py:65-67
 
 
@@ -68,14 +77,14 @@ def pca(  # noqa: PLR0912, PLR0913, PLR0915
     Differences from the reference are confined to HOW the decomposition is computed:
     `svd_solver` None/'arpack' -> block-Krylov solver converged to ARPACK-level accuracy,
     'randomized' -> randomized subspace iteration, 'covariance_eigh' -> exact covariance + eigh.
-    `chunked=True` (IncrementalPCA) is not offered on the GPU path.
+    `chunked=True` streams row chunks of `chunk_size` cells through the device; the result is exact (not
+    IncrementalPCA's approximation) and identical to the one-shot fit.
     """
     from ._pca_solver import GpuBackend, pca_fit
 
     seed, _meta = resolve_seed(rng, random_state)
-    if chunked:
-        msg = "chunked (incremental) PCA is not implemented on the MI355X path; the whole CSR fits in HBM."
-        raise NotImplementedError(msg)
+    if chunked and not zero_center:  # the reference's chunked path is IncrementalPCA: centred only (`:262-266`)
+        raise ValueError("chunked PCA centres the data: pass zero_center=True (the default) with chunked=True")
     if return_anndata := is_anndata(data):
         adata = data.copy() if copy else data
     else:
@@ -122,8 +131,26 @@ def pca(  # noqa: PLR0912, PLR0913, PLR0915
         raise ValueError(f"svd_solver={svd_solver!r} is not supported")
 
     backend = GpuBackend()
-    res = pca_fit(backend.upload(as_csr_f32(x)), n_comps, backend=backend, zero_center=zero_center,
-                  svd_solver=svd_solver, seed=seed)
+    if chunked:
+        # Rows are streamed through the device `chunk_size` at a time (the reference runs sklearn's IncrementalPCA over
+        # `adata.chunked_X(chunk_size)`, `_pca/__init__.py:262-285`, an approximation).  Here the fixed-point Gram
+        # matrix is additive over row chunks, so the chunked fit is EXACT and bitwise equal to the one-shot fit; HBM
+        # holds two chunks at a time unless everything fits, in which case the chunks stay resident between passes.
+        from ._pca_solver import _ChunkedRows
+
+        xc = as_csr_f32(x)
+        step = int(chunk_size) if chunk_size is not None else 1_000_000
+        if step < 1:
+            raise ValueError("chunk_size must be a positive number of observations")
+        import os
+
+        # SCAMD_PCA_CHUNK_RESIDENT=0 forces the streaming mode (every pass uploads again) whatever the free memory
+        budget = 0 if os.environ.get("SCAMD_PCA_CHUNK_RESIDENT") == "0" else int(0.4 * torch_free_bytes())
+        rows = _ChunkedRows([xc[i:i + step] for i in range(0, n_obs, step)], n_vars, resident_budget_bytes=budget)
+        res = pca_fit(rows, n_comps, backend=backend, zero_center=zero_center, svd_solver=svd_solver, seed=seed)
+    else:
+        res = pca_fit(backend.upload(as_csr_f32(x)), n_comps, backend=backend, zero_center=zero_center,
+                      svd_solver=svd_solver, seed=seed)
     x_pca = res.scores.cpu().numpy()
     in_dtype = x.dtype if np.issubdtype(x.dtype, np.floating) else np.dtype("float64")
     components = res.components.astype(in_dtype, copy=False)

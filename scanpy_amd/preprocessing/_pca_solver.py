@@ -90,6 +90,22 @@ class GpuBackend:
         dv = torch.from_numpy(np.ascontiguousarray(x_csr.data, dtype=np.float32)).to(self.device)
         return (ip, ix, dv, x_csr.shape[0], x_csr.shape[1])
 
+    def upload_prefetch(self, x_csr):
+        """`upload` on a side stream, so that the copy of the next row chunk overlaps the kernels of the current one;
+        `wait_prefetch` makes the compute stream wait for it (and ties the buffers' lifetime to the compute stream)."""
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._copy_stream):
+            h = self.upload(x_csr)
+        self._pending = h
+        return h
+
+    def wait_prefetch(self):
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_stream(self._copy_stream)
+        for t in self._pending[:3]:
+            t.record_stream(cur)
+
     def transpose(self, a):
         ip, ix, dv, n, g = a
         t_ip, t_ix, t_dv = self.K.csr_transpose(ip, ix, dv, n, g)
@@ -257,15 +273,65 @@ def _dense_topk_eigh(amat: torch.Tensor, k: int, rng: np.random.Generator, tol: 
     return theta[:k], v[:, :k]
 
 
+class _ChunkedRows:
+    """Row chunks of a host CSR matrix streamed through the device (`sc.pp.pca(..., chunked=True)`).
+
+    `handles(backend)` yields one device CSR handle per chunk, uploading chunk i + 1 on the backend's copy stream while
+    the kernels of chunk i run.  When the whole matrix fits the budget the handles are kept after the first pass
+    (`resident`), otherwise every pass uploads again: HBM holds two chunks at a time, whatever the matrix size."""
+
+    def __init__(self, host_chunks, n_cols: int, *, resident_budget_bytes: int = 0):
+        self._host = list(host_chunks)
+        self.n_chunks = len(self._host)
+        self.n_rows = int(sum(c.shape[0] for c in self._host))
+        self.n_cols = int(n_cols)
+        nbytes = sum(c.data.nbytes + c.indices.nbytes + 8 * (c.shape[0] + 1) for c in self._host)
+        self.resident = nbytes <= resident_budget_bytes
+        self._cached = None
+
+    @classmethod
+    def single(cls, handle):
+        self = cls.__new__(cls)
+        self._host, self.n_chunks, self.n_rows, self.n_cols = [], 1, handle[3], handle[4]
+        self.resident, self._cached = True, [handle]
+        return self
+
+    def handles(self, backend):
+        if self._cached is not None:
+            yield from self._cached
+            return
+        keep = [] if self.resident else None
+        upload = getattr(backend, "upload_prefetch", backend.upload)
+        nxt = upload(self._host[0])
+        for i in range(self.n_chunks):
+            cur = nxt
+            if hasattr(backend, "wait_prefetch"):
+                backend.wait_prefetch()
+            nxt = None
+            if keep is not None:
+                keep.append(cur)
+            yield cur  # the caller enqueues this chunk's kernels ...
+            if i + 1 < self.n_chunks:
+                nxt = upload(self._host[i + 1])  # ... and the next upload overlaps them
+        if keep is not None:
+            self._cached = keep
+
+
 def _pca_fit_gram(a, n_comps: int, backend, comm, zero_center: bool, seed: int, tol: float) -> "PCAResult | None":
     """Covariance route: exact fixed-point Gram matrix (one pass over the CSR, `scamd_csr_gram_f32`), all-reduced
     over the row shards as int64 (so the model is bitwise identical for any number of ranks), then a dense
     float64 eigen-solve.  Returns None when the route does not apply (too many genes / overflow risk)."""
-    n_local, g = a[3], a[4]
+    # `a` is one device CSR handle, or a _ChunkedRows (row chunks of a host matrix streamed through the device): the
+    # Gram matrix, the column sums and max|x| are additive / max-able over row chunks exactly as over row shards
+    chunks = a if isinstance(a, _ChunkedRows) else _ChunkedRows.single(a)
+    n_local, g = chunks.n_rows, chunks.n_cols
     if g > GRAM_MAX_GENES or not hasattr(backend, "gram"):
         return None
     dev = backend.device
-    meta = torch.tensor([float(n_local), backend.absmax(a)], dtype=torch.float64, device=dev)
+    absmax_local = 0.0
+    for h in chunks.handles(backend):
+        absmax_local = max(absmax_local, backend.absmax(h))
+    meta = torch.tensor([float(n_local), absmax_local], dtype=torch.float64, device=dev)
     nt = meta[:1].clone()
     mx = meta[1:].clone()
     comm.allreduce_(nt)
@@ -283,7 +349,10 @@ def _pca_fit_gram(a, n_comps: int, backend, comm, zero_center: bool, seed: int, 
     if scale_bits < 8:  # too little resolution left: the float64 Krylov route handles such data
         return None
     scale_bits = min(scale_bits, 40)
-    gq, cq = backend.gram(a, scale_bits)
+    gq = cq = None
+    for h in chunks.handles(backend):
+        gh, ch = backend.gram(h, scale_bits)
+        gq, cq = (gh, ch) if gq is None else (gq + gh, cq + ch)  # int64: exact, order independent
     comm.allreduce_(gq)
     comm.allreduce_(cq)
     inv = 2.0 ** -scale_bits
@@ -300,8 +369,12 @@ def _pca_fit_gram(a, n_comps: int, backend, comm, zero_center: bool, seed: int, 
     v = _sign_flip(v)
     vf = v.to(torch.float32).contiguous()
     shift = (mean @ vf.to(torch.float64)).to(torch.float32) if zero_center else None
-    scores = backend.spmm(a, vf, shift)
+    parts = [backend.spmm(h, vf, shift) for h in chunks.handles(backend)]
+    scores = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
     info["n_operator_applications"] = 1
+    if chunks.n_chunks > 1:
+        info["row_chunks"] = chunks.n_chunks
+        info["chunks_resident"] = chunks.resident
     if zero_center:
         ev = lam / (n - 1)
         total_var = var.sum() * n / (n - 1)
@@ -326,6 +399,13 @@ def pca_fit(a, n_comps: int, *, backend=None, comm=None, zero_center: bool = Tru
     """`a` = backend handle of this rank's CSR rows (from `backend.upload`)."""
     backend = backend or GpuBackend()
     comm = comm or NoComm()
+    if isinstance(a, _ChunkedRows):  # streamed row chunks: only the (additive) Gram route applies
+        res = _pca_fit_gram(a, n_comps, backend, comm, zero_center, seed, tol)
+        if res is None:
+            msg = (f"chunked PCA needs the Gram route: at most {GRAM_MAX_GENES} genes and values whose squares summed "
+                   "over the cells stay below 2^54")
+            raise NotImplementedError(msg)
+        return res
     n_local, g = a[3], a[4]
     if svd_solver in ("arpack", "auto", "covariance_eigh") and block_size is None:
         res = _pca_fit_gram(a, n_comps, backend, comm, zero_center, seed, tol)

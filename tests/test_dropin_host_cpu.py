@@ -100,3 +100,8 @@ def test_leiden_errors(sc, pbmc68k):
 
 def test_leiden_restrict_to_and_keys(sc, pbmc68k):
     gp.test_leiden_restrict_to_and_keys(sc, pbmc68k)
+
+
+@pytest.mark.parametrize("chunk_size", [333, 2000])
+def test_pca_chunked_equals_one_shot(sc, pbmc68k, chunk_size, monkeypatch):
+    gp.test_pca_chunked_equals_one_shot(sc, pbmc68k, chunk_size, "0", monkeypatch)

@@ -374,3 +374,20 @@ def test_neighbors_cosine_metric(sc, pbmc68k):
     assert abs(g - d).max() < 1e-12
     with pytest.raises(ValueError, match="all-zero"):
         sc.MI355XKNNTransformer(metric="cosine").fit_transform(np.zeros((50, 4), dtype=np.float32))
+
+
+@pytest.mark.parametrize("resident", ["1", "0"], ids=["resident", "streamed"])
+@pytest.mark.parametrize("chunk_size", [333, 2000])
+def test_pca_chunked_equals_one_shot(sc, pbmc68k, chunk_size, resident, monkeypatch):
+    """`chunked=True` streams row chunks through the device; the fixed-point Gram matrix is additive over chunks, so the
+    result is the one-shot result bit for bit (the reference's chunked path, IncrementalPCA, is an approximation)"""
+    monkeypatch.setenv("SCAMD_PCA_CHUNK_RESIDENT", resident)  # "0": every pass re-uploads, copies overlap the kernels
+    x = pbmc68k["counts"].astype(np.float32)
+    a1, a2 = sc.AnnData(x.copy()), sc.AnnData(x.copy())
+    sc.pp.pca(a1, n_comps=20)
+    sc.pp.pca(a2, n_comps=20, chunked=True, chunk_size=chunk_size)
+    np.testing.assert_array_equal(a1.varm["PCs"], a2.varm["PCs"])
+    np.testing.assert_array_equal(a1.obsm["X_pca"], a2.obsm["X_pca"])
+    np.testing.assert_array_equal(a1.uns["pca"]["variance"], a2.uns["pca"]["variance"])
+    with pytest.raises(ValueError, match="zero_center"):
+        sc.pp.pca(a2, n_comps=20, chunked=True, zero_center=False)

@@ -118,3 +118,22 @@ def test_dense_topk_flat_tail():
         np.testing.assert_allclose(got_l.numpy(), lam[:k], rtol=1e-10)
         err = np.abs(np.abs(got_v.numpy().T @ q[:, :k]) - np.eye(k)).max()
         assert err < 1e-6, (err, info)
+
+
+@pytest.mark.parametrize("chunk", [1, 97, 400, 5000])
+def test_chunked_rows_equal_one_shot(chunk):
+    """the fixed-point Gram matrix is additive over row chunks: the streamed fit IS the one-shot fit, bit for bit"""
+    from scanpy_amd.datasets import synthetic_planted
+    from scanpy_amd.preprocessing._pca_solver import _ChunkedRows
+
+    x, _ = synthetic_planted(1200, 150, n_types=6, seed=3)
+    be = CpuStubBackend()
+    one = pca_fit(be.upload(x), 10, backend=be)
+    rows = _ChunkedRows([x[i:i + chunk] for i in range(0, x.shape[0], chunk)], x.shape[1])
+    assert not rows.resident
+    many = pca_fit(rows, 10, backend=be)
+    np.testing.assert_array_equal(many.components, one.components)
+    np.testing.assert_array_equal(many.explained_variance, one.explained_variance)
+    np.testing.assert_array_equal(many.scores.numpy(), one.scores.numpy())
+    if chunk < 1200:
+        assert many.info["row_chunks"] == -(-1200 // chunk)
