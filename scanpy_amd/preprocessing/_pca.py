@@ -136,7 +136,7 @@ def pca(  # noqa: PLR0912, PLR0913, PLR0915
         # `adata.chunked_X(chunk_size)`, `_pca/__init__.py:262-285`, an approximation).  Here the fixed-point Gram
         # matrix is additive over row chunks, so the chunked fit is EXACT and bitwise equal to the one-shot fit; HBM
         # holds two chunks at a time unless everything fits, in which case the chunks stay resident between passes.
-        from ._pca_solver import _ChunkedRows
+        from ._pca_solver import CsrRowsView, _ChunkedRows
 
         xc = as_csr_f32(x)
         step = int(chunk_size) if chunk_size is not None else 1_000_000
@@ -146,7 +146,8 @@ def pca(  # noqa: PLR0912, PLR0913, PLR0915
 
         # SCAMD_PCA_CHUNK_RESIDENT=0 forces the streaming mode (every pass uploads again) whatever the free memory
         budget = 0 if os.environ.get("SCAMD_PCA_CHUNK_RESIDENT") == "0" else int(0.4 * torch_free_bytes())
-        rows = _ChunkedRows([xc[i:i + step] for i in range(0, n_obs, step)], n_vars, resident_budget_bytes=budget)
+        rows = _ChunkedRows([CsrRowsView(xc, i, min(i + step, n_obs)) for i in range(0, n_obs, step)], n_vars,
+                            resident_budget_bytes=budget)
         res = pca_fit(rows, n_comps, backend=backend, zero_center=zero_center, svd_solver=svd_solver, seed=seed)
     else:
         res = pca_fit(backend.upload(as_csr_f32(x)), n_comps, backend=backend, zero_center=zero_center,

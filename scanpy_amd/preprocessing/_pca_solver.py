@@ -273,6 +273,23 @@ def _dense_topk_eigh(amat: torch.Tensor, k: int, rng: np.random.Generator, tol: 
     return theta[:k], v[:, :k]
 
 
+class CsrRowsView:
+    """Rows [i0, i1) of a host CSR matrix WITHOUT copying its data / indices (scipy's row slicing copies, and its
+    constructor validates O(nnz): seconds per million cells).  Carries what `backend.upload` reads."""
+
+    def __init__(self, x_csr, i0: int, i1: int):
+        p0, p1 = int(x_csr.indptr[i0]), int(x_csr.indptr[i1])
+        self.indptr = x_csr.indptr[i0:i1 + 1] - x_csr.indptr[i0]
+        self.indices = x_csr.indices[p0:p1]
+        self.data = x_csr.data[p0:p1]
+        self.shape = (i1 - i0, x_csr.shape[1])
+
+    def to_scipy(self):
+        from scipy import sparse
+
+        return sparse.csr_matrix((self.data, self.indices, self.indptr), shape=self.shape)
+
+
 class _ChunkedRows:
     """Row chunks of a host CSR matrix streamed through the device (`sc.pp.pca(..., chunked=True)`).
 

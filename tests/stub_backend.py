@@ -15,6 +15,8 @@ class CpuStubBackend:
     device = torch.device("cpu")
 
     def upload(self, x_csr):
+        if hasattr(x_csr, "to_scipy"):  # CsrRowsView of the chunked PCA
+            x_csr = x_csr.to_scipy()
         x = sparse.csr_matrix(x_csr).astype(np.float32)
         x.sort_indices()
         return (x, None, None, x.shape[0], x.shape[1])
