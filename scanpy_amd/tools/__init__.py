@@ -1,4 +1,5 @@
 from ._leiden import leiden
+from ._leiden_multires import leiden_multires
 from ._umap import umap
 
-__all__ = ["leiden", "umap"]
+__all__ = ["leiden", "leiden_multires", "umap"]
