@@ -31,7 +31,8 @@ constexpr double WSCALE = 4294967296.0;  // 2^32
 constexpr int MAX_LM_ROUNDS = 128;
 constexpr int MAX_RF_ROUNDS = 48;
 constexpr int RF_QUIET_ROUNDS = 3;
-constexpr int RF_BATCH = 4;  // refinement rounds per host round trip
+constexpr int RF_BATCH = 4;      // refinement rounds per host round trip (default; SCAMD_LEIDEN_RF_BATCH overrides)
+constexpr int RF_BATCH_MAX = 16;
 constexpr int MAX_LEVELS = 64;
 constexpr int MAX_OUTER_ITERS = 32;
 
@@ -1320,6 +1321,7 @@ struct LeidenCtx {
   unsigned int seed;
   int lm_stop_permille = 10;  // local moving of a level stops once < 1 % of its vertices move in a round
   int rf_stop_ppm = 500;      // refinement stops once a round merges < 0.05 % of the level's vertices
+  int rf_batch = RF_BATCH;
   // coarse-row build tiers (distinct-neighbour bounds); the env overrides exist so the tests can push small graphs
   // through the workgroup and multi-pass tiers
   int agg_wave_max = WH_MAX_DEG;
@@ -1469,7 +1471,7 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
   int hctl[4] = {0, 0, 0, 0};
   int round = 0;
   while (round < MAX_RF_ROUNDS && ub > 0) {
-    const int batch = std::min(RF_BATCH, MAX_RF_ROUNDS - round);
+    const int batch = std::min(cx.rf_batch, MAX_RF_ROUNDS - round);
     const int first = round;
     const unsigned wgrid = (unsigned)std::min(32768, ceil_div(ub, 4));
     const unsigned tgrid = (unsigned)std::min(32768, ceil_div(ub, 256));
@@ -1519,7 +1521,7 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
       std::swap(b.list_a, b.list_b);
       n_in = rcnt + 2;
     }
-    int hr[8 * RF_BATCH];
+    int hr[8 * RF_BATCH_MAX];
     SCAMD_HIP_CHECK(hipMemcpyAsync(hctl, ctl, sizeof(int) * 4, hipMemcpyDeviceToHost, cx.s));
     SCAMD_HIP_CHECK(hipMemcpyAsync(hr, b.rcounters + 8 * first, sizeof(int) * 8 * batch, hipMemcpyDeviceToHost, cx.s));
     SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
@@ -1725,6 +1727,7 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
   cx.seed = (unsigned int)(seed ^ (seed >> 32)) * 0x9E3779B1u + 0x632BE5ABu;
   if (const char* e = getenv("SCAMD_LEIDEN_LM_STOP_PERMILLE")) cx.lm_stop_permille = atoi(e);
   if (const char* e = getenv("SCAMD_LEIDEN_RF_STOP_PPM")) cx.rf_stop_ppm = atoi(e);
+  if (const char* e = getenv("SCAMD_LEIDEN_RF_BATCH")) cx.rf_batch = std::max(1, std::min(atoi(e), (int)RF_BATCH_MAX));
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_WAVE_MAX")) cx.agg_wave_max = std::min(atoi(e), (int)WH_MAX_DEG);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_MAX")) cx.agg_mid_max = std::min(atoi(e), (int)AGG_MID_MAX);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_PASS_KEYS"))
