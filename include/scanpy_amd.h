@@ -95,6 +95,18 @@ int scamd_fuzzy_simplicial_set_f32(const int32_t* knn_idx, const float* knn_dist
                                    int64_t* out_indptr, int32_t* out_indices, float* out_data,
                                    int64_t cap, float* out_sigma, float* out_rho, int64_t* nnz_host,
                                    void* workspace, size_t workspace_bytes, scamd_stream_t stream);
+/* method='gauss' on the kNN pattern (src/scanpy/neighbors/_connectivity.py:21-100, CSR branch): sigma_i^2 = median of the
+ * squared distances to the row's neighbours, w_ij = sqrt(2 s_i s_j / (s_i^2 + s_j^2)) exp(-d_ij^2 / (s_i^2 + s_j^2)),
+ * w_ji := w_ij where i is not among j's neighbours.  Same in/out conventions and workspace size as the fuzzy set. */
+int scamd_gauss_connectivities_f32(const int32_t* knn_idx, const float* knn_dist, int64_t n, int k, int64_t* out_indptr,
+                                   int32_t* out_indices, float* out_data, int64_t cap, int64_t* nnz_host,
+                                   void* workspace, size_t workspace_bytes, scamd_stream_t stream);
+/* method='jaccard' (PhenoGraph weights, _connectivity.py:141-186): |N(i) & N(j)| / (2 (k-1) - |N(i) & N(j)|) on the kNN
+ * pattern without the self columns, symmetrised by averaging. */
+int scamd_jaccard_connectivities_f32(const int32_t* knn_idx, int64_t n, int k, int64_t* out_indptr,
+                                     int32_t* out_indices, float* out_data, int64_t cap, int64_t* nnz_host,
+                                     void* workspace, size_t workspace_bytes, scamd_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * PCA building blocks on a CSR float32 matrix (n rows = cells, g columns = genes).

@@ -153,3 +153,37 @@ def fuzzy_simplicial_set(knn_indices, knn_dists, n_obs: int, n_neighbors: int, *
     res.eliminate_zeros()
     res.sort_indices()
     return res.astype(np.float32), sigmas, rhos
+
+
+def gauss_knn(knn_indices, knn_dists, n_obs: int):
+    """`gauss(distances, n_neighbors, knn=True)` for a sparse distance matrix (src/scanpy/neighbors/_connectivity.py:
+    21-100, the CSR branch): sigma_i^2 = median of the squared distances to the stored neighbours,
+    w_ij = sqrt(2 sigma_i sigma_j / (sigma_i^2 + sigma_j^2)) exp(-d_ij^2 / (sigma_i^2 + sigma_j^2)) on the kNN pattern,
+    then w_ji := w_ij wherever i is not among j's neighbours.  knn_* include the self column (index 0).  float64."""
+    idx = np.asarray(knn_indices)[:, 1:]
+    d_sq = np.asarray(knn_dists, dtype=np.float64)[:, 1:] ** 2
+    sig_sq = np.median(d_sq, axis=1)
+    sig = np.sqrt(sig_sq)
+    num = 2 * sig[:, None] * sig[idx]
+    den = sig_sq[:, None] + sig_sq[idx]
+    w = np.sqrt(num / den) * np.exp(-d_sq / den)
+    rows = np.repeat(np.arange(n_obs), idx.shape[1])
+    m = sparse.csr_matrix((w.ravel(), (rows, idx.ravel())), shape=(n_obs, n_obs))
+    pattern = m.copy()
+    pattern.data[:] = 1.0
+    missing = pattern.T - pattern.T.multiply(pattern)  # (j, i) stored only as (i, j)
+    fill = m.T.multiply(missing)
+    return (m + fill).tocsr()
+
+
+def jaccard_knn(knn_indices, n_obs: int, n_neighbors: int):
+    """`jaccard(knn_indices, n_obs=, n_neighbors=)` (src/scanpy/neighbors/_connectivity.py:141-186): PhenoGraph's
+    |N(i) & N(j)| / (2 (k - 1) - |N(i) & N(j)|) on the kNN pattern (self excluded), symmetrised by averaging."""
+    idx = np.asarray(knn_indices)[:, 1:]
+    rows = np.repeat(np.arange(n_obs), idx.shape[1])
+    adj = sparse.csr_matrix((np.ones(idx.size), (rows, idx.ravel())), shape=(n_obs, n_obs))
+    shared = np.asarray(adj[rows].multiply(adj[idx.ravel()]).sum(axis=1)).ravel()
+    jac = shared / (2 * (n_neighbors - 1) - shared)
+    mask = jac != 0
+    c = sparse.csr_matrix((jac[mask], (rows[mask], idx.ravel()[mask])), shape=(n_obs, n_obs))
+    return ((c + c.T) / 2).tocsr()

@@ -62,6 +62,38 @@ def fuzzy_simplicial_set(knn_idx: torch.Tensor, knn_dist: torch.Tensor):
     return indptr, indices[:m], data[:m], sigma, rho
 
 
+def _knn_graph(entry: str, knn_idx: torch.Tensor, knn_dist: torch.Tensor | None):
+    """shared driver of the gauss / jaccard connectivity kernels -> (indptr int64, indices int32, data float32)"""
+    dev = require_gpu()
+    lib = _lib.load()
+    n, k = knn_idx.shape
+    knn_idx = knn_idx.to(torch.int32).contiguous()
+    cap = 2 * n * (k - 1)
+    indptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    indices = torch.empty(cap, dtype=torch.int32, device=dev)
+    data = torch.empty(cap, dtype=torch.float32, device=dev)
+    ws, wsz = _ws(lib.scamd_fuzzy_workspace_bytes(n, k), dev)
+    nnz = C.c_int64(0)
+    if entry == "gauss":
+        knn_dist = knn_dist.to(torch.float32).contiguous()
+        rc = lib.scamd_gauss_connectivities_f32(ptr(knn_idx), ptr(knn_dist), n, k, ptr(indptr), ptr(indices), ptr(data), cap,
+                                                C.byref(nnz), ptr(ws), wsz, stream_ptr())
+    else:
+        rc = lib.scamd_jaccard_connectivities_f32(ptr(knn_idx), n, k, ptr(indptr), ptr(indices), ptr(data), cap,
+                                                  C.byref(nnz), ptr(ws), wsz, stream_ptr())
+    _lib.check(rc, f"scamd_{entry}_connectivities_f32")
+    m = int(nnz.value)
+    return indptr, indices[:m], data[:m]
+
+
+def gauss_connectivities(knn_idx: torch.Tensor, knn_dist: torch.Tensor):
+    return _knn_graph("gauss", knn_idx, knn_dist)
+
+
+def jaccard_connectivities(knn_idx: torch.Tensor):
+    return _knn_graph("jaccard", knn_idx, None)
+
+
 def csr_transpose(indptr: torch.Tensor, indices: torch.Tensor, data: torch.Tensor, n: int, g: int):
     dev = require_gpu()
     lib = _lib.load()

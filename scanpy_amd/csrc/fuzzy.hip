@@ -115,7 +115,7 @@ __global__ void fss_rowcount_kernel(const int* __restrict__ outcnt, const int* _
 __global__ void fss_fill_kernel(const int* __restrict__ idx, const float* __restrict__ w,
                                 const float* __restrict__ recw, const int* __restrict__ outcnt,
                                 const int64_t* __restrict__ indptr, int64_t n, int k, int* __restrict__ cursor,
-                                int* __restrict__ tmp_col, float* __restrict__ tmp_val) {
+                                int* __restrict__ tmp_col, float* __restrict__ tmp_val, int mode) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n * k) return;
   const float we = w[e];
@@ -127,15 +127,18 @@ __global__ void fss_fill_kernel(const int* __restrict__ idx, const float* __rest
   int before = 0;
   for (int jj = 0; jj < j; ++jj) before += (w[i * k + jj] > 0.f) ? 1 : 0;
   const int64_t p = indptr[i] + before;
-  // (w + w^T) - w*w^T with one rounding per operation, as scipy's float32 sparse arithmetic does
-  const float val = __fsub_rn(__fadd_rn(we, r), __fmul_rn(we, r));
+  // mode 0 (umap): (w + w^T) - w*w^T with one rounding per operation, as scipy's float32 sparse arithmetic does
+  // mode 1 (gauss): the weight is symmetric by construction; a missing reverse entry is filled in with it
+  // mode 2 (jaccard): (w + w^T) / 2
+  const float val = mode == 0 ? __fsub_rn(__fadd_rn(we, r), __fmul_rn(we, r))
+                              : (mode == 1 ? fmaxf(we, r) : 0.5f * (we + r));
   tmp_col[p] = t;
   tmp_val[p] = val;
   if (r == 0.f) {
     const int slot = atomicAdd(&cursor[t], 1);
     const int64_t pt = indptr[t] + outcnt[t] + slot;
     tmp_col[pt] = (int)i;
-    tmp_val[pt] = we;
+    tmp_val[pt] = mode == 2 ? 0.5f * we : we;
   }
 }
 
@@ -161,6 +164,84 @@ __global__ void fss_sortrows_kernel(const int64_t* __restrict__ indptr, int64_t 
   }
 }
 
+// ---- method='gauss' (src/scanpy/neighbors/_connectivity.py:21-100, CSR branch) -------------------------------------
+// sigma_i^2 = median of the squared distances to the row's stored neighbours (self column excluded)
+__global__ void gauss_sigma_kernel(const int* __restrict__ idx, const float* __restrict__ dist, int64_t n, int k,
+                                   double* __restrict__ sigma_sq) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int* ri = idx + i * k;
+  const float* di = dist + i * k;
+  int m = 0;
+  for (int j = 0; j < k; ++j) m += (ri[j] != (int)i && ri[j] >= 0) ? 1 : 0;
+  // order statistics by rank counting (k is small): numpy's median = mean of the two middle values for even m
+  const int lo_rank = (m - 1) / 2, hi_rank = m / 2;
+  double lo = 0.0, hi = 0.0;
+  for (int j = 0; j < k; ++j) {
+    if (ri[j] == (int)i || ri[j] < 0) continue;
+    const double v = (double)di[j] * (double)di[j];
+    int rank = 0;
+    for (int u = 0; u < k; ++u) {
+      if (ri[u] == (int)i || ri[u] < 0) continue;
+      const double vu = (double)di[u] * (double)di[u];
+      rank += (vu < v || (vu == v && u < j)) ? 1 : 0;
+    }
+    if (rank == lo_rank) lo = v;
+    if (rank == hi_rank) hi = v;
+  }
+  sigma_sq[i] = m > 0 ? 0.5 * (lo + hi) : 0.0;
+}
+
+__global__ void gauss_weight_kernel(const int* __restrict__ idx, const float* __restrict__ dist, int64_t n, int k,
+                                    const double* __restrict__ sigma_sq, float* __restrict__ w,
+                                    int* __restrict__ outcnt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double si2 = sigma_sq[i], si = sqrt(si2);
+  int cnt = 0;
+  for (int j = 0; j < k; ++j) {
+    const int t = idx[i * k + j];
+    float val = 0.f;
+    if (t != (int)i && t >= 0) {
+      const double sj2 = sigma_sq[t], den = si2 + sj2;
+      const double d2 = (double)dist[i * k + j] * (double)dist[i * k + j];
+      val = den > 0.0 ? (float)(sqrt(2.0 * si * sqrt(sj2) / den) * exp(-d2 / den)) : 0.f;
+    }
+    w[i * k + j] = val;
+    cnt += (val > 0.f) ? 1 : 0;
+  }
+  outcnt[i] = cnt;
+}
+
+// ---- method='jaccard' (src/scanpy/neighbors/_connectivity.py:141-186) ------------------------------------------------
+// w_ij = s / (2 (k - 1) - s), s = |N(i) & N(j)| over the neighbour lists without their self columns
+__global__ void jaccard_weight_kernel(const int* __restrict__ idx, int64_t n, int k, float* __restrict__ w) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * k) return;
+  const int64_t i = e / k;
+  const int t = idx[e];
+  float val = 0.f;
+  if (t != (int)i && t >= 0) {
+    const int* ri = idx + i * k;
+    const int* rt = idx + (int64_t)t * k;
+    int shared = 0;
+    for (int a = 0; a < k; ++a) {
+      const int u = ri[a];
+      if (u == (int)i || u < 0) continue;
+      for (int b2 = 0; b2 < k; ++b2) shared += (rt[b2] == u && rt[b2] != t) ? 1 : 0;
+    }
+    val = (float)((double)shared / (double)(2 * (k - 1) - shared));
+  }
+  w[e] = val;
+}
+__global__ void count_positive_rows_kernel(const float* __restrict__ w, int64_t n, int k, int* __restrict__ outcnt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int cnt = 0;
+  for (int j = 0; j < k; ++j) cnt += (w[i * k + j] > 0.f) ? 1 : 0;
+  outcnt[i] = cnt;
+}
+
 struct FuzzyBuffers {
   float* w; float* recw; int* outcnt; int* in_only; int* cursor; int* rowcnt; int64_t* scan_tmp;
   int* tmp_col; float* tmp_val; double* sum;
@@ -180,6 +261,32 @@ static void fuzzy_carve(Workspace& ws, int64_t n, int k, FuzzyBuffers* b) {
   b->sum = ws.take<double>(2);
 }
 
+// directed weights w (> 0 = present) on the kNN pattern -> symmetric CSR with sorted rows; mode = combine rule of
+// fss_fill_kernel
+static int symmetrise(const FuzzyBuffers& b, const int32_t* knn_idx, int64_t n, int k, int mode, int64_t* out_indptr,
+                      int32_t* out_indices, float* out_data, int64_t* nnz_host, hipStream_t s) {
+  const int64_t total = n * k;
+  hipLaunchKernelGGL(fss_recip_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, knn_idx, b.w, n, k, b.recw,
+                     b.in_only);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(fss_rowcount_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, b.outcnt, b.in_only, n,
+                     b.rowcnt);
+  SCAMD_LAUNCH_CHECK();
+  int rc = exclusive_scan_i32_i64(b.rowcnt, n, out_indptr, b.scan_tmp, s);
+  if (rc != SCAMD_OK) return rc;
+  hipLaunchKernelGGL(fss_fill_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, knn_idx, b.w, b.recw,
+                     b.outcnt, out_indptr, n, k, b.cursor, b.tmp_col, b.tmp_val, mode);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(fss_sortrows_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, out_indptr, n, b.tmp_col,
+                     b.tmp_val, out_indices, out_data);
+  SCAMD_LAUNCH_CHECK();
+  int64_t nnz = 0;
+  SCAMD_HIP_CHECK(hipMemcpyAsync(&nnz, out_indptr + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+  *nnz_host = nnz;
+  return SCAMD_OK;
+}
+
 }  // namespace scamd
 
 using namespace scamd;
@@ -189,6 +296,7 @@ extern "C" size_t scamd_fuzzy_workspace_bytes(int64_t n, int k) {
   Workspace ws(nullptr, 0);
   FuzzyBuffers b;
   fuzzy_carve(ws, n, k, &b);
+  (void)ws.take<double>((size_t)n);  // sigma^2 of the gauss kernel: one size serves the three connectivity kernels
   return ws.used();
 }
 
@@ -221,23 +329,60 @@ extern "C" int scamd_fuzzy_simplicial_set_f32(const int32_t* knn_idx, const floa
   hipLaunchKernelGGL(fss_sigma_kernel, dim3(ceil_div(n, 128)), dim3(128), 0, s, knn_idx, knn_dist, n, k, b.sum,
                      out_sigma, out_rho, b.w, b.outcnt);
   SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(fss_recip_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, knn_idx, b.w, n, k, b.recw,
-                     b.in_only);
-  SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(fss_rowcount_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, b.outcnt, b.in_only, n,
-                     b.rowcnt);
-  SCAMD_LAUNCH_CHECK();
-  int rc = exclusive_scan_i32_i64(b.rowcnt, n, out_indptr, b.scan_tmp, s);
-  if (rc != SCAMD_OK) return rc;
-  hipLaunchKernelGGL(fss_fill_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, knn_idx, b.w, b.recw,
-                     b.outcnt, out_indptr, n, k, b.cursor, b.tmp_col, b.tmp_val);
-  SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(fss_sortrows_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, out_indptr, n, b.tmp_col,
-                     b.tmp_val, out_indices, out_data);
-  SCAMD_LAUNCH_CHECK();
-  int64_t nnz = 0;
-  SCAMD_HIP_CHECK(hipMemcpyAsync(&nnz, out_indptr + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-  SCAMD_HIP_CHECK(hipStreamSynchronize(s));
-  *nnz_host = nnz;
+  return symmetrise(b, knn_idx, n, k, 0, out_indptr, out_indices, out_data, nnz_host, s);
+}
+
+static int check_graph_args(const char* what, const int32_t* knn_idx, const void* knn_dist_or_idx, int64_t n, int k,
+                            const int64_t* out_indptr, const int32_t* out_indices, const float* out_data, int64_t cap,
+                            const int64_t* nnz_host) {
+  SCAMD_REQUIRE(knn_idx && knn_dist_or_idx && out_indptr && out_indices && out_data && nnz_host, SCAMD_EINVAL,
+                "%s: null pointer", what);
+  SCAMD_REQUIRE(n >= 1 && k >= 2 && k <= 256, SCAMD_EINVAL, "%s: bad shape n=%lld k=%d (k <= 256)", what, (long long)n, k);
+  SCAMD_REQUIRE(n < (int64_t)1 << 31, SCAMD_EUNSUPPORTED, "%s: n exceeds int32 ids", what);
+  SCAMD_REQUIRE(cap >= 2 * n * (k - 1), SCAMD_ECAPACITY, "%s: cap %lld < 2*n*(k-1) = %lld", what, (long long)cap,
+                (long long)(2 * n * (k - 1)));
   return SCAMD_OK;
+}
+
+extern "C" int scamd_gauss_connectivities_f32(const int32_t* knn_idx, const float* knn_dist, int64_t n, int k,
+                                              int64_t* out_indptr, int32_t* out_indices, float* out_data, int64_t cap,
+                                              int64_t* nnz_host, void* workspace, size_t workspace_bytes,
+                                              scamd_stream_t stream) {
+  int rc = check_graph_args("gauss", knn_idx, knn_dist, n, k, out_indptr, out_indices, out_data, cap, nnz_host);
+  if (rc != SCAMD_OK) return rc;
+  Workspace ws(workspace, workspace_bytes);
+  FuzzyBuffers b;
+  fuzzy_carve(ws, n, k, &b);
+  double* sigma_sq = ws.take<double>((size_t)n);
+  SCAMD_REQUIRE(workspace && ws.ok, SCAMD_EWORKSPACE, "gauss: workspace %zu < required %zu", workspace_bytes, ws.used());
+  hipStream_t s = stream;
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.in_only, 0, sizeof(int) * n, s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.cursor, 0, sizeof(int) * n, s));
+  hipLaunchKernelGGL(gauss_sigma_kernel, dim3(ceil_div(n, 128)), dim3(128), 0, s, knn_idx, knn_dist, n, k, sigma_sq);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gauss_weight_kernel, dim3(ceil_div(n, 128)), dim3(128), 0, s, knn_idx, knn_dist, n, k, sigma_sq, b.w,
+                     b.outcnt);
+  SCAMD_LAUNCH_CHECK();
+  return symmetrise(b, knn_idx, n, k, 1, out_indptr, out_indices, out_data, nnz_host, s);
+}
+
+extern "C" int scamd_jaccard_connectivities_f32(const int32_t* knn_idx, int64_t n, int k, int64_t* out_indptr,
+                                                int32_t* out_indices, float* out_data, int64_t cap, int64_t* nnz_host,
+                                                void* workspace, size_t workspace_bytes, scamd_stream_t stream) {
+  int rc = check_graph_args("jaccard", knn_idx, knn_idx, n, k, out_indptr, out_indices, out_data, cap, nnz_host);
+  if (rc != SCAMD_OK) return rc;
+  Workspace ws(workspace, workspace_bytes);
+  FuzzyBuffers b;
+  fuzzy_carve(ws, n, k, &b);
+  (void)ws.take<double>((size_t)n);  // same layout as the gauss entry point: one workspace size for all three
+  SCAMD_REQUIRE(workspace && ws.ok, SCAMD_EWORKSPACE, "jaccard: workspace %zu < required %zu", workspace_bytes, ws.used());
+  hipStream_t s = stream;
+  const int64_t total = n * k;
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.in_only, 0, sizeof(int) * n, s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.cursor, 0, sizeof(int) * n, s));
+  hipLaunchKernelGGL(jaccard_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, knn_idx, n, k, b.w);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(count_positive_rows_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, b.w, n, k, b.outcnt);
+  SCAMD_LAUNCH_CHECK();
+  return symmetrise(b, knn_idx, n, k, 2, out_indptr, out_indices, out_data, nnz_host, s);
 }

@@ -44,6 +44,24 @@ def _connectivities_umap(knn_indices: np.ndarray, knn_dists: np.ndarray, n_obs: 
     )
 
 
+def _connectivities_kernel(method: str, knn_indices: np.ndarray, knn_dists: np.ndarray, n_obs: int) -> sparse.csr_matrix:
+    """neighbors/_connectivity.py:21-100 ('gauss', sparse branch) / :141-186 ('jaccard') ->
+    scamd_gauss_connectivities_f32 / scamd_jaccard_connectivities_f32."""
+    import torch
+
+    from .. import _kernels
+    from .._device import require_gpu
+
+    dev = require_gpu()
+    idx = torch.from_numpy(np.ascontiguousarray(knn_indices, dtype=np.int32)).to(dev)
+    if method == "gauss":
+        dist = torch.from_numpy(np.ascontiguousarray(knn_dists, dtype=np.float32)).to(dev)
+        indptr, indices, data = _kernels.gauss_connectivities(idx, dist)
+    else:
+        indptr, indices, data = _kernels.jaccard_connectivities(idx)
+    return sparse.csr_matrix((data.cpu().numpy(), indices.cpu().numpy(), indptr.cpu().numpy()), shape=(n_obs, n_obs))
+
+
 class Neighbors:
     """Data represented as graph of nearest neighbors (the slice of the reference class the path needs)."""
 
@@ -119,8 +137,8 @@ class Neighbors:
         if not knn and not (conn_method == "gauss" and transformer is None):
             msg = f"`method = {method!r} only with `knn = True`."
             raise ValueError(msg)
-        if conn_method in {"gauss", "jaccard"}:
-            msg = f"method={conn_method!r} is outside the MI355X hot path (only the default 'umap' kernel is built)."
+        if conn_method == "gauss" and not knn:
+            msg = "method='gauss' with knn=False builds a dense n x n kernel matrix: not offered on the MI355X path."
             raise NotImplementedError(msg)
         if isinstance(transformer, str) and transformer not in {"sklearn", "pynndescent", "mi355x"}:
             msg = f"Unknown transformer: {transformer}. Try passing a class or one of {{'pynndescent', 'sklearn'}}"
@@ -144,6 +162,8 @@ class Neighbors:
         self._connectivities = None
         if conn_method == "umap":
             self._connectivities = _connectivities_umap(knn_indices, knn_distances, self._adata.n_obs)
+        elif conn_method in {"gauss", "jaccard"}:  # neighbors/__init__.py:651-659
+            self._connectivities = _connectivities_kernel(conn_method, knn_indices, knn_distances, self._adata.n_obs)
         self._cc = None  # connected components (neighbors/__init__.py:660-673) are computed on first use
 
 

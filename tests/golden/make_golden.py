@@ -123,6 +123,8 @@ def main() -> None:
         "connectivities_umap",
         "transitions_sym_umap",
         "transitions_umap",
+        "connectivities_gauss_knn",
+        "connectivities_jaccard",
     }
     nb = literal_arrays(REF / "tests/test_neighbors.py", nb_names)
     nb["n_neighbors"] = np.array(3)  # tests/test_neighbors.py:24 (includes the point itself)

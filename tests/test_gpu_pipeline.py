@@ -391,3 +391,28 @@ def test_pca_chunked_equals_one_shot(sc, pbmc68k, chunk_size, resident, monkeypa
     np.testing.assert_array_equal(a1.uns["pca"]["variance"], a2.uns["pca"]["variance"])
     with pytest.raises(ValueError, match="zero_center"):
         sc.pp.pca(a2, n_comps=20, chunked=True, zero_center=False)
+
+
+@pytest.mark.parametrize("method", ["gauss", "jaccard"])
+def test_neighbors_gauss_and_jaccard(sc, neighbors_toy, pbmc68k, method):
+    """tests/test_neighbors.py:196-227: the reference's golden connectivities of the 4-point toy, then the bundled fixture
+    against the oracle restatement (sparsity pattern identical, values to float32 accuracy)"""
+    x = neighbors_toy["X"]
+    k = int(neighbors_toy["n_neighbors"])
+    adata = sc.AnnData(x)
+    sc.pp.neighbors(adata, n_neighbors=k, method=method)
+    golden = neighbors_toy["connectivities_gauss_knn" if method == "gauss" else "connectivities_jaccard"]
+    np.testing.assert_allclose(adata.obsp["connectivities"].toarray(), golden, rtol=1e-6)
+    assert adata.uns["neighbors"]["params"]["method"] == method
+    big = sc.AnnData(pbmc68k["X"].copy())
+    big.obsm["X_pca"] = pbmc68k["X_pca"]
+    sc.pp.neighbors(big, n_neighbors=12, method=method)
+    oi, od, _ = oknn.knn_sklearn(pbmc68k["X_pca"], 12)
+    ref = oc.gauss_knn(oi, od, 700) if method == "gauss" else oc.jaccard_knn(oi, 700, 12)
+    got = big.obsp["connectivities"]
+    assert (abs(got - got.T) > 1e-7).nnz == 0 and got.has_sorted_indices
+    ref.sort_indices()
+    assert np.array_equal(got.indptr, ref.indptr) and np.array_equal(got.indices, ref.indices)
+    np.testing.assert_allclose(got.data, ref.data, rtol=2e-6, atol=1e-9)
+    with pytest.raises(NotImplementedError, match="knn=False"):
+        sc.pp.neighbors(big, method="gauss", knn=False)

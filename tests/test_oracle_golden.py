@@ -84,3 +84,14 @@ def test_connectivities_fixture(pbmc68k, vectorised):
     np.testing.assert_array_equal(c.indptr, ref.indptr)
     np.testing.assert_array_equal(c.indices, ref.indices)
     np.testing.assert_allclose(c.data, ref.data, rtol=0, atol=1e-5)
+
+
+def test_gauss_and_jaccard_golden_toy(neighbors_toy):
+    """tests/test_neighbors.py:65-71, 120-125, 196-227: method='gauss' (knn) and 'jaccard' on the 4-point toy"""
+    x = neighbors_toy["X"]
+    k = int(neighbors_toy["n_neighbors"])
+    idx, dist, _ = oknn.knn_sklearn(x, k)
+    g = oc.gauss_knn(idx, dist, x.shape[0])
+    np.testing.assert_allclose(g.toarray(), neighbors_toy["connectivities_gauss_knn"], rtol=1e-6)
+    j = oc.jaccard_knn(idx, x.shape[0], k)
+    np.testing.assert_allclose(j.toarray(), neighbors_toy["connectivities_jaccard"], rtol=1e-12)
