@@ -1,4 +1,4 @@
-"""The bench line the driver parses: the committed result of the last measured run (profiles/r01f_bench_1M.json, written
+"""The bench line the driver parses: the committed result of the last measured run (profiles/r*_bench_1M.json, written
 by `python bench.py` on an MI355X) carries every field of the contract with consistent values."""
 from __future__ import annotations
 
@@ -9,7 +9,8 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.loads((ROOT / "profiles" / "r01f_bench_1M.json").read_text().strip().splitlines()[-1])
+    latest = sorted((ROOT / "profiles").glob("r*_bench_1M.json"))[-1]  # profiles are named per round: take the newest
+    d = json.loads(latest.read_text().strip().splitlines()[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
