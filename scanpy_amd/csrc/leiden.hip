@@ -321,7 +321,8 @@ __global__ __launch_bounds__(256) void ld_move_kernel(
     if (deg <= GMAX) {
       int* keys = hkeys[grp];
       unsigned long long* vals = hvals[grp];
-      const int nslots = G < 64 ? (deg <= 48 ? 64 : 128) : (deg <= 96 ? 128 : (deg <= 192 ? 256 : 512));
+      int nslots = 64;  // smallest power of two with load <= 3/4 (deg <= GMAX guarantees nslots <= GSLOTS)
+      while (nslots * 3 / 4 < deg) nslots <<= 1;
       for (int i = sub; i < nslots; i += G) {
         keys[i] = WH_EMPTY;
         vals[i] = 0ull;
@@ -1372,10 +1373,18 @@ static int quality(LeidenCtx& cx, const LevelGraph& g, const int* comm, double* 
 
 // levels whose rows are short on average (the kNN graph itself) take the four-vertices-per-wave kernels
 constexpr int QUAD_MAX_DEG = WH_SLOTS / 4 * 3 / 4;  // 96: rows the 128-slot quarter-wave table takes
-static bool level_is_short_rowed(const LevelGraph& g) {
-  if (const char* e = getenv("SCAMD_LEIDEN_QUAD")) return atoi(e) != 0;  // tests: force either kernel family
-  return g.n > 0 && g.nnz / g.n <= 40;
+// lanes per vertex of the decision kernels for this level: 16 (four vertices per wave, rows <= 96), 32 (two per wave,
+// rows <= 192: the first coarse levels, ~64 entries per row) or 64.  SCAMD_LEIDEN_QUAD = 0 / 1 / 2 forces 64 / 16 / 32.
+static int level_lanes(const LevelGraph& g) {
+  if (const char* e = getenv("SCAMD_LEIDEN_QUAD")) {
+    const int v = atoi(e);
+    return v == 1 ? 16 : (v == 2 ? 32 : 64);
+  }
+  if (g.n <= 0) return 64;
+  const int64_t avg = g.nnz / g.n;
+  return avg <= 40 ? 16 : (avg <= 110 ? 32 : 64);
 }
+static bool level_is_short_rowed(const LevelGraph& g) { return level_lanes(g) == 16; }
 
 static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
   LeidenBuffers& b = cx.b;
@@ -1389,10 +1398,23 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
   SCAMD_HIP_CHECK(hipMemsetAsync(b.flag, 0, sizeof(int) * n, cx.s));
   int n_act = g.n;
   int quiet = 0;
-  const bool quad = level_is_short_rowed(g);
+  const int lanes = level_lanes(g);
+  const bool quad = lanes == 16;
   for (int round = 0; round < MAX_LM_ROUNDS && n_act > 0; ++round) {
     SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
-    if (quad) {
+    if (lanes == 32) {
+      hipLaunchKernelGGL(ld_move_kernel<32>, dim3((unsigned)ceil_div(n_act, 8)), dim3(256), 0, cx.s, n_act, b.list_a,
+                         (const int*)nullptr, (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
+                         b.csize, gg, round, cx.seed, b.target, b.mid_list, b.hub_list, b.counters);
+      SCAMD_LAUNCH_CHECK();
+      if (g.max_deg > 2 * QUAD_MAX_DEG) {
+        hipLaunchKernelGGL(ld_move_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(n_act, 4))), dim3(256), 0, cx.s,
+                           n_act, b.list_a, (const int*)b.mid_list, (const int*)(b.counters + 5), g.indptr, g.indices,
+                           g.wq, g.k, b.comm, b.Ktot, b.csize, gg, round, cx.seed, b.target, b.mid_list, b.hub_list,
+                           b.counters);
+        SCAMD_LAUNCH_CHECK();
+      }
+    } else if (quad) {
       hipLaunchKernelGGL(ld_move_kernel<16>, dim3((unsigned)ceil_div(n_act, 16)), dim3(256), 0, cx.s, n_act, b.list_a,
                          (const int*)nullptr, (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
                          b.csize, gg, round, cx.seed, b.target, b.mid_list, b.hub_list, b.counters);

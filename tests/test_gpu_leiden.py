@@ -149,7 +149,8 @@ def test_leiden_quarter_wave_kernels_agree(K, monkeypatch):
     ip, ix, w, n = _graph_dev(adj.astype(np.float32))
     monkeypatch.setenv("SCAMD_LEIDEN_QUAD", "0")
     m0, q0, nc0 = K.leiden(ip, ix, w, n, seed=7)
-    monkeypatch.setenv("SCAMD_LEIDEN_QUAD", "1")
-    m1, q1, nc1 = K.leiden(ip, ix, w, n, seed=7)
-    assert nc0 == nc1 and q0 == q1
-    assert np.array_equal(m0.cpu().numpy(), m1.cpu().numpy())
+    for forced in ("1", "2"):  # 16 and 32 lanes per vertex
+        monkeypatch.setenv("SCAMD_LEIDEN_QUAD", forced)
+        m1, q1, nc1 = K.leiden(ip, ix, w, n, seed=7)
+        assert nc0 == nc1 and q0 == q1
+        assert np.array_equal(m0.cpu().numpy(), m1.cpu().numpy())
