@@ -318,7 +318,7 @@ class _ChunkedRows:
             yield from self._cached
             return
         keep = [] if self.resident else None
-        upload = getattr(backend, "upload_prefetch", backend.upload)
+        upload = backend.upload_prefetch if hasattr(backend, "upload_prefetch") else backend.upload
         nxt = upload(self._host[0])
         for i in range(self.n_chunks):
             cur = nxt

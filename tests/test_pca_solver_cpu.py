@@ -137,3 +137,47 @@ def test_chunked_rows_equal_one_shot(chunk):
     np.testing.assert_array_equal(many.scores.numpy(), one.scores.numpy())
     if chunk < 1200:
         assert many.info["row_chunks"] == -(-1200 // chunk)
+
+
+def test_chunked_rows_prefetch_protocol():
+    """the next block's upload is issued right after the current block is handed to the caller (so it overlaps that
+    block's kernels), `wait_prefetch` precedes every use, and resident blocks are uploaded once for all passes"""
+    from scanpy_amd.preprocessing._pca_solver import _ChunkedRows
+
+    class Recorder:
+        def __init__(self):
+            self.log = []
+
+        def upload_prefetch(self, c):
+            self.log.append(("upload", c))
+            return (c,)
+
+        def wait_prefetch(self):
+            self.log.append(("wait",))
+
+    class Chunk:
+        def __init__(self, tag, rows):
+            self.tag, self.shape = tag, (rows, 5)
+            self.data = self.indices = np.zeros(4, dtype=np.float32)
+
+        def __repr__(self):
+            return self.tag
+
+    chunks = [Chunk("a", 3), Chunk("b", 3), Chunk("c", 2)]
+    rows = _ChunkedRows(chunks, 5)
+    assert (rows.n_rows, rows.n_cols, rows.n_chunks, rows.resident) == (8, 5, 3, False)
+    be = Recorder()
+    for h in rows.handles(be):
+        be.log.append(("use", h[0]))
+    a, b, c = chunks
+    assert be.log == [("upload", a), ("wait",), ("use", a), ("upload", b), ("wait",), ("use", b), ("upload", c), ("wait",),
+                      ("use", c)]
+    n_first = len(be.log)
+    list(rows.handles(be))  # streamed mode: a second pass uploads again
+    assert len(be.log) == n_first + 6
+    res = _ChunkedRows(chunks, 5, resident_budget_bytes=1 << 30)
+    be2 = Recorder()
+    list(res.handles(be2))
+    n_up = sum(1 for e in be2.log if e[0] == "upload")
+    list(res.handles(be2))
+    assert res.resident and n_up == 3 and sum(1 for e in be2.log if e[0] == "upload") == 3
