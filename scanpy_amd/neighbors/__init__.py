@@ -162,9 +162,9 @@ class Neighbors:
         self._connectivities = None
         if conn_method == "umap":
             self._connectivities = _connectivities_umap(knn_indices, knn_distances, self._adata.n_obs)
-        elif conn_method in {"gauss", "jaccard"}:  # neighbors/__init__.py:651-659
+        elif conn_method in {"gauss", "jaccard"}:  # neighbors/__init__.py:694-708
             self._connectivities = _connectivities_kernel(conn_method, knn_indices, knn_distances, self._adata.n_obs)
-        self._cc = None  # connected components (neighbors/__init__.py:660-673) are computed on first use
+        self._cc = None  # connected components (neighbors/__init__.py:666-671) are computed on first use
 
 
 def _get_metadata(key_added, **params):
