@@ -194,7 +194,7 @@ int scamd_modularity_csr_f32(const int64_t* indptr, const int32_t* indices, cons
 int scamd_pp_row_sums_f32(const int64_t* indptr, const int32_t* indices, const float* data, int64_t n, int64_t nnz,
                           const int32_t* col_skip, float* out, scamd_stream_t stream);
 /* out[r] = #{stored x_rj > 0}: `stats.sum(data > 0, axis=1)` of filter_cells(min_genes= / max_genes=)
- * (src/scanpy/preprocessing/_simple.py:176-178); the per-gene counterpart of filter_genes is npos of
+ * (src/scanpy/preprocessing/_simple.py:170-172); the per-gene counterpart of filter_genes is npos of
  * scamd_pp_col_stats_f32 */
 int scamd_pp_row_count_positive_f32(const int64_t* indptr, const float* data, int64_t n, int64_t nnz, int32_t* out,
                                     scamd_stream_t stream);

@@ -1,4 +1,4 @@
-"""`sc.pp.filter_cells` / `sc.pp.filter_genes` on MI355X (reference: src/scanpy/preprocessing/_simple.py:51-307).
+"""`sc.pp.filter_cells` / `sc.pp.filter_genes` on MI355X (reference: src/scanpy/preprocessing/_simple.py:53-307).
 
 The per-cell / per-gene numbers (`n_counts`, `n_genes`, `n_cells`) are one device sweep each (`scamd_pp_row_sums_f32`,
 `scamd_pp_row_count_positive_f32`, `scamd_pp_col_stats_f32`); thresholding, logging and the in-place subsetting of the
@@ -33,7 +33,7 @@ def _subset(number, lo, hi):
 def filter_cells(data, *, min_counts=None, min_genes=None, max_counts=None, max_genes=None, inplace: bool = True,
                  copy: bool = False):
     """Filter cell outliers based on counts and numbers of genes expressed (drop-in for `scanpy.pp.filter_cells`,
-    `_simple.py:51-201`).  AnnData: annotates `obs['n_counts']` / `obs['n_genes']` and subsets in place; matrix: returns
+    `_simple.py:53-196`).  AnnData: annotates `obs['n_counts']` / `obs['n_genes']` and subsets in place; matrix: returns
     `(cell_subset, number_per_cell)`."""
     if copy:
         _log.warning("`copy` is deprecated, use `inplace` instead.")
@@ -63,7 +63,7 @@ def filter_cells(data, *, min_counts=None, min_genes=None, max_counts=None, max_
 
 def filter_genes(data, *, min_counts=None, min_cells=None, max_counts=None, max_cells=None, inplace: bool = True,
                  copy: bool = False):
-    """Filter genes based on number of cells or counts (drop-in for `scanpy.pp.filter_genes`, `_simple.py:204-307`).
+    """Filter genes based on number of cells or counts (drop-in for `scanpy.pp.filter_genes`, `_simple.py:199-307`).
     AnnData: annotates `var['n_counts']` / `var['n_cells']` and subsets in place; matrix: returns
     `(gene_subset, number_per_gene)`."""
     if copy:

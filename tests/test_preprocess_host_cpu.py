@@ -218,7 +218,7 @@ def test_hvg_errors_and_subset(pbmc68k):
 
 
 def check_filters(typ):
-    """src/scanpy/preprocessing/_simple.py:51-307 semantics against plain numpy"""
+    """src/scanpy/preprocessing/_simple.py:53-307 semantics against plain numpy"""
     rng = np.random.default_rng(3)
     dense = rng.poisson(0.4, size=(300, 40)).astype(np.float32)
     dense[7] = 0
