@@ -105,3 +105,95 @@ def test_leiden_restrict_to_and_keys(sc, pbmc68k):
 @pytest.mark.parametrize("chunk_size", [333, 2000])
 def test_pca_chunked_equals_one_shot(sc, pbmc68k, chunk_size, monkeypatch):
     gp.test_pca_chunked_equals_one_shot(sc, pbmc68k, chunk_size, "0", monkeypatch)
+
+
+# ---- more of the reference's tests/test_pca.py semantics, on the host logic (kernel layer stubbed) ------------------
+from scipy import sparse  # noqa: E402
+
+A_LIST = np.array([[0, 0, 7, 0, 0], [8, 5, 0, 2, 0], [6, 0, 0, 2, 5], [0, 0, 0, 1, 0], [8, 8, 2, 1, 0], [0, 0, 0, 4, 5]],
+                  dtype=np.float32)  # tests/test_pca.py:34-41
+ARRAY_TYPES = [pytest.param(lambda a: np.array(a), id="dense"), pytest.param(sparse.csr_matrix, id="csr")]
+
+
+@pytest.mark.parametrize("typ", ARRAY_TYPES)
+def test_mask_var_error(sc, typ):
+    """tests/test_pca.py:406-413"""
+    with pytest.raises(ValueError, match=r"Did not find `adata\.var\['highly_variable'\]`\."):
+        sc.pp.pca(sc.AnnData(typ(A_LIST)), mask_var="highly_variable")
+
+
+def test_mask_length_and_obsm_errors(sc):
+    """tests/test_pca.py:416-436"""
+    adata = sc.AnnData(A_LIST.copy())
+    with pytest.raises(ValueError, match=r"The shape of the mask do not match the data\."):
+        sc.pp.pca(adata, mask_var=np.ones(adata.shape[1] + 1, dtype=bool), copy=True)
+    adata.obsm["X_alt"] = A_LIST.copy()
+    for mask in ("highly_variable", np.array([True, False, True, True, False])):
+        with pytest.raises(ValueError, match=r"Argument `mask_var` is incompatible with `obsm`."):
+            sc.pp.pca(adata, mask_var=mask, obsm="X_alt", copy=True)
+
+
+@pytest.mark.parametrize("typ", ARRAY_TYPES)
+def test_mask_var_argument_equivalence_and_masked_loadings(sc, typ):
+    """tests/test_pca.py:439-481: mask as array == mask as column name; masked genes get zero loadings; the embedding equals
+    the PCA of the subset matrix"""
+    rng = np.random.default_rng(0)
+    x = rng.random((100, 10)).astype(np.float32)
+    mask = np.array([1, 1, 0, 1, 1, 0, 1, 1, 1, 0], dtype=bool)
+    a1, a2, a3 = sc.AnnData(typ(x)), sc.AnnData(typ(x)), sc.AnnData(typ(x[:, mask]))
+    sc.pp.pca(a1, n_comps=4, mask_var=mask)
+    a2.var["mask"] = mask
+    sc.pp.pca(a2, n_comps=4, mask_var="mask")
+    sc.pp.pca(a3, n_comps=4)
+    np.testing.assert_array_equal(a1.obsm["X_pca"], a2.obsm["X_pca"])
+    assert a2.uns["pca"]["params"]["mask_var"] == "mask"
+    assert not a1.varm["PCs"][~mask].any()
+    np.testing.assert_array_equal(a1.obsm["X_pca"], a3.obsm["X_pca"])
+    np.testing.assert_allclose(a1.varm["PCs"][mask], a3.varm["PCs"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("typ", ARRAY_TYPES)
+def test_mask_defaults(sc, typ):
+    """tests/test_pca.py:484-506: `var['highly_variable']` is the default mask; `mask_var=None` switches it off"""
+    adata = sc.AnnData(typ(A_LIST))
+    without_var = sc.pp.pca(adata, n_comps=3, copy=True)
+    adata.var["highly_variable"] = np.array([True, True, False, True, True])
+    with_var = sc.pp.pca(adata, n_comps=3, copy=True)
+    assert without_var.uns["pca"]["params"]["mask_var"] is None
+    assert with_var.uns["pca"]["params"]["mask_var"] == "highly_variable"
+    assert not np.array_equal(without_var.obsm["X_pca"], with_var.obsm["X_pca"])
+    with_no_mask = sc.pp.pca(adata, n_comps=3, mask_var=None, copy=True)
+    np.testing.assert_array_equal(without_var.obsm["X_pca"], with_no_mask.obsm["X_pca"])
+
+
+@pytest.mark.parametrize("rep", ["layer", "obsm"])
+def test_pca_rep(sc, pbmc68k, rep):
+    """tests/test_pca.py:509-540: `layer=` / `obsm=` work like `X`; `obsm` stores the components in `uns`"""
+    x = pbmc68k["counts"].astype(np.float32)[:200]
+    adata = sc.AnnData(x.copy())
+    rep_adata = sc.AnnData(x.copy())
+    if rep == "layer":
+        rep_adata.layers["counts"] = x.copy()
+    else:
+        rep_adata.obsm["counts"] = x.copy()[:, :100]
+        adata = sc.AnnData(x.copy()[:, :100])
+    rep_adata.X = sparse.csr_matrix(x.shape, dtype=np.float32)  # X must not be what gets decomposed
+    sc.pp.pca(adata, n_comps=10, mask_var=None)
+    sc.pp.pca(rep_adata, n_comps=10, **{rep: "counts"}, mask_var=None)
+    assert rep_adata.uns["pca"]["params"][rep] == "counts" and rep not in adata.uns["pca"]["params"]
+    np.testing.assert_array_equal(adata.uns["pca"]["variance"], rep_adata.uns["pca"]["variance"])
+    np.testing.assert_array_equal(adata.uns["pca"]["variance_ratio"], rep_adata.uns["pca"]["variance_ratio"])
+    np.testing.assert_array_equal(adata.obsm["X_pca"], rep_adata.obsm["X_pca"])
+    pcs = rep_adata.varm["PCs"] if rep == "layer" else rep_adata.uns["pca"]["components"]
+    np.testing.assert_array_equal(adata.varm["PCs"], pcs)
+
+
+def test_pca_n_pcs_with_renamed_representation(sc, pbmc68k):
+    """tests/test_pca.py:389-401: `n_pcs` applies to any `use_rep`"""
+    adata = sc.AnnData(pbmc68k["counts"].astype(np.float32))
+    sc.pp.pca(adata, n_comps=20, dtype=np.float64)
+    adata.obsm["X_pca_test"] = adata.obsm["X_pca"]
+    original = sc.pp.neighbors(adata, n_pcs=5, use_rep="X_pca", copy=True)
+    renamed = sc.pp.neighbors(adata, n_pcs=5, use_rep="X_pca_test", copy=True)
+    assert np.allclose(original.obsp["distances"].toarray(), renamed.obsp["distances"].toarray())
+    assert original.uns["neighbors"]["params"]["n_pcs"] == 5
