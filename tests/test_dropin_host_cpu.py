@@ -197,3 +197,50 @@ def test_pca_n_pcs_with_renamed_representation(sc, pbmc68k):
     renamed = sc.pp.neighbors(adata, n_pcs=5, use_rep="X_pca_test", copy=True)
     assert np.allclose(original.obsp["distances"].toarray(), renamed.obsp["distances"].toarray())
     assert original.uns["neighbors"]["params"]["n_pcs"] == 5
+
+
+# ---- more of the reference's tests/test_clustering.py semantics -------------------------------------------------------
+@pytest.mark.parametrize("rng_arg", ["rng", "random_state"])
+@pytest.mark.parametrize("flavor", ["igraph", "leidenalg"])
+def test_leiden_random_state(sc, pbmc68k, flavor, rng_arg):
+    """tests/test_clustering.py:67-102: same seed -> same labels and modularity, another seed -> another clustering"""
+    import pandas as pd
+
+    base = gp._graph_adata(sc, pbmc68k)
+    runs = [sc.tl.leiden(base, flavor=flavor, copy=True, directed=(flavor == "leidenalg"),
+                         n_iterations=2 if flavor == "leidenalg" else -1, **{rng_arg: seed}) for seed in (1, 1, 42, 7, 99)]
+    pd.testing.assert_series_equal(runs[0].obs["leiden"], runs[1].obs["leiden"])
+    assert runs[0].uns["leiden"]["modularity"] == runs[1].uns["leiden"]["modularity"]
+    # the seed reaches the optimiser: some other seed gives another clustering (on a 700-cell graph two seeds can agree)
+    assert any(not r.obs["leiden"].equals(runs[1].obs["leiden"]) for r in runs[2:])
+    assert ("random_state" in runs[0].uns["leiden"]["params"]) == (rng_arg == "random_state")
+
+
+def test_clustering_subset(sc, pbmc68k):
+    """tests/test_clustering.py:177-213: `restrict_to` re-clusters only the chosen cluster's cells"""
+    adata = gp._graph_adata(sc, pbmc68k)
+    sc.tl.leiden(adata, flavor="igraph", key_added="leiden")
+    for c in adata.obs["leiden"].unique()[:4]:
+        cells_in_c = adata.obs["leiden"] == c
+        n_in_c = int(cells_in_c.sum())
+        sc.tl.leiden(adata, flavor="igraph", restrict_to=("leiden", [c]), key_added="leiden_sub")
+        new = adata.obs["leiden_sub"]
+        counts = new[cells_in_c].value_counts()
+        assert counts.sum() == n_in_c
+        nonzero = counts[counts > 0].index
+        assert len(nonzero.intersection(adata.obs["leiden"].cat.categories)) == 0  # only new category names inside c
+        assert (new[~cells_in_c].astype(str) == adata.obs["leiden"][~cells_in_c].astype(str)).all()
+
+
+def test_clustering_custom_key_and_objective(sc, pbmc68k):
+    """tests/test_clustering.py:166-242: parameters are stored under the user's key and never overwritten"""
+    adata = gp._graph_adata(sc, pbmc68k)
+    sc.tl.leiden(adata, flavor="igraph", resolution=0.8)
+    for res in (0.9, 1.1):
+        sc.tl.leiden(adata, flavor="igraph", resolution=res, key_added=f"leiden_{res}")
+    assert adata.uns["leiden"]["params"]["resolution"] == 0.8
+    for res in (0.9, 1.1):
+        assert adata.uns[f"leiden_{res}"]["params"]["resolution"] == res
+    sc.tl.leiden(adata, objective_function="modularity", flavor="igraph", directed=False)
+    with pytest.raises(NotImplementedError, match="objective_function"):
+        sc.tl.leiden(adata, objective_function="CPM", flavor="igraph")
