@@ -244,3 +244,34 @@ def test_clustering_custom_key_and_objective(sc, pbmc68k):
     sc.tl.leiden(adata, objective_function="modularity", flavor="igraph", directed=False)
     with pytest.raises(NotImplementedError, match="objective_function"):
         sc.tl.leiden(adata, objective_function="CPM", flavor="igraph")
+
+
+# ---- tests/test_neighbors_key_added.py semantics ------------------------------------------------------------------------
+@pytest.mark.parametrize("rng_arg", ["rng", "random_state"])
+def test_neighbors_key_added_and_downstream_keys(sc, pbmc68k, rng_arg):
+    """tests/test_neighbors_key_added.py:35-52, 66-100: `key_added` renames the three slots; `neighbors_key=` / `obsp=` of
+    tl.leiden find them"""
+    key = "test"
+    adata = sc.AnnData(pbmc68k["X"], obsm={"X_pca": pbmc68k["X_pca"]})
+    sc.pp.neighbors(adata, n_neighbors=5, **{rng_arg: 0})
+    sc.pp.neighbors(adata, n_neighbors=5, **{rng_arg: 0}, key_added=key)
+    conns_key, dists_key = adata.uns[key]["connectivities_key"], adata.uns[key]["distances_key"]
+    assert (conns_key, dists_key) == (f"{key}_connectivities", f"{key}_distances")
+    assert adata.uns["neighbors"]["params"] == adata.uns[key]["params"]
+    assert ("random_state" in adata.uns[key]["params"]) == (rng_arg == "random_state")
+    assert np.allclose(adata.obsp["connectivities"].toarray(), adata.obsp[conns_key].toarray())
+    assert np.allclose(adata.obsp["distances"].toarray(), adata.obsp[dists_key].toarray())
+    sc.tl.leiden(adata, flavor="igraph", **{rng_arg: 0})
+    for arg in ({"neighbors_key": key}, {"obsp": conns_key}):
+        other = adata.copy()
+        sc.tl.leiden(other, flavor="igraph", **{rng_arg: 0}, **arg)
+        assert adata.uns["leiden"]["params"] == other.uns["leiden"]["params"]
+        assert np.all(adata.obs["leiden"] == other.obs["leiden"])
+
+
+def test_neighbors_without_previous_pca_run(sc, pbmc68k):
+    """tests/test_neighbors_key_added.py:55-63"""
+    adata = sc.AnnData(pbmc68k["X"].copy())
+    with pytest.warns(UserWarning, match=r".*Falling back to preprocessing with `sc.pp.pca` and default params"):
+        sc.pp.neighbors(adata, n_neighbors=5, random_state=0)
+    assert "pca" in adata.uns and adata.obsm["X_pca"].shape == (700, 50)
