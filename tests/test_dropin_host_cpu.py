@@ -33,6 +33,26 @@ def _cpu_kernel_layer(monkeypatch):
         return ol.modularity(adj, membership.numpy(), resolution=resolution)
 
     _kernels.modularity = modularity
+
+    def _graph_tensors(m):
+        m = m.tocsr()
+        m.sort_indices()
+        return (torch.from_numpy(m.indptr.astype(np.int64)), torch.from_numpy(m.indices.astype(np.int32)),
+                torch.from_numpy(m.data.astype(np.float32)))
+
+    def gauss_connectivities(knn_idx, knn_dist):
+        from oracle import connectivities as oc
+
+        return _graph_tensors(oc.gauss_knn(knn_idx.numpy(), knn_dist.numpy(), knn_idx.shape[0]))
+
+    def jaccard_connectivities(knn_idx):
+        from oracle import connectivities as oc
+
+        return _graph_tensors(oc.jaccard_knn(knn_idx.numpy(), knn_idx.shape[0], knn_idx.shape[1]))
+
+    saved.update({name: getattr(_kernels, name) for name in ("gauss_connectivities", "jaccard_connectivities")})
+    _kernels.gauss_connectivities = gauss_connectivities
+    _kernels.jaccard_connectivities = jaccard_connectivities
     yield
     for name, fn in saved.items():
         setattr(_kernels, name, fn)
@@ -275,3 +295,41 @@ def test_neighbors_without_previous_pca_run(sc, pbmc68k):
     with pytest.warns(UserWarning, match=r".*Falling back to preprocessing with `sc.pp.pca` and default params"):
         sc.pp.neighbors(adata, n_neighbors=5, random_state=0)
     assert "pca" in adata.uns and adata.obsm["X_pca"].shape == (700, 50)
+
+
+# ---- tests/test_neighbors.py semantics ------------------------------------------------------------------------------
+@pytest.mark.parametrize("method", ["umap", "gauss", "jaccard"])
+def test_distances_and_connectivities_by_method(sc, neighbors_toy, method):
+    """tests/test_neighbors.py:151-164, 196-227: the three connectivity kernels share the distances; each reproduces its
+    golden matrix"""
+    k = int(neighbors_toy["n_neighbors"])
+    adata = sc.AnnData(neighbors_toy["X"])
+    sc.pp.neighbors(adata, n_neighbors=k, method=method)
+    np.testing.assert_allclose(adata.obsp["distances"].toarray(), neighbors_toy["distances_euclidean"])
+    golden = {"umap": "connectivities_umap", "gauss": "connectivities_gauss_knn", "jaccard": "connectivities_jaccard"}[method]
+    np.testing.assert_allclose(adata.obsp["connectivities"].toarray(), neighbors_toy[golden], rtol=1e-6)
+    with pytest.raises(ValueError, match="`method` needs to be one of"):
+        sc.pp.neighbors(adata, n_neighbors=k, method="rbf")
+
+
+def test_use_rep_argument(sc):
+    """tests/test_neighbors.py:251-261"""
+    adata = sc.AnnData(np.random.default_rng(0).standard_normal((30, 300)).astype(np.float32))
+    sc.pp.pca(adata, n_comps=20)
+    a = sc.Neighbors(adata)
+    a.compute_neighbors(n_pcs=5, use_rep="X_pca")
+    b = sc.Neighbors(adata)
+    b.compute_neighbors(n_pcs=5, use_rep=None)
+    np.testing.assert_allclose(a.distances.toarray(), b.distances.toarray())
+
+
+def test_neighbors_distance_equivalence(sc, pbmc68k):
+    """tests/test_neighbors.py:275-296: `distances=` reuses a distance matrix; only `metric` differs in the params"""
+    adata = sc.AnnData(pbmc68k["X"], obsm={"X_pca": pbmc68k["X_pca"]})
+    adata_d = adata.copy()
+    sc.pp.neighbors(adata)
+    sc.pp.neighbors(adata_d, distances=adata.obsp["distances"])
+    np.testing.assert_allclose(adata.obsp["connectivities"].toarray(), adata_d.obsp["connectivities"].toarray(), rtol=1e-5)
+    np.testing.assert_allclose(adata.obsp["distances"].toarray(), adata_d.obsp["distances"].toarray(), rtol=1e-5)
+    p, p_d = (ad.uns["neighbors"]["params"].copy() for ad in (adata, adata_d))
+    assert p.pop("metric") == "euclidean" and p_d.pop("metric") is None and p == p_d
