@@ -80,7 +80,9 @@ def _single_batch(be, m, var_names, *, n_rows: int, row_mask, filter_unexpressed
         bins = n_bins
     else:
         bins = np.r_[-np.inf, np.percentile(df["means"], np.arange(10, 105, 5)), np.inf]
-    df["mean_bin"] = pd.cut(df["means"], bins=bins)
+    rv = pd.cut(df["means"], bins=bins)
+    # like the reference (`:464-467`): interval categories as strings; the column is part of the `inplace=False` result
+    df["mean_bin"] = rv.cat.set_categories(rv.cat.categories.astype("string"), rename=True)
     # per-bin statistics of the dispersions through pandas, like the reference (`_get_disp_stats`, `:470-482`): ties at
     # the `n_top_genes` cut-off (two-gene bins give +-1/sqrt(2) exactly) then break the same way
     grouped = df.groupby("mean_bin", observed=True)["dispersions"]
@@ -93,7 +95,6 @@ def _single_batch(be, m, var_names, *, n_rows: int, row_mask, filter_unexpressed
         stats = grouped.agg(avg="median", dev=_mad)
     per_gene = stats.loc[df["mean_bin"]].set_index(df.index)
     df["dispersions_norm"] = (df["dispersions"] - per_gene["avg"]) / per_gene["dev"]
-    df = df.drop(columns="mean_bin")
     dn = df["dispersions_norm"].to_numpy()
     if isinstance(cutoff, _Cutoffs):  # `_subset_genes` (`:515-537`)
         hv = cutoff.in_bounds(mean, np.nan_to_num(dn))

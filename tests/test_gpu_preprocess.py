@@ -131,3 +131,11 @@ def test_filters(typ):
 @pytest.mark.parametrize("typ", TYPES, ids=lambda t: t.__name__)
 def test_rep_mutation(typ):
     host.check_rep_mutation(typ)
+
+
+def test_hvg_reference_semantics():
+    host.check_hvg_reference_semantics()
+
+
+def test_hvg_keeps_the_matrix(pbmc68k):
+    host.check_hvg_keeps_the_matrix(pbmc68k)

@@ -307,3 +307,78 @@ class warnings_ignored:
 @pytest.mark.parametrize("typ", TYPES, ids=lambda t: t.__name__)
 def test_rep_mutation(typ):
     check_rep_mutation(typ)
+
+
+# ---- tests/test_highly_variable_genes.py:47-118 semantics (blobs-like data, as sc.datasets.blobs()) -----------------------
+def _blobs_adata():
+    from sklearn.datasets import make_blobs
+
+    x, _ = make_blobs(n_samples=640, n_features=11, centers=5, cluster_std=1.0, random_state=0)
+    return sc.AnnData(x.astype(np.float32))
+
+
+def check_hvg_reference_semantics():
+    with warnings_ignored():
+        adata = _blobs_adata()
+        sc.pp.highly_variable_genes(adata)  # test_runs
+        no_batch = adata.var["highly_variable"].copy()
+        gen = np.random.default_rng(0)
+        adata.obs["batch"] = pd.Categorical(gen.binomial(3, 0.5, size=adata.n_obs))
+        sc.pp.highly_variable_genes(adata, batch_key="batch")  # test_supports_batch
+        assert {"highly_variable_nbatches", "highly_variable_intersection"} <= set(adata.var.columns)
+        # test_no_batch_matches_batch: one batch == no batch
+        one = _blobs_adata()
+        one.obs["batch"] = pd.Categorical(["batch"] * one.n_obs)
+        sc.pp.highly_variable_genes(one, batch_key="batch")
+        assert np.all(no_batch.to_numpy() == one.var["highly_variable"].to_numpy())
+        assert np.all(one.var["highly_variable_intersection"].to_numpy() == one.var["highly_variable"].to_numpy())
+
+        # test_supports_layers: the layer, not X, is analysed
+        def execute(layer):
+            g2 = np.random.default_rng(0)
+            a = _blobs_adata()
+            if layer:
+                shuffled = a.X.copy()
+                g2.shuffle(shuffled)
+                a.layers[layer] = shuffled
+                a.X = np.zeros_like(a.X)
+            a.obs["batch"] = pd.Categorical(g2.binomial(4, 0.5, size=a.n_obs))
+            sc.pp.highly_variable_genes(a, batch_key="batch", n_top_genes=3, layer=layer)
+            assert "highly_variable_nbatches" in a.var.columns and int(a.var["highly_variable"].sum()) == 3
+            return a
+
+        a1, a2 = execute(None), execute("test_layer")
+        assert (a1.var["highly_variable"].to_numpy() != a2.var["highly_variable"].to_numpy()).any()
+        # test_no_inplace: columns of the returned frame
+        for batch_key in (None, "batch"):
+            a = _blobs_adata()
+            if batch_key:
+                a.obs[batch_key] = np.tile(["a", "b"], a.n_obs // 2)
+            df = sc.pp.highly_variable_genes(a, batch_key=batch_key, n_bins=3, inplace=False)
+            cols = {"means", "dispersions", "dispersions_norm", "highly_variable"} | (
+                {"mean_bin"} if batch_key is None else {"highly_variable_nbatches", "highly_variable_intersection"})
+            assert isinstance(df, pd.DataFrame) and set(df.columns) == cols
+
+
+def check_hvg_keeps_the_matrix(pbmc68k):
+    """tests/test_highly_variable_genes.py:118-137 (`test_keep_layer`): annotating does not touch X"""
+    for base in (None, 10):
+        for flavor in ("seurat", "cell_ranger"):
+            adata = sc.AnnData(pbmc68k["counts"].astype(np.float32))
+            sc.pp.filter_genes(adata, min_counts=1)
+            sc.pp.log1p(adata, base=base)
+            assert sparse.issparse(adata.X)
+            x_orig = adata.X.copy()
+            if flavor == "seurat":
+                sc.pp.highly_variable_genes(adata, n_top_genes=50, flavor=flavor)
+            else:
+                sc.pp.highly_variable_genes(adata, flavor=flavor)
+            assert np.allclose(x_orig.toarray(), adata.X.toarray())
+
+
+def test_hvg_reference_semantics():
+    check_hvg_reference_semantics()
+
+
+def test_hvg_keeps_the_matrix(pbmc68k):
+    check_hvg_keeps_the_matrix(pbmc68k)
