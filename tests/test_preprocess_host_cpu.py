@@ -382,3 +382,48 @@ def test_hvg_reference_semantics():
 
 def test_hvg_keeps_the_matrix(pbmc68k):
     check_hvg_keeps_the_matrix(pbmc68k)
+
+
+def check_hvg_batches(pbmc68k):
+    """tests/test_highly_variable_genes.py:513-569 (`test_batches`): the batched result is the per-batch result averaged,
+    genes unexpressed in a batch count as zeros there; :572-580 degenerate batches run; :598-610 n_top_genes warning"""
+    x = pbmc68k["X"].copy()  # the scaled matrix of the fixture, like the reference test
+    x[:100, :100] = 0.0
+    adata = sc.AnnData(x)
+    adata.obs["batch"] = ["0" if i < 100 else "1" for i in range(adata.n_obs)]
+    a1 = sc.AnnData(x[:100].copy())
+    a2 = sc.AnnData(x[100:].copy())
+    with warnings_ignored():
+        sc.pp.highly_variable_genes(adata, batch_key="batch", flavor="cell_ranger", n_top_genes=200)
+        sc.pp.filter_genes(a1, min_cells=1)
+        sc.pp.filter_genes(a2, min_cells=1)
+        hvg1 = sc.pp.highly_variable_genes(a1, flavor="cell_ranger", n_top_genes=200, inplace=False)
+        hvg2 = sc.pp.highly_variable_genes(a2, flavor="cell_ranger", n_top_genes=200, inplace=False)
+    dn = adata.var["dispersions_norm"]
+    # gene 100 is the first gene expressed in batch 0 (genes 0..99 were zeroed there and filtered out of hvg1)
+    first_kept = int(np.flatnonzero((x[:100] > 0).sum(axis=0) >= 1)[0])
+    assert first_kept >= 100
+    pos1 = {g: i for i, g in enumerate(a1.var_names)}
+    pos2 = {g: i for i, g in enumerate(a2.var_names)}
+    for g in (first_kept, first_kept + 1):
+        name = adata.var_names[g]
+        np.testing.assert_allclose(dn.iloc[g], 0.5 * hvg1["dispersions_norm"].iloc[pos1[name]]
+                                   + 0.5 * hvg2["dispersions_norm"].iloc[pos2[name]], rtol=1e-6, atol=1e-6)
+    name0 = adata.var_names[0]
+    if name0 in pos2:
+        np.testing.assert_allclose(dn.iloc[0], 0.5 * hvg2["dispersions_norm"].iloc[pos2[name0]], rtol=1e-6, atol=1e-6)
+    assert {"means", "dispersions", "dispersions_norm", "highly_variable"} <= set(hvg1.columns)
+    rng = np.random.default_rng(0)
+    deg = sc.AnnData(rng.standard_normal((10, 100)).astype(np.float32))
+    deg.obs["batch"] = pd.Categorical([*([1] * 4), *([2] * 5), 3])
+    with warnings_ignored():
+        sc.pp.highly_variable_genes(deg, batch_key="batch")
+    small = sc.AnnData(rng.poisson(2, (100, 30)).astype(np.float32))
+    sc.pp.normalize_total(small)
+    sc.pp.log1p(small)
+    with pytest.warns(UserWarning, match="`n_top_genes`.*> number of normalized dispersions.*returning all genes with normalized dispersions."):
+        sc.pp.highly_variable_genes(small, n_top_genes=1000, flavor="cell_ranger")
+
+
+def test_hvg_batches(pbmc68k):
+    check_hvg_batches(pbmc68k)
