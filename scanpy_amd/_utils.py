@@ -112,3 +112,13 @@ def as_csr_f32(x):
     if not x.has_sorted_indices:
         x = x.sorted_indices()
     return x
+
+
+def view_to_actual(adata) -> None:
+    """src/scanpy/_utils/__init__.py:474-478: in-place functions turn a view into an actual AnnData first."""
+    if getattr(adata, "is_view", False):
+        warnings.warn("Received a view of an AnnData. Making a copy.", UserWarning, stacklevel=3)
+        if hasattr(adata, "_init_as_actual"):  # a real anndata.AnnData
+            adata._init_as_actual(adata.copy())
+        else:  # the stand-in: its views already own their arrays
+            adata.is_view = False

@@ -10,6 +10,7 @@ import numpy as np
 from scipy import sparse
 
 from .._anndata import is_anndata
+from .._utils import view_to_actual
 from . import _csr_device
 from ._pca import _get_arr
 
@@ -56,6 +57,7 @@ def normalize_total(  # noqa: PLR0912
         adata = adata.copy()
     if max_fraction < 0 or max_fraction > 1:
         raise ValueError("Choose max_fraction between 0 and 1.")
+    view_to_actual(adata)  # `_normalization.py:264`
     x = _get_arr(adata, layer=layer, obsm=obsm)
     be = _csr_device.default_backend()
     m = be.upload(x)  # CSC -> CSR like the reference (`:266-267`); integers -> float32 (`:271-272`)

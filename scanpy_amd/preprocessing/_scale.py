@@ -11,6 +11,7 @@ import numpy as np
 from scipy import sparse
 
 from .._anndata import is_anndata
+from .._utils import view_to_actual
 from . import _csr_device
 from ._normalization import _set_obs_rep
 from ._pca import _check_mask, _get_arr
@@ -63,6 +64,7 @@ def scale(data, *, zero_center: bool = True, max_value: float | None = None, cop
         else:
             str_mean_std = ("mean with mask", "std with mask")
         mask_obs = _check_mask(adata, mask_obs, "obs")
+    view_to_actual(adata)  # `_scale.py:315`
     x = _get_arr(adata, layer=layer, obsm=obsm)
     out, mean, std = _scale_matrix(x, zero_center=zero_center, max_value=max_value, mask_obs=mask_obs)
     adata.var[str_mean_std[0]] = mean

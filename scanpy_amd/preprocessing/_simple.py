@@ -8,6 +8,7 @@ import numpy as np
 from scipy import sparse
 
 from .._anndata import is_anndata
+from .._utils import view_to_actual
 from . import _csr_device
 from ._normalization import _set_obs_rep
 from ._pca import _get_arr
@@ -36,6 +37,7 @@ def log1p(data, *, base=None, copy: bool = False, chunked: bool | None = None, c
     if "log1p" in adata.uns:
         logging.getLogger("scanpy_amd").warning("adata.X seems to be already log-transformed.")  # `logg.warning`, `:393-394`
     adata = adata.copy() if copy else adata
+    view_to_actual(adata)  # `_simple.py:397`
     if chunked:
         msg = "chunked log1p is not implemented on the MI355X path: the whole matrix is transformed in one device pass"
         raise NotImplementedError(msg)

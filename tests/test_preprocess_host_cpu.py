@@ -427,3 +427,17 @@ def check_hvg_batches(pbmc68k):
 
 def test_hvg_batches(pbmc68k):
     check_hvg_batches(pbmc68k)
+
+
+def test_views_are_actualised_with_a_warning():
+    """tests/test_normalization.py:85-95 (`test_normalize_total_view`) and the same rule for log1p / scale"""
+    x = np.array([[1, 0], [3, 0], [5, 6]], dtype=np.float32)
+    for func, kw in ((sc.pp.normalize_total, {}), (sc.pp.log1p, {}), (sc.pp.scale, dict(zero_center=False))):
+        adata = sc.AnnData(x.copy())
+        v = adata[:, :]
+        assert v.is_view
+        with pytest.warns(UserWarning, match=r"Received a view"):
+            func(v, **kw)
+        func(adata, **kw)
+        assert not v.is_view
+        np.testing.assert_array_equal(_dense(adata.X), _dense(v.X))
