@@ -13,6 +13,8 @@ from . import tools as tl
 from ._anndata import AnnData
 from ._settings import settings
 from .neighbors import MI355XKNNTransformer, Neighbors
+from .readwrite import read_zarr, write_zarr
 
-__all__ = ["pp", "tl", "metrics", "AnnData", "settings", "Neighbors", "MI355XKNNTransformer"]
+__all__ = ["pp", "tl", "metrics", "AnnData", "settings", "Neighbors", "MI355XKNNTransformer", "read_zarr",
+           "write_zarr"]
 __version__ = "0.1.0"

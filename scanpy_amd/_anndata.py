@@ -15,7 +15,7 @@ from scipy import sparse
 
 class AnnData:
     def __init__(self, X=None, obs=None, var=None, *, obsm=None, varm=None, obsp=None, uns=None, layers=None):
-        if X is not None and not sparse.issparse(X):
+        if X is not None and not sparse.issparse(X) and not getattr(X, "is_backed", False):  # `_backed.BackedCsr`
             X = np.asarray(X)
         self.X = X
         n_obs, n_vars = X.shape if X is not None else (len(obs), len(var))

@@ -16,7 +16,7 @@ from dataclasses import dataclass, field
 import torch
 
 from . import _kernels
-from .preprocessing._pca_solver import GpuBackend, NoComm, pca_fit
+from .preprocessing._pca_solver import GpuBackend, NoComm, _ChunkedRows, pca_fit
 
 
 @dataclass
@@ -94,7 +94,9 @@ def shard_bounds(n_total: int, world_size: int, rank: int) -> tuple[int, int]:
 def run_path(a_handle, n_total: int, *, comm=None, backend=None, n_comps: int = 50, n_neighbors: int = 15,
              resolution: float = 1.0, n_iterations: int = -1, seed: int = 0, svd_solver: str = "arpack",
              timing: bool = False) -> PathResult:
-    """`a_handle` = `GpuBackend.upload(csr_rows_of_this_rank)`; rows of rank r are shard_bounds(n_total, W, r)."""
+    """`a_handle` = `GpuBackend.upload(csr_rows_of_this_rank)`; rows of rank r are shard_bounds(n_total, W, r).
+    Out of core: a `_ChunkedRows` over this rank's rows instead (e.g. `BackedCsr.row_chunks(step, row_begin, row_end)`
+    of an on-disk matrix: every rank streams only its own block from the store)."""
     comm = comm or NoComm()
     backend = backend or GpuBackend()
     tm = _Timer(timing)
@@ -102,7 +104,8 @@ def run_path(a_handle, n_total: int, *, comm=None, backend=None, n_comps: int = 
     world, rank = comm.world_size, comm.rank
     counts = [shard_bounds(n_total, world, r)[1] - shard_bounds(n_total, world, r)[0] for r in range(world)]
     row_begin, row_end = shard_bounds(n_total, world, rank)
-    assert a_handle[3] == row_end - row_begin, "shard does not match shard_bounds()"
+    n_local = a_handle.n_rows if isinstance(a_handle, _ChunkedRows) else a_handle[3]
+    assert n_local == row_end - row_begin, "shard does not match shard_bounds()"
 
     res = pca_fit(a_handle, n_comps, backend=backend, comm=comm, svd_solver=svd_solver, seed=seed)
     tm.mark("pca")

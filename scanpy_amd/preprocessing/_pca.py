@@ -8,6 +8,7 @@ import numpy as np
 from scipy import sparse
 
 from .._anndata import AnnData, is_anndata
+from .._backed import is_backed
 from .._settings import settings
 from .._utils import _UNSET, as_csr_f32, resolve_seed
 
@@ -102,12 +103,17 @@ def pca(  # noqa: PLR0912, PLR0913, PLR0915
     if mask is not None:
         x = x[:, mask]
     n_obs, n_vars = x.shape
+    backed = is_backed(x)  # an on-disk CSR matrix (`read_zarr(..., backed='r')`): streamed through the device by rows
+    if backed and not zero_center:
+        raise ValueError("a backed matrix is streamed through the chunked PCA, which centres the data: pass "
+                         "zero_center=True (the default)")
+    chunked = chunked or backed
 
     if n_comps is None:  # _pca/__init__.py:234-236
         min_dim = min(n_vars, n_obs)
         n_comps = min_dim - 1 if min_dim <= settings.N_PCS else settings.N_PCS
 
-    is_sparse = sparse.issparse(x)
+    is_sparse = sparse.issparse(x) or backed
     if svd_solver in {"auto", "randomized"} and not is_sparse:
         pass  # reference only logs a reproducibility note here (_pca/__init__.py:207-212)
     if svd_solver is None:
@@ -138,7 +144,6 @@ def pca(  # noqa: PLR0912, PLR0913, PLR0915
         # holds two chunks at a time unless everything fits, in which case the chunks stay resident between passes.
         from ._pca_solver import CsrRowsView, _ChunkedRows
 
-        xc = as_csr_f32(x)
         step = int(chunk_size) if chunk_size is not None else 1_000_000
         if step < 1:
             raise ValueError("chunk_size must be a positive number of observations")
@@ -146,8 +151,12 @@ def pca(  # noqa: PLR0912, PLR0913, PLR0915
 
         # SCAMD_PCA_CHUNK_RESIDENT=0 forces the streaming mode (every pass uploads again) whatever the free memory
         budget = 0 if os.environ.get("SCAMD_PCA_CHUNK_RESIDENT") == "0" else int(0.4 * torch_free_bytes())
-        rows = _ChunkedRows([CsrRowsView(xc, i, min(i + step, n_obs)) for i in range(0, n_obs, step)], n_vars,
-                            resident_budget_bytes=budget)
+        if backed:  # lazy row chunks: read + decompressed by a reader thread one chunk ahead of the device
+            host_chunks = x.row_chunks(step)
+        else:
+            xc = as_csr_f32(x)
+            host_chunks = [CsrRowsView(xc, i, min(i + step, n_obs)) for i in range(0, n_obs, step)]
+        rows = _ChunkedRows(host_chunks, n_vars, resident_budget_bytes=budget)
         res = pca_fit(rows, n_comps, backend=backend, zero_center=zero_center, svd_solver=svd_solver, seed=seed)
     else:
         res = pca_fit(backend.upload(as_csr_f32(x)), n_comps, backend=backend, zero_center=zero_center,

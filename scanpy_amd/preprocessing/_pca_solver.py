@@ -84,6 +84,8 @@ class GpuBackend:
         self.K = _kernels
         self.device = require_gpu()
 
+    upload_copies = True  # `upload` returns once the host arrays have been copied: the caller may overwrite them
+
     def upload(self, x_csr):
         ip = torch.from_numpy(np.ascontiguousarray(x_csr.indptr, dtype=np.int64)).to(self.device)
         ix = torch.from_numpy(np.ascontiguousarray(x_csr.indices, dtype=np.int32)).to(self.device)
@@ -302,16 +304,58 @@ class _ChunkedRows:
         self.n_chunks = len(self._host)
         self.n_rows = int(sum(c.shape[0] for c in self._host))
         self.n_cols = int(n_cols)
-        nbytes = sum(c.data.nbytes + c.indices.nbytes + 8 * (c.shape[0] + 1) for c in self._host)
+        nbytes = sum(c.nbytes if hasattr(c, "nbytes") else c.data.nbytes + c.indices.nbytes + 8 * (c.shape[0] + 1)
+                     for c in self._host)
         self.resident = nbytes <= resident_budget_bytes
         self._cached = None
+        # chunks with a `load()` (rows of an on-disk matrix, `_backed.LazyRows`) are materialised by a reader thread,
+        # one chunk ahead of the upload: disk + decompression of chunk i + 2 overlap the copy of i + 1 and the kernels of i
+        self._lazy = any(hasattr(c, "load") for c in self._host)
+        self._ring = None
 
     @classmethod
     def single(cls, handle):
         self = cls.__new__(cls)
         self._host, self.n_chunks, self.n_rows, self.n_cols = [], 1, handle[3], handle[4]
-        self.resident, self._cached = True, [handle]
+        self.resident, self._cached, self._lazy, self._ring = True, [handle], False, None
         return self
+
+    def host_absmax(self) -> float | None:
+        """max |x| without a pass through the device, when every chunk is a row range of ONE on-disk matrix that can
+        answer from its value array (`_backed.BackedCsr.absmax`); float32 maxima are exact, so nothing changes"""
+        if self._cached is not None or not self._host or not all(hasattr(c, "load") for c in self._host):
+            return None
+        owners = {id(getattr(c, "x", None)) for c in self._host}
+        x = getattr(self._host[0], "x", None)
+        if len(owners) != 1 or not hasattr(x, "absmax") or sum(c.shape[0] for c in self._host) != x.shape[0]:
+            return None
+        return x.absmax()
+
+    def _host_chunks(self, recycle: bool):
+        """host chunks in order; lazy ones are loaded by a reader thread one ahead of the consumer.  `recycle`: the
+        consumer is done with chunk i before it asks for chunk i + 1 (an upload that COPIES), so two buffer pairs can
+        be reused in turn -- chunk i + 1 is decoded into one while chunk i is copied out of the other."""
+        if not self._lazy:
+            yield from self._host
+            return
+        from concurrent.futures import ThreadPoolExecutor
+
+        if recycle and self._ring is None and all(hasattr(c, "buffers") for c in self._host):
+            most = max(c.nnz for c in self._host)
+            self._ring = [self._host[0].buffers(most) for _ in range(min(2, self.n_chunks))]
+
+        def load(i):
+            c = self._host[i]
+            if not hasattr(c, "load"):
+                return c
+            return c.load(out=self._ring[i % len(self._ring)]) if recycle and self._ring else c.load()
+
+        with ThreadPoolExecutor(max_workers=1, thread_name_prefix="scamd-rows") as ex:
+            fut = ex.submit(load, 0)
+            for i in range(self.n_chunks):
+                nxt = ex.submit(load, i + 1) if i + 1 < self.n_chunks else None
+                yield fut.result()
+                fut = nxt
 
     def handles(self, backend):
         if self._cached is not None:
@@ -319,7 +363,8 @@ class _ChunkedRows:
             return
         keep = [] if self.resident else None
         upload = backend.upload_prefetch if hasattr(backend, "upload_prefetch") else backend.upload
-        nxt = upload(self._host[0])
+        host = self._host_chunks(recycle=bool(getattr(backend, "upload_copies", False)))
+        nxt = upload(next(host))
         for i in range(self.n_chunks):
             cur = nxt
             if hasattr(backend, "wait_prefetch"):
@@ -329,7 +374,8 @@ class _ChunkedRows:
                 keep.append(cur)
             yield cur  # the caller enqueues this chunk's kernels ...
             if i + 1 < self.n_chunks:
-                nxt = upload(self._host[i + 1])  # ... and the next upload overlaps them
+                nxt = upload(next(host))  # ... and the next upload overlaps them
+        host.close()
         if keep is not None:
             self._cached = keep
 
@@ -345,9 +391,11 @@ def _pca_fit_gram(a, n_comps: int, backend, comm, zero_center: bool, seed: int, 
     if g > GRAM_MAX_GENES or not hasattr(backend, "gram"):
         return None
     dev = backend.device
-    absmax_local = 0.0
-    for h in chunks.handles(backend):
-        absmax_local = max(absmax_local, backend.absmax(h))
+    absmax_local = chunks.host_absmax()  # an on-disk matrix answers from its `data` array alone
+    if absmax_local is None:
+        absmax_local = 0.0
+        for h in chunks.handles(backend):
+            absmax_local = max(absmax_local, backend.absmax(h))
     meta = torch.tensor([float(n_local), absmax_local], dtype=torch.float64, device=dev)
     nt = meta[:1].clone()
     mx = meta[1:].clone()

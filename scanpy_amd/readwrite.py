@@ -1,0 +1,236 @@
+"""`read_zarr` / `write_zarr` for AnnData `.zarr` stores (zarr format 3), with an out-of-core mode for `X`.
+
+The reference re-exports anndata's functions (`src/scanpy/readwrite.py:23-25`; dispatch on the extension at `:837-841`,
+writing at `:720-726`).  anndata and zarr-python are not in this image, so the on-disk element encodings are restated
+from the anndata on-disk format specification ("encoding-type" / "encoding-version" attributes on every node):
+
+    anndata      group {X, layers, obs, var, obsm, varm, obsp, varp, uns, raw}
+    array        zarr array                 string-array   zarr array of data_type "string" (vlen-utf8)
+    rec-array    zarr array of a `struct` data type
+    csr_matrix / csc_matrix   group {data, indices, indptr}, attribute shape
+    dataframe    group, attributes _index, column-order; one child per column + the index
+    categorical  group {categories, codes}, attribute ordered
+    dict         group                      numeric-scalar / string   0-d arrays
+    nullable-integer / nullable-boolean     group {values, mask}
+
+and pinned against the store that anndata itself wrote for the reference (`datasets/10x_pbmc68k_reduced.zarr.zip`,
+tests/test_readwrite_zarr_cpu.py).  `backed='r'` leaves a CSR `X` on disk as a `_backed.BackedCsr`, which
+`pp.pca` streams through the device by row chunks (the role of `anndata.experimental.read_elem_lazy` in
+`docs/tutorials/experimental/dask.ipynb:843-879`).
+"""
+from __future__ import annotations
+
+import warnings
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+from scipy import sparse
+
+from . import _zarr3 as z3
+from ._anndata import AnnData
+from ._backed import BackedCsr, is_backed
+
+# ---------------------------------------------------------------------------------------------------------------------
+# reading
+
+
+def _read_sparse(group):
+    cls = sparse.csr_matrix if group.attrs["encoding-type"] == "csr_matrix" else sparse.csc_matrix
+    shape = tuple(int(s) for s in group.attrs["shape"])
+    return cls((group["data"].read(), group["indices"].read(), group["indptr"].read()), shape=shape)
+
+
+def _read_dataframe(group) -> pd.DataFrame:
+    index = read_elem(group[group.attrs["_index"]])
+    cols = {}
+    for name in group.attrs.get("column-order", []):
+        col = read_elem(group[name])
+        if col is not None:
+            cols[name] = col
+    df = pd.DataFrame(cols, index=pd.Index(np.asarray(index, dtype=object)))
+    name = group.attrs["_index"]
+    df.index.name = None if name in {"_index", "index"} else name
+    return df
+
+
+def read_elem(node):
+    """One element of the store -> its in-memory value (None + a warning for an encoding that is not read here)."""
+    enc = node.attrs.get("encoding-type")
+    if isinstance(node, z3.Array):
+        if enc in {"numeric-scalar", "string"} or node.ndim == 0:
+            v = node.read()[()]
+            return str(v) if node.is_string else v
+        if enc in {None, "array", "string-array", "rec-array"}:
+            return node.read()
+        warnings.warn(f"skipping {node.path!r}: array encoding {enc!r} is not read here", UserWarning, stacklevel=2)
+        return None
+    if enc in {"csr_matrix", "csc_matrix"}:
+        return _read_sparse(node)
+    if enc == "dataframe":
+        return _read_dataframe(node)
+    if enc == "categorical":
+        cats = node["categories"].read()
+        return pd.Categorical.from_codes(node["codes"].read(), categories=pd.Index(cats),
+                                         ordered=bool(node.attrs.get("ordered", False)))
+    if enc in {"nullable-integer", "nullable-boolean"}:
+        values, mask = node["values"].read(), node["mask"].read().astype(bool)
+        if enc == "nullable-boolean":
+            return pd.arrays.BooleanArray(values.astype(bool), mask)
+        return pd.arrays.IntegerArray(values, mask)
+    if enc in {None, "dict", "anndata", "raw"}:
+        out = {}
+        for k in node.keys():
+            v = read_elem(node[k])
+            if v is not None:
+                out[k] = v
+        return out
+    warnings.warn(f"skipping {node.path!r}: group encoding {enc!r} is not read here", UserWarning, stacklevel=2)
+    return None
+
+
+def read_zarr(store, *, backed: str | None = None) -> AnnData:
+    """Read an AnnData `.zarr` directory or `.zarr.zip` (zarr format 3).
+
+    backed
+        None: everything in memory (like `anndata.read_zarr`).  'r': a CSR `X` stays on disk as a `BackedCsr`
+        (its `indptr` is loaded, 8 bytes per cell); `pp.pca` then streams it through the device by row chunks.
+    """
+    if backed not in {None, "r"}:
+        raise ValueError("backed must be None or 'r' (stores are never modified in place)")
+    st = z3.open_store(store)
+    root = z3.Group(st)
+    if root.attrs.get("encoding-type") not in {"anndata", None}:
+        raise ValueError(f"{store}: not an AnnData store (encoding-type {root.attrs.get('encoding-type')!r})")
+    x = None
+    if "X" in root:
+        xn = root["X"]
+        if backed and isinstance(xn, z3.Group):
+            if xn.attrs.get("encoding-type") != "csr_matrix":
+                raise ValueError("backed='r' streams rows of a csr_matrix; this store's X is a "
+                                 f"{xn.attrs.get('encoding-type')!r}")
+            x = BackedCsr(xn)
+        else:
+            x = read_elem(xn)
+    obs = read_elem(root["obs"]) if "obs" in root else None
+    var = read_elem(root["var"]) if "var" in root else None
+    kw = {k: (read_elem(root[k]) or {}) if k in root else {} for k in ("obsm", "varm", "obsp", "uns", "layers")}
+    adata = AnnData(x, obs, var, **kw)
+    if "varp" in root:
+        adata.varp = read_elem(root["varp"]) or {}
+    return adata
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# writing
+
+# elements of the CSR arrays per inner chunk / per shard object: 4 Mi values (16 MB of float32) decode in ~10 ms each
+# on one core, and 64 of them per object keep a 10M x 4k matrix (2e9 values) at ~8 objects per array
+CHUNK_ELEMS = 1 << 22
+CHUNKS_PER_SHARD = 64
+
+
+def _chunking(shape: tuple[int, ...], chunks) -> tuple[tuple[int, ...], tuple[int, ...]]:
+    if len(shape) == 0:
+        return (), ()
+    if chunks is not None and not np.isscalar(chunks) and len(tuple(chunks)) == len(shape):
+        c = tuple(int(v) for v in chunks)
+    else:  # (also: a 2-d `chunks=` request does not apply to the 1-d components of a sparse matrix)
+        row = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+        c = (max(1, min(shape[0], CHUNK_ELEMS // max(1, row))),) + tuple(shape[1:])
+    c = tuple(max(1, min(ci, max(1, s))) for ci, s in zip(c, shape))
+    n0 = -(-shape[0] // c[0]) if shape[0] else 1
+    shard = (c[0] * max(1, min(CHUNKS_PER_SHARD, n0)),) + c[1:]
+    return c, shard
+
+
+def _write_array(st, path: str, value, enc: str, version: str, chunks=None, level: int = 0) -> None:
+    arr = value if isinstance(value, np.ndarray) else np.asarray(value)
+    c, shard = _chunking(arr.shape, chunks)
+    z3.write_array(st, path, arr, chunk_shape=c, shard_shape=shard, level=level,
+                   attributes={"encoding-type": enc, "encoding-version": version} if enc else {})
+
+
+def _write_dataframe(st, path: str, df: pd.DataFrame, level: int) -> None:
+    index_key = df.index.name if df.index.name not in (None, "") else "_index"
+    if index_key in df.columns:
+        raise ValueError(f"the index name {index_key!r} is also a column")
+    z3.write_group(st, path, {"_index": index_key, "column-order": [str(c) for c in df.columns],
+                              "encoding-type": "dataframe", "encoding-version": "0.2.0"})
+    write_elem(st, f"{path}/{index_key}", np.asarray(df.index.astype(str), dtype=object), level=level)
+    for name in df.columns:
+        write_elem(st, f"{path}/{name}", df[name].array if isinstance(df[name].dtype, pd.CategoricalDtype)
+                   or pd.api.types.is_extension_array_dtype(df[name].dtype) else df[name].to_numpy(), level=level)
+
+
+def write_elem(st, path: str, value, *, chunks=None, level: int = 0) -> None:
+    """Write one in-memory value with the anndata encoding of its type."""
+    if is_backed(value):
+        value = value.to_memory()
+    if sparse.issparse(value):
+        fmt = value.format
+        if fmt not in {"csr", "csc"}:
+            value, fmt = value.tocsr(), "csr"
+        z3.write_group(st, path, {"shape": [int(s) for s in value.shape], "encoding-type": f"{fmt}_matrix",
+                                  "encoding-version": "0.1.0"})
+        _write_array(st, f"{path}/data", value.data, None, "", chunks, level)
+        _write_array(st, f"{path}/indices", value.indices, None, "", chunks, level)
+        _write_array(st, f"{path}/indptr", value.indptr, None, "", chunks, level)
+    elif isinstance(value, pd.DataFrame):
+        _write_dataframe(st, path, value, level)
+    elif isinstance(value, (pd.Categorical, pd.Series)) and isinstance(value.dtype, pd.CategoricalDtype):
+        cat = value if isinstance(value, pd.Categorical) else value.array
+        z3.write_group(st, path, {"ordered": bool(cat.ordered), "encoding-type": "categorical",
+                                  "encoding-version": "0.2.0"})
+        write_elem(st, f"{path}/categories", np.asarray(cat.categories), level=level)
+        _write_array(st, f"{path}/codes", np.asarray(cat.codes), "array", "0.2.0", None, level)
+    elif isinstance(value, (pd.arrays.IntegerArray, pd.arrays.BooleanArray)):
+        kind = "nullable-boolean" if isinstance(value, pd.arrays.BooleanArray) else "nullable-integer"
+        z3.write_group(st, path, {"encoding-type": kind, "encoding-version": "0.1.0"})
+        mask = np.asarray(value.isna())
+        fill = False if kind == "nullable-boolean" else 0
+        _write_array(st, f"{path}/values", value.to_numpy(dtype=value.dtype.numpy_dtype, na_value=fill), "array",
+                     "0.2.0", None, level)
+        _write_array(st, f"{path}/mask", mask, "array", "0.2.0", None, level)
+    elif isinstance(value, dict):
+        z3.write_group(st, path, {"encoding-type": "dict", "encoding-version": "0.1.0"})
+        for k, v in value.items():
+            if v is None:
+                continue
+            write_elem(st, f"{path}/{k}", v, level=level)
+    elif isinstance(value, str):
+        _write_array(st, path, np.asarray(value, dtype=object), "string", "0.2.0", None, level)
+    elif isinstance(value, (bool, int, float, np.generic)) and not isinstance(value, np.str_):
+        _write_array(st, path, np.asarray(value), "numeric-scalar", "0.2.0", None, level)
+    else:
+        if isinstance(value, pd.Series):
+            value = value.to_numpy()
+        arr = np.asarray(value)
+        if arr.dtype.names:
+            _write_array(st, path, arr, "rec-array", "0.2.0", None, level)
+        elif arr.dtype.kind in "OUS":
+            _write_array(st, path, arr.astype(object), "string" if arr.ndim == 0 else "string-array", "0.2.0",
+                         chunks if arr.ndim else None, level)
+        elif arr.dtype.kind in "biuf":
+            _write_array(st, path, arr, "numeric-scalar" if arr.ndim == 0 else "array", "0.2.0",
+                         chunks if arr.ndim == 2 else None, level)
+        else:
+            raise TypeError(f"cannot write {path!r}: values of dtype {arr.dtype} have no encoding here")
+
+
+def write_zarr(store, adata, *, chunks=None, level: int = 0) -> None:
+    """Write `adata` as an AnnData `.zarr` directory (zarr format 3, zstd, `sharding_indexed`), readable by
+    `anndata.read_zarr`.  `chunks` = chunk shape of a dense `X` (anndata's `write_zarr(chunks=...)`); CSR components
+    are cut into 4 Mi-element chunks, 64 per shard object, so that row ranges decode in parallel."""
+    path = Path(store)
+    if path.suffix == ".zip":
+        raise ValueError("write a directory store (zip it afterwards if needed)")
+    st = z3.open_store(path, "w")
+    z3.write_group(st, "", {"encoding-type": "anndata", "encoding-version": "0.1.0"})
+    if adata.X is not None:
+        write_elem(st, "X", adata.X, chunks=chunks, level=level)
+    write_elem(st, "obs", adata.obs, level=level)
+    write_elem(st, "var", adata.var, level=level)
+    for name in ("obsm", "varm", "obsp", "varp", "layers", "uns"):
+        write_elem(st, name, dict(getattr(adata, name, None) or {}), level=level)
+    st.close()

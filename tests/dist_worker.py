@@ -75,7 +75,16 @@ def run(rank: int, world: int, init_file: str, out_dir: str, n: int, g: int, n_c
                    ratio=res.explained_variance_ratio, mean=res.mean, lo=lo, hi=hi)
     else:
         _patch_kernels()
-        res = run_path(be.upload(x), n, comm=comm, backend=be, n_comps=n_comps, n_neighbors=10)
+        if mode == "path_backed":  # every rank streams its own row block from the store the test wrote
+            import scanpy_amd as sc
+            from scanpy_amd.preprocessing._pca_solver import _ChunkedRows
+
+            b = sc.read_zarr(Path(out_dir) / "store.zarr", backed="r").X
+            assert (b.rows(lo, hi).to_scipy() != x).nnz == 0
+            a = _ChunkedRows(b.row_chunks(173, lo, hi), g)
+        else:
+            a = be.upload(x)
+        res = run_path(a, n, comm=comm, backend=be, n_comps=n_comps, n_neighbors=10)
         out = dict(scores=res.x_pca.numpy(), knn_idx=res.knn_indices.numpy(), knn_dist=res.knn_distances.numpy(),
                    labels=res.labels.numpy(), q=res.modularity, nc=res.n_communities, lo=lo, hi=hi,
                    has_graph=res.conn_indptr is not None)

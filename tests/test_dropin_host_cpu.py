@@ -333,3 +333,33 @@ def test_neighbors_distance_equivalence(sc, pbmc68k):
     np.testing.assert_allclose(adata.obsp["distances"].toarray(), adata_d.obsp["distances"].toarray(), rtol=1e-5)
     p, p_d = (ad.uns["neighbors"]["params"].copy() for ad in (adata, adata_d))
     assert p.pop("metric") == "euclidean" and p_d.pop("metric") is None and p == p_d
+
+
+@pytest.mark.parametrize("chunk_size", [None, 256, 97])
+@pytest.mark.parametrize("masked", [False, True])
+def test_pca_streams_a_backed_zarr_matrix(sc, pbmc68k, tmp_path, monkeypatch, chunk_size, masked):
+    """`read_zarr(backed='r')` leaves X on disk; `pp.pca` streams its row chunks (reader thread ->
+    upload -> Gram / projection passes) and reproduces the in-memory fit bit for bit, `highly_variable` mask included"""
+    from scipy import sparse
+
+    from scanpy_amd import readwrite as rw
+    from scanpy_amd._backed import BackedCsr
+
+    monkeypatch.setattr(rw, "CHUNK_ELEMS", 5003)  # many inner chunks and several shard objects at this size
+    monkeypatch.setattr(rw, "CHUNKS_PER_SHARD", 4)
+    x = sparse.csr_matrix(np.maximum(pbmc68k["X"], 0).astype(np.float32))
+    a = sc.AnnData(x)
+    if masked:
+        a.var["highly_variable"] = np.arange(x.shape[1]) % 3 != 0
+    sc.write_zarr(tmp_path / "a.zarr", a)
+    b = sc.read_zarr(tmp_path / "a.zarr", backed="r")
+    assert isinstance(b.X, BackedCsr)
+    sc.pp.pca(a, n_comps=20)
+    sc.pp.pca(b, n_comps=20, chunk_size=chunk_size)
+    assert isinstance(b.X, BackedCsr)  # still on disk
+    np.testing.assert_array_equal(b.obsm["X_pca"], a.obsm["X_pca"])
+    np.testing.assert_array_equal(b.varm["PCs"], a.varm["PCs"])
+    np.testing.assert_array_equal(b.uns["pca"]["variance"], a.uns["pca"]["variance"])
+    np.testing.assert_array_equal(b.uns["pca"]["variance_ratio"], a.uns["pca"]["variance_ratio"])
+    with pytest.raises(ValueError, match="zero_center"):
+        sc.pp.pca(b, n_comps=20, zero_center=False)

@@ -70,3 +70,22 @@ def test_full_path_two_ranks_matches_one(tmp_path):
     np.testing.assert_array_equal(two[0]["labels"], two[1]["labels"])
     assert adjusted_rand_score(two[0]["labels"], one["labels"]) > 0.99
     assert int(two[1]["nc"]) == int(two[0]["nc"]) and abs(float(two[1]["q"]) - float(two[0]["q"])) < 1e-12
+
+
+def test_full_path_two_ranks_streaming_their_blocks_from_a_zarr_store(tmp_path, monkeypatch):
+    """out of core + sharded (SURVEY.md 8(e) + 8(f).4): each rank opens the store `backed='r'` and streams only its own
+    row block through the chunked PCA; the result equals the in-memory two-rank run bit for bit"""
+    import scanpy_amd as sc
+    from scanpy_amd import readwrite as rw
+    from scanpy_amd.datasets import synthetic_planted
+
+    n, g, k = 1201, 240, 10
+    monkeypatch.setattr(rw, "CHUNK_ELEMS", 4001)
+    monkeypatch.setattr(rw, "CHUNKS_PER_SHARD", 3)
+    x, _ = synthetic_planted(n, g, n_types=12, seed=5)
+    sc.write_zarr(tmp_path / "store.zarr", sc.AnnData(x))
+    mem = _launch(2, tmp_path, n, g, k, "path")
+    disk = _launch(2, tmp_path, n, g, k, "path_backed")
+    for a, b in zip(mem, disk):
+        for key in ("scores", "knn_idx", "knn_dist", "labels", "q", "nc"):
+            np.testing.assert_array_equal(a[key], b[key], err_msg=key)
