@@ -48,12 +48,17 @@ class BackedCsr:
 
     def __init__(self, group, *, cols: np.ndarray | None = None, _indptr: np.ndarray | None = None):
         enc = group.attrs.get("encoding-type")
+        enc = enc.decode() if isinstance(enc, bytes) else enc
+        if enc is None and "h5sparse_format" in group.attrs:  # files written by anndata < 0.7
+            fmt = group.attrs["h5sparse_format"]
+            enc = f"{fmt.decode() if isinstance(fmt, bytes) else fmt}_matrix"
         if enc != "csr_matrix":
             raise ValueError(f"{group.path!r} holds a {enc!r}, not a csr_matrix: only CSR (rows = cells) can be "
                              "streamed by row ranges")
         self.group = group
         self._data, self._indices = group["data"], group["indices"]
-        n_rows, n_cols = (int(s) for s in group.attrs["shape"])
+        n_rows, n_cols = (int(s) for s in (group.attrs["shape"] if "shape" in group.attrs
+                                            else group.attrs["h5sparse_shape"]))
         self._n_cols_disk = n_cols
         self.indptr = np.asarray(group["indptr"].read(), dtype=np.int64) if _indptr is None else _indptr
         if self.indptr.shape != (n_rows + 1,) or self.indptr[0] != 0 or self.indptr[-1] != self._data.shape[0]:

@@ -54,15 +54,24 @@ def _read_dataframe(group) -> pd.DataFrame:
     return df
 
 
+def _as_str(v):
+    """HDF5 fixed-length strings come back as bytes: decode (zarr / variable-length strings already are str)"""
+    if isinstance(v, np.ndarray) and v.dtype.kind == "S":
+        return np.array([b.decode("utf-8", "replace") for b in v.reshape(-1).tolist()], dtype=object).reshape(v.shape)
+    return v.decode("utf-8", "replace") if isinstance(v, bytes) else v
+
+
 def read_elem(node):
-    """One element of the store -> its in-memory value (None + a warning for an encoding that is not read here)."""
-    enc = node.attrs.get("encoding-type")
-    if isinstance(node, z3.Array):
+    """One element of a zarr store or an HDF5 file -> its in-memory value (None + a warning for an encoding that is
+    not read here).  Arrays are anything with `.read()` (`_zarr3.Array`, `_hdf5.Dataset`), groups anything else."""
+    enc = _as_str(node.attrs.get("encoding-type"))
+    if hasattr(node, "read"):
         if enc in {"numeric-scalar", "string"} or node.ndim == 0:
-            v = node.read()[()]
+            v = _as_str(node.read()[()])
             return str(v) if node.is_string else v
         if enc in {None, "array", "string-array", "rec-array"}:
-            return node.read()
+            v = node.read()
+            return _as_str(v) if node.is_string else v
         warnings.warn(f"skipping {node.path!r}: array encoding {enc!r} is not read here", UserWarning, stacklevel=2)
         return None
     if enc in {"csr_matrix", "csc_matrix"}:
@@ -89,27 +98,16 @@ def read_elem(node):
     return None
 
 
-def read_zarr(store, *, backed: str | None = None) -> AnnData:
-    """Read an AnnData `.zarr` directory or `.zarr.zip` (zarr format 3).
-
-    backed
-        None: everything in memory (like `anndata.read_zarr`).  'r': a CSR `X` stays on disk as a `BackedCsr`
-        (its `indptr` is loaded, 8 bytes per cell); `pp.pca` then streams it through the device by row chunks.
-    """
-    if backed not in {None, "r"}:
-        raise ValueError("backed must be None or 'r' (stores are never modified in place)")
-    st = z3.open_store(store)
-    root = z3.Group(st)
-    if root.attrs.get("encoding-type") not in {"anndata", None}:
-        raise ValueError(f"{store}: not an AnnData store (encoding-type {root.attrs.get('encoding-type')!r})")
+def _read_anndata(root, where, backed) -> AnnData:
+    if _as_str(root.attrs.get("encoding-type")) not in {"anndata", None}:
+        raise ValueError(f"{where}: not an AnnData store (encoding-type {root.attrs.get('encoding-type')!r})")
     x = None
     if "X" in root:
         xn = root["X"]
-        if backed and isinstance(xn, z3.Group):
-            if xn.attrs.get("encoding-type") != "csr_matrix":
-                raise ValueError("backed='r' streams rows of a csr_matrix; this store's X is a "
-                                 f"{xn.attrs.get('encoding-type')!r}")
+        if backed and not hasattr(xn, "read"):
             x = BackedCsr(xn)
+        elif backed:
+            raise ValueError("backed='r' streams rows of a csr_matrix; this store's X is a dense array")
         else:
             x = read_elem(xn)
     obs = read_elem(root["obs"]) if "obs" in root else None
@@ -119,6 +117,117 @@ def read_zarr(store, *, backed: str | None = None) -> AnnData:
     if "varp" in root:
         adata.varp = read_elem(root["varp"]) or {}
     return adata
+
+
+def read_zarr(store, *, backed: str | None = None) -> AnnData:
+    """Read an AnnData `.zarr` directory or `.zarr.zip` (zarr format 3).
+
+    backed
+        None: everything in memory (like `anndata.read_zarr`).  'r': a CSR `X` stays on disk as a `BackedCsr`
+        (its `indptr` is loaded, 8 bytes per cell); `pp.pca` then streams it through the device by row chunks.
+    """
+    if backed not in {None, "r"}:
+        raise ValueError("backed must be None or 'r' (stores are never modified in place)")
+    return _read_anndata(z3.Group(z3.open_store(store)), store, backed)
+
+
+def read_h5ad(filename, backed: str | None = None) -> AnnData:
+    """Read an `.h5ad` file (`anndata.read_h5ad`, re-exported by the reference at `src/scanpy/readwrite.py:15-29` and
+    reached from `sc.read(..., backed=...)`, `:832-835`).  The HDF5 container is read by `scanpy_amd/_hdf5.py` (no h5py
+    in this image); the element encodings are those of `read_zarr`.
+
+    backed
+        None: everything in memory.  'r': a CSR `X` stays on disk as a `BackedCsr` and `pp.pca` streams it through the
+        device by row chunks (chunks are inflated on a thread pool straight into recycled buffers).
+    """
+    if backed not in {None, "r"}:
+        raise ValueError("backed must be None or 'r' (files are never modified in place)")
+    from . import _hdf5
+
+    return _read_anndata(_hdf5.File(filename).root, filename, backed)
+
+
+def read_10x_h5(filename, *, genome: str | None = None, gex_only: bool = True, backup_url: str | None = None) -> AnnData:
+    """Read a 10x-Genomics-formatted HDF5 file (drop-in for `scanpy.read_10x_h5`, src/scanpy/readwrite.py:159-351):
+    Cell Ranger v3+ `matrix/` files and legacy per-genome files; cells x genes CSR float32 (10x stores the transpose
+    as CSC, which is the same three arrays), `var['gene_ids', 'feature_types', 'genome', ...]`, barcodes as obs names.
+    """
+    from . import _hdf5
+
+    path = Path(filename)
+    if not path.is_file():
+        raise FileNotFoundError(f"{path} does not exist" + (" (there is no network here to fetch backup_url)"
+                                                            if backup_url else ""))
+
+    def collect(dsets: dict, group) -> None:  # `_collect_datasets`, `:245-250`
+        for k in group.keys():
+            v = group[k]
+            if hasattr(v, "read"):
+                dsets[k] = v.read()
+            else:
+                collect(dsets, v)
+
+    def matrix_of(dsets):  # `:259-268`: int32 counts are converted to float32 in place
+        n_cols, n_rows = (int(v) for v in dsets["shape"])
+        data = dsets["data"]
+        if data.dtype == np.dtype("int32"):
+            data = data.astype(np.float32)
+        return sparse.csr_matrix((data, dsets["indices"], dsets["indptr"]), shape=(n_rows, n_cols))
+
+    def text(a):
+        return np.asarray(_as_str(a)).astype(str)
+
+    with _hdf5.File(path) as f:
+        try:
+            if "matrix" in f:  # `_read_v3_10x_h5`, `:253-302`
+                dsets: dict = {}
+                collect(dsets, f["matrix"])
+                obs = pd.DataFrame(index=pd.Index(text(dsets["barcodes"])))
+                var_cols = {}
+                if "gene_id" not in dsets:
+                    var_cols["gene_ids"] = text(dsets["id"])
+                else:  # a probe-barcode matrix
+                    var_cols["gene_ids"] = text(dsets["gene_id"])
+                    var_cols["probe_ids"] = text(dsets["id"])
+                var_cols["feature_types"] = text(dsets["feature_type"])
+                if "filtered_barcodes" in f["matrix"]:
+                    obs["filtered_barcodes"] = dsets["filtered_barcodes"].astype(bool)
+                if "features" not in f["matrix"]:
+                    raise ValueError("10x h5 has no features group")
+                feats = f["matrix"]["features"]
+                for name in feats.keys():
+                    item = feats[name]
+                    if hasattr(item, "read") and name not in ["name", "feature_type", "id", "gene_id", "_all_tag_keys"]:
+                        var_cols[name] = dsets[name].astype(bool) if item.dtype.kind == "b" else text(dsets[name])
+                var = pd.DataFrame(var_cols, index=pd.Index(text(dsets["name"])))
+                adata = AnnData(matrix_of(dsets), obs, var)
+                if not var.index.is_unique and not (genome or gex_only):
+                    warnings.warn("Variable names are not unique. To make them unique, call `.var_names_make_unique`.",
+                                  UserWarning, stacklevel=2)
+                if genome:
+                    if genome not in set(adata.var["genome"]):
+                        raise ValueError(f"Could not find data corresponding to genome {genome!r} in {path}. "
+                                         f"Available genomes are: {list(adata.var['genome'].unique())}.")
+                    adata = adata[:, (adata.var["genome"] == genome).to_numpy()]
+                if gex_only:
+                    adata = adata[:, (adata.var["feature_types"] == "Gene Expression").to_numpy()]
+                if adata.is_view:
+                    adata = adata.copy()
+                return adata
+            children = f.keys()  # `_read_legacy_10x_h5`, `:305-351`
+            if not genome:
+                if len(children) > 1:
+                    raise ValueError(f"{path} contains more than one genome. For legacy 10x h5 files you must specify "
+                                     f"the genome if more than one is present. Available genomes are: {children}")
+                genome = children[0]
+            elif genome not in children:
+                raise ValueError(f"Could not find genome {genome!r} in {path}. Available genomes are: {children}")
+            dsets = {}
+            collect(dsets, f[genome])
+            var = pd.DataFrame({"gene_ids": text(dsets["genes"])}, index=pd.Index(text(dsets["gene_names"])))
+            return AnnData(matrix_of(dsets), pd.DataFrame(index=pd.Index(text(dsets["barcodes"]))), var)
+        except KeyError as e:
+            raise Exception("File is missing one or more required datasets.") from e  # noqa: TRY002 (`:241-242`)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
