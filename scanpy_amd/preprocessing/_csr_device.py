@@ -134,6 +134,16 @@ def default_backend():
     return GpuPPBackend()
 
 
+def in_memory(x):
+    """The upstream chain works on a matrix in memory (most of its passes rewrite it); an on-disk matrix
+    (`read_h5ad` / `read_zarr(..., backed='r')`) streams only through `pp.pca`."""
+    if getattr(x, "is_backed", False):
+        raise NotImplementedError(
+            "this function needs the matrix in memory: load it with `adata.X = adata.X.to_memory()` (or read without "
+            "backed='r'); a backed matrix is streamed by `sc.pp.pca` only")
+    return x
+
+
 def mean_var_from_sums(s: np.ndarray, sq: np.ndarray, n: int, *, correction: int = 1):
     """fast_array_utils.stats.mean_var semantics: mean, (E[x^2] - E[x]^2) * n / (n - correction)."""
     mean = s / n

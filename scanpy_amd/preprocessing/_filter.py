@@ -48,7 +48,7 @@ def filter_cells(data, *, min_counts=None, min_genes=None, max_counts=None, max_
         adata._inplace_subset_obs(cell_subset)
         return adata if copy else None
     be = _csr_device.default_backend()
-    m = be.upload(data)
+    m = be.upload(_csr_device.in_memory(data))
     by_counts = min_genes is None and max_genes is None
     number = be.row_sums(m) if by_counts else be.row_count_positive(m)
     cell_subset = _subset(number, min_counts if by_counts else min_genes, max_counts if by_counts else max_genes)
@@ -79,7 +79,7 @@ def filter_genes(data, *, min_counts=None, min_cells=None, max_counts=None, max_
         adata._inplace_subset_var(gene_subset)
         return adata if copy else None
     be = _csr_device.default_backend()
-    m = be.upload(data)
+    m = be.upload(_csr_device.in_memory(data))
     by_counts = min_cells is None and max_cells is None
     s_, _, npos = be.col_stats(m, count_positive=not by_counts)
     number = s_.astype(np.float32) if by_counts else npos

@@ -148,7 +148,7 @@ def highly_variable_genes(  # noqa: PLR0913
                                max_mean=max_mean)
     x = _get_arr(adata, layer=layer)
     be = _csr_device.default_backend()
-    m = be.upload(x)
+    m = be.upload(_csr_device.in_memory(x))
     var_names = adata.var_names
     base = adata.uns.get("log1p", {}).get("base")
     kw = dict(cutoff=cutoff, n_bins=n_bins, flavor=flavor, log1p_base=base)

@@ -60,7 +60,7 @@ def normalize_total(  # noqa: PLR0912
     view_to_actual(adata)  # `_normalization.py:264`
     x = _get_arr(adata, layer=layer, obsm=obsm)
     be = _csr_device.default_backend()
-    m = be.upload(x)  # CSC -> CSR like the reference (`:266-267`); integers -> float32 (`:271-272`)
+    m = be.upload(_csr_device.in_memory(x))  # CSC -> CSR like the reference (`:266-267`); integers -> float32 (`:271-272`)
     counts = be.row_sums(m)
     gene_subset = None
     if exclude_highly_expressed:

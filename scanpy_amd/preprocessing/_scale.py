@@ -25,7 +25,7 @@ def _scale_matrix(x, *, zero_center: bool, max_value, mask_obs):
         mask_obs = np.asarray(mask_obs)
         if mask_obs.dtype != bool or mask_obs.shape != (x.shape[0],):
             raise ValueError("`mask_obs` must be a boolean vector with one entry per observation")
-    m = be.upload(x)
+    m = be.upload(_csr_device.in_memory(x))
     n_rows = x.shape[0] if mask_obs is None else int(mask_obs.sum())
     s, sq, _ = be.col_stats(m, row_mask=mask_obs)
     mean, var = _csr_device.mean_var_from_sums(s, sq, n_rows, correction=1)

@@ -16,7 +16,7 @@ from ._pca import _get_arr
 
 def _log1p_matrix(x, *, base=None):
     be = _csr_device.default_backend()
-    m = be.upload(x, want_csr_rows=False)  # element-wise: the storage format is kept (`log1p_sparse`, `:359-365`)
+    m = be.upload(_csr_device.in_memory(x), want_csr_rows=False)  # element-wise: the storage format is kept (`log1p_sparse`, `:359-365`)
     be.log1p_(m, base)
     return be.download(m)
 

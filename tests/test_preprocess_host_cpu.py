@@ -441,3 +441,17 @@ def test_views_are_actualised_with_a_warning():
         func(adata, **kw)
         assert not v.is_view
         np.testing.assert_array_equal(_dense(adata.X), _dense(v.X))
+
+
+def test_backed_matrices_are_refused_with_a_pointer_to_pca():
+    """an on-disk X (`read_h5ad(..., backed='r')`) streams through `pp.pca` only; the chain says so instead of failing
+    somewhere inside numpy"""
+    from pathlib import Path
+
+    b = sc.read_h5ad(Path(__file__).parent / "golden" / "h5" / "adata_layout.h5ad", backed="r")
+    for fn in (sc.pp.normalize_total, sc.pp.log1p, sc.pp.scale, sc.pp.highly_variable_genes,
+               lambda a: sc.pp.filter_cells(a, min_counts=1), lambda a: sc.pp.filter_genes(a, min_cells=1)):
+        with pytest.raises(NotImplementedError, match="to_memory"):
+            fn(b)
+    a = sc.AnnData(b.X.to_memory(), b.obs, b.var)
+    sc.pp.normalize_total(a)  # and in memory it goes through
