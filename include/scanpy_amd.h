@@ -246,6 +246,18 @@ int scamd_umap_optimize_f32(const int64_t* indptr, const int32_t* indices, const
                             void* workspace, size_t workspace_bytes, scamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Host-side byte codecs of the on-disk readers (csrc/hostio.cpp).  No device work: callable on a
+ * host without a GPU, from many threads at once.  They replace what the reference gets from h5py's bundled filters
+ * when it reads `.h5ad` / 10x `.h5` files (src/scanpy/readwrite.py:15-29, 235-243; `compression='lzf'` is one of
+ * the two codecs its writer offers, :657-667).
+ * scamd_lzf_decompress: liblzf stream -> dst; returns the number of bytes produced (>= 0) or a negative SCAMD_E* code
+ *   (malformed stream, or dst_cap too small).
+ * scamd_unshuffle: inverse of the HDF5 shuffle filter -- src = elem_size byte planes of n_elem bytes, dst = elements.
+ * ---------------------------------------------------------------------------------------- */
+int64_t scamd_lzf_decompress(const void* src, size_t src_len, void* dst, size_t dst_cap);
+int scamd_unshuffle(const void* src, void* dst, size_t n_elem, int elem_size);
+
+/* ------------------------------------------------------------------------------------------
  * Self tests / micro benchmarks (device).  scamd_selftest_mfma_layout checks the
  * v_mfma_f32_32x32x2_f32 operand/result lane mapping the kNN kernel relies on; returns 0 if OK.
  * ---------------------------------------------------------------------------------------- */

@@ -49,6 +49,8 @@ SIGNATURES = {
     "scamd_pp_scale_dense_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _f64, _i32, _vp, _vp, _i32, _vp]),
     "scamd_umap_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "scamd_umap_optimize_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _f64, _f64, _f64, _f64, _f64, _u64, _vp, _vp, _sz, _vp]),
+    "scamd_lzf_decompress": (_i64, [_vp, _sz, _vp, _sz]),
+    "scamd_unshuffle": (_i32, [_vp, _vp, _sz, _i32]),
     "scamd_selftest_mfma_layout": (_i32, [_vp]),
 }
 

@@ -154,6 +154,10 @@ with h5py.File(OUT / "variants_v0.h5", "w") as f:  # default libver: superblock 
         many.create_dataset(f"item{i:02d}", data=np.int32(i))
     f.create_dataset("btree", data=big, chunks=(37,), compression="gzip", shuffle=True)  # a multi-level chunk B-tree
     f.create_dataset("two_d", data=two_d, chunks=(10, 4), compression="gzip")
+    f.create_dataset("lzf", data=big, chunks=(1000,), compression="lzf", shuffle=True)
+    noise = rng.integers(0, 256, 4096).astype(np.uint8)  # incompressible: h5py stores such chunks raw (filter mask)
+    f.create_dataset("lzf_noise", data=np.concatenate([noise, np.zeros(4096, np.uint8)]), chunks=(4096,),
+                     compression="lzf")
     f.create_dataset("fixed_str", data=np.array([b"ab", b"cde", b""], dtype="S3"))
     u8 = f.create_dataset("utf8_fixed", shape=(2,), dtype=h5py.string_dtype("utf-8", 4))
     u8[0], u8[1] = "é", "zz"
@@ -162,7 +166,7 @@ with h5py.File(OUT / "variants_v0.h5", "w") as f:  # default libver: superblock 
         long_attr.attrs[f"key{i}"] = f"value {i}"
     long_attr.attrs["bools"] = np.array([True, False])
     long_attr.attrs["empty"] = h5py.Empty("f")
-expected.update(v_big=big, v_two_d=two_d, v_paged=np.arange(40_000, dtype=np.int32))
+expected.update(v_big=big, v_two_d=two_d, v_paged=np.arange(40_000, dtype=np.int32), v_noise=noise)
 
 # --------------------------------------------------------------------------------------------------------------------
 # 3. 10x v3 layout (features x barcodes, CSC = cells x genes CSR)

@@ -125,6 +125,11 @@ def test_container_variants_old_style(expected):
         np.testing.assert_array_equal(f["btree"].read(), expected["v_big"])  # 271 chunks of 37
         np.testing.assert_array_equal(f["btree"].read(123, 4567), expected["v_big"][123:4567])
         np.testing.assert_array_equal(f["two_d"].read(5, 99), expected["v_two_d"][5:99])
+        np.testing.assert_array_equal(f["lzf"].read(), expected["v_big"])  # h5py's lzf filter + shuffle
+        np.testing.assert_array_equal(f["lzf"].read(1500, 7777), expected["v_big"][1500:7777])
+        noise = f["lzf_noise"].read()  # an incompressible chunk is stored raw and flagged in the chunk's filter mask
+        np.testing.assert_array_equal(noise[:4096], expected["v_noise"])
+        assert not noise[4096:].any()
         assert f["fixed_str"].read().tolist() == [b"ab", b"cde", b""]
         assert f["utf8_fixed"].read().tolist() == ["é", "zz"]
         at = f["attrs"].attrs
@@ -206,3 +211,40 @@ def test_read_10x_h5_legacy_genomes_and_probe_matrices():
             "probe_region"} <= set(probe.var.columns)
     assert probe.var["filtered_probes"].dtype == bool and probe.obs["filtered_barcodes"].dtype == bool
     assert probe.var_names[0] == "Itgb2l|2ef1e7b" and probe.var["probe_ids"].iloc[0].endswith("|Itgb2l|2ef1e7b")
+
+
+def test_host_codecs_of_the_c_abi():
+    """`scamd_unshuffle` / `scamd_lzf_decompress` (include/scanpy_amd.h, csrc/hostio.cpp): no GPU involved"""
+    import ctypes
+
+    from scanpy_amd._lib import load
+
+    lib = load()
+    rng = np.random.default_rng(0)
+    for es in (1, 2, 3, 4, 8, 18):
+        for n in (0, 1, 7, 4096, 10_001):
+            elems = rng.integers(0, 256, (n, es), dtype=np.uint8)
+            planes = np.ascontiguousarray(elems.T).tobytes()
+            for shift in (0, 1):  # aligned and unaligned destinations
+                buf = np.zeros(n * es + shift, dtype=np.uint8)
+                dst = buf[shift:]
+                assert lib.scamd_unshuffle(planes, dst.ctypes.data, n, es) == 0
+                np.testing.assert_array_equal(dst.reshape(n, es), elems)
+    assert lib.scamd_unshuffle(b"", None, 0, 0) < 0
+
+    def lzf(stream: bytes, cap: int):
+        out = ctypes.create_string_buffer(max(cap, 1))
+        got = lib.scamd_lzf_decompress(stream, len(stream), out, cap)
+        return got, out.raw[:max(got, 0)]
+
+    # literal run "abc"; back reference of length 2 + 2 at distance 3 -> "abca"; run-length: distance 1, length 9
+    assert lzf(bytes([2]) + b"abc" + bytes([(2 << 5) | 0, 2]), 64) == (7, b"abcabca")
+    assert lzf(bytes([0]) + b"x" + bytes([(7 << 5) | 0, 0, 0]), 64) == (10, b"x" * 10)
+    assert lzf(b"", 8) == (0, b"")
+    for bad in (bytes([5]) + b"ab",                      # literal run longer than the input
+                bytes([(1 << 5) | 0, 0]),                 # reference before the start of the output
+                bytes([0]) + b"a" + bytes([(7 << 5)]),    # truncated extended length
+                bytes([0]) + b"a" + bytes([(1 << 5)])):   # truncated distance
+        assert lzf(bad, 64)[0] < 0
+    assert lzf(bytes([3]) + b"abcd", 2)[0] < 0  # destination too small
+    assert b"buffers" in lib.scamd_last_error() or b"truncated" in lib.scamd_last_error()
