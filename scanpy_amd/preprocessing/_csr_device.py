@@ -136,11 +136,11 @@ def default_backend():
 
 def in_memory(x):
     """The upstream chain works on a matrix in memory (most of its passes rewrite it); an on-disk matrix
-    (`read_h5ad` / `read_zarr(..., backed='r')`) streams only through `pp.pca`."""
+    (`read_h5ad` / `read_zarr(..., backed='r')`) streams only through `pp.pca` and `pp.highly_variable_genes`."""
     if getattr(x, "is_backed", False):
         raise NotImplementedError(
             "this function needs the matrix in memory: load it with `adata.X = adata.X.to_memory()` (or read without "
-            "backed='r'); a backed matrix is streamed by `sc.pp.pca` only")
+            "backed='r'); a backed matrix is streamed by `sc.pp.pca` and `sc.pp.highly_variable_genes` only")
     return x
 
 

@@ -55,6 +55,28 @@ def _nth_highest(x: np.ndarray, n: int) -> float:
     return np.sort(x)[::-1][n - 1]
 
 
+class _StreamedColStats:
+    """`col_stats` of a backed CSR matrix (`_backed.BackedCsr`): row chunks are read, uploaded and swept one after the
+    other by the real backend; sums, sums of squares and positive counts add up."""
+
+    def __init__(self, be, x, step: int = 1_000_000):
+        self.be, self.x, self.step = be, x, step
+
+    def col_stats(self, m, *, row_mask=None, expm1_scale=None, count_positive: bool = False):
+        tot = None
+        for c in self.x.row_chunks(self.step):
+            if row_mask is not None and not row_mask[c.i0:c.i1].any():
+                continue
+            part = self.be.col_stats(self.be.upload(c.load().to_scipy()),
+                                     row_mask=None if row_mask is None else row_mask[c.i0:c.i1],
+                                     expm1_scale=expm1_scale, count_positive=count_positive)
+            tot = part if tot is None else tuple(None if a is None else a + b for a, b in zip(tot, part))
+        if tot is None:
+            g = self.x.shape[1]
+            tot = (np.zeros(g), np.zeros(g), np.zeros(g, dtype=np.int64) if count_positive else None)
+        return tot
+
+
 def _single_batch(be, m, var_names, *, n_rows: int, row_mask, filter_unexpressed_genes: bool, cutoff, n_bins: int,
                   flavor: str, log1p_base) -> pd.DataFrame:
     """`_highly_variable_genes_single_batch` (`:367-450`) on the rows selected by `row_mask`."""
@@ -148,7 +170,12 @@ def highly_variable_genes(  # noqa: PLR0913
                                max_mean=max_mean)
     x = _get_arr(adata, layer=layer)
     be = _csr_device.default_backend()
-    m = be.upload(_csr_device.in_memory(x))
+    if getattr(x, "is_backed", False):
+        # an on-disk matrix: the per-gene sums are additive over row chunks, so the one sweep this function needs is
+        # streamed (float64 partial sums added on the host) and the matrix never has to fit anywhere
+        be, m = _StreamedColStats(be, x), x
+    else:
+        m = be.upload(x)
     var_names = adata.var_names
     base = adata.uns.get("log1p", {}).get("base")
     kw = dict(cutoff=cutoff, n_bins=n_bins, flavor=flavor, log1p_base=base)
