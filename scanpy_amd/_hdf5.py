@@ -17,8 +17,11 @@ library itself: the reference's PyTables / h5py-written 10x fixtures and h5py-wr
                       compounds of those
     attributes        compact (header messages), versions 1-3
 
-Not read (a clear NotImplementedError says so): dense link / attribute storage (fractal heaps -- groups created with
-`track_order=True` or `libver='latest'` and more than 8 links), extensible-array and B-tree v2 chunk indexes,
+                      dense link storage (fractal heap, scanned in storage order: groups created with
+                      `track_order=True` / `libver='latest'` holding more than 8 links)
+
+Not read (a clear NotImplementedError says so): dense ATTRIBUTE storage (more than 8 attributes on a new-style object),
+fractal heaps that lost objects, extensible-array and B-tree v2 chunk indexes,
 szip / scale-offset / n-bit filters, references, virtual and external datasets.
 """
 from __future__ import annotations
@@ -376,6 +379,113 @@ def _messages(f: File, addr: int):
                 yield mtype, mflags, body
 
 
+def _parse_link(buf, p: int, O: int):
+    """one link message at `p` -> (name, object header address or None for a soft / external link, end offset)"""
+    if buf[p] != 1:
+        raise ValueError("HDF5: bad link message")
+    flags = buf[p + 1]
+    p += 2
+    ltype = 0
+    if flags & 0x08:
+        ltype = buf[p]
+        p += 1
+    if flags & 0x04:
+        p += 8
+    if flags & 0x10:
+        p += 1
+    nb = 1 << (flags & 3)
+    n = _uint(buf, p, nb)
+    p += nb
+    name = bytes(buf[p:p + n]).decode("utf-8")
+    p += n
+    if ltype == 0:
+        return name, _uint(buf, p, O), p + O
+    if ltype == 1:  # soft link: length + path
+        return name, None, p + 2 + _uint(buf, p, 2)
+    return name, None, p + 2 + _uint(buf, p + 1, 2) + 1 if ltype >= 64 else p
+
+
+def _fractal_heap_objects(f: File, addr: int, where: str):
+    """The managed objects of a fractal heap, in storage order (dense link storage of groups created with
+    `track_order=True` / `libver='latest'`: every object is one link message).
+
+    The name-index B-tree (version 2) is not consulted: direct blocks are filled front to back, so the objects of a
+    heap that never lost one are its blocks' contents in order.  The scan must find exactly `number of managed
+    objects` link messages; a heap that lost links (stale bytes or holes in its blocks) is refused, not guessed at."""
+    O, L = f.O, f.L
+    h = f.r.at(addr, 22 + 12 * L + 3 * O + 8)
+    if h[:4] != b"FRHP":
+        raise ValueError(f"HDF5: bad fractal heap header in {where!r}")
+    filt_len = _uint(h, 7, 2)
+    flags = h[9]
+    p = 10 + 4 + L + O  # max managed object size, next huge id, huge-object B-tree
+    p += L + O  # free space, free-space manager
+    p += 2 * L  # managed space, allocated managed space
+    p += L      # allocation iterator offset
+    n_managed = _uint(h, p, L)
+    p += L + 4 * L  # number of managed objects; huge size / count, tiny size / count
+    width = _uint(h, p, 2)
+    start = _uint(h, p + 2, L)
+    max_direct = _uint(h, p + 2 + L, L)
+    max_bits = _uint(h, p + 2 + 2 * L, 2)
+    root = _uint(h, p + 6 + 2 * L, O)
+    cur_rows = _uint(h, p + 6 + 2 * L + O, 2)
+    if filt_len:
+        raise NotImplementedError(f"HDF5: {where!r}: filtered fractal heaps are not read here")
+    off_bytes = (max_bits + 7) // 8
+    dhead = 5 + O + off_bytes + (4 if flags & 0x02 else 0)
+    undef = _UNDEF & ((1 << (8 * O)) - 1)
+
+    def direct_blocks():
+        if cur_rows == 0:
+            if root != undef:
+                yield root, start
+            return
+        stack = [(root, cur_rows)]
+        while stack:
+            iaddr, nrows = stack.pop(0)
+            n_direct_rows = (max_direct // start).bit_length() + 1  # rows whose blocks are still direct blocks
+            ih = 5 + O + off_bytes
+            ents = f.r.at(iaddr, ih + nrows * width * O)
+            if ents[:4] != b"FHIB":
+                raise ValueError(f"HDF5: bad fractal heap indirect block in {where!r}")
+            q = ih
+            for r in range(nrows):
+                size = start if r < 2 else start << (r - 1)
+                for _ in range(width):
+                    child = _uint(ents, q, O)
+                    q += O
+                    if child == undef:
+                        continue
+                    if r < n_direct_rows:
+                        yield child, size
+                    else:  # a nested indirect block covering `size` bytes of heap space
+                        stack.append((child, (size // (start * width)).bit_length()))  # log2(size / (start * width)) + 1
+
+    found = []
+    for baddr, bsize in direct_blocks():
+        blk = f.r.at(baddr, bsize)
+        if blk[:4] != b"FHDB":
+            raise ValueError(f"HDF5: bad fractal heap direct block in {where!r}")
+        q = dhead
+        while q < bsize and blk[q] == 1:  # link messages start with their version, 1
+            try:
+                _, _, end = _parse_link(blk, q, O)
+            except (ValueError, IndexError, UnicodeDecodeError):
+                break
+            if end > bsize:
+                break
+            found.append(blk[q:end])
+            q = end
+    if len(found) != n_managed:
+        # a deleted link leaves its bytes behind (one candidate too many) or a hole that ends the scan of its block
+        # (candidates missing): only the name-index B-tree knows which objects are live
+        raise NotImplementedError(f"HDF5: {where!r}: the sequential scan of its fractal heap found {len(found)} link "
+                                  f"messages where the heap holds {n_managed} (links were deleted from this group; "
+                                  "the version-2 B-tree index is not read here)")
+    return found
+
+
 def _parse_attribute(f: File, body: bytes):
     ver = body[0]
     nsz, tsz, ssz = _uint(body, 2, 2), _uint(body, 4, 2), _uint(body, 6, 2)
@@ -486,29 +596,18 @@ class Group(_Node):
                     else:
                         raise ValueError("HDF5: bad group B-tree node")
             elif mtype == 0x06:  # link message (compact new-style group)
-                flags = body[1]
-                p = 2
-                ltype = 0
-                if flags & 0x08:
-                    ltype = body[p]
-                    p += 1
-                if flags & 0x04:
-                    p += 8
-                if flags & 0x10:
-                    p += 1
-                nb = 1 << (flags & 3)
-                n = _uint(body, p, nb)
-                p += nb
-                lname = bytes(body[p:p + n]).decode("utf-8")
-                p += n
-                if ltype == 0:
-                    links[lname] = _uint(body, p, O)
+                lname, addr, _ = _parse_link(body, 0, O)
+                if addr is not None:
+                    links[lname] = addr
             elif mtype == 0x02:  # link info: dense storage if the fractal heap address is defined
                 flags = body[1]
                 p = 2 + (8 if flags & 1 else 0)
-                if _uint(body, p, O) != _UNDEF & ((1 << (8 * O)) - 1):
-                    raise NotImplementedError(f"HDF5: group {self.name!r} keeps its links in dense storage (fractal "
-                                              "heap: created with track_order / libver='latest'), not read here")
+                heap = _uint(body, p, O)
+                if heap != _UNDEF & ((1 << (8 * O)) - 1):
+                    for obj in _fractal_heap_objects(f, heap, self.name):
+                        lname, addr, _ = _parse_link(obj, 0, O)
+                        if addr is not None:
+                            links[lname] = addr
         self._links = links
         return links
 

@@ -11,6 +11,7 @@ Outputs (committed, ~100 KB):
     tests/golden/h5/variants.h5          container variants: libver='latest' (superblock 3, version-2 object headers,
                                          compact link messages, layout-4 chunk indexes), big-endian, compound, enum,
                                          fletcher32, chunked 2-d with edge chunks, missing chunks, a user block
+    tests/golden/h5/tracked.h5           `track_order=True` groups under the default libver (dense links)
     tests/golden/h5/tenx_v3_like.h5      the 10x Genomics v3 `matrix/` layout (features x barcodes CSC)
     tests/golden/h5/expected.npz         the arrays that went into the files above
 """
@@ -146,8 +147,22 @@ with h5py.File(OUT / "variants.h5", "w", libver="latest", userblock_size=512) as
     sparse_ds = g2.create_dataset("missing_chunks", shape=(300,), dtype=np.int32, chunks=(100,), compression="gzip")
     sparse_ds[100:200] = np.arange(100, dtype=np.int32)
     g2.create_dataset("resizable", data=big[:300], chunks=(100,), maxshape=(None,))  # extensible array: not read
-    for i in range(12):  # > 8 links in a new-style group -> dense link storage: not read
+    for i in range(12):  # > 8 links in a new-style group -> dense link storage (one fractal-heap direct block)
         f.require_group("dense").create_dataset(f"d{i}", data=np.int8(i))
+    wide = f.create_group("dense_wide")  # enough links for an indirect block over several direct blocks
+    target = wide.create_dataset("target", data=np.int16(7))
+    for i in range(700):
+        wide[f"hard_link_number_{i:04d}"] = target
+    holes = f.create_group("dense_holes")  # links deleted from a dense group: refused, not guessed at
+    for i in range(20):
+        holes[f"h{i:02d}"] = target
+    for i in (3, 4, 11):
+        del holes[f"h{i:02d}"]
+with h5py.File(OUT / "tracked.h5", "w", track_order=True) as f:  # default libver + creation-order tracking
+    f.attrs["a"] = 1
+    tg = f.create_group("g", track_order=True)
+    for i in range(15):
+        tg.create_dataset(f"k{14 - i:02d}", data=np.int32(i))
 with h5py.File(OUT / "variants_v0.h5", "w") as f:  # default libver: superblock 0, symbol-table groups, B-tree v1
     many = f.create_group("many")
     for i in range(40):  # more than one SNOD leaf

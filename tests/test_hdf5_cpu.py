@@ -80,7 +80,8 @@ def test_backed_h5ad_rows(expected):
 
 def test_container_variants_new_style(expected):
     """libver='latest': superblock 3 behind a 512-byte user block, version-2 object headers, compact link messages,
-    layout-4 chunk indexes (single chunk, fixed array, paged fixed array), fletcher32, big-endian, compact layout"""
+    layout-4 chunk indexes (single chunk, fixed array, paged fixed array), fletcher32, big-endian, compact layout,
+    dense link storage"""
     f = h5.File(H5 / "variants.h5")
     assert f.r.base == 512 and f.attrs["title"] == "libver latest"
     np.testing.assert_array_equal(f.attrs["numbers"], np.arange(5, dtype=np.int16))
@@ -107,8 +108,14 @@ def test_container_variants_new_style(expected):
     np.testing.assert_array_equal(g2["missing_chunks"].read(150, 250), want[150:250])
     with pytest.raises(NotImplementedError, match="extensible array"):
         g2["resizable"]
-    with pytest.raises(NotImplementedError, match="dense storage"):
-        f["dense"].keys()
+    # dense link storage (more than 8 links in a new-style group): fractal heap scanned in storage order
+    assert f["dense"].keys() == sorted(f"d{i}" for i in range(12))
+    assert [int(f["dense"][f"d{i}"][()]) for i in range(12)] == list(range(12))
+    wide = f["dense_wide"]  # 701 links: an indirect block over several direct blocks
+    assert wide.keys() == [f"hard_link_number_{i:04d}" for i in range(700)] + ["target"]
+    assert wide["hard_link_number_0456"][()] == 7
+    with pytest.raises(NotImplementedError, match="links were deleted"):
+        f["dense_holes"].keys()  # stale link messages in the heap: refused rather than listed wrongly
     with pytest.raises(KeyError):
         g["nope"]
     with pytest.raises(IndexError):
@@ -136,6 +143,14 @@ def test_container_variants_old_style(expected):
         assert [at[f"key{i}"] for i in range(20)] == [f"value {i}" for i in range(20)]
         assert at["bools"].tolist() == [True, False] and at["bools"].dtype == bool and at["empty"] is None
         assert "btree" in f and "nope" not in f and f["many/item07"][()] == 7
+
+
+def test_track_order_groups():
+    """`h5py.File(..., track_order=True)` under the default libver: creation-order tracked groups with dense links"""
+    with h5.File(H5 / "tracked.h5") as f:
+        assert f.attrs["a"] == 1
+        assert f["g"].keys() == [f"k{i:02d}" for i in range(15)]
+        assert [int(f["g"][f"k{i:02d}"][()]) for i in range(15)] == list(range(14, -1, -1))
 
 
 def test_not_hdf5(tmp_path):
