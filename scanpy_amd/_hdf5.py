@@ -186,7 +186,7 @@ def _parse_type(buf, off: int) -> tuple[_Type, int]:
             if mt.kind != "fixed":
                 raise NotImplementedError("HDF5: compound members of variable length are not read here")
             names.append(name)
-            types.append(mt.dtype)
+            types.append(np.dtype(bool) if mt.enum == "bool" and mt.size == 1 else mt.dtype)
             offsets.append(moff)
         return _Type(np.dtype({"names": names, "formats": types, "offsets": offsets, "itemsize": size}), size=size), p
     if cls == 8:  # enumeration (h5py stores numpy bool as ENUM {FALSE=0, TRUE=1} of int8)

@@ -65,6 +65,8 @@ def read_elem(node):
     """One element of a zarr store or an HDF5 file -> its in-memory value (None + a warning for an encoding that is
     not read here).  Arrays are anything with `.read()` (`_zarr3.Array`, `_hdf5.Dataset`), groups anything else."""
     enc = _as_str(node.attrs.get("encoding-type"))
+    if enc == "null":  # anndata >= 0.11 stores None this way
+        return None
     if hasattr(node, "read"):
         if enc in {"numeric-scalar", "string"} or node.ndim == 0:
             v = _as_str(node.read()[()])
@@ -98,6 +100,16 @@ def read_elem(node):
     return None
 
 
+def _legacy_frame(v):
+    """files written by anndata < 0.7 keep obs / var as one compound dataset (fixed-length strings, an `index` field)"""
+    if isinstance(v, np.ndarray) and v.dtype.names:
+        cols = {n: _as_str(v[n]) for n in v.dtype.names}
+        key = next((k for k in ("index", "obs_names", "var_names", "_index") if k in cols), None)
+        index = pd.Index(cols.pop(key)) if key else pd.RangeIndex(v.shape[0]).astype(str)
+        return pd.DataFrame(cols, index=index)
+    return v
+
+
 def _read_anndata(root, where, backed) -> AnnData:
     if _as_str(root.attrs.get("encoding-type")) not in {"anndata", None}:
         raise ValueError(f"{where}: not an AnnData store (encoding-type {root.attrs.get('encoding-type')!r})")
@@ -110,8 +122,8 @@ def _read_anndata(root, where, backed) -> AnnData:
             raise ValueError("backed='r' streams rows of a csr_matrix; this store's X is a dense array")
         else:
             x = read_elem(xn)
-    obs = read_elem(root["obs"]) if "obs" in root else None
-    var = read_elem(root["var"]) if "var" in root else None
+    obs = _legacy_frame(read_elem(root["obs"])) if "obs" in root else None
+    var = _legacy_frame(read_elem(root["var"])) if "var" in root else None
     kw = {k: (read_elem(root[k]) or {}) if k in root else {} for k in ("obsm", "varm", "obsp", "uns", "layers")}
     adata = AnnData(x, obs, var, **kw)
     if "varp" in root:

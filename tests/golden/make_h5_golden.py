@@ -124,6 +124,21 @@ with h5py.File(OUT / "adata_layout.h5ad", "w") as f:
 expected.update(ad_names=np.array(names), ad_counts=counts, ad_codes=codes, ad_batch=np.array(batch), ad_dbl=dbl,
                 ad_score_v=score_v, ad_score_m=score_m, ad_hv=hv, ad_xpca=xpca, ad_rec_a=rec["a"], ad_rec_b=rec["b"])
 
+# the layout anndata < 0.7 wrote: obs / var as compound datasets, X marked with h5sparse_* attributes
+with h5py.File(OUT / "legacy_layout.h5ad", "w") as f:
+    xg = f.create_group("X")
+    xg.attrs["h5sparse_format"] = np.bytes_("csr")
+    xg.attrs["h5sparse_shape"] = np.array([n, g], dtype=np.int64)
+    xg.create_dataset("data", data=data, chunks=(512,), compression="gzip")
+    xg.create_dataset("indices", data=indices, chunks=(512,), compression="gzip")
+    xg.create_dataset("indptr", data=indptr)
+    o = np.zeros(n, dtype=[("index", "S9"), ("n_counts", "<f4")])
+    o["index"], o["n_counts"] = [s.encode() for s in names], counts
+    f.create_dataset("obs", data=o)
+    v = np.zeros(g, dtype=[("index", "S6"), ("highly_variable", "?")])
+    v["index"], v["highly_variable"] = [f"gene{i}".encode() for i in range(g)], hv
+    f.create_dataset("var", data=v)
+
 # --------------------------------------------------------------------------------------------------------------------
 # 2. container variants
 big = rng.integers(0, 1000, 10_000).astype(np.int64)

@@ -78,6 +78,17 @@ def test_backed_h5ad_rows(expected):
         sc.read_h5ad(H5 / "adata_layout.h5ad", backed="r+")
 
 
+def test_legacy_layout(expected):
+    """anndata < 0.7: compound obs / var datasets, `h5sparse_format` / `h5sparse_shape` on X"""
+    a = sc.read_h5ad(H5 / "legacy_layout.h5ad", backed="r")
+    assert isinstance(a.X, BackedCsr) and a.shape == (500, 60)
+    assert (a.X.to_memory() != sparse.csr_matrix(expected["ad_dense"])).nnz == 0
+    assert list(a.obs_names) == list(expected["ad_names"]) and list(a.obs.columns) == ["n_counts"]
+    np.testing.assert_array_equal(a.obs["n_counts"].to_numpy(), expected["ad_counts"])
+    np.testing.assert_array_equal(a.var["highly_variable"].to_numpy(), expected["ad_hv"])
+    assert a.var["highly_variable"].dtype == bool and a.var_names[5] == "gene5"
+
+
 def test_container_variants_new_style(expected):
     """libver='latest': superblock 3 behind a 512-byte user block, version-2 object headers, compact link messages,
     layout-4 chunk indexes (single chunk, fixed array, paged fixed array), fletcher32, big-endian, compact layout,
