@@ -20,46 +20,53 @@ from ._common import (
     get_indices_distances_from_dense_matrix,
     get_indices_distances_from_sparse_matrix,
     get_sparse_matrix_from_indices_distances,
+    graph_from_device,
+    sparse_distances_from_device,
 )
-from ._transformer import METRICS, MI355XKNNTransformer, knn_search
+from ._transformer import METRICS, MI355XKNNTransformer, knn_search, knn_search_device
 
 __all__ = ["neighbors", "Neighbors", "MI355XKNNTransformer"]
 
 _METHODS = ("umap", "gauss", "jaccard")
 
 
-def _connectivities_umap(knn_indices: np.ndarray, knn_dists: np.ndarray, n_obs: int) -> sparse.csr_matrix:
+def _to_device(a, dtype):
+    """host array or torch tensor (already on the device: the built-in search hands its lists over without a round
+    trip through the host) -> contiguous device tensor of `dtype`"""
+    import torch
+
+    from .._device import require_gpu
+
+    if isinstance(a, torch.Tensor):
+        return a.to(dtype).contiguous()
+    np_dtype = {torch.int32: np.int32, torch.float32: np.float32}[dtype]
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np_dtype)).to(require_gpu())
+
+
+def _connectivities_umap(knn_indices, knn_dists, n_obs: int) -> sparse.csr_matrix:
     """neighbors/_connectivity.py:103-138 -> scamd_fuzzy_simplicial_set_f32."""
     import torch
 
     from .. import _kernels
-    from .._device import require_gpu
 
-    dev = require_gpu()
-    idx = torch.from_numpy(np.ascontiguousarray(knn_indices, dtype=np.int32)).to(dev)
-    dist = torch.from_numpy(np.ascontiguousarray(knn_dists, dtype=np.float32)).to(dev)
-    indptr, indices, data, _, _ = _kernels.fuzzy_simplicial_set(idx, dist)
-    return sparse.csr_matrix(
-        (data.cpu().numpy(), indices.cpu().numpy(), indptr.cpu().numpy()), shape=(n_obs, n_obs)
-    )
+    indptr, indices, data, _, _ = _kernels.fuzzy_simplicial_set(_to_device(knn_indices, torch.int32),
+                                                                _to_device(knn_dists, torch.float32))
+    return graph_from_device(indptr, indices, data, n_obs)
 
 
-def _connectivities_kernel(method: str, knn_indices: np.ndarray, knn_dists: np.ndarray, n_obs: int) -> sparse.csr_matrix:
+def _connectivities_kernel(method: str, knn_indices, knn_dists, n_obs: int) -> sparse.csr_matrix:
     """neighbors/_connectivity.py:21-100 ('gauss', sparse branch) / :141-186 ('jaccard') ->
     scamd_gauss_connectivities_f32 / scamd_jaccard_connectivities_f32."""
     import torch
 
     from .. import _kernels
-    from .._device import require_gpu
 
-    dev = require_gpu()
-    idx = torch.from_numpy(np.ascontiguousarray(knn_indices, dtype=np.int32)).to(dev)
+    idx = _to_device(knn_indices, torch.int32)
     if method == "gauss":
-        dist = torch.from_numpy(np.ascontiguousarray(knn_dists, dtype=np.float32)).to(dev)
-        indptr, indices, data = _kernels.gauss_connectivities(idx, dist)
+        indptr, indices, data = _kernels.gauss_connectivities(idx, _to_device(knn_dists, torch.float32))
     else:
         indptr, indices, data = _kernels.jaccard_connectivities(idx)
-    return sparse.csr_matrix((data.cpu().numpy(), indices.cpu().numpy(), indptr.cpu().numpy()), shape=(n_obs, n_obs))
+    return graph_from_device(indptr, indices, data, n_obs)
 
 
 class Neighbors:
@@ -154,8 +161,9 @@ class Neighbors:
             # built-in exact search: (n, k) arrays straight from the device, self column first with an
             # exact 0 (what the reference gets after zeroing the diagonal, neighbors/__init__.py:639-648)
             k = min(n_neighbors, self._adata.n_obs)
-            knn_indices, knn_distances = knn_search(x, k, metric=metric)
-            self._distances = get_sparse_matrix_from_indices_distances(knn_indices, knn_distances, keep_self=False)
+            # (the lists stay on the device: they feed the connectivity kernel as they are)
+            knn_indices, knn_distances = knn_search_device(x, k, metric=metric)
+            self._distances = sparse_distances_from_device(knn_indices, knn_distances)
         else:  # user-supplied estimator instance: the reference's plug-in route, used as-is (:788, :638)
             self._distances = transformer.fit_transform(x)
             knn_indices, knn_distances = get_indices_distances_from_sparse_matrix(self._distances, n_neighbors)

@@ -29,6 +29,47 @@ def get_sparse_matrix_from_indices_distances(indices, distances, *, keep_self: b
     return sparse.csr_matrix((distances.copy().ravel(), indices.copy().ravel(), indptr), shape=(n, n))
 
 
+def csr_from_trusted_arrays(data, indices, indptr, shape) -> sparse.csr_matrix:
+    """scipy CSR around arrays that come straight out of our kernels (consistent by construction), skipping the
+    constructor's O(nnz) passes (index-dtype scan of min / max, format checks, copies): ~60 ms per matrix at 1M cells,
+    more than the kernels that produced it.  `indices` and `indptr` must share one integer dtype."""
+    assert indices.dtype == indptr.dtype and indptr.shape[0] == shape[0] + 1
+    m = sparse.csr_matrix(shape, dtype=data.dtype)
+    m.data, m.indices, m.indptr = data, indices, indptr
+    return m
+
+
+def sparse_distances_from_device(idx, dist) -> sparse.csr_matrix:
+    """`get_sparse_matrix_from_indices_distances(..., keep_self=False)` (_common.py:35-61) for the (n, k) lists of the
+    built-in search while they are still torch tensors: the self column is dropped on the device and the two arrays
+    arrive on the host in their final layout (no host-side slicing copies)."""
+    import torch
+
+    n, k = idx.shape
+    if k < 1 or not bool((idx[:, 0] == torch.arange(n, device=idx.device, dtype=idx.dtype)).any()):
+        msg = "The first neighbor should be the cell itself."
+        raise AssertionError(msg)
+    nnz = n * (k - 1)
+    itype = torch.int32 if max(nnz, n) < 2**31 else torch.int64
+    indices = idx[:, 1:].to(itype).contiguous().reshape(-1).cpu().numpy()
+    data = dist[:, 1:].contiguous().reshape(-1).cpu().numpy()
+    indptr = np.arange(0, nnz + 1, k - 1, dtype=indices.dtype) if k > 1 else np.zeros(n + 1, dtype=indices.dtype)
+    return csr_from_trusted_arrays(data, indices, indptr, (n, n))
+
+
+def graph_from_device(indptr, indices, data, n_obs: int) -> sparse.csr_matrix:
+    """connectivities CSR (device tensors of a `_kernels.*connectivities` / `fuzzy_simplicial_set` call) -> scipy"""
+    import torch
+
+    itype = torch.int32 if max(int(indices.numel()), n_obs) < 2**31 else torch.int64
+    m = csr_from_trusted_arrays(data.cpu().numpy(), indices.to(itype).cpu().numpy(), indptr.to(itype).cpu().numpy(),
+                                (n_obs, n_obs))
+    # the C ABI promises sorted, duplicate-free rows (include/scanpy_amd.h): recording it saves scipy (and tl.leiden)
+    # an O(nnz) check per use
+    m.has_canonical_format = True
+    return m
+
+
 def get_indices_distances_from_dense_matrix(d: np.ndarray, n_neighbors: int):
     """_common.py:64-71."""
     sample_range = np.arange(d.shape[0])[:, None]

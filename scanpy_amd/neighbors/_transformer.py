@@ -17,9 +17,9 @@ from scipy import sparse
 METRICS = ("euclidean", "l2", "cosine")
 
 
-def knn_search(x, k: int, *, q_begin: int = 0, n_query: int | None = None, metric: str = "euclidean"):
-    """Exact kNN on the GPU.  -> (indices int64 [nq, k], distances float64 [nq, k]); column 0 is the row itself with
-    distance exactly 0.
+def knn_search_device(x, k: int, *, q_begin: int = 0, n_query: int | None = None, metric: str = "euclidean"):
+    """Exact kNN on the GPU, results left on the device: (indices int32 [nq, k], distances float64 [nq, k]); column 0
+    is the row itself with distance exactly 0.
 
     metric 'cosine' (sklearn: 1 - x.y / (|x||y|)): on unit-length rows the Euclidean order IS the cosine order and
     1 - cos = |x^ - y^|^2 / 2, so the rows are normalised on the device and the Euclidean kernel does the search."""
@@ -42,6 +42,12 @@ def knn_search(x, k: int, *, q_begin: int = 0, n_query: int | None = None, metri
     idx, dist, _ = _kernels.knn(xd, k, q_begin=q_begin, n_query=n_query)
     if metric == "cosine":
         dist = 0.5 * dist * dist
+    return idx, dist
+
+
+def knn_search(x, k: int, *, q_begin: int = 0, n_query: int | None = None, metric: str = "euclidean"):
+    """`knn_search_device` with the results on the host: (indices int64 [nq, k], distances float64 [nq, k])."""
+    idx, dist = knn_search_device(x, k, q_begin=q_begin, n_query=n_query, metric=metric)
     return idx.cpu().numpy().astype(np.int64), dist.cpu().numpy()
 
 

@@ -74,7 +74,8 @@ def leiden_partition(adjacency, *, resolution=1.0, n_iterations=-1, seed=0, use_
     from .._device import require_gpu
 
     dev = require_gpu()
-    adj = sparse.csr_matrix(adjacency)
+    # (a CSR matrix is used as it is: re-wrapping it would drop its cached `has_sorted_indices`, an O(nnz) check)
+    adj = adjacency if sparse.isspmatrix_csr(adjacency) else sparse.csr_matrix(adjacency)
     if not adj.has_sorted_indices:
         adj = adj.sorted_indices()
     n = adj.shape[0]
@@ -146,7 +147,9 @@ def leiden(  # noqa: PLR0913
         # order of the label strings is the numeric order, so the codes come straight from a searchsorted instead of
         # a million int -> str conversions (~100 ms at 1M cells)
         uniq = np.unique(groups)
-        adata.obs[key_added] = pd.Categorical.from_codes(np.searchsorted(uniq, groups), categories=[str(u) for u in uniq])
+        # (the optimiser numbers communities 0..C-1: then the labels are their own codes)
+        codes = groups if uniq.size and uniq[0] == 0 and uniq[-1] == uniq.size - 1 else np.searchsorted(uniq, groups)
+        adata.obs[key_added] = pd.Categorical.from_codes(codes, categories=[str(u) for u in uniq])
     else:
         adata.obs[key_added] = pd.Categorical(
             values=groups.astype("U"),
