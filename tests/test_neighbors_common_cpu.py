@@ -77,3 +77,39 @@ def test_ragged_matrix_takes_slow_path_with_warning():
     with pytest.warns(RuntimeWarning, match="no constant number of neighbors"):
         ind, dist = get_indices_distances_from_sparse_matrix(mat, 4)
     assert ind.shape == (10, 4)
+
+
+def test_device_list_route_equals_the_reference_conventions():
+    """`sparse_distances_from_device` / `graph_from_device` (the built-in search keeps its lists as torch tensors and
+    wraps the CSR slots without scipy's validation passes) == the checked constructions of `_common.py:35-61`"""
+    import torch
+    from scipy import sparse
+
+    from scanpy_amd.neighbors import _common as c
+
+    rng = np.random.default_rng(0)
+    n, k = 300, 7
+    idx = np.stack([rng.permutation(n)[:k] for _ in range(n)]).astype(np.int32)
+    idx[:, 0] = np.arange(n)
+    dist = np.sort(rng.random((n, k)), axis=1)
+    dist[:, 0] = 0.0
+    fast = c.sparse_distances_from_device(torch.from_numpy(idx), torch.from_numpy(dist))
+    ref = c.get_sparse_matrix_from_indices_distances(idx.astype(np.int64), dist, keep_self=False)
+    assert fast.shape == ref.shape and fast.dtype == ref.dtype == np.float64
+    assert fast.indices.dtype == fast.indptr.dtype == ref.indices.dtype == np.int32
+    np.testing.assert_array_equal(fast.indptr, ref.indptr)
+    np.testing.assert_array_equal(fast.indices, ref.indices)
+    np.testing.assert_array_equal(fast.data, ref.data)
+    assert (fast @ np.ones(n)).shape == (n,) and (fast.T.tocsr() != ref.T.tocsr()).nnz == 0  # behaves as a CSR
+    bad = idx.copy()
+    bad[:, 0] = (np.arange(n) + 1) % n
+    with pytest.raises(AssertionError, match="first neighbor should be the cell itself"):
+        c.sparse_distances_from_device(torch.from_numpy(bad), torch.from_numpy(dist))
+    g = sparse.random(n, n, density=0.05, format="csr", dtype=np.float32, random_state=1)
+    g.sort_indices()
+    m = c.graph_from_device(torch.from_numpy(g.indptr.astype(np.int64)), torch.from_numpy(g.indices.astype(np.int32)),
+                            torch.from_numpy(g.data), n)
+    assert (m != g).nnz == 0 and m.indices.dtype == m.indptr.dtype == np.int32
+    assert m.has_sorted_indices and m.has_canonical_format  # recorded, and true of what the kernels return
+    with pytest.raises(AssertionError):
+        c.csr_from_trusted_arrays(g.data, g.indices.astype(np.int32), g.indptr.astype(np.int64), (n, n))
