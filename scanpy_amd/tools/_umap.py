@@ -140,7 +140,8 @@ def umap_embedding(connectivities, *, n_components=2, n_epochs=None, a, b, gamma
     # the graph goes to the device as it is stored (CSR); pruning and the epoch schedule are computed there
     # (`prune_and_schedule_device` == `_prune_and_schedule`, which a COO round trip through scipy makes 50x slower than
     # the whole optimisation at 1M cells)
-    csr = sparse.csr_matrix(connectivities)
+    # (a CSR matrix is used as it is: re-wrapping would drop the canonical-format flag `pp.neighbors` recorded)
+    csr = connectivities if sparse.isspmatrix_csr(connectivities) else sparse.csr_matrix(connectivities)
     if not csr.has_canonical_format:
         csr = csr.copy()
         csr.sum_duplicates()
