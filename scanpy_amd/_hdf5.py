@@ -643,7 +643,7 @@ class Group(_Node):
 class Dataset(_Node):
     def __init__(self, f: File, addr: int, name: str):
         super().__init__(f, addr, name)
-        O, L = f.O, f.L
+        L = f.L
         self.filters: list[tuple[int, tuple[int, ...]]] = []
         self.fill = None
         self.type = self.shape = None

@@ -19,11 +19,10 @@ from .._utils import _UNSET, choose_representation, resolve_seed
 from ._common import (
     get_indices_distances_from_dense_matrix,
     get_indices_distances_from_sparse_matrix,
-    get_sparse_matrix_from_indices_distances,
     graph_from_device,
     sparse_distances_from_device,
 )
-from ._transformer import METRICS, MI355XKNNTransformer, knn_search, knn_search_device
+from ._transformer import METRICS, MI355XKNNTransformer, knn_search_device
 
 __all__ = ["neighbors", "Neighbors", "MI355XKNNTransformer"]
 

@@ -4,9 +4,6 @@ from __future__ import annotations
 
 import logging
 
-import numpy as np
-from scipy import sparse
-
 from .._anndata import is_anndata
 from .._utils import view_to_actual
 from . import _csr_device

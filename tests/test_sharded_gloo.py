@@ -9,7 +9,6 @@ import sys
 from pathlib import Path
 
 import numpy as np
-import pytest
 
 from scanpy_amd._pipeline import shard_bounds
 

@@ -3,7 +3,6 @@ from __future__ import annotations
 
 import numpy as np
 import pytest
-from scipy import sparse
 
 import scanpy_amd as sc
 from oracle import umap as ou
