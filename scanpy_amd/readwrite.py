@@ -265,78 +265,139 @@ def _chunking(shape: tuple[int, ...], chunks) -> tuple[tuple[int, ...], tuple[in
     return c, shard
 
 
-def _write_array(st, path: str, value, enc: str, version: str, chunks=None, level: int = 0) -> None:
-    arr = value if isinstance(value, np.ndarray) else np.asarray(value)
-    c, shard = _chunking(arr.shape, chunks)
-    z3.write_array(st, path, arr, chunk_shape=c, shard_shape=shard, level=level,
-                   attributes={"encoding-type": enc, "encoding-version": version} if enc else {})
+class _ZarrSink:
+    """where `write_elem` puts groups and arrays: a zarr-v3 directory store"""
+
+    def __init__(self, store, level: int):
+        self.st, self.level = store, level
+
+    def group(self, path: str, attrs: dict) -> None:
+        z3.write_group(self.st, path, attrs)
+
+    def array(self, path: str, value, enc: str | None, version: str, chunks=None) -> None:
+        arr = value if isinstance(value, np.ndarray) else np.asarray(value)
+        c, shard = _chunking(arr.shape, chunks)
+        z3.write_array(self.st, path, arr, chunk_shape=c, shard_shape=shard, level=self.level,
+                       attributes={"encoding-type": enc, "encoding-version": version} if enc else {})
+
+    def close(self) -> None:
+        self.st.close()
 
 
-def _write_dataframe(st, path: str, df: pd.DataFrame, level: int) -> None:
+class _H5Sink:
+    """... or an HDF5 file: the nodes are collected as a tree and written in post-order by `_hdf5_write.write_tree`
+    (arrays are referenced, not copied, until then)"""
+
+    SMALL = 1 << 16  # datasets below this many bytes stay contiguous, as anndata leaves scalars and short vectors
+
+    def __init__(self, path, compression: str | None, level: int):
+        from . import _hdf5_write as hw
+
+        self.hw, self.path, self.compression, self.level = hw, path, compression, level
+        self.root = None
+
+    @staticmethod
+    def _attrs(attrs: dict) -> dict:
+        out = {}
+        for k, v in attrs.items():
+            if k == "shape":
+                v = np.asarray(v, dtype=np.int64)
+            elif k == "column-order":
+                v = np.asarray(list(v), dtype=object)
+            out[k] = v
+        return out
+
+    def group(self, path: str, attrs: dict) -> None:
+        node = self.hw.Node(self._attrs(attrs), is_group=True)
+        if path == "":
+            self.root = node
+        else:
+            self.root.add(path, node)
+
+    def array(self, path: str, value, enc: str | None, version: str, chunks=None) -> None:
+        arr = value if isinstance(value, (np.ndarray, str)) else np.asarray(value)
+        nbytes = arr.nbytes if isinstance(arr, np.ndarray) and arr.dtype.kind not in "OU" else 0
+        comp = self.compression if nbytes >= self.SMALL else None
+        attrs = {"encoding-type": enc, "encoding-version": version} if enc else {}
+        self.root.add(path, self.hw.Node(attrs, arr, compression=comp))
+
+    def close(self) -> None:
+        self.hw.write_tree(self.path, self.root, level=self.level)
+
+
+def _write_dataframe(sink, path: str, df: pd.DataFrame) -> None:
     index_key = df.index.name if df.index.name not in (None, "") else "_index"
     if index_key in df.columns:
         raise ValueError(f"the index name {index_key!r} is also a column")
-    z3.write_group(st, path, {"_index": index_key, "column-order": [str(c) for c in df.columns],
-                              "encoding-type": "dataframe", "encoding-version": "0.2.0"})
-    write_elem(st, f"{path}/{index_key}", np.asarray(df.index.astype(str), dtype=object), level=level)
+    sink.group(path, {"_index": index_key, "column-order": [str(c) for c in df.columns],
+                      "encoding-type": "dataframe", "encoding-version": "0.2.0"})
+    write_elem(sink, f"{path}/{index_key}", np.asarray(df.index.astype(str), dtype=object))
     for name in df.columns:
-        write_elem(st, f"{path}/{name}", df[name].array if isinstance(df[name].dtype, pd.CategoricalDtype)
-                   or pd.api.types.is_extension_array_dtype(df[name].dtype) else df[name].to_numpy(), level=level)
+        write_elem(sink, f"{path}/{name}", df[name].array if isinstance(df[name].dtype, pd.CategoricalDtype)
+                   or pd.api.types.is_extension_array_dtype(df[name].dtype) else df[name].to_numpy())
 
 
-def write_elem(st, path: str, value, *, chunks=None, level: int = 0) -> None:
-    """Write one in-memory value with the anndata encoding of its type."""
+def write_elem(sink, path: str, value, *, chunks=None) -> None:
+    """Write one in-memory value with the anndata encoding of its type (the same for both containers)."""
     if is_backed(value):
         value = value.to_memory()
     if sparse.issparse(value):
         fmt = value.format
         if fmt not in {"csr", "csc"}:
             value, fmt = value.tocsr(), "csr"
-        z3.write_group(st, path, {"shape": [int(s) for s in value.shape], "encoding-type": f"{fmt}_matrix",
-                                  "encoding-version": "0.1.0"})
-        _write_array(st, f"{path}/data", value.data, None, "", chunks, level)
-        _write_array(st, f"{path}/indices", value.indices, None, "", chunks, level)
-        _write_array(st, f"{path}/indptr", value.indptr, None, "", chunks, level)
+        sink.group(path, {"shape": [int(s) for s in value.shape], "encoding-type": f"{fmt}_matrix",
+                          "encoding-version": "0.1.0"})
+        sink.array(f"{path}/data", value.data, None, "", chunks)
+        sink.array(f"{path}/indices", value.indices, None, "", chunks)
+        sink.array(f"{path}/indptr", value.indptr, None, "", chunks)
     elif isinstance(value, pd.DataFrame):
-        _write_dataframe(st, path, value, level)
+        _write_dataframe(sink, path, value)
     elif isinstance(value, (pd.Categorical, pd.Series)) and isinstance(value.dtype, pd.CategoricalDtype):
         cat = value if isinstance(value, pd.Categorical) else value.array
-        z3.write_group(st, path, {"ordered": bool(cat.ordered), "encoding-type": "categorical",
-                                  "encoding-version": "0.2.0"})
-        write_elem(st, f"{path}/categories", np.asarray(cat.categories), level=level)
-        _write_array(st, f"{path}/codes", np.asarray(cat.codes), "array", "0.2.0", None, level)
+        sink.group(path, {"ordered": bool(cat.ordered), "encoding-type": "categorical", "encoding-version": "0.2.0"})
+        write_elem(sink, f"{path}/categories", np.asarray(cat.categories))
+        sink.array(f"{path}/codes", np.asarray(cat.codes), "array", "0.2.0")
     elif isinstance(value, (pd.arrays.IntegerArray, pd.arrays.BooleanArray)):
         kind = "nullable-boolean" if isinstance(value, pd.arrays.BooleanArray) else "nullable-integer"
-        z3.write_group(st, path, {"encoding-type": kind, "encoding-version": "0.1.0"})
-        mask = np.asarray(value.isna())
+        sink.group(path, {"encoding-type": kind, "encoding-version": "0.1.0"})
         fill = False if kind == "nullable-boolean" else 0
-        _write_array(st, f"{path}/values", value.to_numpy(dtype=value.dtype.numpy_dtype, na_value=fill), "array",
-                     "0.2.0", None, level)
-        _write_array(st, f"{path}/mask", mask, "array", "0.2.0", None, level)
+        sink.array(f"{path}/values", value.to_numpy(dtype=value.dtype.numpy_dtype, na_value=fill), "array", "0.2.0")
+        sink.array(f"{path}/mask", np.asarray(value.isna()), "array", "0.2.0")
     elif isinstance(value, dict):
-        z3.write_group(st, path, {"encoding-type": "dict", "encoding-version": "0.1.0"})
+        sink.group(path, {"encoding-type": "dict", "encoding-version": "0.1.0"})
         for k, v in value.items():
             if v is None:
                 continue
-            write_elem(st, f"{path}/{k}", v, level=level)
+            write_elem(sink, f"{path}/{k}", v)
     elif isinstance(value, str):
-        _write_array(st, path, np.asarray(value, dtype=object), "string", "0.2.0", None, level)
+        sink.array(path, np.asarray(value, dtype=object), "string", "0.2.0")
     elif isinstance(value, (bool, int, float, np.generic)) and not isinstance(value, np.str_):
-        _write_array(st, path, np.asarray(value), "numeric-scalar", "0.2.0", None, level)
+        sink.array(path, np.asarray(value), "numeric-scalar", "0.2.0")
     else:
         if isinstance(value, pd.Series):
             value = value.to_numpy()
         arr = np.asarray(value)
         if arr.dtype.names:
-            _write_array(st, path, arr, "rec-array", "0.2.0", None, level)
+            sink.array(path, arr, "rec-array", "0.2.0")
         elif arr.dtype.kind in "OUS":
-            _write_array(st, path, arr.astype(object), "string" if arr.ndim == 0 else "string-array", "0.2.0",
-                         chunks if arr.ndim else None, level)
+            sink.array(path, arr.astype(object), "string" if arr.ndim == 0 else "string-array", "0.2.0",
+                       chunks if arr.ndim else None)
         elif arr.dtype.kind in "biuf":
-            _write_array(st, path, arr, "numeric-scalar" if arr.ndim == 0 else "array", "0.2.0",
-                         chunks if arr.ndim == 2 else None, level)
+            sink.array(path, arr, "numeric-scalar" if arr.ndim == 0 else "array", "0.2.0",
+                       chunks if arr.ndim == 2 else None)
         else:
             raise TypeError(f"cannot write {path!r}: values of dtype {arr.dtype} have no encoding here")
+
+
+def _write_anndata(sink, adata, chunks=None) -> None:
+    sink.group("", {"encoding-type": "anndata", "encoding-version": "0.1.0"})
+    if adata.X is not None:
+        write_elem(sink, "X", adata.X, chunks=chunks)
+    write_elem(sink, "obs", adata.obs)
+    write_elem(sink, "var", adata.var)
+    for name in ("obsm", "varm", "obsp", "varp", "layers", "uns"):
+        write_elem(sink, name, dict(getattr(adata, name, None) or {}))
+    sink.close()
 
 
 def write_zarr(store, adata, *, chunks=None, level: int = 0) -> None:
@@ -346,12 +407,46 @@ def write_zarr(store, adata, *, chunks=None, level: int = 0) -> None:
     path = Path(store)
     if path.suffix == ".zip":
         raise ValueError("write a directory store (zip it afterwards if needed)")
-    st = z3.open_store(path, "w")
-    z3.write_group(st, "", {"encoding-type": "anndata", "encoding-version": "0.1.0"})
-    if adata.X is not None:
-        write_elem(st, "X", adata.X, chunks=chunks, level=level)
-    write_elem(st, "obs", adata.obs, level=level)
-    write_elem(st, "var", adata.var, level=level)
-    for name in ("obsm", "varm", "obsp", "varp", "layers", "uns"):
-        write_elem(st, name, dict(getattr(adata, name, None) or {}), level=level)
-    st.close()
+    _write_anndata(_ZarrSink(z3.open_store(path, "w"), level), adata, chunks)
+
+
+def write_h5ad(filename, adata, *, compression: str | None = None, compression_opts: int | None = None) -> None:
+    """Write `adata` as an `.h5ad` file (`AnnData.write_h5ad`, what `sc.write` calls: src/scanpy/readwrite.py:727-740).
+    The classic HDF5 container h5py writes by default, produced by `scanpy_amd/_hdf5_write.py`; files were read back
+    with the HDF5 library (h5py) in the tests.  compression: None or 'gzip' (+ shuffle), level `compression_opts`
+    (default 4); 'lzf' is not written here."""
+    if compression not in {None, "gzip"}:
+        raise NotImplementedError(f"compression={compression!r}: None and 'gzip' are written here")
+    _write_anndata(_H5Sink(filename, compression, 4 if compression_opts is None else int(compression_opts)), adata)
+
+
+def write(filename, adata, *, ext: str | None = None, compression: str | None = "gzip",
+          compression_opts: int | None = None) -> None:
+    """Write AnnData objects to file (drop-in for `scanpy.write`, src/scanpy/readwrite.py:657-740): the extension picks
+    the container -- 'h5ad' (default when there is none) or 'zarr'; 'csv' is not offered on this path."""
+    filename = Path(filename)
+    if ext is None:
+        ext = filename.suffix.lstrip(".") or "h5ad"
+        if not filename.suffix:
+            filename = filename.with_suffix(".h5ad")
+    if ext == "zarr":
+        write_zarr(filename, adata)
+    elif ext in {"h5ad", "h5"}:
+        write_h5ad(filename, adata, compression=compression, compression_opts=compression_opts)
+    else:
+        raise ValueError(f"This has to be a {'h5ad'!r} or {'zarr'!r} file ({ext!r} is not written on this path).")
+
+
+def read(filename, backed: str | None = None, *, ext: str | None = None, **kwargs) -> AnnData:
+    """Read a file by its extension (the `.h5ad` / `.h5` / `.zarr` branches of `scanpy.read`,
+    src/scanpy/readwrite.py:71-157, 808-841; text, Excel, mtx and loom inputs are not offered on this path)."""
+    filename = Path(filename)
+    name = filename.name
+    ext = ext or ("zarr" if name.endswith((".zarr", ".zarr.zip")) else filename.suffix.lstrip("."))
+    if kwargs:
+        raise TypeError(f"read() got unexpected arguments {sorted(kwargs)} (the text-format options do not apply here)")
+    if ext in {"h5ad", "h5"}:
+        return read_h5ad(filename, backed=backed)
+    if ext == "zarr":
+        return read_zarr(filename, backed=backed)
+    raise ValueError(f"{filename}: only 'h5ad', 'h5' and 'zarr' files are read on this path (got {ext!r})")
