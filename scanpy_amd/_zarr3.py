@@ -172,6 +172,10 @@ class DirectoryStore:
         d = self.root / prefix if prefix else self.root
         return sorted(p.name for p in d.iterdir() if p.is_dir() and (p / "zarr.json").is_file())
 
+    def subdirs(self, prefix: str) -> list[str]:
+        d = self.root / prefix if prefix else self.root
+        return sorted(p.name for p in d.iterdir() if p.is_dir())
+
     def close(self) -> None:
         with self._lock:
             for fd in self._fds.values():
@@ -199,10 +203,11 @@ class ZipStore:
         names = self.z.namelist()
         # a store zipped together with its top-level directory: strip the common prefix
         self._prefix = ""
-        if "zarr.json" not in names:
+        if "zarr.json" not in names and ".zgroup" not in names:
             tops = {n.split("/", 1)[0] for n in names}
-            if len(tops) == 1 and f"{next(iter(tops))}/zarr.json" in names:
-                self._prefix = next(iter(tops)) + "/"
+            top = next(iter(tops)) if len(tops) == 1 else None
+            if top is not None and (f"{top}/zarr.json" in names or f"{top}/.zgroup" in names):
+                self._prefix = top + "/"
 
     def _info(self, key: str):
         return self.z.getinfo(self._prefix + key)  # the LAST entry of that name: later appends override
@@ -242,6 +247,14 @@ class ZipStore:
                     out.add(rest)
         return sorted(out)
 
+    def subdirs(self, prefix: str) -> list[str]:
+        base = self._prefix + (prefix + "/" if prefix else "")
+        out = set()
+        for n in self.z.namelist():
+            if n.startswith(base) and "/" in n[len(base):]:
+                out.add(n[len(base):].split("/", 1)[0])
+        return sorted(out)
+
     def set(self, key: str, value: bytes) -> None:
         raise PermissionError("store opened read-only")
 
@@ -250,6 +263,17 @@ class ZipStore:
         if self._fd is not None:
             os.close(self._fd)
             self._fd = None
+
+
+def open_root(store):
+    """root group of a store, whichever zarr format it is in (3: `zarr.json`; 2: `.zgroup`, read by `_zarr2`)"""
+    if store.exists("zarr.json"):
+        return Group(store)
+    if store.exists(".zgroup"):
+        from . import _zarr2
+
+        return _zarr2.Group(store)
+    raise ValueError("not a zarr store: neither `zarr.json` (format 3) nor `.zgroup` (format 2) at its root")
 
 
 def open_store(path, mode: str = "r"):

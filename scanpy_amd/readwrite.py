@@ -132,7 +132,7 @@ def _read_anndata(root, where, backed) -> AnnData:
 
 
 def read_zarr(store, *, backed: str | None = None) -> AnnData:
-    """Read an AnnData `.zarr` directory or `.zarr.zip` (zarr format 3).
+    """Read an AnnData `.zarr` directory or `.zarr.zip` (zarr format 3, or format 2 as anndata < 0.11 wrote it).
 
     backed
         None: everything in memory (like `anndata.read_zarr`).  'r': a CSR `X` stays on disk as a `BackedCsr`
@@ -140,7 +140,7 @@ def read_zarr(store, *, backed: str | None = None) -> AnnData:
     """
     if backed not in {None, "r"}:
         raise ValueError("backed must be None or 'r' (stores are never modified in place)")
-    return _read_anndata(z3.Group(z3.open_store(store)), store, backed)
+    return _read_anndata(z3.open_root(z3.open_store(store)), store, backed)
 
 
 def read_h5ad(filename, backed: str | None = None) -> AnnData:
