@@ -181,6 +181,47 @@ def highly_variable_genes(x, *, flavor="seurat", n_top_genes=None, min_disp=0.5,
 # --------------------------------------------------------------------------------------------------
 # scale  (src/scanpy/preprocessing/_scale.py:137-282)
 # --------------------------------------------------------------------------------------------------
+def highly_variable_genes_seurat_v3(x, *, n_top_genes=2000, batch=None, span=0.3, flavor="seurat_v3"):
+    """`_highly_variable_genes_seurat_v3` (src/scanpy/preprocessing/_highly_variable_genes.py:118-316) on a dense or
+    sparse count matrix -> DataFrame (means, variances, variances_norm, highly_variable_rank,
+    highly_variable_nbatches, highly_variable); the LOESS is oracle/loess.py."""
+    from .loess import loess
+
+    xd = np.asarray(x.toarray() if sparse.issparse(x) else x, dtype=np.float64)
+    n, g = xd.shape
+    means, variances = xd.mean(axis=0), xd.var(axis=0, ddof=1)
+    batch = np.zeros(n, dtype=int) if batch is None else np.asarray(batch)
+    norm = []
+    for b in np.unique(batch):
+        xb = xd[batch == b]
+        nb = xb.shape[0]
+        mean, var = xb.mean(axis=0), xb.var(axis=0, ddof=1)
+        est = np.zeros(g)
+        ok = var > 0
+        if ok.any():
+            est[ok] = loess(np.log10(mean[ok]), np.log10(var[ok]), span=span, degree=2)
+        reg_std = np.sqrt(10 ** est)
+        clip = reg_std * np.sqrt(nb) + mean
+        stored = xb != 0  # the reference sums over the STORED values of a sparse batch (`:75-115`)
+        clipped = np.where(stored, np.minimum(xb, clip[None, :]), 0.0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            norm.append((1 / ((nb - 1) * reg_std ** 2)) * (nb * mean ** 2 + (clipped ** 2).sum(axis=0)
+                                                             - 2 * clipped.sum(axis=0) * mean))
+    norm = np.stack(norm)
+    ranked = np.argsort(np.argsort(-norm, axis=1), axis=1).astype(np.float32)
+    nb_high = (ranked < n_top_genes).sum(axis=0)
+    ranked[ranked >= n_top_genes] = np.nan
+    med = np.ma.median(np.ma.masked_invalid(ranked), axis=0).filled(np.nan)
+    df = pd.DataFrame({"means": means, "variances": variances, "variances_norm": norm.mean(axis=0),
+                       "highly_variable_rank": med, "highly_variable_nbatches": nb_high})
+    keys, asc = (["highly_variable_rank", "highly_variable_nbatches"], [True, False]) if flavor == "seurat_v3" \
+        else (["highly_variable_nbatches", "highly_variable_rank"], [False, True])
+    top = df[keys].sort_values(keys, ascending=asc, na_position="last").index[:n_top_genes]
+    df["highly_variable"] = False
+    df.loc[top, "highly_variable"] = True
+    return df
+
+
 def scale(x, *, zero_center=True, max_value=None, mask_obs=None):
     """`scale_array` (`:153-229`) / `scale_array_masked` (`:232-277`).  Returns (X_scaled, mean, std).
 

@@ -134,6 +134,80 @@ def _single_batch(be, m, var_names, *, n_rows: int, row_mask, filter_unexpressed
     return df
 
 
+def _seurat_v3(adata, *, flavor: str, layer, n_top_genes: int, batch_key, check_values: bool, span: float,
+               subset: bool, inplace: bool):
+    """`_highly_variable_genes_seurat_v3` (`:118-316`): variance of each gene after standardising with a LOESS trend of
+    log10(variance) on log10(mean) (per batch) and clipping at sqrt(n) standard deviations.  Three device sweeps per
+    batch -- per-gene sums (mean, variance), the clipped sums -- and a LOESS on the host (`_loess.py`, R's dloess)."""
+    from ._loess import loess_fit
+
+    x = _get_arr(adata, layer=layer)
+    be = _csr_device.default_backend()
+    m = be.upload(_csr_device.in_memory(x))
+    n_obs, n_vars = adata.n_obs, adata.n_vars
+    if check_values and not be.nonnegative_integers(m):
+        warnings.warn(f"`flavor={flavor!r}` expects raw count data, but non-integers were found.", UserWarning,
+                      stacklevel=3)
+    s, sq, _ = be.col_stats(m)
+    means, variances = _csr_device.mean_var_from_sums(s, sq, n_obs, correction=1)
+    if batch_key is None:
+        batch_codes, batches = np.zeros(n_obs, dtype=np.int64), [0]
+    else:
+        col = adata.obs[batch_key]
+        batch_codes, uniq = pd.factorize(col.to_numpy(), sort=True)  # `np.unique(batch_info)` order (`:196`)
+        batches = list(range(len(uniq)))
+    norm_gene_vars = []
+    for b in batches:
+        mask = None if batch_key is None else batch_codes == b
+        n_b = n_obs if mask is None else int(mask.sum())
+        if mask is None:
+            mean, var = means, variances
+        else:
+            sb, sqb, _ = be.col_stats(m, row_mask=mask)
+            mean, var = _csr_device.mean_var_from_sums(sb, sqb, n_b, correction=1)
+        estimat_var = np.zeros(n_vars, dtype=np.float64)
+        not_const = var > 0
+        if not_const.any():
+            estimat_var[not_const] = loess_fit(np.log10(mean[not_const]), np.log10(var[not_const]), span=span, degree=2)
+        reg_std = np.sqrt(10 ** estimat_var)
+        clip_val = reg_std * np.sqrt(n_b) + mean  # clip large values as in Seurat (`:231-233`)
+        sq_sum, c_sum = be.clip_col_sums(m, clip_val, row_mask=mask)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            norm_gene_vars.append((1 / ((n_b - 1) * np.square(reg_std)))
+                                  * ((n_b * np.square(mean)) + sq_sum - 2 * c_sum * mean))
+    norm_gene_vars = np.stack(norm_gene_vars, axis=0)
+    ranked = np.argsort(np.argsort(-norm_gene_vars, axis=1), axis=1).astype(np.float32)  # small rank = most variable
+    num_batches_high_var = np.sum((ranked < n_top_genes).astype(int), axis=0)
+    ranked[ranked >= n_top_genes] = np.nan
+    median_ranked = np.ma.median(np.ma.masked_invalid(ranked), axis=0).filled(np.nan)
+    df = pd.DataFrame(index=adata.var_names)
+    df["means"], df["variances"] = means, variances
+    df = df.assign(gene_name=df.index, highly_variable_nbatches=num_batches_high_var,
+                   highly_variable_rank=median_ranked, variances_norm=np.mean(norm_gene_vars, axis=0))
+    if flavor == "seurat_v3":
+        sort_cols, ascending = ["highly_variable_rank", "highly_variable_nbatches"], [True, False]
+    else:
+        sort_cols, ascending = ["highly_variable_nbatches", "highly_variable_rank"], [False, True]
+    sorted_index = df[sort_cols].sort_values(sort_cols, ascending=ascending, na_position="last").index
+    df["highly_variable"] = False
+    df.loc[sorted_index[:int(n_top_genes)], "highly_variable"] = True
+    if not inplace:
+        if batch_key is None:
+            df = df.drop(["highly_variable_nbatches"], axis=1)
+        if subset:
+            df = df.iloc[df["highly_variable"].to_numpy(), :]
+        return df
+    adata.uns["hvg"] = {"flavor": flavor}
+    for key in ("highly_variable", "highly_variable_rank", "means", "variances"):
+        adata.var[key] = df[key].to_numpy()
+    adata.var["variances_norm"] = df["variances_norm"].to_numpy().astype("float64", copy=False)
+    if batch_key is not None:
+        adata.var["highly_variable_nbatches"] = df["highly_variable_nbatches"].to_numpy()
+    if subset:
+        adata._inplace_subset_var(df["highly_variable"].to_numpy())
+    return None
+
+
 def highly_variable_genes(  # noqa: PLR0913
     adata,
     *,
@@ -154,16 +228,15 @@ def highly_variable_genes(  # noqa: PLR0913
 ):
     """Annotate highly variable genes (drop-in for `scanpy.pp.highly_variable_genes`, `:630`).
 
-    Expects logarithmised data.  `flavor='seurat_v3'` / `'seurat_v3_paper'` needs scikit-misc's LOESS, which is not
-    installed: the same ImportError as the reference's (`:137-141`)."""
+    Expects logarithmised data, except `flavor='seurat_v3'` / `'seurat_v3_paper'`, which expect counts; their LOESS
+    (scikit-misc in the reference) is `_loess.py`, pinned to Seurat's own numbers."""
     if not is_anndata(adata):
         msg = ("`pp.highly_variable_genes` expects an `AnnData` argument, "
                "pass `inplace=False` if you want to return a `pd.DataFrame`.")
         raise ValueError(msg)
     if flavor in {"seurat_v3", "seurat_v3_paper"}:
-        msg = ("No module named 'skmisc' (flavor 'seurat_v3' fits a LOESS with scikit-misc, `:153-157`). "
-               "Please install `scikit-misc` and try again.")
-        raise ImportError(msg)
+        return _seurat_v3(adata, flavor=flavor, layer=layer, n_top_genes=2000 if n_top_genes is None else n_top_genes,
+                          batch_key=batch_key, check_values=check_values, span=span, subset=subset, inplace=inplace)
     if flavor not in {"seurat", "cell_ranger"}:
         raise ValueError('`flavor` needs to be "seurat" or "cell_ranger"')
     cutoff = _Cutoffs.validate(n_top_genes=n_top_genes, min_disp=min_disp, max_disp=max_disp, min_mean=min_mean,

@@ -158,6 +158,17 @@ def main() -> None:
                 "X_scaled_for_mask", "X_centered_for_mask", "X_scaled_for_mask_clipped"}
     np.savez(OUT / "scale_toy.npz", **literal_arrays(REF / "tests/test_scaling.py", sc_names))
 
+    # Seurat's vst table for pbmc3k (tests/_scripts/seurat_extract_hvg_v3.r wrote it): per gene the mean, the
+    # variance and `variance.expected` = 10 ** (R's loess(log10(variance) ~ log10(mean), span = 0.3) fitted values),
+    # the known answers of scanpy_amd/preprocessing/_loess.py; plus the 2000 genes Seurat's SelectIntegrationFeatures
+    # picked with a batch covariate (tests/test_highly_variable_genes.py:462-491)
+    import pandas as pd
+
+    vst = pd.read_csv(REF / "tests/_scripts/seurat_hvg_v3.csv.gz", index_col=0)
+    np.savez_compressed(OUT / "loess_seurat_v3.npz", mean=vst["mean"].to_numpy(), variance=vst["variance"].to_numpy(),
+                        variance_expected=vst["variance.expected"].to_numpy(),
+                        variance_standardized=vst["variance.standardized"].to_numpy())
+
     for f in ("pca_toy.npz", "neighbors_toy.npz", "pbmc68k_reduced.npz", "hvg_golden.npz", "scale_toy.npz"):
         print(f, (OUT / f).stat().st_size, "bytes")
 

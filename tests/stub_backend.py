@@ -127,6 +127,16 @@ class CpuStubPPBackend:
         return (np.bincount(cols, weights=v64, minlength=g), np.bincount(cols, weights=v64 * v64, minlength=g),
                 np.bincount(cols[v > 0], minlength=g).astype(np.int64) if count_positive else None)
 
+    def nonnegative_integers(self, m):
+        return not np.signbit(m.data).any() and not np.any((m.data % 1) != 0)
+
+    def clip_col_sums(self, m, clip_val, *, row_mask=None):
+        sel = np.ones(m.data.size, bool) if row_mask is None else np.asarray(row_mask, bool)[m.rows]
+        v = np.minimum(m.data[sel].astype(np.float64), np.asarray(clip_val, dtype=np.float64)[m.indices[sel]])
+        g = m.shape[1]
+        return (np.bincount(m.indices[sel], weights=v * v, minlength=g),
+                np.bincount(m.indices[sel], weights=v, minlength=g))
+
     def scale_csr_(self, m, std, *, max_value=None, row_mask=None):
         sel = np.ones(m.data.size, bool) if row_mask is None else np.asarray(row_mask, bool)[m.rows]
         v = m.data[sel].astype(np.float64) / np.asarray(std)[m.indices[sel]]

@@ -205,8 +205,8 @@ def test_log1p_warns_when_already_logged_and_keeps_format(caplog):
 
 def test_hvg_errors_and_subset(pbmc68k):
     adata = sc.AnnData(pbmc68k["raw_X"].copy())
-    with pytest.raises(ImportError, match="scikit-misc"):
-        sc.pp.highly_variable_genes(adata, flavor="seurat_v3")
+    with pytest.raises(ValueError, match='`flavor` needs to be "seurat" or "cell_ranger"'):
+        sc.pp.highly_variable_genes(adata, flavor="svr")
     with pytest.raises(ValueError, match="expects an `AnnData`"):
         sc.pp.highly_variable_genes(adata.X)
     with pytest.warns(UserWarning, match="all cutoffs are ignored"):
