@@ -13,8 +13,8 @@ from . import tools as tl
 from ._anndata import AnnData
 from ._settings import settings
 from .neighbors import MI355XKNNTransformer, Neighbors
-from .readwrite import read, read_10x_h5, read_h5ad, read_zarr, write, write_h5ad, write_zarr
+from .readwrite import read, read_10x_h5, read_10x_mtx, read_h5ad, read_zarr, write, write_h5ad, write_zarr
 
 __all__ = ["pp", "tl", "metrics", "AnnData", "settings", "Neighbors", "MI355XKNNTransformer", "read_zarr",
-           "write_zarr", "read_h5ad", "read_10x_h5", "write_h5ad", "read", "write"]
+           "write_zarr", "read_h5ad", "read_10x_h5", "write_h5ad", "read", "write", "read_10x_mtx"]
 __version__ = "0.1.0"

@@ -242,6 +242,67 @@ def read_10x_h5(filename, *, genome: str | None = None, gex_only: bool = True, b
             raise Exception("File is missing one or more required datasets.") from e  # noqa: TRY002 (`:241-242`)
 
 
+def make_index_unique(index: pd.Index, join: str = "-") -> pd.Index:
+    """`anndata.utils.make_index_unique`: later duplicates get '-1', '-2', ... appended (skipping names already taken)"""
+    if index.is_unique:
+        return index
+    values = index.to_numpy().astype(object).copy()
+    taken = set(values.tolist())
+    counters: dict = {}
+    dup = index.duplicated(keep="first")
+    for i in np.flatnonzero(dup):
+        v = values[i]
+        k = counters.get(v, 0)
+        while True:
+            k += 1
+            cand = f"{v}{join}{k}"
+            if cand not in taken:
+                break
+        counters[v] = k
+        taken.add(cand)
+        values[i] = cand
+    return pd.Index(values)
+
+
+def read_10x_mtx(path, *, var_names: str = "gene_symbols", make_unique: bool = True, cache: bool = False,
+                 cache_compression=None, gex_only: bool = True, prefix: str | None = None, compressed: bool = True,
+                 sparse_format: str = "csr") -> AnnData:
+    """Read a 10x-Genomics-formatted mtx directory (drop-in for `scanpy.read_10x_mtx`, src/scanpy/readwrite.py:512-654):
+    Cell Ranger v2 (`genes.tsv`, plain files) and v3+ (`features.tsv.gz`, gzipped unless `compressed=False`) layouts,
+    `prefix`, `var_names`, `make_unique`, `gex_only`; cells x genes float32 in `sparse_format`.  `cache` is accepted
+    and ignored (there is no h5ad cache directory on this path)."""
+    from scipy.io import mmread
+
+    path = Path(path)
+    prefix = "" if prefix is None else prefix
+    if var_names not in {"gene_symbols", "gene_ids"}:
+        raise ValueError("`var_names` needs to be 'gene_symbols' or 'gene_ids'")
+    if sparse_format not in {"csr", "csc", "coo"}:
+        raise ValueError("`sparse_format` needs to be 'csr', 'csc' or 'coo'")
+    is_legacy = (path / f"{prefix}genes.tsv").is_file()
+    suffix = "" if is_legacy else (".gz" if compressed else "")
+    x = mmread(str(path / f"{prefix}matrix.mtx{suffix}"))  # genes x cells, COO
+    if x.dtype != np.float32:
+        x = x.astype(np.float32)
+    x = x.T  # cells x genes
+    x = x.tocsr() if sparse_format == "csr" else x.tocsc() if sparse_format == "csc" else x.tocoo()
+    genes = pd.read_csv(path / f"{prefix}{'genes' if is_legacy else 'features'}.tsv{suffix}", header=None, sep="\t")
+    if var_names == "gene_symbols":
+        idx = pd.Index(genes[1].array)
+        if make_unique:
+            idx = make_index_unique(idx)
+        var = pd.DataFrame({"gene_ids": genes[0].to_numpy()}, index=idx.astype("str"))
+    else:
+        var = pd.DataFrame({"gene_symbols": genes[1].to_numpy()}, index=pd.Index(genes[0].array.astype("str")))
+    if not is_legacy:
+        var["feature_types"] = genes[2].to_numpy()
+    barcodes = pd.read_csv(path / f"{prefix}barcodes.tsv{suffix}", header=None)
+    adata = AnnData(x, pd.DataFrame(index=pd.Index(barcodes[0].array.astype("str"))), var)
+    if is_legacy or not gex_only:
+        return adata
+    return adata[:, (adata.var["feature_types"] == "Gene Expression").to_numpy()].copy()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # writing
 

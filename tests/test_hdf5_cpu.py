@@ -274,3 +274,67 @@ def test_host_codecs_of_the_c_abi():
         assert lzf(bad, 64)[0] < 0
     assert lzf(bytes([3]) + b"abcd", 2)[0] < 0  # destination too small
     assert b"buffers" in lib.scamd_last_error() or b"truncated" in lib.scamd_last_error()
+
+
+def _write_mtx_dir(d: Path, m, barcodes, ids, names, types=None, *, gz: bool, prefix: str = ""):
+    from scipy.io import mmwrite
+
+    d.mkdir(parents=True, exist_ok=True)
+    mmwrite(str(d / f"{prefix}matrix.mtx"), sparse.coo_matrix(m.T), field="integer")
+    feats = "\n".join("\t".join(filter(None, (i, n, t))) for i, n, t in
+                      zip(ids, names, types or [None] * len(ids))) + "\n"
+    files = {f"{prefix}barcodes.tsv": "\n".join(barcodes) + "\n",
+             f"{prefix}{'features' if types else 'genes'}.tsv": feats}
+    for name, text in files.items():
+        (d / name).write_text(text)
+    if gz:
+        for name in [f"{prefix}matrix.mtx", *files]:
+            raw = (d / name).read_bytes()
+            with gzip.open(d / (name + ".gz"), "wb") as fh:
+                fh.write(raw)
+            (d / name).unlink()
+
+
+def test_read_10x_mtx_layouts(tmp_path):
+    """src/scanpy/readwrite.py:512-654: v2 (`genes.tsv`) and v3 (`features.tsv.gz`) directories, `prefix`, `var_names`,
+    `make_unique`, `gex_only`, `compressed=False`, `sparse_format`"""
+    rng = np.random.default_rng(0)
+    m = sparse.csr_matrix((rng.random((30, 8)) < 0.3) * rng.integers(1, 9, (30, 8)))
+    barcodes = [f"BC{i:02d}-1" for i in range(30)]
+    ids = [f"ENSG{i:04d}" for i in range(8)]
+    names = ["A", "B", "A", "C", "A", "A-1", "D", "E"]  # duplicates, and a name that collides with a made-unique one
+    types = ["Gene Expression"] * 6 + ["Antibody Capture"] * 2
+    _write_mtx_dir(tmp_path / "v2", m, barcodes, ids, names, gz=False)
+    a = sc.read_10x_mtx(tmp_path / "v2")
+    assert a.shape == (30, 8) and sparse.isspmatrix_csr(a.X) and a.X.dtype == np.float32 and (a.X != m).nnz == 0
+    assert list(a.var_names) == ["A", "B", "A-2", "C", "A-3", "A-1", "D", "E"]  # `anndata.utils.make_index_unique`
+    assert list(a.var["gene_ids"]) == ids and list(a.obs_names) == barcodes and list(a.var.columns) == ["gene_ids"]
+    assert list(sc.read_10x_mtx(tmp_path / "v2", make_unique=False).var_names) == names
+    b = sc.read_10x_mtx(tmp_path / "v2", var_names="gene_ids", sparse_format="csc")
+    assert list(b.var_names) == ids and list(b.var["gene_symbols"]) == names and sparse.isspmatrix_csc(b.X)
+    _write_mtx_dir(tmp_path / "v3", m, barcodes, ids, names, types, gz=True, prefix="s1_")
+    c = sc.read_10x_mtx(tmp_path / "v3", prefix="s1_")
+    assert c.shape == (30, 6) and set(c.var["feature_types"]) == {"Gene Expression"} and (c.X != m[:, :6]).nnz == 0
+    full = sc.read_10x_mtx(tmp_path / "v3", prefix="s1_", gex_only=False)
+    assert full.shape == (30, 8) and list(full.var.columns) == ["gene_ids", "feature_types"]
+    _write_mtx_dir(tmp_path / "star", m, barcodes, ids, names, types, gz=False)  # STARsolo: v3 files, not gzipped
+    assert sc.read_10x_mtx(tmp_path / "star", compressed=False, gex_only=False).shape == (30, 8)
+    with pytest.raises(ValueError, match="`var_names` needs to be"):
+        sc.read_10x_mtx(tmp_path / "v2", var_names="nope")
+
+
+@needs_reference
+@pytest.mark.parametrize(("mtx_rel", "h5_rel"), [
+    ("1.2.0/filtered_gene_bc_matrices/hg19_chr21", "1.2.0/filtered_gene_bc_matrices_h5.h5"),
+    ("3.0.0/filtered_feature_bc_matrix", "3.0.0/filtered_feature_bc_matrix.h5"),
+])
+def test_read_10x_mtx_equals_read_10x_h5(mtx_rel, h5_rel):
+    """the reference's own assertion (tests/test_read_10x.py:58-95): both readers return the same AnnData"""
+    mtx = sc.read_10x_mtx(REF_10X / mtx_rel, var_names="gene_symbols")
+    h5f = sc.read_10x_h5(REF_10X / h5_rel)
+    if "3.0.0" in h5_rel:
+        del h5f.var["genome"]
+    assert sparse.isspmatrix_csr(mtx.X) and mtx.shape == h5f.shape
+    assert (mtx.obs == h5f.obs).all(axis=None) and (mtx.var == h5f.var).all(axis=None)
+    assert list(mtx.var_names) == list(h5f.var_names) and list(mtx.obs_names) == list(h5f.obs_names)
+    assert np.allclose(mtx.X.toarray(), h5f.X.toarray())
