@@ -73,7 +73,15 @@ def read_elem(node):
             return str(v) if node.is_string else v
         if enc in {None, "array", "string-array", "rec-array"}:
             v = node.read()
-            return _as_str(v) if node.is_string else v
+            v = _as_str(v) if node.is_string else v
+            cats = node.attrs.get("categories")
+            if cats is not None and hasattr(cats, "addr"):
+                # anndata 0.7.x (dataframe encoding 0.1.0): integer codes whose `categories` attribute is an HDF5 object
+                # reference to `<frame>/__categories/<column>`
+                cat_node = node.file.deref(cats)
+                return pd.Categorical.from_codes(v, categories=pd.Index(_as_str(cat_node.read())),
+                                                 ordered=bool(cat_node.attrs.get("ordered", False)))
+            return v
         warnings.warn(f"skipping {node.path!r}: array encoding {enc!r} is not read here", UserWarning, stacklevel=2)
         return None
     if enc in {"csr_matrix", "csc_matrix"}:

@@ -124,6 +124,30 @@ with h5py.File(OUT / "adata_layout.h5ad", "w") as f:
 expected.update(ad_names=np.array(names), ad_counts=counts, ad_codes=codes, ad_batch=np.array(batch), ad_dbl=dbl,
                 ad_score_v=score_v, ad_score_m=score_m, ad_hv=hv, ad_xpca=xpca, ad_rec_a=rec["a"], ad_rec_b=rec["b"])
 
+# the dataframe encoding of anndata 0.7.x (version 0.1.0): categorical columns are integer codes whose `categories`
+# attribute is an object reference into `<frame>/__categories`
+with h5py.File(OUT / "adata_07_layout.h5ad", "w") as f:
+    enc(f, "anndata", "0.1.0")
+    write_csr(f, "X", data, indices, indptr, (n, g))
+    o = f.create_group("obs")
+    enc(o, "dataframe", "0.1.0")
+    o.attrs["_index"] = "_index"
+    o.attrs["column-order"] = vstr(["louvain", "n_counts"])
+    o.create_dataset("_index", data=vstr(names))
+    cg = o.create_group("__categories")
+    cd = cg.create_dataset("louvain", data=vstr(["0", "1", "2", "10"]))
+    cd.attrs["ordered"] = False
+    codes07 = np.where(codes < 0, 0, codes).astype(np.int8)
+    lv = o.create_dataset("louvain", data=codes07)
+    lv.attrs["categories"] = cd.ref
+    o.create_dataset("n_counts", data=counts)
+    v07 = f.create_group("var")
+    enc(v07, "dataframe", "0.1.0")
+    v07.attrs["_index"] = "_index"
+    v07.attrs["column-order"] = np.array([], dtype=np.float64)  # what h5py stores for an empty list
+    v07.create_dataset("_index", data=vstr([f"gene{i}" for i in range(g)]))
+expected.update(ad07_codes=codes07)
+
 # the layout anndata < 0.7 wrote: obs / var as compound datasets, X marked with h5sparse_* attributes
 with h5py.File(OUT / "legacy_layout.h5ad", "w") as f:
     xg = f.create_group("X")

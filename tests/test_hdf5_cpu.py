@@ -78,6 +78,19 @@ def test_backed_h5ad_rows(expected):
         sc.read_h5ad(H5 / "adata_layout.h5ad", backed="r+")
 
 
+def test_anndata_07_layout_categoricals_by_object_reference(expected):
+    """dataframe encoding 0.1.0 (anndata 0.7.x): codes + a `categories` attribute that is an HDF5 object reference"""
+    a = sc.read_h5ad(H5 / "adata_07_layout.h5ad")
+    assert list(a.obs.columns) == ["louvain", "n_counts"] and a.var.shape == (60, 0)
+    assert list(a.obs["louvain"].cat.categories) == ["0", "1", "2", "10"] and not a.obs["louvain"].cat.ordered
+    np.testing.assert_array_equal(a.obs["louvain"].cat.codes.to_numpy(), expected["ad07_codes"])
+    np.testing.assert_array_equal(a.obs["n_counts"].to_numpy(), expected["ad_counts"])
+    assert (a.X != sparse.csr_matrix(expected["ad_dense"])).nnz == 0
+    with h5.File(H5 / "adata_07_layout.h5ad") as f:
+        ref = f["obs"]["louvain"].attrs["categories"]
+        assert isinstance(ref, h5.Reference) and f.deref(ref).read().tolist() == ["0", "1", "2", "10"]
+
+
 def test_legacy_layout(expected):
     """anndata < 0.7: compound obs / var datasets, `h5sparse_format` / `h5sparse_shape` on X"""
     a = sc.read_h5ad(H5 / "legacy_layout.h5ad", backed="r")
