@@ -75,6 +75,11 @@ def read_elem(node):
             v = node.read()
             v = _as_str(v) if node.is_string else v
             cats = node.attrs.get("categories")
+            if isinstance(cats, str) and hasattr(node, "store"):
+                # the same encoding in a zarr store: the attribute is the path `__categories/<column>` inside the frame
+                cat_node = type(node)(node.store, f"{node.path.rsplit('/', 1)[0]}/{cats}")
+                return pd.Categorical.from_codes(v, categories=pd.Index(_as_str(cat_node.read())),
+                                                 ordered=bool(cat_node.attrs.get("ordered", False)))
             if cats is not None and hasattr(cats, "addr"):
                 # anndata 0.7.x (dataframe encoding 0.1.0): integer codes whose `categories` attribute is an HDF5 object
                 # reference to `<frame>/__categories/<column>`

@@ -198,6 +198,15 @@ def test_v2_anndata_store_with_the_encodings_of_anndata_0_8(tmp_path):
               filters=[{"id": "vlen-utf8"}], attrs={"encoding-type": "string-array", "encoding-version": "0.2.0"})
     nn = rng.integers(0, 100, n)
     _write_v2(root, "obs/n", nn, (300,), blosc, enc_blosc, attrs={"encoding-type": "array", "encoding-version": "0.2.0"})
+    # ... and a categorical the way anndata 0.7.x wrote it: codes + `categories` = a path into `__categories`
+    (root / "obs" / ".zattrs").write_text(json.dumps({"encoding-type": "dataframe", "encoding-version": "0.1.0",
+                                                       "_index": "_index", "column-order": ["louvain", "n", "phase"]}))
+    (root / "obs" / "__categories").mkdir()
+    (root / "obs" / "__categories" / ".zgroup").write_text('{"zarr_format": 2}')
+    _write_v2(root, "obs/__categories/phase", np.array(["G1", "S"], dtype=object), (2,), None, lambda raw, ts: raw,
+              filters=[{"id": "vlen-utf8"}], attrs={"ordered": True})
+    phase = rng.integers(0, 2, n).astype(np.int8)
+    _write_v2(root, "obs/phase", phase, (n,), None, lambda raw, ts: raw, attrs={"categories": "__categories/phase"})
     group("var", {"encoding-type": "dataframe", "encoding-version": "0.2.0", "_index": "_index", "column-order": []})
     _write_v2(root, "var/_index", np.array([f"g{i}" for i in range(g)], dtype=object), (g,), None, lambda raw, ts: raw,
               filters=[{"id": "vlen-utf8"}])
@@ -206,7 +215,9 @@ def test_v2_anndata_store_with_the_encodings_of_anndata_0_8(tmp_path):
     _write_v2(root, "obsm/X_pca", pca, (256, 5), blosc, enc_blosc)
 
     a = sc.read_zarr(root)
-    assert (a.X != x).nnz == 0 and list(a.obs_names) == list(names) and list(a.obs.columns) == ["louvain", "n"]
+    assert (a.X != x).nnz == 0 and list(a.obs_names) == list(names) and list(a.obs.columns) == ["louvain", "n", "phase"]
+    assert list(a.obs["phase"].cat.categories) == ["G1", "S"] and a.obs["phase"].cat.ordered
+    np.testing.assert_array_equal(a.obs["phase"].cat.codes.to_numpy(), phase)
     np.testing.assert_array_equal(a.obs["louvain"].cat.codes.to_numpy(), codes)
     np.testing.assert_array_equal(a.obs["n"].to_numpy(), nn)
     np.testing.assert_array_equal(a.obsm["X_pca"], pca)
