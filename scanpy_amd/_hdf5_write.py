@@ -153,6 +153,8 @@ class H5Writer:
     def dataset(self, data, attrs: dict | None = None, *, compression: str | None = None, level: int = 4,
                 chunk_rows: int | None = None) -> int:
         """write one dataset (numeric / bool / record array, or a sequence of str) -> its object header address"""
+        if hasattr(data, "pieces"):  # a 1-d column that arrives in consecutive pieces (an on-disk matrix being copied)
+            return self._streamed(data, attrs, compression, level)
         is_text = isinstance(data, str) or (isinstance(data, np.ndarray) and data.dtype.kind in "OU") \
             or (not isinstance(data, np.ndarray) and not np.isscalar(data) and len(data) > 0
                 and isinstance(data[0], str))
@@ -201,6 +203,64 @@ class H5Writer:
             msgs.append(self._attribute(k, v))
         return self._header(msgs)
 
+    def _streamed(self, col, attrs, compression, level: int) -> int:
+        """`col`: .shape (n,), .dtype, .pieces() -> consecutive 1-d arrays; never more than a piece + a chunk in memory"""
+        dt = np.dtype(col.dtype)
+        n, esize = int(col.shape[0]), dt.itemsize
+        msgs = [_message(0x01, _space_message((n,))), _message(0x03, _dtype_message(dt), 1)]
+        if compression is None or n == 0:
+            addr, total = None, 0
+            for piece in col.pieces():
+                piece = np.ascontiguousarray(piece, dtype=dt)
+                if piece.size == 0:
+                    continue
+                a = self.put(memoryview(piece).cast("B"), align=8 if addr is None else 1)
+                addr = a if addr is None else addr
+                total += piece.nbytes
+            assert total == n * esize, "streamed column shorter than announced"
+            msgs.append(_message(0x05, bytes([2, 2, 2, 1, 0, 0, 0, 0]), 1))
+            msgs.append(_message(0x08, bytes([3, 1]) + (struct.pack("<Q", addr) if addr is not None else _UNDEF)
+                                 + struct.pack("<Q", total)))
+        else:
+            c0 = max(1, min(n, CHUNK_BYTES // esize))
+            buf = np.empty(c0, dtype=dt)
+            fill, done = 0, 0
+            entries = []
+
+            def flush(count: int) -> None:
+                nonlocal done
+                if count < c0:
+                    buf[count:] = 0  # edge chunks are stored whole
+                b = buf.view(np.uint8).reshape(-1, esize)
+                blob = zlib.compress(np.ascontiguousarray(b.T).tobytes() if esize > 1 else b.tobytes(), level)
+                entries.append((len(blob), (done,), self.put(blob, align=1)))
+                done += c0
+
+            for piece in col.pieces():
+                piece = np.ascontiguousarray(piece, dtype=dt)
+                p = 0
+                while p < piece.size:
+                    take = min(c0 - fill, piece.size - p)
+                    buf[fill:fill + take] = piece[p:p + take]
+                    fill += take
+                    p += take
+                    if fill == c0:
+                        flush(c0)
+                        fill = 0
+            if fill:
+                flush(fill)
+            assert done >= n, "streamed column shorter than announced"
+            btree = self._chunk_btree(entries, 1, c0)
+            msgs.append(_message(0x05, bytes([2, 3, 0, 1, 0, 0, 0, 0]), 1))
+            pipeline = (bytes([1, 2, 0, 0, 0, 0, 0, 0])
+                        + struct.pack("<HHHH", 2, 8, 1, 1) + b"shuffle\0" + struct.pack("<II", esize, 0)
+                        + struct.pack("<HHHH", 1, 8, 1, 1) + b"deflate\0" + struct.pack("<II", level, 0))
+            msgs.append(_message(0x0B, pipeline, 1))
+            msgs.append(_message(0x08, bytes([3, 2, 2]) + struct.pack("<Q", btree) + struct.pack("<II", c0, esize)))
+        for k, v in (attrs or {}).items():
+            msgs.append(self._attribute(k, v))
+        return self._header(msgs)
+
     def _chunks(self, arr: np.ndarray, cshape, esize: int, level: int) -> int:
         """chunks along axis 0 (the other axes whole): shuffle + deflate each, write them, then their B-tree"""
         from ._zarr3 import decode_pool
@@ -224,12 +284,16 @@ class H5Writer:
             batch = starts[lo:lo + 64]
             for i0, blob in zip(batch, decode_pool().map(encode, batch)):
                 entries.append((len(blob), (i0,) + (0,) * (nd - 1), self.put(blob, align=1)))
+        return self._chunk_btree(entries, nd, c0)
+
+    def _chunk_btree(self, entries, nd: int, c0: int) -> int:
+        """B-tree v1 (node type 1) over written chunks: entries = [(stored size, origin tuple, address)] in order"""
         ksz = 8 + 8 * (nd + 1)
 
         def key(size: int, offsets) -> bytes:
             return struct.pack("<II", size, 0) + b"".join(struct.pack("<Q", o) for o in offsets) + struct.pack("<Q", 0)
 
-        end_key = key(0, (starts[-1] + c0,) + (0,) * (nd - 1))
+        end_key = key(0, (entries[-1][1][0] + c0,) + (0,) * (nd - 1))
         level_items = [(key(sz, off), addr) for sz, off, addr in entries]  # (first key of the child, child address)
         node_size = 24 + 2 * CHUNK_K * (ksz + 8) + ksz
         lvl = 0

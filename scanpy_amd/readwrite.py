@@ -363,6 +363,7 @@ class _H5Sink:
     (arrays are referenced, not copied, until then)"""
 
     SMALL = 1 << 16  # datasets below this many bytes stay contiguous, as anndata leaves scalars and short vectors
+    streams = True   # `array` accepts columns that arrive in pieces (`_BackedColumn`)
 
     def __init__(self, path, compression: str | None, level: int):
         from . import _hdf5_write as hw
@@ -389,8 +390,8 @@ class _H5Sink:
             self.root.add(path, node)
 
     def array(self, path: str, value, enc: str | None, version: str, chunks=None) -> None:
-        arr = value if isinstance(value, (np.ndarray, str)) else np.asarray(value)
-        nbytes = arr.nbytes if isinstance(arr, np.ndarray) and arr.dtype.kind not in "OU" else 0
+        arr = value if isinstance(value, (np.ndarray, str)) or hasattr(value, "pieces") else np.asarray(value)
+        nbytes = arr.nbytes if not isinstance(arr, str) and np.dtype(arr.dtype).kind not in "OU" else 0
         comp = self.compression if nbytes >= self.SMALL else None
         attrs = {"encoding-type": enc, "encoding-version": version} if enc else {}
         self.root.add(path, self.hw.Node(attrs, arr, compression=comp))
@@ -411,8 +412,33 @@ def _write_dataframe(sink, path: str, df: pd.DataFrame) -> None:
                    or pd.api.types.is_extension_array_dtype(df[name].dtype) else df[name].to_numpy())
 
 
+class _BackedColumn:
+    """`data` or `indices` of a `BackedCsr`, handed to a streaming writer piece by piece (row blocks of the source)"""
+
+    def __init__(self, x, which: str, rows_per_piece: int = 1 << 20):
+        self.arr = x._data if which == "data" else x._indices
+        self.indptr, self.step = x.indptr, rows_per_piece
+        self.shape, self.dtype = (int(x.indptr[-1]),), self.arr.dtype
+        self.nbytes = self.shape[0] * self.arr.dtype.itemsize
+
+    def pieces(self):
+        n = self.indptr.shape[0] - 1
+        for i0 in range(0, n, self.step):
+            p0, p1 = int(self.indptr[i0]), int(self.indptr[min(i0 + self.step, n)])
+            if p1 > p0:
+                yield self.arr.read(p0, p1)
+
+
 def write_elem(sink, path: str, value, *, chunks=None) -> None:
     """Write one in-memory value with the anndata encoding of its type (the same for both containers)."""
+    if is_backed(value) and getattr(sink, "streams", False) and value._cols is None:
+        # an on-disk matrix goes from store to file block by block: it is never whole in memory
+        sink.group(path, {"shape": [int(s) for s in value.shape], "encoding-type": "csr_matrix",
+                          "encoding-version": "0.1.0"})
+        sink.array(f"{path}/data", _BackedColumn(value, "data"), None, "")
+        sink.array(f"{path}/indices", _BackedColumn(value, "indices"), None, "")
+        sink.array(f"{path}/indptr", value.indptr, None, "")
+        return
     if is_backed(value):
         value = value.to_memory()
     if sparse.issparse(value):

@@ -180,3 +180,31 @@ def test_write_and_read_dispatch_on_the_extension(tmp_path):
         sc.read(tmp_path / "z.csv")
     with pytest.raises(TypeError, match="unexpected"):
         sc.read(tmp_path / "x.h5ad", delimiter=",")
+
+
+@pytest.mark.parametrize("compression", [None, "gzip"])
+@pytest.mark.parametrize("source", ["zarr", "h5ad"])
+def test_backed_matrix_is_copied_block_by_block(tmp_path, monkeypatch, compression, source):
+    """`write_h5ad` of an AnnData whose X is still on disk streams `data` / `indices` from the source store into the
+    new file (never whole in memory); the copy equals the original"""
+    from scanpy_amd import readwrite as rw
+    from scanpy_amd._backed import BackedCsr
+
+    monkeypatch.setattr(hw, "CHUNK_BYTES", 1 << 10)
+    monkeypatch.setattr("scanpy_amd.readwrite._H5Sink.SMALL", 256)
+    real_init = rw._BackedColumn.__init__
+    monkeypatch.setattr(rw._BackedColumn, "__init__", lambda self, x, which, rows=97: real_init(self, x, which, rows))
+    monkeypatch.setattr(BackedCsr, "to_memory", lambda self: (_ for _ in ()).throw(AssertionError("materialised")))
+    a = _toy_adata(1000, 30)
+    src = tmp_path / ("src.zarr" if source == "zarr" else "src.h5ad")
+    sc.write(src, a, **({} if source == "zarr" else {"compression": None}))
+    b = sc.read(src, backed="r")
+    sc.write_h5ad(tmp_path / "copy.h5ad", b, compression=compression)
+    monkeypatch.undo()
+    c = sc.read_h5ad(tmp_path / "copy.h5ad")
+    assert (c.X != a.X).nnz == 0 and c.X.dtype == a.X.dtype and list(c.obs_names) == list(a.obs_names)
+    np.testing.assert_array_equal(c.X.indptr, a.X.indptr)
+    if _has_h5py():
+        v = _library_view(tmp_path / "copy.h5ad")["children"]["X"]["children"]
+        assert v["data"]["shape"] == [a.X.nnz] and abs(v["data"]["sum"] - float(a.X.data.sum(dtype=np.float64))) < 1e-3
+        assert v["indices"]["sum"] == float(a.X.indices.sum()) and v["data"]["compression"] == compression
