@@ -1,0 +1,101 @@
+"""-m gpu: the routes added after this round's GPU minutes were spent, on the real kernels for the first time -- the
+out-of-core PCA (zarr / h5ad, resident and streamed), `highly_variable_genes` on a backed matrix and with
+`flavor='seurat_v3'`, and the device-list route of `pp.neighbors`.  (Named to sort last: these have only ever run
+against the CPU stand-in kernels, tests/test_dropin_host_cpu.py, tests/test_loess_cpu.py.)"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sc():
+    import scanpy_amd
+
+    return scanpy_amd
+
+
+def _matrix(n=6000, g=400, seed=3):
+    from scanpy_amd.datasets import synthetic_planted
+
+    return synthetic_planted(n, g, n_types=8, seed=seed)[0]
+
+
+@pytest.mark.parametrize("container", ["zarr", "h5ad"])
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_backed_pca_equals_in_memory(sc, tmp_path, monkeypatch, container, resident):
+    from scanpy_amd import readwrite as rw
+
+    monkeypatch.setenv("SCAMD_PCA_CHUNK_RESIDENT", resident)
+    monkeypatch.setattr(rw, "CHUNK_ELEMS", 50_021)
+    x = _matrix()
+    a = sc.AnnData(x)
+    a.var["highly_variable"] = np.arange(x.shape[1]) % 4 != 0
+    path = tmp_path / f"a.{container}"
+    sc.write(path, a)
+    b = sc.read(path, backed="r")
+    assert b.X.is_backed
+    sc.pp.pca(a, n_comps=30)
+    sc.pp.pca(b, n_comps=30, chunk_size=1700)
+    np.testing.assert_array_equal(b.obsm["X_pca"], a.obsm["X_pca"])
+    np.testing.assert_array_equal(b.varm["PCs"], a.varm["PCs"])
+    np.testing.assert_array_equal(b.uns["pca"]["variance_ratio"], a.uns["pca"]["variance_ratio"])
+    sc.pp.neighbors(b)
+    sc.tl.leiden(b, flavor="igraph", n_iterations=2)
+    assert b.obs["leiden"].nunique() >= 4 and b.X.is_backed
+
+
+def test_hvg_on_a_backed_matrix_and_seurat_v3(sc, tmp_path, pbmc68k):
+    from oracle import preprocess as op
+
+    counts = pbmc68k["counts"].astype(np.float32)
+    a = sc.AnnData(counts)
+    sc.pp.highly_variable_genes(a, flavor="seurat_v3", n_top_genes=200)
+    ref = op.highly_variable_genes_seurat_v3(counts, n_top_genes=200)
+    np.testing.assert_allclose(a.var["means"], ref["means"], rtol=1e-6)
+    np.testing.assert_allclose(a.var["variances"], ref["variances"], rtol=1e-5)
+    np.testing.assert_allclose(a.var["variances_norm"], ref["variances_norm"], rtol=1e-5, equal_nan=True)
+    assert (a.var["highly_variable"].to_numpy() != ref["highly_variable"].to_numpy()).sum() <= 2
+    batch = np.arange(counts.shape[0]) % 2
+    a.obs["batch"] = batch
+    df = sc.pp.highly_variable_genes(a, flavor="seurat_v3_paper", n_top_genes=150, batch_key="batch", inplace=False)
+    refb = op.highly_variable_genes_seurat_v3(counts, n_top_genes=150, batch=batch, flavor="seurat_v3_paper")
+    np.testing.assert_allclose(df["variances_norm"], refb["variances_norm"], rtol=1e-5, equal_nan=True)
+    # the classic flavor, streamed from disk
+    logn = sparse.csr_matrix(pbmc68k["raw_X"]).astype(np.float32)
+    mem = sc.AnnData(logn)
+    sc.write_zarr(tmp_path / "l.zarr", mem)
+    disk = sc.read_zarr(tmp_path / "l.zarr", backed="r")
+    sc.pp.highly_variable_genes(mem, n_top_genes=100)
+    sc.pp.highly_variable_genes(disk, n_top_genes=100)
+    np.testing.assert_allclose(disk.var["dispersions_norm"], mem.var["dispersions_norm"], rtol=1e-5, atol=1e-7,
+                               equal_nan=True)
+
+
+def test_neighbors_device_list_route(sc, pbmc68k):
+    """the lists stay on the device between the search and the connectivity kernel; the slots must be what the
+    host-side conventions (`_common.py:35-61`) build from the same search"""
+    from scanpy_amd.neighbors._common import get_sparse_matrix_from_indices_distances
+    from scanpy_amd.neighbors._transformer import knn_search
+
+    a = sc.AnnData(pbmc68k["X"])
+    a.obsm["X_pca"] = pbmc68k["X_pca"].astype(np.float32)
+    sc.pp.neighbors(a, n_neighbors=12, use_rep="X_pca")
+    idx, dist = knn_search(a.obsm["X_pca"], 12)
+    want = get_sparse_matrix_from_indices_distances(idx, dist, keep_self=False)
+    got = a.obsp["distances"]
+    assert got.shape == want.shape and got.dtype == np.float64 and got.indices.dtype == got.indptr.dtype
+    np.testing.assert_array_equal(got.indptr, want.indptr)
+    np.testing.assert_array_equal(got.indices, want.indices)
+    np.testing.assert_array_equal(got.data, want.data)
+    conn = a.obsp["connectivities"]
+    chk = conn.copy()
+    chk.has_sorted_indices = False  # force scipy to look: the recorded flag must be true
+    chk.sort_indices()
+    assert (chk != conn).nnz == 0 and np.array_equal(chk.indices, conn.indices)
+    assert (abs(conn - conn.T) > 1e-7).nnz == 0
+    sc.tl.leiden(a, flavor="igraph", n_iterations=2)
+    assert a.obs["leiden"].cat.categories.tolist() == [str(i) for i in range(a.obs["leiden"].nunique())]
