@@ -92,6 +92,20 @@ class GpuBackend:
         dv = torch.from_numpy(np.ascontiguousarray(x_csr.data, dtype=np.float32)).to(self.device)
         return (ip, ix, dv, x_csr.shape[0], x_csr.shape[1])
 
+    def host_buffers(self, n: int, index_dtype, value_dtype):
+        """staging buffers for the chunks of an on-disk matrix (`_ChunkedRows` decodes into two such pairs in turn).
+        SCAMD_PIN_STAGING=1 makes them page-locked (`hipHostMalloc` through torch), so that the upload is a direct DMA
+        instead of a copy through the runtime's bounce buffers -- opt-in until it has been measured on the GPU box."""
+        import os
+
+        if os.environ.get("SCAMD_PIN_STAGING") != "1":
+            return np.empty(n, dtype=index_dtype), np.empty(n, dtype=value_dtype)
+        tdt = {np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64, np.dtype(np.float32): torch.float32,
+               np.dtype(np.float64): torch.float64}
+        pair = tuple(torch.empty(max(n, 1), dtype=tdt[np.dtype(d)], pin_memory=True) for d in (index_dtype, value_dtype))
+        self._pinned = getattr(self, "_pinned", []) + [pair]  # keep the tensors alive as long as the backend
+        return tuple(t.numpy()[:n] for t in pair)
+
     def upload_prefetch(self, x_csr):
         """`upload` on a side stream, so that the copy of the next row chunk overlaps the kernels of the current one;
         `wait_prefetch` makes the compute stream wait for it (and ties the buffers' lifetime to the compute stream)."""
@@ -342,7 +356,8 @@ class _ChunkedRows:
 
         if recycle and self._ring is None and all(hasattr(c, "buffers") for c in self._host):
             most = max(c.nnz for c in self._host)
-            self._ring = [self._host[0].buffers(most) for _ in range(min(2, self.n_chunks))]
+            make = getattr(self, "_make_buffers", None) or self._host[0].buffers
+            self._ring = [make(most) for _ in range(min(2, self.n_chunks))]
 
         def load(i):
             c = self._host[i]
@@ -363,6 +378,9 @@ class _ChunkedRows:
             return
         keep = [] if self.resident else None
         upload = backend.upload_prefetch if hasattr(backend, "upload_prefetch") else backend.upload
+        if self._lazy and self._ring is None and hasattr(backend, "host_buffers") and hasattr(self._host[0], "buffers"):
+            probe = self._host[0].buffers(0)  # (dtypes of the on-disk index / value arrays)
+            self._make_buffers = lambda n: backend.host_buffers(n, probe[0].dtype, probe[1].dtype)
         host = self._host_chunks(recycle=bool(getattr(backend, "upload_copies", False)))
         nxt = upload(next(host))
         for i in range(self.n_chunks):

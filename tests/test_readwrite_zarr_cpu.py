@@ -327,3 +327,32 @@ def test_backed_absmax_from_the_value_array(tmp_path, monkeypatch):
     assert _ChunkedRows([x[:400], x[400:]], 30).host_absmax() is None  # in-memory chunks: the device pass answers
     sc.write_zarr(tmp_path / "e.zarr", sc.AnnData(sparse.csr_matrix((5, 4), dtype=np.float32)))
     assert sc.read_zarr(tmp_path / "e.zarr", backed="r").X.absmax() == 0.0
+
+
+def test_staging_buffers_come_from_the_backend_when_it_offers_them(tmp_path, monkeypatch):
+    """`GpuBackend.host_buffers` (page-locked when SCAMD_PIN_STAGING=1) is where `_ChunkedRows` gets its two decode
+    buffer pairs from; without the switch they are plain numpy arrays of the on-disk dtypes"""
+    from scanpy_amd.preprocessing._pca_solver import GpuBackend, _ChunkedRows
+
+    x = sparse.random(500, 20, density=0.2, format="csr", dtype=np.float32, random_state=0)
+    sc.write_zarr(tmp_path / "x.zarr", sc.AnnData(x))
+    b = sc.read_zarr(tmp_path / "x.zarr", backed="r").X
+    handed = []
+
+    class Backend:
+        upload_copies = True
+
+        def host_buffers(self, n, idt, vdt):
+            pair = GpuBackend.host_buffers(self, n, idt, vdt)
+            handed.append(pair)
+            return pair
+
+        def upload(self, c):
+            return c.to_scipy().copy()
+
+    monkeypatch.delenv("SCAMD_PIN_STAGING", raising=False)
+    rows = _ChunkedRows(b.row_chunks(120), 20)
+    got = list(rows.handles(Backend()))
+    assert (sparse.vstack(got) != x).nnz == 0
+    assert len(handed) == 2 and all(p[0].dtype == np.int32 and p[1].dtype == np.float32 for p in handed)
+    assert rows._ring[0][0] is handed[0][0]

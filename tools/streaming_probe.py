@@ -62,6 +62,14 @@ def main():
                 res[key], got = timed(run)
                 res[key] = round(res[key], 3)
                 assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), key
+    os.environ["SCAMD_PCA_CHUNK_RESIDENT"] = "0"
+    os.environ["SCAMD_PIN_STAGING"] = "1"  # page-locked staging buffers (opt-in): does the streamed fit gain?
+    for name, reader, path in (("zarr", sc.read_zarr, work / "x.zarr"), ("h5ad", sc.read_h5ad, work / "x.h5ad")):
+        key = f"pca_backed_{name}_streamed_pinned_chunk1000k_s"
+        res[key], got = timed(lambda reader=reader, path=path: fit(reader(path, backed="r"), chunk_size=1_000_000))
+        res[key] = round(res[key], 3)
+        assert np.array_equal(got[0], ref[0]), key
+    os.environ.pop("SCAMD_PIN_STAGING", None)
     os.environ.pop("SCAMD_PCA_CHUNK_RESIDENT", None)
     res["pca_in_memory_s"] = round(res["pca_in_memory_s"], 3)
     res["bitwise_equal"] = True
