@@ -1356,7 +1356,12 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
     SCAMD_LAUNCH_CHECK();
   }
   // 6. pruned sweep
-  auto kern = knn_select_reg_kernel<H, 64, 3, true>;
+  // register budget: cut for 3 resident blocks per CU by default (168 VGPRs; the H = 25 / 32 instantiations then spill
+  // 96 / 236 bytes per lane to scratch, `-Rpass-analysis=kernel-resource-usage`); SCAMD_KNN_IVF_WPS=2 selects the
+  // build cut for 2 blocks per CU (no spills) -- an A/B switch until both have been measured
+  const char* wps_env = getenv("SCAMD_KNN_IVF_WPS");
+  auto kern = (wps_env && atoi(wps_env) == 2) ? knn_select_reg_kernel<H, 64, 2, true>
+                                               : knn_select_reg_kernel<H, 64, 3, true>;
   const size_t lds = C::LDS_BYTES + 64;
   SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
