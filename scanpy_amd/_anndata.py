@@ -27,6 +27,7 @@ class AnnData:
         self.uns = dict(uns or {})
         self.layers = dict(layers or {})
         self.is_view = False
+        self.raw = None  # optionally another AnnData over the same cells (`adata.raw`), set by the readers
 
     @property
     def n_obs(self) -> int:

@@ -141,6 +141,13 @@ def _read_anndata(root, where, backed) -> AnnData:
     adata = AnnData(x, obs, var, **kw)
     if "varp" in root:
         adata.varp = read_elem(root["varp"]) or {}
+    if "raw" in root:  # `adata.raw`: the matrix (and var) before gene filtering, same cells (anndata's "raw" encoding)
+        rg = root["raw"]
+        if not hasattr(rg, "read") and "X" in rg:  # (a store without raw may hold a null / scalar placeholder there)
+            rx = rg["X"]
+            rx = BackedCsr(rx) if backed and not hasattr(rx, "read") else read_elem(rx)
+            rvar = _legacy_frame(read_elem(rg["var"])) if "var" in rg else None
+            adata.raw = AnnData(rx, adata.obs, rvar, varm=(read_elem(rg["varm"]) or {}) if "varm" in rg else {})
     return adata
 
 
@@ -497,6 +504,12 @@ def _write_anndata(sink, adata, chunks=None) -> None:
     write_elem(sink, "var", adata.var)
     for name in ("obsm", "varm", "obsp", "varp", "layers", "uns"):
         write_elem(sink, name, dict(getattr(adata, name, None) or {}))
+    raw = getattr(adata, "raw", None)
+    if raw is not None and getattr(raw, "X", None) is not None:
+        sink.group("raw", {"encoding-type": "raw", "encoding-version": "0.1.0"})
+        write_elem(sink, "raw/X", raw.X)
+        write_elem(sink, "raw/var", raw.var)
+        write_elem(sink, "raw/varm", dict(getattr(raw, "varm", None) or {}))
     sink.close()
 
 

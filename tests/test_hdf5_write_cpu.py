@@ -208,3 +208,23 @@ def test_backed_matrix_is_copied_block_by_block(tmp_path, monkeypatch, compressi
         v = _library_view(tmp_path / "copy.h5ad")["children"]["X"]["children"]
         assert v["data"]["shape"] == [a.X.nnz] and abs(v["data"]["sum"] - float(a.X.data.sum(dtype=np.float64))) < 1e-3
         assert v["indices"]["sum"] == float(a.X.indices.sum()) and v["data"]["compression"] == compression
+
+
+@pytest.mark.parametrize("ext", ["h5ad", "zarr"])
+def test_raw_round_trips(tmp_path, ext):
+    """`adata.raw` (matrix + var before gene filtering; anndata's `raw` group) survives write -> read in both containers"""
+    a = _toy_adata(200, 30)
+    full = sparse.random(200, 45, density=0.2, format="csr", dtype=np.float32, random_state=9)
+    a.raw = sc.AnnData(full, a.obs, pd.DataFrame({"gene_ids": [f"E{i}" for i in range(45)]},
+                                                 index=[f"r{i}" for i in range(45)]))
+    sc.write(tmp_path / f"a.{ext}", a, **({"compression": None} if ext == "h5ad" else {}))
+    b = sc.read(tmp_path / f"a.{ext}")
+    assert b.raw is not None and b.raw.shape == (200, 45) and (b.raw.X != full).nnz == 0
+    assert list(b.raw.var_names) == [f"r{i}" for i in range(45)] and list(b.raw.var["gene_ids"])[:2] == ["E0", "E1"]
+    assert list(b.raw.obs_names) == list(a.obs_names) and (b.X != a.X).nnz == 0
+    c = sc.read(tmp_path / f"a.{ext}", backed="r")
+    assert c.raw.X.is_backed and c.X.is_backed
+    if ext == "h5ad" and _has_h5py():
+        v = _library_view(tmp_path / "a.h5ad")["children"]["raw"]
+        assert v["attrs"]["encoding-type"] == "raw" and sorted(v["children"]) == ["X", "var", "varm"]
+        assert v["children"]["X"]["attrs"]["shape"] == [200, 45]
