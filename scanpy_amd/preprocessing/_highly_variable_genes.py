@@ -76,6 +76,21 @@ class _StreamedColStats:
             tot = (np.zeros(g), np.zeros(g), np.zeros(g, dtype=np.int64) if count_positive else None)
         return tot
 
+    def clip_col_sums(self, m, clip_val, *, row_mask=None):
+        g = self.x.shape[1]
+        tot = (np.zeros(g), np.zeros(g))
+        for c in self.x.row_chunks(self.step):
+            if row_mask is not None and not row_mask[c.i0:c.i1].any():
+                continue
+            part = self.be.clip_col_sums(self.be.upload(c.load().to_scipy()), clip_val,
+                                         row_mask=None if row_mask is None else row_mask[c.i0:c.i1])
+            tot = (tot[0] + part[0], tot[1] + part[1])
+        return tot
+
+    def nonnegative_integers(self, m) -> bool:
+        return all(self.be.nonnegative_integers(self.be.upload(c.load().to_scipy()))
+                   for c in self.x.row_chunks(self.step))
+
 
 def _single_batch(be, m, var_names, *, n_rows: int, row_mask, filter_unexpressed_genes: bool, cutoff, n_bins: int,
                   flavor: str, log1p_base) -> pd.DataFrame:
@@ -143,7 +158,10 @@ def _seurat_v3(adata, *, flavor: str, layer, n_top_genes: int, batch_key, check_
 
     x = _get_arr(adata, layer=layer)
     be = _csr_device.default_backend()
-    m = be.upload(_csr_device.in_memory(x))
+    if getattr(x, "is_backed", False):  # every sweep of this flavor is a sum over cells: streamed like `col_stats`
+        be, m = _StreamedColStats(be, x), x
+    else:
+        m = be.upload(x)
     n_obs, n_vars = adata.n_obs, adata.n_vars
     if check_values and not be.nonnegative_integers(m):
         warnings.warn(f"`flavor={flavor!r}` expects raw count data, but non-integers were found.", UserWarning,

@@ -134,3 +134,22 @@ def test_clip_col_sums_tensor_ops_equal_the_stub():
     assert _csr_device.GpuPPBackend.nonnegative_integers(None, dm) is False
     dm.data[3] = -0.0
     assert _csr_device.GpuPPBackend.nonnegative_integers(None, dm) is False  # signbit, like the reference
+
+
+def test_seurat_v3_streams_a_backed_count_matrix(pbmc68k, tmp_path, monkeypatch):
+    """all three sweeps of the flavor are sums over cells, so an on-disk count matrix is streamed by row chunks"""
+    from scanpy_amd.preprocessing import _highly_variable_genes as hvg
+
+    x = _counts(pbmc68k)
+    a = sc.AnnData(x)
+    a.obs["batch"] = pd.Categorical(np.arange(x.shape[0]) % 2)
+    sc.write_h5ad(tmp_path / "c.h5ad", a)
+    b = sc.read_h5ad(tmp_path / "c.h5ad", backed="r")
+    orig = hvg._StreamedColStats.__init__
+    monkeypatch.setattr(hvg._StreamedColStats, "__init__", lambda self, be, x, step=111: orig(self, be, x, step))
+    for kw in (dict(), dict(batch_key="batch")):
+        ra = sc.pp.highly_variable_genes(a, flavor="seurat_v3", n_top_genes=120, inplace=False, **kw)
+        rb = sc.pp.highly_variable_genes(b, flavor="seurat_v3", n_top_genes=120, inplace=False, **kw)
+        np.testing.assert_allclose(rb["variances_norm"], ra["variances_norm"], rtol=1e-9, equal_nan=True)
+        assert (rb["highly_variable"].to_numpy() != ra["highly_variable"].to_numpy()).sum() <= 2
+    assert b.X.is_backed
