@@ -17,8 +17,9 @@ from scipy import sparse
 class HostCsrRows:
     """Rows of a CSR matrix as three host arrays (what `GpuBackend.upload` reads) -- no scipy validation pass."""
 
-    def __init__(self, indptr, indices, data, shape):
+    def __init__(self, indptr, indices, data, shape, ops=()):
         self.indptr, self.indices, self.data, self.shape = indptr, indices, data, (int(shape[0]), int(shape[1]))
+        self.ops = tuple(ops)  # pending device transforms of these rows (see `BackedCsr.with_op`)
 
     @property
     def nbytes(self) -> int:
@@ -46,7 +47,8 @@ class BackedCsr:
     format = "csr"
     ndim = 2
 
-    def __init__(self, group, *, cols: np.ndarray | None = None, _indptr: np.ndarray | None = None):
+    def __init__(self, group, *, cols: np.ndarray | None = None, _indptr: np.ndarray | None = None, _ops=()):
+        self._ops = tuple(_ops)
         enc = group.attrs.get("encoding-type")
         enc = enc.decode() if isinstance(enc, bytes) else enc
         if enc is None and "h5sparse_format" in group.attrs:  # files written by anndata < 0.7
@@ -76,6 +78,15 @@ class BackedCsr:
         """stored values on disk (before any column selection)"""
         return int(self.indptr[-1])
 
+    def with_op(self, *op) -> "BackedCsr":
+        """the same matrix with one more PENDING transform -- ('row_divide', float32 factor per row) or ('log1p', base)
+        -- that is applied on the device to every row chunk after its upload (`pp.normalize_total` / `pp.log1p` on a
+        backed matrix): the values on disk are never rewritten and no arithmetic happens on the host."""
+        return BackedCsr(self.group, cols=self._cols, _indptr=self.indptr, _ops=self._ops + (tuple(op),))
+
+    def _ops_for(self, i0: int, i1: int) -> tuple:
+        return tuple((k, v[i0:i1]) if k == "row_divide" else (k, v) for k, v in self._ops)
+
     def rows(self, i0: int, i1: int, *, out: tuple[np.ndarray, np.ndarray] | None = None) -> HostCsrRows:
         """`out` = (indices buffer, data buffer) of the on-disk dtypes and at least nnz(rows) elements each: the chunks
         are decoded into their heads instead of fresh arrays (first-touch page faults of fresh memory cost more than
@@ -88,18 +99,18 @@ class BackedCsr:
         indices = self._indices.read(p0, p1, out=None if out is None else out[0][:p1 - p0])
         data = self._data.read(p0, p1, out=None if out is None else out[1][:p1 - p0])
         if self._cols is None and _rows_sorted(indptr, indices):
-            return HostCsrRows(indptr, indices, data, (i1 - i0, self.shape[1]))
+            return HostCsrRows(indptr, indices, data, (i1 - i0, self.shape[1]), self._ops_for(i0, i1))
         m = sparse.csr_matrix((data, indices, indptr), shape=(i1 - i0, self._n_cols_disk))
         if self._cols is not None:
             m = m[:, self._cols]
         if not m.has_sorted_indices:
             m.sort_indices()
-        return HostCsrRows(m.indptr.astype(np.int64), m.indices, m.data, m.shape)
+        return HostCsrRows(m.indptr.astype(np.int64), m.indices, m.data, m.shape, self._ops_for(i0, i1))
 
     def absmax(self) -> float | None:
         """max |value| over the stored values, from the `data` array alone (40 % of the bytes of a full pass) -- or
         None under a column selection, where the excluded columns would count."""
-        if self._cols is not None:
+        if self._cols is not None or self._ops:  # (pending transforms change the values: the device pass answers)
             return None
         from ._zarr3 import decode_pool
 
@@ -125,7 +136,15 @@ class BackedCsr:
         return [LazyRows(self, i, min(i + step, stop)) for i in range(start, stop, step)]
 
     def to_memory(self):
-        return self.rows(0, self.shape[0]).to_scipy()
+        rows = self.rows(0, self.shape[0])
+        if not rows.ops:
+            return rows.to_scipy()
+        from .preprocessing import _csr_device  # pending transforms run on the device, like everywhere else
+
+        be = _csr_device.default_backend()
+        m = be.upload(rows.to_scipy())
+        apply_ops_pp(be, m, rows.ops)
+        return be.download(m)
 
     def __getitem__(self, index):
         """`x[i0:i1]` -> scipy CSR of those rows; `x[:, mask]` -> a BackedCsr with the column selection pending."""
@@ -136,11 +155,13 @@ class BackedCsr:
             cols = np.asarray(cols)
             if self._cols is not None:
                 cols = self._cols[np.flatnonzero(cols) if cols.dtype == bool else cols]
-            return BackedCsr(self.group, cols=cols, _indptr=self.indptr)
+            return BackedCsr(self.group, cols=cols, _indptr=self.indptr, _ops=self._ops)
         if isinstance(index, slice) and index == slice(None):
             return self
         if isinstance(index, slice) and index.step in (None, 1):
             i0, i1, _ = index.indices(self.shape[0])
+            if self._ops:
+                raise IndexError("row slices of a backed matrix with pending transforms are not offered: use to_memory()")
             return self.rows(i0, max(i0, i1)).to_scipy()
         raise IndexError("a backed CSR matrix is subset by columns (`x[:, mask]`) or by a row range (`x[i0:i1]`)")
 
@@ -148,8 +169,9 @@ class BackedCsr:
         return self  # read-only: nothing to protect from writes
 
     def __repr__(self) -> str:
+        pending = f", pending {[k for k, _ in self._ops]}" if self._ops else ""
         return (f"<BackedCsr {self.shape[0]} x {self.shape[1]} {self.dtype} with {self.nnz} stored values at "
-                f"{self.group.path!r}>")
+                f"{self.group.path!r}{pending}>")
 
 
 class LazyRows:
@@ -169,6 +191,17 @@ class LazyRows:
 
     def load(self, out: tuple[np.ndarray, np.ndarray] | None = None) -> HostCsrRows:
         return self.x.rows(self.i0, self.i1, out=out)
+
+
+def apply_ops_pp(be, m, ops) -> None:
+    """pending row transforms on a `_csr_device.DeviceMatrix` through the normalisation kernels"""
+    for kind, arg in ops:
+        if kind == "row_divide":
+            be.row_divide_(m, arg)
+        elif kind == "log1p":
+            be.log1p_(m, arg)
+        else:
+            raise ValueError(f"unknown pending transform {kind!r}")
 
 
 def is_backed(x) -> bool:

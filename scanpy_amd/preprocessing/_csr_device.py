@@ -164,11 +164,12 @@ def default_backend():
 
 def in_memory(x):
     """The upstream chain works on a matrix in memory (most of its passes rewrite it); an on-disk matrix
-    (`read_h5ad` / `read_zarr(..., backed='r')`) streams only through `pp.pca` and `pp.highly_variable_genes`."""
+    (`read_h5ad` / `read_zarr(..., backed='r')`) streams through `pp.pca` and `pp.highly_variable_genes`;
+    `pp.normalize_total` / `pp.log1p` turn into pending transforms of it."""
     if getattr(x, "is_backed", False):
         raise NotImplementedError(
             "this function needs the matrix in memory: load it with `adata.X = adata.X.to_memory()` (or read without "
-            "backed='r'); a backed matrix is streamed by `sc.pp.pca` and `sc.pp.highly_variable_genes` only")
+            "backed='r'); on a backed matrix only normalize_total, log1p, highly_variable_genes and pca are offered")
     return x
 
 

@@ -62,12 +62,21 @@ class _StreamedColStats:
     def __init__(self, be, x, step: int = 1_000_000):
         self.be, self.x, self.step = be, x, step
 
+    def _chunk(self, c):
+        """upload one row chunk and run the matrix' pending transforms (normalize_total / log1p) on it"""
+        from .._backed import apply_ops_pp
+
+        rows = c.load()
+        m = self.be.upload(rows.to_scipy())
+        apply_ops_pp(self.be, m, rows.ops)
+        return m
+
     def col_stats(self, m, *, row_mask=None, expm1_scale=None, count_positive: bool = False):
         tot = None
         for c in self.x.row_chunks(self.step):
             if row_mask is not None and not row_mask[c.i0:c.i1].any():
                 continue
-            part = self.be.col_stats(self.be.upload(c.load().to_scipy()),
+            part = self.be.col_stats(self._chunk(c),
                                      row_mask=None if row_mask is None else row_mask[c.i0:c.i1],
                                      expm1_scale=expm1_scale, count_positive=count_positive)
             tot = part if tot is None else tuple(None if a is None else a + b for a, b in zip(tot, part))
@@ -82,13 +91,13 @@ class _StreamedColStats:
         for c in self.x.row_chunks(self.step):
             if row_mask is not None and not row_mask[c.i0:c.i1].any():
                 continue
-            part = self.be.clip_col_sums(self.be.upload(c.load().to_scipy()), clip_val,
+            part = self.be.clip_col_sums(self._chunk(c), clip_val,
                                          row_mask=None if row_mask is None else row_mask[c.i0:c.i1])
             tot = (tot[0] + part[0], tot[1] + part[1])
         return tot
 
     def nonnegative_integers(self, m) -> bool:
-        return all(self.be.nonnegative_integers(self.be.upload(c.load().to_scipy()))
+        return all(self.be.nonnegative_integers(self._chunk(c))
                    for c in self.x.row_chunks(self.step))
 
 

@@ -33,6 +33,38 @@ def _compute_nnz_median(counts: np.ndarray):
     return np.median(counts[counts > 0])
 
 
+def _normalize_total_backed(adata, x, be, *, target_sum, exclude_highly_expressed, key_added, layer, obsm, inplace, copy):
+    """An on-disk matrix: the counts per cell are summed on the device chunk by chunk (one streamed pass; per-row sums
+    do not depend on the chunking), and the division becomes a PENDING transform of the matrix, applied to every row
+    chunk after its upload -- nothing is rewritten and nothing is materialised."""
+    from .._backed import apply_ops_pp
+
+    if exclude_highly_expressed:
+        raise NotImplementedError("exclude_highly_expressed needs two more passes over the matrix and is not offered "
+                                  "for a backed matrix: load it with `adata.X = adata.X.to_memory()`")
+    parts = []
+    for c in x.row_chunks(1_000_000):
+        rows = c.load()
+        m = be.upload(rows.to_scipy())
+        apply_ops_pp(be, m, rows.ops)
+        parts.append(be.row_sums(m))
+    counts = np.concatenate(parts) if parts else np.zeros(0, dtype=np.float32)
+    if target_sum is None:
+        target_sum = _compute_nnz_median(counts)
+    factor = counts / target_sum
+    if not np.all(factor > 0):
+        warnings.warn("Some cells have zero counts", UserWarning, stacklevel=3)
+    out = x.with_op("row_divide", np.ascontiguousarray(factor, dtype=np.float32))
+    dat = dict(X=out, norm_factor=factor)
+    if inplace:
+        if key_added is not None:
+            adata.obs[key_added] = factor
+        _set_obs_rep(adata, out, layer=layer, obsm=obsm)
+    if copy:
+        return adata
+    return None if inplace else dat
+
+
 def normalize_total(  # noqa: PLR0912
     adata,
     *,
@@ -60,6 +92,10 @@ def normalize_total(  # noqa: PLR0912
     view_to_actual(adata)  # `_normalization.py:264`
     x = _get_arr(adata, layer=layer, obsm=obsm)
     be = _csr_device.default_backend()
+    if getattr(x, "is_backed", False):
+        return _normalize_total_backed(adata, x, be, target_sum=target_sum,
+                                       exclude_highly_expressed=exclude_highly_expressed, key_added=key_added,
+                                       layer=layer, obsm=obsm, inplace=inplace, copy=copy)
     m = be.upload(_csr_device.in_memory(x))  # CSC -> CSR like the reference (`:266-267`); integers -> float32 (`:271-272`)
     counts = be.row_sums(m)
     gene_subset = None

@@ -106,6 +106,18 @@ class GpuBackend:
         self._pinned = getattr(self, "_pinned", []) + [pair]  # keep the tensors alive as long as the backend
         return tuple(t.numpy()[:n] for t in pair)
 
+    def apply_ops(self, a, ops) -> None:
+        """pending row transforms of an on-disk matrix (`_backed.BackedCsr.with_op`) on an uploaded chunk, in place"""
+        ip, _, dv, n, _ = a
+        for kind, arg in ops:
+            if kind == "row_divide":
+                f = torch.from_numpy(np.ascontiguousarray(arg, dtype=np.float32)).to(self.device)
+                self.K.pp_row_divide_(ip, dv, n, f)
+            elif kind == "log1p":
+                self.K.pp_log1p_(dv, arg)
+            else:
+                raise ValueError(f"unknown pending transform {kind!r}")
+
     def upload_prefetch(self, x_csr):
         """`upload` on a side stream, so that the copy of the next row chunk overlaps the kernels of the current one;
         `wait_prefetch` makes the compute stream wait for it (and ties the buffers' lifetime to the compute stream)."""
@@ -382,17 +394,21 @@ class _ChunkedRows:
             probe = self._host[0].buffers(0)  # (dtypes of the on-disk index / value arrays)
             self._make_buffers = lambda n: backend.host_buffers(n, probe[0].dtype, probe[1].dtype)
         host = self._host_chunks(recycle=bool(getattr(backend, "upload_copies", False)))
-        nxt = upload(next(host))
+        first = next(host)
+        nxt, nxt_ops = upload(first), getattr(first, "ops", ())
         for i in range(self.n_chunks):
-            cur = nxt
+            cur, cur_ops = nxt, nxt_ops
             if hasattr(backend, "wait_prefetch"):
                 backend.wait_prefetch()
+            if cur_ops:  # pending normalize_total / log1p of an on-disk matrix: on the device, on the compute stream
+                backend.apply_ops(cur, cur_ops)
             nxt = None
             if keep is not None:
                 keep.append(cur)
             yield cur  # the caller enqueues this chunk's kernels ...
             if i + 1 < self.n_chunks:
-                nxt = upload(next(host))  # ... and the next upload overlaps them
+                h = next(host)
+                nxt, nxt_ops = upload(h), getattr(h, "ops", ())  # ... and the next upload overlaps them
         host.close()
         if keep is not None:
             self._cached = keep

@@ -39,6 +39,9 @@ def log1p(data, *, base=None, copy: bool = False, chunked: bool | None = None, c
         msg = "chunked log1p is not implemented on the MI355X path: the whole matrix is transformed in one device pass"
         raise NotImplementedError(msg)
     x = _get_arr(adata, layer=layer, obsm=obsm)
-    _set_obs_rep(adata, _log1p_matrix(x, base=base), layer=layer, obsm=obsm)
+    if getattr(x, "is_backed", False):  # an on-disk matrix: a pending transform, applied per uploaded row chunk
+        _set_obs_rep(adata, x.with_op("log1p", base), layer=layer, obsm=obsm)
+    else:
+        _set_obs_rep(adata, _log1p_matrix(x, base=base), layer=layer, obsm=obsm)
     adata.uns["log1p"] = {"base": base}
     return adata if copy else None

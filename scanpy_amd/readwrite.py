@@ -438,7 +438,7 @@ class _BackedColumn:
 
 def write_elem(sink, path: str, value, *, chunks=None) -> None:
     """Write one in-memory value with the anndata encoding of its type (the same for both containers)."""
-    if is_backed(value) and getattr(sink, "streams", False) and value._cols is None:
+    if is_backed(value) and getattr(sink, "streams", False) and value._cols is None and not value._ops:
         # an on-disk matrix goes from store to file block by block: it is never whole in memory
         sink.group(path, {"shape": [int(s) for s in value.shape], "encoding-type": "csr_matrix",
                           "encoding-version": "0.1.0"})

@@ -21,6 +21,19 @@ class CpuStubBackend:
         x.sort_indices()
         return (x, None, None, x.shape[0], x.shape[1])
 
+    def apply_ops(self, a, ops):
+        """same float32 arithmetic as CpuStubPPBackend.row_divide_ / log1p_ below"""
+        x = a[0]
+        rows = np.repeat(np.arange(x.shape[0]), np.diff(x.indptr))
+        for kind, arg in ops:
+            if kind == "row_divide":
+                f = np.asarray(arg, dtype=np.float32)
+                f = np.where(f == 0, np.float32(1), f)
+                x.data = (x.data / f[rows]).astype(np.float32)
+            else:
+                v = np.log1p(x.data)
+                x.data = (v * np.float32(1.0 / np.log(arg))).astype(np.float32) if arg is not None else v
+
     def transpose(self, a):
         xt = a[0].T.tocsr()
         xt.sort_indices()

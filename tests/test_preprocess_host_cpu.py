@@ -443,18 +443,57 @@ def test_views_are_actualised_with_a_warning():
         np.testing.assert_array_equal(_dense(adata.X), _dense(v.X))
 
 
-def test_backed_matrices_are_refused_with_a_pointer_to_pca():
-    """an on-disk X (`read_h5ad(..., backed='r')`) streams through `pp.pca` only; the chain says so instead of failing
-    somewhere inside numpy"""
+def test_backed_matrices_passes_that_need_the_whole_matrix_are_refused():
+    """an on-disk X (`read_h5ad(..., backed='r')`): `scale` and the filters rewrite / subset the matrix and say so
+    instead of failing somewhere inside numpy (normalize_total, log1p, highly_variable_genes and pca stream)"""
     from pathlib import Path
 
     b = sc.read_h5ad(Path(__file__).parent / "golden" / "h5" / "adata_layout.h5ad", backed="r")
-    for fn in (sc.pp.normalize_total, sc.pp.log1p, sc.pp.scale,
-               lambda a: sc.pp.filter_cells(a, min_counts=1), lambda a: sc.pp.filter_genes(a, min_cells=1)):
+    for fn in (sc.pp.scale, lambda a: sc.pp.filter_cells(a, min_counts=1), lambda a: sc.pp.filter_genes(a, min_cells=1)):
         with pytest.raises(NotImplementedError, match="to_memory"):
             fn(b)
-    a = sc.AnnData(b.X.to_memory(), b.obs, b.var)
-    sc.pp.normalize_total(a)  # and in memory it goes through
+    with pytest.raises(NotImplementedError, match="exclude_highly_expressed"):
+        sc.pp.normalize_total(b, exclude_highly_expressed=True)
+
+
+@pytest.mark.parametrize("container", ["h5ad", "zarr"])
+def test_counts_on_disk_to_log_normalised_statistics_without_materialising(pbmc68k, tmp_path, monkeypatch, container):
+    """normalize_total / log1p on a backed count matrix become PENDING transforms (applied on the device to every row
+    chunk after its upload): factors, statistics and the materialised matrix equal the in-memory chain"""
+    from scipy import sparse
+
+    from scanpy_amd._backed import BackedCsr
+    from scanpy_amd.preprocessing import _highly_variable_genes as hvg
+
+    counts = sparse.csr_matrix(pbmc68k["counts"]).astype(np.float32)
+    a = sc.AnnData(counts.copy())
+    sc.write(tmp_path / f"c.{container}", a, **({"compression": None} if container == "h5ad" else {}))
+    b = sc.read(tmp_path / f"c.{container}", backed="r")
+    orig = hvg._StreamedColStats.__init__
+    monkeypatch.setattr(hvg._StreamedColStats, "__init__", lambda self, be, x, step=150: orig(self, be, x, step))
+    sc.pp.normalize_total(a, target_sum=1e4, key_added="nf")
+    sc.pp.normalize_total(b, target_sum=1e4, key_added="nf")
+    np.testing.assert_array_equal(b.obs["nf"].to_numpy(), a.obs["nf"].to_numpy())
+    sc.pp.log1p(a)
+    sc.pp.log1p(b)
+    assert isinstance(b.X, BackedCsr) and [k for k, _ in b.X._ops] == ["row_divide", "log1p"] and b.uns["log1p"] == {"base": None}
+    assert "pending ['row_divide', 'log1p']" in repr(b.X) and b.X.absmax() is None
+    sc.pp.highly_variable_genes(a, n_top_genes=150)
+    sc.pp.highly_variable_genes(b, n_top_genes=150)
+    np.testing.assert_allclose(b.var["means"], a.var["means"], rtol=1e-9)
+    np.testing.assert_allclose(b.var["dispersions_norm"], a.var["dispersions_norm"], rtol=1e-6, atol=1e-9, equal_nan=True)
+    assert (b.var["highly_variable"].to_numpy() != a.var["highly_variable"].to_numpy()).sum() <= 2
+    got = b.X.to_memory()  # (through the device backend: no arithmetic on the host)
+    assert (got != a.X).nnz == 0 and got.dtype == np.float32
+    # median target, base-2 logarithm, a second normalisation on top of a pending one
+    a2, b2 = sc.AnnData(counts.copy()), sc.read(tmp_path / f"c.{container}", backed="r")
+    for ad in (a2, b2):
+        sc.pp.normalize_total(ad)
+        sc.pp.log1p(ad, base=2)
+        sc.pp.normalize_total(ad, target_sum=50.0)
+    assert (b2.X.to_memory() != a2.X).nnz == 0
+    res = sc.pp.normalize_total(sc.read(tmp_path / f"c.{container}", backed="r"), inplace=False)
+    assert set(res) == {"X", "norm_factor"} and res["X"].is_backed
 
 
 @pytest.mark.parametrize("flavor", ["seurat", "cell_ranger"])

@@ -99,3 +99,25 @@ def test_neighbors_device_list_route(sc, pbmc68k):
     assert (abs(conn - conn.T) > 1e-7).nnz == 0
     sc.tl.leiden(a, flavor="igraph", n_iterations=2)
     assert a.obs["leiden"].cat.categories.tolist() == [str(i) for i in range(a.obs["leiden"].nunique())]
+
+
+def test_counts_on_disk_to_clusters(sc, tmp_path, pbmc68k):
+    """normalize_total / log1p as pending transforms of an on-disk count matrix, streamed HVG and PCA: the PCA equals
+    the in-memory chain bit for bit (tests/test_dropin_host_cpu.py runs the same body on the CPU stand-ins)"""
+    counts = sparse.csr_matrix(pbmc68k["counts"]).astype(np.float32)
+    a = sc.AnnData(counts.copy())
+    sc.write_h5ad(tmp_path / "counts.h5ad", a)
+    b = sc.read_h5ad(tmp_path / "counts.h5ad", backed="r")
+    for ad in (a, b):
+        sc.pp.normalize_total(ad, target_sum=1e4, key_added="nf")
+        sc.pp.log1p(ad)
+        sc.pp.highly_variable_genes(ad, n_top_genes=300)
+    np.testing.assert_array_equal(b.obs["nf"].to_numpy(), a.obs["nf"].to_numpy())
+    np.testing.assert_allclose(b.var["dispersions_norm"], a.var["dispersions_norm"], rtol=1e-5, atol=1e-7, equal_nan=True)
+    b.var["highly_variable"] = a.var["highly_variable"].to_numpy()
+    sc.pp.pca(a, n_comps=15)
+    sc.pp.pca(b, n_comps=15, chunk_size=130)
+    assert b.X.is_backed
+    np.testing.assert_array_equal(b.obsm["X_pca"], a.obsm["X_pca"])
+    np.testing.assert_array_equal(b.varm["PCs"], a.varm["PCs"])
+    assert (b.X.to_memory() != a.X).nnz == 0
