@@ -328,7 +328,7 @@ def decode_pool() -> ThreadPoolExecutor:
     global _pool
     with _pool_lock:
         if _pool is None:
-            _pool = ThreadPoolExecutor(max_workers=max(2, min(16, os.cpu_count() or 2)),
+            _pool = ThreadPoolExecutor(max_workers=max(2, min(32, os.cpu_count() or 2)),
                                        thread_name_prefix="scamd-zarr")
         return _pool
 

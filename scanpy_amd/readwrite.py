@@ -160,7 +160,11 @@ def read_zarr(store, *, backed: str | None = None) -> AnnData:
     """
     if backed not in {None, "r"}:
         raise ValueError("backed must be None or 'r' (stores are never modified in place)")
-    return _read_anndata(z3.open_root(z3.open_store(store)), store, backed)
+    st = z3.open_store(store)
+    adata = _read_anndata(z3.open_root(st), store, backed)
+    if not backed:
+        st.close()  # (a backed matrix keeps reading from the store)
+    return adata
 
 
 def read_h5ad(filename, backed: str | None = None) -> AnnData:
@@ -176,7 +180,11 @@ def read_h5ad(filename, backed: str | None = None) -> AnnData:
         raise ValueError("backed must be None or 'r' (files are never modified in place)")
     from . import _hdf5
 
-    return _read_anndata(_hdf5.File(filename).root, filename, backed)
+    f = _hdf5.File(filename)
+    adata = _read_anndata(f.root, filename, backed)
+    if not backed:
+        f.close()  # (a backed matrix keeps reading from the file)
+    return adata
 
 
 def read_10x_h5(filename, *, genome: str | None = None, gex_only: bool = True, backup_url: str | None = None) -> AnnData:
