@@ -69,6 +69,8 @@ def choose_representation(adata, *, use_rep=None, n_pcs=None):
     else:
         msg = f"Did not find {use_rep} in `.obsm.keys()`. You need to compute it first."
         raise ValueError(msg)
+    if getattr(x, "is_backed", False):  # `.X` itself as the representation: a search needs it whole
+        x = x.to_memory()
     return x
 
 
