@@ -28,6 +28,7 @@ class AnnData:
         self.layers = dict(layers or {})
         self.is_view = False
         self.raw = None  # optionally another AnnData over the same cells (`adata.raw`), set by the readers
+        self.varp = {}
 
     @property
     def n_obs(self) -> int:
@@ -58,9 +59,12 @@ class AnnData:
         """anndata's `AnnData._inplace_subset_obs` (used by `filter_cells`)."""
         sub = self[np.asarray(index)]
         self.X, self.obs, self.obsm, self.layers, self.obsp = sub.X, sub.obs.copy(), sub.obsm, sub.layers, sub.obsp
+        self.raw = sub.raw  # `raw` keeps all genes but follows the cells
+        if self.raw is not None:
+            self.raw.obs = self.obs
 
     def copy(self) -> "AnnData":
-        return AnnData(
+        out = AnnData(
             None if self.X is None else self.X.copy(),
             self.obs.copy(),
             self.var.copy(),
@@ -70,6 +74,12 @@ class AnnData:
             uns=_copy.deepcopy(self.uns),
             layers={k: v.copy() for k, v in self.layers.items()},
         )
+        out.varp = {k: v.copy() for k, v in self.varp.items()}
+        if self.raw is not None:
+            r = self.raw
+            out.raw = AnnData(None if r.X is None else r.X.copy(), out.obs, r.var.copy(),
+                              varm={k: v.copy() for k, v in r.varm.items()})
+        return out
 
     def __getitem__(self, index) -> "AnnData":
         """Only `adata[:, var_mask]` and `adata[obs_mask]` / `adata[obs_mask, :]` are supported."""
@@ -87,8 +97,14 @@ class AnnData:
             uns=self.uns,
             layers={k: v[oi][:, vi] for k, v in self.layers.items()},
         )
-        if isinstance(vi, slice) and vi == slice(None):
-            sub.obsp = {k: v[oi][:, oi] for k, v in self.obsp.items()}
+        all_obs = isinstance(oi, slice) and oi == slice(None)
+        all_var = isinstance(vi, slice) and vi == slice(None)
+        # pairwise slots follow their own axis only: obsp survives any var subset and vice versa
+        sub.obsp = dict(self.obsp) if all_obs else {k: v[oi][:, oi] for k, v in self.obsp.items()}
+        sub.varp = dict(self.varp) if all_var else {k: v[vi][:, vi] for k, v in self.varp.items()}
+        if self.raw is not None:  # `raw` keeps every gene; it follows the cells only
+            r = self.raw
+            sub.raw = r if all_obs else AnnData(None if r.X is None else r.X[oi], sub.obs, r.var, varm=r.varm)
         sub.is_view = True
         return sub
 

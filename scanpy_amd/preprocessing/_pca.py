@@ -100,6 +100,10 @@ def pca(  # noqa: PLR0912, PLR0913, PLR0915
     mask_var_param, mask = mask_var, _check_mask(adata, mask_var, "var")
 
     x = _get_arr(adata, layer=layer, obsm=obsm)
+    if obsm is not None:
+        # the reference subsets the AnnData by var and then reads `adata_comp.obsm[obsm]` unmasked
+        # (_pca/__init__.py:228-232): the var mask is recorded in `params` but never slices an obsm matrix
+        mask = None
     if mask is not None:
         x = x[:, mask]
     n_obs, n_vars = x.shape

@@ -297,6 +297,13 @@ def _dense_topk_eigh(amat: torch.Tensor, k: int, rng: np.random.Generator, tol: 
         n_gemm += m - 1
         theta, v, av = rr(_cholqr2(y))
         n_gemm += 1
+    if not resid < tol:
+        # 24 filtered iterations did not reach the tolerance (clustered spectrum at the cut): the full
+        # eigendecomposition is slower but unconditional -- never hand back an unconverged basis silently
+        lam, vv = torch.linalg.eigh(amat)
+        info.update(dense_solver="eigh_after_unconverged_subspace", residual=0.0, subspace_residual=resid,
+                    n_outer=outer, n_gemm=n_gemm, block_size=b)
+        return lam.flip(0)[:k], vv.flip(1)[:, :k]
     info.update(dense_solver="chebyshev_subspace", residual=resid, n_outer=outer, n_gemm=n_gemm, block_size=b)
     return theta[:k], v[:, :k]
 
@@ -443,11 +450,15 @@ def _pca_fit_gram(a, n_comps: int, backend, comm, zero_center: bool, seed: int, 
     if n_comps == min(n, g):
         raise ValueError(f"n_components={n_comps!r} must be strictly less than min(n_samples, n_features)="
                          f"{min(n, g)!r} with svd_solver='arpack'")
-    bound = max(n * absmax * absmax, 1e-300)
-    scale_bits = int(np.floor(62.0 - np.log2(bound)))
-    if scale_bits < 8:  # too little resolution left: the float64 Krylov route handles such data
+    # 2^S is bounded by the overflow of BOTH fixed-point sums: sum x_a x_b 2^S <= n absmax^2 2^S and the column sums
+    # sum x 2^S <= n absmax 2^S must stay below 2^62; 60 is the C entry's cap
+    bound = max(n * absmax * absmax, n * absmax, 1e-300)
+    scale_bits = min(int(np.floor(62.0 - np.log2(bound))), 60)
+    # resolution of one product relative to the largest one: 2^-(S + log2 absmax^2).  Below the 24 bits of the float32
+    # inputs (very large n * dynamic range, or |x| so small that S hits its cap) the fixed-point Gram matrix would be
+    # a PCA of rounding noise: the float64 Krylov route handles such data
+    if absmax > 0.0 and scale_bits + 2.0 * np.log2(absmax) < 24.0:
         return None
-    scale_bits = min(scale_bits, 40)
     gq = cq = None
     for h in chunks.handles(backend):
         gh, ch = backend.gram(h, scale_bits)

@@ -20,6 +20,8 @@ tests/test_readwrite_zarr_cpu.py).  `backed='r'` leaves a CSR `X` on disk as a `
 """
 from __future__ import annotations
 
+import os
+import shutil
 import warnings
 from pathlib import Path
 
@@ -528,7 +530,23 @@ def write_zarr(store, adata, *, chunks=None, level: int = 0) -> None:
     path = Path(store)
     if path.suffix == ".zip":
         raise ValueError("write a directory store (zip it afterwards if needed)")
-    _write_anndata(_ZarrSink(z3.open_store(path, "w"), level), adata, chunks)
+    # written next to the target and moved into place on success: `adata` may be backed by the very store it is
+    # written to (`read(p, backed='r')` -> `write(p, ...)`), which must stay readable until the last block is copied
+    tmp = path.with_name(f".{path.name}.tmp{os.getpid()}")
+    if tmp.exists():
+        shutil.rmtree(tmp)
+    try:
+        _write_anndata(_ZarrSink(z3.open_store(tmp, "w"), level), adata, chunks)
+        old = None
+        if path.exists():
+            old = path.with_name(f".{path.name}.old{os.getpid()}")
+            os.replace(path, old)
+        os.replace(tmp, path)
+        if old is not None:
+            shutil.rmtree(old, ignore_errors=True) if old.is_dir() else old.unlink()
+    except BaseException:
+        shutil.rmtree(tmp, ignore_errors=True)
+        raise
 
 
 def write_h5ad(filename, adata, *, compression: str | None = None, compression_opts: int | None = None) -> None:
@@ -538,7 +556,15 @@ def write_h5ad(filename, adata, *, compression: str | None = None, compression_o
     (default 4); 'lzf' is not written here."""
     if compression not in {None, "gzip"}:
         raise NotImplementedError(f"compression={compression!r}: None and 'gzip' are written here")
-    _write_anndata(_H5Sink(filename, compression, 4 if compression_opts is None else int(compression_opts)), adata)
+    # temporary file in the same directory + atomic rename: the target may be the file `adata.X` is backed by
+    filename = Path(filename)
+    tmp = filename.with_name(f".{filename.name}.tmp{os.getpid()}")
+    try:
+        _write_anndata(_H5Sink(tmp, compression, 4 if compression_opts is None else int(compression_opts)), adata)
+        os.replace(tmp, filename)
+    except BaseException:
+        tmp.unlink(missing_ok=True)
+        raise
 
 
 def write(filename, adata, *, ext: str | None = None, compression: str | None = "gzip",
