@@ -15,8 +15,19 @@ Extra objects in the line:
   roofline      knn_select_reg_kernel (FP32 MFMA): achieved = 2 * 50 flop per evaluated (query, candidate) pair
                 (scamd_knn_last_select_pairs; the exact cell-pruned search skips provably empty cells) / its HIP-event
                 duration (scamd_knn_last_select_ms), peak = 157.3 TFLOP/s (MI355X_MICROARCH.md).
+  value_host_to_host   the BASELINE metric at the drop-in boundary: AnnData with a host CSR in -> sc.pp.pca /
+                sc.pp.neighbors / sc.tl.leiden -> slots written on the host (H2D, kernels, D2H, scipy / pandas slot
+                construction), warm process, best of `--h2h-reps`; `value` is the device-resident figure.
+  structure_none       the same path on the pure-noise variant of the matrix: nothing can be pruned, the
+                kNN sweep evaluates every pair -- the regime the roofline of the brute-force sweep is quoted on.
+                `--structure none|weak|planted` makes any of the three the timed workload.
   cpu_baseline  the reference's CPU call chain (sklearn PCA arpack + sklearn brute kNN = reference calls; oracle
-                fuzzy set + oracle Leiden) on a bounded sample of the same matrix, on this box's host cores.
+                fuzzy set + oracle Leiden) on the first n cells of the same matrix for n in `--cpu-sizes`, on this box's
+                host cores; kNN fitted with the n^2 law, the other stages linearly, and extrapolated to the full size
+                (BASELINE.md section 3).
+  parity        (`--verify`, default at N=1) the GPU path against that CPU chain on the largest CPU sample, stage by
+                stage (every stage fed the CPU chain's previous output, so a gate isolates one stage) and end to end;
+                the process exits non-zero when a north_star gate breaks.
 """
 from __future__ import annotations
 
@@ -41,43 +52,234 @@ def parse_args():
     ap.add_argument("--n-comps", type=int, default=50)
     ap.add_argument("--n-neighbors", type=int, default=15)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=200_000, help="cells in the CPU-baseline sample (0 = skip)")
-    return ap.parse_args()
+    ap.add_argument("--cpu-sizes", type=str, default="100000,250000,500000",
+                    help="cell counts of the CPU-baseline samples (n^2 fit of the brute kNN); '' or 0 = skip")
+    ap.add_argument("--cpu-sample", type=int, default=None, help="(old flag) one CPU-baseline sample size; 0 = skip")
+    ap.add_argument("--cpu-budget-s", type=float, default=150.0,
+                    help="stop adding CPU samples once the next one is predicted to exceed this many seconds in total")
+    ap.add_argument("--structure", choices=("planted", "weak", "none"), default="planted",
+                    help="planted: 64 separated cell types (BASELINE.md section 3); weak: overlapping types; "
+                         "none: pure noise (throughput / roofline only, loadings and labels are ill-conditioned)")
+    ap.add_argument("--verify", dest="verify", action="store_true", default=None,
+                    help="compare the GPU path with the CPU chain on the largest CPU sample (default at N=1)")
+    ap.add_argument("--no-verify", dest="verify", action="store_false")
+    ap.add_argument("--h2h-reps", type=int, default=3, help="repetitions of the host-to-host drop-in measurement (0 = skip)")
+    ap.add_argument("--no-noise-variant", action="store_true", help="skip the `structure_none` side measurement")
+    ap.add_argument("--no-side", action="store_true", help="skip upstream_chain / umap_layout side measurements")
+    a = ap.parse_args()
+    if a.cpu_sample is not None:
+        a.cpu_sizes = str(a.cpu_sample)
+    a.cpu_sizes = [int(v) for v in a.cpu_sizes.split(",") if v.strip() and int(v) > 0]
+    return a
 
 
-def cpu_baseline(n_sample: int, n_vars: int, n_comps: int, k: int, seed: int) -> dict:
-    """Reference CPU chain on the first `n_sample` cells of the same synthetic matrix (rank 0, N=1 only)."""
+# p_programme of `synthetic_planted`: the probability that a cell expresses its type's gene in a stratum
+STRUCTURE = {"planted": 0.7, "weak": 0.12, "none": 0.0}
+
+
+def make_matrix(n, g, seed, structure, row_range=None):
+    from scanpy_amd.datasets import synthetic_planted
+
+    return synthetic_planted(n, g, seed=seed, p_programme=STRUCTURE[structure], row_range=row_range)
+
+
+def cpu_chain(x, n_comps: int, k: int) -> dict:
+    """The reference's CPU call chain on one matrix: stage seconds + every stage's output (kept for `parity`)."""
     import numpy as np
 
     from oracle import connectivities as oc
     from oracle import knn as oknn
     from oracle import leiden as ol
     from oracle import pca as opca
-    from scanpy_amd.datasets import synthetic_planted
 
-    ol.build()
-    x, _ = synthetic_planted(n_sample, n_vars, seed=seed)
+    n = x.shape[0]
     t0 = time.perf_counter()
     ref = opca.pca_reference(x, n_comps)
     t1 = time.perf_counter()
-    idx, dist, _ = oknn.knn_sklearn(ref["X_pca"].astype(np.float32), k, n_jobs=-1)
+    x_pca = np.ascontiguousarray(ref["X_pca"], dtype=np.float32)
+    idx, dist, _ = oknn.knn_sklearn(x_pca, k, n_jobs=-1)
     t2 = time.perf_counter()
-    conn, _, _ = oc.fuzzy_simplicial_set(idx, dist, n_sample, k)
+    conn, _, _ = oc.fuzzy_simplicial_set(idx, dist, n, k)
     t3 = time.perf_counter()
-    ol.leiden(conn, resolution=1.0, n_iterations=-1, seed=0)
+    labels, q = ol.leiden(conn, resolution=1.0, n_iterations=-1, seed=0)
     t4 = time.perf_counter()
-    total = t4 - t0
-    return {
-        "value": n_sample / total,
+    return {"n": n, "seconds": {"pca": t1 - t0, "knn": t2 - t1, "connectivities": t3 - t2, "leiden": t4 - t3},
+            "components": ref["components"], "x_pca": x_pca, "idx": idx, "dist": dist, "conn": conn, "labels": labels,
+            "modularity": q}
+
+
+def cpu_baseline(x_full, truth, sizes, n_full: int, n_comps: int, k: int, budget_s: float):
+    """Reference CPU chain on the first n cells of the same synthetic matrix for each n in `sizes` (rank 0, N=1 only).
+    -> (the `cpu_baseline` object, the chain outputs of the largest sample that ran)."""
+    import numpy as np
+
+    from oracle import leiden as ol
+
+    ol.build()
+    runs, last, spent = [], None, 0.0
+    for n_s in sorted(min(v, x_full.shape[0]) for v in sizes):
+        if runs:  # predicted cost of this sample from the previous one: kNN ~ n^2, the rest ~ n
+            p = runs[-1]
+            r = n_s / p["n"]
+            pred = p["knn"] * r * r + (p["pca"] + p["connectivities"] + p["leiden"]) * r
+            if spent + pred > budget_s:
+                break
+        c = cpu_chain(x_full[:n_s], n_comps, k)
+        sec = c["seconds"]
+        runs.append({"n": n_s, **sec, "total": sum(sec.values())})
+        spent += runs[-1]["total"]
+        last = c
+    # fits through the origin: kNN = a n^2 (least squares over the samples), every other stage = b n
+    ns = np.array([r["n"] for r in runs], dtype=np.float64)
+    a_knn = float((np.array([r["knn"] for r in runs]) * ns ** 2).sum() / (ns ** 4).sum())
+    lin = {st: float((np.array([r[st] for r in runs]) * ns).sum() / (ns ** 2).sum()) for st in ("pca", "connectivities", "leiden")}
+    est = {"knn": a_knn * n_full ** 2, **{st: b * n_full for st, b in lin.items()}}
+    est_total = sum(est.values())
+    big = runs[-1]
+    obj = {
+        "value": n_full / est_total,
         "unit": "cells/s",
         "cores": os.cpu_count(),
         "kind": "port",
-        "sample": (f"first {n_sample} cells x {n_vars} genes of the same synthetic CSR; sklearn PCA(arpack) "
-                   f"{t1 - t0:.2f}s + sklearn brute kNN(n_jobs=-1) {t2 - t1:.2f}s (the reference's own calls) + oracle "
-                   f"fuzzy_simplicial_set {t3 - t2:.2f}s + oracle Leiden {t4 - t3:.2f}s; brute kNN is O(n^2), so the "
-                   "CPU rate at the full 1M cells is far lower than at this sample size"),
-        "seconds": total,
+        "sample": (f"first n cells x {x_full.shape[1]} genes of the same synthetic CSR for n in {[r['n'] for r in runs]}: "
+                   "sklearn PCA(arpack) + sklearn brute kNN(n_jobs=-1) (the reference's own calls) + oracle "
+                   "fuzzy_simplicial_set + oracle Leiden (igraph / umap-learn absent); `value` = the full "
+                   f"{n_full} cells / the seconds extrapolated from these samples (brute kNN = a*n^2 least squares, "
+                   "the other stages linear in n; BASELINE.md section 3); `measured` holds what was timed"),
+        "measured": runs,
+        "extrapolated_seconds_at_full_size": {**est, "total": est_total},
+        "largest_sample_cells_per_s": big["n"] / big["total"],
+        "seconds": spent,
     }
+    return obj, last
+
+
+def parity_block(x_full, truth, chain: dict, n_comps: int, k: int) -> dict:
+    """GPU path vs the CPU chain on the chain's sample (the first chain['n'] cells), through the drop-in calls.
+    Stage-wise: each GPU stage is fed the CPU chain's output of the previous stage, so each gate isolates one stage;
+    end to end: all three stages on the GPU from the matrix."""
+    import numpy as np
+
+    import scanpy_amd as sc
+    from oracle import compare as cmp
+    from oracle import leiden as ol
+
+    n_s = chain["n"]
+    x = x_full[:n_s]
+    out = {"sample_cells": n_s, "gates": dict(cmp.GATES)}
+    # end to end on the GPU
+    a = sc.AnnData(x)
+    sc.pp.pca(a, n_comps=n_comps)
+    sc.pp.neighbors(a, n_neighbors=k)
+    sc.tl.leiden(a, flavor="igraph", n_iterations=-1)
+    gpu_labels = a.obs["leiden"].cat.codes.to_numpy()
+    out["pca_loading_err"] = cmp.pca_loading_err(a.varm["PCs"].T, chain["components"])
+    out["leiden_ari_vs_cpu_chain"] = cmp.ari(gpu_labels, chain["labels"])
+    out["n_clusters"] = {"gpu": int(gpu_labels.max()) + 1, "cpu_chain": int(chain["labels"].max()) + 1}
+    out["modularity"] = {"gpu": float(a.uns["leiden"]["modularity"]), "cpu_chain": chain["modularity"]}
+    if truth is not None:
+        out["ari_vs_truth"] = {"gpu": cmp.ari(gpu_labels, truth[:n_s]), "cpu_chain": cmp.ari(chain["labels"], truth[:n_s])}
+    e2e = a.obsp["distances"]
+    got = np.sort(e2e.indices.reshape(n_s, k - 1), axis=1)
+    out["knn_rows_equal_end_to_end"] = float((got == np.sort(chain["idx"][:, 1:], axis=1)).all(axis=1).mean())
+    # stage-wise: neighbors on the CPU chain's embedding
+    b = sc.AnnData(x)
+    b.obsm["X_pca"] = chain["x_pca"]
+    sc.pp.neighbors(b, n_neighbors=k, use_rep="X_pca")
+    d = b.obsp["distances"]
+    gi = np.hstack([np.arange(n_s, dtype=np.int64)[:, None], d.indices.reshape(n_s, k - 1)])
+    gd = np.hstack([np.zeros((n_s, 1)), d.data.reshape(n_s, k - 1)])
+    bad, differ = cmp.knn_rows_differing_beyond_ties(gi, gd, chain["idx"], chain["dist"])
+    out["knn_rows_differing_beyond_ties"] = bad
+    out["knn_rows_differing_at_ties"] = differ - bad
+    out["knn_max_rel_distance_err"] = float(np.max(np.abs(np.sort(gd, axis=1) - np.sort(chain["dist"], axis=1))
+                                                   / np.maximum(np.sort(chain["dist"], axis=1), 1e-30)))
+    # (the GPU search returns the float64 distance rounded once to float32, sklearn's differ from that in the last bit;
+    # umap's bisection stops when |sum - log2 k| < 1e-5, so a one-ulp input change moves a few sigmas by ~1e-5:
+    # informational, the reference's own bar for recomputed distances is rtol 1e-5, tests/test_neighbors.py:275-296)
+    cerr_g, same_g = cmp.conn_max_abs(b.obsp["connectivities"], chain["conn"])
+    out["conn_max_abs_from_gpu_distances"] = cerr_g
+    # stage-wise: the fuzzy set from the CPU chain's OWN distances (`pp.neighbors(distances=...)`)
+    from oracle import knn as oknn
+
+    f = sc.AnnData(x[:, :1])
+    sc.pp.neighbors(f, n_neighbors=k, distances=oknn.sparse_from_indices_distances(chain["idx"], chain["dist"], keep_self=False))
+    cerr, same = cmp.conn_max_abs(f.obsp["connectivities"], chain["conn"])
+    out["conn_max_abs"] = cerr
+    out["conn_same_pattern"] = bool(same and same_g)
+    # stage-wise: Leiden on the CPU chain's graph; the oracle's own seed-to-seed agreement is the noise floor
+    c = sc.AnnData(x[:, :1])
+    sc.tl.leiden(c, adjacency=chain["conn"], flavor="igraph", n_iterations=-1)
+    out["leiden_ari_stagewise"] = cmp.ari(c.obs["leiden"].cat.codes.to_numpy(), chain["labels"])
+    out["leiden_modularity_stagewise"] = {"gpu": float(c.uns["leiden"]["modularity"]), "cpu_chain": chain["modularity"]}
+    other, q_other = ol.leiden(chain["conn"], resolution=1.0, n_iterations=-1, seed=1)
+    out["cpu_chain_seed0_vs_seed1_ari"] = cmp.ari(other, chain["labels"])
+    fails = []
+    if out["pca_loading_err"] > cmp.GATES["pca_loading_err"]:
+        fails.append("pca_loading_err")
+    if out["knn_rows_differing_beyond_ties"] > 0:
+        fails.append("knn_rows_differing_beyond_ties")
+    if out["conn_max_abs"] > cmp.GATES["conn_max_abs"] or not same:
+        fails.append("conn_max_abs")
+    floor = min(cmp.GATES["leiden_ari_vs_cpu_chain"], out["cpu_chain_seed0_vs_seed1_ari"])
+    if min(out["leiden_ari_vs_cpu_chain"], out["leiden_ari_stagewise"]) < floor:
+        fails.append("leiden_ari_vs_cpu_chain")
+    out["leiden_ari_bar"] = floor
+    out["failed_gates"] = fails
+    return out
+
+
+def host_to_host(x, n_comps: int, k: int, reps: int) -> dict:
+    """The BASELINE metric at the drop-in boundary (SURVEY 8(d) bullet 1): a host AnnData in, the slots on the host
+    out, through sc.pp.pca / sc.pp.neighbors / sc.tl.leiden."""
+    import scanpy_amd as sc
+
+    best, runs = None, []
+    for _ in range(reps):
+        a = sc.AnnData(x)
+        t0 = time.perf_counter()
+        sc.pp.pca(a, n_comps=n_comps)
+        t1 = time.perf_counter()
+        sc.pp.neighbors(a, n_neighbors=k)
+        t2 = time.perf_counter()
+        sc.tl.leiden(a, flavor="igraph", n_iterations=-1)
+        t3 = time.perf_counter()
+        r = {"pca_ms": (t1 - t0) * 1e3, "neighbors_ms": (t2 - t1) * 1e3, "leiden_ms": (t3 - t2) * 1e3, "total_ms": (t3 - t0) * 1e3}
+        runs.append(r)
+        if best is None or r["total_ms"] < best["total_ms"]:
+            best = r
+    return {"value": x.shape[0] / (best["total_ms"] * 1e-3), "unit": "cells/s", "best": best, "first": runs[0], "reps": reps,
+            "n_clusters": int(a.obs["leiden"].nunique()),
+            "note": "host AnnData (CSR f32) in -> obsm/varm/uns/obsp/obs slots on the host out; includes H2D of X, D2H of "
+                    "the results and the scipy / pandas slot construction; warm process"}
+
+
+def noise_variant(args, backend, kw) -> dict:
+    """`structure_none`: the path on the pure-noise matrix of the same shape (rank 0, N=1): no cell can be pruned."""
+    import torch
+
+    from scanpy_amd import _lib
+    from scanpy_amd._pipeline import run_path
+
+    lib = _lib.load()
+    x, _ = make_matrix(args.n_obs, args.n_vars, args.seed, "none")
+    h = backend.upload(x)
+    del x
+    run_path(h, args.n_obs, **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = run_path(h, args.n_obs, timing=True, **kw)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    sel, pairs = float(lib.scamd_knn_last_select_ms()), float(lib.scamd_knn_last_select_pairs())
+    brute = float(args.n_obs) ** 2
+    tf = 2.0 * pairs * args.n_comps / (sel * 1e-3) / 1e12 if sel > 0 else None
+    return {"note": "same shape, p_programme = 0 (i.i.d. genes): PCA spectrum without a gap, kNN without prunable cells; "
+                    "1 warm-up + 1 timed step, outside `value`",
+            "ms_per_step": ms, "cells_per_s": args.n_obs / (ms * 1e-3), "stage_ms": res.stage_ms,
+            "pairs_evaluated_fraction": pairs / brute, "knn_select_ms": sel, "knn_select_tflops": tf,
+            "knn_select_frac_of_157.3": tf / 157.3 if tf else None, "n_communities": res.n_communities,
+            "modularity": res.modularity, "pca_info": {k: v for k, v in res.info.items() if k != "knn_fallback_queries"}}
 
 
 def _profiled_traffic(mode: str):
@@ -200,7 +402,6 @@ def main() -> None:
 
     from scanpy_amd import _lib
     from scanpy_amd._pipeline import run_path, shard_bounds
-    from scanpy_amd.datasets import synthetic_planted
     from scanpy_amd.preprocessing._pca_solver import GpuBackend, NoComm, TorchDistComm
 
     comm = NoComm()
@@ -215,7 +416,7 @@ def main() -> None:
     n = args.n_obs
     lo, hi = shard_bounds(n, world, rank)
     t_gen = time.perf_counter()
-    x, _ = synthetic_planted(n, args.n_vars, seed=args.seed, row_range=(lo, hi))
+    x, truth = make_matrix(n, args.n_vars, args.seed, args.structure, row_range=(lo, hi))
     t_gen = time.perf_counter() - t_gen
     backend = GpuBackend()
     t_h2d = time.perf_counter()
@@ -223,7 +424,9 @@ def main() -> None:
     torch.cuda.synchronize()
     t_h2d = time.perf_counter() - t_h2d
     nnz_local = x.nnz
-    del x
+    side = world == 1  # the side measurements and the CPU legs need the host matrix: rank 0 of a single-GPU run only
+    if not side:
+        del x
 
     def sync_all():
         torch.cuda.synchronize()
@@ -280,7 +483,7 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": (f"synthetic planted log-normal CSR {n} cells x {args.n_vars} genes (~5% nnz), PCA {args.n_comps} "
+                "workload": (f"synthetic {args.structure}-structure log-normal CSR {n} cells x {args.n_vars} genes (~5% nnz), PCA {args.n_comps} "
                              f"(exact Gram + dense eigensolve, arpack accuracy) + exact kNN k={args.n_neighbors} (cell-pruned brute force) + umap "
                              "connectivities + Leiden res=1.0 n_iterations=-1 (" + _baseline_config(n, args.n_vars, world) + ")"),
                 "n_obs": n,
@@ -307,12 +510,37 @@ def main() -> None:
             "result": {"n_communities": res.n_communities, "modularity": res.modularity, **res.info},
             "setup_s": {"generate": t_gen, "h2d": t_h2d},
         }
-        if world == 1:
-            out["upstream_chain"] = upstream_chain(handle)
-            out["umap_layout"] = umap_layout(res, n)
-        if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n), args.n_vars, args.n_comps, args.n_neighbors, args.seed)
+        out["config"]["structure"] = args.structure
+        rc = 0
+        if side:
+            if not args.no_side:
+                out["upstream_chain"] = upstream_chain(handle)
+                out["umap_layout"] = umap_layout(res, n)
+            del handle, res
+            if args.h2h_reps > 0:
+                h2h = host_to_host(x, args.n_comps, args.n_neighbors, args.h2h_reps)
+                out["value_host_to_host"] = h2h["value"]
+                out["host_to_host"] = h2h
+            if not args.no_noise_variant and args.structure != "none":
+                out["structure_none"] = noise_variant(args, backend, kw)
+            if args.cpu_sizes:
+                out["cpu_baseline"], chain = cpu_baseline(x, truth, args.cpu_sizes, n, args.n_comps, args.n_neighbors,
+                                                          args.cpu_budget_s)
+                if args.verify is not False:
+                    par = parity_block(x, truth if args.structure != "none" else None, chain, args.n_comps, args.n_neighbors)
+                    if args.structure == "none":
+                        # i.i.d. genes: no spectral gap (loadings are arbitrary within the bulk) and no communities
+                        # -> only the kNN and connectivity gates are meaningful
+                        par["failed_gates"] = [f for f in par["failed_gates"] if f in ("knn_rows_differing_beyond_ties", "conn_max_abs")]
+                        par["note"] = "structure none: loadings / label gates not asserted"
+                    out["parity"] = par
+                    rc = 1 if par["failed_gates"] else 0
         print(json.dumps(out), flush=True)
+        if rc:
+            print(f"PARITY GATES FAILED: {out['parity']['failed_gates']}", file=sys.stderr, flush=True)
+            if world > 1:
+                dist.destroy_process_group()
+            raise SystemExit(2)
     if world > 1:
         dist.destroy_process_group()
 

@@ -298,6 +298,16 @@ __global__ __launch_bounds__(NW * 64) void knn_select_kernel(const float* __rest
 __device__ __forceinline__ float readlane_f32(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
+// v_writelane_b32 (value and lane uniform): clang has no builtin for it, the LLVM intrinsic is reached by its name
+extern "C" __device__ int scamd_llvm_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+// List keys of the register-list kernel: the float32 score with its 5 low mantissa bits replaced by the number of the
+// slot (lane of idx[r], within the query's half) that holds the candidate's row id -- the keys stay sorted along the
+// lanes, the row ids never move.  A key differs from its score by < 32 ulp (KEY_SLACK_ULPS, part of the certificate's
+// error bound); empty entries are KEY_BIG | slot.
+constexpr int KEY_SLOT_MASK = 31;
+constexpr float KEY_BIG = 3.0e38f;
+// float32 bit patterns -> integers whose signed order is the float order (scalar unit: gfx950 has no SALU float compare)
+__device__ __forceinline__ int key_order(int bits) { return bits ^ ((bits >> 31) & 0x7fffffff); }
 
 template <int H, int TC_ = 64>
 struct RegCfg {
@@ -403,18 +413,19 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
   float athr = half ? 1.0f : 0.0f;
   float key[16];
   int idx[16];
+  // empty list: KEY_BIG with ascending slot numbers (ascending keys along the lanes of each half)
+  const float key_empty = __int_as_float((__float_as_int(KEY_BIG) & ~KEY_SLOT_MASK) | l31);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    key[r] = INFINITY;
+    key[r] = key_empty;
     idx[r] = -1;
   }
 
   int n_sub = 0;  // sub-tiles of the current sweep
   // cell-pruned mode: `minima` = the pre-pass over the own cell (key[r] collects, per lane, the smallest score of the
-  // candidates j = lane (mod 32): 32 distinct candidates per query); athr_floor = the threshold derived from it,
+  // candidates j = lane (mod 32): 32 distinct candidates per query); the threshold derived from it seeds the list,
   // which the list threshold can only tighten (same lane layout as athr)
   bool minima = false;
-  float athr_floor = half ? 1.0f : -INFINITY;
   // B operand of sub-tile g of the current sweep: lane l holds candidate (l&31), the same dim slice as A, then
   // the extra k slot
   auto load_b = [&](int g, float (&b)[HP]) {
@@ -431,36 +442,46 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
   };
   // Insert the survivors of a sub-tile.  acc[r] = score - (threshold its chain used); that threshold is lane
   // i(r,h) of `athr_used` (negated).  all = true (very first sub-tile): every finite score is inserted.
+  // The two halves of a register (two queries) are handled one after the other, so every operand of an insertion is a
+  // scalar: per survivor 2 readlanes (score, largest key), 1 writelane (row id into the evicted entry's slot) and
+  // DPP shift + lane-0 fix + v_med3 on the keys -- new_key[l] = med3(key[l-1], key[l], v) IS the sorted insertion
+  // (key[l-1] <= key[l]): v below both -> the left neighbour moves up, between -> v lands here, above -> unchanged.
+  // The row ids stay where they are (slot = low 5 key bits).  On gfx950 the f32 MFMA shares the VALU lanes, and a
+  // streaming top-k list takes ~100 insertions per query at 1M rows: this path, not the filter, is what the MFMA
+  // stream competes with (round 1: 16 VALU per survivor + 15 per register with a hit, 147 VALU per sub-tile in all).
+  auto insert_half = [&](const f32x16& acc, float athr_used, int cbase, const int r, const int h, unsigned int bits) {
+    const int ih = (r & 3) + 8 * (r >> 2) + 4 * h;      // this half's query = its lane of the threshold operand
+    const float tu = -readlane_f32(athr_used, ih);
+    const float sc = acc[r] + tu;                        // the float32 score again (+- 1 ulp)
+    do {
+      const int s = __builtin_ctz(bits);
+      const int vb = __builtin_amdgcn_readlane(__float_as_int(sc), 32 * h + s);
+      const int lastb = __builtin_amdgcn_readlane(__float_as_int(key[r]), 32 * h + 31);
+      // (a survivor of a threshold one sub-tile old may no longer beat the list's largest entry)
+      if (key_order(vb) < key_order(lastb)) {
+        const int slot = lastb & KEY_SLOT_MASK;          // the evicted entry's slot is reused
+        const float kv = __int_as_float((vb & ~KEY_SLOT_MASK) | slot);
+        idx[r] = scamd_llvm_writelane(cbase + s, 32 * h + slot, idx[r]);
+        // lane l-1's key by DPP wave_shr:1; lanes 0 and 32 have no left neighbour
+        float upk = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(key[r]), 0x138, 0xf, 0xf, true));
+        upk = (l31 == 0) ? -INFINITY : upk;
+        const float nk = __builtin_amdgcn_fmed3f(upk, key[r], kv);
+        key[r] = (half == h) ? nk : key[r];
+      }
+      bits &= bits - 1;
+    } while (bits);
+    // new threshold of this query -> its lane of the A operand of the extra k-pair
+    const float t = readlane_f32(key[r], 32 * h + thr_lane);
+    athr = __int_as_float(scamd_llvm_writelane(__float_as_int(-t), ih, __float_as_int(athr)));
+  };
   auto insert = [&](const f32x16& acc, float athr_used, int cbase, bool all) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const unsigned long long m = all ? __ballot(acc[r] < INFINITY) : __ballot(acc[r] < 0.f);
       if (m) {
-        const int i0 = (r & 3) + 8 * (r >> 2), i1 = i0 + 4;
-        const float tu0 = -readlane_f32(athr_used, i0), tu1 = -readlane_f32(athr_used, i1);
-        const float sc = acc[r] + (half ? tu1 : tu0);  // the float32 score again (+- 1 ulp)
-        unsigned int lo = (unsigned int)m, hi = (unsigned int)(m >> 32);
-        while (lo | hi) {
-          const int slo = lo ? __builtin_ctz(lo) : 0, shi = hi ? __builtin_ctz(hi) : 0;
-          const float vlo = lo ? readlane_f32(sc, slo) : INFINITY;
-          const float vhi = hi ? readlane_f32(sc, 32 + shi) : INFINITY;
-          const float v = half ? vhi : vlo;
-          const int ci = cbase + (half ? shi : slo);
-          // lane l-1's entry by DPP wave_shr:1 (one VALU op, no LDS round trip); lane 32 receives lane 31's
-          // value, which `first` ignores
-          const float upk = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(key[r]), 0x138, 0xf, 0xf, false));
-          const int upi = __builtin_amdgcn_update_dpp(0, idx[r], 0x138, 0xf, 0xf, false);
-          const bool gt = key[r] > v;
-          const bool first = (l31 == 0) || !(upk > v);
-          key[r] = gt ? (first ? v : upk) : key[r];
-          idx[r] = gt ? (first ? ci : upi) : idx[r];
-          lo &= lo - 1;
-          hi &= hi - 1;
-        }
-        // new thresholds of the two queries this register belongs to -> their lanes of the A operand
-        const float t0 = readlane_f32(key[r], thr_lane), t1 = readlane_f32(key[r], 32 + thr_lane);
-        athr = (lane == i0) ? -t0 : ((lane == i1) ? -t1 : athr);
-        if constexpr (IVF) athr = fmaxf(athr, athr_floor);  // -thr = max(-t, -thr_floor); 1.0 stays 1.0 on lanes >= 32
+        const unsigned int lo = (unsigned int)m, hi = (unsigned int)(m >> 32);
+        if (lo) insert_half(acc, athr_used, cbase, r, 0, lo);
+        if (hi) insert_half(acc, athr_used, cbase, r, 1, hi);
       }
     }
   };
@@ -628,16 +649,23 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
         const int i0 = (r & 3) + 8 * (r >> 2), i1 = i0 + 4;
         const float t0 = readlane_f32(x, thr_lane), t1 = readlane_f32(x, 32 + thr_lane);
         athr = (lane == i0) ? -t0 : ((lane == i1) ? -t1 : athr);
-        key[r] = INFINITY;
+        // the list starts out as 32 placeholders AT the pre-pass threshold (row id -1): the list's thr_rank-th entry
+        // can then never exceed that proven bound, and real entries (all below it) displace the placeholders from
+        // the top.  Slot numbers ascend with the key: l31 for a positive threshold, 31 - l31 for a negative one.
+        const int tb = __float_as_int(fminf(half ? t1 : t0, KEY_BIG));  // (never +inf: its mantissa holds the slot)
+        key[r] = __int_as_float((tb & ~KEY_SLOT_MASK) | (tb < 0 ? 31 - l31 : l31));
       }
-      athr_floor = athr;
     }
     bool first = true;
     for (int ci = 0; ci < iv.n_cells; ++ci) {
       const float lb = lb2[ci];
       if (!(lb < INFINITY)) break;  // empty cells sort last
       if (ci > 0) {
-        float dthr = (half == 0 && qvalid) ? (qn - athr) : -INFINITY;  // athr = -thr on lanes 0..31
+        // athr = -thr on lanes 0..31.  thr lives in score space (||c||^2 - 2 q.c), where float32 carries an absolute
+        // error of ~(d + 14) 2^-24 ||q||^2 (the rounding of ||q||^2 itself, of the sum below and of the scores the
+        // threshold was taken from); far from the origin (||q||^2 >> d^2) that exceeds the 1e-3 relative slack of
+        // the test below, so it is added per query: 1e-5 >= 142 * 2^-24 covers d <= 128
+        float dthr = (half == 0 && qvalid) ? (qn - athr) + 1e-5f * qn : -INFINITY;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) dthr = fmaxf(dthr, __shfl_xor(dthr, o));
         if (lane == 0) wmax[wave] = dthr;
@@ -820,9 +848,11 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
     double dk = (kk > 0) ? skth[w] : 0.0;
     double tau = (double)cand_tau[qi];
     double cmax = (double)__uint_as_float(*cmax_bits);
-    // |s_float32 - s_exact| <= (2H+2) u (||c||^2 + 2 ||q|| ||c||), u = 2^-24; 2H+2 <= 130.
-    double eps = cert_scale * 130.0 * 5.9604644775390625e-08 * (cmax + 2.0 * sqrt(qn * cmax));
-    bool certified = (tau == INFINITY) || ((dk - qn) + eps < tau);
+    // |s_float32 - s_exact| <= (2H+2) u (||c||^2 + 2 ||q|| ||c||), u = 2^-24; 2H+2 <= 130.  The register-list kernel
+    // keeps a slot number in the 5 low mantissa bits of its keys: the threshold and the keys it was compared with are
+    // each off by < 32 ulp = 64 u |score| -> 194.  tau >= 1e38: the list never filled (fewer than thr_rank rows).
+    double eps = cert_scale * 194.0 * 5.9604644775390625e-08 * (cmax + 2.0 * sqrt(qn * cmax));
+    bool certified = (tau >= 1e38f) || ((dk - qn) + eps < tau);
     kth_d2[qi] = dk;
     if (!certified) {
       int slot = atomicAdd(n_flag, 1);

@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <ctime>
 
 namespace scamd {
 
@@ -1330,13 +1331,8 @@ struct LeidenCtx {
   int agg_pass_keys = AGG_BIG_PASS;
 };
 
-static bool leiden_debug() {
-  static const bool d = [] {
-    const char* e = getenv("SCAMD_LEIDEN_DEBUG");
-    return e && e[0] == '1';
-  }();
-  return d;
-}
+static bool g_leiden_debug = false;  // SCAMD_LEIDEN_DEBUG=1, read at every entry (tools switch it inside one process)
+static bool leiden_debug() { return g_leiden_debug; }
 
 static int read_counters(LeidenCtx& cx, int* h, int cnt) {
   SCAMD_HIP_CHECK(hipMemcpyAsync(h, cx.b.counters, sizeof(int) * cnt, hipMemcpyDeviceToHost, cx.s));
@@ -1636,6 +1632,13 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
 }
 
 // one Leiden iteration starting from the level-0 partition in b.memb; result back into b.memb
+static double dbg_now(LeidenCtx& cx) {  // debug trace only: drains the stream, then host time in ms
+  (void)hipStreamSynchronize(cx.s);
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
 static int leiden_iteration(LeidenCtx& cx, const LevelGraph& g0) {
   LeidenBuffers& b = cx.b;
   SCAMD_HIP_CHECK(hipMemcpyAsync(b.comm, b.memb, sizeof(int) * g0.n, hipMemcpyDeviceToDevice, cx.s));
@@ -1644,16 +1647,24 @@ static int leiden_iteration(LeidenCtx& cx, const LevelGraph& g0) {
   LevelGraph g = g0;
   for (int level = 0; level < MAX_LEVELS; ++level) {
     int moves = 0;
+    const bool dbg = leiden_debug();
+    const double t0 = dbg ? dbg_now(cx) : 0.0;
     int rc = local_moving(cx, g, &moves);
     if (rc != SCAMD_OK) return rc;
+    const double t1 = dbg ? dbg_now(cx) : 0.0;
     int merged = 0;
     rc = refinement(cx, g, &merged);
     if (rc != SCAMD_OK) return rc;
+    const double t2 = dbg ? dbg_now(cx) : 0.0;
+    if (dbg)
+      fprintf(stderr, "[leiden] level %d n=%d nnz=%lld maxdeg=%d: local moving %.2f ms (%d moves), refinement %.2f ms (%d merged)\n",
+              level, g.n, (long long)g.nnz, g.max_deg, t1 - t0, moves, t2 - t1, merged);
     if (merged == 0) break;
     LevelGraph gn;
     int n_new = 0;
     rc = aggregate(cx, g, g0.n, level & 1, &gn, &n_new);
     if (rc != SCAMD_OK) return rc;
+    if (dbg) fprintf(stderr, "[leiden] level %d aggregate %.2f ms -> n=%d\n", level, dbg_now(cx) - t2, n_new);
     if (n_new == g.n) break;
     g = gn;
   }
@@ -1743,6 +1754,10 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
   SCAMD_REQUIRE(n >= 1 && n < ((int64_t)1 << 31) && nnz >= 0, SCAMD_EINVAL, "leiden: bad shape n=%lld nnz=%lld",
                 (long long)n, (long long)nnz);
   SCAMD_REQUIRE(resolution >= 0.0, SCAMD_EINVAL, "leiden: negative resolution");
+  {
+    const char* e = getenv("SCAMD_LEIDEN_DEBUG");
+    g_leiden_debug = e && e[0] == '1';
+  }
   LeidenCtx cx;
   cx.s = stream;
   cx.gamma = resolution;
@@ -1783,6 +1798,7 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
       if (rc == SCAMD_OK) rc = quality(cx, g0, b.memb, &q);
       if (rc != SCAMD_OK) return rc;
       const bool improved = q > q_best + 1e-12;
+      if (leiden_debug()) fprintf(stderr, "[leiden] iteration %d: Q = %.10f (best before %.10f)\n", it, q, q_best);
       if (improved) {
         q_best = q;
         SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb_best, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
@@ -1810,6 +1826,10 @@ extern "C" int scamd_modularity_csr_f32(const int64_t* indptr, const int32_t* in
   SCAMD_REQUIRE(indptr && membership && modularity_host && (nnz == 0 || (indices && weights)), SCAMD_EINVAL,
                 "modularity: null pointer");
   SCAMD_REQUIRE(n >= 1 && n < ((int64_t)1 << 31) && nnz >= 0, SCAMD_EINVAL, "modularity: bad shape");
+  {
+    const char* e = getenv("SCAMD_LEIDEN_DEBUG");
+    g_leiden_debug = e && e[0] == '1';
+  }
   LeidenCtx cx;
   cx.s = stream;
   cx.gamma = resolution;
