@@ -36,10 +36,45 @@ constexpr int FALLBACK_CAP = 2048;    // collected rows per uncertified query
 constexpr int FALLBACK_CHUNK = 1024;  // uncertified queries processed per launch
 
 // ------------------------------------------------------------------------------------------------
-// pack: zero-padded [n_pad][DP] copy, float32 squared norms (rounded once from float64), max norm
+// centring: the float32 pass works on x - mu (mu = column means, float32).  Euclidean distances do not change, the
+// scores ||c||^2 - 2 q.c do: far from the origin (||x||^2 >> d^2) they lose every digit that matters -- at an offset
+// of 300 per coordinate a float32 ulp of a score is 0.5 against squared neighbour distances of ~100, every query
+// failed its certificate and went through the float64 scan.  fl(x - mu) is exact to 2^-24 relative per coordinate;
+// that perturbation is part of the certificate's error bound (knn_rerank_kernel).  The exact passes (re-rank, fallback)
+// read the caller's x.  Two stages, fixed summation order: the same mu for the same input, run to run.
 // ------------------------------------------------------------------------------------------------
-__global__ void knn_pack_kernel(const float* __restrict__ x, int64_t n, int d, int64_t ld, int DP,
-                                int64_t n_pad, float* __restrict__ xp, float* __restrict__ cn,
+constexpr int MEAN_BLOCKS = 256;
+__global__ __launch_bounds__(256) void knn_colsum_kernel(const float* __restrict__ x, int64_t n, int d, int64_t ld,
+                                                         double* __restrict__ partial /* [MEAN_BLOCKS][128] */) {
+  __shared__ double sh[256];
+  const int cols = d <= 64 ? 64 : 128, rpar = 256 / cols;
+  const int c = threadIdx.x % cols, rr = threadIdx.x / cols;
+  const int64_t chunk = (n + MEAN_BLOCKS - 1) / MEAN_BLOCKS;
+  const int64_t r0 = (int64_t)blockIdx.x * chunk, r1 = std::min<int64_t>(n, r0 + chunk);
+  double s = 0.0;
+  if (c < d)
+    for (int64_t r = r0 + rr; r < r1; r += rpar) s += (double)x[r * ld + c];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (rr == 0) {
+    for (int j = 1; j < rpar; ++j) s += sh[j * cols + c];
+    if (c < 128) partial[(int64_t)blockIdx.x * 128 + c] = (c < d) ? s : 0.0;
+  }
+  if (cols == 64 && threadIdx.x >= 64 && threadIdx.x < 128) partial[(int64_t)blockIdx.x * 128 + threadIdx.x] = 0.0;
+}
+__global__ __launch_bounds__(128) void knn_colmean_kernel(const double* __restrict__ partial, int64_t n, int d,
+                                                          float* __restrict__ mu /* [128] */) {
+  const int c = threadIdx.x;
+  double s = 0.0;
+  for (int b = 0; b < MEAN_BLOCKS; ++b) s += partial[(int64_t)b * 128 + c];
+  mu[c] = (c < d && n > 0) ? (float)(s / (double)n) : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pack: zero-padded [n_pad][DP] copy of x - mu, float32 squared norms (rounded once from float64), max norm
+// ------------------------------------------------------------------------------------------------
+__global__ void knn_pack_kernel(const float* __restrict__ x, const float* __restrict__ mu, int64_t n, int d, int64_t ld,
+                                int DP, int64_t n_pad, float* __restrict__ xp, float* __restrict__ cn,
                                 unsigned int* __restrict__ cmax_bits) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -48,7 +83,7 @@ __global__ void knn_pack_kernel(const float* __restrict__ x, int64_t n, int d, i
   for (int64_t r = wave; r < n_pad; r += nwaves) {
     double s = 0.0;
     for (int c = lane; c < DP; c += 64) {
-      float v = (r < n && c < d) ? x[r * ld + c] : 0.f;
+      float v = (r < n && c < d) ? __fsub_rn(x[r * ld + c], mu[c]) : 0.f;
       xp[r * DP + c] = v;
       s += (double)v * (double)v;
     }
@@ -322,8 +357,8 @@ struct RegCfg {
 
 // packed image of x for the register-list kernel: [n_pad][DPL] float32 (layout above); rows >= n get
 // ||c||^2 = +inf so that they can never be selected.
-__global__ void knn_pack_image_kernel(const float* __restrict__ x, int64_t n, int d, int64_t ld, int H, int HP,
-                                      int DPL, int64_t n_pad, float* __restrict__ xp,
+__global__ void knn_pack_image_kernel(const float* __restrict__ x, const float* __restrict__ mu, int64_t n, int d,
+                                      int64_t ld, int H, int HP, int DPL, int64_t n_pad, float* __restrict__ xp,
                                       unsigned int* __restrict__ cmax_bits) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -332,7 +367,7 @@ __global__ void knn_pack_image_kernel(const float* __restrict__ x, int64_t n, in
   for (int64_t r = wave; r < n_pad; r += nwaves) {
     double s = 0.0;
     for (int c = lane; c < d; c += 64) {
-      double v = (r < n) ? (double)x[r * ld + c] : 0.0;
+      double v = (r < n) ? (double)__fsub_rn(x[r * ld + c], mu[c]) : 0.0;
       s += v * v;
     }
 #pragma unroll
@@ -343,7 +378,7 @@ __global__ void knn_pack_image_kernel(const float* __restrict__ x, int64_t n, in
       float v = 0.f;
       if (hh < 2) {
         const int dim = hh * H + cc;
-        if (cc < H) v = (r < n && dim < d) ? x[r * ld + dim] : 0.f;
+        if (cc < H) v = (r < n && dim < d) ? __fsub_rn(x[r * ld + dim], mu[dim]) : 0.f;
         else if (cc == H) v = (hh == 0) ? 1.0f : nf;  // B operand of the extra k-pair: [1 | ||c||^2]
       }
       xp[r * DPL + c] = v;
@@ -373,6 +408,9 @@ struct IvfArgs {
   const float* order_lb2;   // [n_cells][n_cells] the squared lower bounds in that order (INF = empty cell)
   const int* perm;          // [n_image_rows] original row id of an image row (-1 = padding)
   unsigned long long* pairs; // (query, candidate) pairs evaluated, for the roofline figure
+  const int* block_perm;     // [n_blocks] launch slot -> block: cells with the longest expected sweep first (LPT)
+  int debug_no_insert;       // debug (SCAMD_KNN_DEBUG_NO_INSERT=1): survivors are dropped -- WRONG results, MFMA-side ceiling
+  unsigned long long* trace; // debug (SCAMD_KNN_TRACE=<file>): per block {start, end (100 MHz clock), tiles swept, hw id}
   int n_cells, dc;          // dc = stride of `centers` (>= d)
   int d;
 };
@@ -390,17 +428,20 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int thr_lane = thr_rank - 1;
+  // block id: the pruned sweep hands out its blocks longest-expected-sweep first (block_perm)
+  int blk = blockIdx.x;
+  if constexpr (IVF) blk = iv.block_perm[blockIdx.x];
 
   // A operand: lane l holds query (l&31), dims [half*H, half*H+H), pre-scaled by -2
   float aq[H];
   int64_t qrow;          // image row of this lane's query
   bool qvalid = true;
   if constexpr (IVF) {
-    const int p = iv.qpos[(int64_t)blockIdx.x * C::QB + wave * 32 + l31];
+    const int p = iv.qpos[(int64_t)blk * C::QB + wave * 32 + l31];
     qvalid = p >= 0;
     qrow = qvalid ? p : 0;
   } else {
-    qrow = q_begin + (int64_t)blockIdx.x * C::QB + wave * 32 + l31;
+    qrow = q_begin + (int64_t)blk * C::QB + wave * 32 + l31;
     if (qrow > n_pad - 1) qrow = n_pad - 1;  // padded query slot: results are never read
   }
   {
@@ -521,6 +562,9 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
         return;
       }
     }
+    if constexpr (IVF) {
+      if (iv.debug_no_insert) return;
+    }
     if (hit) insert(acc_prev, athr_prev, row0 + (g - 1) * 32, false);
   };
 
@@ -605,7 +649,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     sweep(0, n_tiles_all, true);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int64_t q = (int64_t)blockIdx.x * C::QB + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int64_t q = (int64_t)blk * C::QB + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       cand_idx[q * C::KP + l31] = idx[r];
       if (l31 == thr_lane) cand_tau[q] = key[r];
     }
@@ -613,7 +657,9 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     // ---- cell order of this block: row a of the per-cell tables (ascending lower bound, own cell first), built once
     // per cell by ivf_cell_order_kernel instead of once per block ----
     float* wmax = smem + 2 * TC * DPL;  // [4]
-    const int a = iv.block_cell[blockIdx.x];
+    const unsigned long long trace_t0 = iv.trace ? wall_clock64() : 0ull;
+    unsigned long long trace_tiles = 0;
+    const int a = iv.block_cell[blk];
     const int* order = iv.order + (int64_t)a * iv.n_cells;
     const float* lb2 = iv.order_lb2 + (int64_t)a * iv.n_cells;
     // exact threshold distance^2 of a query = thr (score space) + ||q||^2; per wave the max over its real queries
@@ -678,12 +724,24 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
       }
       const int b = order[ci];
       if (tid == 0) atomicAdd(iv.pairs, (unsigned long long)iv.cell_ntiles[b] * TC * C::QB);
+      trace_tiles += iv.cell_ntiles[b];
       sweep(iv.cell_tile0[b], iv.cell_ntiles[b], first);
       first = false;
       __syncthreads();  // all fragment reads of this cell are done before the next sweep restages the tiles
     }
+    if (iv.trace && tid == 0) {
+      unsigned int hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      unsigned int xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      unsigned long long* tr = iv.trace + (size_t)blk * 4;
+      tr[0] = trace_t0;
+      tr[1] = wall_clock64();
+      tr[2] = trace_tiles;
+      tr[3] = ((unsigned long long)xcc << 32) | hw;
+    }
     // results go to the ORIGINAL query / row ids
-    const int qbase = (int64_t)blockIdx.x * C::QB + wave * 32;
+    const int qbase = (int64_t)blk * C::QB + wave * 32;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qslot = qbase + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -706,7 +764,8 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
 __global__ __launch_bounds__(256) void ivf_cell_order_kernel(const float* __restrict__ centers, int d,
                                                              const float* __restrict__ radius,
                                                              const int* __restrict__ cell_ntiles, int n_cells,
-                                                             int* __restrict__ order_out, float* __restrict__ lb2_out) {
+                                                             int* __restrict__ order_out, float* __restrict__ lb2_out,
+                                                             int* __restrict__ work_out) {
   extern __shared__ __attribute__((aligned(16))) float co_smem[];
   int npow = 1;
   while (npow < n_cells) npow <<= 1;
@@ -753,6 +812,61 @@ __global__ __launch_bounds__(256) void ivf_cell_order_kernel(const float* __rest
     order_out[(int64_t)a * n_cells + i] = order[i];
     lb2_out[(int64_t)a * n_cells + i] = lb2[i];
   }
+  // expected sweep length of a block of this cell (a ranking, not a bound: only the launch order uses it): the tiles
+  // of the cells whose lower bound is within the cell's own radius -- in a clustered embedding, the cells of the same
+  // cluster.  Neighbour distances are of the order of the radius of a ~2000-row cell in 50 dimensions.
+  __shared__ int s_work;
+  if (tid == 0) s_work = 0;
+  __syncthreads();
+  int wsum = 0;
+  for (int i = tid; i < n_cells; i += 256)
+    if (lb2[i] <= ra * ra) wsum += cell_ntiles[order[i]];
+  atomicAdd(&s_work, wsum);
+  __syncthreads();
+  if (tid == 0) work_out[a] = cell_ntiles[a] > 0 ? s_work : 0;
+}
+
+// Launch order of the pruned sweep: cells by decreasing expected work (ties: cell id), every cell's blocks together.
+// One workgroup; n_cells <= IVF_MAX_CELLS = 1024.  Blocks differ 10x in duration (cluster sizes); in block-id order the
+// last ~12 % of a launch ran with most CUs idle (SCAMD_KNN_TRACE timeline, round 2).
+__global__ __launch_bounds__(1024) void ivf_block_order_kernel(const int* __restrict__ work, const int* __restrict__ blk_off,
+                                                               const int* __restrict__ blk_cnt, int n_cells,
+                                                               int* __restrict__ block_perm) {
+  __shared__ long long key[IVF_MAX_CELLS];
+  __shared__ int start[IVF_MAX_CELLS];
+  const int tid = threadIdx.x;
+  // descending work, ascending cell: key = (~work << 32) | cell, sorted ascending
+  key[tid] = tid < n_cells ? (((long long)(0x7fffffff - work[tid])) << 32) | (unsigned int)tid : 0x7fffffffffffffffll;
+  __syncthreads();
+  for (int kk = 2; kk <= IVF_MAX_CELLS; kk <<= 1) {
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      const int p = tid ^ j;
+      if (p > tid) {
+        const bool up = (tid & kk) == 0;
+        const long long a = key[tid], b = key[p];
+        if ((a > b) == up) {
+          key[tid] = b;
+          key[p] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // exclusive scan of the block counts in sorted order (serial: 1024 entries)
+  if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i < n_cells; ++i) {
+      const int c = (int)(key[i] & 0xffffffffll);
+      start[i] = run;
+      run += blk_cnt[c];
+    }
+  }
+  __syncthreads();
+  if (tid < n_cells) {
+    const int c = (int)(key[tid] & 0xffffffffll);
+    const int o = blk_off[c], cnt = blk_cnt[c], st = start[tid];
+    for (int t = 0; t < cnt; ++t) block_perm[st + t] = o + t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -764,8 +878,8 @@ __device__ inline bool key_less(double da, int ia, double db, int ib) {
 
 template <int KP>
 __global__ __launch_bounds__(256) void knn_rerank_kernel(
-    const float* __restrict__ x, int64_t n, int d, int64_t ld, int64_t q_begin, int64_t n_query,
-    int k, const int* __restrict__ cand_idx, const float* __restrict__ cand_tau,
+    const float* __restrict__ x, const float* __restrict__ mu, int64_t n, int d, int64_t ld, int64_t q_begin,
+    int64_t n_query, int k, const int* __restrict__ cand_idx, const float* __restrict__ cand_tau,
     const unsigned int* __restrict__ cmax_bits, double cert_scale, int32_t* __restrict__ out_idx,
     double* __restrict__ out_dist, double* __restrict__ kth_d2, int* __restrict__ flag_list,
     int* __restrict__ n_flag) {
@@ -783,8 +897,11 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
 
-  double qn = 0.0;
-  for (int c = 0; c < d; ++c) qn += (double)qs[w][c] * (double)qs[w][c];
+  double qn = 0.0;  // ||fl(q - mu)||^2: the norm of the query's image row (the thresholds live in that frame)
+  for (int c = 0; c < d; ++c) {
+    const double qc = (double)__fsub_rn(qs[w][c], mu[c]);
+    qn += qc * qc;
+  }
 
   double myd[PER];
   int myi[PER];
@@ -851,7 +968,9 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
     // |s_float32 - s_exact| <= (2H+2) u (||c||^2 + 2 ||q|| ||c||), u = 2^-24; 2H+2 <= 130.  The register-list kernel
     // keeps a slot number in the 5 low mantissa bits of its keys: the threshold and the keys it was compared with are
     // each off by < 32 ulp = 64 u |score| -> 194.  tau >= 1e38: the list never filled (fewer than thr_rank rows).
-    double eps = cert_scale * 194.0 * 5.9604644775390625e-08 * (cmax + 2.0 * sqrt(qn * cmax));
+    // Centring: the image holds fl(x - mu), each coordinate off by <= u |x - mu|, so a squared distance between image
+    // rows differs from the true one by <= 4 u (qn + cmax) <= 8 u (cmax + 2 ||q|| ||c||) -> 202.
+    double eps = cert_scale * 202.0 * 5.9604644775390625e-08 * (cmax + 2.0 * sqrt(qn * cmax));
     bool certified = (tau >= 1e38f) || ((dk - qn) + eps < tau);
     kth_d2[qi] = dk;
     if (!certified) {
@@ -1028,7 +1147,8 @@ __global__ void ivf_scatter_kernel(const int* __restrict__ labels, int64_t n, co
 
 // image of the cell-sorted rows (layout of knn_pack_image_kernel); padding rows get ||c||^2 = +inf.  Also the
 // cell radii: max distance of a member to its cell's centre (float32, as uint bits for atomicMax).
-__global__ void ivf_pack_image_kernel(const float* __restrict__ x, int d, int64_t ld, int H, int HP, int DPL,
+__global__ void ivf_pack_image_kernel(const float* __restrict__ x, const float* __restrict__ mu, int d, int64_t ld,
+                                      int H, int HP, int DPL,
                                       int64_t n_img, const int* __restrict__ perm, const int* __restrict__ labels,
                                       const int* __restrict__ cell_map, const float* __restrict__ cent,
                                       float* __restrict__ xp, unsigned int* __restrict__ cmax_bits,
@@ -1046,7 +1166,8 @@ __global__ void ivf_pack_image_kernel(const float* __restrict__ x, int d, int64_
       cell = cell_map[labels[src]];
       for (int c = lane; c < d; c += 64) {
         const float v = x[(int64_t)src * ld + c];
-        s += (double)v * (double)v;
+        const float vc = __fsub_rn(v, mu[c]);  // the image row (centred); the cell geometry stays in x's own frame
+        s += (double)vc * (double)vc;
         const float df = v - cent[cell * d + c];
         dc2 = fmaf(df, df, dc2);
       }
@@ -1062,7 +1183,7 @@ __global__ void ivf_pack_image_kernel(const float* __restrict__ x, int d, int64_
       float v = 0.f;
       if (hh < 2) {
         const int dim = hh * H + cc;
-        if (cc < H) v = (src >= 0 && dim < d) ? x[(int64_t)src * ld + dim] : 0.f;
+        if (cc < H) v = (src >= 0 && dim < d) ? __fsub_rn(x[(int64_t)src * ld + dim], mu[dim]) : 0.f;
         else if (cc == H) v = (hh == 0) ? 1.0f : nf;
       }
       xp[r * DPL + c] = v;
@@ -1158,16 +1279,18 @@ static bool knn_plan(int64_t n, int d, int64_t n_query, int k, KnnPlan* p) {
 }
 
 struct KnnBuffers {
-  float* xp; float* cn; unsigned int* cmax; int* cand_idx; float* cand_tau; double* kth_d2;
+  float* xp; float* cn; float* mu; double* mean_partial; unsigned int* cmax; int* cand_idx; float* cand_tau; double* kth_d2;
   int* flag_list; int* counters; double* scratch_d; int* scratch_i; int* fb_counts;
   // cell-pruned search
   int* labels; int* perm; int* qpos; int* block_cell; float* cent; long long* sums; int* cell_ints;
-  unsigned int* radius_bits; int* cell_order; float* cell_lb2;
+  unsigned int* radius_bits; int* cell_order; float* cell_lb2; int* cell_aux; int* block_perm;
 };
 
 static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffers* b) {
   b->xp = ws.take<float>((size_t)p.n_pad * p.row_dwords);
   b->cn = ws.take<float>((size_t)p.n_pad);
+  b->mu = ws.take<float>(128);
+  b->mean_partial = ws.take<double>((size_t)MEAN_BLOCKS * 128);
   b->cmax = ws.take<unsigned int>(4);
   b->cand_idx = ws.take<int>((size_t)p.nq_pad * p.KP);
   b->cand_tau = ws.take<float>((size_t)p.nq_pad);
@@ -1183,6 +1306,7 @@ static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffe
   b->radius_bits = nullptr;
   b->cell_order = nullptr;
   b->cell_lb2 = nullptr;
+  b->cell_aux = b->block_perm = nullptr;
   if (p.ivf) {
     b->labels = ws.take<int>((size_t)p.n_pad);  // sample labels, then labels of all rows
     b->perm = ws.take<int>((size_t)p.n_img_max);
@@ -1194,6 +1318,8 @@ static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffe
     b->radius_bits = ws.take<unsigned int>((size_t)p.n_cells);
     b->cell_order = ws.take<int>((size_t)p.n_cells * p.n_cells);
     b->cell_lb2 = ws.take<float>((size_t)p.n_cells * p.n_cells);
+    b->cell_aux = ws.take<int>((size_t)p.n_cells * 3);  // expected work, first block, block count of every cell
+    b->block_perm = ws.take<int>((size_t)(p.n_slot_max / 128 + 1));
   }
 }
 
@@ -1336,7 +1462,7 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
     mc[tgt] += h_cnt[c];
     mq[tgt] += h_cnt[nc + c];
   }
-  std::vector<int> h_row_off(nc), h_slot_off(nc), h_tile0(nc), h_ntiles(nc), h_block_cell;
+  std::vector<int> h_row_off(nc), h_slot_off(nc), h_tile0(nc), h_ntiles(nc), h_block_cell, h_blk(2 * nc);
   int64_t rows = 0, slots = 0;
   for (int c = 0; c < nc; ++c) {
     h_row_off[c] = (int)rows;
@@ -1345,6 +1471,8 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
     rows += (int64_t)h_ntiles[c] * 64;
     h_slot_off[c] = (int)slots;
     const int nb = (mq[c] + 127) / 128;
+    h_blk[c] = (int)h_block_cell.size();  // first block of the cell
+    h_blk[nc + c] = nb;
     for (int t = 0; t < nb; ++t) h_block_cell.push_back(c);
     slots += (int64_t)nb * 128;
   }
@@ -1357,6 +1485,7 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   SCAMD_HIP_CHECK(hipMemcpyAsync(tile0, h_tile0.data(), sizeof(int) * nc, hipMemcpyHostToDevice, s));
   SCAMD_HIP_CHECK(hipMemcpyAsync(ntiles, h_ntiles.data(), sizeof(int) * nc, hipMemcpyHostToDevice, s));
   SCAMD_HIP_CHECK(hipMemcpyAsync(b.block_cell, h_block_cell.data(), sizeof(int) * n_blocks, hipMemcpyHostToDevice, s));
+  SCAMD_HIP_CHECK(hipMemcpyAsync(b.cell_aux + nc, h_blk.data(), sizeof(int) * 2 * nc, hipMemcpyHostToDevice, s));
   SCAMD_HIP_CHECK(hipMemsetAsync(row_cur, 0, sizeof(int) * nc, s));
   SCAMD_HIP_CHECK(hipMemsetAsync(slot_cur, 0, sizeof(int) * nc, s));
   SCAMD_HIP_CHECK(hipMemsetAsync(b.perm, 0xff, sizeof(int) * rows, s));
@@ -1370,7 +1499,7 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   SCAMD_LAUNCH_CHECK();
   {
     const int blocks = (int)std::min<int64_t>((rows + 3) / 4, 256 * 16);
-    hipLaunchKernelGGL(ivf_pack_image_kernel, dim3(blocks), dim3(256), 0, s, x, d, ld, H, C::HP, C::DPL, rows, b.perm,
+    hipLaunchKernelGGL(ivf_pack_image_kernel, dim3(blocks), dim3(256), 0, s, x, b.mu, d, ld, H, C::HP, C::DPL, rows, b.perm,
                        b.labels, cell_map, b.cent, b.xp, b.cmax, b.radius_bits);
     SCAMD_LAUNCH_CHECK();
   }
@@ -1382,7 +1511,11 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
     SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_cell_order_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)olds));
     hipLaunchKernelGGL(ivf_cell_order_kernel, dim3(nc), dim3(256), olds, s, b.cent, d,
-                       reinterpret_cast<const float*>(b.radius_bits), ntiles, nc, b.cell_order, b.cell_lb2);
+                       reinterpret_cast<const float*>(b.radius_bits), ntiles, nc, b.cell_order, b.cell_lb2, b.cell_aux);
+    SCAMD_LAUNCH_CHECK();
+    // launch order: longest expected sweeps first
+    hipLaunchKernelGGL(ivf_block_order_kernel, dim3(1), dim3(1024), 0, s, b.cell_aux, b.cell_aux + nc, b.cell_aux + 2 * nc,
+                       nc, b.block_perm);
     SCAMD_LAUNCH_CHECK();
   }
   // 6. pruned sweep
@@ -1409,11 +1542,33 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   iv.n_cells = nc;
   iv.dc = d;
   iv.d = d;
+  iv.block_perm = b.block_perm;
+  {
+    const char* e = getenv("SCAMD_KNN_DEBUG_NO_INSERT");
+    iv.debug_no_insert = (e && e[0] == '1') ? 1 : 0;
+  }
+  iv.trace = nullptr;
+  const char* trace_path = getenv("SCAMD_KNN_TRACE");  // debug: per-block timeline of the sweep, dumped to this file
+  if (trace_path && trace_path[0]) {
+    SCAMD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&iv.trace), sizeof(unsigned long long) * 4 * n_blocks));
+    SCAMD_HIP_CHECK(hipMemsetAsync(iv.trace, 0, sizeof(unsigned long long) * 4 * n_blocks, s));
+  }
   SCAMD_HIP_CHECK(hipEventRecord(ev0, s));
   hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(C::NT), lds, s, b.xp, (int)(rows / 64), rows, q_begin, p.thr_rank,
                      b.cand_idx, b.cand_tau, iv);
   SCAMD_LAUNCH_CHECK();
   SCAMD_HIP_CHECK(hipEventRecord(ev1, s));
+  if (iv.trace) {
+    std::vector<unsigned long long> h((size_t)4 * n_blocks);
+    SCAMD_HIP_CHECK(hipMemcpyAsync(h.data(), iv.trace, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, s));
+    SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+    SCAMD_HIP_CHECK(hipFree(iv.trace));
+    if (FILE* f = fopen(trace_path, "wb")) {
+      fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
+      fwrite(h_block_cell.data(), sizeof(int), h_block_cell.size(), f);
+      fclose(f);
+    }
+  }
   return SCAMD_OK;
 }
 
@@ -1469,14 +1624,18 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
 
   SCAMD_HIP_CHECK(hipMemsetAsync(b.cmax, 0, 16, s));
   SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, 16, s));
+  hipLaunchKernelGGL(knn_colsum_kernel, dim3(MEAN_BLOCKS), dim3(256), 0, s, x, n, d, ld_x, b.mean_partial);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(knn_colmean_kernel, dim3(1), dim3(128), 0, s, b.mean_partial, n, d, b.mu);
+  SCAMD_LAUNCH_CHECK();
   if (!p.ivf) {
     int blocks = (int)std::min<int64_t>((p.n_pad + 3) / 4, 256 * 16);
     if (p.reg) {
       const int HP = (p.H + 1 + 3) / 4 * 4;
-      hipLaunchKernelGGL(knn_pack_image_kernel, dim3(blocks), dim3(256), 0, s, x, n, d, ld_x, p.H, HP,
+      hipLaunchKernelGGL(knn_pack_image_kernel, dim3(blocks), dim3(256), 0, s, x, b.mu, n, d, ld_x, p.H, HP,
                          p.row_dwords, p.n_pad, b.xp, b.cmax);
     } else {
-      hipLaunchKernelGGL(knn_pack_kernel, dim3(blocks), dim3(256), 0, s, x, n, d, ld_x, 2 * p.H,
+      hipLaunchKernelGGL(knn_pack_kernel, dim3(blocks), dim3(256), 0, s, x, b.mu, n, d, ld_x, 2 * p.H,
                          p.n_pad, b.xp, b.cn, b.cmax);
     }
     SCAMD_LAUNCH_CHECK();
@@ -1500,7 +1659,7 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
   {
     int blocks = (int)((n_query + 3) / 4);
 #define RERANK(KP_)                                                                              \
-  hipLaunchKernelGGL(knn_rerank_kernel<KP_>, dim3(blocks), dim3(256), 0, s, x, n, d, ld_x, q_begin, \
+  hipLaunchKernelGGL(knn_rerank_kernel<KP_>, dim3(blocks), dim3(256), 0, s, x, b.mu, n, d, ld_x, q_begin, \
                      n_query, k, b.cand_idx, b.cand_tau, b.cmax, cert_scale, out_idx, out_dist,  \
                      b.kth_d2, b.flag_list, b.counters)
     if (p.KP == 32) RERANK(32);

@@ -220,7 +220,17 @@ struct WaveHash {
 // hand every vertex with more than WH_MAX_DEG neighbours to these block-per-vertex kernels (hub list filled
 // through counters[4]) instead of letting ONE wave grind through an O(deg^2) compare while the grid waits.
 constexpr int BHUB_SLOTS = 8192;
-constexpr int BHUB_MAX_DEG = 6000;  // beyond it (table load > 0.73) the all-pairs wave path is used
+constexpr int BHUB_MAX_DEG = 6000;  // longest row one pass of the table takes (load <= 0.73)
+// Longer rows (the coarse levels of a weakly clustered graph are nearly dense: 20k vertices with up to 18k
+// neighbours each) are swept in P = ceil(deg / BHUB_PASS_DEG) passes: pass p only sees the neighbour groups of hash
+// class p, so a pass holds ~deg / P <= 3072 distinct keys.  (Round 1 sent such rows through an all-pairs
+// readlane compare, O(deg^2): 1.6 s for ONE local-moving round of a 26k-vertex level, 43 s per Leiden call on a
+// structure-less 1M-cell graph.)
+constexpr int BHUB_PASS_DEG = 3072;
+__device__ __forceinline__ int bhub_passes(int deg) { return deg <= BHUB_MAX_DEG ? 1 : (deg + BHUB_PASS_DEG - 1) / BHUB_PASS_DEG; }
+__device__ __forceinline__ int bhub_class(int c, int n_pass) {
+  return (int)((hash32((unsigned int)c * 0x9E3779B1u + 0x7F4A7C15u) >> 7) % (unsigned int)n_pass);
+}
 
 struct BlockHash {
   int* keys;
@@ -245,6 +255,20 @@ struct BlockHash {
       slot = (slot + 1) & (nslots - 1);
     }
     atomicAdd(&vals[slot], (unsigned long long)w);
+  }
+  // multi-pass rows: the number of distinct keys of a pass is bounded only in expectation -> bounded probing;
+  // false = table full (the caller raises the error flag, the host turns it into SCAMD_EINTERNAL)
+  __device__ __forceinline__ bool add_bounded(int c, long long w) {
+    unsigned int slot = hash32((unsigned int)c) & (nslots - 1);
+    for (int probes = 0; probes < nslots; ++probes) {
+      const int prev = atomicCAS(&keys[slot], WH_EMPTY, c);
+      if (prev == WH_EMPTY || prev == c) {
+        atomicAdd(&vals[slot], (unsigned long long)w);
+        return true;
+      }
+      slot = (slot + 1) & (nslots - 1);
+    }
+    return false;
   }
 };
 
@@ -307,7 +331,7 @@ __global__ __launch_bounds__(256) void ld_move_kernel(
         if (sub == 0) ovf_list[atomicAdd(&counters[5], 1)] = w;
         continue;
       }
-    } else if (deg > WH_MAX_DEG && deg <= BHUB_MAX_DEG) {  // hub: decided by ld_move_hub_kernel
+    } else if (deg > WH_MAX_DEG) {  // hub: decided by ld_move_hub_kernel (any length: multi-pass table)
       if (sub == 0) hub_list[atomicAdd(&counters[4], 1)] = w;
       continue;
     }
@@ -423,7 +447,7 @@ __global__ __launch_bounds__(256) void ld_move_kernel(
 
 // Hub vertices of the active list (positions in hub_list[0 .. counters[4])): one workgroup each.
 __global__ __launch_bounds__(256) void ld_move_hub_kernel(
-    const int* __restrict__ hub_list, const int* __restrict__ counters, const int* __restrict__ list,
+    const int* __restrict__ hub_list, int* __restrict__ counters, const int* __restrict__ list,
     const int64_t* __restrict__ indptr, const int* __restrict__ indices, const long long* __restrict__ wq,
     const long long* __restrict__ k, const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot,
     const int* __restrict__ csize, double g, int round, unsigned int seed, int* __restrict__ decision) {
@@ -440,33 +464,40 @@ __global__ __launch_bounds__(256) void ld_move_hub_kernel(
     const int64_t beg = indptr[v];
     const int deg = (int)(indptr[v + 1] - beg);
     const double Ka_wo = (double)(long long)(Ktot[a] - (unsigned long long)k[v]);
-    bh.size_for(deg);
-    bh.clear();
-    __syncthreads();
-    for (int e = threadIdx.x; e < deg; e += blockDim.x) {
-      const int u = indices[beg + e];
-      if (u != v) bh.add(comm[u], wq[beg + e]);
-    }
-    __syncthreads();
+    const int n_pass = bhub_passes(deg);
+    bh.size_for(n_pass > 1 ? BHUB_SLOTS : deg);
     Cand best;
     best.val = 0.0;
     best.c = -1;
     best.pr = 0;
     long long w_own = 0;
-    for (int sl = threadIdx.x; sl < bh.nslots; sl += blockDim.x) {
-      const int c = bh.keys[sl];
-      if (c != WH_EMPTY) {
-        const long long sum = (long long)bh.vals[sl];
-        if (c == a) {
-          w_own = sum;
-        } else {
-          Cand x;
-          x.val = (double)sum - g * kv * (double)(long long)Ktot[c];
-          x.c = c;
-          x.pr = prio(c, seed);
-          if (cand_better(x, best)) best = x;
+    for (int pass = 0; pass < n_pass; ++pass) {
+      bh.clear();
+      __syncthreads();
+      for (int e = threadIdx.x; e < deg; e += blockDim.x) {
+        const int u = indices[beg + e];
+        if (u == v) continue;
+        const int c = comm[u];
+        if (n_pass == 1) bh.add(c, wq[beg + e]);
+        else if (bhub_class(c, n_pass) == pass && !bh.add_bounded(c, wq[beg + e])) counters[7] = 1;
+      }
+      __syncthreads();
+      for (int sl = threadIdx.x; sl < bh.nslots; sl += blockDim.x) {
+        const int c = bh.keys[sl];
+        if (c != WH_EMPTY) {
+          const long long sum = (long long)bh.vals[sl];
+          if (c == a) {
+            w_own = sum;
+          } else {
+            Cand x;
+            x.val = (double)sum - g * kv * (double)(long long)Ktot[c];
+            x.c = c;
+            x.pr = prio(c, seed);
+            if (cand_better(x, best)) best = x;
+          }
         }
       }
+      __syncthreads();  // the scan of this pass is done before the next pass clears the table
     }
     best = block_best(best, w_own, sh_c, sh_w);
     if (threadIdx.x == 0) {
@@ -627,6 +658,20 @@ __device__ __forceinline__ bool mover_bit(int v, int round, unsigned int seed) {
   return (hash32((unsigned int)v * 0x9E3779B1u + (unsigned int)round * 0x85EBCA77u + seed) >> 7) & 1u;
 }
 
+// Randomised merge rule of the refinement (Traag et al. 2019, leidenalg's `refine_consider_comms` with theta = beta):
+// v joins r with probability ~ exp(gain(v, r) / beta) among the well-connected candidates of non-negative gain, "stay"
+// (gain 0) included.  Sampled with the Gumbel-max trick: argmax_r gain_r / beta + G(v, r, round, seed) with
+// counter-based noise, so the choice is a pure function of its arguments -- every kernel variant draws the same
+// target, runs are bitwise reproducible.  (Round 1 took the beta -> 0 limit; on graphs without clean structure the
+// greedy rule ends in visibly worse optima: 0.8101 vs 0.8121 on the bundled fixture, the same value the CPU oracle
+// reaches when its beta is set to 1e-7.)  c = v encodes "stay".
+__device__ __forceinline__ double refine_noise(int v, int c, int round, unsigned int seed) {
+  const unsigned int h = hash32((unsigned int)v * 0x9E3779B1u ^
+                                hash32((unsigned int)c * 0x85EBCA77u + (unsigned int)round * 0xC2B2AE3Du + seed));
+  const double u = ((double)h + 0.5) * (1.0 / 4294967296.0);
+  return -log(-log(u));
+}
+
 // G lanes per candidate (see ld_move_kernel: G = 16 puts four candidates in a wave on short-rowed levels, rows longer
 // than the 128-slot table go to ovf_list / counters[5] and are proposed by the G = 64 instantiation in indirect mode).
 // target[v] = refined community to join, -1 = none this round (stay a candidate), -2 = no longer a singleton
@@ -637,7 +682,8 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
     const int64_t* __restrict__ indptr, const int* __restrict__ indices, const long long* __restrict__ wq,
     const long long* __restrict__ k, const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot,
     const int* __restrict__ ref, const int* __restrict__ refsize, const unsigned long long* __restrict__ Kref,
-    const unsigned long long* __restrict__ Eref, double g, int round, unsigned int seed, int* __restrict__ target,
+    const unsigned long long* __restrict__ Eref, double g, double inv_beta /* 1 / (beta * 2^32); 0 = greedy */,
+    int round, unsigned int seed, int* __restrict__ target,
     int* __restrict__ ovf_list, int* __restrict__ hub_list, int* __restrict__ counters,
     const int* __restrict__ n_cand_dev, const int* __restrict__ stop) {
   constexpr int GROUPS = 256 / G;
@@ -667,7 +713,7 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
           if (sub == 0) ovf_list[atomicAdd(&counters[5], 1)] = w;
           continue;
         }
-      } else if (deg > WH_MAX_DEG && deg <= BHUB_MAX_DEG) {  // hub: proposed by ld_refine_propose_hub_kernel
+      } else if (deg > WH_MAX_DEG) {  // hub: proposed by ld_refine_propose_hub_kernel (any length)
         if (sub == 0) hub_list[atomicAdd(&counters[4], 1)] = v;
         continue;
       }
@@ -707,7 +753,7 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
             const double gain = (double)sum - g * kv * Kr;
             if (ok_target && gain >= 0.0) {
               Cand x;
-              x.val = gain;
+              x.val = inv_beta > 0.0 ? gain * inv_beta + refine_noise(v, c, round, seed) : gain;
               x.c = c;
               x.pr = prio(c, seed);
               if (cand_better(x, best)) best = x;
@@ -764,6 +810,8 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
         if (cand_better(y, best)) best = y;
       }
       tgt = best.c;
+      // "stay" drawn against the best candidate: a singleton that stays is done (it may still be joined)
+      if (inv_beta > 0.0 && tgt >= 0 && !(best.val > refine_noise(v, v, round, seed))) tgt = -2;
     }
     if (sub == 0) target[v] = tgt;
   }
@@ -771,11 +819,12 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
 
 // Hub candidates (vertex ids in hub_list[0 .. counters[4])): one workgroup each; same rule as the wave kernel.
 __global__ __launch_bounds__(256) void ld_refine_propose_hub_kernel(
-    const int* __restrict__ hub_list, const int* __restrict__ counters, const int64_t* __restrict__ indptr,
+    const int* __restrict__ hub_list, int* __restrict__ counters, const int64_t* __restrict__ indptr,
     const int* __restrict__ indices, const long long* __restrict__ wq, const long long* __restrict__ k,
     const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot, const int* __restrict__ ref,
     const int* __restrict__ refsize, const unsigned long long* __restrict__ Kref,
-    const unsigned long long* __restrict__ Eref, double g, int round, unsigned int seed, int* __restrict__ target) {
+    const unsigned long long* __restrict__ Eref, double g, double inv_beta, int round, unsigned int seed,
+    int* __restrict__ target) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long hub_smem[];
   BlockHash bh{reinterpret_cast<int*>(hub_smem + BHUB_SLOTS), hub_smem, BHUB_SLOTS};
   __shared__ Cand sh_c[4];
@@ -788,39 +837,47 @@ __global__ __launch_bounds__(256) void ld_refine_propose_hub_kernel(
     const double KC = (double)(long long)Ktot[a];
     const int64_t beg = indptr[v];
     const int deg = (int)(indptr[v + 1] - beg);
-    bh.size_for(deg);
-    bh.clear();
-    __syncthreads();
-    for (int e = threadIdx.x; e < deg; e += blockDim.x) {
-      const int u = indices[beg + e];
-      if (u != v && comm[u] == a) bh.add(ref[u], wq[beg + e]);
-    }
-    __syncthreads();
+    const int n_pass = bhub_passes(deg);
+    bh.size_for(n_pass > 1 ? BHUB_SLOTS : deg);
     Cand best;
     best.val = 0.0;
     best.c = -1;
     best.pr = 0;
     long long dummy = 0;
-    for (int sl = threadIdx.x; sl < bh.nslots; sl += blockDim.x) {
-      const int c = bh.keys[sl];
-      if (c != WH_EMPTY && c != v) {
-        const long long sum = (long long)bh.vals[sl];
-        const double Kr = (double)(long long)Kref[c];
-        const bool single = refsize[c] == 1;
-        const bool ok_target = (!single || !mover_bit(c, round, seed)) &&
-                               ((double)(long long)Eref[c] >= g * Kr * (KC - Kr));
-        const double gain = (double)sum - g * kv * Kr;
-        if (ok_target && gain >= 0.0) {
-          Cand x;
-          x.val = gain;
-          x.c = c;
-          x.pr = prio(c, seed);
-          if (cand_better(x, best)) best = x;
+    for (int pass = 0; pass < n_pass; ++pass) {
+      bh.clear();
+      __syncthreads();
+      for (int e = threadIdx.x; e < deg; e += blockDim.x) {
+        const int u = indices[beg + e];
+        if (u == v || comm[u] != a) continue;
+        const int c = ref[u];
+        if (n_pass == 1) bh.add(c, wq[beg + e]);
+        else if (bhub_class(c, n_pass) == pass && !bh.add_bounded(c, wq[beg + e])) counters[7] = 1;
+      }
+      __syncthreads();
+      for (int sl = threadIdx.x; sl < bh.nslots; sl += blockDim.x) {
+        const int c = bh.keys[sl];
+        if (c != WH_EMPTY && c != v) {
+          const long long sum = (long long)bh.vals[sl];
+          const double Kr = (double)(long long)Kref[c];
+          const bool single = refsize[c] == 1;
+          const bool ok_target = (!single || !mover_bit(c, round, seed)) &&
+                                 ((double)(long long)Eref[c] >= g * Kr * (KC - Kr));
+          const double gain = (double)sum - g * kv * Kr;
+          if (ok_target && gain >= 0.0) {
+            Cand x;
+            x.val = inv_beta > 0.0 ? gain * inv_beta + refine_noise(v, c, round, seed) : gain;
+            x.c = c;
+            x.pr = prio(c, seed);
+            if (cand_better(x, best)) best = x;
+          }
         }
       }
+      __syncthreads();
     }
     best = block_best(best, dummy, sh_c, sh_w);
-    if (threadIdx.x == 0) target[v] = best.c;
+    if (threadIdx.x == 0)
+      target[v] = (inv_beta > 0.0 && best.c >= 0 && !(best.val > refine_noise(v, v, round, seed))) ? -2 : best.c;
     __syncthreads();
   }
 }
@@ -1320,6 +1377,8 @@ struct LeidenCtx {
   LeidenBuffers b;
   double gamma;
   double m2;  // total (quantised) weight = sum of strengths
+  double inv_beta = 0.0;  // 1 / (beta * 2^32): randomness of the refinement's merge rule (0 = greedy)
+  int iter = 0;           // outer iteration: part of the refinement's noise seed
   unsigned int seed;
   int lm_stop_permille = 10;  // local moving of a level stops once < 1 % of its vertices move in a round
   int rf_stop_ppm = 500;      // refinement stops once a round merges < 0.05 % of the level's vertices
@@ -1439,9 +1498,10 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
     hipLaunchKernelGGL(ld_compact_kernel, dim3((unsigned)ceil_div(g.n, 1024)), dim3(1024), 0, cx.s, g.n, b.flag,
                        b.list_b, b.counters);
     SCAMD_LAUNCH_CHECK();
-    int h[3];
-    rc = read_counters(cx, h, 3);
+    int h[8];
+    rc = read_counters(cx, h, 8);
     if (rc != SCAMD_OK) return rc;
+    SCAMD_REQUIRE(h[7] == 0, SCAMD_EINTERNAL, "leiden: hub table overflow (local moving)");
     if (leiden_debug()) fprintf(stderr, "[leiden] lm n=%d round=%d act=%d moved=%d blocked=%d next=%d\n", g.n, round, n_act, h[0], h[1], h[2]);
     std::swap(b.list_a, b.list_b);
     n_act = h[2];
@@ -1452,7 +1512,8 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
     // Vertex-by-vertex merging of whole communities is what the coarser levels are for: once fewer than
     // lm_stop_permille/1000 of the level's vertices move in a round, go on to refinement + aggregation (the
     // outer iterations repeat until nothing improves, so no move is lost, it is only made at a cheaper level).
-    if (round >= 1 && (long long)h[0] * 1000 < (long long)g.n * cx.lm_stop_permille) break;
+    // (first outer iteration only: the later ones polish, and a level of theirs moves few vertices anyway)
+    if (cx.iter == 0 && round >= 1 && (long long)h[0] * 1000 < (long long)g.n * cx.lm_stop_permille) break;
   }
   return SCAMD_OK;
 }
@@ -1460,6 +1521,7 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
 static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
   LeidenBuffers& b = cx.b;
   const double gg = cx.gamma / cx.m2;
+  const unsigned int rseed = cx.seed + 0x9E3779B9u * (unsigned int)cx.iter;  // fresh merge noise every outer iteration
   const size_t n = (size_t)g.n;
   if (level_is_short_rowed(g))
     hipLaunchKernelGGL(ld_within_kernel<16>, dim3((unsigned)ceil_div(g.n, 16)), dim3(256), 0, cx.s, g.n, g.indptr,
@@ -1500,25 +1562,25 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
       if (quad) {
         hipLaunchKernelGGL(ld_refine_propose_kernel<16>, dim3(qgrid), dim3(256), 0, cx.s, b.list_a, (const int*)nullptr,
                            (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref,
-                           b.Eref, gg, round, cx.seed, b.target, b.mid_list, b.hub_list, rcnt, n_in, (const int*)ctl);
+                           b.Eref, gg, cx.inv_beta, round, rseed, b.target, b.mid_list, b.hub_list, rcnt, n_in, (const int*)ctl);
         SCAMD_LAUNCH_CHECK();
         if (g.max_deg > QUAD_MAX_DEG) {
           hipLaunchKernelGGL(ld_refine_propose_kernel<64>, dim3(std::min(wgrid, 2048u)), dim3(256), 0, cx.s, b.list_a,
                              (const int*)b.mid_list, (const int*)(rcnt + 5), g.indptr, g.indices, g.wq, g.k, b.comm,
-                             b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, gg, round, cx.seed, b.target, b.mid_list,
+                             b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, gg, cx.inv_beta, round, rseed, b.target, b.mid_list,
                              b.hub_list, rcnt, n_in, (const int*)ctl);
           SCAMD_LAUNCH_CHECK();
         }
       } else {
         hipLaunchKernelGGL(ld_refine_propose_kernel<64>, dim3(wgrid), dim3(256), 0, cx.s, b.list_a, (const int*)nullptr,
                            (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref,
-                           b.Eref, gg, round, cx.seed, b.target, b.mid_list, b.hub_list, rcnt, n_in, (const int*)ctl);
+                           b.Eref, gg, cx.inv_beta, round, rseed, b.target, b.mid_list, b.hub_list, rcnt, n_in, (const int*)ctl);
         SCAMD_LAUNCH_CHECK();
       }
       if (g.max_deg > WH_MAX_DEG) {
         hipLaunchKernelGGL(ld_refine_propose_hub_kernel, dim3(HUB_GRID), dim3(256), HUB_LDS, cx.s, b.hub_list, rcnt,
-                           g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, gg, round,
-                           cx.seed, b.target);
+                           g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, gg,
+                           cx.inv_beta, round, rseed, b.target);
         SCAMD_LAUNCH_CHECK();
       }
       hipLaunchKernelGGL(ld_refine_apply_kernel, dim3(tgrid), dim3(256), 0, cx.s, ub, b.list_a, b.target, g.k, b.ref,
@@ -1546,6 +1608,8 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
     if (leiden_debug())
       for (int i = 0; i < batch && first + i < hctl[2]; ++i)
         fprintf(stderr, "[leiden] rf n=%d round=%d cand=%d merges=%d\n", g.n, first + i, hr[8 * i + 2], hr[8 * i]);
+    for (int i = 0; i < batch; ++i)
+      SCAMD_REQUIRE(hr[8 * i + 7] == 0, SCAMD_EINTERNAL, "leiden: hub table overflow (refinement)");
     if (hctl[0]) break;
     ub = hr[8 * (batch - 1) + 2];
   }
@@ -1749,7 +1813,6 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
                                     int64_t nnz, double resolution, int n_iterations, double beta, uint64_t seed,
                                     int32_t* membership, double* modularity_host, int32_t* n_communities_host,
                                     void* workspace, size_t workspace_bytes, scamd_stream_t stream) {
-  (void)beta;  // the refinement takes the beta -> 0 (greedy) limit of the randomised merge rule
   SCAMD_REQUIRE(indptr && membership && (nnz == 0 || (indices && weights)), SCAMD_EINVAL, "leiden: null pointer");
   SCAMD_REQUIRE(n >= 1 && n < ((int64_t)1 << 31) && nnz >= 0, SCAMD_EINVAL, "leiden: bad shape n=%lld nnz=%lld",
                 (long long)n, (long long)nnz);
@@ -1761,6 +1824,7 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
   LeidenCtx cx;
   cx.s = stream;
   cx.gamma = resolution;
+  cx.inv_beta = beta > 0.0 ? 1.0 / (beta * WSCALE) : 0.0;  // beta <= 0: the greedy limit (largest gain, no "stay")
   cx.seed = (unsigned int)(seed ^ (seed >> 32)) * 0x9E3779B1u + 0x632BE5ABu;
   if (const char* e = getenv("SCAMD_LEIDEN_LM_STOP_PERMILLE")) cx.lm_stop_permille = atoi(e);
   if (const char* e = getenv("SCAMD_LEIDEN_RF_STOP_PPM")) cx.rf_stop_ppm = atoi(e);
@@ -1790,7 +1854,9 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
     if (rc != SCAMD_OK) return rc;
     SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb_best, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
     const int max_iter = n_iterations < 0 ? MAX_OUTER_ITERS : n_iterations;
+    int bad_iters = 0;
     for (int it = 0; it < max_iter; ++it) {
+      cx.iter = it;
       rc = leiden_iteration(cx, g0);
       if (rc != SCAMD_OK) return rc;
       double q = 0.0;
@@ -1798,15 +1864,24 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
       if (rc == SCAMD_OK) rc = quality(cx, g0, b.memb, &q);
       if (rc != SCAMD_OK) return rc;
       const bool improved = q > q_best + 1e-12;
+      const bool worse = q < q_best - 1e-12;
       if (leiden_debug()) fprintf(stderr, "[leiden] iteration %d: Q = %.10f (best before %.10f)\n", it, q, q_best);
       if (improved) {
         q_best = q;
+        bad_iters = 0;
         SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb_best, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
       } else {
-        // synchronous moves are not monotone: keep the best partition seen
+        // synchronous moves and the randomised refinement are not monotone: keep the best partition seen
         SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb, b.memb_best, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
       }
-      if (n_iterations < 0 && !improved) break;
+      // n_iterations < 0: until an iteration changes nothing (leidenalg: `while diff_inc > 0`).  An iteration that
+      // reproduces the best quality exactly found nothing to move -> done.  One that came out WORSE was unlucky in its
+      // random merges (the next one draws different noise, cx.iter is part of the noise seed): two of those in a row end
+      // the run as well -- without this patience a single unlucky iteration right after the first one froze the
+      // result of ONE iteration (Q 0.8028 instead of 0.812 on the 700-cell fixture).
+      if (n_iterations < 0 && !improved) {
+        if (!worse || ++bad_iters >= 2) break;
+      }
     }
   }
   int nc = 0;
