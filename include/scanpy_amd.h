@@ -153,6 +153,40 @@ size_t scamd_csr_gram_workspace_bytes(int64_t n, int64_t g);
 int scamd_csr_gram_f32(const int64_t* indptr, const int32_t* indices, const float* data, int64_t n, int64_t g,
                        int64_t nnz, int scale_bits, int64_t* gram, int64_t ld_gram, int64_t* colsum,
                        float* absmax_host, void* workspace, size_t workspace_bytes, scamd_stream_t stream);
+/* Top-k eigenpairs of a symmetric POSITIVE SEMI-DEFINITE float64 matrix a [g x g] (leading dimension lda), the dense half
+ * of the Gram-route PCA: what sklearn's PCA(svd_solver='arpack') obtains from ARPACK on the implicitly centred matrix
+ * (sklearn/decomposition/_pca.py:704-793, called at src/scanpy/preprocessing/_pca/__init__.py:287-308) and the reference's
+ * covariance route from `eigh` (src/scanpy/preprocessing/_pca/_dask.py:28-132).  Chebyshev-filtered subspace iteration on a
+ * block of <= 128 vectors; hand-written float64 MFMA GEMMs, CholeskyQR2, one-workgroup Jacobi (csrc/dense.hip).
+ *   lam [k] descending; v [g x k] row-major, column j = unit eigenvector j (sign unspecified)
+ *   tol: Ritz residual |A v - lam v| / lam_0 of the k pairs (2e-8 reproduces ARPACK-level loadings)
+ *   info_host (optional, 6 ints): outer iterations, operator applications, block size, Cholesky retries, then the final
+ *             residual as a float64 in [4..5]
+ * Supported: g <= 128 (full decomposition) or g >= 256 with k <= 96; SCAMD_EUNSUPPORTED otherwise or when the block turns
+ * out numerically rank deficient / the iteration does not converge (callers then use a full eigendecomposition). */
+size_t scamd_eigh_topk_workspace_bytes(int64_t g, int k);
+int scamd_eigh_topk_f64(const double* a, int64_t g, int64_t lda, int k, uint64_t seed, double tol, double* lam, double* v,
+                        int32_t* info_host, void* workspace, size_t workspace_bytes, scamd_stream_t stream);
+/* Building blocks of the above on caller buffers (tests): op 1: out0[m x n] = in0^T in1 with in0 [kdim x m], in1 [kdim x n];
+ * op 2: out0[m x m] = CholeskyQR factor S of the Gram matrix in0 [m x m] (Z S orthonormal when in0 = Z^T Z), *flag_host =
+ * 1 on a non-positive pivot; op 3: out0[m] = eigenvalues (descending), out1[m x m] = eigenvectors (columns) of the
+ * symmetric PSD in0 [m x m], *flag_host = Jacobi sweeps.  m <= 128 for ops 2 and 3. */
+int scamd_dense_debug_f64(int op, const double* in0, const double* in1, int m, int n, int kdim, double* out0, double* out1,
+                          int32_t* flag_host, scamd_stream_t stream);
+/* sc.pp.pca(svd_solver='arpack' accuracy) on a resident CSR float32 matrix in ONE call (the `pca_csr_f32` entry of the
+ * boundary: src/scanpy/preprocessing/_pca/__init__.py:53-384 without its AnnData handling): max|x| -> exact fixed-point
+ * Gram matrix -> top-n_comps eigenpairs -> sklearn's sign convention (svd_flip, u_based_decision=False) -> scores.
+ *   scores [n x n_comps] float32 = X V - 1 (mu^T V) (zero_center) or X V
+ *   components [n_comps x g] float64 (rows = components_), variance / variance_ratio [n_comps] (explained_variance_,
+ *   explained_variance_ratio_ of sklearn PCA, or of TruncatedSVD when zero_center = 0), mean [g] float64
+ *   info_host (optional, 8 ints): as scamd_eigh_topk_f64, then [6] = scale_bits of the fixed-point Gram matrix
+ * Single device, g <= 8192, n_comps <= 96; a row-sharded run all-reduces the int64 Gram matrix between
+ * scamd_csr_gram_f32 and scamd_eigh_topk_f64 instead. */
+size_t scamd_pca_csr_workspace_bytes(int64_t n, int64_t g, int n_comps);
+int scamd_pca_csr_f32(const int64_t* indptr, const int32_t* indices, const float* data, int64_t n, int64_t g, int64_t nnz,
+                      int n_comps, int zero_center, uint64_t seed, double tol, float* scores, double* components,
+                      double* variance, double* variance_ratio, double* mean, int32_t* info_host, void* workspace,
+                      size_t workspace_bytes, scamd_stream_t stream);
 /* colsum[l] (float64) = 1^T Y for Y [n, l] float32, fixed summation order. */
 size_t scamd_colsum_workspace_bytes(int l);
 int scamd_colsum_f32_f64(const float* y, int64_t n, int l, double* colsum,

@@ -19,7 +19,7 @@ LIBDIR = PKG / "_lib"
 LIBNAME = "libscanpy_amd.so"
 ARCH = "gfx950"
 
-SOURCES = ["capi.cpp", "hostio.cpp", "knn.hip", "fuzzy.hip", "pca.hip", "gram.hip", "leiden.hip", "preprocess.hip", "umap.hip"]
+SOURCES = ["capi.cpp", "hostio.cpp", "knn.hip", "fuzzy.hip", "pca.hip", "gram.hip", "dense.hip", "leiden.hip", "preprocess.hip", "umap.hip"]
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-pass-failed",
             "-ffp-contract=off"]
 

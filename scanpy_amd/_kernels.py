@@ -173,6 +173,73 @@ def spmm_f64acc(indptr, indices, data, n_rows: int, b: torch.Tensor, scale: torc
     return w
 
 
+def dense_debug(op: int, in0: torch.Tensor, in1: torch.Tensor | None = None):
+    """building blocks of the dense eigensolver on caller buffers (csrc/dense.hip; tests).  op 1: in0^T in1;
+    op 2: CholeskyQR factor of a Gram matrix -> (S, pivot_failed); op 3: Jacobi eigh -> (theta, Y, sweeps)."""
+    dev = require_gpu()
+    lib = _lib.load()
+    in0 = in0.to(torch.float64).contiguous()
+    flag = C.c_int(0)
+    if op == 1:
+        in1 = in1.to(torch.float64).contiguous()
+        kdim, m = in0.shape
+        n = in1.shape[1]
+        out = torch.empty((m, n), dtype=torch.float64, device=dev)
+        rc = lib.scamd_dense_debug_f64(1, ptr(in0), ptr(in1), m, n, kdim, ptr(out), None, C.byref(flag), stream_ptr())
+        _lib.check(rc, "scamd_dense_debug_f64")
+        return out
+    m = in0.shape[0]
+    out0 = torch.empty((m, m) if op == 2 else (m,), dtype=torch.float64, device=dev)
+    out1 = torch.empty((m, m), dtype=torch.float64, device=dev)
+    rc = lib.scamd_dense_debug_f64(op, ptr(in0), None, m, m, m, ptr(out0), ptr(out1), C.byref(flag), stream_ptr())
+    _lib.check(rc, "scamd_dense_debug_f64")
+    return (out0, int(flag.value)) if op == 2 else (out0, out1, int(flag.value))
+
+
+def eigh_topk(a: torch.Tensor, k: int, *, seed: int = 0, tol: float = 2e-8):
+    """Top-k eigenpairs of the symmetric PSD float64 matrix a [g, g] -> (lam [k] descending, v [g, k], info dict).
+    Raises ScamdError (SCAMD_EUNSUPPORTED) outside the device solver's range or when it does not converge."""
+    dev = require_gpu()
+    lib = _lib.load()
+    assert a.dtype == torch.float64 and a.dim() == 2 and a.shape[0] == a.shape[1] and a.is_cuda
+    a = a.contiguous()
+    g = a.shape[0]
+    lam = torch.empty(k, dtype=torch.float64, device=dev)
+    v = torch.empty((g, k), dtype=torch.float64, device=dev)
+    info = (C.c_int32 * 8)()
+    need = lib.scamd_eigh_topk_workspace_bytes(g, k)
+    ws, wsz = _ws(need, dev)
+    rc = lib.scamd_eigh_topk_f64(ptr(a), g, a.stride(0), k, int(seed) & (2**64 - 1), float(tol), ptr(lam), ptr(v), info,
+                                 ptr(ws), wsz, stream_ptr())
+    _lib.check(rc, "scamd_eigh_topk_f64")
+    resid = C.cast(C.byref(info, 16), C.POINTER(C.c_double))[0]
+    return lam, v, {"n_outer": info[0], "n_gemm": info[1], "block_size": info[2], "chol_retries": info[3], "residual": resid}
+
+
+def pca_csr(indptr, indices, data, n: int, g: int, n_comps: int, *, zero_center: bool = True, seed: int = 0,
+            tol: float = 2e-8):
+    """`scamd_pca_csr_f32`: the whole Gram-route PCA of a resident CSR matrix in one C call.
+    -> (scores f32 [n, k], components f64 [k, g], variance [k], variance_ratio [k], mean [g], info dict)"""
+    dev = require_gpu()
+    lib = _lib.load()
+    k = int(n_comps)
+    scores = torch.empty((n, k), dtype=torch.float32, device=dev)
+    comps = torch.empty((k, g), dtype=torch.float64, device=dev)
+    var = torch.empty(k, dtype=torch.float64, device=dev)
+    ratio = torch.empty(k, dtype=torch.float64, device=dev)
+    mean = torch.empty(g, dtype=torch.float64, device=dev)
+    info = (C.c_int32 * 8)()
+    need = lib.scamd_pca_csr_workspace_bytes(n, g, k)
+    ws, wsz = _ws(need, dev)
+    rc = lib.scamd_pca_csr_f32(ptr(indptr), ptr(indices), ptr(data), n, g, data.numel(), k, 1 if zero_center else 0,
+                               int(seed) & (2**64 - 1), float(tol), ptr(scores), ptr(comps), ptr(var), ptr(ratio), ptr(mean),
+                               info, ptr(ws), wsz, stream_ptr())
+    _lib.check(rc, "scamd_pca_csr_f32")
+    resid = C.cast(C.byref(info, 16), C.POINTER(C.c_double))[0]
+    return scores, comps, var, ratio, mean, {"n_outer": info[0], "n_gemm": info[1], "block_size": info[2],
+                                             "chol_retries": info[3], "residual": resid, "scale_bits": info[6]}
+
+
 def colsum(y: torch.Tensor) -> torch.Tensor:
     dev = require_gpu()
     lib = _lib.load()

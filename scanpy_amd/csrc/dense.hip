@@ -1,0 +1,975 @@
+// Dense float64 side of the PCA: top-k eigenpairs of the g x g covariance-like matrix A = X^T X - n mu mu^T.
+//
+// Replaces, for the Gram route of sc.pp.pca, what sklearn's PCA(svd_solver='arpack') gets from ARPACK
+// (sklearn/decomposition/_pca.py:704-793 as called at src/scanpy/preprocessing/_pca/__init__.py:287-308) and what the
+// reference's own covariance route gets from `eigh` (src/scanpy/preprocessing/_pca/_dask.py:28-132): round 1 ran this
+// part through torch.linalg (rocBLAS GEMMs + ~100 small rocSOLVER kernels, ~10 ms at g = 2000, 6 of them in six
+// 128 x 128 `eigh` calls).  Here every piece is a hand-written gfx950 kernel:
+//   * tall-skinny GEMMs (g x g x 128, 128 x 128 x g) on the float64 matrix cores, v_mfma_f64_16x16x4_f64: one kernel,
+//     C = alpha P^T Q + beta1 D1 + beta2 D2 with P, Q stored k-major, so that both operand fragments are 128-byte
+//     coalesced rows (A is symmetric: A Z = A^T Z); 32 x 32 output tile per workgroup, the K range split over its four
+//     waves and reduced through LDS in a fixed order (bitwise reproducible);
+//   * CholeskyQR of a g x 128 block = Gram matrix (same GEMM) + one-workgroup 128 x 128 Cholesky / triangular inverse in
+//     LDS + a panel-times-small product; twice (CholeskyQR2), shifted on a failed pivot;
+//   * the 128 x 128 Rayleigh-Ritz eigenproblem by one-sided (Hestenes) Jacobi in ONE workgroup, matrix resident in LDS
+//     (133 KB of the 160): 64 disjoint column pairs per step, 16 lanes per pair, round-robin ordering;
+//   * Chebyshev-filtered subspace iteration (Zhou & Saad) around them: the filter steps are the GEMM with the
+//     three-term recurrence in its epilogue.
+// Algorithmic work at g = 2000, b = 128: 2 g^2 b = 1.0e9 flop per operator application (~13 us at the 78.6 TFLOP/s
+// float64 matrix peak), ~11-26 applications; everything else is O(g b^2) or O(b^3).
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+namespace scamd {
+
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+constexpr int DB_MAX = 128;      // largest block size / Jacobi dimension
+constexpr int DB_LD = DB_MAX + 2;  // LDS column stride (doubles): 1040 B, not a multiple of the 256-B bank period
+
+__device__ __forceinline__ unsigned int dhash32(unsigned int x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+
+// Cross-lane float64 through DPP (one VALU move per dword, no LDS crossbar round trip as with ds_bpermute):
+// CTRL = DPP control word: 0x120 + n = row_ror:n (rotate within a row of 16 lanes), 0xB1 = quad_perm [1,0,3,2],
+// 0x4E = quad_perm [2,3,0,1], 0x141 = row_half_mirror (lane i <-> 7 - i within 8).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// sum over the 16 lanes of a DPP row, result in every lane
+__device__ __forceinline__ double row16_sum(double x) {
+  x += dpp_f64<0x128>(x);
+  x += dpp_f64<0x124>(x);
+  x += dpp_f64<0x122>(x);
+  x += dpp_f64<0x121>(x);
+  return x;
+}
+// sum over aligned groups of 8 lanes, result in every lane
+__device__ __forceinline__ double oct_sum(double x) {
+  x += dpp_f64<0xB1>(x);
+  x += dpp_f64<0x4E>(x);
+  x += dpp_f64<0x141>(x);
+  return x;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C[M x N] = alpha * sum_k P[k][m] Q[k][n] + beta1 * D1[m][n] + beta2 * D2[m][n]     (float64, MFMA 16x16x4)
+// P: [K x ldp], Q: [K x ldq] row-major (k-major).  grid (ceil(M/32), ceil(N/32)), 512 threads: wave w owns the
+// w-th eighth of K and the whole 32 x 32 tile (2 x 2 MFMA tiles); the eight partial tiles are summed in a fixed order.
+// MFMA operand layout (v_mfma_f64_16x16x4_f64): A fragment lane l = A[i = l & 15][k = l >> 4], B fragment lane l =
+// B[k = l >> 4][j = l & 15], accumulator register v of lane l = D[i = (l >> 4) + 4 v][j = l & 15] (NOT the
+// 4 (l >> 4) + v of the float32 16x16x4 instruction; pinned by tests/test_gpu_dense.py::test_dgemm_tn).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void dgemm_tn_kernel(const double* __restrict__ P, int64_t ldp,
+                                                       const double* __restrict__ Q, int64_t ldq, int M, int N, int K,
+                                                       double alpha, const double* __restrict__ D1, int64_t ldd1,
+                                                       double beta1, const double* __restrict__ D2, int64_t ldd2,
+                                                       double beta2, double* __restrict__ C, int64_t ldc) {
+  __shared__ double red[8][32 * 32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int kc = ((K + 7) / 8 + 3) / 4 * 4;  // K range of a wave (eight of them), a multiple of 4
+  const int kb = wave * kc, ke = min(K, kb + kc);
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[a][b][v] = 0.0;
+  const bool mv0 = m0 + l15 < M, mv1 = m0 + 16 + l15 < M;
+  const bool nv0 = n0 + l15 < N, nv1 = n0 + 16 + l15 < N;
+  const double* pp = P + m0 + l15;
+  const double* qq = Q + n0 + l15;
+#pragma unroll 4
+  for (int k0 = kb; k0 < ke; k0 += 4) {
+    const int kk = k0 + kq;
+    const bool kv = kk < ke;
+    const double a0 = (kv && mv0) ? pp[(int64_t)kk * ldp] : 0.0;
+    const double a1 = (kv && mv1) ? pp[(int64_t)kk * ldp + 16] : 0.0;
+    const double b0 = (kv && nv0) ? qq[(int64_t)kk * ldq] : 0.0;
+    const double b1 = (kv && nv1) ? qq[(int64_t)kk * ldq + 16] : 0.0;
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) red[wave][(16 * a + kq + 4 * v) * 32 + 16 * b + l15] = acc[a][b][v];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = threadIdx.x + 512 * j;
+    const int r = idx >> 5, c = idx & 31;
+    const int m = m0 + r, n = n0 + c;
+    if (m < M && n < N) {
+      double s = (((red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx])) +
+                  ((red[4][idx] + red[5][idx]) + (red[6][idx] + red[7][idx])));
+      s *= alpha;
+      if (D1) s += beta1 * D1[(int64_t)m * ldd1 + n];
+      if (D2) s += beta2 * D2[(int64_t)m * ldd2 + n];
+      C[(int64_t)m * ldc + n] = s;
+    }
+  }
+}
+
+static int dgemm_tn(hipStream_t s, const double* P, int64_t ldp, const double* Q, int64_t ldq, int M, int N, int K,
+                    double alpha, const double* D1, int64_t ldd1, double beta1, const double* D2, int64_t ldd2,
+                    double beta2, double* C, int64_t ldc) {
+  hipLaunchKernelGGL(dgemm_tn_kernel, dim3((M + 31) / 32, (N + 31) / 32), dim3(512), 0, s, P, ldp, Q, ldq, M, N, K,
+                     alpha, D1, ldd1, beta1, D2, ldd2, beta2, C, ldc);
+  SCAMD_LAUNCH_CHECK();
+  return SCAMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Cholesky of the column-normalised Gram matrix + the factor CholeskyQR applies, one workgroup, matrix in LDS.
+//   in : G [b x b] (ld b) = Z^T Z, shift >= 0 (relative, added to the unit diagonal)
+//   out: S [b x b] row-major with Z_new = Z S orthonormal: S = D^-1 L^-T, D = sqrt(diag G), L L^T = D^-1 G D^-1 + shift I
+//        flag: 1 if a pivot was not positive (S is then garbage)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void chol_factor_kernel(const double* __restrict__ G, int b, double shift,
+                                                           double* __restrict__ S, int* __restrict__ flag) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];  // L [b][DB_LD] (row-major, padded) + dinv[b]
+  double* L = sm;
+  double* dinv = sm + DB_MAX * DB_LD;
+  const int tid = threadIdx.x;
+  const int row = tid >> 3, part = tid & 7;  // 128 rows x 8 partial sums
+  for (int j = tid; j < b; j += 1024) {
+    const double d = G[(int64_t)j * b + j];
+    dinv[j] = d > 0.0 ? 1.0 / sqrt(d) : 0.0;
+  }
+  __syncthreads();
+  for (int e = tid; e < b * b; e += 1024) {
+    const int i = e / b, j = e - i * b;
+    double v = G[(int64_t)i * b + j] * dinv[i] * dinv[j];
+    if (i == j) v = (dinv[i] > 0.0 ? 1.0 : 0.0) + shift;
+    L[i * DB_LD + j] = v;
+  }
+  __syncthreads();
+  // left-looking Cholesky, column j from the finished columns: L[i][j] = (A[i][j] - sum_{k<j} L[i][k] L[j][k]) / L[j][j];
+  // the dot products of all rows i >= j run at once, eight lanes each (reduced through DPP)
+  bool bad = false;
+  __shared__ double sh_piv[2];
+  for (int j = 0; j < b; ++j) {
+    double acc = 0.0;
+    const bool mine = row >= j && row < b;
+    if (mine)
+      for (int k = part; k < j; k += 8) acc = fma(L[row * DB_LD + k], L[j * DB_LD + k], acc);
+    acc = oct_sum(acc);
+    const double v = mine ? L[row * DB_LD + j] - acc : 0.0;
+    if (row == j && part == 0) sh_piv[j & 1] = v;
+    __syncthreads();
+    const double piv = sh_piv[j & 1];
+    if (!(piv > 0.0)) {  // uniform: every thread reads the same pivot
+      bad = true;
+      break;
+    }
+    if (mine && part == 0) L[row * DB_LD + j] = (row == j) ? sqrt(piv) : v / sqrt(piv);
+    __syncthreads();  // column j is final before the next column's dot products read it
+  }
+  if (bad) {
+    if (tid == 0) *flag = 1;
+    return;
+  }
+  // X = L^-1 (lower triangular), row by row: X[j][c] = (delta_jc - sum_{c <= k < j} L[j][k] X[k][c]) / L[j][j] for all
+  // columns c <= j at once (thread group `row` = c, eight lanes split k).  X[k][c] (k > c) lives in the unused UPPER
+  // triangle at (c, k); X[c][c] = 1 / L[c][c].
+  {
+    const int c = row;
+    const double xcc = c < b ? 1.0 / L[c * DB_LD + c] : 0.0;
+    for (int j = 1; j < b; ++j) {
+      double acc = 0.0;
+      if (c < j) {
+        for (int k = c + 1 + part; k < j; k += 8) acc = fma(L[j * DB_LD + k], L[c * DB_LD + k], acc);
+        if (part == 0) acc = fma(L[j * DB_LD + c], xcc, acc);
+      }
+      acc = oct_sum(acc);
+      if (c < j && part == 0) L[c * DB_LD + j] = -acc / L[j * DB_LD + j];
+      __syncthreads();
+    }
+  }
+  // S[k][n] = X[n][k] * dinv[k] for n >= k, 0 below the diagonal
+  for (int e = tid; e < b * b; e += 1024) {
+    const int k = e / b, n = e - k * b;
+    double v = 0.0;
+    if (n == k) v = 1.0 / L[k * DB_LD + k];
+    else if (n > k) v = L[k * DB_LD + n];
+    S[e] = v * dinv[k];
+  }
+}
+
+// C[g x b] = Z[g x b] S[b x b] (plain FMA: O(g b^2), 1/16 of a GEMM application); 256 threads = 8 rows x 32 column quads
+__global__ __launch_bounds__(256) void panel_small_kernel(const double* __restrict__ Z, const double* __restrict__ S, int g,
+                                                          int b, int bo /* columns of S / C */, double* __restrict__ C) {
+  __shared__ double zrow[8][DB_MAX];
+  const int r = threadIdx.x >> 5, cq = threadIdx.x & 31;
+  const int m = blockIdx.x * 8 + r;
+  for (int k = cq; k < b; k += 32) zrow[r][k] = (m < g) ? Z[(int64_t)m * b + k] : 0.0;
+  __syncthreads();
+  if (m >= g) return;
+  for (int n0 = cq * 4; n0 < bo; n0 += 128) {
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+    for (int k = 0; k < b; ++k) {
+      const double z = zrow[r][k];
+      const double* sp = S + (int64_t)k * bo + n0;
+      c0 = fma(z, sp[0], c0);
+      if (n0 + 1 < bo) c1 = fma(z, sp[1], c1);
+      if (n0 + 2 < bo) c2 = fma(z, sp[2], c2);
+      if (n0 + 3 < bo) c3 = fma(z, sp[3], c3);
+    }
+    double* cp = C + (int64_t)m * bo + n0;
+    cp[0] = c0;
+    if (n0 + 1 < bo) cp[1] = c1;
+    if (n0 + 2 < bo) cp[2] = c2;
+    if (n0 + 3 < bo) cp[3] = c3;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Eigen-decomposition of a symmetric b x b matrix (b <= 128) by one-sided Jacobi, one workgroup of 512 threads.
+// W = T (columns in LDS); rotations orthogonalise the columns: at convergence W = T Y with Y orthogonal, column i =
+// theta_i y_i.  64 disjoint pairs per step (round-robin tournament), 8 lanes per pair.  Output: theta[b] descending by
+// |theta| (the sign is recovered from y^T T y = sign * |W_i|), Y [b x b] row-major, column j = eigenvector j.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void jacobi_eigh_kernel(const double* __restrict__ T, int b, double* __restrict__ theta,
+                                                          double* __restrict__ Y, int* __restrict__ sweeps_out) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];  // W [n2][DB_LD] column-major: W[c * DB_LD + i]
+  double* W = sm;
+  double* nrm = sm + DB_MAX * DB_LD;  // [DB_MAX]
+  __shared__ float off_arr[64];  // per group: largest |cos| between two columns it met in the sweep
+  __shared__ int rank_of[DB_MAX];
+  const int tid = threadIdx.x;
+  const int n2 = (b + 1) & ~1;  // even number of players (a padding column of zeros never rotates)
+  for (int e = tid; e < n2 * DB_LD; e += 512) {
+    const int c = e / DB_LD, i = e - c * DB_LD;
+    W[e] = (c < b && i < b) ? T[(int64_t)i * b + c] : 0.0;
+  }
+  __syncthreads();
+  // 64 groups of 8 lanes, one column pair each.  The kernel is bound by the instruction THROUGHPUT of its one CU (every
+  // lane of a group repeats the rotation's scalar arithmetic): eight lanes per pair instead of sixteen halves the
+  // redundant work per SIMD, the rotation is computed with two rsqrt and no division, the reductions run on DPP.
+  const int grp = tid >> 3, t8 = tid & 7;
+  const int nm1 = n2 - 1;
+  int sweep = 0;
+  for (; sweep < 30; ++sweep) {
+    float my_off = 0.f;  // (no shared counter inside the step loop: 64 same-address LDS atomics per step serialise)
+    // round-robin tournament: player n2-1 stays, the others rotate; group g > 0 plays (step + g, step - g) mod (n2 - 1)
+    int p = grp == 0 ? nm1 : grp % nm1;
+    int q = grp == 0 ? 0 : (nm1 - grp % nm1) % nm1;
+    for (int step = 0; step < nm1; ++step) {
+      const bool act = grp < n2 / 2 && p < b && q < b;
+      if (act) {
+        double* wp = W + p * DB_LD;
+        double* wq = W + q * DB_LD;
+        double a = 0.0, bb = 0.0, c = 0.0;
+        for (int i = t8; i < b; i += 8) {
+          const double x = wp[i], y = wq[i];
+          a = fma(x, x, a);
+          bb = fma(y, y, bb);
+          c = fma(x, y, c);
+        }
+        a = oct_sum(a);
+        bb = oct_sum(bb);
+        c = oct_sum(c);
+        const double ab = a * bb;
+        if (c * c > 1e-30 * ab) {  // |c| / sqrt(a bb) > 1e-15
+          // rotation by theta with tan(2 theta) = 2c / (bb - a): cos(2 theta) = |d| / r, r = hypot(d, 2c)
+          const double d = bb - a, tau = 2.0 * c;
+          const double inv_r = rsqrt(fma(d, d, tau * tau));
+          const double h = fma(0.5 * fabs(d), inv_r, 0.5);  // cos^2 of the smaller angle
+          const double inv_cs = rsqrt(h);
+          const double cs = h * inv_cs;
+          const double sn = (d >= 0.0 ? 0.5 : -0.5) * tau * inv_r * inv_cs;
+          for (int i = t8; i < b; i += 8) {
+            const double x = wp[i], y = wq[i];
+            wp[i] = cs * x - sn * y;
+            wq[i] = sn * x + cs * y;
+          }
+          my_off = fmaxf(my_off, (float)(fabs(c) * rsqrt(ab)));
+        }
+      }
+      if (grp != 0) {
+        p = p + 1 == nm1 ? 0 : p + 1;
+        q = q + 1 == nm1 ? 0 : q + 1;
+      } else {
+        q = step + 1;
+      }
+      __syncthreads();
+    }
+    if (t8 == 0) off_arr[grp] = my_off;
+    __syncthreads();
+    float off = 0.f;
+    for (int i = 0; i < 64; ++i) off = fmaxf(off, off_arr[i]);
+    __syncthreads();  // everybody has the sweep's maximum before the next sweep overwrites the array
+    if (off < 1e-13f) {
+      ++sweep;
+      break;
+    }
+  }
+  // column norms, ranks (descending norm, ties by index)
+  if (tid < n2) {
+    double a = 0.0;
+    for (int i = 0; i < b; ++i) a = fma(W[tid * DB_LD + i], W[tid * DB_LD + i], a);
+    nrm[tid] = tid < b ? sqrt(a) : -1.0;
+  }
+  __syncthreads();
+  if (tid < b) {
+    int r = 0;
+    const double me = nrm[tid];
+    for (int j = 0; j < b; ++j) r += (nrm[j] > me || (nrm[j] == me && j < tid)) ? 1 : 0;
+    rank_of[tid] = r;
+  }
+  __syncthreads();
+  // W_c = T y_c = theta_c y_c at convergence: theta_c = |W_c| (T is positive semi-definite: the Rayleigh-Ritz matrix
+  // of a covariance), y_c = W_c / |W_c|
+  for (int c = grp; c < b; c += 64) {
+    const double nv = nrm[c];
+    const double inv = nv > 0.0 ? 1.0 / nv : 0.0;
+    const int r = rank_of[c];
+    if (t8 == 0) theta[r] = nv;
+    for (int i = t8; i < b; i += 8) Y[(int64_t)i * b + r] = W[c * DB_LD + i] * inv;
+  }
+  if (tid == 0 && sweeps_out) *sweeps_out = sweep;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// small element-wise / reduction kernels
+// ---------------------------------------------------------------------------------------------------------------------
+// Z[g x b] <- standard normal, counter-based (Box-Muller on two hashes of (seed, element))
+__global__ void randn_kernel(double* __restrict__ z, int64_t count, unsigned int seed) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const unsigned int h1 = dhash32((unsigned int)i * 0x9E3779B1u + seed);
+  const unsigned int h2 = dhash32(h1 ^ 0x85EBCA77u ^ (unsigned int)(i >> 32));
+  const double u1 = ((double)h1 + 0.5) * (1.0 / 4294967296.0), u2 = ((double)h2 + 0.5) * (1.0 / 4294967296.0);
+  z[i] = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+
+// y = a x1 + b x2 (element-wise)
+__global__ void axpby_kernel(int64_t count, double a, const double* __restrict__ x1, double b,
+                             const double* __restrict__ x2, double* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) y[i] = a * x1[i] + b * x2[i];
+}
+
+// T <- (T + T^T) / 2 in place (b x b)
+__global__ void symmetrize_kernel(double* __restrict__ t, int b) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= b * b) return;
+  const int i = e / b, j = e - i * b;
+  if (j > i) {
+    const double v = 0.5 * (t[(int64_t)i * b + j] + t[(int64_t)j * b + i]);
+    t[(int64_t)i * b + j] = v;
+    t[(int64_t)j * b + i] = v;
+  }
+}
+
+// Rayleigh quotients t_j = z_j^T (A z_j) of an orthonormal block: out[1] = min_j t_j, out[2] = max_j t_j (one workgroup)
+__global__ __launch_bounds__(1024) void rq_minmax_kernel(const double* __restrict__ Z, const double* __restrict__ AZ, int g,
+                                                         int b, double* __restrict__ out) {
+  __shared__ double part[8][DB_MAX];
+  const int c = threadIdx.x & 127, rr = threadIdx.x >> 7;
+  double s = 0.0;
+  if (c < b)
+    for (int m = rr; m < g; m += 8) s = fma(Z[(int64_t)m * b + c], AZ[(int64_t)m * b + c], s);
+  part[rr][c] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double mn = INFINITY, mx = -INFINITY;
+    for (int j = 0; j < b; ++j) {
+      double t = 0.0;
+      for (int r = 0; r < 8; ++r) t += part[r][j];
+      mn = fmin(mn, t);
+      mx = fmax(mx, t);
+    }
+    out[1] = mn;
+    out[2] = mx;
+  }
+}
+
+// out[0] = max_{j < k} |AV_j - theta_j V_j| / max(theta_0, tiny); one workgroup, fixed order
+__global__ __launch_bounds__(1024) void residual_kernel(const double* __restrict__ V, const double* __restrict__ AV,
+                                                        const double* __restrict__ theta, int g, int b, int k,
+                                                        double* __restrict__ out) {
+  __shared__ double part[8][DB_MAX];
+  const int c = threadIdx.x & 127, rr = threadIdx.x >> 7;
+  double s = 0.0;
+  if (c < k) {
+    const double th = theta[c];
+    for (int m = rr; m < g; m += 8) {
+      const double d = AV[(int64_t)m * b + c] - th * V[(int64_t)m * b + c];
+      s = fma(d, d, s);
+    }
+  }
+  part[rr][c] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double mx = 0.0;
+    for (int j = 0; j < k; ++j) {
+      double t = 0.0;
+      for (int r = 0; r < 8; ++r) t += part[r][j];
+      mx = fmax(mx, sqrt(t));
+    }
+    out[0] = mx / fmax(theta[0], 1e-300);
+  }
+}
+
+// A[g x g] (float64) = gram_q * inv - n mu mu^T with mu = colsum_q * inv / n (the fixed-point Gram matrix of gram.hip);
+// also mean[g] and var[g] (population variance of every column, clamped at 0)
+__global__ void cov_from_gram_kernel(const long long* __restrict__ gram, int64_t ld_gram, const long long* __restrict__ colsum,
+                                     int g, double inv, double n, int zero_center, double* __restrict__ a,
+                                     double* __restrict__ mean, double* __restrict__ var) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)g * g) return;
+  const int i = (int)(e / g), j = (int)(e - (int64_t)i * g);
+  const double mi = (double)colsum[i] * inv / n, mj = (double)colsum[j] * inv / n;
+  // gram is exactly symmetric (integer sums); read the (min, max) entry so that A is symmetric to the bit as well
+  const int lo = min(i, j), hi = max(i, j);
+  const double gv = (double)gram[(int64_t)lo * ld_gram + hi] * inv;
+  a[e] = zero_center ? gv - n * mi * mj : gv;
+  if (i == j) {
+    mean[i] = mi;
+    var[i] = fmax(gv / n - mi * mi, 0.0);
+  }
+}
+
+// sign convention of sklearn's svd_flip(u_based_decision=False): the largest-|.| loading of a component is positive.
+// V [g x b] (first k columns used) -> comp64 [k x g] (row = component), v32 [g x k] float32 for the scores SpMM.
+__global__ __launch_bounds__(256) void finalize_components_kernel(const double* __restrict__ V, int g, int b, int k,
+                                                                  double* __restrict__ comp64, float* __restrict__ v32) {
+  __shared__ double bv[256];
+  __shared__ int bi[256];
+  const int c = blockIdx.x;
+  double best = -1.0;
+  int besti = 0;
+  for (int m = threadIdx.x; m < g; m += 256) {
+    const double a = fabs(V[(int64_t)m * b + c]);
+    if (a > best) {
+      best = a;
+      besti = m;
+    }
+  }
+  bv[threadIdx.x] = best;
+  bi[threadIdx.x] = besti;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      const double ob = bv[threadIdx.x + o];
+      const int oi = bi[threadIdx.x + o];
+      if (ob > bv[threadIdx.x] || (ob == bv[threadIdx.x] && oi < bi[threadIdx.x])) {
+        bv[threadIdx.x] = ob;
+        bi[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  const double sg = V[(int64_t)bi[0] * b + c] < 0.0 ? -1.0 : 1.0;
+  for (int m = threadIdx.x; m < g; m += 256) {
+    const double v = sg * V[(int64_t)m * b + c];
+    comp64[(int64_t)c * g + m] = v;
+    if (v32) v32[(int64_t)m * k + c] = (float)v;
+  }
+}
+
+// shift[c] (float32) = sum_m mean[m] * (double)v32[m][c]  (the projection of the column means: X V - 1 shift^T)
+__global__ __launch_bounds__(256) void mean_shift_kernel(const double* __restrict__ mean, const float* __restrict__ v32, int g,
+                                                         int k, float* __restrict__ shift, double* __restrict__ proj) {
+  __shared__ double part[256];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int m = threadIdx.x; m < g; m += 256) s = fma(mean[m], (double)v32[(int64_t)m * k + c], s);
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 256; ++i) t += part[i];
+    shift[c] = (float)t;
+    proj[c] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------------------------------
+struct DenseBuffers {
+  double* z[7];  // g x b panels
+  double* gm; double* s; double* t; double* y; double* theta; double* resid; int* flags;
+};
+
+static void dense_carve(Workspace& ws, int64_t g, int b, DenseBuffers* d) {
+  for (int i = 0; i < 7; ++i) d->z[i] = ws.take<double>((size_t)g * b);
+  d->gm = ws.take<double>((size_t)b * b);
+  d->s = ws.take<double>((size_t)b * b);
+  d->t = ws.take<double>((size_t)b * b);
+  d->y = ws.take<double>((size_t)b * b);
+  d->theta = ws.take<double>((size_t)b + 8);
+  d->resid = ws.take<double>(8);
+  d->flags = ws.take<int>(8);
+}
+
+static int dense_block_size(int64_t g, int k) {
+  if (g <= DB_MAX) return (int)g;  // the whole space: one Rayleigh-Ritz is the full decomposition
+  int b = (std::max(k + 64, 2 * k) + 15) / 16 * 16;
+  b = std::min<int>(b, DB_MAX);
+  return (int)std::min<int64_t>(b, g);
+}
+
+struct DenseCtx {
+  hipStream_t s;
+  const double* a;
+  int64_t lda;
+  int g, b;
+  DenseBuffers d;
+  int n_gemm = 0, n_chol_retry = 0;
+};
+
+static constexpr size_t CHOL_LDS = (size_t)(DB_MAX * DB_LD + DB_MAX) * sizeof(double);
+static constexpr size_t JAC_LDS = (size_t)(DB_MAX * DB_LD + DB_MAX) * sizeof(double);
+
+// zout = orthonormal basis of span(zin) by CholeskyQR2: two rounds of (Gram matrix, Cholesky factor, block times factor).
+// A failed pivot (the block is a Chebyshev-filtered one: kappa 1e9 and beyond, up to numerical rank deficiency) inserts
+// a SHIFTED round (Fukaya et al. 2020: factor G + s I, s ~ 11 (g b + b (b + 1)) u |Y|^2; every such round divides kappa by
+// ~1 / sqrt(s) ~ 3e3) and starts the count of plain rounds again; directions that were lost to rounding come back as
+// orthonormal noise, as they do from a Householder QR.  zin and tmp are overwritten; zin, tmp, zout are distinct panels.
+static int cholqr2(DenseCtx& cx, double* zin, double* tmp, double* zout) {
+  const int g = cx.g, b = cx.b;
+  double* cur = zin;
+  double* other = tmp;
+  int plain_ok = 0, shifted_rounds = 0;
+  const double s0 = 11.0 * ((double)g * b + (double)b * (b + 1)) * 2.220446049250313e-16 * b;
+  while (plain_ok < 2) {
+    int rc = dgemm_tn(cx.s, cur, b, cur, b, b, b, g, 1.0, nullptr, 0, 0.0, nullptr, 0, 0.0, cx.d.gm, b);
+    if (rc != SCAMD_OK) return rc;
+    double shift = 0.0;
+    for (int attempt = 0;; ++attempt) {
+      int bad = 0;
+      SCAMD_HIP_CHECK(hipMemsetAsync(cx.d.flags, 0, sizeof(int), cx.s));
+      hipLaunchKernelGGL(chol_factor_kernel, dim3(1), dim3(1024), CHOL_LDS, cx.s, cx.d.gm, b, shift, cx.d.s, cx.d.flags);
+      SCAMD_LAUNCH_CHECK();
+      SCAMD_HIP_CHECK(hipMemcpyAsync(&bad, cx.d.flags, sizeof(int), hipMemcpyDeviceToHost, cx.s));
+      SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+      if (!bad) break;
+      SCAMD_REQUIRE(attempt < 4 && shifted_rounds < 8, SCAMD_EUNSUPPORTED,
+                    "dense eigensolver: CholeskyQR gave up on the block (%d shifted rounds, attempt %d)", shifted_rounds,
+                    attempt);
+      shift = attempt == 0 ? s0 : shift * 1e3;
+      ++cx.n_chol_retry;
+    }
+    const bool was_shifted = shift > 0.0;
+    double* dst = (!was_shifted && plain_ok == 1) ? zout : other;
+    hipLaunchKernelGGL(panel_small_kernel, dim3((g + 7) / 8), dim3(256), 0, cx.s, cur, cx.d.s, g, b, b, dst);
+    SCAMD_LAUNCH_CHECK();
+    if (dst == other) std::swap(cur, other);
+    if (was_shifted) {
+      plain_ok = 0;
+      ++shifted_rounds;
+    } else {
+      ++plain_ok;
+    }
+  }
+  return SCAMD_OK;
+}
+
+// Rayleigh-Ritz on the orthonormal block z: az = A z, T = z^T az, T = Y diag(theta) Y^T, v = z Y, av = az Y
+static int rayleigh_ritz(DenseCtx& cx, const double* z, double* az, double* v, double* av, double* h_theta) {
+  const int g = cx.g, b = cx.b;
+  int rc = dgemm_tn(cx.s, cx.a, cx.lda, z, b, g, b, g, 1.0, nullptr, 0, 0.0, nullptr, 0, 0.0, az, b);
+  if (rc != SCAMD_OK) return rc;
+  ++cx.n_gemm;
+  rc = dgemm_tn(cx.s, z, b, az, b, b, b, g, 1.0, nullptr, 0, 0.0, nullptr, 0, 0.0, cx.d.t, b);
+  if (rc != SCAMD_OK) return rc;
+  hipLaunchKernelGGL(symmetrize_kernel, dim3((b * b + 255) / 256), dim3(256), 0, cx.s, cx.d.t, b);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(jacobi_eigh_kernel, dim3(1), dim3(512), JAC_LDS, cx.s, cx.d.t, b, cx.d.theta, cx.d.y,
+                     cx.d.flags + 1);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(panel_small_kernel, dim3((g + 7) / 8), dim3(256), 0, cx.s, z, cx.d.y, g, b, b, v);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(panel_small_kernel, dim3((g + 7) / 8), dim3(256), 0, cx.s, az, cx.d.y, g, b, b, av);
+  SCAMD_LAUNCH_CHECK();
+  SCAMD_HIP_CHECK(hipMemcpyAsync(h_theta, cx.d.theta, sizeof(double) * b, hipMemcpyDeviceToHost, cx.s));
+  return SCAMD_OK;
+}
+
+// top-k eigenpairs of the symmetric PSD matrix a [g x g]: theta (device, descending) and v = cx.d.z[3] [g x b]
+static int dense_topk(DenseCtx& cx, int k, unsigned int seed, double tol, int* n_outer_out, double* resid_out) {
+  const int g = cx.g, b = cx.b;
+  DenseBuffers& d = cx.d;
+  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_factor_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHOL_LDS));
+  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_eigh_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)JAC_LDS));
+  std::vector<double> h_theta(b);
+  double h_resid = INFINITY;
+  double *z = d.z[0], *tmp = d.z[1], *az = d.z[2], *v = d.z[3], *av = d.z[4], *y0 = d.z[5], *y1 = d.z[6];
+  if (b == g) {
+    // the block is the whole space: one Rayleigh-Ritz on the identity-like basis = a full eigendecomposition
+    hipLaunchKernelGGL(randn_kernel, dim3((unsigned)(((int64_t)g * b + 255) / 256)), dim3(256), 0, cx.s, z, (int64_t)g * b,
+                       seed);
+    SCAMD_LAUNCH_CHECK();
+    int rc = cholqr2(cx, z, tmp, y0);
+    if (rc != SCAMD_OK) return rc;
+    rc = rayleigh_ritz(cx, y0, az, v, av, h_theta.data());
+    if (rc != SCAMD_OK) return rc;
+    SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+    *n_outer_out = 0;
+    *resid_out = 0.0;
+    return SCAMD_OK;
+  }
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)(((int64_t)g * b + 255) / 256)), dim3(256), 0, cx.s, z, (int64_t)g * b, seed);
+  SCAMD_LAUNCH_CHECK();
+  const int64_t cnt = (int64_t)g * b;
+  const unsigned egrid = (unsigned)((cnt + 255) / 256);
+  // One Chebyshev filter of degree m on the block (vv, avv = A vv), damping [0, c] and scaled to ~1 at `top`; the result
+  // ends up in z.  vv / avv are left intact.
+  auto filter = [&](const double* vv, const double* avv, double c, double top, int m) -> int {
+    const double e = 0.5 * c, center = 0.5 * c;
+    double sigma = e / (top - center);
+    const double sigma1 = sigma;
+    hipLaunchKernelGGL(axpby_kernel, dim3(egrid), dim3(256), 0, cx.s, cnt, sigma1 / e, avv, -center * sigma1 / e, vv, y0);
+    SCAMD_LAUNCH_CHECK();
+    const double* yprev = vv;
+    double* ycur = y0;
+    double* ynew = y1;
+    for (int it = 2; it <= m; ++it) {
+      const double sigma2 = 1.0 / (2.0 / sigma1 - sigma);
+      const double al = 2.0 * sigma2 / e;
+      int rcf = dgemm_tn(cx.s, cx.a, cx.lda, ycur, b, g, b, g, al, ycur, b, -center * al, yprev, b, -(sigma * sigma2), ynew, b);
+      if (rcf != SCAMD_OK) return rcf;
+      ++cx.n_gemm;
+      double* old = (yprev == vv) ? z : const_cast<double*>(yprev);  // vv is never written: z joins the rotation
+      yprev = ycur;
+      ycur = ynew;
+      ynew = old;
+      sigma = sigma2;
+    }
+    if (ycur != z) SCAMD_HIP_CHECK(hipMemcpyAsync(z, ycur, sizeof(double) * cnt, hipMemcpyDeviceToDevice, cx.s));
+    return SCAMD_OK;
+  };
+  // two power steps (A (A z): the condition number of the block grows by (lambda_1 / lambda_b)^2, well within
+  // CholeskyQR2's reach) and one orthonormalisation
+  int rc = dgemm_tn(cx.s, cx.a, cx.lda, z, b, g, b, g, 1.0, nullptr, 0, 0.0, nullptr, 0, 0.0, y1, b);
+  if (rc != SCAMD_OK) return rc;
+  rc = dgemm_tn(cx.s, cx.a, cx.lda, y1, b, g, b, g, 1.0, nullptr, 0, 0.0, nullptr, 0, 0.0, z, b);
+  if (rc != SCAMD_OK) return rc;
+  cx.n_gemm += 2;
+  rc = cholqr2(cx, z, tmp, v);
+  if (rc != SCAMD_OK) return rc;
+  // First filter straight on this basis, bounds from its Rayleigh quotients: a Rayleigh-Ritz here would only re-mix
+  // the block (the filter does not care) at the price of one more 128 x 128 eigenproblem, the most expensive kernel of
+  // the solve.  c = smallest quotient (>= lambda_b is not guaranteed, the filter only needs a cut inside the unwanted
+  // part), top = largest quotient (a scaling).
+  rc = dgemm_tn(cx.s, cx.a, cx.lda, v, b, g, b, g, 1.0, nullptr, 0, 0.0, nullptr, 0, 0.0, av, b);
+  if (rc != SCAMD_OK) return rc;
+  ++cx.n_gemm;
+  hipLaunchKernelGGL(rq_minmax_kernel, dim3(1), dim3(1024), 0, cx.s, v, av, g, b, d.resid);
+  SCAMD_LAUNCH_CHECK();
+  double h_rq[3] = {0.0, 0.0, 0.0};
+  SCAMD_HIP_CHECK(hipMemcpyAsync(h_rq, d.resid, sizeof(double) * 3, hipMemcpyDeviceToHost, cx.s));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  if (h_rq[2] > h_rq[1] && h_rq[1] > 0.0) {
+    rc = filter(v, av, h_rq[1], h_rq[2], 8);
+    if (rc != SCAMD_OK) return rc;
+    rc = cholqr2(cx, z, tmp, y0);
+    if (rc != SCAMD_OK) return rc;
+    rc = rayleigh_ritz(cx, y0, az, v, av, h_theta.data());
+  } else {
+    SCAMD_HIP_CHECK(hipMemcpyAsync(y0, v, sizeof(double) * cnt, hipMemcpyDeviceToDevice, cx.s));
+    rc = rayleigh_ritz(cx, y0, az, v, av, h_theta.data());
+  }
+  if (rc != SCAMD_OK) return rc;
+  int outer = 0;
+  const char* dbg_env = getenv("SCAMD_DENSE_DEBUG");
+  const bool dbg = dbg_env && dbg_env[0] == '1';
+  constexpr int MAX_OUTER = 60;
+  for (outer = 1;; ++outer) {
+    hipLaunchKernelGGL(residual_kernel, dim3(1), dim3(1024), 0, cx.s, v, av, d.theta, g, b, k, d.resid);
+    SCAMD_LAUNCH_CHECK();
+    SCAMD_HIP_CHECK(hipMemcpyAsync(&h_resid, d.resid, sizeof(double), hipMemcpyDeviceToHost, cx.s));
+    SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));  // (also completes the copy of theta)
+    if (dbg)
+      fprintf(stderr, "[dense] outer %d: residual %.3e, theta[0] %.6e theta[k-1] %.6e theta[b-1] %.6e, gemms %d, chol retries %d\n",
+              outer, h_resid, h_theta[0], h_theta[k - 1], h_theta[b - 1], cx.n_gemm, cx.n_chol_retry);
+    if (h_resid < tol) break;
+    SCAMD_REQUIRE(outer < MAX_OUTER, SCAMD_EUNSUPPORTED,
+                  "dense eigensolver: residual %.3e above the tolerance %.3e after %d filtered iterations", h_resid, tol,
+                  MAX_OUTER);
+    const double c = std::max(h_theta[b - 1], 0.0), top = h_theta[0];
+    if (!(top > c && c > 0.0)) {
+      // rank-deficient block (c == 0): a plain power step on the Ritz block
+      rc = dgemm_tn(cx.s, cx.a, cx.lda, av, b, g, b, g, 1.0, nullptr, 0, 0.0, nullptr, 0, 0.0, z, b);
+      if (rc != SCAMD_OK) return rc;
+      ++cx.n_gemm;
+    } else {
+      // Degree: the filter grows like cosh(m acosh x), x = (lambda - center) / e, so the LARGEST wanted eigenvalue is
+      // amplified exp(m (acosh x_1 - acosh x_k)) times more than the smallest wanted one.  Beyond ~1e9 every column
+      // is the leading eigenvector plus rounding noise and the k-th pair never converges (seen with k = 40 on a
+      // matrix with 29 separated eigenvalues above a bulk: residual stuck at 1e-7, a Cholesky retry every iteration).
+      const double e = 0.5 * c, center = 0.5 * c;
+      const double x1 = (top - center) / e, xk = std::max((h_theta[k - 1] - center) / e, 1.0);
+      const double spread = std::acosh(x1) - std::acosh(xk);
+      int m = 16;
+      if (spread > 0.0) m = std::max(4, std::min(m, (int)std::floor(20.7 / spread)));
+      rc = filter(v, av, c, top, m);
+      if (rc != SCAMD_OK) return rc;
+    }
+    rc = cholqr2(cx, z, tmp, y0);
+    if (rc != SCAMD_OK) return rc;
+    rc = rayleigh_ritz(cx, y0, az, v, av, h_theta.data());
+    if (rc != SCAMD_OK) return rc;
+  }
+  *n_outer_out = outer;
+  *resid_out = h_resid;
+  return SCAMD_OK;
+}
+
+}  // namespace scamd
+
+using namespace scamd;
+
+extern "C" size_t scamd_eigh_topk_workspace_bytes(int64_t g, int k) {
+  if (g < 1 || k < 1) return 0;
+  Workspace ws(nullptr, 0);
+  DenseBuffers d;
+  dense_carve(ws, g, dense_block_size(g, k), &d);
+  return ws.used();
+}
+
+extern "C" int scamd_eigh_topk_f64(const double* a, int64_t g, int64_t lda, int k, uint64_t seed, double tol,
+                                   double* lam, double* v, int32_t* info_host, void* workspace, size_t workspace_bytes,
+                                   scamd_stream_t stream) {
+  SCAMD_REQUIRE(a && lam && v, SCAMD_EINVAL, "eigh_topk: null pointer");
+  SCAMD_REQUIRE(g >= 1 && lda >= g && k >= 1 && k <= g, SCAMD_EINVAL, "eigh_topk: bad shape g=%lld k=%d", (long long)g, k);
+  SCAMD_REQUIRE(g < ((int64_t)1 << 30), SCAMD_EUNSUPPORTED, "eigh_topk: g too large");
+  const int b = dense_block_size(g, k);
+  SCAMD_REQUIRE(b == g || k + 32 <= b, SCAMD_EUNSUPPORTED,
+                "eigh_topk: k=%d needs a block beyond %d columns (use a full eigendecomposition)", k, DB_MAX);
+  SCAMD_REQUIRE(b == g || g >= 2 * b, SCAMD_EUNSUPPORTED, "eigh_topk: g=%lld between %d and %d is served by a full eigh",
+                (long long)g, DB_MAX, 2 * DB_MAX);
+  DenseCtx cx;
+  cx.s = stream;
+  cx.a = a;
+  cx.lda = lda;
+  cx.g = (int)g;
+  cx.b = b;
+  Workspace ws(workspace, workspace_bytes);
+  dense_carve(ws, g, b, &cx.d);
+  SCAMD_REQUIRE(workspace && ws.ok, SCAMD_EWORKSPACE, "eigh_topk: workspace %zu < required %zu", workspace_bytes, ws.used());
+  int n_outer = 0;
+  double resid = 0.0;
+  int rc = dense_topk(cx, k, (unsigned int)(seed ^ (seed >> 32)) * 0x9E3779B1u + 12345u, tol, &n_outer, &resid);
+  if (rc != SCAMD_OK) return rc;
+  // lam[k], v [g x k] row-major (column j = eigenvector j), unsigned
+  SCAMD_HIP_CHECK(hipMemcpyAsync(lam, cx.d.theta, sizeof(double) * k, hipMemcpyDeviceToDevice, stream));
+  SCAMD_HIP_CHECK(hipMemcpy2DAsync(v, sizeof(double) * k, cx.d.z[3], sizeof(double) * b, sizeof(double) * k, (size_t)g,
+                                   hipMemcpyDeviceToDevice, stream));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(stream));
+  if (info_host) {
+    info_host[0] = n_outer;
+    info_host[1] = cx.n_gemm;
+    info_host[2] = b;
+    info_host[3] = cx.n_chol_retry;
+    double r = resid;
+    memcpy(info_host + 4, &r, sizeof(double));  // info_host[4..5] = residual (float64)
+  }
+  return SCAMD_OK;
+}
+
+// debug / test entry: the building blocks on caller buffers.  op 1: C[M x N] = P^T Q (P [K x M], Q [K x N]);
+// op 2: S = CholeskyQR factor of G [b x b] (flag_host = pivot failure); op 3: (theta, Y) = eigh(T [b x b]).
+extern "C" int scamd_dense_debug_f64(int op, const double* in0, const double* in1, int m, int n, int kdim, double* out0,
+                                     double* out1, int32_t* flag_host, scamd_stream_t stream) {
+  SCAMD_REQUIRE(in0 && out0, SCAMD_EINVAL, "dense_debug: null pointer");
+  if (op == 1) {
+    SCAMD_REQUIRE(in1, SCAMD_EINVAL, "dense_debug: null pointer");
+    int rc = dgemm_tn(stream, in0, m, in1, n, m, n, kdim, 1.0, nullptr, 0, 0.0, nullptr, 0, 0.0, out0, n);
+    if (rc != SCAMD_OK) return rc;
+  } else if (op == 2 || op == 3) {
+    const int b = m;
+    SCAMD_REQUIRE(b >= 1 && b <= DB_MAX, SCAMD_EINVAL, "dense_debug: b=%d", b);
+    int* dflag = nullptr;
+    SCAMD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dflag), 2 * sizeof(int)));
+    SCAMD_HIP_CHECK(hipMemsetAsync(dflag, 0, 2 * sizeof(int), stream));
+    if (op == 2) {
+      SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_factor_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHOL_LDS));
+      hipLaunchKernelGGL(chol_factor_kernel, dim3(1), dim3(1024), CHOL_LDS, stream, in0, b, 0.0, out0, dflag);
+    } else {
+      SCAMD_REQUIRE(out1, SCAMD_EINVAL, "dense_debug: null pointer");
+      SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_eigh_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)JAC_LDS));
+      hipLaunchKernelGGL(jacobi_eigh_kernel, dim3(1), dim3(512), JAC_LDS, stream, in0, b, out0, out1, dflag + 1);
+    }
+    SCAMD_LAUNCH_CHECK();
+    int h[2] = {0, 0};
+    SCAMD_HIP_CHECK(hipMemcpyAsync(h, dflag, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    SCAMD_HIP_CHECK(hipStreamSynchronize(stream));
+    SCAMD_HIP_CHECK(hipFree(dflag));
+    if (flag_host) *flag_host = op == 2 ? h[0] : h[1];
+    return SCAMD_OK;
+  } else {
+    SCAMD_REQUIRE(false, SCAMD_EINVAL, "dense_debug: op=%d", op);
+  }
+  SCAMD_HIP_CHECK(hipStreamSynchronize(stream));
+  return SCAMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// sc.pp.pca on a resident CSR matrix in ONE call (SURVEY.md 8(b).3 `pca_csr_f32`): the exact Gram route of
+// scanpy_amd/preprocessing/_pca_solver.py without Python -- max|x| -> fixed-point X^T X (gram.hip) -> A = G - n mu mu^T ->
+// top-k eigenpairs (above) -> sign convention of sklearn's svd_flip -> scores X V - 1 (mu^T V) (pca.hip) -> variances.
+// Single device; a multi-rank run all-reduces the fixed-point Gram matrix between the two halves and therefore uses
+// the building blocks (scamd_csr_gram_f32, scamd_eigh_topk_f64, scamd_spmm_csr_f32) instead.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace scamd {
+struct PcaBuffers {
+  long long* gram; long long* colsum; double* a; double* var; float* v32; float* shift; double* varsum; double* proj;
+  void* gram_ws; size_t gram_ws_bytes; void* dense_ws; size_t dense_ws_bytes;
+};
+static void pca_carve(Workspace& ws, int64_t n, int64_t g, int k, PcaBuffers* b) {
+  const int64_t gp = (g + 127) / 128 * 128;
+  b->gram = ws.take<long long>((size_t)gp * gp);
+  b->colsum = ws.take<long long>((size_t)gp);
+  b->a = ws.take<double>((size_t)g * g);
+  b->var = ws.take<double>((size_t)g);
+  b->v32 = ws.take<float>((size_t)g * k);
+  b->shift = ws.take<float>((size_t)k + 8);
+  b->varsum = ws.take<double>(8);
+  b->proj = ws.take<double>((size_t)k + 8);
+  b->gram_ws_bytes = scamd_csr_gram_workspace_bytes(n, g);
+  b->gram_ws = ws.take<char>(b->gram_ws_bytes);
+  b->dense_ws_bytes = scamd_eigh_topk_workspace_bytes(g, k);
+  b->dense_ws = ws.take<char>(b->dense_ws_bytes);
+}
+// out[0] = sum of var[0..g) in index order (one thread: g <= 65535)
+__global__ void sum_kernel(const double* __restrict__ x, int g, double* __restrict__ out) {
+  double s = 0.0;
+  for (int i = 0; i < g; ++i) s += x[i];
+  out[0] = s;
+}
+// zero_center: variance[c] = theta[c] / (n - 1) (sklearn PCA: S^2 / (n - 1)); otherwise the variance of the scores of
+// the uncentred decomposition, theta[c] / n - (mu^T v_c)^2 (TruncatedSVD); ratio[c] = variance[c] / total
+__global__ void variance_kernel(const double* __restrict__ theta, int k, double denom, const double* __restrict__ proj,
+                                const double* __restrict__ varsum, double total_scale, double* __restrict__ variance,
+                                double* __restrict__ ratio) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= k) return;
+  double ev = fmax(theta[c], 0.0) / denom;
+  if (proj) ev = fmax(ev - proj[c] * proj[c], 0.0);
+  variance[c] = ev;
+  const double tot = varsum[0] * total_scale;
+  ratio[c] = tot > 0.0 ? ev / tot : 0.0;
+}
+}  // namespace scamd
+
+extern "C" size_t scamd_pca_csr_workspace_bytes(int64_t n, int64_t g, int n_comps) {
+  if (n < 1 || g < 1 || n_comps < 1) return 0;
+  Workspace ws(nullptr, 0);
+  PcaBuffers b;
+  pca_carve(ws, n, g, n_comps, &b);
+  return ws.used();
+}
+
+extern "C" int scamd_pca_csr_f32(const int64_t* indptr, const int32_t* indices, const float* data, int64_t n, int64_t g,
+                                 int64_t nnz, int n_comps, int zero_center, uint64_t seed, double tol, float* scores,
+                                 double* components, double* variance, double* variance_ratio, double* mean,
+                                 int32_t* info_host, void* workspace, size_t workspace_bytes, scamd_stream_t stream) {
+  SCAMD_REQUIRE(indptr && scores && components && variance && variance_ratio && mean, SCAMD_EINVAL, "pca: null pointer");
+  SCAMD_REQUIRE(n >= 2 && g >= 1 && nnz >= 0, SCAMD_EINVAL, "pca: bad shape n=%lld g=%lld", (long long)n, (long long)g);
+  const int k = n_comps;
+  SCAMD_REQUIRE(k >= 1 && k < std::min<int64_t>(n, g), SCAMD_EINVAL,
+                "n_components=%d must be strictly less than min(n_samples, n_features)=%lld with svd_solver='arpack'", k,
+                (long long)std::min<int64_t>(n, g));
+  SCAMD_REQUIRE(g <= 8192, SCAMD_EUNSUPPORTED, "pca: the Gram route takes up to 8192 genes (g=%lld)", (long long)g);
+  Workspace ws(workspace, workspace_bytes);
+  PcaBuffers b;
+  pca_carve(ws, n, g, k, &b);
+  SCAMD_REQUIRE(workspace && ws.ok, SCAMD_EWORKSPACE, "pca: workspace %zu < required %zu", workspace_bytes, ws.used());
+  hipStream_t s = stream;
+  const int64_t gp = (g + 127) / 128 * 128;
+  // 1. max |x| -> scale of the fixed-point sums (both sum x_a x_b 2^S and sum x 2^S must stay below 2^62)
+  float absmax = 0.f;
+  int rc = scamd_csr_gram_f32(indptr, indices, data, n, g, nnz, 0, nullptr, 0, nullptr, &absmax, b.gram_ws, b.gram_ws_bytes, s);
+  if (rc != SCAMD_OK) return rc;
+  const double am = (double)absmax;
+  const double bound = std::max(std::max((double)n * am * am, (double)n * am), 1e-300);
+  int scale_bits = std::min((int)std::floor(62.0 - std::log2(bound)), 60);
+  SCAMD_REQUIRE(!(am > 0.0) || scale_bits + 2.0 * std::log2(am) >= 24.0, SCAMD_EUNSUPPORTED,
+                "pca: fixed-point resolution below float32 for this n and dynamic range (max|x| = %g)", am);
+  scale_bits = std::max(scale_bits, 0);
+  // 2. G = X^T X, column sums (int64, exact)
+  rc = scamd_csr_gram_f32(indptr, indices, data, n, g, nnz, scale_bits, reinterpret_cast<int64_t*>(b.gram), gp,
+                          reinterpret_cast<int64_t*>(b.colsum), nullptr, b.gram_ws, b.gram_ws_bytes, s);
+  if (rc != SCAMD_OK) return rc;
+  // 3. A = G - n mu mu^T, means, column variances
+  const double inv = std::ldexp(1.0, -scale_bits);
+  hipLaunchKernelGGL(cov_from_gram_kernel, dim3((unsigned)(((int64_t)g * g + 255) / 256)), dim3(256), 0, s, b.gram, gp,
+                     b.colsum, (int)g, inv, (double)n, zero_center ? 1 : 0, b.a, mean, b.var);
+  SCAMD_LAUNCH_CHECK();
+  // 4. top-k eigenpairs
+  const int bsz = dense_block_size(g, k);
+  SCAMD_REQUIRE((bsz == g || k + 32 <= bsz) && (bsz == g || g >= 2 * bsz), SCAMD_EUNSUPPORTED,
+                "pca: n_comps=%d / g=%lld outside the device eigensolver's range", k, (long long)g);
+  DenseCtx cx;
+  cx.s = s;
+  cx.a = b.a;
+  cx.lda = g;
+  cx.g = (int)g;
+  cx.b = bsz;
+  Workspace dws(b.dense_ws, b.dense_ws_bytes);
+  dense_carve(dws, g, bsz, &cx.d);
+  int n_outer = 0;
+  double resid = 0.0;
+  rc = dense_topk(cx, k, (unsigned int)(seed ^ (seed >> 32)) * 0x9E3779B1u + 12345u, tol, &n_outer, &resid);
+  if (rc != SCAMD_OK) return rc;
+  // 5. sign convention, float32 loadings, projected means
+  hipLaunchKernelGGL(finalize_components_kernel, dim3(k), dim3(256), 0, s, cx.d.z[3], (int)g, bsz, k, components, b.v32);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mean_shift_kernel, dim3(k), dim3(256), 0, s, mean, b.v32, (int)g, k, b.shift, b.proj);
+  SCAMD_LAUNCH_CHECK();
+  // 6. scores = X V - 1 shift^T
+  rc = scamd_spmm_csr_f32(indptr, indices, data, n, g, b.v32, k, zero_center ? b.shift : nullptr, scores, s);
+  if (rc != SCAMD_OK) return rc;
+  // 7. explained variance (sklearn: S^2 / (n - 1); ratio against the total variance with the same n / (n - 1) factor;
+  //    zero_center = False is TruncatedSVD: variance of the scores is not what this entry returns -- lam / n there)
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1), 0, s, b.var, (int)g, b.varsum);
+  SCAMD_LAUNCH_CHECK();
+  const double denom = zero_center ? (double)(n - 1) : (double)n;
+  const double total_scale = zero_center ? (double)n / (double)(n - 1) : 1.0;
+  hipLaunchKernelGGL(variance_kernel, dim3(1), dim3(256), 0, s, cx.d.theta, k, denom,
+                     zero_center ? (const double*)nullptr : (const double*)b.proj, b.varsum, total_scale, variance,
+                     variance_ratio);
+  SCAMD_LAUNCH_CHECK();
+  SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+  if (info_host) {
+    info_host[0] = n_outer;
+    info_host[1] = cx.n_gemm;
+    info_host[2] = bsz;
+    info_host[3] = cx.n_chol_retry;
+    memcpy(info_host + 4, &resid, sizeof(double));
+    info_host[6] = scale_bits;
+    info_host[7] = 0;
+  }
+  return SCAMD_OK;
+}
+

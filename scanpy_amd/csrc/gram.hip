@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace scamd {
 
@@ -62,6 +63,10 @@ __global__ __launch_bounds__(256) void gram_tileptr_kernel(const int64_t* __rest
   for (int u = last_tile + 1 + lane; u <= ntile; u += 64) out[u] = (unsigned short)len;
 }
 
+// A_FROM_MEM: every lane reads the tile-a entry of its row group straight from memory (one address per 8 lanes, L1
+// hits) instead of receiving it through two ds_bpermute: the kernel is bound by the LDS pipe (bpermute + 64-bit
+// atomic), the vector-memory pipe is idle.
+template <bool A_FROM_MEM>
 __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ data,
     int64_t n, int ntile, const unsigned short* __restrict__ ptr, int rows_per_chunk, double scale,
@@ -123,13 +128,24 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
           va_l = data[pa + pc + q];
         }
         const int cnt = min(8, max_na - pc);
-        for (int pp = 0; pp < cnt; ++pp) {
-          const int src = (lane & ~7) | pp;
-          const int ja = __shfl(ja_l, src);
-          const float va = __shfl(va_l, src);
-          if (has_b && pc + pp < na) {
-            const long long v = llrint((double)va * vb);
-            atomicAdd(&tile[ja * GT + jb], (unsigned long long)v);
+        if constexpr (A_FROM_MEM) {
+          for (int pp = 0; pp < cnt; ++pp) {
+            if (has_b && pc + pp < na) {
+              const int ja = indices[pa + pc + pp] - a0;
+              const float va = data[pa + pc + pp];
+              const long long v = llrint((double)va * vb);
+              atomicAdd(&tile[ja * GT + jb], (unsigned long long)v);
+            }
+          }
+        } else {
+          for (int pp = 0; pp < cnt; ++pp) {
+            const int src = (lane & ~7) | pp;
+            const int ja = __shfl(ja_l, src);
+            const float va = __shfl(va_l, src);
+            if (has_b && pc + pp < na) {
+              const long long v = llrint((double)va * vb);
+              atomicAdd(&tile[ja * GT + jb], (unsigned long long)v);
+            }
           }
         }
       }
@@ -211,11 +227,16 @@ extern "C" int scamd_csr_gram_f32(const int64_t* indptr, const int32_t* indices,
   const int rows_per_chunk = (int)((n + n_chunks - 1) / n_chunks);
   n_chunks = (int)((n + rows_per_chunk - 1) / rows_per_chunk);
   const size_t lds = (size_t)(GT * GT + GT) * sizeof(unsigned long long);
-  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_tile_kernel),
+  static const bool a_from_mem = [] {
+    const char* e = getenv("SCAMD_GRAM_A_FROM_MEM");
+    return e && e[0] == '1';
+  }();
+  auto gram_kernel = a_from_mem ? gram_tile_kernel<true> : gram_tile_kernel<false>;
+  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // column sums are scaled by 2^scale_bits as well (x * 2^S), products by 2^S: x_a * (x_b * 2^S)
   const double scale = std::ldexp(1.0, scale_bits);
-  hipLaunchKernelGGL(gram_tile_kernel, dim3((unsigned)npair, (unsigned)n_chunks), dim3(GRAM_THREADS), lds, s, indptr,
+  hipLaunchKernelGGL(gram_kernel, dim3((unsigned)npair, (unsigned)n_chunks), dim3(GRAM_THREADS), lds, s, indptr,
                      indices, data, n, ntile, ptr, rows_per_chunk, scale,
                      reinterpret_cast<unsigned long long*>(gram), ld_gram, reinterpret_cast<unsigned long long*>(colsum));
   SCAMD_LAUNCH_CHECK();

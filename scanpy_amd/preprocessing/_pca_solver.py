@@ -258,6 +258,19 @@ def _dense_topk_eigh(amat: torch.Tensor, k: int, rng: np.random.Generator, tol: 
         info.update(dense_solver="eigh", residual=0.0)
         return lam.flip(0)[:k], v.flip(1)[:, :k]
     dev = amat.device
+    if amat.is_cuda and k + 32 <= 128:
+        # the hand-written float64 path (csrc/dense.hip: MFMA GEMMs, CholeskyQR2, one-workgroup Jacobi); the torch.linalg
+        # formulation below is what the CPU stand-in of the tests runs and the fallback for a block the device solver
+        # gives up on (numerically rank deficient / not converged: SCAMD_EUNSUPPORTED, a loud message either way)
+        from .. import _kernels as K
+        from .._lib import ScamdError
+
+        try:
+            lam, v, dinfo = K.eigh_topk(amat, k, seed=int(rng.integers(0, 2**31 - 1)), tol=tol)
+            info.update(dense_solver="chebyshev_subspace", **dinfo)
+            return lam, v
+        except ScamdError as e:
+            info["device_eigensolver_fallback"] = str(e)
 
     def rr(z):
         az = amat @ z
@@ -284,8 +297,14 @@ def _dense_topk_eigh(amat: torch.Tensor, k: int, rng: np.random.Generator, tol: 
             theta, v, av = rr(z)
             n_gemm += 1
             continue
-        m = 8 if outer == 1 else 16
         e, center = 0.5 * c, 0.5 * c
+        # degree: the filter amplifies the largest wanted eigenvalue exp(m (acosh x_1 - acosh x_k)) times more than the
+        # smallest wanted one; beyond ~1e9 every column is the leading eigenvector plus rounding noise (csrc/dense.hip)
+        x1, xk = (top - center) / e, max((float(theta[k - 1]) - center) / e, 1.0)
+        spread = float(np.arccosh(x1) - np.arccosh(xk))
+        m = 8 if outer == 1 else 16
+        if spread > 0.0:
+            m = max(4, min(m, int(np.floor(20.7 / spread))))
         sigma = e / (top - center)
         sigma1 = sigma
         y_prev = v
