@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--n-comps", type=int, default=50)
     ap.add_argument("--n-neighbors", type=int, default=15)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1: strong = --n-obs cells split over the ranks (BASELINE configs[3]); weak = --n-obs cells PER "
+                         "rank (e.g. --n-obs 1250000 --n-vars 4000 --gpus 8 is the configs[4] shape, 10M x 4k)")
     ap.add_argument("--cpu-sizes", type=str, default="100000,250000,500000",
                     help="cell counts of the CPU-baseline samples (n^2 fit of the brute kNN); '' or 0 = skip")
     ap.add_argument("--cpu-sample", type=int, default=None, help="(old flag) one CPU-baseline sample size; 0 = skip")
@@ -413,7 +416,7 @@ def main() -> None:
             dist.init_process_group(backend="nccl", device_id=dev)
         comm = TorchDistComm()
 
-    n = args.n_obs
+    n = args.n_obs * (world if args.scaling == "weak" else 1)
     lo, hi = shard_bounds(n, world, rank)
     t_gen = time.perf_counter()
     x, truth = make_matrix(n, args.n_vars, args.seed, args.structure, row_range=(lo, hi))
@@ -478,7 +481,7 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -489,7 +492,8 @@ def main() -> None:
                 "n_obs": n,
                 "n_vars": args.n_vars,
                 "nnz_per_rank": int(nnz_local),
-                "parallelism": f"cells row-sharded x{world}; leiden on rank 0",
+                "parallelism": (f"cells row-sharded x{world}: int64 Gram all-reduce, embedding all-gather, fuzzy-set rows per "
+                                "rank with an all-to-all of the directed edges; leiden on rank 0"),
             },
             "roofline": {
                 "kernel": "knn_select_reg_kernel<25,64,3> (v_mfma_f32_32x32x2_f32), exact cell-pruned sweep",

@@ -95,6 +95,22 @@ int scamd_fuzzy_simplicial_set_f32(const int32_t* knn_idx, const float* knn_dist
                                    int64_t* out_indptr, int32_t* out_indices, float* out_data,
                                    int64_t cap, float* out_sigma, float* out_rho, int64_t* nnz_host,
                                    void* workspace, size_t workspace_bytes, scamd_stream_t stream);
+/* Row-sharded fuzzy simplicial set (one process per GPU, rows [row_begin, row_begin + n_local) of n_total; knn_idx holds
+ * GLOBAL row ids).  weights: sigma / rho / membership strengths of the local rows -- w [n_local, k] (0 = absent: the self
+ * column, padding), out_count[i] = entries of row i with w > 0; sum_all_dev = device double holding the sum of ALL
+ * n_total * k distances (the caller all-reduces it; used only for the rows without a positive distance, as in
+ * umap.smooth_knn_dist).  merge_rows: the symmetrisation C = W + W^T - W o W^T of the local rows given their in-edges
+ * (in_indptr [n_local + 1], in_src ascending within a row, in_w: the (j, i, w_ji) triples the other ranks sent for
+ * these rows); bit-identical to the rows scamd_fuzzy_simplicial_set_f32 produces on one device.  cap >= nnz of the
+ * local rows (<= n_local * (k - 1) + number of in-edges). */
+int scamd_fuzzy_weights_f32(const int32_t* knn_idx, const float* knn_dist, int64_t n_local, int k, int64_t row_begin,
+                            int64_t n_total, const double* sum_all_dev, float* w, float* out_sigma, float* out_rho,
+                            int32_t* out_count, scamd_stream_t stream);
+size_t scamd_fuzzy_merge_workspace_bytes(int64_t n_local, int64_t cap);
+int scamd_fuzzy_merge_rows_f32(const int32_t* knn_idx, const float* w, int64_t n_local, int k, const int64_t* in_indptr,
+                               const int32_t* in_src, const float* in_w, int64_t* out_indptr, int32_t* out_indices,
+                               float* out_data, int64_t cap, int64_t* nnz_host, void* workspace, size_t workspace_bytes,
+                               scamd_stream_t stream);
 /* method='gauss' on the kNN pattern (src/scanpy/neighbors/_connectivity.py:21-100, CSR branch): sigma_i^2 = median of the
  * squared distances to the row's neighbours, w_ij = sqrt(2 s_i s_j / (s_i^2 + s_j^2)) exp(-d_ij^2 / (s_i^2 + s_j^2)),
  * w_ji := w_ij where i is not among j's neighbours.  Same in/out conventions and workspace size as the fuzzy set. */

@@ -62,6 +62,46 @@ def fuzzy_simplicial_set(knn_idx: torch.Tensor, knn_dist: torch.Tensor):
     return indptr, indices[:m], data[:m], sigma, rho
 
 
+def fuzzy_weights(knn_idx: torch.Tensor, knn_dist: torch.Tensor, row_begin: int, n_total: int, sum_all: torch.Tensor):
+    """membership strengths of a rank's own rows (row-sharded fuzzy set, step 1).  knn_idx holds global row ids;
+    sum_all = device float64 [1], the sum of all n_total * k distances.  -> w float32 [n_local, k] (0 = absent)"""
+    dev = require_gpu()
+    n, k = knn_idx.shape
+    knn_idx = knn_idx.to(torch.int32).contiguous()
+    knn_dist = knn_dist.to(torch.float32).contiguous()
+    sum_all = sum_all.to(torch.float64).contiguous()
+    w = torch.empty((n, k), dtype=torch.float32, device=dev)
+    cnt = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().scamd_fuzzy_weights_f32(ptr(knn_idx), ptr(knn_dist), n, k, int(row_begin), int(n_total),
+                                                   ptr(sum_all), ptr(w), None, None, ptr(cnt), stream_ptr()),
+               "scamd_fuzzy_weights_f32")
+    return w
+
+
+def fuzzy_merge_rows(knn_idx: torch.Tensor, w: torch.Tensor, in_indptr: torch.Tensor, in_src: torch.Tensor,
+                     in_w: torch.Tensor):
+    """symmetrised rows of a rank (row-sharded fuzzy set, step 3) from its out-edges (knn_idx, w) and the in-edges the
+    other ranks sent, sorted by (row, source).  -> (indptr int64 [n_local + 1], indices int32 (global), data float32)"""
+    dev = require_gpu()
+    lib = _lib.load()
+    n, k = knn_idx.shape
+    knn_idx = knn_idx.to(torch.int32).contiguous()
+    w = w.to(torch.float32).contiguous()
+    in_indptr = in_indptr.to(torch.int64).contiguous()
+    in_src = in_src.to(torch.int32).contiguous()
+    in_w = in_w.to(torch.float32).contiguous()
+    cap = n * (k - 1) + int(in_src.numel())
+    indptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    indices = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+    data = torch.empty(max(cap, 1), dtype=torch.float32, device=dev)
+    ws, wsz = _ws(lib.scamd_fuzzy_merge_workspace_bytes(n, cap), dev)
+    nnz = C.c_int64(0)
+    rc = lib.scamd_fuzzy_merge_rows_f32(ptr(knn_idx), ptr(w), n, k, ptr(in_indptr), ptr(in_src), ptr(in_w), ptr(indptr),
+                                        ptr(indices), ptr(data), cap, C.byref(nnz), ptr(ws), wsz, stream_ptr())
+    _lib.check(rc, "scamd_fuzzy_merge_rows_f32")
+    return indptr, indices[: nnz.value], data[: nnz.value]
+
+
 def _knn_graph(entry: str, knn_idx: torch.Tensor, knn_dist: torch.Tensor | None):
     """shared driver of the gauss / jaccard connectivity kernels -> (indptr int64, indices int32, data float32)"""
     dev = require_gpu()

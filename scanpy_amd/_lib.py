@@ -24,6 +24,9 @@ SIGNATURES = {
     "scamd_knn_last_select_pairs": (_f64, []),
     "scamd_fuzzy_workspace_bytes": (_sz, [_i64, _i32]),
     "scamd_fuzzy_simplicial_set_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp, C.POINTER(_i64), _vp, _sz, _vp]),
+    "scamd_fuzzy_weights_f32": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "scamd_fuzzy_merge_workspace_bytes": (_sz, [_i64, _i64]),
+    "scamd_fuzzy_merge_rows_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), _vp, _sz, _vp]),
     "scamd_gauss_connectivities_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, C.POINTER(_i64), _vp, _sz, _vp]),
     "scamd_jaccard_connectivities_f32": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, C.POINTER(_i64), _vp, _sz, _vp]),
     "scamd_csr_row_stats_f32": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),

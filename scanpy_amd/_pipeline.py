@@ -4,10 +4,13 @@ Everything stays in HBM between stages; the AnnData front-ends (`pp.pca`, `pp.ne
 are host-side wrappers around the same stage functions.
 
 Row sharding: rank r owns the contiguous cell block [row_begin, row_end).
-  pca        all-reduce of g x b float64 panels (<= 1 MB)            -> scores stay sharded
-  neighbors  all-gather of the n x 50 embedding (200 MB at 1M cells) -> each rank answers its own queries
-  graph      all-gather of the kNN lists (n x k x 12 B)              -> fuzzy set + Leiden on rank 0
-  leiden     does not shard (global community totals, order dependent): runs on rank 0, labels broadcast
+  pca        all-reduce of the int64 Gram matrix (32 MB at 2000 genes) -> scores stay sharded
+  neighbors  all-gather of the n x 50 embedding (200 MB at 1M cells)   -> each rank answers its own queries
+  graph      every rank: membership strengths of its own rows; all-to-all of the directed edges (j, i, w_ij) to the
+             owner of row j (12 B per edge, E / P edges per rank); every rank merges its rows of
+             C = W + W^T - W o W^T -- bit for bit the rows the single-device kernel produces
+  leiden     does not shard (global community totals, order dependent): the CSR pieces are sent to rank 0, which
+             runs it; labels broadcast
 """
 from __future__ import annotations
 
@@ -84,6 +87,103 @@ def _all_gather_rows(t: torch.Tensor, comm, counts: list[int]) -> torch.Tensor:
     return torch.cat([buf[r * mx: r * mx + c] for r, c in enumerate(counts)], dim=0)
 
 
+def _staged(t: torch.Tensor, group) -> bool:
+    """device tensors under gloo (validation runs with several ranks on one GPU) go through host memory"""
+    import torch.distributed as dist
+
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_to_all_rows(send: torch.Tensor, send_counts: list[int], group) -> torch.Tensor:
+    """variable-sized all-to-all of the rows of `send` [m, c] (rows grouped by destination rank, `send_counts` rows
+    each): one collective for the counts, one for the payload (RCCL all-to-all over xGMI; gloo in the CPU tests)"""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    dev = send.device
+    staged = _staged(send, group)
+    cdev = torch.device("cpu") if staged else dev
+    sc = torch.tensor(send_counts, dtype=torch.int64, device=cdev)
+    rc = torch.empty(world, dtype=torch.int64, device=cdev)
+    dist.all_to_all_single(rc, sc, group=group)
+    recv_counts = [int(v) for v in rc.tolist()]
+    src = send.cpu() if staged else send.contiguous()
+    out = torch.empty((sum(recv_counts), send.shape[1]), dtype=send.dtype, device=cdev)
+    dist.all_to_all_single(out, src, output_split_sizes=recv_counts, input_split_sizes=list(send_counts), group=group)
+    return out.to(dev) if staged else out
+
+
+def _send(t: torch.Tensor, dst: int, group) -> None:
+    import torch.distributed as dist
+
+    dist.send(t.cpu() if _staged(t, group) else t.contiguous(), dst=dst, group=group)
+
+
+def _recv(shape, dtype, dev, src: int, group) -> torch.Tensor:
+    import torch.distributed as dist
+
+    staged = dev.type == "cuda" and dist.get_backend(group) == "gloo"
+    buf = torch.empty(shape, dtype=dtype, device="cpu" if staged else dev)
+    dist.recv(buf, src=src, group=group)
+    return buf.to(dev) if staged else buf
+
+
+def sharded_fuzzy_rows(idx: torch.Tensor, dist32: torch.Tensor, comm, counts: list[int], row_begin: int, n_total: int):
+    """This rank's rows of the symmetric fuzzy graph: local membership strengths, all-to-all of the
+    directed edges to the owners of their targets, local merge.  -> (indptr [n_local + 1], indices (global), data)"""
+    import numpy as np
+
+    group = getattr(comm, "group", None)
+    dev = idx.device
+    n_local, k = idx.shape
+    total = dist32.to(torch.float64).sum().reshape(1)
+    comm.allreduce_(total)  # the only global quantity of smooth_knn_dist: the mean of ALL distances
+    w = _kernels.fuzzy_weights(idx, dist32, row_begin, n_total, total)
+    mask = w > 0
+    rows = torch.arange(row_begin, row_begin + n_local, device=dev, dtype=torch.int32)[:, None].expand(-1, k)
+    j, i, ww = idx[mask].to(torch.int32), rows[mask], w[mask]
+    ends = torch.from_numpy(np.cumsum(counts)).to(dev)
+    dest = torch.bucketize(j.to(torch.int64), ends, right=True)  # owner of row j
+    order = torch.argsort(dest, stable=True)
+    send = torch.stack([j[order], i[order], ww[order].view(torch.int32)], dim=1).contiguous()  # (j, i, w_ij) as int32 x 3
+    send_counts = torch.bincount(dest, minlength=comm.world_size).tolist()
+    recv = _all_to_all_rows(send, send_counts, group)
+    jl = recv[:, 0].to(torch.int64) - row_begin
+    src = recv[:, 1].contiguous()
+    order2 = torch.argsort(jl * n_total + src.to(torch.int64))  # by (row, source): the merge kernel bisects the sources
+    in_indptr = torch.zeros(n_local + 1, dtype=torch.int64, device=dev)
+    in_indptr[1:] = torch.cumsum(torch.bincount(jl, minlength=n_local), dim=0)
+    return _kernels.fuzzy_merge_rows(idx, w, in_indptr, src[order2], recv[:, 2].contiguous().view(torch.float32)[order2])
+
+
+def _gather_csr_rows_to_root(indptr, indices, data, comm, n_total: int):
+    """rank 0 receives every rank's CSR rows and stitches the n_total-row matrix together; the others return None"""
+    import torch.distributed as dist
+
+    group = getattr(comm, "group", None)
+    dev = indices.device
+    staged = _staged(indices, group)
+    nnz = torch.tensor([int(indices.numel())], dtype=torch.int64, device="cpu" if staged else dev)
+    all_nnz = [torch.zeros_like(nnz) for _ in range(comm.world_size)]
+    dist.all_gather(all_nnz, nnz, group=group)
+    rowcnt = (indptr[1:] - indptr[:-1]).to(torch.int32)
+    if comm.rank != 0:
+        _send(rowcnt, 0, group)
+        _send(indices, 0, group)
+        _send(data, 0, group)
+        return None, None, None
+    rc, ix, dv = [rowcnt], [indices], [data]
+    for r in range(1, comm.world_size):
+        lo, hi = shard_bounds(n_total, comm.world_size, r)
+        m = int(all_nnz[r].item())
+        rc.append(_recv((hi - lo,), torch.int32, dev, r, group))
+        ix.append(_recv((m,), torch.int32, dev, r, group))
+        dv.append(_recv((m,), torch.float32, dev, r, group))
+    ci = torch.zeros(n_total + 1, dtype=torch.int64, device=dev)
+    ci[1:] = torch.cumsum(torch.cat(rc).to(torch.int64), dim=0)
+    return ci, torch.cat(ix), torch.cat(dv)
+
+
 def shard_bounds(n_total: int, world_size: int, rank: int) -> tuple[int, int]:
     """Contiguous, balanced row blocks: the first n_total % world_size ranks get one extra row."""
     base, rem = divmod(n_total, world_size)
@@ -113,15 +213,17 @@ def run_path(a_handle, n_total: int, *, comm=None, backend=None, n_comps: int = 
     k = min(n_neighbors, n_total)
     idx, dist, n_fallback = _kernels.knn(emb, k, q_begin=row_begin, n_query=row_end - row_begin)
     tm.mark("knn")
-    idx_all = _all_gather_rows(idx, comm, counts)
-    dist_all = _all_gather_rows(dist.to(torch.float32), comm, counts)
     dev = emb.device
     labels = torch.empty(n_total, dtype=torch.int32, device=dev)
     q, nc = 0.0, 0
     ci = cx = cd = None
+    if world == 1:
+        ci, cx, cd, _, _ = _kernels.fuzzy_simplicial_set(idx, dist.to(torch.float32))
+    else:
+        li, lx, ld = sharded_fuzzy_rows(idx, dist.to(torch.float32), comm, counts, row_begin, n_total)
+        ci, cx, cd = _gather_csr_rows_to_root(li, lx, ld, comm, n_total)
+    tm.mark("connectivities")
     if rank == 0:
-        ci, cx, cd, _, _ = _kernels.fuzzy_simplicial_set(idx_all, dist_all)
-        tm.mark("connectivities")
         labels, q, nc = _kernels.leiden(ci, cx, cd, n_total, resolution=resolution, n_iterations=n_iterations, seed=seed)
         tm.mark("leiden")
     if world > 1:

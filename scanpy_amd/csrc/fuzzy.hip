@@ -25,12 +25,15 @@ __global__ void fss_sum_kernel(const float* __restrict__ d, int64_t total, doubl
 }
 
 // one thread per row
+// (row shards: the rows are rows row_begin .. row_begin + n - 1 of an n_total-row problem; idx holds GLOBAL row ids and
+// *sum_all is the sum of all n_total * k distances)
 __global__ void fss_sigma_kernel(const int* __restrict__ idx, const float* __restrict__ dist, int64_t n,
                                  int k, const double* __restrict__ sum_all, float* __restrict__ sigma_out,
                                  float* __restrict__ rho_out, float* __restrict__ w,
-                                 int* __restrict__ outcnt) {
+                                 int* __restrict__ outcnt, int64_t row_begin, int64_t n_total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const int self_id = (int)(row_begin + i);
   const float* di = dist + i * k;
   const int* ii = idx + i * k;
   float rho = 0.f;
@@ -68,7 +71,7 @@ __global__ void fss_sigma_kernel(const int* __restrict__ idx, const float* __res
     double mean_i = rowsum / (double)k;
     if ((double)sigma < 1e-3 * mean_i) sigma = (float)(1e-3 * mean_i);
   } else {
-    double mean_all = *sum_all / ((double)n * (double)k);
+    double mean_all = *sum_all / ((double)n_total * (double)k);
     if ((double)sigma < 1e-3 * mean_all) sigma = (float)(1e-3 * mean_all);
   }
   if (sigma_out) sigma_out[i] = sigma;
@@ -78,7 +81,7 @@ __global__ void fss_sigma_kernel(const int* __restrict__ idx, const float* __res
     int t = ii[j];
     float val;
     float df = __fsub_rn(di[j], rho);
-    if (t == (int)i || t < 0) val = 0.f;
+    if (t == self_id || t < 0) val = 0.f;
     else if (df <= 0.f || sigma == 0.f) val = 1.f;
     else val = (float)exp(-(double)__fdiv_rn(df, sigma));  // correctly rounded, keeps float32 subnormals
     w[i * k + j] = val;
@@ -327,9 +330,129 @@ extern "C" int scamd_fuzzy_simplicial_set_f32(const int32_t* knn_idx, const floa
     SCAMD_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(fss_sigma_kernel, dim3(ceil_div(n, 128)), dim3(128), 0, s, knn_idx, knn_dist, n, k, b.sum,
-                     out_sigma, out_rho, b.w, b.outcnt);
+                     out_sigma, out_rho, b.w, b.outcnt, (int64_t)0, n);
   SCAMD_LAUNCH_CHECK();
   return symmetrise(b, knn_idx, n, k, 0, out_indptr, out_indices, out_data, nnz_host, s);
+}
+
+// ---- row-sharded fuzzy set ("symmetrisation needs one more all-to-all of (j, i, w) triples") ----------
+// Rank r owns rows [row_begin, row_begin + n_local).  1. scamd_fuzzy_weights_f32: sigma / rho / membership strengths of
+// its own rows (the only global quantity is the sum of all distances, one all-reduced double).  2. The caller sends every
+// directed edge (i -> j, w_ij > 0) to the owner of row j (all-to-all) and sorts what it receives by (row, source).
+// 3. scamd_fuzzy_merge_rows_f32: C[i][j] = w_ij + w_ji - w_ij w_ji over the union of row i's out- and in-edges, float32
+// with one rounding per operation -- the same expression, hence the same bits, as the single-device kernel.
+extern "C" int scamd_fuzzy_weights_f32(const int32_t* knn_idx, const float* knn_dist, int64_t n_local, int k,
+                                       int64_t row_begin, int64_t n_total, const double* sum_all_dev, float* w,
+                                       float* out_sigma, float* out_rho, int32_t* out_count, scamd_stream_t stream) {
+  SCAMD_REQUIRE(knn_idx && knn_dist && sum_all_dev && w && out_count, SCAMD_EINVAL, "fuzzy_weights: null pointer");
+  SCAMD_REQUIRE(n_local >= 0 && k >= 2 && k <= 1024 && row_begin >= 0 && row_begin + n_local <= n_total &&
+                    n_total < ((int64_t)1 << 31),
+                SCAMD_EINVAL, "fuzzy_weights: bad shape");
+  if (n_local == 0) return SCAMD_OK;
+  hipLaunchKernelGGL(fss_sigma_kernel, dim3(ceil_div(n_local, 128)), dim3(128), 0, stream, knn_idx, knn_dist, n_local, k,
+                     sum_all_dev, out_sigma, out_rho, w, out_count, row_begin, n_total);
+  SCAMD_LAUNCH_CHECK();
+  return SCAMD_OK;
+}
+
+namespace scamd {
+// entries of the merged row: the out-edges with w > 0, then the in-edges whose source is not among them
+__global__ void fss_merge_count_kernel(const int* __restrict__ idx, const float* __restrict__ w, int64_t n, int k,
+                                       const int64_t* __restrict__ in_indptr, const int* __restrict__ in_src,
+                                       int* __restrict__ rowcnt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int cnt = 0;
+  for (int j = 0; j < k; ++j) cnt += (w[i * k + j] > 0.f) ? 1 : 0;
+  for (int64_t e = in_indptr[i]; e < in_indptr[i + 1]; ++e) {
+    const int src = in_src[e];
+    bool found = false;
+    for (int j = 0; j < k; ++j) found |= (w[i * k + j] > 0.f && idx[i * k + j] == src);
+    cnt += found ? 0 : 1;
+  }
+  rowcnt[i] = cnt;
+}
+__global__ void fss_merge_fill_kernel(const int* __restrict__ idx, const float* __restrict__ w, int64_t n, int k,
+                                      const int64_t* __restrict__ in_indptr, const int* __restrict__ in_src,
+                                      const float* __restrict__ in_w, const int64_t* __restrict__ out_indptr,
+                                      int* __restrict__ tmp_col, float* __restrict__ tmp_val) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t p = out_indptr[i];
+  const int64_t e0 = in_indptr[i], e1 = in_indptr[i + 1];
+  for (int j = 0; j < k; ++j) {
+    const float we = w[i * k + j];
+    if (!(we > 0.f)) continue;
+    const int t = idx[i * k + j];
+    float r = 0.f;  // reverse weight: binary search of t among the (ascending) sources of the in-edges
+    int64_t lo = e0, hi = e1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (in_src[mid] < t) lo = mid + 1;
+      else hi = mid;
+    }
+    if (lo < e1 && in_src[lo] == t) r = in_w[lo];
+    tmp_col[p] = t;
+    tmp_val[p] = __fsub_rn(__fadd_rn(we, r), __fmul_rn(we, r));
+    ++p;
+  }
+  for (int64_t e = e0; e < e1; ++e) {
+    const int src = in_src[e];
+    bool found = false;
+    for (int j = 0; j < k; ++j) found |= (w[i * k + j] > 0.f && idx[i * k + j] == src);
+    if (!found) {
+      tmp_col[p] = src;
+      tmp_val[p] = in_w[e];
+      ++p;
+    }
+  }
+}
+}  // namespace scamd
+
+extern "C" size_t scamd_fuzzy_merge_workspace_bytes(int64_t n_local, int64_t cap) {
+  if (n_local < 0 || cap < 0) return 0;
+  Workspace ws(nullptr, 0);
+  (void)ws.take<int>((size_t)n_local + 1);
+  (void)ws.take<int64_t>((size_t)scan_num_blocks(std::max<int64_t>(n_local, 1)) + 2);
+  (void)ws.take<int>((size_t)cap);
+  (void)ws.take<float>((size_t)cap);
+  return ws.used();
+}
+
+extern "C" int scamd_fuzzy_merge_rows_f32(const int32_t* knn_idx, const float* w, int64_t n_local, int k,
+                                          const int64_t* in_indptr, const int32_t* in_src, const float* in_w,
+                                          int64_t* out_indptr, int32_t* out_indices, float* out_data, int64_t cap,
+                                          int64_t* nnz_host, void* workspace, size_t workspace_bytes,
+                                          scamd_stream_t stream) {
+  SCAMD_REQUIRE(knn_idx && w && in_indptr && out_indptr && out_indices && out_data && nnz_host, SCAMD_EINVAL,
+                "fuzzy_merge: null pointer");
+  SCAMD_REQUIRE(n_local >= 1 && k >= 2 && k <= 1024 && cap >= 0, SCAMD_EINVAL, "fuzzy_merge: bad shape");
+  Workspace ws(workspace, workspace_bytes);
+  int* rowcnt = ws.take<int>((size_t)n_local + 1);
+  int64_t* scan_tmp = ws.take<int64_t>((size_t)scan_num_blocks(n_local) + 2);
+  int* tmp_col = ws.take<int>((size_t)cap);
+  float* tmp_val = ws.take<float>((size_t)cap);
+  SCAMD_REQUIRE(workspace && ws.ok, SCAMD_EWORKSPACE, "fuzzy_merge: workspace %zu < required %zu", workspace_bytes, ws.used());
+  hipStream_t s = stream;
+  hipLaunchKernelGGL(fss_merge_count_kernel, dim3(ceil_div(n_local, 128)), dim3(128), 0, s, knn_idx, w, n_local, k,
+                     in_indptr, in_src, rowcnt);
+  SCAMD_LAUNCH_CHECK();
+  int rc = exclusive_scan_i32_i64(rowcnt, n_local, out_indptr, scan_tmp, s);
+  if (rc != SCAMD_OK) return rc;
+  int64_t nnz = 0;
+  SCAMD_HIP_CHECK(hipMemcpyAsync(&nnz, out_indptr + n_local, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+  SCAMD_REQUIRE(nnz <= cap, SCAMD_ECAPACITY, "fuzzy_merge: %lld entries exceed the capacity %lld", (long long)nnz,
+                (long long)cap);
+  hipLaunchKernelGGL(fss_merge_fill_kernel, dim3(ceil_div(n_local, 128)), dim3(128), 0, s, knn_idx, w, n_local, k,
+                     in_indptr, in_src, in_w, out_indptr, tmp_col, tmp_val);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(fss_sortrows_kernel, dim3(ceil_div(n_local, 4)), dim3(256), 0, s, out_indptr, n_local, tmp_col,
+                     tmp_val, out_indices, out_data);
+  SCAMD_LAUNCH_CHECK();
+  *nnz_host = nnz;
+  SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+  return SCAMD_OK;
 }
 
 static int check_graph_args(const char* what, const int32_t* knn_idx, const void* knn_dist_or_idx, int64_t n, int k,

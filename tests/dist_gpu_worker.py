@@ -40,7 +40,9 @@ def run(rank: int, world: int, init_file: str, out_dir: str, n: int, g: int, n_c
     np.savez(Path(out_dir) / f"gpu_rank{rank}_of{world}.npz", scores=res.x_pca.cpu().numpy(), components=res.components,
              variance=res.variance, knn_idx=res.knn_indices.cpu().numpy(), knn_dist=res.knn_distances.cpu().numpy(),
              labels=res.labels.cpu().numpy(), q=res.modularity, nc=res.n_communities, lo=lo, hi=hi,
-             has_graph=res.conn_indptr is not None)
+             has_graph=res.conn_indptr is not None,
+             **({"conn_indptr": res.conn_indptr.cpu().numpy(), "conn_indices": res.conn_indices.cpu().numpy(),
+                 "conn_data": res.conn_data.cpu().numpy()} if res.conn_indptr is not None else {}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -47,8 +47,42 @@ def _patch_kernels():
         memb, q = ol.leiden(adj, resolution=resolution, n_iterations=n_iterations, seed=seed)
         return torch.from_numpy(memb.astype(np.int32)), q, int(memb.max()) + 1
 
+    def fuzzy_weights(knn_idx, knn_dist, row_begin, n_total, sum_all):
+        """membership strengths of a row shard (CPU stand-in of scamd_fuzzy_weights_f32)"""
+        idx = knn_idx.numpy()
+        d = knn_dist.numpy().astype(np.float32)
+        n, k = idx.shape
+        sig, rho = oc.smooth_knn_dist_vec(d, k)  # (the global mean only matters for rows without a positive distance)
+        # compute_membership_strengths zeroes the entries equal to the LOCAL row number (and -1 = missing): map the own
+        # global id to the local one and every other id to a value that is neither
+        self_local = np.where(idx == (row_begin + np.arange(n))[:, None], np.arange(n)[:, None], n_total + 7)
+        _, _, val = oc.compute_membership_strengths(self_local, d, sig, rho)
+        return torch.from_numpy(val.reshape(n, k).astype(np.float32))
+
+    def fuzzy_merge_rows(knn_idx, w, in_indptr, in_src, in_w):
+        """W + W^T - W o W^T on the local rows from out-edges and received in-edges (stand-in of the merge kernel)"""
+        idx, wv = knn_idx.numpy(), w.numpy()
+        ip, src, win = in_indptr.numpy(), in_src.numpy(), in_w.numpy()
+        n, k = idx.shape
+        indptr, cols, vals = [0], [], []
+        for i in range(n):
+            out = {int(idx[i, j]): np.float32(wv[i, j]) for j in range(k) if wv[i, j] > 0}
+            inn = {int(src[e]): np.float32(win[e]) for e in range(ip[i], ip[i + 1])}
+            row = {}
+            for c in set(out) | set(inn):
+                a, b = out.get(c, np.float32(0)), inn.get(c, np.float32(0))
+                row[c] = np.float32(np.float32(a + b) - np.float32(a * b))
+            for c in sorted(row):
+                cols.append(c)
+                vals.append(row[c])
+            indptr.append(len(cols))
+        return (torch.from_numpy(np.asarray(indptr, dtype=np.int64)), torch.from_numpy(np.asarray(cols, dtype=np.int32)),
+                torch.from_numpy(np.asarray(vals, dtype=np.float32)))
+
     _kernels.knn = knn
     _kernels.fuzzy_simplicial_set = fuzzy_simplicial_set
+    _kernels.fuzzy_weights = fuzzy_weights
+    _kernels.fuzzy_merge_rows = fuzzy_merge_rows
     _kernels.leiden = leiden
 
 
@@ -88,6 +122,8 @@ def run(rank: int, world: int, init_file: str, out_dir: str, n: int, g: int, n_c
         out = dict(scores=res.x_pca.numpy(), knn_idx=res.knn_indices.numpy(), knn_dist=res.knn_distances.numpy(),
                    labels=res.labels.numpy(), q=res.modularity, nc=res.n_communities, lo=lo, hi=hi,
                    has_graph=res.conn_indptr is not None)
+        if res.conn_indptr is not None:
+            out.update(conn_indptr=res.conn_indptr.numpy(), conn_indices=res.conn_indices.numpy(), conn_data=res.conn_data.numpy())
     np.savez(Path(out_dir) / f"rank{rank}_of{world}.npz", **out)
     if world > 1:
         dist.barrier()

@@ -40,6 +40,10 @@ def test_ranks_sharing_one_gpu_match_single_rank(tmp_path, world):
     np.testing.assert_array_equal(dist, one["knn_dist"])
     # graph + Leiden on rank 0 only, labels broadcast: identical to the single-rank labels
     assert bool(many[0]["has_graph"]) and not any(bool(r["has_graph"]) for r in many[1:])
+    # the graph itself: per-rank membership strengths + all-to-all of the directed edges + per-rank merge give the rows of
+    # the single-device fuzzy set bit for bit (same float32 expression on the same operands)
+    for key in ("conn_indptr", "conn_indices", "conn_data"):
+        np.testing.assert_array_equal(many[0][key], one[key], err_msg=key)
     for r in many:
         np.testing.assert_array_equal(r["labels"], one["labels"])
         assert int(r["nc"]) == int(one["nc"]) and float(r["q"]) == float(one["q"])

@@ -69,6 +69,15 @@ def test_full_path_two_ranks_matches_one(tmp_path):
     np.testing.assert_array_equal(two[0]["labels"], two[1]["labels"])
     assert adjusted_rand_score(two[0]["labels"], one["labels"]) > 0.99
     assert int(two[1]["nc"]) == int(two[0]["nc"]) and abs(float(two[1]["q"]) - float(two[0]["q"])) < 1e-12
+    # the graph rank 0 assembled from the two ranks' rows (membership strengths per shard, all-to-all of the directed
+    # edges, local merge) is the single-process graph: same pattern, same values
+    from oracle import connectivities as oc
+
+    ref, _, _ = oc.fuzzy_simplicial_set(idx, dist.astype(np.float32), n, k)  # from the two ranks' own kNN lists
+    ref.sort_indices()
+    np.testing.assert_array_equal(two[0]["conn_indptr"], ref.indptr)
+    np.testing.assert_array_equal(two[0]["conn_indices"], ref.indices)
+    np.testing.assert_allclose(two[0]["conn_data"], ref.data, rtol=0, atol=1e-6)
 
 
 def test_full_path_two_ranks_streaming_their_blocks_from_a_zarr_store(tmp_path, monkeypatch):
