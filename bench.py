@@ -13,7 +13,8 @@ timed region ends with the labels on the device.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
   roofline      knn_select_reg_kernel (FP32 MFMA): achieved = 2 * 50 flop per evaluated (query, candidate) pair
-                (scamd_knn_last_select_pairs; the exact cell-pruned search skips provably empty cells) / its HIP-event
+                (scamd_knn_last_select_pairs: the pairs of the swept cells, WITHOUT the threshold pre-pass that re-scores
+                every block's own cell; the exact cell-pruned search skips provably empty cells) / its HIP-event
                 duration (scamd_knn_last_select_ms), peak = 157.3 TFLOP/s (MI355X_MICROARCH.md).
   value_host_to_host   the BASELINE metric at the drop-in boundary: AnnData with a host CSR in -> sc.pp.pca /
                 sc.pp.neighbors / sc.tl.leiden -> slots written on the host (H2D, kernels, D2H, scipy / pandas slot
@@ -275,12 +276,14 @@ def noise_variant(args, backend, kw) -> dict:
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3
     sel, pairs = float(lib.scamd_knn_last_select_ms()), float(lib.scamd_knn_last_select_pairs())
+    pre = float(lib.scamd_knn_last_select_prepass_pairs())
     brute = float(args.n_obs) ** 2
     tf = 2.0 * pairs * args.n_comps / (sel * 1e-3) / 1e12 if sel > 0 else None
     return {"note": "same shape, p_programme = 0 (i.i.d. genes): PCA spectrum without a gap, kNN without prunable cells; "
                     "1 warm-up + 1 timed step, outside `value`",
             "ms_per_step": ms, "cells_per_s": args.n_obs / (ms * 1e-3), "stage_ms": res.stage_ms,
-            "pairs_evaluated_fraction": pairs / brute, "knn_select_ms": sel, "knn_select_tflops": tf,
+            "pairs_evaluated_fraction": pairs / brute, "prepass_pairs_fraction_of_useful": pre / pairs if pairs else None,
+            "knn_select_ms": sel, "knn_select_tflops": tf,
             "knn_select_frac_of_157.3": tf / 157.3 if tf else None, "n_communities": res.n_communities,
             "modularity": res.modularity, "pca_info": {k: v for k, v in res.info.items() if k != "knn_fallback_queries"}}
 
@@ -442,13 +445,14 @@ def main() -> None:
     for _ in range(args.warmup):
         run_path(handle, n, **kw)
     lib = _lib.load()
-    select_ms, select_pairs, stage_acc, res = [], [], {}, None
+    select_ms, select_pairs, prepass_pairs, stage_acc, res = [], [], [], {}, None
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = run_path(handle, n, timing=True, **kw)
         select_ms.append(float(lib.scamd_knn_last_select_ms()))
         select_pairs.append(float(lib.scamd_knn_last_select_pairs()))
+        prepass_pairs.append(float(lib.scamd_knn_last_select_prepass_pairs()))
         for kname, v in res.stage_ms.items():
             stage_acc[kname] = stage_acc.get(kname, 0.0) + v
     sync_all()
@@ -508,6 +512,10 @@ def main() -> None:
                 "launch_ms": sel,
                 "algorithmic_flop_per_launch": flops,
                 "pairs_evaluated_fraction": pairs / brute_pairs if brute_pairs > 0 else None,
+                # executed but not useful: the threshold pre-pass re-scores every block's own cell; NOT in `achieved`
+                "prepass_pairs_fraction_of_useful": (sum(prepass_pairs) / max(len(prepass_pairs), 1)) / pairs if pairs > 0 else None,
+                "executed_tflops_incl_prepass": (2.0 * (pairs + sum(prepass_pairs) / max(len(prepass_pairs), 1)) * args.n_comps
+                                                 / (sel * 1e-3) / 1e12) if sel > 0 else None,
                 "brute_force_equivalent_tflops": 2.0 * brute_pairs * args.n_comps / (sel * 1e-3) / 1e12 if sel > 0 else None,
             },
             "stage_ms_per_step": {kname: v / max(args.steps, 1) for kname, v in stage_acc.items()},

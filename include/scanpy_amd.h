@@ -76,8 +76,12 @@ int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x,
  * recent scamd_knn_l2_f32 call; -1 if none.  Used by bench.py for the roofline figure. */
 float scamd_knn_last_select_ms(void);
 /* (query, candidate) pairs that call's selection kernel evaluated: n_query * n for the brute-force sweep, fewer when
- * the cell-pruned search (n >= 65536) could skip far cells; -1 if none.  Executed flop = 2 * d * pairs. */
+ * the cell-pruned search (n >= 65536) could skip far cells (the threshold pre-pass not included); -1 if none.
+ * Useful flop = 2 * d * pairs. */
 double scamd_knn_last_select_pairs(void);
+/* Pairs the same kernel evaluated in its threshold pre-pass (the own cell of every block, scored once more only to seed
+ * the list thresholds): executed by the kernel, NOT useful work -- kept out of the roofline's algorithmic flop. */
+double scamd_knn_last_select_prepass_pairs(void);
 
 /* ------------------------------------------------------------------------------------------
  * Fuzzy simplicial set -- umap connectivities from a kNN result.

@@ -26,6 +26,7 @@
 
 static thread_local float g_last_select_ms = -1.f;
 static thread_local double g_last_select_pairs = -1.0;
+static thread_local double g_last_select_prepass_pairs = -1.0;
 
 namespace scamd {
 
@@ -674,7 +675,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     {
       minima = true;
       const int pre_tiles = min(iv.cell_ntiles[a], 48);
-      if (tid == 0) atomicAdd(iv.pairs, (unsigned long long)pre_tiles * TC * C::QB);  // evaluated pairs, counted
+      if (tid == 0) atomicAdd(iv.pairs + 1, (unsigned long long)pre_tiles * TC * C::QB);  // counted apart: not useful work
       sweep(iv.cell_tile0[a], pre_tiles, false);
       minima = false;
       __syncthreads();
@@ -1296,7 +1297,7 @@ static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffe
   b->cand_tau = ws.take<float>((size_t)p.nq_pad);
   b->kth_d2 = ws.take<double>((size_t)n_query);
   b->flag_list = ws.take<int>((size_t)n_query);
-  b->counters = ws.take<int>(4);
+  b->counters = ws.take<int>(8);  // [0] uncertified, [1] overflow, [2..3] swept pairs, [4..5] pre-pass pairs (u64)
   b->scratch_d = ws.take<double>((size_t)FALLBACK_CHUNK * FALLBACK_CAP);
   b->scratch_i = ws.take<int>((size_t)FALLBACK_CHUNK * FALLBACK_CAP);
   b->fb_counts = ws.take<int>((size_t)FALLBACK_CHUNK);
@@ -1491,7 +1492,7 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   SCAMD_HIP_CHECK(hipMemsetAsync(b.perm, 0xff, sizeof(int) * rows, s));
   SCAMD_HIP_CHECK(hipMemsetAsync(b.qpos, 0xff, sizeof(int) * slots, s));
   SCAMD_HIP_CHECK(hipMemsetAsync(b.radius_bits, 0, sizeof(unsigned int) * nc, s));
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 2, 0, 8, s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 2, 0, 16, s));
   SCAMD_HIP_CHECK(hipStreamSynchronize(s));  // the host vectors above must outlive their copies
   // 4. cell-sorted image
   hipLaunchKernelGGL(ivf_scatter_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, b.labels, n, cell_map, row_off,
@@ -1588,6 +1589,7 @@ using namespace scamd;
 
 extern "C" float scamd_knn_last_select_ms(void) { return g_last_select_ms; }
 extern "C" double scamd_knn_last_select_pairs(void) { return g_last_select_pairs; }
+extern "C" double scamd_knn_last_select_prepass_pairs(void) { return g_last_select_prepass_pairs; }
 
 extern "C" size_t scamd_knn_workspace_bytes(int64_t n, int d, int64_t n_query, int k) {
   KnnPlan p;
@@ -1623,7 +1625,7 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
   hipStream_t s = stream;
 
   SCAMD_HIP_CHECK(hipMemsetAsync(b.cmax, 0, 16, s));
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, 16, s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, 32, s));
   hipLaunchKernelGGL(knn_colsum_kernel, dim3(MEAN_BLOCKS), dim3(256), 0, s, x, n, d, ld_x, b.mean_partial);
   SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(knn_colmean_kernel, dim3(1), dim3(128), 0, s, b.mean_partial, n, d, b.mu);
@@ -1668,8 +1670,8 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
 #undef RERANK
     SCAMD_LAUNCH_CHECK();
   }
-  int h_counters[4] = {0, 0, 0, 0};
-  SCAMD_HIP_CHECK(hipMemcpyAsync(h_counters, b.counters, 16, hipMemcpyDeviceToHost, s));
+  int h_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  SCAMD_HIP_CHECK(hipMemcpyAsync(h_counters, b.counters, 32, hipMemcpyDeviceToHost, s));
   SCAMD_HIP_CHECK(hipStreamSynchronize(s));
   {
     float ms = -1.f;
@@ -1680,6 +1682,9 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
     unsigned long long pairs = 0;
     memcpy(&pairs, &h_counters[2], 8);
     g_last_select_pairs = p.ivf ? (double)pairs : (double)n_query * (double)n;
+    unsigned long long pre = 0;
+    memcpy(&pre, &h_counters[4], 8);
+    g_last_select_prepass_pairs = p.ivf ? (double)pre : 0.0;
   }
   const int n_flag = h_counters[0];
   if (n_fallback_host) *n_fallback_host = n_flag;

@@ -436,6 +436,9 @@ __global__ __launch_bounds__(256) void ld_move_kernel(
       target = best.c;
       const unsigned int pa = prio(a, seed), pb = best.pr;
       allowed = (round & 1) ? (pb > pa || (pb == pa && target > a)) : (pb < pa || (pb == pa && target < a));
+      // (Measured dead end, round 2: applying this rule only to singleton <-> singleton moves -- the Grappolo / Vite
+      // heuristic -- oscillates on kNN graphs: 282 instead of 49 rounds and 87 instead of 41 ms on the planted 1M graph,
+      // modularity 0.66 instead of 0.71 on the weak one.)
     } else if (stay < 0.0 && Ka_wo > 0.0 && csize[v] == 0) {
       // leaving for an empty community (id = own vertex id, free at the snapshot) beats staying
       wants = true;
@@ -1465,7 +1468,8 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
   int quiet = 0;
   const int lanes = level_lanes(g);
   const bool quad = lanes == 16;
-  for (int round = 0; round < MAX_LM_ROUNDS && n_act > 0; ++round) {
+  for (int rnd = 0; rnd < MAX_LM_ROUNDS && n_act > 0; ++rnd) {
+    const int round = rnd;
     SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
     if (lanes == 32) {
       hipLaunchKernelGGL(ld_move_kernel<32>, dim3((unsigned)ceil_div(n_act, 8)), dim3(256), 0, cx.s, n_act, b.list_a,
@@ -1512,7 +1516,7 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
     rc = read_counters(cx, h, 8);
     if (rc != SCAMD_OK) return rc;
     SCAMD_REQUIRE(h[7] == 0, SCAMD_EINTERNAL, "leiden: hub table overflow (local moving)");
-    if (leiden_debug()) fprintf(stderr, "[leiden] lm n=%d round=%d act=%d moved=%d blocked=%d next=%d\n", g.n, round, n_act, h[0], h[1], h[2]);
+    if (leiden_debug()) fprintf(stderr, "[leiden] lm n=%d round=%d act=%d moved=%d blocked=%d next=%d\n", g.n, rnd, n_act, h[0], h[1], h[2]);
     std::swap(b.list_a, b.list_b);
     n_act = h[2];
     *total_moves += h[0];
@@ -1523,7 +1527,7 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
     // lm_stop_permille/1000 of the level's vertices move in a round, go on to refinement + aggregation (the
     // outer iterations repeat until nothing improves, so no move is lost, it is only made at a cheaper level).
     // (first outer iteration only: the later ones polish, and a level of theirs moves few vertices anyway)
-    if (cx.iter == 0 && round >= 1 && (long long)h[0] * 1000 < (long long)g.n * cx.lm_stop_permille) break;
+    if (cx.iter == 0 && rnd >= 1 && (long long)h[0] * 1000 < (long long)g.n * cx.lm_stop_permille) break;
   }
   return SCAMD_OK;
 }
