@@ -410,6 +410,7 @@ struct IvfArgs {
   const int* perm;          // [n_image_rows] original row id of an image row (-1 = padding)
   unsigned long long* pairs; // (query, candidate) pairs evaluated, for the roofline figure
   const int* block_perm;     // [n_blocks] launch slot -> block: cells with the longest expected sweep first (LPT)
+  int prepass_tiles;         // tiles of the own cell the threshold pre-pass scores (SCAMD_KNN_PREPASS_TILES, default 16)
   int debug_no_insert;       // debug (SCAMD_KNN_DEBUG_NO_INSERT=1): survivors are dropped -- WRONG results, MFMA-side ceiling
   unsigned long long* trace; // debug (SCAMD_KNN_TRACE=<file>): per block {start, end (100 MHz clock), tiles swept, hw id}
   int n_cells, dc;          // dc = stride of `centers` (>= d)
@@ -674,7 +675,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     // The real sweep then starts with that threshold: about half as many insertions in total.
     {
       minima = true;
-      const int pre_tiles = min(iv.cell_ntiles[a], 48);
+      const int pre_tiles = min(iv.cell_ntiles[a], iv.prepass_tiles);
       if (tid == 0) atomicAdd(iv.pairs + 1, (unsigned long long)pre_tiles * TC * C::QB);  // counted apart: not useful work
       sweep(iv.cell_tile0[a], pre_tiles, false);
       minima = false;
@@ -1544,6 +1545,10 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   iv.dc = d;
   iv.d = d;
   iv.block_perm = b.block_perm;
+  {
+    const char* e = getenv("SCAMD_KNN_PREPASS_TILES");
+    iv.prepass_tiles = e ? std::max(1, atoi(e)) : 16;  // measured at 1M: 48 -> 29.3 ms, 24 / 12 -> 29.0, 6 -> 29.6, 2 -> 30.2
+  }
   {
     const char* e = getenv("SCAMD_KNN_DEBUG_NO_INSERT");
     iv.debug_no_insert = (e && e[0] == '1') ? 1 : 0;

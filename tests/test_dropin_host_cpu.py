@@ -414,3 +414,68 @@ def test_counts_on_disk_to_clusters_without_materialising(sc, pbmc68k, tmp_path,
     sc.write_h5ad(tmp_path / "out.h5ad", b)  # X with pending transforms is materialised through the device backend
     back = sc.read_h5ad(tmp_path / "out.h5ad")
     assert (back.X != a.X).nnz == 0 and list(back.obs["leiden"]) == list(b.obs["leiden"])
+
+
+def test_pca_obsm_ignores_the_highly_variable_mask(monkeypatch):
+    """`pp.pca(adata, obsm='rep')` with a `highly_variable` column in `.var` must not slice the obsm
+    matrix with the var mask (the reference subsets the AnnData and then reads `obsm` unmasked,
+    src/scanpy/preprocessing/_pca/__init__.py:228-232); `params` still records the mask."""
+    import numpy as np
+    import pandas as pd
+    from scipy import sparse
+
+    import scanpy_amd as sc
+    from scanpy_amd.preprocessing import _pca as P
+    from scanpy_amd.preprocessing import _pca_solver as S
+    from stub_backend import CpuStubBackend
+
+    monkeypatch.setattr(S, "GpuBackend", CpuStubBackend)
+    rng = np.random.default_rng(0)
+    x = sparse.random(60, 30, density=0.3, random_state=1, format="csr", dtype=np.float32)
+    a = sc.AnnData(x)
+    a.var["highly_variable"] = rng.random(30) < 0.5
+    a.obsm["rep"] = rng.standard_normal((60, 12)).astype(np.float32)
+    P.pca(a, n_comps=5, obsm="rep")
+    assert a.obsm["X_pca"].shape == (60, 5)
+    assert a.uns["pca"]["params"]["mask_var"] == "highly_variable" and a.uns["pca"]["params"]["obsm"] == "rep"
+    assert a.uns["pca"]["components"].shape == (12, 5)
+    assert "PCs" not in a.varm
+
+
+def test_write_to_the_backing_file_keeps_the_data(tmp_path):
+    """`sc.write(p, sc.read(p, backed='r'))` used to truncate the file it was streaming from"""
+    import numpy as np
+    from scipy import sparse
+
+    import scanpy_amd as sc
+
+    x = sparse.random(200, 40, density=0.2, random_state=3, format="csr", dtype=np.float32)
+    for ext in ("h5ad", "zarr"):
+        p = tmp_path / f"same.{ext}"
+        sc.write(p, sc.AnnData(x))
+        b = sc.read(p, backed="r")
+        sc.write(p, b)
+        again = sc.read(p)
+        assert (again.X != x).nnz == 0
+        assert not [f for f in tmp_path.iterdir() if ".tmp" in f.name or ".old" in f.name]
+
+
+def test_anndata_copy_and_subset_carry_raw_and_varp():
+    """the stand-in AnnData dropped `raw` / `varp` on copy and never subset `raw` along obs"""
+    import numpy as np
+    from scipy import sparse
+
+    import scanpy_amd as sc
+
+    x = sparse.random(30, 8, density=0.5, random_state=0, format="csr", dtype=np.float32)
+    a = sc.AnnData(x)
+    a.raw = sc.AnnData(sparse.random(30, 20, density=0.5, random_state=1, format="csr", dtype=np.float32), a.obs)
+    a.varp["corr"] = np.eye(8)
+    a.obsp["g"] = sparse.identity(30, format="csr")
+    c = a.copy()
+    assert c.raw is not None and c.raw.X.shape == (30, 20) and "corr" in c.varp
+    keep = np.arange(30) % 3 == 0
+    a._inplace_subset_obs(keep)
+    assert a.raw.X.shape == (10, 20) and a.X.shape == (10, 8) and a.obsp["g"].shape == (10, 10)
+    sub = c[:, np.arange(8) < 4]
+    assert sub.obsp["g"].shape == (30, 30) and sub.varp["corr"].shape == (4, 4)
