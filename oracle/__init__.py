@@ -20,5 +20,11 @@ Pinning status (see DESIGN.md "Oracle"):
                        determinism, NMI>0.9 across flavors, and modularity).  `oracle/leiden.c`
                        restates Traag et al. 2019 with the call contract of
                        src/scanpy/tools/_leiden.py:166-196; modularity is cross-checked against
-                       networkx and planted partitions.
+                       networkx and planted partitions.  The one set of reference-PRODUCED labels in the
+                       tree anchors it (tests/test_gpu_parity_hard.py): the `louvain` column of the bundled
+                       fixture (src/scanpy/datasets/_datasets.py:349-427) -- NMI of the oracle's partition
+                       of the fixture's own graph against it 0.90 (0.93 at matched cluster count), above
+                       the reference's cross-implementation bar (tests/test_clustering.py:130-163).
+  * compare.py      -- the north-star gates (loadings 1e-4, kNN sets equal beyond ties, connectivities 1e-5,
+                       ARI 0.99) as functions, used by tests/ and by bench.py's `parity` leg.
 """
