@@ -272,6 +272,12 @@ int scamd_pp_log1p_f32(float* data, int64_t count, double base, scamd_stream_t s
 int scamd_pp_col_stats_f32(const int64_t* indptr, const int32_t* indices, const float* data, int64_t n, int64_t g,
                            int64_t nnz, const uint8_t* row_mask, int transform, double tscale, double* sum,
                            double* sumsq, uint64_t* npos /* may be NULL */, scamd_stream_t stream);
+/* The same sweep with every value clipped from above at clip[gene] (float64) before it is summed: `clip_square_sum` of
+ * flavor='seurat_v3' (src/scanpy/preprocessing/_highly_variable_genes.py:75-115: sum and sum of squares of
+ * min(x, sigma_hat * sqrt(n) + mu) per gene). */
+int scamd_pp_col_stats_clip_f32(const int64_t* indptr, const int32_t* indices, const float* data, int64_t n, int64_t g,
+                                int64_t nnz, const uint8_t* row_mask, const double* clip, double* sum, double* sumsq,
+                                scamd_stream_t stream);
 /* zero_center=False: x_rc = min(max_value, x_rc / std[c]) on the masked rows, sparsity kept: scale_and_clip_csr
  * (src/scanpy/preprocessing/_scale.py:280-295) */
 int scamd_pp_scale_csr_f32(const int64_t* indptr, const int32_t* indices, float* data, int64_t n, int64_t nnz,

@@ -385,6 +385,21 @@ def pp_col_stats(indptr, indices, data, n: int, g: int, *, row_mask: torch.Tenso
     return s, sq, npos
 
 
+def pp_col_stats_clip(indptr, indices, data, n: int, g: int, clip: torch.Tensor, *, row_mask: torch.Tensor | None = None):
+    """-> (sum float64 [g], sumsq float64 [g]) of min(x, clip[gene]) over the stored values of the masked rows."""
+    dev = require_gpu()
+    clip = clip.to(torch.float64).contiguous()
+    assert clip.numel() == g
+    s = torch.empty(g, dtype=torch.float64, device=dev)
+    sq = torch.empty(g, dtype=torch.float64, device=dev)
+    if row_mask is not None:
+        assert row_mask.dtype == torch.uint8 and row_mask.numel() == n
+    rc = _lib.load().scamd_pp_col_stats_clip_f32(ptr(indptr), ptr(indices), ptr(data), n, g, data.numel(), ptr(row_mask),
+                                                 ptr(clip), ptr(s), ptr(sq), stream_ptr())
+    _lib.check(rc, "scamd_pp_col_stats_clip_f32")
+    return s, sq
+
+
 def pp_scale_csr_(indptr, indices, data, n: int, std: torch.Tensor, *, max_value: float | None = None,
                   row_mask: torch.Tensor | None = None) -> None:
     require_gpu()

@@ -54,6 +54,7 @@ SIGNATURES = {
     "scamd_pp_row_divide_f32": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "scamd_pp_log1p_f32": (_i32, [_vp, _i64, _f64, _vp]),
     "scamd_pp_col_stats_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i32, _f64, _vp, _vp, _vp, _vp]),
+    "scamd_pp_col_stats_clip_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "scamd_pp_scale_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _f64, _i32, _vp, _vp]),
     "scamd_pp_scale_dense_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _f64, _i32, _vp, _vp, _i32, _vp]),
     "scamd_umap_workspace_bytes": (_sz, [_i64, _i64, _i32]),

@@ -148,7 +148,8 @@ __global__ __launch_bounds__(PP_BLOCK) void pp_col_stats_kernel(const int64_t* _
                                                                 const int32_t* __restrict__ indices,
                                                                 const float* __restrict__ data, int64_t n, int g,
                                                                 const uint8_t* __restrict__ row_mask, int transform,
-                                                                float tscale, double* __restrict__ sum,
+                                                                float tscale, const double* __restrict__ clip,
+                                                                double* __restrict__ sum,
                                                                 double* __restrict__ sumsq,
                                                                 unsigned long long* __restrict__ npos) {
   extern __shared__ __attribute__((aligned(16))) double pp_smem[];
@@ -170,7 +171,8 @@ __global__ __launch_bounds__(PP_BLOCK) void pp_col_stats_kernel(const int64_t* _
     for (int64_t p = indptr[r] + sub; p < e; p += G) {
       const int c = indices[p];
       const float v = pp_transform(data[p], transform, tscale);
-      const double dv = (double)v;
+      double dv = (double)v;
+      if (clip) dv = fmin(dv, clip[c]);  // `clip_square_sum` of flavor='seurat_v3' (_highly_variable_genes.py:75-115)
       if (LDS) {
         atomicAdd(&s_sum[c], dv);
         atomicAdd(&s_sq[c], dv * dv);
@@ -341,16 +343,16 @@ extern "C" int scamd_pp_log1p_f32(float* data, int64_t count, double base, scamd
 
 template <int G>
 static int launch_col_stats(const int64_t* indptr, const int32_t* indices, const float* data, int64_t n, int g,
-                            const uint8_t* row_mask, int transform, float tscale, double* sum, double* sumsq,
-                            unsigned long long* npos, hipStream_t stream) {
+                            const uint8_t* row_mask, int transform, float tscale, const double* clip, double* sum,
+                            double* sumsq, unsigned long long* npos, hipStream_t stream) {
   if (g <= PP_LDS_GENES) {
     const size_t lds = (size_t)g * (8 + 8 + 4) + 16;
     const unsigned blocks = (unsigned)std::min<int64_t>(std::max<int64_t>(ceil_div(n, (PP_BLOCK / G) * 16), 1), 512);
     hipLaunchKernelGGL((pp_col_stats_kernel<true, G>), dim3(blocks), dim3(PP_BLOCK), lds, stream, indptr, indices, data, n, g,
-                       row_mask, transform, tscale, sum, sumsq, npos);
+                       row_mask, transform, tscale, clip, sum, sumsq, npos);
   } else {
     hipLaunchKernelGGL((pp_col_stats_kernel<false, G>), dim3(group_grid(n, G)), dim3(PP_BLOCK), 0, stream, indptr, indices,
-                       data, n, g, row_mask, transform, tscale, sum, sumsq, npos);
+                       data, n, g, row_mask, transform, tscale, clip, sum, sumsq, npos);
   }
   SCAMD_LAUNCH_CHECK();
   return SCAMD_OK;
@@ -368,10 +370,26 @@ extern "C" int scamd_pp_col_stats_f32(const int64_t* indptr, const int32_t* indi
   if (n == 0 || g == 0) return SCAMD_OK;
   unsigned long long* np = reinterpret_cast<unsigned long long*>(npos);
   switch (lanes_per_row(indptr, n, nnz)) {
-    case 8: return launch_col_stats<8>(indptr, indices, data, n, (int)g, row_mask, transform, (float)tscale, sum, sumsq, np, stream);
-    case 16: return launch_col_stats<16>(indptr, indices, data, n, (int)g, row_mask, transform, (float)tscale, sum, sumsq, np, stream);
-    case 32: return launch_col_stats<32>(indptr, indices, data, n, (int)g, row_mask, transform, (float)tscale, sum, sumsq, np, stream);
-    default: return launch_col_stats<64>(indptr, indices, data, n, (int)g, row_mask, transform, (float)tscale, sum, sumsq, np, stream);
+    case 8: return launch_col_stats<8>(indptr, indices, data, n, (int)g, row_mask, transform, (float)tscale, nullptr, sum, sumsq, np, stream);
+    case 16: return launch_col_stats<16>(indptr, indices, data, n, (int)g, row_mask, transform, (float)tscale, nullptr, sum, sumsq, np, stream);
+    case 32: return launch_col_stats<32>(indptr, indices, data, n, (int)g, row_mask, transform, (float)tscale, nullptr, sum, sumsq, np, stream);
+    default: return launch_col_stats<64>(indptr, indices, data, n, (int)g, row_mask, transform, (float)tscale, nullptr, sum, sumsq, np, stream);
+  }
+}
+
+extern "C" int scamd_pp_col_stats_clip_f32(const int64_t* indptr, const int32_t* indices, const float* data, int64_t n,
+                                           int64_t g, int64_t nnz, const uint8_t* row_mask, const double* clip,
+                                           double* sum, double* sumsq, scamd_stream_t stream) {
+  SCAMD_REQUIRE(indptr && clip && n >= 0 && g >= 0 && nnz >= 0 && g < ((int64_t)1 << 31) && (g == 0 || (sum && sumsq)),
+                SCAMD_EINVAL, "pp_col_stats_clip: bad argument");
+  SCAMD_HIP_CHECK(hipMemsetAsync(sum, 0, sizeof(double) * (size_t)g, stream));
+  SCAMD_HIP_CHECK(hipMemsetAsync(sumsq, 0, sizeof(double) * (size_t)g, stream));
+  if (n == 0 || g == 0) return SCAMD_OK;
+  switch (lanes_per_row(indptr, n, nnz)) {
+    case 8: return launch_col_stats<8>(indptr, indices, data, n, (int)g, row_mask, 0, 1.0f, clip, sum, sumsq, nullptr, stream);
+    case 16: return launch_col_stats<16>(indptr, indices, data, n, (int)g, row_mask, 0, 1.0f, clip, sum, sumsq, nullptr, stream);
+    case 32: return launch_col_stats<32>(indptr, indices, data, n, (int)g, row_mask, 0, 1.0f, clip, sum, sumsq, nullptr, stream);
+    default: return launch_col_stats<64>(indptr, indices, data, n, (int)g, row_mask, 0, 1.0f, clip, sum, sumsq, nullptr, stream);
   }
 }
 

@@ -121,22 +121,13 @@ class GpuPPBackend:
     def clip_col_sums(self, m: DeviceMatrix, clip_val: np.ndarray, *, row_mask=None):
         """`clip_square_sum` (_highly_variable_genes.py:75-115): per gene, sum and sum of squares of
         min(x, clip_val[gene]) over the stored values of the masked rows -> (sum of squares, sum), float64.
-        Device tensor ops (gather, minimum, float64 scatter-add), not a hand-written kernel yet: one pass of
-        `flavor='seurat_v3'`, 16 B of traffic per stored value."""
+        One sweep of `scamd_pp_col_stats_clip_f32` (the column-statistics kernel with the clip applied before the sums)."""
         import torch
 
         dev = m.data.device
         clip = torch.from_numpy(np.ascontiguousarray(clip_val, dtype=np.float64)).to(dev)
-        idx = m.indices.to(torch.int64)
-        v = torch.minimum(m.data.to(torch.float64), clip[idx])
-        if row_mask is not None:
-            keep_rows = torch.from_numpy(np.ascontiguousarray(row_mask, dtype=bool)).to(dev)
-            rows = torch.repeat_interleave(torch.arange(m.n_major, device=dev), m.indptr[1:] - m.indptr[:-1])
-            keep = keep_rows[rows]
-            v, idx = v[keep], idx[keep]
-        g = m.shape[1]
-        s = torch.zeros(g, dtype=torch.float64, device=dev).index_add_(0, idx, v)
-        sq = torch.zeros(g, dtype=torch.float64, device=dev).index_add_(0, idx, v * v)
+        mask = None if row_mask is None else torch.from_numpy(np.ascontiguousarray(row_mask, dtype=np.uint8)).to(dev)
+        s, sq = self.K.pp_col_stats_clip(m.indptr, m.indices, m.data, m.n_major, m.shape[1], clip, row_mask=mask)
         return sq.cpu().numpy(), s.cpu().numpy()
 
     def scale_csr_(self, m: DeviceMatrix, std: np.ndarray, *, max_value=None, row_mask=None) -> None:

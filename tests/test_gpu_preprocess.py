@@ -139,3 +139,30 @@ def test_hvg_reference_semantics():
 
 def test_hvg_keeps_the_matrix(pbmc68k):
     host.check_hvg_keeps_the_matrix(pbmc68k)
+
+
+def test_col_stats_clip_kernel_matches_numpy():
+    """`scamd_pp_col_stats_clip_f32` (the `clip_square_sum` sweep of flavor='seurat_v3'): per-gene sums of min(x, clip)"""
+    import torch
+    from scipy import sparse
+
+    from scanpy_amd import _kernels as K
+
+    rng = np.random.default_rng(4)
+    for n, g in ((3000, 500), (700, 5000)):  # LDS table / global-atomic variant (g > 4096)
+        x = sparse.random(n, g, density=0.05, random_state=7, format="csr", dtype=np.float32)
+        x.data = np.rint(x.data * 40).astype(np.float32)
+        clip = rng.uniform(2.0, 30.0, size=g)
+        mask = (rng.random(n) < 0.6).astype(np.uint8)
+        ip = torch.from_numpy(x.indptr.astype(np.int64)).cuda()
+        ix = torch.from_numpy(x.indices.astype(np.int32)).cuda()
+        dv = torch.from_numpy(x.data).cuda()
+        for m in (None, mask):
+            s, sq = K.pp_col_stats_clip(ip, ix, dv, n, g, torch.from_numpy(clip).cuda(),
+                                        row_mask=None if m is None else torch.from_numpy(m).cuda())
+            xm = x if m is None else x[m.astype(bool)]
+            c = xm.tocsc()
+            v = np.minimum(c.data.astype(np.float64), np.repeat(clip, np.diff(c.indptr)))
+            cols = np.repeat(np.arange(g), np.diff(c.indptr))
+            np.testing.assert_allclose(s.cpu().numpy(), np.bincount(cols, weights=v, minlength=g), rtol=1e-12, atol=1e-9)
+            np.testing.assert_allclose(sq.cpu().numpy(), np.bincount(cols, weights=v * v, minlength=g), rtol=1e-12, atol=1e-9)
