@@ -66,6 +66,15 @@ __global__ __launch_bounds__(256) void gram_tileptr_kernel(const int64_t* __rest
 // A_FROM_MEM: every lane reads the tile-a entry of its row group straight from memory (one address per 8 lanes, L1
 // hits) instead of receiving it through two ds_bpermute: the kernel is bound by the LDS pipe (bpermute + 64-bit
 // atomic), the vector-memory pipe is idle.
+// round-to-nearest-even of a float64 to int64: the 1.5 * 2^52 trick where it is exact, llrint beyond
+__device__ __forceinline__ long long fixed_round(double x) {
+  if (fabs(x) < 2251799813685248.0) {  // 2^51
+    const double t = x + 6755399441055744.0;  // 1.5 * 2^52: the sum's low mantissa bits are round(x) in two's complement
+    return __double_as_longlong(t) - 0x4338000000000000ll;
+  }
+  return llrint(x);
+}
+
 template <bool A_FROM_MEM>
 __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ data,
@@ -128,6 +137,26 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
           va_l = data[pa + pc + q];
         }
         const int cnt = min(8, max_na - pc);
+        if constexpr (!A_FROM_MEM) {
+          // The 16 permutes of a group of eight tile-a entries are issued back to back and waited for once, the eight
+          // (predicated) atomics follow without a wait in between; the float64 -> int64 rounding is the 2^52 trick
+          // (exact for |x| < 2^51, llrint otherwise).  Measured: 13.2 ms either way (the rolled loop waited lgkmcnt(0)
+          // per product) -- the kernel is bound by the rate of the 64-bit LDS atomic itself (~0.65 lanes per CU cycle
+          // on scattered addresses), not by the latency of its operands.
+          int ja8[8];
+          float va8[8];
+#pragma unroll
+          for (int pp = 0; pp < 8; ++pp) {
+            const int src = (lane & ~7) | pp;
+            ja8[pp] = __shfl(ja_l, src);
+            va8[pp] = __shfl(va_l, src);
+          }
+#pragma unroll
+          for (int pp = 0; pp < 8; ++pp) {
+            if (has_b && pc + pp < na) atomicAdd(&tile[ja8[pp] * GT + jb], (unsigned long long)fixed_round((double)va8[pp] * vb));
+          }
+          continue;
+        }
         if constexpr (A_FROM_MEM) {
           for (int pp = 0; pp < cnt; ++pp) {
             if (has_b && pc + pp < na) {

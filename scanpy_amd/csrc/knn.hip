@@ -967,12 +967,14 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
     double dk = (kk > 0) ? skth[w] : 0.0;
     double tau = (double)cand_tau[qi];
     double cmax = (double)__uint_as_float(*cmax_bits);
-    // |s_float32 - s_exact| <= (2H+2) u (||c||^2 + 2 ||q|| ||c||), u = 2^-24; 2H+2 <= 130.  The register-list kernel
-    // keeps a slot number in the 5 low mantissa bits of its keys: the threshold and the keys it was compared with are
-    // each off by < 32 ulp = 64 u |score| -> 194.  tau >= 1e38: the list never filled (fewer than thr_rank rows).
+    // |s_float32 - s_exact| <= (2H+2) u (||c||^2 + 2 ||q|| ||c||), u = 2^-24; 2H+2 <= 130.
     // Centring: the image holds fl(x - mu), each coordinate off by <= u |x - mu|, so a squared distance between image
-    // rows differs from the true one by <= 4 u (qn + cmax) <= 8 u (cmax + 2 ||q|| ||c||) -> 202.
-    double eps = cert_scale * 202.0 * 5.9604644775390625e-08 * (cmax + 2.0 * sqrt(qn * cmax));
+    // rows differs from the true one by <= 4 u (qn + cmax) <= 8 u (cmax + 2 ||q|| ||c||) -> 138.
+    // Slot keys (register-list kernel): the threshold and the keys it was compared with carry a slot number in their
+    // 5 low mantissa bits, i.e. each is off by < 32 ulp OF ITS OWN MAGNITUDE -- the threshold's, not cmax's (keys far
+    // above the threshold cannot be confused with it): 128 u |tau| with a factor 2 for a binade boundary.  (Charging it
+    // against cmax as well, factor 202, sent 4317 instead of 379 queries of the 10M x 50 run to the float64 scan: +3 s.)
+    double eps = cert_scale * 5.9604644775390625e-08 * (138.0 * (cmax + 2.0 * sqrt(qn * cmax)) + 128.0 * fabs(tau));
     bool certified = (tau >= 1e38f) || ((dk - qn) + eps < tau);
     kth_d2[qi] = dk;
     if (!certified) {
