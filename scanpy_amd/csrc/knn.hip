@@ -1026,6 +1026,57 @@ __global__ __launch_bounds__(256) void knn_fallback_scan_kernel(
   }
 }
 
+// The same scan restricted to the cells that can hold a row within the bound (cell-pruned mode): a cell whose ball
+// lies farther from the query than sqrt(bound) is skipped, |q - x| >= |q - mu_c| - r_c for every member x.  The float64
+// scan over ALL rows cost 0.7 ms per query at 10M rows (1.1 s for the 1499 uncertified queries of the 10M x 50 run);
+// with ~2.5 % of the rows in reach it is noise again.  grid (cell chunks, queries).
+__global__ __launch_bounds__(256) void knn_fallback_scan_cells_kernel(
+    const float* __restrict__ x, int d, int64_t ld, int64_t q_begin, const int* __restrict__ flag_list, int flag_begin,
+    const double* __restrict__ kth_d2, double* __restrict__ scratch_d, int* __restrict__ scratch_i, int* __restrict__ counts,
+    const float* __restrict__ cent, const float* __restrict__ radius, const int* __restrict__ cell_tile0,
+    const int* __restrict__ cell_ntiles, const int* __restrict__ perm, int n_cells) {
+  __shared__ float qs[128];
+  const int fb = blockIdx.y;
+  const int64_t qi = flag_list[flag_begin + fb];
+  const int64_t q = q_begin + qi;
+  double* bd = scratch_d + (int64_t)fb * FALLBACK_CAP;
+  int* bi = scratch_i + (int64_t)fb * FALLBACK_CAP;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) qs[c] = x[q * ld + c];
+  __syncthreads();
+  const double bound = kth_d2[qi];
+  const int per = (n_cells + gridDim.x - 1) / gridDim.x;
+  const int c0 = blockIdx.x * per, c1 = min(n_cells, c0 + per);
+  for (int c = c0; c < c1; ++c) {
+    const int nt = cell_ntiles[c];
+    if (nt == 0) continue;
+    double dc2 = 0.0;  // (every thread: uniform, 50 fused multiply-adds)
+    for (int t = 0; t < d; ++t) {
+      const double df = (double)qs[t] - (double)cent[c * d + t];
+      dc2 = fma(df, df, dc2);
+    }
+    const double lb = sqrt(dc2) * (1.0 - 1e-6) - (double)radius[c];  // (the radius is stored inflated by 1e-4)
+    if (lb > 0.0 && lb * lb > bound * (1.0 + 1e-9)) continue;
+    const int64_t r0 = (int64_t)cell_tile0[c] * 64, r1 = r0 + (int64_t)nt * 64;
+    for (int64_t row = r0 + threadIdx.x; row < r1; row += blockDim.x) {
+      const int orig = perm[row];
+      if (orig < 0 || orig == q) continue;
+      const float* cp = x + (int64_t)orig * ld;
+      double s = 0.0;
+      for (int t = 0; t < d; ++t) {
+        const double df = (double)qs[t] - (double)cp[t];
+        s = fma(df, df, s);
+      }
+      if (s <= bound) {
+        const int slot = atomicAdd(&counts[fb], 1);
+        if (slot < FALLBACK_CAP) {
+          bd[slot] = s;
+          bi[slot] = orig;
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void knn_fallback_rank_kernel(
     int k, const int* __restrict__ flag_list, int flag_begin, const double* __restrict__ scratch_d,
     const int* __restrict__ scratch_i, const int* __restrict__ counts, int32_t* __restrict__ out_idx,
@@ -1698,9 +1749,18 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
   for (int begin = 0; begin < n_flag; begin += FALLBACK_CHUNK) {
     int count = std::min(FALLBACK_CHUNK, n_flag - begin);
     SCAMD_HIP_CHECK(hipMemsetAsync(b.fb_counts, 0, sizeof(int) * count, s));
-    const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(FALLBACK_ROW_CHUNKS, n / 2048));
-    hipLaunchKernelGGL(knn_fallback_scan_kernel, dim3(chunks, count), dim3(256), 0, s, x, n, d, ld_x, q_begin,
-                       b.flag_list, begin, b.kth_d2, b.scratch_d, b.scratch_i, b.fb_counts);
+    if (p.ivf) {
+      // cell tables of run_ivf_select (same carving): tile0 = cell_ints + 7 nc, ntiles = the recycled sums buffer
+      const int nc = p.n_cells;
+      hipLaunchKernelGGL(knn_fallback_scan_cells_kernel, dim3(std::min(nc, 64), count), dim3(256), 0, s, x, d, ld_x, q_begin,
+                         b.flag_list, begin, b.kth_d2, b.scratch_d, b.scratch_i, b.fb_counts, b.cent,
+                         reinterpret_cast<const float*>(b.radius_bits), b.cell_ints + 7 * nc,
+                         reinterpret_cast<const int*>(b.sums), b.perm, nc);
+    } else {
+      const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(FALLBACK_ROW_CHUNKS, n / 2048));
+      hipLaunchKernelGGL(knn_fallback_scan_kernel, dim3(chunks, count), dim3(256), 0, s, x, n, d, ld_x, q_begin,
+                         b.flag_list, begin, b.kth_d2, b.scratch_d, b.scratch_i, b.fb_counts);
+    }
     SCAMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(knn_fallback_rank_kernel, dim3(count), dim3(256), 0, s, k, b.flag_list, begin, b.scratch_d,
                        b.scratch_i, b.fb_counts, out_idx, out_dist, b.counters + 1);

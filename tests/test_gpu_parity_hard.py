@@ -253,3 +253,25 @@ def test_chain_100k_vs_cpu_chain():
     assert par["leiden_ari_vs_cpu_chain"] >= 0.99 and par["leiden_ari_stagewise"] >= 0.99
     assert par["ari_vs_truth"]["gpu"] >= 0.99
     assert par["knn_rows_equal_end_to_end"] > 0.999
+
+
+def test_knn_forced_fallback_through_the_cell_scan(K, monkeypatch):
+    """every query forced through the float64 fallback (cert_scale = 1e30) in cell-pruned mode: the fallback scans only
+    the cells whose ball reaches the query's bound -- same lists as the certified run, bit for bit"""
+    from scanpy_amd.datasets import blobs_embedding
+
+    monkeypatch.setenv("SCAMD_KNN_IVF", "1")
+    for kind in ("blobs", "offset", "noise"):
+        n = 12000
+        if kind == "noise":
+            x = np.random.default_rng(3).standard_normal((n, 50)).astype(np.float32)
+        else:
+            x, _ = blobs_embedding(n, 50, n_types=9, seed=23)
+            if kind == "offset":
+                x = x + np.float32(120.0)
+        xd = _dev(x)
+        i1, d1, n1 = K.knn(xd, 15)
+        i2, d2, n2 = K.knn(xd, 15, cert_scale=1e30)
+        assert n2 == n and n1 < n // 10
+        np.testing.assert_array_equal(i1.cpu().numpy(), i2.cpu().numpy())
+        np.testing.assert_array_equal(d1.cpu().numpy(), d2.cpu().numpy())
