@@ -66,6 +66,24 @@ __global__ __launch_bounds__(256) void gram_tileptr_kernel(const int64_t* __rest
 // A_FROM_MEM: every lane reads the tile-a entry of its row group straight from memory (one address per 8 lanes, L1
 // hits) instead of receiving it through two ds_bpermute: the kernel is bound by the LDS pipe (bpermute + 64-bit
 // atomic), the vector-memory pipe is idle.
+// Broadcast lane PP of every aligned group of 8 lanes to the whole group with DPP (VALU) instead of ds_bpermute: a quad
+// broadcast, then the other quad's copy by a row shift of 4 and a select.  The permutes were two of the three LDS-pipe
+// instructions per product of this kernel and the VALU is 22 % busy (profiles/r03c_pca_stage_pmc1.csv) -- measured: no
+// change (12.4 ms): what binds is the third one, the 64-bit LDS atomic.
+template <int PP>
+__device__ __forceinline__ int bcast8(int x, bool upper_quad) {
+  constexpr int Q = PP & 3;
+  constexpr int QUAD = Q | (Q << 2) | (Q << 4) | (Q << 6);
+  const int y = __builtin_amdgcn_update_dpp(0, x, QUAD, 0xf, 0xf, false);
+  if constexpr (PP < 4) {
+    const int z = __builtin_amdgcn_update_dpp(0, y, 0x114, 0xf, 0xf, false);  // row_shr:4: lane i <- lane i - 4
+    return upper_quad ? z : y;
+  } else {
+    const int z = __builtin_amdgcn_update_dpp(0, y, 0x104, 0xf, 0xf, false);  // row_shl:4: lane i <- lane i + 4
+    return upper_quad ? y : z;
+  }
+}
+
 // round-to-nearest-even of a float64 to int64: the 1.5 * 2^52 trick where it is exact, llrint beyond
 __device__ __forceinline__ long long fixed_round(double x) {
   if (fabs(x) < 2251799813685248.0) {  // 2^51
@@ -99,92 +117,132 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
   const int64_t r0 = (int64_t)chunk * rows_per_chunk;
   const int64_t r1 = std::min<int64_t>(n, r0 + rows_per_chunk);
   const int a0 = a * GT, b0 = b * GT;
-  for (int64_t grp = r0 + (int64_t)wave * 8; grp < r1; grp += (GRAM_THREADS / 64) * 8) {
+  // Two-stage software pipeline over the wave's steps (8 rows each).  PMC (profiles/r03c_pca_stage_pmc1.csv): 69 % of the
+  // wave cycles of the straight loop were spent parked on s_waitcnt; a step is a chain of three dependent global loads
+  // (tile pointers + indptr -> the row's entries of tile b -> of tile a) in front of ~40 products.  With the pointers of
+  // step s + 2 and the first entry chunks of step s + 1 in flight while step s is computed: 13.2 -> 12.4 ms.  The rest of
+  // the parking is lgkmcnt: 5.3e9 atomic lanes in 12.4 ms = 0.8 per CU cycle -- the 64-bit ds_add retires about one lane
+  // per cycle on scattered addresses, and that, not its operands, is the wall.
+  struct Ptrs {
+    int na, nb;
+    int64_t pa, pb;
+  };
+  struct Ents {
+    int ja_l, jb;
+    float va_l, vbf;
+  };
+  const int64_t gstep = (GRAM_THREADS / 64) * 8;
+  auto load_ptrs = [&](int64_t grp) -> Ptrs {
+    Ptrs t{0, 0, 0, 0};
     const int64_t row = grp + rs;
-    int na = 0, nb = 0;
-    int64_t pa = 0, pb = 0;
-    if (row < r1) {
+    if (grp < r1 && row < r1) {
       const unsigned short* pr = ptr + row * (ntile + 1);
       const int64_t rb = indptr[row];
       const int a_lo = pr[a], a_hi = pr[a + 1], b_lo = pr[b], b_hi = pr[b + 1];
-      na = a_hi - a_lo;
-      nb = b_hi - b_lo;
-      pa = rb + a_lo;
-      pb = rb + b_lo;
+      t.na = a_hi - a_lo;
+      t.nb = b_hi - b_lo;
+      t.pa = rb + a_lo;
+      t.pb = rb + b_lo;
     }
+    return t;
+  };
+  auto load_ents = [&](const Ptrs& t) -> Ents {  // first chunk of eight entries of either tile: lane q holds entry q
+    Ents e{0, 0, 0.f, 0.f};
+    if (q < t.nb) {
+      e.jb = indices[t.pb + q] - b0;
+      e.vbf = data[t.pb + q];
+    }
+    if (q < t.na) {
+      e.ja_l = indices[t.pa + q] - a0;
+      e.va_l = data[t.pa + q];
+    }
+    return e;
+  };
+  const int64_t g_first = r0 + (int64_t)wave * 8;
+  Ptrs pt_cur = load_ptrs(g_first);
+  Ents en_cur = load_ents(pt_cur);
+  Ptrs pt_nxt = load_ptrs(g_first + gstep);
+  for (int64_t grp = g_first; grp < r1; grp += gstep) {
+    // issue the loads of the following steps before this step's products
+    const Ents en_nxt = load_ents(pt_nxt);
+    const Ptrs pt_nn = load_ptrs(grp + 2 * gstep);
+    const int na = pt_cur.na, nb = pt_cur.nb;
+    const int64_t pa = pt_cur.pa, pb = pt_cur.pb;
     int max_na = na, max_nb = nb;
 #pragma unroll
     for (int o = 32; o >= 8; o >>= 1) {
       max_na = max(max_na, __shfl_xor(max_na, o));
       max_nb = max(max_nb, __shfl_xor(max_nb, o));
     }
-    if (max_na == 0 || max_nb == 0) continue;
-    for (int qc = 0; qc < max_nb; qc += 8) {
-      const int myq = qc + q;
-      const bool has_b = myq < nb;
-      int jb = 0;
-      double vb = 0.0;
-      if (has_b) {
-        jb = indices[pb + myq] - b0;
-        vb = (double)data[pb + myq] * scale;
+    if (max_na != 0 && max_nb != 0) {
+      for (int qc = 0; qc < max_nb; qc += 8) {
+        const int myq = qc + q;
+        const bool has_b = myq < nb;
+        int jb = en_cur.jb;
+        double vb = (double)en_cur.vbf * scale;
+        if (qc > 0) {  // rows with more than eight entries in tile b: later chunks straight from memory
+          jb = 0;
+          vb = 0.0;
+          if (has_b) {
+            jb = indices[pb + myq] - b0;
+            vb = (double)data[pb + myq] * scale;
+          }
+        }
+        for (int pc = 0; pc < max_na; pc += 8) {
+          // the group's next 8 entries of tile a: lane q holds entry pc + q
+          int ja_l = en_cur.ja_l;
+          float va_l = en_cur.va_l;
+          if (pc > 0) {
+            ja_l = 0;
+            va_l = 0.f;
+            if (pc + q < na) {
+              ja_l = indices[pa + pc + q] - a0;
+              va_l = data[pa + pc + q];
+            }
+          }
+          if constexpr (!A_FROM_MEM) {
+            // the 16 permutes of a group of eight tile-a entries are issued back to back and waited for once, the eight
+            // (predicated) atomics follow without a wait in between; the float64 -> int64 rounding is the 2^52 trick
+            // (exact for |x| < 2^51, llrint otherwise)
+            int ja8[8];
+            float va8[8];
+            const bool uq = (lane & 4) != 0;
+            const int vai = __float_as_int(va_l);
+            ja8[0] = bcast8<0>(ja_l, uq); va8[0] = __int_as_float(bcast8<0>(vai, uq));
+            ja8[1] = bcast8<1>(ja_l, uq); va8[1] = __int_as_float(bcast8<1>(vai, uq));
+            ja8[2] = bcast8<2>(ja_l, uq); va8[2] = __int_as_float(bcast8<2>(vai, uq));
+            ja8[3] = bcast8<3>(ja_l, uq); va8[3] = __int_as_float(bcast8<3>(vai, uq));
+            ja8[4] = bcast8<4>(ja_l, uq); va8[4] = __int_as_float(bcast8<4>(vai, uq));
+            ja8[5] = bcast8<5>(ja_l, uq); va8[5] = __int_as_float(bcast8<5>(vai, uq));
+            ja8[6] = bcast8<6>(ja_l, uq); va8[6] = __int_as_float(bcast8<6>(vai, uq));
+            ja8[7] = bcast8<7>(ja_l, uq); va8[7] = __int_as_float(bcast8<7>(vai, uq));
+#pragma unroll
+            for (int pp = 0; pp < 8; ++pp) {
+              if (has_b && pc + pp < na)
+                atomicAdd(&tile[ja8[pp] * GT + jb], (unsigned long long)fixed_round((double)va8[pp] * vb));
+            }
+          } else {
+            const int cnt = min(8, max_na - pc);
+            for (int pp = 0; pp < cnt; ++pp) {
+              if (has_b && pc + pp < na) {
+                const int ja = indices[pa + pc + pp] - a0;
+                const float va = data[pa + pc + pp];
+                atomicAdd(&tile[ja * GT + jb], (unsigned long long)fixed_round((double)va * vb));
+              }
+            }
+          }
+        }
       }
-      for (int pc = 0; pc < max_na; pc += 8) {
-        // the group's next 8 entries of tile a: lane q holds entry pc + q
-        int ja_l = 0;
-        float va_l = 0.f;
-        if (pc + q < na) {
-          ja_l = indices[pa + pc + q] - a0;
-          va_l = data[pa + pc + q];
-        }
-        const int cnt = min(8, max_na - pc);
-        if constexpr (!A_FROM_MEM) {
-          // The 16 permutes of a group of eight tile-a entries are issued back to back and waited for once, the eight
-          // (predicated) atomics follow without a wait in between; the float64 -> int64 rounding is the 2^52 trick
-          // (exact for |x| < 2^51, llrint otherwise).  Measured: 13.2 ms either way (the rolled loop waited lgkmcnt(0)
-          // per product) -- the kernel is bound by the rate of the 64-bit LDS atomic itself (~0.65 lanes per CU cycle
-          // on scattered addresses), not by the latency of its operands.
-          int ja8[8];
-          float va8[8];
-#pragma unroll
-          for (int pp = 0; pp < 8; ++pp) {
-            const int src = (lane & ~7) | pp;
-            ja8[pp] = __shfl(ja_l, src);
-            va8[pp] = __shfl(va_l, src);
-          }
-#pragma unroll
-          for (int pp = 0; pp < 8; ++pp) {
-            if (has_b && pc + pp < na) atomicAdd(&tile[ja8[pp] * GT + jb], (unsigned long long)fixed_round((double)va8[pp] * vb));
-          }
-          continue;
-        }
-        if constexpr (A_FROM_MEM) {
-          for (int pp = 0; pp < cnt; ++pp) {
-            if (has_b && pc + pp < na) {
-              const int ja = indices[pa + pc + pp] - a0;
-              const float va = data[pa + pc + pp];
-              const long long v = llrint((double)va * vb);
-              atomicAdd(&tile[ja * GT + jb], (unsigned long long)v);
-            }
-          }
-        } else {
-          for (int pp = 0; pp < cnt; ++pp) {
-            const int src = (lane & ~7) | pp;
-            const int ja = __shfl(ja_l, src);
-            const float va = __shfl(va_l, src);
-            if (has_b && pc + pp < na) {
-              const long long v = llrint((double)va * vb);
-              atomicAdd(&tile[ja * GT + jb], (unsigned long long)v);
-            }
-          }
+      if (diag && q == 0) {  // column sums ride along on the diagonal items: lane q == 0 of each row group
+        for (int p = 0; p < na; ++p) {
+          const long long v = llrint((double)data[pa + p] * scale);
+          atomicAdd(&csum[indices[pa + p] - a0], (unsigned long long)v);
         }
       }
     }
-    if (diag && q == 0) {  // column sums ride along on the diagonal items: lane q == 0 of each row group
-      for (int p = 0; p < na; ++p) {
-        const long long v = llrint((double)data[pa + p] * scale);
-        atomicAdd(&csum[indices[pa + p] - a0], (unsigned long long)v);
-      }
-    }
+    pt_cur = pt_nxt;
+    en_cur = en_nxt;
+    pt_nxt = pt_nn;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < GT * GT; i += GRAM_THREADS) {
