@@ -63,13 +63,19 @@ __global__ __launch_bounds__(256) void gram_tileptr_kernel(const int64_t* __rest
   for (int u = last_tile + 1 + lane; u <= ntile; u += 64) out[u] = (unsigned short)len;
 }
 
+// What binds this kernel (round-2 measurements, tools/probes/lds_atomic_probe.hip + profiles/r03c_pca_stage_pmc*.csv):
+// NOT the 64-bit LDS atomic -- the probe retires 14 ds_add_u64 lanes per CU per ns (3.6e12 /s chip-wide, ds_add_u32 23,
+// ds_add_f64 7.5), the 5e9 products of the 1M x 2k matrix would take 1.4 ms at that rate.  The waves were parked on
+// s_waitcnt (69 % of the wave-cycles): every step's pointer and entry loads were waited for where they were issued.
+// Three fixes, each measured: requesting the next step's loads one step ahead and keeping the RAW loaded values until
+// their step (any arithmetic at the load site makes the compiler wait there: 12.4 -> 10.3 ms), prefetching the first
+// SIXTEEN entries per row and tile instead of eight (10.3 -> 9.0 ms), column sums from the prefetched registers.  What
+// is left is instruction issue: ~45 % of the lanes of a product instruction carry a product (8 lanes per row against
+// 6.4 entries per tile, the a-loop runs to the longest of 8 rows).
 // A_FROM_MEM: every lane reads the tile-a entry of its row group straight from memory (one address per 8 lanes, L1
-// hits) instead of receiving it through two ds_bpermute: the kernel is bound by the LDS pipe (bpermute + 64-bit
-// atomic), the vector-memory pipe is idle.
+// hits) instead of receiving it by a broadcast: slower (17.5 ms), kept behind SCAMD_GRAM_A_FROM_MEM for measurements.
 // Broadcast lane PP of every aligned group of 8 lanes to the whole group with DPP (VALU) instead of ds_bpermute: a quad
-// broadcast, then the other quad's copy by a row shift of 4 and a select.  The permutes were two of the three LDS-pipe
-// instructions per product of this kernel and the VALU is 22 % busy (profiles/r03c_pca_stage_pmc1.csv) -- measured: no
-// change (12.4 ms): what binds is the third one, the 64-bit LDS atomic.
+// broadcast, then the other quad's copy by a row shift of 4 and a select (same speed as the permute when it was tried).
 template <int PP>
 __device__ __forceinline__ int bcast8(int x, bool upper_quad) {
   constexpr int Q = PP & 3;
@@ -123,51 +129,76 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
   // step s + 2 and the first entry chunks of step s + 1 in flight while step s is computed: 13.2 -> 12.4 ms.  The rest of
   // the parking is lgkmcnt: 5.3e9 atomic lanes in 12.4 ms = 0.8 per CU cycle -- the 64-bit ds_add retires about one lane
   // per cycle on scattered addresses, and that, not its operands, is the wall.
-  struct Ptrs {
-    int na, nb;
-    int64_t pa, pb;
+  // (the structs hold RAW loaded values: any arithmetic on them at the point of the load makes the compiler wait for
+  // the load right there -- `indices[p] - b0` in the first version of this pipeline put an s_waitcnt vmcnt behind every
+  // prefetch and the pipeline did nothing)
+  struct PtrsRaw {
+    unsigned short a_lo, a_hi, b_lo, b_hi;
+    int64_t rb;
+    bool valid;
   };
-  struct Ents {
-    int ja_l, jb;
-    float va_l, vbf;
+  struct EntsRaw {  // lane q: entries q and q + 8 of either tile
+    int ja, jb, ja2, jb2;
+    float va, vb, va2, vb2;
   };
   const int64_t gstep = (GRAM_THREADS / 64) * 8;
-  auto load_ptrs = [&](int64_t grp) -> Ptrs {
-    Ptrs t{0, 0, 0, 0};
+  auto load_ptrs = [&](int64_t grp) -> PtrsRaw {
+    PtrsRaw t{0, 0, 0, 0, 0, false};
     const int64_t row = grp + rs;
     if (grp < r1 && row < r1) {
       const unsigned short* pr = ptr + row * (ntile + 1);
-      const int64_t rb = indptr[row];
-      const int a_lo = pr[a], a_hi = pr[a + 1], b_lo = pr[b], b_hi = pr[b + 1];
-      t.na = a_hi - a_lo;
-      t.nb = b_hi - b_lo;
-      t.pa = rb + a_lo;
-      t.pb = rb + b_lo;
+      t.rb = indptr[row];
+      t.a_lo = pr[a];
+      t.a_hi = pr[a + 1];
+      t.b_lo = pr[b];
+      t.b_hi = pr[b + 1];
+      t.valid = true;
     }
     return t;
   };
-  auto load_ents = [&](const Ptrs& t) -> Ents {  // first chunk of eight entries of either tile: lane q holds entry q
-    Ents e{0, 0, 0.f, 0.f};
-    if (q < t.nb) {
-      e.jb = indices[t.pb + q] - b0;
-      e.vbf = data[t.pb + q];
+  // the first sixteen entries of either tile (columns still absolute).  Eight rows of a 5 %-dense matrix have a tile with
+  // more than eight entries in four steps out of five, so the second chunk is prefetched with the first: fetched on
+  // demand it put two to three serial memory latencies into most steps (2.4 us per step per wave, measured)
+  auto load_ents = [&](int na_, int nb_, int64_t pa_, int64_t pb_) -> EntsRaw {
+    EntsRaw e{0, 0, 0, 0, 0.f, 0.f, 0.f, 0.f};
+    if (q < nb_) {
+      e.jb = indices[pb_ + q];
+      e.vb = data[pb_ + q];
     }
-    if (q < t.na) {
-      e.ja_l = indices[t.pa + q] - a0;
-      e.va_l = data[t.pa + q];
+    if (q < na_) {
+      e.ja = indices[pa_ + q];
+      e.va = data[pa_ + q];
+    }
+    if (q + 8 < nb_) {
+      e.jb2 = indices[pb_ + q + 8];
+      e.vb2 = data[pb_ + q + 8];
+    }
+    if (q + 8 < na_) {
+      e.ja2 = indices[pa_ + q + 8];
+      e.va2 = data[pa_ + q + 8];
     }
     return e;
   };
   const int64_t g_first = r0 + (int64_t)wave * 8;
-  Ptrs pt_cur = load_ptrs(g_first);
-  Ents en_cur = load_ents(pt_cur);
-  Ptrs pt_nxt = load_ptrs(g_first + gstep);
+  int na, nb;
+  int64_t pa, pb;
+  {
+    const PtrsRaw t = load_ptrs(g_first);
+    na = t.valid ? t.a_hi - t.a_lo : 0;
+    nb = t.valid ? t.b_hi - t.b_lo : 0;
+    pa = t.rb + t.a_lo;
+    pb = t.rb + t.b_lo;
+  }
+  EntsRaw en_cur = load_ents(na, nb, pa, pb);
+  PtrsRaw pt_nxt = load_ptrs(g_first + gstep);
   for (int64_t grp = g_first; grp < r1; grp += gstep) {
-    // issue the loads of the following steps before this step's products
-    const Ents en_nxt = load_ents(pt_nxt);
-    const Ptrs pt_nn = load_ptrs(grp + 2 * gstep);
-    const int na = pt_cur.na, nb = pt_cur.nb;
-    const int64_t pa = pt_cur.pa, pb = pt_cur.pb;
+    // the pointers of the next step were requested one step ago: turn them into ranges, request that step's entries and
+    // the pointers of the step after it -- all before this step's products
+    const int na_n = pt_nxt.valid ? pt_nxt.a_hi - pt_nxt.a_lo : 0;
+    const int nb_n = pt_nxt.valid ? pt_nxt.b_hi - pt_nxt.b_lo : 0;
+    const int64_t pa_n = pt_nxt.rb + pt_nxt.a_lo, pb_n = pt_nxt.rb + pt_nxt.b_lo;
+    const EntsRaw en_nxt = load_ents(na_n, nb_n, pa_n, pb_n);
+    const PtrsRaw pt_nn = load_ptrs(grp + 2 * gstep);
     int max_na = na, max_nb = nb;
 #pragma unroll
     for (int o = 32; o >= 8; o >>= 1) {
@@ -178,9 +209,9 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
       for (int qc = 0; qc < max_nb; qc += 8) {
         const int myq = qc + q;
         const bool has_b = myq < nb;
-        int jb = en_cur.jb;
-        double vb = (double)en_cur.vbf * scale;
-        if (qc > 0) {  // rows with more than eight entries in tile b: later chunks straight from memory
+        int jb = (qc == 0 ? en_cur.jb : en_cur.jb2) - b0;
+        double vb = (double)(qc == 0 ? en_cur.vb : en_cur.vb2) * scale;
+        if (qc > 8) {  // rows with more than sixteen entries in tile b: later chunks straight from memory
           jb = 0;
           vb = 0.0;
           if (has_b) {
@@ -190,9 +221,9 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
         }
         for (int pc = 0; pc < max_na; pc += 8) {
           // the group's next 8 entries of tile a: lane q holds entry pc + q
-          int ja_l = en_cur.ja_l;
-          float va_l = en_cur.va_l;
-          if (pc > 0) {
+          int ja_l = (pc == 0 ? en_cur.ja : en_cur.ja2) - a0;
+          float va_l = pc == 0 ? en_cur.va : en_cur.va2;
+          if (pc > 8) {
             ja_l = 0;
             va_l = 0.f;
             if (pc + q < na) {
@@ -200,6 +231,8 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
               va_l = data[pa + pc + q];
             }
           }
+          if (diag && qc == 0 && pc + q < na)  // column sums ride along on the diagonal items
+            atomicAdd(&csum[ja_l], (unsigned long long)llrint((double)va_l * scale));
           if constexpr (!A_FROM_MEM) {
             // the 16 permutes of a group of eight tile-a entries are issued back to back and waited for once, the eight
             // (predicated) atomics follow without a wait in between; the float64 -> int64 rounding is the 2^52 trick
@@ -233,14 +266,11 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
           }
         }
       }
-      if (diag && q == 0) {  // column sums ride along on the diagonal items: lane q == 0 of each row group
-        for (int p = 0; p < na; ++p) {
-          const long long v = llrint((double)data[pa + p] * scale);
-          atomicAdd(&csum[indices[pa + p] - a0], (unsigned long long)v);
-        }
-      }
     }
-    pt_cur = pt_nxt;
+    na = na_n;
+    nb = nb_n;
+    pa = pa_n;
+    pb = pb_n;
     en_cur = en_nxt;
     pt_nxt = pt_nn;
   }

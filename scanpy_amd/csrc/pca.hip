@@ -140,6 +140,10 @@ __global__ __launch_bounds__(64) void tr_scatter_kernel(const int64_t* __restric
 // Y = A * B - 1 shift^T  (float32).  One wave per CSR row; lane = output column (CPL columns/lane).
 // The row's (index, value) pairs are loaded 64 at a time and broadcast with readlane; B rows
 // (l*4 bytes, L2-resident panel) are read coalesced.
+// Memory-level parallelism is the whole game here: the first version waited for every B row before its fma (one load
+// in flight per wave, 80 % of the wave-cycles parked on s_waitcnt: profiles/r03c_pca_stage_pmc1.csv).  Now GU = 8 B rows
+// are requested back to back and consumed in the same order (the sum is bit for bit the old one), the next 64 entries
+// of the row and the next row's extent are requested before the current ones are used.
 // ------------------------------------------------------------------------------------------------
 template <int CPL>
 __global__ __launch_bounds__(256) void spmm_rows_f32_kernel(const int64_t* __restrict__ indptr,
@@ -148,45 +152,71 @@ __global__ __launch_bounds__(256) void spmm_rows_f32_kernel(const int64_t* __res
                                                             const float* __restrict__ b, int l,
                                                             const float* __restrict__ shift,
                                                             float* __restrict__ y) {
+  constexpr int GU = 8;
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   float sh[CPL];
+  bool colok[CPL];
+  int colc[CPL];  // lanes past the last column read the last column (no divergence around the gathers), store nothing
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
-    int col = lane + 64 * c;
-    sh[c] = (shift && col < l) ? shift[col] : 0.f;
+    const int col = lane + 64 * c;
+    colok[c] = col < l;
+    colc[c] = min(col, l - 1);
+    sh[c] = (shift && colok[c]) ? shift[col] : 0.f;
   }
+  if (wave >= n) return;
+  int64_t rb = indptr[wave], re = indptr[wave + 1];
   for (int64_t row = wave; row < n; row += nwaves) {
-    const int64_t rb = indptr[row], re = indptr[row + 1];
+    // the next row's extent (raw: consumed at the bottom of the loop)
+    const int64_t nrow = row + nwaves < n ? row + nwaves : row;
+    const int64_t nrb = indptr[nrow], nre = indptr[nrow + 1];
     float acc[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+    int ci = 0;
+    float cv = 0.f;
+    if (rb + lane < re) {
+      ci = indices[rb + lane];
+      cv = data[rb + lane];
+    }
     for (int64_t p0 = rb; p0 < re; p0 += 64) {
-      const int64_t p = p0 + lane;
-      int ci = 0;
-      float cv = 0.f;
-      if (p < re) {
-        ci = indices[p];
-        cv = data[p];
+      int ci_n = 0;
+      float cv_n = 0.f;
+      if (p0 + 64 + lane < re) {
+        ci_n = indices[p0 + 64 + lane];
+        cv_n = data[p0 + 64 + lane];
       }
       const int cnt = (int)std::min<int64_t>(64, re - p0);
-      for (int u = 0; u < cnt; ++u) {
-        const int j = __builtin_amdgcn_readlane(ci, u);
-        const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), u));
-        const float* brow = b + (int64_t)j * l;
+      for (int u = 0; u < cnt; u += GU) {
+        float bv[GU][CPL], vv[GU];
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-          int col = lane + 64 * c;
-          if (col < l) acc[c] = fmaf(v, brow[col], acc[c]);
+        for (int t = 0; t < GU; ++t) {
+          // past the end of the row: the row's last entry again, its product is not added below
+          const int uu = min(u + t, cnt - 1);
+          const int j = __builtin_amdgcn_readlane(ci, uu);
+          vv[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), uu));
+          const float* brow = b + (int64_t)j * l;
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) bv[t][c] = brow[colc[c]];
+        }
+#pragma unroll
+        for (int t = 0; t < GU; ++t) {
+          if (u + t < cnt) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) acc[c] = fmaf(vv[t], bv[t][c], acc[c]);
+          }
         }
       }
+      ci = ci_n;
+      cv = cv_n;
     }
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-      int col = lane + 64 * c;
-      if (col < l) y[row * l + col] = acc[c] - sh[c];
-    }
+    for (int c = 0; c < CPL; ++c)
+      if (colok[c]) y[row * l + lane + 64 * c] = acc[c] - sh[c];
+    rb = nrb;
+    re = nre;
   }
 }
 
