@@ -30,8 +30,17 @@ constexpr int GRAM_THREADS = 1024;  // 16 waves per block, one block per CU (LDS
 
 __global__ void gram_absmax_kernel(const float* __restrict__ data, int64_t nnz, unsigned int* __restrict__ out_bits) {
   float m = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x)
-    m = fmaxf(m, fabsf(data[i]));
+  // 16-byte loads over the aligned middle of the array, scalars at both ends
+  const int64_t head = std::min<int64_t>(nnz, (int64_t)((16 - (reinterpret_cast<uintptr_t>(data) & 15)) & 15) / 4);
+  const int64_t nvec = (nnz - head) / 4;
+  const float4* dv = reinterpret_cast<const float4*>(data + head);
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = tid; i < nvec; i += nthr) {
+    const float4 v = dv[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (tid < head) m = fmaxf(m, fabsf(data[tid]));
+  for (int64_t i = head + nvec * 4 + tid; i < nnz; i += nthr) m = fmaxf(m, fabsf(data[i]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out_bits, __float_as_uint(m));
