@@ -322,10 +322,30 @@ __global__ __launch_bounds__(256) void ld_move_kernel(
   const int grp = threadIdx.x / G;
   const int n_items = sub_list ? *sub_count : n_act;
   for (int item = blockIdx.x * GROUPS + grp; item < n_items; item += gridDim.x * GROUPS) {
+    // The decision of one vertex is a chain of dependent gathers (list -> indptr -> indices -> comm -> Ktot) and the
+    // kernel is bound by its length: everything that depends on the same address is requested together, before the
+    // first branch that needs any of it (written the obvious way the compiler keeps seven round trips in series:
+    // list, indptr, [degree branch] comm[v] / k[v], Ktot[a], indices, comm[u], Ktot[c]; now five).
     const int w = sub_list ? sub_list[item] : item;
     const int v = list[w];
     const int64_t beg = indptr[v];
-    const int deg = (int)(indptr[v + 1] - beg);
+    const int64_t end = indptr[v + 1];
+    const int a = comm[v];
+    const long long kq = k[v];
+    const int deg = (int)(end - beg);
+    // the row's first 2 G entries (rows of the kNN graph itself: all of them)
+    int u_pre[2];
+    long long w_pre[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int e = sub + t * G;
+      u_pre[t] = e < deg ? indices[beg + e] : v;
+      w_pre[t] = e < deg ? wq[beg + e] : 0ll;
+    }
+    const unsigned long long Ka = Ktot[a];
+    int c_pre[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) c_pre[t] = comm[u_pre[t]];
     if (G < 64) {
       if (deg > GMAX) {  // decided by the wave-per-vertex instantiation
         if (sub == 0) ovf_list[atomicAdd(&counters[5], 1)] = w;
@@ -335,9 +355,8 @@ __global__ __launch_bounds__(256) void ld_move_kernel(
       if (sub == 0) hub_list[atomicAdd(&counters[4], 1)] = w;
       continue;
     }
-    const int a = comm[v];
-    const double kv = (double)k[v];
-    const double Ka_wo = (double)(long long)(Ktot[a] - (unsigned long long)k[v]);  // own community without v
+    const double kv = (double)kq;
+    const double Ka_wo = (double)(long long)(Ka - (unsigned long long)kq);  // own community without v
     Cand best;
     best.val = 0.0;
     best.c = -1;
@@ -352,28 +371,49 @@ __global__ __launch_bounds__(256) void ld_move_kernel(
         keys[i] = WH_EMPTY;
         vals[i] = 0ull;
       }
-      for (int e = sub; e < deg; e += G) {
+      auto insert = [&](int c, long long wt) {
+        unsigned int slot = hash32((unsigned int)c) & (nslots - 1);
+        for (;;) {
+          const int prev = atomicCAS(&keys[slot], WH_EMPTY, c);
+          if (prev == WH_EMPTY || prev == c) break;
+          slot = (slot + 1) & (nslots - 1);
+        }
+        atomicAdd(&vals[slot], (unsigned long long)wt);
+      };
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        if (sub + t * G < deg && u_pre[t] != v) insert(c_pre[t], w_pre[t]);
+      for (int e = sub + 2 * G; e < deg; e += G) {
         const int u = indices[beg + e];
-        if (u != v) {
-          const int c = comm[u];
-          unsigned int slot = hash32((unsigned int)c) & (nslots - 1);
-          for (;;) {
-            const int prev = atomicCAS(&keys[slot], WH_EMPTY, c);
-            if (prev == WH_EMPTY || prev == c) break;
-            slot = (slot + 1) & (nslots - 1);
-          }
-          atomicAdd(&vals[slot], (unsigned long long)wq[beg + e]);
+        if (u != v) insert(comm[u], wq[beg + e]);
+      }
+      // candidates: the community totals of all occupied slots of this lane are requested before the first is used
+      constexpr int MAXSL = GSLOTS / G;
+      // (no per-lane branch around the gather and no constant merged into its result: either makes the compiler wait
+      // for the load where it is issued; empty slots read Ktot[a], the wave skips slot ranges none of its tables has)
+      int cs[MAXSL];
+      unsigned long long kt[MAXSL];
+#pragma unroll
+      for (int t = 0; t < MAXSL; ++t) cs[t] = WH_EMPTY;
+#pragma unroll
+      for (int t = 0; t < MAXSL; ++t) {
+        const int sl = sub + t * G;
+        if (__ballot(sl < nslots)) {
+          cs[t] = sl < nslots ? __hip_atomic_load(&keys[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : WH_EMPTY;
+          kt[t] = Ktot[cs[t] != WH_EMPTY ? cs[t] : a];
         }
       }
-      for (int sl = sub; sl < nslots; sl += G) {
-        const int c = __hip_atomic_load(&keys[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+      for (int t = 0; t < MAXSL; ++t) {
+        const int c = cs[t];
         if (c != WH_EMPTY) {
-          const long long sum = (long long)__hip_atomic_load(&vals[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const long long sum =
+              (long long)__hip_atomic_load(&vals[sub + t * G], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           if (c == a) {
             w_own = sum;
           } else {
             Cand x;
-            x.val = (double)sum - g * kv * (double)(long long)Ktot[c];
+            x.val = (double)sum - g * kv * (double)(long long)kt[t];
             x.c = c;
             x.pr = prio(c, seed);
             if (cand_better(x, best)) best = x;
@@ -710,17 +750,37 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
   // list length of this round, produced on the device by the previous round (or the overflow count of this one)
   const int n_items = sub_list ? *sub_count : *n_cand_dev;
   for (int item = blockIdx.x * GROUPS + grp; item < n_items; item += gridDim.x * GROUPS) {
+    // (gathers grouped by what they depend on, as in ld_move_kernel: list -> {refsize, ref, k, comm, indptr}[v] ->
+    // {Ktot[a], indices, wq} -> {comm, ref}[u] -> {Kref, refsize, Eref}[c]; most launches of a refinement are short
+    // lists whose time IS the length of this chain)
     const int w = sub_list ? sub_list[item] : item;
     const int v = list[w];
+    const int rs_v = refsize[v], ref_v = ref[v];
+    const long long kq = k[v];
+    const int a = comm[v];
+    const int64_t beg = indptr[v];
+    const int64_t end = indptr[v + 1];
     int tgt = -1;
-    if (refsize[v] != 1 || ref[v] != v) {
+    if (rs_v != 1 || ref_v != v) {
       tgt = -2;
     } else if (mover_bit(v, round, seed)) {
-      const double kv = (double)k[v];
-      const int a = comm[v];
+      const int deg = (int)(end - beg);
+      int u_pre[2];
+      long long w_pre[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int e = sub + t * G;
+        u_pre[t] = e < deg ? indices[beg + e] : v;
+        w_pre[t] = e < deg ? wq[beg + e] : 0ll;
+      }
       const double KC = (double)(long long)Ktot[a];
-      const int64_t beg = indptr[v];
-      const int deg = (int)(indptr[v + 1] - beg);
+      int cm_pre[2], rf_pre[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        cm_pre[t] = comm[u_pre[t]];
+        rf_pre[t] = ref[u_pre[t]];
+      }
+      const double kv = (double)kq;
       if (G < 64) {
         if (deg > GMAX) {  // proposed by the wave-per-candidate instantiation
           if (sub == 0) ovf_list[atomicAdd(&counters[5], 1)] = w;
@@ -742,27 +802,50 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
           keys[i] = WH_EMPTY;
           vals[i] = 0ull;
         }
-        for (int e = sub; e < deg; e += G) {
+        auto insert = [&](int c, long long wt) {
+          unsigned int slot = hash32((unsigned int)c) & (nslots - 1);
+          for (;;) {
+            const int prev = atomicCAS(&keys[slot], WH_EMPTY, c);
+            if (prev == WH_EMPTY || prev == c) break;
+            slot = (slot + 1) & (nslots - 1);
+          }
+          atomicAdd(&vals[slot], (unsigned long long)wt);
+        };
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          if (sub + t * G < deg && u_pre[t] != v && cm_pre[t] == a) insert(rf_pre[t], w_pre[t]);
+        for (int e = sub + 2 * G; e < deg; e += G) {
           const int u = indices[beg + e];
-          if (u != v && comm[u] == a) {
-            const int c = ref[u];
-            unsigned int slot = hash32((unsigned int)c) & (nslots - 1);
-            for (;;) {
-              const int prev = atomicCAS(&keys[slot], WH_EMPTY, c);
-              if (prev == WH_EMPTY || prev == c) break;
-              slot = (slot + 1) & (nslots - 1);
-            }
-            atomicAdd(&vals[slot], (unsigned long long)wq[beg + e]);
+          if (u != v && comm[u] == a) insert(ref[u], wq[beg + e]);
+        }
+        constexpr int MAXSL = GSLOTS / G;
+        int cs[MAXSL], rsz[MAXSL];
+        unsigned long long kr[MAXSL], er[MAXSL];
+#pragma unroll
+        for (int t = 0; t < MAXSL; ++t) cs[t] = WH_EMPTY;
+#pragma unroll
+        for (int t = 0; t < MAXSL; ++t) {
+          const int sl = sub + t * G;
+          if (__ballot(sl < nslots)) {  // (see ld_move_kernel: uniform skip, no per-lane branch around the gathers)
+            int c = sl < nslots ? __hip_atomic_load(&keys[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : WH_EMPTY;
+            if (c == v) c = WH_EMPTY;
+            cs[t] = c;
+            const int ci = c != WH_EMPTY ? c : v;
+            kr[t] = Kref[ci];
+            rsz[t] = refsize[ci];
+            er[t] = Eref[ci];
           }
         }
-        for (int sl = sub; sl < nslots; sl += G) {
-          const int c = __hip_atomic_load(&keys[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (c != WH_EMPTY && c != v) {
-            const long long sum = (long long)__hip_atomic_load(&vals[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const double Kr = (double)(long long)Kref[c];
-            const bool single = refsize[c] == 1;
+#pragma unroll
+        for (int t = 0; t < MAXSL; ++t) {
+          const int c = cs[t];
+          if (c != WH_EMPTY) {
+            const long long sum =
+                (long long)__hip_atomic_load(&vals[sub + t * G], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const double Kr = (double)(long long)kr[t];
+            const bool single = rsz[t] == 1;
             const bool ok_target = (!single || !mover_bit(c, round, seed)) &&
-                                   ((double)(long long)Eref[c] >= g * Kr * (KC - Kr));  // target well connected
+                                   ((double)(long long)er[t] >= g * Kr * (KC - Kr));  // target well connected
             const double gain = (double)sum - g * kv * Kr;
             if (ok_target && gain >= 0.0) {
               Cand x;
