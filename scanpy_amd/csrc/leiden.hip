@@ -579,12 +579,18 @@ __global__ __launch_bounds__(256) void ld_apply_kernel(int n_act, const int* __r
   }
   __syncthreads();
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int64_t beg = 0, end = 0;
+  bool mover = false;
   if (w < n_act) {
     const int d = decision[w];
     if (d != -1) {
       const int v = list[w];
       flag[v] = 1;
       if (d >= 0) {
+        mover = true;
+        beg = indptr[v];
+        end = indptr[v + 1];
         const int a = comm[v];
         comm[v] = d;
         const unsigned long long kq = (unsigned long long)k[v];
@@ -592,12 +598,26 @@ __global__ __launch_bounds__(256) void ld_apply_kernel(int n_act, const int* __r
         atomicAdd(&Ktot[a], 0ull - kq);
         atomicAdd(&csize[d], 1);
         atomicSub(&csize[a], 1);
-        for (int64_t e = indptr[v]; e < indptr[v + 1]; ++e) flag[indices[e]] = 1;
         atomicAdd(&s_moved, 1);
       } else {
         atomicAdd(&s_blocked, 1);
       }
     }
+  }
+  // the movers' neighbours are flagged by the whole wave, two movers at a time (32 lanes each, coalesced row reads): a
+  // thread per mover walked its row entry by entry, one load in flight, every lane on a different cache line
+  unsigned long long m = __ballot(mover);
+  while (m) {
+    const int b0 = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    int b1 = b0;
+    if (m) {
+      b1 = __ffsll((long long)m) - 1;
+      m &= m - 1;
+    }
+    const int src = lane < 32 ? b0 : b1;
+    const int64_t rb = __shfl(beg, src), re = (lane >= 32 && b1 == b0) ? rb : __shfl(end, src);
+    for (int64_t e = rb + (lane & 31); e < re; e += 32) flag[indices[e]] = 1;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -647,10 +667,12 @@ __global__ __launch_bounds__(256) void ld_within_kernel(int n, const int64_t* __
   const int v = blockIdx.x * (256 / G) + threadIdx.x / G;
   if (v >= n) return;
   const int a = comm[v];
+  const int64_t beg = indptr[v], end = indptr[v + 1];
   long long s = 0;
-  for (int64_t e = indptr[v] + sub; e < indptr[v + 1]; e += G) {
+  for (int64_t e = beg + sub; e < end; e += G) {
     const int u = indices[e];
-    if (u != v && comm[u] == a) s += wq[e];
+    const long long we = wq[e];  // requested with the index, not after the community test
+    if (u != v && comm[u] == a) s += we;
   }
 #pragma unroll
   for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -663,11 +685,20 @@ __global__ void ld_refine_candidates_kernel(int n, const long long* __restrict__
                                             const unsigned long long* __restrict__ Ktot,
                                             const long long* __restrict__ a_in, double g, int* __restrict__ list,
                                             int* __restrict__ counters) {
-  int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= n) return;
-  const double kv = (double)k[v];
-  const double KC = (double)(long long)Ktot[comm[v]];
-  if ((double)a_in[v] >= g * kv * (KC - kv)) list[atomicAdd(&counters[2], 1)] = v;
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool take = false;
+  if (v < n) {
+    const double kv = (double)k[v];
+    const double KC = (double)(long long)Ktot[comm[v]];
+    take = (double)a_in[v] >= g * kv * (KC - kv);
+  }
+  // one returning atomic per wave, not per vertex (the list order is irrelevant: it is a set)
+  const unsigned long long m = __ballot(take);
+  int base = 0;
+  if (lane == 0 && m) base = atomicAdd(&counters[2], __popcll(m));
+  base = __shfl(base, 0);
+  if (take) list[base + __popcll(m & ((1ull << lane) - 1ull))] = v;
 }
 
 // Exact incremental update of w(r, C - r) after a round of merges.  For a vertex v that joined t this round
@@ -684,16 +715,22 @@ __global__ __launch_bounds__(256) void ld_refine_cut_update_kernel(
   const int sub = threadIdx.x % G;
   n_join = *n_join_dev;
   for (int w = blockIdx.x * (256 / G) + threadIdx.x / G; w < n_join; w += gridDim.x * (256 / G)) {
+  // (everything that hangs on the same address is requested together: the && chain of the obvious form is four
+  // round trips per neighbour -- comm[u], then ref[u], then stamp[u], then the weight)
   const int v = jlist[w];
   const int a = comm[v], t = ref[v];
+  const int64_t beg = indptr[v], end = indptr[v + 1];
+  const long long av = a_in[v];
   long long s = 0;
-  for (int64_t e = indptr[v] + sub; e < indptr[v + 1]; e += G) {
+  for (int64_t e = beg + sub; e < end; e += G) {
     const int u = indices[e];
-    if (u != v && comm[u] == a && ref[u] == t) s += (stamp[u] == round) ? wq[e] : 2 * wq[e];
+    const long long we = wq[e];
+    const int cu = comm[u], ru = ref[u], su = stamp[u];
+    if (u != v && cu == a && ru == t) s += (su == round) ? we : 2 * we;
   }
 #pragma unroll
   for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if (sub == 0) atomicAdd(&Eref[t], (unsigned long long)(a_in[v] - s));
+  if (sub == 0) atomicAdd(&Eref[t], (unsigned long long)(av - s));
   }
 }
 
@@ -1148,9 +1185,30 @@ __global__ __launch_bounds__(256) void ld_agg_wave_kernel(
   WaveHash wh{hkeys[threadIdx.x >> 6], hvals[threadIdx.x >> 6], WH_SLOTS};
   wh.size_for((int)need);
   wh.clear(lane);
-  for (int64_t i = m0; i < m1; ++i) {
-    const int v = members[i];
-    for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) wh.add(cid[indices[e]], wq[e]);
+  // The members' row extents are fetched 64 at a time (one coalesced gather), then two rows are in flight at once:
+  // walking the members one by one is a chain members -> indptr -> indices -> cid per 24-entry row with nothing else
+  // in flight.
+  for (int64_t i0 = m0; i0 < m1; i0 += 64) {
+    const int cnt = (int)(m1 - i0 < 64 ? m1 - i0 : 64);
+    long long mb = 0, me = 0;
+    if (lane < cnt) {
+      const int v = members[i0 + lane];
+      mb = indptr[v];
+      me = indptr[v + 1];
+    }
+    for (int j = 0; j < cnt; j += 2) {
+      const int j1 = j + 1 < cnt ? j + 1 : j;
+      const long long b0 = readlane_i64(mb, j), e0 = readlane_i64(me, j);
+      const long long b1 = readlane_i64(mb, j1), e1 = j1 != j ? readlane_i64(me, j1) : b1;
+      const bool h0 = b0 + lane < e0, h1 = b1 + lane < e1;
+      const int x0 = h0 ? indices[b0 + lane] : 0, x1 = h1 ? indices[b1 + lane] : 0;
+      const long long w0 = h0 ? wq[b0 + lane] : 0ll, w1 = h1 ? wq[b1 + lane] : 0ll;
+      const int c0 = cid[x0], c1 = cid[x1];
+      if (h0) wh.add(c0, w0);
+      if (h1) wh.add(c1, w1);
+      for (int64_t e = b0 + 64 + lane; e < e0; e += 64) wh.add(cid[indices[e]], wq[e]);
+      for (int64_t e = b1 + 64 + lane; e < e1; e += 64) wh.add(cid[indices[e]], wq[e]);
+    }
   }
   int base = 0;
   for (int s0 = 0; s0 < wh.nslots; s0 += 64) {
@@ -1201,9 +1259,22 @@ __global__ __launch_bounds__(THREADS) void ld_agg_block_kernel(
         vals[i] = 0ull;
       }
       __syncthreads();
+      // the extent of a wave's next member row is requested while the current row is walked
+      int64_t nb = 0, ne = 0;
+      if (m0 + wv < m1) {
+        const int v = members[m0 + wv];
+        nb = indptr[v];
+        ne = indptr[v + 1];
+      }
       for (int64_t i = m0 + wv; i < m1; i += THREADS / 64) {
-        const int v = members[i];
-        for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) {
+        const int64_t rb = nb, re = ne;
+        if (i + THREADS / 64 < m1) {
+          const int vn = members[i + THREADS / 64];
+          nb = indptr[vn];
+          ne = indptr[vn + 1];
+        }
+        for (int64_t e = rb + lane; e < re; e += 64) {
+          const long long we = wq[e];
           const int key = cid[indices[e]];
           if (n_pass > 1 && (hash32((unsigned int)key * 0x9E3779B1u + 0x7F4A7C15u) >> 8) % n_pass != pass) continue;
           unsigned int slot = hash32((unsigned int)key) & (nslots - 1);
@@ -1211,7 +1282,7 @@ __global__ __launch_bounds__(THREADS) void ld_agg_block_kernel(
           for (;;) {
             const int prev = atomicCAS(&keys[slot], WH_EMPTY, key);
             if (prev == WH_EMPTY || prev == key) {
-              atomicAdd(&vals[slot], (unsigned long long)wq[e]);
+              atomicAdd(&vals[slot], (unsigned long long)we);
               break;
             }
             slot = (slot + 1) & (nslots - 1);
@@ -1265,16 +1336,21 @@ __global__ __launch_bounds__(256) void ld_agg_compact_kernel(int nn, const int64
 
 // ---- quality ---------------------------------------------------------------------------------------
 // internal[0] += sum over stored entries inside a community (self loops included)
+// G lanes per vertex (16 on the kNN graph itself: four rows in flight per wave instead of one)
+template <int G>
 __global__ __launch_bounds__(256) void ld_internal_kernel(int n, const int64_t* __restrict__ indptr,
                                                           const int* __restrict__ indices,
                                                           const long long* __restrict__ wq, const int* __restrict__ comm,
                                                           unsigned long long* __restrict__ internal) {
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, sub = threadIdx.x % G;
   long long s = 0;
-  for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < n; v += gridDim.x * 4) {
+  for (int v = blockIdx.x * (256 / G) + threadIdx.x / G; v < n; v += gridDim.x * (256 / G)) {
     const int a = comm[v];
-    for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64)
-      if (comm[indices[e]] == a) s += wq[e];
+    const int64_t beg = indptr[v], end = indptr[v + 1];
+    for (int64_t e = beg + sub; e < end; e += G) {
+      const long long we = wq[e];
+      if (comm[indices[e]] == a) s += we;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -1506,8 +1582,12 @@ static int compute_totals(LeidenCtx& cx, const LevelGraph& g, const int* comm) {
 // modularity of `comm` on level graph g (needs Ktot up to date)
 static int quality(LeidenCtx& cx, const LevelGraph& g, const int* comm, double* q) {
   SCAMD_HIP_CHECK(hipMemsetAsync(cx.b.total + 1, 0, sizeof(unsigned long long), cx.s));
-  hipLaunchKernelGGL(ld_internal_kernel, dim3((unsigned)std::min(2048, ceil_div(g.n, 4))), dim3(256), 0, cx.s, g.n, g.indptr, g.indices, g.wq,
-                     comm, cx.b.total + 1);
+  if (g.nnz <= (int64_t)48 * g.n)
+    hipLaunchKernelGGL(ld_internal_kernel<16>, dim3((unsigned)std::min(2048, ceil_div(g.n, 16))), dim3(256), 0, cx.s, g.n,
+                       g.indptr, g.indices, g.wq, comm, cx.b.total + 1);
+  else
+    hipLaunchKernelGGL(ld_internal_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(g.n, 4))), dim3(256), 0, cx.s, g.n,
+                       g.indptr, g.indices, g.wq, comm, cx.b.total + 1);
   SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(ld_sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(1024), 0, cx.s, g.n, cx.b.Ktot, cx.m2, cx.b.dscratch + 4);
   SCAMD_LAUNCH_CHECK();
