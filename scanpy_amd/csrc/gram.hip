@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void gram_tileptr_kernel(const int64_t* __rest
   for (int u = last_tile + 1 + lane; u <= ntile; u += 64) out[u] = (unsigned short)len;
 }
 
-// What binds this kernel (round-2 measurements, tools/probes/lds_atomic_probe.hip + profiles/r03c_pca_stage_pmc*.csv):
+// What binds this kernel (round-2 measurements, tools/probes/lds_atomic_probe.hip + profiles/r02p_pca_stage_pmc*.csv):
 // NOT the 64-bit LDS atomic -- the probe retires 14 ds_add_u64 lanes per CU per ns (3.6e12 /s chip-wide, ds_add_u32 23,
 // ds_add_f64 7.5), the 5e9 products of the 1M x 2k matrix would take 1.4 ms at that rate.  The waves were parked on
 // s_waitcnt (69 % of the wave-cycles): every step's pointer and entry loads were waited for where they were issued.
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
   const int64_t r0 = (int64_t)chunk * rows_per_chunk;
   const int64_t r1 = std::min<int64_t>(n, r0 + rows_per_chunk);
   const int a0 = a * GT, b0 = b * GT;
-  // Two-stage software pipeline over the wave's steps (8 rows each).  PMC (profiles/r03c_pca_stage_pmc1.csv): 69 % of the
+  // Two-stage software pipeline over the wave's steps (8 rows each).  PMC (profiles/r02p_pca_stage_pmc1.csv): 69 % of the
   // wave cycles of the straight loop were spent parked on s_waitcnt; a step is a chain of three dependent global loads
   // (tile pointers + indptr -> the row's entries of tile b -> of tile a) in front of ~40 products.  With the pointers of
   // step s + 2 and the first entry chunks of step s + 1 in flight while step s is computed: 13.2 -> 12.4 ms.  The rest of

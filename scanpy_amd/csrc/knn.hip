@@ -929,8 +929,21 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
       if (idx >= 0 && idx < n && idx != q) {
         const float* cp = x + (int64_t)idx * ld;
         double s = 0.0;
-        for (int c = 0; c < d; ++c) {
-          double df = (double)qs[w][c] - (double)cp[c];
+        // eight coordinates of the candidate's row requested at a time, summed in the same order as one by one (every
+        // lane walks its own row: one load in flight per lane made this kernel 50 serial cache round trips per query)
+        int c = 0;
+        for (; c + 8 <= d; c += 8) {
+          float t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] = cp[c + u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const double df = (double)qs[w][c + u] - (double)t[u];
+            s = fma(df, df, s);
+          }
+        }
+        for (; c < d; ++c) {
+          const double df = (double)qs[w][c] - (double)cp[c];
           s = fma(df, df, s);
         }
         myd[p] = s;
@@ -1128,53 +1141,64 @@ __global__ void ivf_init_kernel(const float* __restrict__ x, int64_t n, int d, i
   for (int j = threadIdx.x; j < d; j += blockDim.x) cent[c * d + j] = x[row * ld + j];
 }
 
-// One thread per sampled row (row = start + j * step, j < count), the row in registers: nearest centroid by
-// (x - c)^2 with the centroids staged through LDS in chunks of 64 (broadcast reads).  accumulate != 0: fixed-point
-// sums / counts of the Lloyd update.  qcounts != NULL: additionally counts the rows of the query range [q0, q1).
+// centroid table of the assignment kernel: [n_cells][DP] rows of float4 = the centroid, zeros, |c|^2 / 2 in the last column
+__global__ void ivf_centpad_kernel(const float* __restrict__ cent, int n_cells, int d, int DP, float* __restrict__ centp) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_cells * DP) return;
+  const int c = e / DP, t = e - c * DP;
+  float v = 0.f;
+  if (t < d) {
+    v = cent[c * d + t];
+  } else if (t == DP - 1) {
+    float hn = 0.f;
+    for (int u = 0; u < d; ++u) hn = fmaf(cent[c * d + u], cent[c * d + u], hn);
+    v = 0.5f * hn;
+  }
+  centp[e] = v;
+}
+
+// One thread per sampled row (row = start + j * step, j < count), the row in registers.
+// nearest centroid = argmax_c (x . c - |c|^2 / 2): ONE fused multiply-add per dimension, two dimensions per
+// v_pk_fma_f32 with the centroid as the SCALAR operand (the table is the same for every lane: s_load through the
+// constant cache, no LDS).  History: (x - c)^2 from an LDS-staged table was a subtract and an fma per dimension,
+// unpacked -- 2.4 ms of VALU issue at 1M x 1024 x 50; the packed dot product from LDS 1.7 ms, bound by the broadcast
+// ds_read_b128 (13 per centroid and wave).  The half norm rides in the last column against a -1 in the row.  A
+// different rounding than the difference form can move a row between two almost equidistant cells; cells only steer
+// the pruning, never the result.
+// accumulate != 0: fixed-point sums / counts of the Lloyd update.  qcounts != NULL: additionally counts the rows of the
+// query range [q0, q1).
 template <int H>
 __global__ __launch_bounds__(256) void ivf_assign_kernel(const float* __restrict__ x, int d, int64_t ld, int64_t start,
-                                                         int64_t step, int64_t count, const float* __restrict__ cent,
+                                                         int64_t step, int64_t count, const float* __restrict__ centp,
                                                          int n_cells, int* __restrict__ labels, int accumulate,
                                                          long long* __restrict__ sums, int* __restrict__ counts,
                                                          int64_t q0, int64_t q1, int* __restrict__ qcounts) {
-  constexpr int CH = 64;                  // centroids per LDS chunk
-  constexpr int DP = (2 * H + 3) / 4 * 4;  // dims padded to float4
-  __shared__ __attribute__((aligned(16))) float cc[CH * DP];
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  constexpr int DP = (2 * H + 1 + 3) / 4 * 4;  // dims + the norm column, padded to float4
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool valid = j < count;
   const int64_t row = valid ? start + j * step : start;
   float xr[DP];
 #pragma unroll
   for (int c = 0; c < DP; ++c) xr[c] = (c < d) ? x[row * ld + c] : 0.f;
-  float best = INFINITY;
+  xr[DP - 1] = -1.0f;
+  float best = -INFINITY;
   int bi = 0;
-  for (int c0 = 0; c0 < n_cells; c0 += CH) {
-    __syncthreads();
-    const int nc = min(CH, n_cells - c0);
-    for (int e = threadIdx.x; e < nc * DP; e += 256) {
-      const int c = e / DP, t = e - c * DP;
-      cc[e] = (t < d) ? cent[(c0 + c) * d + t] : 0.f;
-    }
-    __syncthreads();
-    for (int c = 0; c < nc; ++c) {
-      const float4* cp = reinterpret_cast<const float4*>(cc + c * DP);
-      float s = 0.f;
+  for (int c = 0; c < n_cells; ++c) {
+    const float4* cp = reinterpret_cast<const float4*>(centp + (int64_t)c * DP);
+    f2 s = {0.f, 0.f};
 #pragma unroll
-      for (int t4 = 0; t4 < DP / 4; ++t4) {
-        const float4 v = cp[t4];
-        float df = xr[4 * t4 + 0] - v.x;
-        s = fmaf(df, df, s);
-        df = xr[4 * t4 + 1] - v.y;
-        s = fmaf(df, df, s);
-        df = xr[4 * t4 + 2] - v.z;
-        s = fmaf(df, df, s);
-        df = xr[4 * t4 + 3] - v.w;
-        s = fmaf(df, df, s);
-      }
-      if (s < best) {
-        best = s;
-        bi = c0 + c;
-      }
+    for (int t4 = 0; t4 < DP / 4; ++t4) {
+      const float4 v = cp[t4];
+      const f2 xa = {xr[4 * t4 + 0], xr[4 * t4 + 1]}, xb = {xr[4 * t4 + 2], xr[4 * t4 + 3]};
+      const f2 va = {v.x, v.y}, vb = {v.z, v.w};
+      s = __builtin_elementwise_fma(xa, va, s);
+      s = __builtin_elementwise_fma(xb, vb, s);
+    }
+    const float score = s.x + s.y;
+    if (score > best) {
+      best = score;
+      bi = c;
     }
   }
   if (!valid) return;
@@ -1356,7 +1380,7 @@ struct KnnBuffers {
   float* xp; float* cn; float* mu; double* mean_partial; unsigned int* cmax; int* cand_idx; float* cand_tau; double* kth_d2;
   int* flag_list; int* counters; double* scratch_d; int* scratch_i; int* fb_counts;
   // cell-pruned search
-  int* labels; int* perm; int* qpos; int* block_cell; float* cent; long long* sums; int* cell_ints;
+  int* labels; int* perm; int* qpos; int* block_cell; float* cent; float* centp; long long* sums; int* cell_ints;
   unsigned int* radius_bits; int* cell_order; float* cell_lb2; int* cell_aux; int* block_perm;
 };
 
@@ -1375,7 +1399,7 @@ static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffe
   b->scratch_i = ws.take<int>((size_t)FALLBACK_CHUNK * FALLBACK_CAP);
   b->fb_counts = ws.take<int>((size_t)FALLBACK_CHUNK);
   b->labels = b->perm = b->qpos = b->block_cell = b->cell_ints = nullptr;
-  b->cent = nullptr;
+  b->cent = b->centp = nullptr;
   b->sums = nullptr;
   b->radius_bits = nullptr;
   b->cell_order = nullptr;
@@ -1387,6 +1411,7 @@ static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffe
     b->qpos = ws.take<int>((size_t)p.n_slot_max);
     b->block_cell = ws.take<int>((size_t)(p.n_slot_max / 128 + 1));
     b->cent = ws.take<float>((size_t)p.n_cells * 128);
+    b->centp = ws.take<float>((size_t)p.n_cells * 136);  // [n_cells][2H + norm column, padded to float4]
     b->sums = ws.take<long long>((size_t)p.n_cells * 128);
     b->cell_ints = ws.take<int>((size_t)p.n_cells * 8);  // counts, qcounts, map, row_off, row_cur, slot_off, slot_cur, tile0/ntiles reuse
     b->radius_bits = ws.take<unsigned int>((size_t)p.n_cells);
@@ -1483,6 +1508,7 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   int* ntiles = reinterpret_cast<int*>(b.sums);  // the sums buffer is free once the quantiser is done
   // 1. quantiser: Lloyd on a strided sample
   auto assign = ivf_assign_kernel<H>;
+  constexpr int DPA = (2 * H + 1 + 3) / 4 * 4;  // row length of the padded centroid table (ivf_assign_kernel)
   hipLaunchKernelGGL(ivf_init_kernel, dim3(nc), dim3(64), 0, s, x, n, d, ld, nc, b.cent);
   SCAMD_LAUNCH_CHECK();
   const int64_t n_sample = std::min<int64_t>(n, (int64_t)64 * nc);
@@ -1490,8 +1516,11 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   for (int it = 0; it < 3; ++it) {
     SCAMD_HIP_CHECK(hipMemsetAsync(b.sums, 0, sizeof(long long) * nc * d, s));
     SCAMD_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * nc, s));
+    hipLaunchKernelGGL(ivf_centpad_kernel, dim3((unsigned)ceil_div((int64_t)nc * DPA, 256)), dim3(256), 0, s, b.cent, nc, d,
+                       DPA, b.centp);
+    SCAMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(assign, dim3((unsigned)ceil_div(n_sample, 256)), dim3(256), 0, s, x, d, ld,
-                       (int64_t)0, step, n_sample, b.cent, nc, b.labels, 1, b.sums, counts, (int64_t)0, (int64_t)0,
+                       (int64_t)0, step, n_sample, b.centp, nc, b.labels, 1, b.sums, counts, (int64_t)0, (int64_t)0,
                        (int*)nullptr);
     SCAMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(ivf_update_kernel, dim3((unsigned)ceil_div((int64_t)nc * d, 256)), dim3(256), 0, s, b.sums,
@@ -1500,8 +1529,11 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   }
   // 2. every row to its cell
   SCAMD_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * 2 * nc, s));
+  hipLaunchKernelGGL(ivf_centpad_kernel, dim3((unsigned)ceil_div((int64_t)nc * DPA, 256)), dim3(256), 0, s, b.cent, nc, d,
+                     DPA, b.centp);
+  SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(assign, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, x, d, ld,
-                     (int64_t)0, (int64_t)1, n, b.cent, nc, b.labels, 0, (long long*)nullptr, counts, q_begin,
+                     (int64_t)0, (int64_t)1, n, b.centp, nc, b.labels, 0, (long long*)nullptr, counts, q_begin,
                      q_begin + n_query, qcounts);
   SCAMD_LAUNCH_CHECK();
   std::vector<int> h_cnt(2 * nc);

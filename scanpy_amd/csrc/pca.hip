@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64) void tr_scatter_kernel(const int64_t* __restric
 // The row's (index, value) pairs are loaded 64 at a time and broadcast with readlane; B rows
 // (l*4 bytes, L2-resident panel) are read coalesced.
 // Memory-level parallelism is the whole game here: the first version waited for every B row before its fma (one load
-// in flight per wave, 80 % of the wave-cycles parked on s_waitcnt: profiles/r03c_pca_stage_pmc1.csv).  Now GU = 8 B rows
+// in flight per wave, 80 % of the wave-cycles parked on s_waitcnt: profiles/r02p_pca_stage_pmc1.csv).  Now GU = 8 B rows
 // are requested back to back and consumed in the same order (the sum is bit for bit the old one), the next 64 entries
 // of the row and the next row's extent are requested before the current ones are used.
 // ------------------------------------------------------------------------------------------------

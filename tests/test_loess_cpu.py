@@ -109,9 +109,11 @@ def test_seurat_v3_warns_on_non_counts_and_handles_constant_genes(pbmc68k):
     assert not b.var["highly_variable"].iloc[:5].any() and int(b.var["highly_variable"].sum()) == 50
 
 
-def test_clip_col_sums_tensor_ops_equal_the_stub():
-    """`GpuPPBackend.clip_col_sums` / `nonnegative_integers` are device tensor ops (no kernel of their own yet): run the
-    very same code on CPU tensors and compare with the numpy stand-in"""
+def test_clip_col_sums_stub_and_value_check_tensor_ops():
+    """The numpy stand-in of `clip_col_sums` against the reference formula (`clip_square_sum`,
+    _highly_variable_genes.py:75-115; the product's kernel `scamd_pp_col_stats_clip_f32` is compared with the same
+    formula in tests/test_gpu_preprocess.py), and `GpuPPBackend.nonnegative_integers` -- plain tensor ops -- run on CPU
+    tensors."""
     import torch
 
     rng = np.random.default_rng(1)
@@ -125,10 +127,14 @@ def test_clip_col_sums_tensor_ops_equal_the_stub():
     clip = rng.random(40) * 10
     mask = rng.random(300) < 0.5
     for rm in (None, mask):
-        got = _csr_device.GpuPPBackend.clip_col_sums(None, dm, clip, row_mask=rm)
-        want = stub.clip_col_sums(ms, clip, row_mask=rm)
-        np.testing.assert_allclose(got[0], want[0], rtol=1e-12)
-        np.testing.assert_allclose(got[1], want[1], rtol=1e-12)
+        d = x.toarray().astype(np.float64)
+        if rm is not None:
+            d = d[rm]
+        c = np.minimum(d, clip[None, :]) * (d != 0)
+        want_sq, want_s = (c * c).sum(axis=0), c.sum(axis=0)
+        got = stub.clip_col_sums(ms, clip, row_mask=rm)
+        np.testing.assert_allclose(got[0], want_sq, rtol=1e-12)
+        np.testing.assert_allclose(got[1], want_s, rtol=1e-12)
     assert _csr_device.GpuPPBackend.nonnegative_integers(None, dm) is True
     dm.data[3] = 0.5
     assert _csr_device.GpuPPBackend.nonnegative_integers(None, dm) is False
