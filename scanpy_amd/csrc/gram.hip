@@ -108,13 +108,31 @@ __device__ __forceinline__ long long fixed_round(double x) {
   return llrint(x);
 }
 
-template <bool A_FROM_MEM>
+// FAST: every product is rounded with the 2^52 trick alone (two instructions) and a product outside its range
+// (|x| >= 2^51, or NaN) only raises `*flag`; the host then runs the !FAST instantiation -- fixed_round with its llrint
+// branch -- which returns at once unless the flag is up, after a kernel that clears the (then meaningless) sums.  The
+// branchy form cost the common case dearly: the compiler does not jump over the llrint side, its six float64
+// instructions issue with an empty exec mask behind EVERY product, plus four scalar instructions of mask bookkeeping.
+template <bool A_FROM_MEM, bool FAST>
 __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ data,
     int64_t n, int ntile, const unsigned short* __restrict__ ptr, int rows_per_chunk, double scale,
-    unsigned long long* __restrict__ gram, int64_t ld, unsigned long long* __restrict__ colsum) {
+    unsigned long long* __restrict__ gram, int64_t ld, unsigned long long* __restrict__ colsum,
+    unsigned int* __restrict__ flag) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long tile[];  // [GT][GT] + [GT] column sums
   unsigned long long* csum = tile + GT * GT;
+  if constexpr (!FAST) {
+    if (*flag == 0u) return;
+  }
+  bool out_of_range = false;
+  auto round_product = [&](double x) -> unsigned long long {
+    if constexpr (FAST) {
+      out_of_range |= !(fabs(x) < 2251799813685248.0);
+      return (unsigned long long)(__double_as_longlong(x + 6755399441055744.0) - 0x4338000000000000ll);
+    } else {
+      return (unsigned long long)fixed_round(x);
+    }
+  };
   // blockIdx.x -> (pair index, chunk); pair index -> (a, b), a <= b
   const int chunk = blockIdx.y;
   int a = 0, rem = blockIdx.x;
@@ -261,7 +279,7 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
 #pragma unroll
             for (int pp = 0; pp < 8; ++pp) {
               if (has_b && pc + pp < na)
-                atomicAdd(&tile[ja8[pp] * GT + jb], (unsigned long long)fixed_round((double)va8[pp] * vb));
+                atomicAdd(&tile[ja8[pp] * GT + jb], round_product((double)va8[pp] * vb));
             }
           } else {
             const int cnt = min(8, max_na - pc);
@@ -269,7 +287,7 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
               if (has_b && pc + pp < na) {
                 const int ja = indices[pa + pc + pp] - a0;
                 const float va = data[pa + pc + pp];
-                atomicAdd(&tile[ja * GT + jb], (unsigned long long)fixed_round((double)va * vb));
+                atomicAdd(&tile[ja * GT + jb], round_product((double)va * vb));
               }
             }
           }
@@ -291,6 +309,18 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
   if (diag)
     for (int i = threadIdx.x; i < GT; i += GRAM_THREADS)
       if (csum[i]) atomicAdd(&colsum[a0 + i], csum[i]);
+  if constexpr (FAST) {
+    if (__any(out_of_range) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+  }
+}
+
+// the fast pass met a product outside the range of its rounding: clear what it accumulated
+__global__ void gram_clear_if_flagged_kernel(unsigned long long* __restrict__ gram, int64_t n_gram,
+                                             unsigned long long* __restrict__ colsum, int64_t n_col,
+                                             const unsigned int* __restrict__ flag) {
+  if (*flag == 0u) return;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_gram; i += (int64_t)gridDim.x * blockDim.x) gram[i] = 0ull;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_col; i += (int64_t)gridDim.x * blockDim.x) colsum[i] = 0ull;
 }
 
 // lower triangle <- upper triangle (tile pairs a < b were accumulated into the upper block only)
@@ -357,14 +387,26 @@ extern "C" int scamd_csr_gram_f32(const int64_t* indptr, const int32_t* indices,
     const char* e = getenv("SCAMD_GRAM_A_FROM_MEM");
     return e && e[0] == '1';
   }();
-  auto gram_kernel = a_from_mem ? gram_tile_kernel<true> : gram_tile_kernel<false>;
+  auto gram_kernel = a_from_mem ? gram_tile_kernel<true, true> : gram_tile_kernel<false, true>;
+  auto gram_exact = gram_tile_kernel<false, false>;
   SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_exact),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // column sums are scaled by 2^scale_bits as well (x * 2^S), products by 2^S: x_a * (x_b * 2^S)
   const double scale = std::ldexp(1.0, scale_bits);
+  unsigned int* flag = mx + 1;  // products outside the fast rounding's range (see gram_tile_kernel)
+  SCAMD_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(unsigned int), s));
+  unsigned long long* gram_u = reinterpret_cast<unsigned long long*>(gram);
+  unsigned long long* colsum_u = reinterpret_cast<unsigned long long*>(colsum);
   hipLaunchKernelGGL(gram_kernel, dim3((unsigned)npair, (unsigned)n_chunks), dim3(GRAM_THREADS), lds, s, indptr,
-                     indices, data, n, ntile, ptr, rows_per_chunk, scale,
-                     reinterpret_cast<unsigned long long*>(gram), ld_gram, reinterpret_cast<unsigned long long*>(colsum));
+                     indices, data, n, ntile, ptr, rows_per_chunk, scale, gram_u, ld_gram, colsum_u, flag);
+  SCAMD_LAUNCH_CHECK();
+  // no-ops unless the flag went up (no host round trip: the entry stays stream-ordered)
+  hipLaunchKernelGGL(gram_clear_if_flagged_kernel, dim3(1024), dim3(256), 0, s, gram_u, gp * ld_gram, colsum_u, gp, flag);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gram_exact, dim3((unsigned)npair, (unsigned)n_chunks), dim3(GRAM_THREADS), lds, s, indptr,
+                     indices, data, n, ntile, ptr, rows_per_chunk, scale, gram_u, ld_gram, colsum_u, flag);
   SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(gram_mirror_kernel, dim3((unsigned)ceil_div(gp, 256), (unsigned)gp), dim3(256), 0, s,
                      reinterpret_cast<long long*>(gram), gp, ld_gram);

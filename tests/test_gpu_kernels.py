@@ -299,6 +299,51 @@ def test_csr_gram_bit_exact(K, n, g, density):
     np.testing.assert_array_equal(gq2.cpu().numpy(), gq)
 
 
+@pytest.mark.gpu
+def test_csr_gram_products_beyond_the_fast_rounding(K):
+    """Products of 2^51 and more leave the range of the fast kernel's 2^52 rounding trick: it raises a device flag, the
+    sums are cleared and the exact instantiation (llrint) runs -- all stream-ordered.  A few huge values among ordinary
+    ones, bit-exact against Python integers; a second, all-small call on the same workspace must not see a stale flag."""
+    import torch
+    from fractions import Fraction
+    from scipy import sparse
+
+    rng = np.random.default_rng(5)
+    n, g, sb = 700, 300, 36
+    x = sparse.random(n, g, density=0.08, random_state=rng, format="csr", dtype=np.float32)
+    x.data = np.log1p(np.exp(rng.standard_normal(x.nnz))).astype(np.float32)
+    big = rng.choice(x.nnz, size=25, replace=False)
+    x.data[big] = rng.uniform(300.0, 900.0, size=25).astype(np.float32)  # 300^2 * 2^36 = 6e15 > 2^51
+    x.sort_indices()
+
+    def run(m):
+        ip = torch.from_numpy(m.indptr.astype(np.int64)).cuda()
+        ix = torch.from_numpy(m.indices.astype(np.int32)).cuda()
+        dv = torch.from_numpy(m.data).cuda()
+        gq, cq = K.csr_gram(ip, ix, dv, n, g, sb)
+        return gq.cpu().numpy()[:g, :g], cq.cpu().numpy()[:g]
+
+    def exact(m):
+        ref = [[0] * g for _ in range(g)]
+        for r in range(n):
+            lo, hi = m.indptr[r], m.indptr[r + 1]
+            cols, vals = m.indices[lo:hi], m.data[lo:hi]
+            for ja, va in zip(cols, vals):
+                for jb, vb in zip(cols, vals):
+                    # the kernel rounds fl64(va * fl64(vb * 2^S)) to nearest-even: both products are exact in float64
+                    ref[ja][jb] += round(Fraction(float(va)) * Fraction(float(vb)) * 2 ** sb)
+        return np.array(ref, dtype=object)
+
+    gq, _ = run(x)
+    assert float(np.abs(x.data).max()) ** 2 * 2.0 ** sb > 2.0 ** 51
+    ref = exact(x)
+    assert (gq.astype(object) == ref).all()
+    small = x.copy()
+    small.data = np.minimum(small.data, 8.0).astype(np.float32)
+    gs, _ = run(small)
+    assert (gs.astype(object) == exact(small)).all()
+
+
 @pytest.mark.parametrize("d", [50, 20])
 def test_knn_cell_pruned_equals_brute_force(K, monkeypatch, d):
     """the exact cell-pruned sweep returns what the brute-force sweep returns (bitwise: both end in the same float64
