@@ -86,16 +86,15 @@ __global__ __launch_bounds__(256) void gram_tileptr_kernel(const int64_t* __rest
 // Broadcast lane PP of every aligned group of 8 lanes to the whole group with DPP (VALU) instead of ds_bpermute: a quad
 // broadcast, then the other quad's copy by a row shift of 4 and a select (same speed as the permute when it was tried).
 template <int PP>
-__device__ __forceinline__ int bcast8(int x, bool upper_quad) {
+__device__ __forceinline__ int bcast8(int x) {
   constexpr int Q = PP & 3;
   constexpr int QUAD = Q | (Q << 2) | (Q << 4) | (Q << 6);
   const int y = __builtin_amdgcn_update_dpp(0, x, QUAD, 0xf, 0xf, false);
+  // the other quad's copy: a row shift by 4 written only into the quads that need it (bank mask), the rest keeps y
   if constexpr (PP < 4) {
-    const int z = __builtin_amdgcn_update_dpp(0, y, 0x114, 0xf, 0xf, false);  // row_shr:4: lane i <- lane i - 4
-    return upper_quad ? z : y;
+    return __builtin_amdgcn_update_dpp(y, y, 0x114, 0xf, 0xa, false);  // row_shr:4 into quads 1 and 3
   } else {
-    const int z = __builtin_amdgcn_update_dpp(0, y, 0x104, 0xf, 0xf, false);  // row_shl:4: lane i <- lane i + 4
-    return upper_quad ? y : z;
+    return __builtin_amdgcn_update_dpp(y, y, 0x104, 0xf, 0x5, false);  // row_shl:4 into quads 0 and 2
   }
 }
 
@@ -109,7 +108,7 @@ __device__ __forceinline__ long long fixed_round(double x) {
 }
 
 // FAST: every product is rounded with the 2^52 trick alone (two instructions) and a product outside its range
-// (|x| >= 2^51, or NaN) only raises `*flag`; the host then runs the !FAST instantiation -- fixed_round with its llrint
+// (|x| >= 2^51) only raises `*flag`; the host then runs the !FAST instantiation -- fixed_round with its llrint
 // branch -- which returns at once unless the flag is up, after a kernel that clears the (then meaningless) sums.  The
 // branchy form cost the common case dearly: the compiler does not jump over the llrint side, its six float64
 // instructions issue with an empty exec mask behind EVERY product, plus four scalar instructions of mask bookkeeping.
@@ -124,10 +123,11 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
   if constexpr (!FAST) {
     if (*flag == 0u) return;
   }
-  bool out_of_range = false;
+  // FAST: the range of the products is bounded once per wave from the largest |value| it met in either tile (two
+  // v_max_f32 per eight products; tracking the products themselves was two to four instructions behind each of them)
+  float amax = 0.f, bmax = 0.f;
   auto round_product = [&](double x) -> unsigned long long {
     if constexpr (FAST) {
-      out_of_range |= !(fabs(x) < 2251799813685248.0);
       return (unsigned long long)(__double_as_longlong(x + 6755399441055744.0) - 0x4338000000000000ll);
     } else {
       return (unsigned long long)fixed_round(x);
@@ -237,15 +237,17 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
         const int myq = qc + q;
         const bool has_b = myq < nb;
         int jb = (qc == 0 ? en_cur.jb : en_cur.jb2) - b0;
-        double vb = (double)(qc == 0 ? en_cur.vb : en_cur.vb2) * scale;
+        float vbf = qc == 0 ? en_cur.vb : en_cur.vb2;
         if (qc > 8) {  // rows with more than sixteen entries in tile b: later chunks straight from memory
           jb = 0;
-          vb = 0.0;
+          vbf = 0.f;
           if (has_b) {
             jb = indices[pb + myq] - b0;
-            vb = (double)data[pb + myq] * scale;
+            vbf = data[pb + myq];
           }
         }
+        if constexpr (FAST) bmax = fmaxf(bmax, fabsf(vbf));
+        const double vb = (double)vbf * scale;
         for (int pc = 0; pc < max_na; pc += 8) {
           // the group's next 8 entries of tile a: lane q holds entry pc + q
           int ja_l = (pc == 0 ? en_cur.ja : en_cur.ja2) - a0;
@@ -258,6 +260,7 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
               va_l = data[pa + pc + q];
             }
           }
+          if constexpr (FAST) amax = fmaxf(amax, fabsf(va_l));
           if (diag && qc == 0 && pc + q < na)  // column sums ride along on the diagonal items
             atomicAdd(&csum[ja_l], (unsigned long long)llrint((double)va_l * scale));
           if constexpr (!A_FROM_MEM) {
@@ -266,16 +269,15 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
             // (exact for |x| < 2^51, llrint otherwise)
             int ja8[8];
             float va8[8];
-            const bool uq = (lane & 4) != 0;
             const int vai = __float_as_int(va_l);
-            ja8[0] = bcast8<0>(ja_l, uq); va8[0] = __int_as_float(bcast8<0>(vai, uq));
-            ja8[1] = bcast8<1>(ja_l, uq); va8[1] = __int_as_float(bcast8<1>(vai, uq));
-            ja8[2] = bcast8<2>(ja_l, uq); va8[2] = __int_as_float(bcast8<2>(vai, uq));
-            ja8[3] = bcast8<3>(ja_l, uq); va8[3] = __int_as_float(bcast8<3>(vai, uq));
-            ja8[4] = bcast8<4>(ja_l, uq); va8[4] = __int_as_float(bcast8<4>(vai, uq));
-            ja8[5] = bcast8<5>(ja_l, uq); va8[5] = __int_as_float(bcast8<5>(vai, uq));
-            ja8[6] = bcast8<6>(ja_l, uq); va8[6] = __int_as_float(bcast8<6>(vai, uq));
-            ja8[7] = bcast8<7>(ja_l, uq); va8[7] = __int_as_float(bcast8<7>(vai, uq));
+            ja8[0] = bcast8<0>(ja_l); va8[0] = __int_as_float(bcast8<0>(vai));
+            ja8[1] = bcast8<1>(ja_l); va8[1] = __int_as_float(bcast8<1>(vai));
+            ja8[2] = bcast8<2>(ja_l); va8[2] = __int_as_float(bcast8<2>(vai));
+            ja8[3] = bcast8<3>(ja_l); va8[3] = __int_as_float(bcast8<3>(vai));
+            ja8[4] = bcast8<4>(ja_l); va8[4] = __int_as_float(bcast8<4>(vai));
+            ja8[5] = bcast8<5>(ja_l); va8[5] = __int_as_float(bcast8<5>(vai));
+            ja8[6] = bcast8<6>(ja_l); va8[6] = __int_as_float(bcast8<6>(vai));
+            ja8[7] = bcast8<7>(ja_l); va8[7] = __int_as_float(bcast8<7>(vai));
 #pragma unroll
             for (int pp = 0; pp < 8; ++pp) {
               if (has_b && pc + pp < na)
@@ -310,7 +312,12 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
     for (int i = threadIdx.x; i < GT; i += GRAM_THREADS)
       if (csum[i]) atomicAdd(&colsum[a0 + i], csum[i]);
   if constexpr (FAST) {
-    if (__any(out_of_range) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      amax = fmaxf(amax, __shfl_xor(amax, o));
+      bmax = fmaxf(bmax, __shfl_xor(bmax, o));
+    }
+    if (!((double)amax * ((double)bmax * scale) < 2251799813685248.0) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
   }
 }
 
