@@ -83,19 +83,13 @@ __global__ __launch_bounds__(256) void gram_tileptr_kernel(const int64_t* __rest
 // 6.4 entries per tile, the a-loop runs to the longest of 8 rows).
 // A_FROM_MEM: every lane reads the tile-a entry of its row group straight from memory (one address per 8 lanes, L1
 // hits) instead of receiving it by a broadcast: slower (17.5 ms), kept behind SCAMD_GRAM_A_FROM_MEM for measurements.
-// Broadcast lane PP of every aligned group of 8 lanes to the whole group with DPP (VALU) instead of ds_bpermute: a quad
-// broadcast, then the other quad's copy by a row shift of 4 and a select (same speed as the permute when it was tried).
+// Broadcast lane PP of every aligned group of 8 lanes to the whole group.  Tried: ds_bpermute (two LDS instructions with
+// a lane-address register), DPP (quad broadcast + bank-masked row shift: three VALU with the copy the tied operand
+// needs) and ds_swizzle (one instruction): 7.0 ms with DPP, 6.9 with the swizzle once the kernel was issue-bound.
 template <int PP>
 __device__ __forceinline__ int bcast8(int x) {
-  constexpr int Q = PP & 3;
-  constexpr int QUAD = Q | (Q << 2) | (Q << 4) | (Q << 6);
-  const int y = __builtin_amdgcn_update_dpp(0, x, QUAD, 0xf, 0xf, false);
-  // the other quad's copy: a row shift by 4 written only into the quads that need it (bank mask), the rest keeps y
-  if constexpr (PP < 4) {
-    return __builtin_amdgcn_update_dpp(y, y, 0x114, 0xf, 0xa, false);  // row_shr:4 into quads 1 and 3
-  } else {
-    return __builtin_amdgcn_update_dpp(y, y, 0x104, 0xf, 0x5, false);  // row_shl:4 into quads 0 and 2
-  }
+  // ds_swizzle, bit-mask mode: lane' = (lane & 0b11000) | PP inside each group of 32 -- one LDS-crossbar instruction
+  return __builtin_amdgcn_ds_swizzle(x, 0x18 | (PP << 5));
 }
 
 // round-to-nearest-even of a float64 to int64: the 1.5 * 2^52 trick where it is exact, llrint beyond
