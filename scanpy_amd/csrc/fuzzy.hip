@@ -193,16 +193,27 @@ __global__ void fss_sortrows_kernel(const int64_t* __restrict__ indptr, int64_t 
     }
     return;
   }
-  for (int e = lane; e < len; e += 64) {
-    const int c = tmp_col[base + e];
-    const float v = tmp_val[base + e];
+  // hub rows (the symmetrised kNN graph of the 1M planted matrix has rows of 1.4k entries): 64 elements are ranked at a
+  // time against the row read in coalesced chunks of 64, compared from registers.  Ranking them against the row read
+  // entry by entry from memory (len^2 / 64 dependent loads in ONE wave) WAS this kernel's duration: 1.4 ms, the other
+  // 999,990 rows done long before (11 waves per CU in flight on average, profiles/r02f_fuzzy_pmc1.csv).
+  for (int e0 = 0; e0 < len; e0 += 64) {
+    const int e = e0 + lane;
+    const int c = e < len ? tmp_col[base + e] : 0x7fffffff;
+    const float v = e < len ? tmp_val[base + e] : 0.f;
     int rank = 0;
-    for (int u = 0; u < len; ++u) {
-      int cu = tmp_col[base + u];
-      rank += (cu < c || (cu == c && u < e)) ? 1 : 0;
+    for (int u0 = 0; u0 < len; u0 += 64) {
+      const int cu_l = u0 + lane < len ? tmp_col[base + u0 + lane] : 0x7fffffff;
+      const int cnt = min(64, len - u0);
+      for (int t = 0; t < cnt; ++t) {
+        const int cu = __builtin_amdgcn_readlane(cu_l, t);
+        rank += (cu < c || (cu == c && u0 + t < e)) ? 1 : 0;
+      }
     }
-    out_col[base + rank] = c;
-    out_val[base + rank] = v;
+    if (e < len) {
+      out_col[base + rank] = c;
+      out_val[base + rank] = v;
+    }
   }
 }
 

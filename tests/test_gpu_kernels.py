@@ -203,6 +203,28 @@ def test_fuzzy_synthetic(K, n, k):
     _fuzzy_vs_oracle(K, idx.cpu().numpy(), dist.cpu().numpy(), k)
 
 
+def test_fuzzy_hub_rows(K):
+    """Rows of the symmetric graph far longer than a wave (three hubs that are neighbours of most points: hand-made kNN
+    lists, the kernel does not look at geometry): the per-row sort ranks them in register chunks of 64; pattern and
+    weights against the oracle."""
+    rng = np.random.default_rng(11)
+    n, k = 3000, 10
+    idx = np.empty((n, k), dtype=np.int32)
+    for i in range(n):
+        others = rng.choice(n - 4, size=k - 2, replace=False) + 3  # never a hub, maybe i itself
+        others = others[others != i][: k - 2]
+        while others.size < k - 2:
+            c = int(rng.integers(3, n))
+            if c != i and c not in others:
+                others = np.append(others, c)
+        hub = int(rng.integers(0, 3))
+        idx[i] = [i, hub if hub != i else (hub + 1) % 3, *others]
+    dist = np.sort(rng.random((n, k)).astype(np.float32) + 0.1, axis=1)
+    dist[:, 0] = 0.0
+    got = _fuzzy_vs_oracle(K, idx, dist.astype(np.float64), k)
+    assert np.diff(got.indptr).max() > 500, np.diff(got.indptr).max()
+
+
 # ---------------------------------------------------------------------------------------------------
 def _rand_csr(n, g, density, seed):
     rng = np.random.default_rng(seed)
