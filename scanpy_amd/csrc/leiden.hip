@@ -669,10 +669,22 @@ __global__ __launch_bounds__(256) void ld_within_kernel(int n, const int64_t* __
   const int a = comm[v];
   const int64_t beg = indptr[v], end = indptr[v + 1];
   long long s = 0;
-  for (int64_t e = beg + sub; e < end; e += G) {
-    const int u = indices[e];
-    const long long we = wq[e];  // requested with the index, not after the community test
-    if (u != v && comm[u] == a) s += we;
+  // four entries per lane in flight: a hub row (1.4k entries on the 1M kNN graph) walked one dependent gather pair at
+  // a time by 16 lanes is ~90 serial round trips -- the tail of the whole launch
+  for (int64_t e = beg + sub; e < end; e += 4 * G) {
+    int u[4], cu[4];
+    long long we[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int64_t ee = e + t * G;
+      u[t] = ee < end ? indices[ee] : v;
+      we[t] = ee < end ? wq[ee] : 0ll;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) cu[t] = comm[u[t]];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (u[t] != v && cu[t] == a) s += we[t];
   }
 #pragma unroll
   for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -722,11 +734,24 @@ __global__ __launch_bounds__(256) void ld_refine_cut_update_kernel(
   const int64_t beg = indptr[v], end = indptr[v + 1];
   const long long av = a_in[v];
   long long s = 0;
-  for (int64_t e = beg + sub; e < end; e += G) {
-    const int u = indices[e];
-    const long long we = wq[e];
-    const int cu = comm[u], ru = ref[u], su = stamp[u];
-    if (u != v && cu == a && ru == t) s += (su == round) ? we : 2 * we;
+  for (int64_t e = beg + sub; e < end; e += 2 * G) {  // two entries per lane in flight (hub rows: see ld_within_kernel)
+    int u[2], cu[2], ru[2], su[2];
+    long long we[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t ee = e + j * G;
+      u[j] = ee < end ? indices[ee] : v;
+      we[j] = ee < end ? wq[ee] : 0ll;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      cu[j] = comm[u[j]];
+      ru[j] = ref[u[j]];
+      su[j] = stamp[u[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (u[j] != v && cu[j] == a && ru[j] == t) s += (su[j] == round) ? we[j] : 2 * we[j];
   }
 #pragma unroll
   for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -1347,9 +1372,20 @@ __global__ __launch_bounds__(256) void ld_internal_kernel(int n, const int64_t* 
   for (int v = blockIdx.x * (256 / G) + threadIdx.x / G; v < n; v += gridDim.x * (256 / G)) {
     const int a = comm[v];
     const int64_t beg = indptr[v], end = indptr[v + 1];
-    for (int64_t e = beg + sub; e < end; e += G) {
-      const long long we = wq[e];
-      if (comm[indices[e]] == a) s += we;
+    for (int64_t e = beg + sub; e < end; e += 4 * G) {  // (four entries per lane in flight: see ld_within_kernel)
+      int u[4], cu[4];
+      long long we[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int64_t ee = e + t * G;
+        u[t] = ee < end ? indices[ee] : v;
+        we[t] = ee < end ? wq[ee] : 0ll;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) cu[t] = comm[u[t]];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (cu[t] == a) s += we[t];
     }
   }
 #pragma unroll
