@@ -5,7 +5,7 @@
 // PCAEighDask.fit at _pca/_dask.py:28-132) and, through it, every CSR pass of the PCA solve: once G (g x g) and
 // the column sums are on the device, the eigen-solve is dense GEMM work on a 32 MB matrix.
 //
-// Design (LDS-atomic bound, deterministic):
+// Design (deterministic; what bounds it: see the notes in front of bcast8 below):
 //   * genes are cut into tiles of T = 128; a work item = (tile pair a <= b, row chunk); its T x T block of G lives
 //     in LDS as int64 (128 KB) and is accumulated with ds_add_u64 -- integer addition is associative, so the
 //     result does not depend on the order in which waves/lanes/blocks (or ranks) add: bitwise reproducible;
