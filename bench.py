@@ -258,6 +258,13 @@ def host_to_host(x, n_comps: int, k: int, reps: int) -> dict:
                     "the results and the scipy / pandas slot construction; warm process"}
 
 
+def _sha(t) -> str:
+    """sha1 (first 16 hex digits) of a device tensor's bytes: lets two runs / boxes be compared bit for bit"""
+    import hashlib
+
+    return hashlib.sha1(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16]
+
+
 def noise_variant(args, backend, kw) -> dict:
     """`structure_none`: the path on the pure-noise matrix of the same shape (rank 0, N=1): no cell can be pruned."""
     import torch
@@ -285,7 +292,9 @@ def noise_variant(args, backend, kw) -> dict:
             "pairs_evaluated_fraction": pairs / brute, "prepass_pairs_fraction_of_useful": pre / pairs if pairs else None,
             "knn_select_ms": sel, "knn_select_tflops": tf,
             "knn_select_frac_of_157.3": tf / 157.3 if tf else None, "n_communities": res.n_communities,
-            "modularity": res.modularity, "pca_info": {k: v for k, v in res.info.items() if k != "knn_fallback_queries"}}
+            "modularity": res.modularity, "labels_sha": _sha(res.labels),
+            "graph_sha": {"indptr": _sha(res.conn_indptr), "indices": _sha(res.conn_indices), "data": _sha(res.conn_data)},
+            "pca_info": {k: v for k, v in res.info.items() if k != "knn_fallback_queries"}}
 
 
 def _profiled_traffic(mode: str):
@@ -519,7 +528,8 @@ def main() -> None:
                 "brute_force_equivalent_tflops": 2.0 * brute_pairs * args.n_comps / (sel * 1e-3) / 1e12 if sel > 0 else None,
             },
             "stage_ms_per_step": {kname: v / max(args.steps, 1) for kname, v in stage_acc.items()},
-            "result": {"n_communities": res.n_communities, "modularity": res.modularity, **res.info},
+            "result": {"n_communities": res.n_communities, "modularity": res.modularity, "labels_sha": _sha(res.labels),
+                       **res.info},
             "setup_s": {"generate": t_gen, "h2d": t_h2d},
         }
         out["config"]["structure"] = args.structure

@@ -54,6 +54,7 @@ class AnnData:
         """anndata's `AnnData._inplace_subset_var` (used by `highly_variable_genes(subset=True)`)."""
         sub = self[:, np.asarray(index)]
         self.X, self.var, self.varm, self.layers = sub.X, sub.var.copy(), sub.varm, sub.layers
+        self.varp = sub.varp
 
     def _inplace_subset_obs(self, index) -> None:
         """anndata's `AnnData._inplace_subset_obs` (used by `filter_cells`)."""

@@ -916,7 +916,8 @@ extern "C" int scamd_pca_csr_f32(const int64_t* indptr, const int32_t* indices, 
   int scale_bits = std::min((int)std::floor(62.0 - std::log2(bound)), 60);
   SCAMD_REQUIRE(!(am > 0.0) || scale_bits + 2.0 * std::log2(am) >= 24.0, SCAMD_EUNSUPPORTED,
                 "pca: fixed-point resolution below float32 for this n and dynamic range (max|x| = %g)", am);
-  scale_bits = std::max(scale_bits, 0);
+  SCAMD_REQUIRE(scale_bits >= 0, SCAMD_EUNSUPPORTED,
+                "pca: n * max|x|^2 = %g exceeds the int64 fixed-point range (2^62): values are not normalised", bound);
   // 2. G = X^T X, column sums (int64, exact)
   rc = scamd_csr_gram_f32(indptr, indices, data, n, g, nnz, scale_bits, reinterpret_cast<int64_t*>(b.gram), gp,
                           reinterpret_cast<int64_t*>(b.colsum), nullptr, b.gram_ws, b.gram_ws_bytes, s);

@@ -616,7 +616,9 @@ __global__ __launch_bounds__(256) void ld_apply_kernel(int n_act, const int* __r
       m &= m - 1;
     }
     const int src = lane < 32 ? b0 : b1;
-    const int64_t rb = __shfl(beg, src), re = (lane >= 32 && b1 == b0) ? rb : __shfl(end, src);
+    // (both shuffles run with every lane active: a bpermute under a partial exec mask reads 0 from disabled lanes)
+    const int64_t rb = __shfl(beg, src), re_s = __shfl(end, src);
+    const int64_t re = (lane >= 32 && b1 == b0) ? rb : re_s;
     for (int64_t e = rb + (lane & 31); e < re; e += 32) flag[indices[e]] = 1;
   }
   __syncthreads();

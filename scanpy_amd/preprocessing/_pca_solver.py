@@ -476,7 +476,8 @@ def _pca_fit_gram(a, n_comps: int, backend, comm, zero_center: bool, seed: int, 
     # resolution of one product relative to the largest one: 2^-(S + log2 absmax^2).  Below the 24 bits of the float32
     # inputs (very large n * dynamic range, or |x| so small that S hits its cap) the fixed-point Gram matrix would be
     # a PCA of rounding noise: the float64 Krylov route handles such data
-    if absmax > 0.0 and scale_bits + 2.0 * np.log2(absmax) < 24.0:
+    # (a negative S means even 2^0 overflows the int64 sums -- n * absmax^2 > 2^62 -- and is outside the C entry's range)
+    if scale_bits < 0 or (absmax > 0.0 and scale_bits + 2.0 * np.log2(absmax) < 24.0):
         return None
     gq = cq = None
     for h in chunks.handles(backend):

@@ -535,9 +535,9 @@ def write_zarr(store, adata, *, chunks=None, level: int = 0) -> None:
     tmp = path.with_name(f".{path.name}.tmp{os.getpid()}")
     if tmp.exists():
         shutil.rmtree(tmp)
+    old = None
     try:
         _write_anndata(_ZarrSink(z3.open_store(tmp, "w"), level), adata, chunks)
-        old = None
         if path.exists():
             old = path.with_name(f".{path.name}.old{os.getpid()}")
             os.replace(path, old)
@@ -545,6 +545,9 @@ def write_zarr(store, adata, *, chunks=None, level: int = 0) -> None:
         if old is not None:
             shutil.rmtree(old, ignore_errors=True) if old.is_dir() else old.unlink()
     except BaseException:
+        # interrupted between the two renames: put the original store back before giving up
+        if old is not None and old.exists() and not path.exists():
+            os.replace(old, path)
         shutil.rmtree(tmp, ignore_errors=True)
         raise
 
