@@ -203,6 +203,18 @@ def parity_block(x_full, truth, chain: dict, n_comps: int, k: int) -> dict:
     # informational, the reference's own bar for recomputed distances is rtol 1e-5, tests/test_neighbors.py:275-296)
     cerr_g, same_g = cmp.conn_max_abs(b.obsp["connectivities"], chain["conn"])
     out["conn_max_abs_from_gpu_distances"] = cerr_g
+    # end-to-end gate in the reference's own form (rtol 1e-5, tests/test_neighbors.py:275-296: connectivities recomputed
+    # from GIVEN distances): asserted on every entry whose two end points have float32 neighbour lists bit-identical to
+    # the CPU chain's; the rows where a float32 distance differs in its last bit are counted (gate: <= 1e-4 of the rows)
+    # and their worst entry is `conn_max_abs_from_gpu_distances` above (informational: umap's bisection stops at
+    # |sum - log2 k| < 1e-5, so a one-ulp input change legitimately moves a sigma by ~1e-5)
+    og, oc_ = np.argsort(gi, axis=1), np.argsort(chain["idx"], axis=1)
+    gi_s, ci_s = np.take_along_axis(gi, og, 1), np.take_along_axis(chain["idx"], oc_, 1)
+    gd_s = np.take_along_axis(gd, og, 1).astype(np.float32)
+    cd_s = np.take_along_axis(chain["dist"], oc_, 1).astype(np.float32)
+    row_ok = (gi_s == ci_s).all(axis=1) & (gd_s == cd_s).all(axis=1)
+    out["conn_e2e_rows_distance_ulp_fraction"] = float(1.0 - row_ok.mean())
+    out["conn_e2e_max_rel"], out["conn_e2e_entries_compared"] = cmp.conn_max_rel(b.obsp["connectivities"], chain["conn"], row_ok)
     # stage-wise: the fuzzy set from the CPU chain's OWN distances (`pp.neighbors(distances=...)`)
     from oracle import knn as oknn
 
@@ -210,6 +222,7 @@ def parity_block(x_full, truth, chain: dict, n_comps: int, k: int) -> dict:
     sc.pp.neighbors(f, n_neighbors=k, distances=oknn.sparse_from_indices_distances(chain["idx"], chain["dist"], keep_self=False))
     cerr, same = cmp.conn_max_abs(f.obsp["connectivities"], chain["conn"])
     out["conn_max_abs"] = cerr
+    out["conn_max_rel"], _ = cmp.conn_max_rel(f.obsp["connectivities"], chain["conn"])
     out["conn_same_pattern"] = bool(same and same_g)
     # stage-wise: Leiden on the CPU chain's graph; the oracle's own seed-to-seed agreement is the noise floor
     c = sc.AnnData(x[:, :1])
@@ -225,10 +238,62 @@ def parity_block(x_full, truth, chain: dict, n_comps: int, k: int) -> dict:
         fails.append("knn_rows_differing_beyond_ties")
     if out["conn_max_abs"] > cmp.GATES["conn_max_abs"] or not same:
         fails.append("conn_max_abs")
+    if out["conn_max_rel"] > cmp.GATES["conn_max_rel"]:
+        fails.append("conn_max_rel")
+    if out["conn_e2e_max_rel"] > cmp.GATES["conn_e2e_max_rel"] or not same_g:
+        fails.append("conn_e2e_max_rel")
+    if out["conn_e2e_rows_distance_ulp_fraction"] > cmp.GATES["conn_e2e_rows_distance_ulp_fraction"]:
+        fails.append("conn_e2e_rows_distance_ulp_fraction")
+    out["relaxed_gates"] = {
+        "conn_max_abs_from_gpu_distances": "not gated on the rows whose float32 distances differ from the CPU chain's in the "
+        "last bit (counted by conn_e2e_rows_distance_ulp_fraction, gated at 1e-4 of the rows); every other entry is gated "
+        "end to end at rtol 1e-5 (conn_e2e_max_rel)"}
     floor = min(cmp.GATES["leiden_ari_vs_cpu_chain"], out["cpu_chain_seed0_vs_seed1_ari"])
     if min(out["leiden_ari_vs_cpu_chain"], out["leiden_ari_stagewise"]) < floor:
         fails.append("leiden_ari_vs_cpu_chain")
     out["leiden_ari_bar"] = floor
+    out["failed_gates"] = fails
+    return out
+
+
+def parity_weak(args, n_s: int = 100_000, n_seeds: int = 5) -> dict:
+    """`parity.weak`: Leiden where the answer is NOT unambiguous -- a `weak` sample (overlapping gene programmes, the
+    CPU oracle's own seeds agree only partly).  The oracle's seeds 0 .. n_seeds-1 on the CPU chain's graph define the
+    distribution; gates: the GPU modularity (same graph, seed 0) is not below the oracle's worst seed, and the GPU
+    partition agrees with the oracle's seed-0 partition at least as well as the oracle's other seeds do (- 0.01)."""
+    import numpy as np
+
+    import scanpy_amd as sc
+    from oracle import compare as cmp
+    from oracle import leiden as ol
+
+    x, truth = make_matrix(n_s, args.n_vars, args.seed, "weak")
+    chain = cpu_chain(x, args.n_comps, args.n_neighbors)
+    seeds = [(chain["labels"], chain["modularity"])] + [ol.leiden(chain["conn"], resolution=1.0, n_iterations=-1, seed=s)
+                                                        for s in range(1, n_seeds)]
+    q_or = np.array([q for _, q in seeds])
+    floor = min(cmp.ari(seeds[0][0], m) for m, _ in seeds[1:])
+    c = sc.AnnData(x[:, :1])
+    sc.tl.leiden(c, adjacency=chain["conn"], flavor="igraph", n_iterations=-1)
+    g_lab = c.obs["leiden"].cat.codes.to_numpy()
+    q_gpu = float(c.uns["leiden"]["modularity"])
+    a = sc.AnnData(x)
+    sc.pp.pca(a, n_comps=args.n_comps)
+    sc.pp.neighbors(a, n_neighbors=args.n_neighbors)
+    sc.tl.leiden(a, flavor="igraph", n_iterations=-1)
+    e_lab = a.obs["leiden"].cat.codes.to_numpy()
+    out = {"sample_cells": n_s, "structure": "weak", "oracle_seeds": n_seeds,
+           "oracle_modularity_range": [float(q_or.min()), float(q_or.max())], "gpu_modularity_same_graph": q_gpu,
+           "oracle_seed_floor_ari": floor, "gpu_vs_oracle_seed0_ari": cmp.ari(g_lab, seeds[0][0]),
+           "gpu_end_to_end_vs_oracle_seed0_ari": cmp.ari(e_lab, seeds[0][0]),
+           "n_clusters": {"gpu": int(g_lab.max()) + 1, "oracle": [int(m.max()) + 1 for m, _ in seeds]},
+           "ari_vs_truth": {"gpu": cmp.ari(g_lab, truth), "oracle_seed0": cmp.ari(seeds[0][0], truth)},
+           "gates": {"modularity": "gpu >= oracle minimum - 1e-4", "ari": "gpu_vs_oracle_seed0_ari >= oracle_seed_floor_ari - 0.01"}}
+    fails = []
+    if q_gpu < q_or.min() - 1e-4:
+        fails.append("weak_modularity_below_oracle_range")
+    if out["gpu_vs_oracle_seed0_ari"] < floor - 0.01:
+        fails.append("weak_ari_below_oracle_seed_floor")
     out["failed_gates"] = fails
     return out
 
@@ -555,6 +620,9 @@ def main() -> None:
                         # -> only the kNN and connectivity gates are meaningful
                         par["failed_gates"] = [f for f in par["failed_gates"] if f in ("knn_rows_differing_beyond_ties", "conn_max_abs")]
                         par["note"] = "structure none: loadings / label gates not asserted"
+                    if args.structure == "planted":
+                        par["weak"] = parity_weak(args)
+                        par["failed_gates"] = par["failed_gates"] + par["weak"]["failed_gates"]
                     out["parity"] = par
                     rc = 1 if par["failed_gates"] else 0
         print(json.dumps(out), flush=True)

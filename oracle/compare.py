@@ -9,7 +9,8 @@ from __future__ import annotations
 
 import numpy as np
 
-GATES = {"pca_loading_err": 1e-4, "knn_rows_differing_beyond_ties": 0, "conn_max_abs": 1e-5, "leiden_ari_vs_cpu_chain": 0.99}
+GATES = {"pca_loading_err": 1e-4, "knn_rows_differing_beyond_ties": 0, "conn_max_abs": 1e-5, "conn_max_rel": 1e-5,
+         "conn_e2e_max_rel": 1e-5, "conn_e2e_rows_distance_ulp_fraction": 1e-4, "leiden_ari_vs_cpu_chain": 0.99}
 
 
 def pca_loading_err(components_a, components_b) -> float:
@@ -56,3 +57,23 @@ def ari(labels_a, labels_b) -> float:
     from sklearn.metrics import adjusted_rand_score
 
     return float(adjusted_rand_score(np.asarray(labels_a), np.asarray(labels_b)))
+
+
+def conn_max_rel(conn_a, conn_b, row_ok=None):
+    """-> (max |a - b| / |b| over the stored entries, number of entries compared); both matrices must have the same
+    sparsity pattern.  `row_ok` (bool per row): only entries (i, j) with row_ok[i] and row_ok[j] are compared -- the value
+    of an entry of the fuzzy union depends on the neighbour lists of both of its end points.  This is the form of the
+    reference's own check of connectivities recomputed from given distances (tests/test_neighbors.py:275-296, rtol 1e-5)."""
+    a, b = conn_a.tocsr(), conn_b.tocsr()
+    a.sort_indices()
+    b.sort_indices()
+    if not (a.nnz == b.nnz and np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)):
+        return float("inf"), 0
+    da, db = a.data.astype(np.float64), b.data.astype(np.float64)
+    keep = np.ones(a.nnz, dtype=bool)
+    if row_ok is not None:
+        rows = np.repeat(np.arange(a.shape[0]), np.diff(a.indptr))
+        keep = row_ok[rows] & row_ok[a.indices]
+    if not keep.any():
+        return 0.0, 0
+    return float((np.abs(da - db)[keep] / np.abs(db[keep])).max()), int(keep.sum())

@@ -128,6 +128,25 @@ def _recv(shape, dtype, dev, src: int, group) -> torch.Tensor:
     return buf.to(dev) if staged else buf
 
 
+def fixed_point_distance_sum(dist32: torch.Tensor, n_elements_total: int, comm) -> torch.Tensor:
+    """Sum of ALL ranks' distances as a float64 [1] device tensor, bit-identical to the single-device kernels
+    (csrc/fuzzy.hip: fss_max_kernel / fss_sum_kernel / fss_sum_final_kernel) for any sharding: the distances are added as
+    int64 fixed point scaled by 2^S, S = 61 - e - ceil(log2(count)) with max < 2^e -- integer sums do not depend on the
+    order, a float64 sum (torch.sum + all-reduce in rank order) does."""
+    import math
+
+    dev = dist32.device
+    mx = dist32.max().reshape(1).to(torch.float64) if dist32.numel() else torch.zeros(1, dtype=torch.float64, device=dev)
+    comm.allreduce_max_(mx)
+    m = float(mx.item())
+    e = math.frexp(m if m > 0.0 else 1.0)[1]
+    lg = max(0, (int(n_elements_total) - 1).bit_length())
+    s_bits = 61 - e - lg
+    isum = torch.round(dist32.to(torch.float64) * (2.0 ** s_bits)).to(torch.int64).sum().reshape(1)
+    comm.allreduce_(isum)
+    return isum.to(torch.float64) * (2.0 ** -s_bits)
+
+
 def sharded_fuzzy_rows(idx: torch.Tensor, dist32: torch.Tensor, comm, counts: list[int], row_begin: int, n_total: int):
     """This rank's rows of the symmetric fuzzy graph: local membership strengths, all-to-all of the
     directed edges to the owners of their targets, local merge.  -> (indptr [n_local + 1], indices (global), data)"""
@@ -136,8 +155,7 @@ def sharded_fuzzy_rows(idx: torch.Tensor, dist32: torch.Tensor, comm, counts: li
     group = getattr(comm, "group", None)
     dev = idx.device
     n_local, k = idx.shape
-    total = dist32.to(torch.float64).sum().reshape(1)
-    comm.allreduce_(total)  # the only global quantity of smooth_knn_dist: the mean of ALL distances
+    total = fixed_point_distance_sum(dist32, n_total * k, comm)  # the only global quantity of smooth_knn_dist
     w = _kernels.fuzzy_weights(idx, dist32, row_begin, n_total, total)
     mask = w > 0
     rows = torch.arange(row_begin, row_begin + n_local, device=dev, dtype=torch.int32)[:, None].expand(-1, k)

@@ -14,14 +14,43 @@
 
 namespace scamd {
 
-__global__ void fss_sum_kernel(const float* __restrict__ d, int64_t total, double* __restrict__ sum) {
-  double s = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x)
-    s += (double)d[i];
+// Sum of all distances (the only global quantity of smooth_knn_dist: the floor of sigma on rows without a positive
+// distance is 1e-3 * the mean of ALL distances), ORDER INDEPENDENT: the distances are added as 64-bit fixed-point
+// integers scaled by 2^S, S chosen from the largest distance and the element count so that the sum cannot overflow.
+// Integer addition is associative, so the value does not depend on the grid, on the atomics' order or on how the rows
+// are sharded over ranks (the row-sharded path computes the same integers with torch and all-reduces them:
+// scanpy_amd/_pipeline.py:fixed_point_distance_sum) -- a float64 atomic sum made the sharded rows differ from the
+// single-device rows in the last bit whenever the floor was hit.
+__global__ void fss_max_kernel(const float* __restrict__ d, int64_t total, unsigned int* __restrict__ mx_bits) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, d[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  // (distances are >= 0: the bit patterns of non-negative floats order like the values)
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(mx_bits, __float_as_uint(m));
+}
+// S = 61 - e - ceil(log2(total)) with max < 2^e: every term is < 2^(61 - ceil(log2 total)), the sum < 2^61
+__device__ __forceinline__ int fss_sum_scale_bits(float mx, int64_t total) {
+  int e = 0;
+  (void)frexpf(mx > 0.f ? mx : 1.f, &e);
+  int lg = 0;
+  while (((int64_t)1 << lg) < total) ++lg;
+  return 61 - e - lg;
+}
+__global__ void fss_sum_kernel(const float* __restrict__ d, int64_t total, const unsigned int* __restrict__ mx_bits,
+                               unsigned long long* __restrict__ isum) {
+  const double scale = ldexp(1.0, fss_sum_scale_bits(__uint_as_float(*mx_bits), total));
+  long long s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    s += llrint((double)d[i] * scale);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if ((threadIdx.x & 63) == 0) atomicAdd(sum, s);
+  if ((threadIdx.x & 63) == 0 && s != 0) atomicAdd(isum, (unsigned long long)s);
+}
+__global__ void fss_sum_final_kernel(const unsigned long long* __restrict__ isum, const unsigned int* __restrict__ mx_bits,
+                                     int64_t total, double* __restrict__ sum) {
+  sum[0] = ldexp((double)(long long)isum[0], -fss_sum_scale_bits(__uint_as_float(*mx_bits), total));
 }
 
 // one thread per row
@@ -311,7 +340,7 @@ static void fuzzy_carve(Workspace& ws, int64_t n, int k, FuzzyBuffers* b) {
   b->scan_tmp = ws.take<int64_t>((size_t)scan_num_blocks(n) + 2);
   b->tmp_col = ws.take<int>(cap);
   b->tmp_val = ws.take<float>(cap);
-  b->sum = ws.take<double>(2);
+  b->sum = ws.take<double>(4);
 }
 
 // directed weights w (> 0 = present) on the kNN pattern -> symmetric CSR with sorted rows; mode = combine rule of
@@ -371,12 +400,18 @@ extern "C" int scamd_fuzzy_simplicial_set_f32(const int32_t* knn_idx, const floa
                 ws.used());
   hipStream_t s = stream;
   const int64_t total = n * k;
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.sum, 0, 16, s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.sum, 0, 32, s));  // [0] sum (double), [1] fixed-point sum, [2] bits of the max
   SCAMD_HIP_CHECK(hipMemsetAsync(b.in_only, 0, sizeof(int) * n, s));
   SCAMD_HIP_CHECK(hipMemsetAsync(b.cursor, 0, sizeof(int) * n, s));
   {
     int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
-    hipLaunchKernelGGL(fss_sum_kernel, dim3(blocks), dim3(256), 0, s, knn_dist, total, b.sum);
+    unsigned long long* isum = reinterpret_cast<unsigned long long*>(b.sum + 1);
+    unsigned int* mx_bits = reinterpret_cast<unsigned int*>(b.sum + 2);
+    hipLaunchKernelGGL(fss_max_kernel, dim3(blocks), dim3(256), 0, s, knn_dist, total, mx_bits);
+    SCAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fss_sum_kernel, dim3(blocks), dim3(256), 0, s, knn_dist, total, mx_bits, isum);
+    SCAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fss_sum_final_kernel, dim3(1), dim3(1), 0, s, isum, mx_bits, total, b.sum);
     SCAMD_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(fss_sigma_kernel, dim3(ceil_div(n, 128)), dim3(128), 0, s, knn_idx, knn_dist, n, k, b.sum,
@@ -474,9 +509,15 @@ extern "C" int scamd_fuzzy_merge_rows_f32(const int32_t* knn_idx, const float* w
                                           int64_t* out_indptr, int32_t* out_indices, float* out_data, int64_t cap,
                                           int64_t* nnz_host, void* workspace, size_t workspace_bytes,
                                           scamd_stream_t stream) {
+  SCAMD_REQUIRE(n_local >= 0 && k >= 2 && k <= 1024 && cap >= 0, SCAMD_EINVAL, "fuzzy_merge: bad shape");
+  if (n_local == 0) {  // a rank that owns no rows (n_total < world size): an empty CSR (empty tensors may be null)
+    SCAMD_REQUIRE(out_indptr && nnz_host, SCAMD_EINVAL, "fuzzy_merge: null pointer");
+    SCAMD_HIP_CHECK(hipMemsetAsync(out_indptr, 0, sizeof(int64_t), stream));
+    *nnz_host = 0;
+    return SCAMD_OK;
+  }
   SCAMD_REQUIRE(knn_idx && w && in_indptr && out_indptr && out_indices && out_data && nnz_host, SCAMD_EINVAL,
                 "fuzzy_merge: null pointer");
-  SCAMD_REQUIRE(n_local >= 1 && k >= 2 && k <= 1024 && cap >= 0, SCAMD_EINVAL, "fuzzy_merge: bad shape");
   Workspace ws(workspace, workspace_bytes);
   int* rowcnt = ws.take<int>((size_t)n_local + 1);
   int64_t* scan_tmp = ws.take<int64_t>((size_t)scan_num_blocks(n_local) + 2);

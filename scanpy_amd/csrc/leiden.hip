@@ -4,17 +4,18 @@
 // (objective 'modularity') as called at src/scanpy/tools/_leiden.py:167-196 on the graph built by
 // src/scanpy/_utils/__init__.py:278-304.  Same three phases as Traag et al. 2019,
 // re-designed for a GPU:
-//   1. local moving   -- synchronous rounds; one wave per vertex accumulates the weight towards each
-//                        neighbouring community (all-pairs readlane compare, no hash table) and picks
-//                        the best move from a snapshot of the community totals; moves towards
-//                        lower/higher-priority communities alternate by round so that swaps cannot
-//                        oscillate; only vertices next to a change stay active (the queue of the
-//                        sequential algorithm).
-//   2. refinement     -- inside each community singletons merge into well-connected sub-communities
-//                        with the largest non-negative gain (beta -> 0 limit of the randomised rule);
-//                        a per-round mover/non-mover hash bit makes simultaneous merges chain-free.
-//   3. aggregation    -- coarse edges are combined in an open-addressing hash table with 64-bit
-//                        integer atomics, then rank-sorted per row.
+//   1. local moving   -- SWEEPS of K class sub-rounds (K = 8 on large levels): the active vertices of a sweep are split
+//                        into K hash classes; sub-round r decides (one wave / half / quarter wave per vertex: weight
+//                        towards each neighbouring community in an LDS hash, best move from a snapshot of the community
+//                        totals) and applies the moves of class r only, so class r + 1 sees them -- a deterministic
+//                        stand-in for the sequential queue: every sub-round is a synchronous step on a snapshot, the
+//                        classes are re-drawn every sweep, only vertices next to a change stay active.
+//   2. refinement     -- ONE sweep of K class sub-rounds over the well-connected singletons of each community
+//                        (leidenalg visits every vertex exactly once, in random order): the singletons of class r merge
+//                        into a well-connected sub-community drawn with probability ~ exp(gain / beta); targets are
+//                        grown sub-communities and singletons of OTHER classes, so simultaneous merges cannot chain.
+//   3. aggregation    -- members of every coarse node gathered contiguously, one wave / workgroup per coarse node
+//                        combines their rows in an LDS hash.
 // ALL weight sums are 64-bit fixed point (weight * 2^32): integer addition is associative, so atomic
 // accumulation order cannot change any result -- labels are bitwise reproducible run to run.
 // Memory-latency / gather bound: per round ~E*(4+8+4) B of edge data + n*24 B of vertex data.
@@ -29,15 +30,15 @@
 namespace scamd {
 
 constexpr double WSCALE = 4294967296.0;  // 2^32
-constexpr int MAX_LM_ROUNDS = 128;
-constexpr int MAX_RF_ROUNDS = 48;
-constexpr int RF_QUIET_ROUNDS = 3;
-constexpr int RF_BATCH = 4;      // refinement rounds per host round trip (default; SCAMD_LEIDEN_RF_BATCH overrides)
-constexpr int RF_BATCH_MAX = 16;
+constexpr int MAX_LM_SWEEPS = 96;
+constexpr int LM_DIR_AFTER = 32;  // sweeps after which the direction rule (termination guarantee) is switched on
+constexpr int MAX_CLASSES = 32;   // most class sub-rounds per sweep (local moving) / per refinement
+constexpr int DEF_CLASSES = 8;    // default
+constexpr int CTR_STRIDE = 16;    // ints per counter block
 constexpr int MAX_LEVELS = 64;
 constexpr int MAX_OUTER_ITERS = 32;
 
-__device__ __forceinline__ unsigned int hash32(unsigned int x) {
+__host__ __device__ __forceinline__ unsigned int hash32(unsigned int x) {
   x ^= x >> 16;
   x *= 0x7feb352dU;
   x ^= x >> 15;
@@ -475,10 +476,10 @@ __global__ __launch_bounds__(256) void ld_move_kernel(
       wants = true;
       target = best.c;
       const unsigned int pa = prio(a, seed), pb = best.pr;
-      allowed = (round & 1) ? (pb > pa || (pb == pa && target > a)) : (pb < pa || (pb == pa && target < a));
-      // (Measured dead end, round 2: applying this rule only to singleton <-> singleton moves -- the Grappolo / Vite
-      // heuristic -- oscillates on kNN graphs: 282 instead of 49 rounds and 87 instead of 41 ms on the planted 1M graph,
-      // modularity 0.66 instead of 0.71 on the weak one.)
+      // direction rule (round >= 0 only: the termination guarantee of the late sweeps, see local_moving): moves towards
+      // lower / higher priority communities alternate, so that two communities cannot keep swapping members
+      if (round >= 0)
+        allowed = (round & 1) ? (pb > pa || (pb == pa && target > a)) : (pb < pa || (pb == pa && target < a));
     } else if (stay < 0.0 && Ka_wo > 0.0 && csize[v] == 0) {
       // leaving for an empty community (id = own vertex id, free at the snapshot) beats staying
       wants = true;
@@ -493,7 +494,8 @@ __global__ __launch_bounds__(256) void ld_move_hub_kernel(
     const int* __restrict__ hub_list, int* __restrict__ counters, const int* __restrict__ list,
     const int64_t* __restrict__ indptr, const int* __restrict__ indices, const long long* __restrict__ wq,
     const long long* __restrict__ k, const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot,
-    const int* __restrict__ csize, double g, int round, unsigned int seed, int* __restrict__ decision) {
+    const int* __restrict__ csize, double g, int round, unsigned int seed, int* __restrict__ decision,
+    int* __restrict__ err) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long hub_smem[];
   BlockHash bh{reinterpret_cast<int*>(hub_smem + BHUB_SLOTS), hub_smem, BHUB_SLOTS};
   __shared__ Cand sh_c[4];
@@ -522,7 +524,7 @@ __global__ __launch_bounds__(256) void ld_move_hub_kernel(
         if (u == v) continue;
         const int c = comm[u];
         if (n_pass == 1) bh.add(c, wq[beg + e]);
-        else if (bhub_class(c, n_pass) == pass && !bh.add_bounded(c, wq[beg + e])) counters[7] = 1;
+        else if (bhub_class(c, n_pass) == pass && !bh.add_bounded(c, wq[beg + e])) *err = 1;
       }
       __syncthreads();
       for (int sl = threadIdx.x; sl < bh.nslots; sl += blockDim.x) {
@@ -551,7 +553,8 @@ __global__ __launch_bounds__(256) void ld_move_hub_kernel(
         wants = true;
         target = best.c;
         const unsigned int pa = prio(a, seed), pb = best.pr;
-        allowed = (round & 1) ? (pb > pa || (pb == pa && target > a)) : (pb < pa || (pb == pa && target < a));
+        if (round >= 0)
+          allowed = (round & 1) ? (pb > pa || (pb == pa && target > a)) : (pb < pa || (pb == pa && target < a));
       } else if (stay < 0.0 && Ka_wo > 0.0 && csize[v] == 0) {
         wants = true;
         target = v;
@@ -628,34 +631,49 @@ __global__ __launch_bounds__(256) void ld_apply_kernel(int n_act, const int* __r
   }
 }
 
-// flags -> compact list (order irrelevant: every decision of a round reads the same snapshot); clears the flags.
-// counters[2] = list length.  One atomic per 1024-vertex block.
-__global__ __launch_bounds__(1024) void ld_compact_kernel(int n, int* __restrict__ flag, int* __restrict__ list,
-                                                          int* __restrict__ counters) {
-  __shared__ int wsum[16];
-  __shared__ int base;
+// Class of a vertex in a sweep: a fresh hash per sweep (salt), so two neighbours that shared a class -- and could
+// therefore move at the same time, e.g. swap communities -- almost surely do not share it in the next sweep.
+__device__ __forceinline__ int lm_class(int v, unsigned int salt, int n_cls) {
+  return (int)((hash32((unsigned int)v * 0x9E3779B1u + salt) >> 9) & (unsigned int)(n_cls - 1));
+}
+
+// flags -> n_cls class lists (lists[c * n ..]), counts in cls_count[0 .. n_cls); clears the flags.  flag == nullptr:
+// every vertex is active (first sweep of a level).  The order inside a list is irrelevant (every decision of a
+// sub-round reads the same snapshot).  One atomic per class and 1024-vertex block.
+__global__ __launch_bounds__(1024) void ld_compact_cls_kernel(int n, int* __restrict__ flag, int* __restrict__ lists,
+                                                              int* __restrict__ cls_count, int n_cls, unsigned int salt) {
+  __shared__ int wcnt[16][MAX_CLASSES];
+  __shared__ int base[MAX_CLASSES];
   const int v = blockIdx.x * 1024 + threadIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int f = 0;
+  int cls = -1;
   if (v < n) {
-    f = flag[v];
-    if (f) flag[v] = 0;
+    int f = 1;
+    if (flag) {
+      f = flag[v];
+      if (f) flag[v] = 0;
+    }
+    if (f) cls = lm_class(v, salt, n_cls);
   }
-  const unsigned long long m = __ballot(f != 0);
-  const int rank = __popcll(m & ((1ull << lane) - 1ull));
-  if (lane == 0) wsum[wv] = __popcll(m);
+  int rank = 0;
+  for (int c = 0; c < n_cls; ++c) {
+    const unsigned long long m = __ballot(cls == c);
+    if (cls == c) rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wcnt[wv][c] = __popcll(m);
+  }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if ((int)threadIdx.x < n_cls) {
+    const int c = threadIdx.x;
     int tot = 0;
     for (int i = 0; i < 16; ++i) {
-      const int c = wsum[i];
-      wsum[i] = tot;
-      tot += c;
+      const int t = wcnt[i][c];
+      wcnt[i][c] = tot;
+      tot += t;
     }
-    base = tot ? atomicAdd(&counters[2], tot) : 0;
+    base[c] = tot ? atomicAdd(&cls_count[c], tot) : 0;
   }
   __syncthreads();
-  if (f) list[base + wsum[wv] + rank] = v;
+  if (cls >= 0) lists[(size_t)cls * n + base[cls] + wcnt[wv][cls] + rank] = v;
 }
 
 // ---- phase 2: refinement ---------------------------------------------------------------------------
@@ -694,25 +712,41 @@ __global__ __launch_bounds__(256) void ld_within_kernel(int n, const int64_t* __
 }
 
 // candidates of the refinement: vertices that are well connected inside their community
-// (w(v, C - v) >= gamma k_v (K_C - k_v) / 2m); all of them start as singletons.  counters[2] = list length
-__global__ void ld_refine_candidates_kernel(int n, const long long* __restrict__ k, const int* __restrict__ comm,
-                                            const unsigned long long* __restrict__ Ktot,
-                                            const long long* __restrict__ a_in, double g, int* __restrict__ list,
-                                            int* __restrict__ counters) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  bool take = false;
+// (w(v, C - v) >= gamma k_v (K_C - k_v) / 2m); all of them start as singletons.  They are written as n_cls class lists
+// (lists[c * n ..], counts in cls_count[0 .. n_cls)): class c is visited in sub-round c of the refinement.
+__global__ __launch_bounds__(1024) void ld_refine_candidates_kernel(
+    int n, const long long* __restrict__ k, const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot,
+    const long long* __restrict__ a_in, double g, int* __restrict__ lists, int* __restrict__ cls_count, int n_cls,
+    unsigned int salt) {
+  __shared__ int wcnt[16][MAX_CLASSES];
+  __shared__ int base[MAX_CLASSES];
+  const int v = blockIdx.x * 1024 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int cls = -1;
   if (v < n) {
     const double kv = (double)k[v];
     const double KC = (double)(long long)Ktot[comm[v]];
-    take = (double)a_in[v] >= g * kv * (KC - kv);
+    if ((double)a_in[v] >= g * kv * (KC - kv)) cls = lm_class(v, salt, n_cls);
   }
-  // one returning atomic per wave, not per vertex (the list order is irrelevant: it is a set)
-  const unsigned long long m = __ballot(take);
-  int base = 0;
-  if (lane == 0 && m) base = atomicAdd(&counters[2], __popcll(m));
-  base = __shfl(base, 0);
-  if (take) list[base + __popcll(m & ((1ull << lane) - 1ull))] = v;
+  int rank = 0;
+  for (int c = 0; c < n_cls; ++c) {
+    const unsigned long long m = __ballot(cls == c);
+    if (cls == c) rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wcnt[wv][c] = __popcll(m);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < n_cls) {
+    const int c = threadIdx.x;
+    int tot = 0;
+    for (int i = 0; i < 16; ++i) {
+      const int t = wcnt[i][c];
+      wcnt[i][c] = tot;
+      tot += t;
+    }
+    base[c] = tot ? atomicAdd(&cls_count[c], tot) : 0;
+  }
+  __syncthreads();
+  if (cls >= 0) lists[(size_t)cls * n + base[cls] + wcnt[wv][cls] + rank] = v;
 }
 
 // Exact incremental update of w(r, C - r) after a round of merges.  For a vertex v that joined t this round
@@ -761,20 +795,11 @@ __global__ __launch_bounds__(256) void ld_refine_cut_update_kernel(
   }
 }
 
-// Mover / non-mover split of a refinement round: movers propose, only non-mover singletons (and grown communities) are
-// targets, so simultaneous merges cannot chain.  The low bit of `seed` selects the schedule: 1 = seven of eight vertices
-// move in round 0 and three of four in round 1 -- the refined communities then grow from ~n/8 seeds instead of ~n/3,
-// i.e. the next level is ~3x smaller (a parallel refinement cannot merge two grown communities, so the number of seeds
-// of the first rounds IS the size of the next level); 0 = one of two in every round (round 1 behaviour).
-__device__ __forceinline__ bool mover_bit(int v, int round, unsigned int seed) {
-  const unsigned int h = hash32((unsigned int)v * 0x9E3779B1u + (unsigned int)round * 0x85EBCA77u + (seed | 1u)) >> 7;
-  if (seed & 1u) {
-    if (round == 0) return (h & 7u) != 0u;
-    if (round == 1) return (h & 3u) != 0u;
-  }
-  return h & 1u;
-}
-
+// Sub-round c of the refinement: the singletons of class c propose, the targets are grown sub-communities and singletons
+// of OTHER classes (a singleton of the same class may itself leave in this sub-round), so simultaneous merges cannot
+// chain; classes < c have had their turn (their results are visible), classes > c get theirs later unless somebody
+// joins them first.  After the n_cls sub-rounds every candidate was considered exactly once -- leidenalg's
+// `merge_nodes_constrained` visits every vertex once, in random order.
 // Randomised merge rule of the refinement (Traag et al. 2019, leidenalg's `refine_consider_comms` with theta = beta):
 // v joins r with probability ~ exp(gain(v, r) / beta) among the well-connected candidates of non-negative gain, "stay"
 // (gain 0) included.  Sampled with the Gumbel-max trick: argmax_r gain_r / beta + G(v, r, round, seed) with
@@ -791,8 +816,8 @@ __device__ __forceinline__ double refine_noise(int v, int c, int round, unsigned
 
 // G lanes per candidate (see ld_move_kernel: G = 16 puts four candidates in a wave on short-rowed levels, rows longer
 // than the 128-slot table go to ovf_list / counters[5] and are proposed by the G = 64 instantiation in indirect mode).
-// target[v] = refined community to join, -1 = none this round (stay a candidate), -2 = no longer a singleton
-// (somebody joined it): drop from the candidate list.
+// `list` holds the candidates of class `round` (the sub-round's number).  target[v] = refined community to join,
+// -1 = no admissible target, -2 = no longer a singleton (somebody joined it) or "stay" was drawn.
 template <int G>
 __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
     const int* __restrict__ list, const int* __restrict__ sub_list, const int* __restrict__ sub_count,
@@ -800,9 +825,8 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
     const long long* __restrict__ k, const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot,
     const int* __restrict__ ref, const int* __restrict__ refsize, const unsigned long long* __restrict__ Kref,
     const unsigned long long* __restrict__ Eref, double g, double inv_beta /* 1 / (beta * 2^32); 0 = greedy */,
-    int round, unsigned int seed, int* __restrict__ target,
-    int* __restrict__ ovf_list, int* __restrict__ hub_list, int* __restrict__ counters,
-    const int* __restrict__ n_cand_dev, const int* __restrict__ stop) {
+    int round, int n_cls, unsigned int salt, unsigned int seed, int* __restrict__ target,
+    int* __restrict__ ovf_list, int* __restrict__ hub_list, int* __restrict__ counters, int n_cand) {
   constexpr int GROUPS = 256 / G;
   constexpr int GSLOTS = WH_SLOTS * G / 64;
   constexpr int GMAX = GSLOTS * 3 / 4;
@@ -810,9 +834,7 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
   __shared__ unsigned long long hvals[GROUPS][GSLOTS];
   const int sub = threadIdx.x % G;
   const int grp = threadIdx.x / G;
-  if (*stop) return;
-  // list length of this round, produced on the device by the previous round (or the overflow count of this one)
-  const int n_items = sub_list ? *sub_count : *n_cand_dev;
+  const int n_items = sub_list ? *sub_count : n_cand;
   for (int item = blockIdx.x * GROUPS + grp; item < n_items; item += gridDim.x * GROUPS) {
     // (gathers grouped by what they depend on, as in ld_move_kernel: list -> {refsize, ref, k, comm, indptr}[v] ->
     // {Ktot[a], indices, wq} -> {comm, ref}[u] -> {Kref, refsize, Eref}[c]; most launches of a refinement are short
@@ -827,7 +849,7 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
     int tgt = -1;
     if (rs_v != 1 || ref_v != v) {
       tgt = -2;
-    } else if (mover_bit(v, round, seed)) {
+    } else {
       const int deg = (int)(end - beg);
       int u_pre[2];
       long long w_pre[2];
@@ -908,7 +930,7 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
                 (long long)__hip_atomic_load(&vals[sub + t * G], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const double Kr = (double)(long long)kr[t];
             const bool single = rsz[t] == 1;
-            const bool ok_target = (!single || !mover_bit(c, round, seed)) &&
+            const bool ok_target = (!single || lm_class(c, salt, n_cls) != round) &&
                                    ((double)(long long)er[t] >= g * Kr * (KC - Kr));  // target well connected
             const double gain = (double)sum - g * kv * Kr;
             if (ok_target && gain >= 0.0) {
@@ -948,7 +970,7 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
           if (c >= 0 && c != v) {
             const double Kr = (double)(long long)Kref[c];
             const bool single = refsize[c] == 1;
-            const bool ok_target = (!single || !mover_bit(c, round, seed)) &&
+            const bool ok_target = (!single || lm_class(c, salt, n_cls) != round) &&
                                    ((double)(long long)Eref[c] >= g * Kr * (KC - Kr));  // target well connected
             const double gain = (double)sum - g * kv * Kr;
             if (ok_target && gain >= 0.0) {
@@ -983,8 +1005,8 @@ __global__ __launch_bounds__(256) void ld_refine_propose_hub_kernel(
     const int* __restrict__ indices, const long long* __restrict__ wq, const long long* __restrict__ k,
     const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot, const int* __restrict__ ref,
     const int* __restrict__ refsize, const unsigned long long* __restrict__ Kref,
-    const unsigned long long* __restrict__ Eref, double g, double inv_beta, int round, unsigned int seed,
-    int* __restrict__ target) {
+    const unsigned long long* __restrict__ Eref, double g, double inv_beta, int round, int n_cls, unsigned int salt,
+    unsigned int seed, int* __restrict__ target, int* __restrict__ err) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long hub_smem[];
   BlockHash bh{reinterpret_cast<int*>(hub_smem + BHUB_SLOTS), hub_smem, BHUB_SLOTS};
   __shared__ Cand sh_c[4];
@@ -1012,7 +1034,7 @@ __global__ __launch_bounds__(256) void ld_refine_propose_hub_kernel(
         if (u == v || comm[u] != a) continue;
         const int c = ref[u];
         if (n_pass == 1) bh.add(c, wq[beg + e]);
-        else if (bhub_class(c, n_pass) == pass && !bh.add_bounded(c, wq[beg + e])) counters[7] = 1;
+        else if (bhub_class(c, n_pass) == pass && !bh.add_bounded(c, wq[beg + e])) *err = 1;
       }
       __syncthreads();
       for (int sl = threadIdx.x; sl < bh.nslots; sl += blockDim.x) {
@@ -1021,7 +1043,7 @@ __global__ __launch_bounds__(256) void ld_refine_propose_hub_kernel(
           const long long sum = (long long)bh.vals[sl];
           const double Kr = (double)(long long)Kref[c];
           const bool single = refsize[c] == 1;
-          const bool ok_target = (!single || !mover_bit(c, round, seed)) &&
+          const bool ok_target = (!single || lm_class(c, salt, n_cls) != round) &&
                                  ((double)(long long)Eref[c] >= g * Kr * (KC - Kr));
           const double gain = (double)sum - g * kv * Kr;
           if (ok_target && gain >= 0.0) {
@@ -1042,65 +1064,34 @@ __global__ __launch_bounds__(256) void ld_refine_propose_hub_kernel(
   }
 }
 
-// counters: [0] merges (= joiner list length), [2] next candidate list length
+// counters: [0] merges of this sub-round (= joiner list length)
 __global__ void ld_refine_apply_kernel(int n_cand, const int* __restrict__ list, const int* __restrict__ target,
                                        const long long* __restrict__ k, int* __restrict__ ref,
                                        int* __restrict__ refsize, unsigned long long* __restrict__ Kref,
                                        unsigned long long* __restrict__ Eref, int* __restrict__ stamp, int round,
-                                       int* __restrict__ jlist, int* __restrict__ list_next,
-                                       int* __restrict__ counters, const int* __restrict__ n_cand_dev,
-                                       const int* __restrict__ stop) {
+                                       int* __restrict__ jlist, int* __restrict__ counters) {
   const int lane = threadIdx.x & 63;
-  if (*stop) return;
-  n_cand = *n_cand_dev;
   for (int w0 = blockIdx.x * blockDim.x; w0 < n_cand; w0 += gridDim.x * blockDim.x) {
-  const int w = w0 + threadIdx.x;
-  const int v = (w < n_cand) ? list[w] : -1;
-  const int t = (v >= 0) ? target[v] : -2;
-  // list appends are aggregated per wave: one returning atomic per wave instead of one per element
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  const unsigned long long mj = __ballot(t >= 0), mk = __ballot(t == -1);
-  int bj = 0, bk = 0;
-  if (lane == 0) {
-    if (mj) bj = atomicAdd(&counters[0], __popcll(mj));
-    if (mk) bk = atomicAdd(&counters[2], __popcll(mk));
+    const int w = w0 + threadIdx.x;
+    const int v = (w < n_cand) ? list[w] : -1;
+    const int t = (v >= 0) ? target[v] : -2;
+    // list appends are aggregated per wave: one returning atomic per wave instead of one per element
+    const unsigned long long mj = __ballot(t >= 0);
+    int bj = 0;
+    if (lane == 0 && mj) bj = atomicAdd(&counters[0], __popcll(mj));
+    bj = __shfl(bj, 0);
+    if (t >= 0) {
+      // v is a singleton (ref[v] == v) joining t; t's members do not move in this sub-round
+      ref[v] = t;
+      atomicAdd(&refsize[t], 1);
+      atomicAdd(&Kref[t], (unsigned long long)k[v]);
+      refsize[v] = 0;
+      Kref[v] = 0;
+      Eref[v] = 0;
+      stamp[v] = round;
+      jlist[bj + __popcll(mj & ((1ull << lane) - 1ull))] = v;
+    }
   }
-  bj = __shfl(bj, 0);
-  bk = __shfl(bk, 0);
-  if (t >= 0) {
-    // v is a singleton (ref[v] == v) joining t; t's members do not move this round
-    ref[v] = t;
-    atomicAdd(&refsize[t], 1);
-    atomicAdd(&Kref[t], (unsigned long long)k[v]);
-    refsize[v] = 0;
-    Kref[v] = 0;
-    Eref[v] = 0;
-    stamp[v] = round;
-    jlist[bj + __popcll(mj & lt)] = v;
-  } else if (t == -1) {
-    list_next[bk + __popcll(mk & lt)] = v;
-  }
-  }
-}
-
-// round control, one thread: the stop rule of the refinement (RF_QUIET_ROUNDS rounds without a merge, or an empty
-// candidate list) evaluated on the device so that a batch of rounds runs without a host round trip.
-// ctl: [0] stop, [1] quiet rounds, [2] rounds done, [3] total merges
-// The merge counts of successive rounds fall geometrically (each round pairs about half of the remaining
-// singleton/target couples: 323k, 179k, 89k, ... at 1M vertices); once a round merges fewer than stop_ppm
-// millionths of the level's vertices the rest is left to the next level, where those singletons are ordinary
-// coarse nodes of their community (leidenalg's refinement visits every vertex exactly once, it does not iterate
-// to a fixed point either).
-__global__ void ld_refine_ctl_kernel(const int* __restrict__ counters, int* __restrict__ ctl, int n_level,
-                                     int stop_ppm) {
-  if (ctl[0]) return;
-  const int merges = counters[0];
-  const int quiet = merges == 0 ? ctl[1] + 1 : 0;
-  ctl[1] = quiet;
-  ctl[2] += 1;
-  ctl[3] += merges;
-  if (quiet >= RF_QUIET_ROUNDS || counters[2] == 0) ctl[0] = 1;
-  if (merges > 0 && (long long)merges * 1000000ll < (long long)n_level * stop_ppm) ctl[0] = 1;
 }
 
 __global__ void ld_refine_init_kernel(int n, const long long* __restrict__ k, const long long* __restrict__ a_in,
@@ -1508,7 +1499,7 @@ struct LeidenBuffers {
   long long* wq0; long long* k0;
   CoarseBuf cb[2];
   int* comm; int* comm_next; int* csize; int* csize_next; unsigned long long* Ktot; unsigned long long* Ktot_next;
-  int* list_a; int* list_b; int* rlist; int* touched; int* hub_list;
+  int* cls_lists; int* rlist; int* touched; int* hub_list;
   int* ref; int* target; int* refsize; unsigned long long* Kref; unsigned long long* Eref; long long* a_in;
   int* flag; int64_t* newid; int64_t* scan_tmp; int* cid; int* rep; int* comm_tmp;
   int* node_of; int* memb; int* memb_best;
@@ -1535,8 +1526,7 @@ static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b
   b->csize_next = ws.take<int>(N);
   b->Ktot = ws.take<unsigned long long>(N);
   b->Ktot_next = ws.take<unsigned long long>(N);
-  b->list_a = ws.take<int>(N);
-  b->list_b = ws.take<int>(N);
+  b->cls_lists = ws.take<int>(MAX_CLASSES * N);  // class lists of a sweep (local moving) / of the refinement
   b->rlist = ws.take<int>(N);
   b->hub_list = ws.take<int>(N);
   b->touched = ws.take<int>(N);
@@ -1567,7 +1557,7 @@ static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b
   b->rowcnt = ws.take<int>(N);
   b->cursor = ws.take<int>(N);
   b->counters = ws.take<int>(8);
-  b->rcounters = ws.take<int>(8 * MAX_RF_ROUNDS + 8);
+  b->rcounters = ws.take<int>(CTR_STRIDE * (MAX_CLASSES + 2));
   b->total = ws.take<unsigned long long>(4);
   b->dscratch = ws.take<double>(4 + SUMSQ_BLOCKS);
   b->ckeys = ws.take<unsigned long long>(N);
@@ -1590,9 +1580,9 @@ struct LeidenCtx {
   double inv_beta = 0.0;  // 1 / (beta * 2^32): randomness of the refinement's merge rule (0 = greedy)
   int iter = 0;           // outer iteration: part of the refinement's noise seed
   unsigned int seed;
-  int lm_stop_permille = 10;  // local moving of a level stops once < 1 % of its vertices move in a round
-  int rf_stop_ppm = 500;      // refinement stops once a round merges < 0.05 % of the level's vertices
-  int rf_batch = RF_BATCH;
+  int lm_stop_permille = 20;  // local moving of a level stops once < 2 % of its vertices move in a sweep
+  int lm_classes = 0;         // class sub-rounds per local-moving sweep (0 = by level size; SCAMD_LEIDEN_LM_CLASSES)
+  int rf_classes = 0;         // class sub-rounds of the refinement (0 = by level size; SCAMD_LEIDEN_RF_CLASSES)
   // coarse-row build tiers (distinct-neighbour bounds); the env overrides exist so the tests can push small graphs
   // through the workgroup and multi-pass tiers
   int agg_wave_max = WH_MAX_DEG;
@@ -1655,80 +1645,118 @@ static int level_lanes(const LevelGraph& g) {
 }
 static bool level_is_short_rowed(const LevelGraph& g) { return level_lanes(g) == 16; }
 
+// class sub-rounds per sweep: 8 everywhere.  (4 / 2 on levels below 16384 / 1024 vertices saved ~1 ms of launch latency
+// per call, but the fewer the classes the more neighbours move at once: on the 700-cell fixture one seed in ten then
+// ended in a worse optimum, Q 0.8101 against the oracle's minimum 0.8120.)
+static int lm_classes(const LeidenCtx& cx, int n) {
+  (void)n;
+  return cx.lm_classes > 0 ? cx.lm_classes : DEF_CLASSES;
+}
+// (refinement: a singleton cannot join a singleton of its OWN class -- with 8 classes an eighth of the targets the
+// sequential algorithm would see are excluded, which on small graphs costs quality: 700-cell fixture over 30 seeds, runs
+// ending below Q 0.8115: oracle 0, 32 classes 0, 8 classes 2, 2 classes 5.  Small levels therefore take 32 sub-rounds.)
+static int rf_classes(const LeidenCtx& cx, int n) {
+  if (cx.rf_classes > 0) return cx.rf_classes;
+  return n <= 4096 ? MAX_CLASSES : DEF_CLASSES;
+}
+
 static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
   LeidenBuffers& b = cx.b;
   const double gg = cx.gamma / cx.m2;
   *total_moves = 0;
   int rc = compute_totals(cx, g, b.comm);
   if (rc != SCAMD_OK) return rc;
-  hipLaunchKernelGGL(ld_iota_kernel, GRID1(g.n), 0, cx.s, b.list_a, g.n);
-  SCAMD_LAUNCH_CHECK();
   const size_t n = (size_t)g.n;
   SCAMD_HIP_CHECK(hipMemsetAsync(b.flag, 0, sizeof(int) * n, cx.s));
-  int n_act = g.n;
-  int quiet = 0;
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));  // [0] moved, [1] blocked (cumulative), [7] error
   const int lanes = level_lanes(g);
-  const bool quad = lanes == 16;
-  for (int rnd = 0; rnd < MAX_LM_ROUNDS && n_act > 0; ++rnd) {
-    const int round = rnd;
-    SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
-    if (lanes == 32) {
-      hipLaunchKernelGGL(ld_move_kernel<32>, dim3((unsigned)ceil_div(n_act, 8)), dim3(256), 0, cx.s, n_act, b.list_a,
-                         (const int*)nullptr, (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
-                         b.csize, gg, round, cx.seed, b.target, b.mid_list, b.hub_list, b.counters);
-      SCAMD_LAUNCH_CHECK();
-      if (g.max_deg > 2 * QUAD_MAX_DEG) {
-        hipLaunchKernelGGL(ld_move_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(n_act, 4))), dim3(256), 0, cx.s,
-                           n_act, b.list_a, (const int*)b.mid_list, (const int*)(b.counters + 5), g.indptr, g.indices,
-                           g.wq, g.k, b.comm, b.Ktot, b.csize, gg, round, cx.seed, b.target, b.mid_list, b.hub_list,
-                           b.counters);
+  const int n_cls = lm_classes(cx, g.n);
+  int* sw = b.rcounters;  // block 0: class list lengths of the sweep; block r + 1: hub / overflow counts of sub-round r
+  int moved_before = 0, quiet = 0, moved_prev2 = 0;
+  for (int sweep = 0; sweep < MAX_LM_SWEEPS; ++sweep) {
+    SCAMD_HIP_CHECK(hipMemsetAsync(sw, 0, sizeof(int) * CTR_STRIDE * (n_cls + 1), cx.s));
+    const unsigned int salt = hash32(cx.seed + 0x85EBCA77u * (unsigned int)(sweep + 1) + 0xC2B2AE3Du * (unsigned int)cx.iter);
+    hipLaunchKernelGGL(ld_compact_cls_kernel, dim3((unsigned)ceil_div(g.n, 1024)), dim3(1024), 0, cx.s, g.n,
+                       sweep == 0 ? (int*)nullptr : b.flag, b.cls_lists, sw, n_cls, salt);
+    SCAMD_LAUNCH_CHECK();
+    int hc[MAX_CLASSES], ht[8];
+    SCAMD_HIP_CHECK(hipMemcpyAsync(hc, sw, sizeof(int) * n_cls, hipMemcpyDeviceToHost, cx.s));
+    SCAMD_HIP_CHECK(hipMemcpyAsync(ht, b.counters, sizeof(int) * 8, hipMemcpyDeviceToHost, cx.s));
+    SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+    SCAMD_REQUIRE(ht[7] == 0, SCAMD_EINTERNAL, "leiden: hub table overflow (local moving)");
+    int n_act = 0;
+    for (int c = 0; c < n_cls; ++c) n_act += hc[c];
+    const int moved_last = ht[0] - moved_before;  // moves of the previous sweep
+    moved_before = ht[0];
+    *total_moves = ht[0];
+    if (leiden_debug())
+      fprintf(stderr, "[leiden] lm n=%d sweep=%d classes=%d act=%d moved_prev=%d blocked_total=%d\n", g.n, sweep, n_cls, n_act,
+              moved_last, ht[1]);
+    if (n_act == 0) break;
+    if (sweep > 0) {
+      // (with the direction rule on, blocked vertices stay active without anybody moving: two such sweeps end the level)
+      quiet = (moved_last == 0) ? quiet + 1 : 0;
+      if (quiet >= 2) break;
+      // Vertex-by-vertex merging of whole communities is what the coarser levels are for: once fewer than
+      // lm_stop_permille/1000 of the level's vertices move in a sweep, go on to refinement + aggregation (the
+      // outer iterations repeat until nothing improves, so no move is lost, it is only made at a cheaper level).
+      // (first outer iteration only: the later ones polish, and a level of theirs moves few vertices anyway)
+      // The other half of the rule: the move counts of a level fall geometrically while vertices settle (749k, 178k,
+      // 55k, 19k, 12k at 1M planted cells) and then RISE again for twenty sweeps (15k ... 74k ... 8k) while fragments
+      // coalesce one boundary vertex at a time -- exactly the work that is cheaper one level up.  A sweep that does not
+      // move at least a tenth fewer vertices than the one before it ends the level (first outer iteration only).
+      if (cx.iter == 0 && sweep >= 2) {
+        if ((long long)moved_last * 1000 < (long long)g.n * cx.lm_stop_permille) break;
+        if (sweep >= 3 && (long long)moved_last * 10 > (long long)moved_prev2 * 9) break;
+      }
+      moved_prev2 = moved_last;
+    }
+    // the direction rule is the termination guarantee only: synchronous sub-rounds without it converge in a few sweeps
+    // on every graph tried, with it (round 2's scheme) about half of the wanted moves of a round were blocked
+    const int dir_round = sweep >= LM_DIR_AFTER ? sweep : -1;
+    for (int c = 0; c < n_cls; ++c) {
+      const int cnt = hc[c];
+      if (cnt == 0) continue;
+      const int* list = b.cls_lists + (size_t)c * n;
+      int* ctr = sw + CTR_STRIDE * (c + 1);
+      if (lanes == 32) {
+        hipLaunchKernelGGL(ld_move_kernel<32>, dim3((unsigned)ceil_div(cnt, 8)), dim3(256), 0, cx.s, cnt, list,
+                           (const int*)nullptr, (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
+                           b.csize, gg, dir_round, cx.seed, b.target, b.mid_list, b.hub_list, ctr);
+        SCAMD_LAUNCH_CHECK();
+        if (g.max_deg > 2 * QUAD_MAX_DEG) {
+          hipLaunchKernelGGL(ld_move_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(cnt, 4))), dim3(256), 0, cx.s,
+                             cnt, list, (const int*)b.mid_list, (const int*)(ctr + 5), g.indptr, g.indices, g.wq, g.k,
+                             b.comm, b.Ktot, b.csize, gg, dir_round, cx.seed, b.target, b.mid_list, b.hub_list, ctr);
+          SCAMD_LAUNCH_CHECK();
+        }
+      } else if (lanes == 16) {
+        hipLaunchKernelGGL(ld_move_kernel<16>, dim3((unsigned)ceil_div(cnt, 16)), dim3(256), 0, cx.s, cnt, list,
+                           (const int*)nullptr, (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
+                           b.csize, gg, dir_round, cx.seed, b.target, b.mid_list, b.hub_list, ctr);
+        SCAMD_LAUNCH_CHECK();
+        if (g.max_deg > QUAD_MAX_DEG) {
+          hipLaunchKernelGGL(ld_move_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(cnt, 4))), dim3(256), 0, cx.s,
+                             cnt, list, (const int*)b.mid_list, (const int*)(ctr + 5), g.indptr, g.indices, g.wq, g.k,
+                             b.comm, b.Ktot, b.csize, gg, dir_round, cx.seed, b.target, b.mid_list, b.hub_list, ctr);
+          SCAMD_LAUNCH_CHECK();
+        }
+      } else {
+        hipLaunchKernelGGL(ld_move_kernel<64>, GRIDW(cnt), 0, cx.s, cnt, list, (const int*)nullptr, (const int*)nullptr,
+                           g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg, dir_round, cx.seed, b.target,
+                           b.mid_list, b.hub_list, ctr);
         SCAMD_LAUNCH_CHECK();
       }
-    } else if (quad) {
-      hipLaunchKernelGGL(ld_move_kernel<16>, dim3((unsigned)ceil_div(n_act, 16)), dim3(256), 0, cx.s, n_act, b.list_a,
-                         (const int*)nullptr, (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
-                         b.csize, gg, round, cx.seed, b.target, b.mid_list, b.hub_list, b.counters);
-      SCAMD_LAUNCH_CHECK();
-      if (g.max_deg > QUAD_MAX_DEG) {
-        hipLaunchKernelGGL(ld_move_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(n_act, 4))), dim3(256), 0, cx.s,
-                           n_act, b.list_a, (const int*)b.mid_list, (const int*)(b.counters + 5), g.indptr, g.indices,
-                           g.wq, g.k, b.comm, b.Ktot, b.csize, gg, round, cx.seed, b.target, b.mid_list, b.hub_list,
-                           b.counters);
+      if (g.max_deg > WH_MAX_DEG) {
+        hipLaunchKernelGGL(ld_move_hub_kernel, dim3((unsigned)std::min(HUB_GRID, cnt)), dim3(256), HUB_LDS, cx.s, b.hub_list,
+                           ctr, list, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg, dir_round, cx.seed,
+                           b.target, b.counters + 7);
         SCAMD_LAUNCH_CHECK();
       }
-    } else {
-      hipLaunchKernelGGL(ld_move_kernel<64>, GRIDW(n_act), 0, cx.s, n_act, b.list_a, (const int*)nullptr,
-                         (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg, round,
-                         cx.seed, b.target, b.mid_list, b.hub_list, b.counters);
+      hipLaunchKernelGGL(ld_apply_kernel, GRID1(cnt), 0, cx.s, cnt, list, b.target, g.indptr, g.indices, g.k, b.comm,
+                         b.Ktot, b.csize, b.flag, b.counters);
       SCAMD_LAUNCH_CHECK();
     }
-    if (g.max_deg > WH_MAX_DEG) {
-      hipLaunchKernelGGL(ld_move_hub_kernel, dim3(HUB_GRID), dim3(256), HUB_LDS, cx.s, b.hub_list, b.counters, b.list_a,
-                         g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg, round, cx.seed, b.target);
-      SCAMD_LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(ld_apply_kernel, GRID1(n_act), 0, cx.s, n_act, b.list_a, b.target, g.indptr, g.indices, g.k,
-                       b.comm, b.Ktot, b.csize, b.flag, b.counters);
-    SCAMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ld_compact_kernel, dim3((unsigned)ceil_div(g.n, 1024)), dim3(1024), 0, cx.s, g.n, b.flag,
-                       b.list_b, b.counters);
-    SCAMD_LAUNCH_CHECK();
-    int h[8];
-    rc = read_counters(cx, h, 8);
-    if (rc != SCAMD_OK) return rc;
-    SCAMD_REQUIRE(h[7] == 0, SCAMD_EINTERNAL, "leiden: hub table overflow (local moving)");
-    if (leiden_debug()) fprintf(stderr, "[leiden] lm n=%d round=%d act=%d moved=%d blocked=%d next=%d\n", g.n, rnd, n_act, h[0], h[1], h[2]);
-    std::swap(b.list_a, b.list_b);
-    n_act = h[2];
-    *total_moves += h[0];
-    // moves blocked by the direction rule get their chance in the next (opposite) round
-    quiet = (h[0] == 0) ? quiet + 1 : 0;
-    if (quiet >= 2) break;
-    // Vertex-by-vertex merging of whole communities is what the coarser levels are for: once fewer than
-    // lm_stop_permille/1000 of the level's vertices move in a round, go on to refinement + aggregation (the
-    // outer iterations repeat until nothing improves, so no move is lost, it is only made at a cheaper level).
-    // (first outer iteration only: the later ones polish, and a level of theirs moves few vertices anyway)
-    if (cx.iter == 0 && rnd >= 1 && (long long)h[0] * 1000 < (long long)g.n * cx.lm_stop_permille) break;
   }
   return SCAMD_OK;
 }
@@ -1736,17 +1764,12 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
 static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
   LeidenBuffers& b = cx.b;
   const double gg = cx.gamma / cx.m2;
-  // fresh merge noise every outer iteration; bit 0 = mover schedule (mover_bit), SCAMD_LEIDEN_RF_SEEDS=0: the 1/2 split
-  // (measured: the 7/8 schedule makes 1M planted cells 41 -> 36 ms and the weak graph 880 -> 680 ms, but the coarser
-  // refinement costs quality on hard graphs -- fixture Q min 0.8054 vs 0.8115, weak-graph ARI vs the oracle 0.60 vs
-  // 0.70 -- so it is opt-in: SCAMD_LEIDEN_RF_SEEDS=1)
-  static const bool few_seeds = [] {
-    const char* e = getenv("SCAMD_LEIDEN_RF_SEEDS");
-    return e && e[0] == '1';
-  }();
-  const unsigned int rseed = ((cx.seed + 0x9E3779B9u * (unsigned int)cx.iter) & ~1u) | (few_seeds ? 1u : 0u);
+  // fresh merge noise and fresh classes every outer iteration
+  const unsigned int rseed = cx.seed + 0x9E3779B9u * (unsigned int)cx.iter;
+  const unsigned int salt = hash32(rseed ^ 0x5bd1e995u);
   const size_t n = (size_t)g.n;
-  if (level_is_short_rowed(g))
+  const bool quad = level_is_short_rowed(g);
+  if (quad)
     hipLaunchKernelGGL(ld_within_kernel<16>, dim3((unsigned)ceil_div(g.n, 16)), dim3(256), 0, cx.s, g.n, g.indptr,
                        g.indices, g.wq, b.comm, b.a_in);
   else
@@ -1754,89 +1777,73 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
   SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(ld_refine_init_kernel, GRID1(g.n), 0, cx.s, g.n, g.k, b.a_in, b.ref, b.refsize, b.Kref, b.Eref);
   SCAMD_LAUNCH_CHECK();
+  const int n_cls = rf_classes(cx, g.n);
+  int* rc0 = b.rcounters;  // block 0: class list lengths; block c + 1: [0] joiners, [4] hubs, [5] overflow of sub-round c
+  SCAMD_HIP_CHECK(hipMemsetAsync(rc0, 0, sizeof(int) * CTR_STRIDE * (n_cls + 1), cx.s));
   SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.touched, 0xff, sizeof(int) * n, cx.s));  // join-round stamps: -1 = never
-  hipLaunchKernelGGL(ld_refine_candidates_kernel, GRID1(g.n), 0, cx.s, g.n, g.k, b.comm, b.Ktot, b.a_in, gg, b.list_a,
-                     b.counters);
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.touched, 0xff, sizeof(int) * n, cx.s));  // join sub-round stamps: -1 = never
+  hipLaunchKernelGGL(ld_refine_candidates_kernel, dim3((unsigned)ceil_div(g.n, 1024)), dim3(1024), 0, cx.s, g.n, g.k,
+                     b.comm, b.Ktot, b.a_in, gg, b.cls_lists, rc0, n_cls, salt);
   SCAMD_LAUNCH_CHECK();
-  int h[4];
-  int rc = read_counters(cx, h, 4);
-  if (rc != SCAMD_OK) return rc;
+  int hc[MAX_CLASSES];
+  SCAMD_HIP_CHECK(hipMemcpyAsync(hc, rc0, sizeof(int) * n_cls, hipMemcpyDeviceToHost, cx.s));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
   *n_merged = 0;
-  const bool quad = level_is_short_rowed(g);
-  // Rounds run in batches of RF_BATCH without a host round trip: list lengths, merge counts and the stop rule
-  // live on the device (one 8-int counter block per round + ld_refine_ctl_kernel); the host only sizes the grids
-  // from the last list length it has seen (lengths never grow) and looks at the stop flag between batches.
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.rcounters, 0, sizeof(int) * (8 * MAX_RF_ROUNDS + 8), cx.s));
-  int* ctl = b.rcounters + 8 * MAX_RF_ROUNDS;
-  const int* n_in = b.counters + 2;  // length of the initial candidate list
-  int ub = h[2];
-  int hctl[4] = {0, 0, 0, 0};
-  int round = 0;
-  while (round < MAX_RF_ROUNDS && ub > 0) {
-    const int batch = std::min(cx.rf_batch, MAX_RF_ROUNDS - round);
-    const int first = round;
-    const unsigned wgrid = (unsigned)std::min(32768, ceil_div(ub, 4));
-    const unsigned tgrid = (unsigned)std::min(32768, ceil_div(ub, 256));
-    const unsigned qgrid = (unsigned)std::min(32768, ceil_div(ub, 16));
-    int* rcnt = nullptr;
-    for (int i = 0; i < batch; ++i, ++round) {
-      rcnt = b.rcounters + 8 * round;
-      if (quad) {
-        hipLaunchKernelGGL(ld_refine_propose_kernel<16>, dim3(qgrid), dim3(256), 0, cx.s, b.list_a, (const int*)nullptr,
-                           (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref,
-                           b.Eref, gg, cx.inv_beta, round, rseed, b.target, b.mid_list, b.hub_list, rcnt, n_in, (const int*)ctl);
-        SCAMD_LAUNCH_CHECK();
-        if (g.max_deg > QUAD_MAX_DEG) {
-          hipLaunchKernelGGL(ld_refine_propose_kernel<64>, dim3(std::min(wgrid, 2048u)), dim3(256), 0, cx.s, b.list_a,
-                             (const int*)b.mid_list, (const int*)(rcnt + 5), g.indptr, g.indices, g.wq, g.k, b.comm,
-                             b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, gg, cx.inv_beta, round, rseed, b.target, b.mid_list,
-                             b.hub_list, rcnt, n_in, (const int*)ctl);
-          SCAMD_LAUNCH_CHECK();
-        }
-      } else {
-        hipLaunchKernelGGL(ld_refine_propose_kernel<64>, dim3(wgrid), dim3(256), 0, cx.s, b.list_a, (const int*)nullptr,
-                           (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref,
-                           b.Eref, gg, cx.inv_beta, round, rseed, b.target, b.mid_list, b.hub_list, rcnt, n_in, (const int*)ctl);
+  // ONE sweep of n_cls sub-rounds, no host round trip in between: every candidate is considered exactly once (see
+  // ld_refine_propose_kernel); the joiner counts stay on the device until the end
+  for (int c = 0; c < n_cls; ++c) {
+    const int cnt = hc[c];
+    if (cnt == 0) continue;
+    const int* list = b.cls_lists + (size_t)c * n;
+    int* ctr = rc0 + CTR_STRIDE * (c + 1);
+    const unsigned wgrid = (unsigned)std::min(32768, ceil_div(cnt, 4));
+    const unsigned tgrid = (unsigned)std::min(32768, ceil_div(cnt, 256));
+    const unsigned qgrid = (unsigned)std::min(32768, ceil_div(cnt, 16));
+    if (quad) {
+      hipLaunchKernelGGL(ld_refine_propose_kernel<16>, dim3(qgrid), dim3(256), 0, cx.s, list, (const int*)nullptr,
+                         (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref,
+                         b.Eref, gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.mid_list, b.hub_list, ctr, cnt);
+      SCAMD_LAUNCH_CHECK();
+      if (g.max_deg > QUAD_MAX_DEG) {
+        hipLaunchKernelGGL(ld_refine_propose_kernel<64>, dim3(std::min(wgrid, 2048u)), dim3(256), 0, cx.s, list,
+                           (const int*)b.mid_list, (const int*)(ctr + 5), g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
+                           b.ref, b.refsize, b.Kref, b.Eref, gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.mid_list,
+                           b.hub_list, ctr, cnt);
         SCAMD_LAUNCH_CHECK();
       }
-      if (g.max_deg > WH_MAX_DEG) {
-        hipLaunchKernelGGL(ld_refine_propose_hub_kernel, dim3(HUB_GRID), dim3(256), HUB_LDS, cx.s, b.hub_list, rcnt,
-                           g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref, gg,
-                           cx.inv_beta, round, rseed, b.target);
-        SCAMD_LAUNCH_CHECK();
-      }
-      hipLaunchKernelGGL(ld_refine_apply_kernel, dim3(tgrid), dim3(256), 0, cx.s, ub, b.list_a, b.target, g.k, b.ref,
-                         b.refsize, b.Kref, b.Eref, b.touched, round, b.rlist, b.list_b, rcnt, n_in, (const int*)ctl);
+    } else {
+      hipLaunchKernelGGL(ld_refine_propose_kernel<64>, dim3(wgrid), dim3(256), 0, cx.s, list, (const int*)nullptr,
+                         (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref,
+                         b.Eref, gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.mid_list, b.hub_list, ctr, cnt);
       SCAMD_LAUNCH_CHECK();
-      if (quad) {
-        hipLaunchKernelGGL(ld_refine_cut_update_kernel<16>, dim3(qgrid), dim3(256), 0, cx.s, ub, b.rlist, g.indptr, g.indices,
-                           g.wq, b.comm, b.ref, b.touched, b.a_in, round, b.Eref, (const int*)rcnt);
-        SCAMD_LAUNCH_CHECK();
-      } else {
-        hipLaunchKernelGGL(ld_refine_cut_update_kernel<64>, dim3(wgrid), dim3(256), 0, cx.s, ub, b.rlist, g.indptr, g.indices,
-                           g.wq, b.comm, b.ref, b.touched, b.a_in, round, b.Eref, (const int*)rcnt);
-        SCAMD_LAUNCH_CHECK();
-      }
-      SCAMD_LAUNCH_CHECK();
-      hipLaunchKernelGGL(ld_refine_ctl_kernel, dim3(1), dim3(1), 0, cx.s, (const int*)rcnt, ctl, g.n, cx.rf_stop_ppm);
-      SCAMD_LAUNCH_CHECK();
-      std::swap(b.list_a, b.list_b);
-      n_in = rcnt + 2;
     }
-    int hr[8 * RF_BATCH_MAX];
-    SCAMD_HIP_CHECK(hipMemcpyAsync(hctl, ctl, sizeof(int) * 4, hipMemcpyDeviceToHost, cx.s));
-    SCAMD_HIP_CHECK(hipMemcpyAsync(hr, b.rcounters + 8 * first, sizeof(int) * 8 * batch, hipMemcpyDeviceToHost, cx.s));
-    SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
-    if (leiden_debug())
-      for (int i = 0; i < batch && first + i < hctl[2]; ++i)
-        fprintf(stderr, "[leiden] rf n=%d round=%d cand=%d merges=%d\n", g.n, first + i, hr[8 * i + 2], hr[8 * i]);
-    for (int i = 0; i < batch; ++i)
-      SCAMD_REQUIRE(hr[8 * i + 7] == 0, SCAMD_EINTERNAL, "leiden: hub table overflow (refinement)");
-    if (hctl[0]) break;
-    ub = hr[8 * (batch - 1) + 2];
+    if (g.max_deg > WH_MAX_DEG) {
+      hipLaunchKernelGGL(ld_refine_propose_hub_kernel, dim3((unsigned)std::min(HUB_GRID, cnt)), dim3(256), HUB_LDS, cx.s,
+                         b.hub_list, ctr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref,
+                         gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.counters + 7);
+      SCAMD_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(ld_refine_apply_kernel, dim3(tgrid), dim3(256), 0, cx.s, cnt, list, b.target, g.k, b.ref,
+                       b.refsize, b.Kref, b.Eref, b.touched, c, b.rlist, ctr);
+    SCAMD_LAUNCH_CHECK();
+    if (quad)
+      hipLaunchKernelGGL(ld_refine_cut_update_kernel<16>, dim3(qgrid), dim3(256), 0, cx.s, cnt, b.rlist, g.indptr,
+                         g.indices, g.wq, b.comm, b.ref, b.touched, b.a_in, c, b.Eref, (const int*)ctr);
+    else
+      hipLaunchKernelGGL(ld_refine_cut_update_kernel<64>, dim3(wgrid), dim3(256), 0, cx.s, cnt, b.rlist, g.indptr,
+                         g.indices, g.wq, b.comm, b.ref, b.touched, b.a_in, c, b.Eref, (const int*)ctr);
+    SCAMD_LAUNCH_CHECK();
   }
-  *n_merged = hctl[3];
+  int hr[CTR_STRIDE * (MAX_CLASSES + 1)], herr = 0;
+  SCAMD_HIP_CHECK(hipMemcpyAsync(hr, rc0, sizeof(int) * CTR_STRIDE * (n_cls + 1), hipMemcpyDeviceToHost, cx.s));
+  SCAMD_HIP_CHECK(hipMemcpyAsync(&herr, b.counters + 7, sizeof(int), hipMemcpyDeviceToHost, cx.s));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  SCAMD_REQUIRE(herr == 0, SCAMD_EINTERNAL, "leiden: hub table overflow (refinement)");
+  for (int c = 0; c < n_cls; ++c) {
+    *n_merged += hr[CTR_STRIDE * (c + 1)];
+    if (leiden_debug())
+      fprintf(stderr, "[leiden] rf n=%d class=%d/%d cand=%d merges=%d\n", g.n, c, n_cls, hc[c], hr[CTR_STRIDE * (c + 1)]);
+  }
   return SCAMD_OK;
 }
 
@@ -2050,8 +2057,13 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
   cx.inv_beta = beta > 0.0 ? 1.0 / (beta * WSCALE) : 0.0;  // beta <= 0: the greedy limit (largest gain, no "stay")
   cx.seed = (unsigned int)(seed ^ (seed >> 32)) * 0x9E3779B1u + 0x632BE5ABu;
   if (const char* e = getenv("SCAMD_LEIDEN_LM_STOP_PERMILLE")) cx.lm_stop_permille = atoi(e);
-  if (const char* e = getenv("SCAMD_LEIDEN_RF_STOP_PPM")) cx.rf_stop_ppm = atoi(e);
-  if (const char* e = getenv("SCAMD_LEIDEN_RF_BATCH")) cx.rf_batch = std::max(1, std::min(atoi(e), (int)RF_BATCH_MAX));
+  auto classes_env = [](const char* name) {
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : 0;
+    return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) ? v : 0;
+  };
+  cx.lm_classes = classes_env("SCAMD_LEIDEN_LM_CLASSES");
+  cx.rf_classes = classes_env("SCAMD_LEIDEN_RF_CLASSES");
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_WAVE_MAX")) cx.agg_wave_max = std::min(atoi(e), (int)WH_MAX_DEG);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_MAX")) cx.agg_mid_max = std::min(atoi(e), (int)AGG_MID_MAX);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_PASS_KEYS"))

@@ -18,7 +18,6 @@ VARIANTS = [
     {"SCAMD_LEIDEN_QUAD": "1"},                                # 16 lanes per vertex everywhere
     {"SCAMD_LEIDEN_QUAD": "2"},                                # 32 lanes per vertex everywhere
     {"SCAMD_LEIDEN_AGG_WAVE_MAX": "48", "SCAMD_LEIDEN_AGG_MID_MAX": "256", "SCAMD_LEIDEN_AGG_PASS_KEYS": "512"},
-    {"SCAMD_LEIDEN_RF_BATCH": "1"},
 ]
 
 
