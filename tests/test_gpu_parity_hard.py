@@ -149,7 +149,7 @@ def test_leiden_overlapping_blobs_vs_oracle_seed_distribution(K, spread):
           f"ARI truth gpu {ari_t:.4f} oracle {ari_t_or:.4f}")
     assert abs(q - ol.modularity(adj, m)) < 1e-8
     assert q >= q_or.min() - 2e-3 * max(1.0 - q_or.min(), 0.05), "modularity below the oracle's seed distribution"
-    assert ari_o >= min(0.99, floor - 0.02)
+    assert ari_o >= min(0.99, floor - 0.01)
     assert ari_t >= ari_t_or - 0.02
 
 
@@ -187,7 +187,7 @@ def test_leiden_fixture_seed_distribution_and_reference_labels(K, pbmc68k):
     assert gq.mean() >= oq.mean() - 1e-3
     assert gq.min() >= q_ref - 1e-3, "at least the modularity of the reference's own labels"
     assert np.mean(g_nmi) >= np.mean(o_nmi) - 0.02
-    assert cross >= floor - 0.05
+    assert cross >= floor - 0.01  # (round 2: 0.05; measured 0.9842 against a floor of 0.9884)
     # matched cluster count: scan the resolution until the partition has as many clusters as the reference's
     best = None
     for res in np.linspace(0.4, 1.6, 25):
@@ -221,7 +221,7 @@ def test_leiden_weak_planted_matrix_chain(K):
               f"ARI gpu-oracle {ari_o:.4f} (oracle seed floor {floor:.4f}); ARI truth gpu "
               f"{adjusted_rand_score(truth, m):.4f} oracle {adjusted_rand_score(truth, oracle[0][0]):.4f}")
         assert q >= q_min - 2e-3
-        assert ari_o >= min(0.99, floor - 0.03)
+        assert ari_o >= min(0.99, floor - 0.01)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
