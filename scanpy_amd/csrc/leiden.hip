@@ -88,12 +88,21 @@ __global__ __launch_bounds__(256) void ld_sum_kernel(const long long* __restrict
   if ((threadIdx.x & 63) == 0 && s != 0) atomicAdd(total, (unsigned long long)s);
 }
 
-__global__ void ld_maxdeg_kernel(const int64_t* __restrict__ indptr, int n, int* __restrict__ out) {
+// row-length statistics of a level: out[0] = longest row, out[1 .. 3] = rows longer than 96 / 192 / 384 entries (the
+// bounds of the quarter- / half- / full-wave tables: levels without such rows skip the overflow / hub launches, the
+// others size those grids by the counts)
+__global__ void ld_degstats_kernel(const int64_t* __restrict__ indptr, int n, int* __restrict__ out) {
   int v = blockIdx.x * blockDim.x + threadIdx.x;
   int d = (v < n) ? (int)(indptr[v + 1] - indptr[v]) : 0;
+  const unsigned long long m1 = __ballot(d > 96), m2 = __ballot(d > 192), m3 = __ballot(d > 384);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) d = max(d, __shfl_xor(d, o));
-  if ((threadIdx.x & 63) == 0 && d > 0) atomicMax(out, d);
+  if ((threadIdx.x & 63) == 0 && d > 0) {
+    atomicMax(out, d);
+    if (m1) atomicAdd(out + 1, __popcll(m1));
+    if (m2) atomicAdd(out + 2, __popcll(m2));
+    if (m3) atomicAdd(out + 3, __popcll(m3));
+  }
 }
 
 __global__ void ld_iota_kernel(int* __restrict__ a, int n) {
@@ -1486,6 +1495,7 @@ __global__ void ld_gather_kernel(int n, const int* __restrict__ comm, const int*
 struct LevelGraph {
   int n = 0;
   int max_deg = 0;  // largest row length: levels without hubs skip the block-per-vertex kernels
+  int n_gt96 = 0, n_gt192 = 0, n_gt384 = 0;  // rows beyond the quarter- / half- / full-wave tables
   int64_t nnz = 0;
   const int64_t* indptr = nullptr;
   const int* indices = nullptr;
@@ -1558,7 +1568,7 @@ static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b
   b->big_list = ws.take<int>(N);
   b->rowcnt = ws.take<int>(N);
   b->cursor = ws.take<int>(N);
-  b->counters = ws.take<int>(8);
+  b->counters = ws.take<int>(16);  // [0..7] phase counters, [8..11] row-length statistics of the level being built
   b->rcounters = ws.take<int>(CTR_AREA);
   b->total = ws.take<unsigned long long>(4);
   b->dscratch = ws.take<double>(4 + SUMSQ_BLOCKS);
@@ -1646,7 +1656,8 @@ static int quality(LeidenCtx& cx, const LevelGraph& g, const int* comm, double* 
 }
 
 // levels whose rows are short on average (the kNN graph itself) take the four-vertices-per-wave kernels
-constexpr int QUAD_MAX_DEG = WH_SLOTS / 4 * 3 / 4;  // 96: rows the 128-slot quarter-wave table takes
+static_assert(WH_SLOTS / 4 * 3 / 4 == 96 && WH_SLOTS / 2 * 3 / 4 == 192 && WH_MAX_DEG == 384,
+              "ld_degstats_kernel counts the rows beyond the 128- / 256- / 512-slot tables");
 // lanes per vertex of the decision kernels for this level: 16 (four vertices per wave, rows <= 96), 32 (two per wave,
 // rows <= 192: the first coarse levels, ~64 entries per row) or 64.  SCAMD_LEIDEN_QUAD = 0 / 1 / 2 forces 64 / 16 / 32.
 static int level_lanes(const LevelGraph& g) {
@@ -1739,8 +1750,8 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
                            (const int*)nullptr, (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
                            b.csize, gg, dir_round, cx.seed, b.target, b.mid_list, b.hub_list, ctr);
         SCAMD_LAUNCH_CHECK();
-        if (g.max_deg > 2 * QUAD_MAX_DEG) {
-          hipLaunchKernelGGL(ld_move_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(cnt, 4))), dim3(256), 0, cx.s,
+        if (g.n_gt192 > 0) {
+          hipLaunchKernelGGL(ld_move_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(std::min(cnt, g.n_gt192), 4))), dim3(256), 0, cx.s,
                              cnt, list, (const int*)b.mid_list, (const int*)(ctr + 5), g.indptr, g.indices, g.wq, g.k,
                              b.comm, b.Ktot, b.csize, gg, dir_round, cx.seed, b.target, b.mid_list, b.hub_list, ctr);
           SCAMD_LAUNCH_CHECK();
@@ -1750,8 +1761,8 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
                            (const int*)nullptr, (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
                            b.csize, gg, dir_round, cx.seed, b.target, b.mid_list, b.hub_list, ctr);
         SCAMD_LAUNCH_CHECK();
-        if (g.max_deg > QUAD_MAX_DEG) {
-          hipLaunchKernelGGL(ld_move_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(cnt, 4))), dim3(256), 0, cx.s,
+        if (g.n_gt96 > 0) {
+          hipLaunchKernelGGL(ld_move_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(std::min(cnt, g.n_gt96), 4))), dim3(256), 0, cx.s,
                              cnt, list, (const int*)b.mid_list, (const int*)(ctr + 5), g.indptr, g.indices, g.wq, g.k,
                              b.comm, b.Ktot, b.csize, gg, dir_round, cx.seed, b.target, b.mid_list, b.hub_list, ctr);
           SCAMD_LAUNCH_CHECK();
@@ -1762,8 +1773,8 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
                            b.mid_list, b.hub_list, ctr);
         SCAMD_LAUNCH_CHECK();
       }
-      if (g.max_deg > WH_MAX_DEG) {
-        hipLaunchKernelGGL(ld_move_hub_kernel, dim3((unsigned)std::min(HUB_GRID, cnt)), dim3(256), HUB_LDS, cx.s, b.hub_list,
+      if (g.n_gt384 > 0) {
+        hipLaunchKernelGGL(ld_move_hub_kernel, dim3((unsigned)std::min(HUB_GRID, std::min(cnt, g.n_gt384))), dim3(256), HUB_LDS, cx.s, b.hub_list,
                            ctr, list, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg, dir_round, cx.seed,
                            b.target, b.counters + 7);
         SCAMD_LAUNCH_CHECK();
@@ -1821,8 +1832,8 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
                          b.Eref, gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.mid_list, b.hub_list, ctr, cnt);
       SCAMD_LAUNCH_CHECK();
       LD_DBG_SYNC(cx, "rf propose<16> n=%d class=%d cnt=%d", g.n, c, cnt);
-      if (g.max_deg > QUAD_MAX_DEG) {
-        hipLaunchKernelGGL(ld_refine_propose_kernel<64>, dim3(std::min(wgrid, 2048u)), dim3(256), 0, cx.s, list,
+      if (g.n_gt96 > 0) {
+        hipLaunchKernelGGL(ld_refine_propose_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(std::min(cnt, g.n_gt96), 4))), dim3(256), 0, cx.s, list,
                            (const int*)b.mid_list, (const int*)(ctr + 5), g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
                            b.ref, b.refsize, b.Kref, b.Eref, gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.mid_list,
                            b.hub_list, ctr, cnt);
@@ -1836,8 +1847,8 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
       SCAMD_LAUNCH_CHECK();
       LD_DBG_SYNC(cx, "rf propose<64> n=%d class=%d cnt=%d", g.n, c, cnt);
     }
-    if (g.max_deg > WH_MAX_DEG) {
-      hipLaunchKernelGGL(ld_refine_propose_hub_kernel, dim3((unsigned)std::min(HUB_GRID, cnt)), dim3(256), HUB_LDS, cx.s,
+    if (g.n_gt384 > 0) {
+      hipLaunchKernelGGL(ld_refine_propose_hub_kernel, dim3((unsigned)std::min(HUB_GRID, std::min(cnt, g.n_gt384))), dim3(256), HUB_LDS, cx.s,
                          b.hub_list, ctr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref,
                          gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.counters + 7);
       SCAMD_LAUNCH_CHECK();
@@ -1906,15 +1917,24 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
                      b.cid, b.agg_col, b.agg_w, b.rowcnt, b.mid_list, b.big_list, b.counters, cx.agg_wave_max,
                      cx.agg_mid_max);
   SCAMD_LAUNCH_CHECK();
-  // workgroup tiers: 512 threads on the 48 KB tables (3 per CU), 1024 threads on the 96 KB table (1 per CU)
-  hipLaunchKernelGGL((ld_agg_block_kernel<AGG_MID_SLOTS, 512>), dim3(768), dim3(512), (size_t)AGG_MID_SLOTS * 12, cx.s,
-                     b.mid_list, b.counters + 4, inn, b.moff, b.eoff, b.members, g.indptr, g.indices, g.wq, b.cid,
-                     b.agg_col, b.agg_w, b.rowcnt, b.counters + 7, AGG_MID_MAX);
-  SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL((ld_agg_block_kernel<BHUB_SLOTS, 1024>), dim3(HUB_GRID), dim3(1024), HUB_LDS, cx.s, b.big_list,
-                     b.counters + 5, inn, b.moff, b.eoff, b.members, g.indptr, g.indices, g.wq, b.cid, b.agg_col,
-                     b.agg_w, b.rowcnt, b.counters + 7, cx.agg_pass_keys);
-  SCAMD_LAUNCH_CHECK();
+  // workgroup tiers: 512 threads on the 48 KB tables (3 per CU), 1024 threads on the 96 KB table (1 per CU).  Their list
+  // lengths are read back first: an empty launch of these shapes costs 40 / 140 us (768 x 512 / 512 x 1024 threads with
+  // 48 / 96 KB of LDS each), a host round trip 15 -- and most levels of a clustered graph have no such rows at all.
+  int htier[2] = {0, 0};
+  SCAMD_HIP_CHECK(hipMemcpyAsync(htier, b.counters + 4, sizeof(int) * 2, hipMemcpyDeviceToHost, cx.s));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  if (htier[0] > 0) {
+    hipLaunchKernelGGL((ld_agg_block_kernel<AGG_MID_SLOTS, 512>), dim3((unsigned)std::min(768, htier[0])), dim3(512),
+                       (size_t)AGG_MID_SLOTS * 12, cx.s, b.mid_list, b.counters + 4, inn, b.moff, b.eoff, b.members, g.indptr,
+                       g.indices, g.wq, b.cid, b.agg_col, b.agg_w, b.rowcnt, b.counters + 7, AGG_MID_MAX);
+    SCAMD_LAUNCH_CHECK();
+  }
+  if (htier[1] > 0) {
+    hipLaunchKernelGGL((ld_agg_block_kernel<BHUB_SLOTS, 1024>), dim3((unsigned)std::min(HUB_GRID, htier[1])), dim3(1024),
+                       HUB_LDS, cx.s, b.big_list, b.counters + 5, inn, b.moff, b.eoff, b.members, g.indptr, g.indices, g.wq,
+                       b.cid, b.agg_col, b.agg_w, b.rowcnt, b.counters + 7, cx.agg_pass_keys);
+    SCAMD_LAUNCH_CHECK();
+  }
   CoarseBuf& cb = b.cb[dst];
   rc = exclusive_scan_i32_i64(b.rowcnt, nn, cb.indptr, b.scan_tmp, cx.s);
   if (rc != SCAMD_OK) return rc;
@@ -1924,13 +1944,13 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
                      cb.indices, cb.wq);
   SCAMD_LAUNCH_CHECK();
   int64_t nnz_new = 0;
-  int max_deg = 0;
+  int dstat[4] = {0, 0, 0, 0};
   int agg_err = 0;
   SCAMD_HIP_CHECK(hipMemcpyAsync(&agg_err, b.counters + 7, sizeof(int), hipMemcpyDeviceToHost, cx.s));
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 6, 0, sizeof(int), cx.s));
-  hipLaunchKernelGGL(ld_maxdeg_kernel, GRID1(nn), 0, cx.s, cb.indptr, (int)nn, b.counters + 6);
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 8, 0, sizeof(int) * 4, cx.s));
+  hipLaunchKernelGGL(ld_degstats_kernel, GRID1(nn), 0, cx.s, cb.indptr, (int)nn, b.counters + 8);
   SCAMD_LAUNCH_CHECK();
-  SCAMD_HIP_CHECK(hipMemcpyAsync(&max_deg, b.counters + 6, sizeof(int), hipMemcpyDeviceToHost, cx.s));
+  SCAMD_HIP_CHECK(hipMemcpyAsync(dstat, b.counters + 8, sizeof(int) * 4, hipMemcpyDeviceToHost, cx.s));
   SCAMD_HIP_CHECK(hipMemcpyAsync(&nnz_new, cb.indptr + nn, sizeof(int64_t), hipMemcpyDeviceToHost, cx.s));
   hipLaunchKernelGGL(ld_strength_kernel, GRIDW(nn), 0, cx.s, cb.indptr, cb.wq, (int)nn, cb.k);
   SCAMD_LAUNCH_CHECK();
@@ -1938,7 +1958,10 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
   SCAMD_REQUIRE(agg_err == 0, SCAMD_EINTERNAL, "leiden: coarse-row table overflow");
   out->n = (int)nn;
-  out->max_deg = max_deg;
+  out->max_deg = dstat[0];
+  out->n_gt96 = dstat[1];
+  out->n_gt192 = dstat[2];
+  out->n_gt384 = dstat[3];
   out->nnz = nnz_new;
   out->indptr = cb.indptr;
   out->indices = cb.indices;
@@ -2030,16 +2053,19 @@ static int setup_level0(LeidenCtx& cx, const int64_t* indptr, const int32_t* ind
   SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(ld_sum_kernel, dim3(256), dim3(256), 0, cx.s, b.k0, (int)n, b.total);
   SCAMD_LAUNCH_CHECK();
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 6, 0, sizeof(int), cx.s));
-  hipLaunchKernelGGL(ld_maxdeg_kernel, GRID1(n), 0, cx.s, indptr, (int)n, b.counters + 6);
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 8, 0, sizeof(int) * 4, cx.s));
+  hipLaunchKernelGGL(ld_degstats_kernel, GRID1(n), 0, cx.s, indptr, (int)n, b.counters + 8);
   SCAMD_LAUNCH_CHECK();
   unsigned long long tot = 0;
-  int max_deg = 0;
+  int dstat[4] = {0, 0, 0, 0};
   SCAMD_HIP_CHECK(hipMemcpyAsync(&tot, b.total, sizeof(tot), hipMemcpyDeviceToHost, cx.s));
-  SCAMD_HIP_CHECK(hipMemcpyAsync(&max_deg, b.counters + 6, sizeof(int), hipMemcpyDeviceToHost, cx.s));
+  SCAMD_HIP_CHECK(hipMemcpyAsync(dstat, b.counters + 8, sizeof(int) * 4, hipMemcpyDeviceToHost, cx.s));
   SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
   cx.m2 = (double)tot;
-  g0->max_deg = max_deg;
+  g0->max_deg = dstat[0];
+  g0->n_gt96 = dstat[1];
+  g0->n_gt192 = dstat[2];
+  g0->n_gt384 = dstat[3];
   g0->n = (int)n;
   g0->nnz = nnz;
   g0->indptr = indptr;
