@@ -1363,6 +1363,480 @@ __global__ __launch_bounds__(256) void ld_agg_compact_kernel(int nn, const int64
   }
 }
 
+// ---- small levels: everything in ONE workgroup ---------------------------------------------------------
+// The last levels of every run are tiny (planted 1M cells: 170, 80, 67, 64 nodes; the 700-cell fixture is such a level
+// from the start): as separate kernels each of them costs ~65 launches and 5 host round trips = 0.5 ms of pure
+// latency, ten such levels per call.  From the first level with at most SMALL_N nodes and SMALL_NNZ entries on, ONE
+// workgroup runs local moving, refinement and aggregation of all remaining levels: the per-node state lives in LDS, the
+// rows stay in global memory (written by this workgroup, read after a device-scope fence), 8 waves take 8 nodes at a
+// time -- decide on a snapshot, barrier, apply, barrier -- so at most 8 nodes move at once, closer to the sequential
+// algorithm than any class schedule (a node's neighbour weights are summed in a dense per-wave table indexed by
+// community, with a touched list: no hashing, any row length).  Same arithmetic and same rules as the kernels above.
+constexpr int SMALL_N = 1024;
+constexpr int SMALL_NNZ = 65536;
+constexpr int SM_WAVES = 8;
+constexpr int SM_THREADS = SM_WAVES * 64;
+
+struct SmallArgs {
+  const int64_t* indptr;   // entry level
+  const int* indices;
+  const long long* wq;
+  const long long* k;
+  int n;
+  int* ix[2];              // coarse levels, ping-pong
+  long long* w[2];
+  int first_dst;
+  int* comm;               // in: partition of the entry nodes; out: final community of every entry node
+  double gg;               // gamma / 2m
+  double inv_beta;
+  unsigned int seed;
+  int iter;
+  int lm_stop_permille;
+  int* info;               // [0] levels, [1] moves, [2] merges, [3] nodes of the last level
+};
+
+struct SmallLds {
+  unsigned long long acc[SM_WAVES][SMALL_N];
+  unsigned short touched[SM_WAVES][SMALL_N];
+  unsigned long long Ktot[SMALL_N];
+  long long kk[SMALL_N];
+  int ip[SMALL_N + 1];
+  int comm[SMALL_N];
+  int csize[SMALL_N];          // local moving: community sizes; aggregation: new partition of the coarse nodes
+  unsigned short order[SMALL_N];
+  unsigned short tail_of[SMALL_N];
+  unsigned char flag[SMALL_N];
+  int ref[SMALL_N];
+  int refsize[SMALL_N];
+  union {
+    struct {
+      unsigned long long Kref[SMALL_N];
+      unsigned long long Eref[SMALL_N];
+      long long a_in[SMALL_N];
+      int stamp[SMALL_N];
+    } rf;
+    struct {
+      int cid[SMALL_N];
+      int members[SMALL_N];
+      int moff[SMALL_N + 1];
+      int rep[SMALL_N];
+      int rowptr[SMALL_N + 1];
+    } ag;
+  } u;
+  int tcnt[SM_WAVES];
+  int dec[SM_WAVES];
+  int rset[SM_WAVES];
+  int scan_w[SM_WAVES];
+  int s_n_act, s_moved, s_merged, s_nn;
+};
+static_assert(sizeof(SmallLds) <= 160 * 1024, "SmallLds must fit the 160 KB of LDS");
+
+// exclusive scan of x[0 .. n) (n <= 2 * SM_THREADS) in place; returns the total.  All threads call.
+__device__ __forceinline__ int small_scan(int* x, int n, int* scan_w) {
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int i0 = 2 * t, i1 = 2 * t + 1;
+  const int a0 = i0 < n ? x[i0] : 0, a1 = i1 < n ? x[i1] : 0;
+  int inc = a0 + a1;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(inc, o);
+    if (lane >= o) inc += y;
+  }
+  if (lane == 63) scan_w[wv] = inc;
+  __syncthreads();
+  int off = 0, tot = 0;
+  for (int i = 0; i < SM_WAVES; ++i) {
+    const int s = scan_w[i];
+    if (i < wv) off += s;
+    tot += s;
+  }
+  const int ex = off + inc - (a0 + a1);
+  if (i0 < n) x[i0] = ex;
+  if (i1 < n) x[i1] = ex + a0;
+  __syncthreads();
+  return tot;
+}
+
+// flagged items of [0, n) -> order[0 .. count), ascending; returns count.  pred(v) evaluated by thread v % SM_THREADS.
+template <typename P>
+__device__ __forceinline__ int small_compact(int n, P pred, unsigned short* order, int* scan_w) {
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  int base = 0;
+  for (int v0 = 0; v0 < n; v0 += SM_THREADS) {
+    const int v = v0 + t;
+    const bool f = v < n && pred(v);
+    const unsigned long long m = __ballot(f);
+    if (lane == 0) scan_w[wv] = __popcll(m);
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int i = 0; i < SM_WAVES; ++i) {
+      const int s = scan_w[i];
+      if (i < wv) off += s;
+      tot += s;
+    }
+    if (f) order[base + off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)v;
+    base += tot;
+    __syncthreads();
+  }
+  return base;
+}
+
+__global__ __launch_bounds__(SM_THREADS) void ld_small_levels_kernel(SmallArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char small_smem[];
+  SmallLds& L = *reinterpret_cast<SmallLds*>(small_smem);
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int n_in = a.n;
+  int n = a.n;
+  const int* ix = a.indices;
+  const long long* wq = a.wq;
+  int dst = a.first_dst;
+  // ---- entry level into LDS
+  for (int v = t; v < n; v += SM_THREADS) {
+    L.ip[v] = (int)(a.indptr[v] - a.indptr[0]);
+    L.kk[v] = a.k[v];
+    L.comm[v] = a.comm[v];
+    L.tail_of[v] = (unsigned short)v;
+  }
+  if (t == 0) L.ip[n] = (int)(a.indptr[n] - a.indptr[0]);
+  ix += a.indptr[0];
+  wq += a.indptr[0];
+  for (int i = t; i < SM_WAVES * SMALL_N; i += SM_THREADS) (&L.acc[0][0])[i] = 0ull;
+  __syncthreads();
+  int levels = 0, tot_moves = 0, tot_merges = 0;
+  unsigned long long* acc = L.acc[wv];
+  unsigned short* touched = L.touched[wv];
+
+  // weight from row v towards each distinct group key(u) of its neighbours u (u != v, pass(u)): dense table + touched
+  // list of this wave; returns the number of distinct groups.  Entries of weight 0 carry nothing and are skipped (the
+  // first-touch test is `old sum == 0`).
+  auto gather_row = [&](int v, auto key, auto pass) -> int {
+    if (lane == 0) L.tcnt[wv] = 0;
+    const int beg = L.ip[v], end = L.ip[v + 1];
+    for (int e = beg + lane; e < end; e += 64) {
+      const int u = ix[e];
+      const long long w = wq[e];
+      if (u != v && w != 0 && pass(u)) {
+        const int c = key(u);
+        const unsigned long long old = atomicAdd(&acc[c], (unsigned long long)w);
+        if (old == 0ull) touched[atomicAdd(&L.tcnt[wv], 1)] = (unsigned short)c;
+      }
+    }
+    return __hip_atomic_load(&L.tcnt[wv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+
+  for (;;) {
+    ++levels;
+    // ================= local moving =================
+    for (int c = t; c < n; c += SM_THREADS) {
+      L.Ktot[c] = 0ull;
+      L.csize[c] = 0;
+      L.flag[c] = 1;
+    }
+    __syncthreads();
+    for (int v = t; v < n; v += SM_THREADS) {
+      atomicAdd(&L.Ktot[L.comm[v]], (unsigned long long)L.kk[v]);
+      atomicAdd(&L.csize[L.comm[v]], 1);
+    }
+    __syncthreads();
+    int moved_prev2 = 0, quiet = 0;
+    for (int sweep = 0; sweep < MAX_LM_SWEEPS; ++sweep) {
+      const int n_act = small_compact(n, [&](int v) { return L.flag[v] != 0; }, L.order, L.scan_w);
+      if (n_act == 0) break;
+      if (t == 0) L.s_moved = 0;
+      int m = 1;
+      while (m < n_act) m <<= 1;
+      const unsigned int hs = hash32(a.seed + 0x85EBCA77u * (unsigned int)(sweep + 1) + 0xC2B2AE3Du * (unsigned int)a.iter +
+                                     0x27D4EB2Fu * (unsigned int)levels);
+      const unsigned int pa = hs | 1u, pb = hs >> 11;
+      const int dir_round = sweep >= LM_DIR_AFTER ? sweep : -1;
+      __syncthreads();
+      for (int r0 = 0; r0 < m; r0 += SM_WAVES) {
+        const int pos = (int)(((unsigned int)(r0 + wv) * pa + pb) & (unsigned int)(m - 1));
+        const int v = pos < n_act ? (int)L.order[pos] : -1;
+        int decision = -1;
+        if (v >= 0) {
+          const int ca = L.comm[v];
+          const long long kq = L.kk[v];
+          const double kv = (double)kq;
+          const double Ka_wo = (double)(long long)(L.Ktot[ca] - (unsigned long long)kq);
+          const int tc = gather_row(v, [&](int u) { return L.comm[u]; }, [&](int) { return true; });
+          Cand best;
+          best.val = 0.0;
+          best.c = -1;
+          best.pr = 0;
+          long long w_own = 0;
+          for (int i = lane; i < tc; i += 64) {
+            const int c = touched[i];
+            const long long sum = (long long)acc[c];
+            acc[c] = 0ull;
+            if (c == ca) {
+              w_own = sum;
+            } else {
+              Cand x;
+              x.val = (double)sum - a.gg * kv * (double)(long long)L.Ktot[c];
+              x.c = c;
+              x.pr = prio(c, a.seed);
+              if (cand_better(x, best)) best = x;
+            }
+          }
+          best = wave_best(best);
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) w_own = max(w_own, __shfl_xor(w_own, o));
+          const double stay = (double)w_own - a.gg * kv * Ka_wo;
+          if (best.c >= 0 && best.val > stay) {
+            bool allowed = true;
+            if (dir_round >= 0) {
+              const unsigned int p0 = prio(ca, a.seed), p1 = best.pr;
+              allowed = (dir_round & 1) ? (p1 > p0 || (p1 == p0 && best.c > ca)) : (p1 < p0 || (p1 == p0 && best.c < ca));
+            }
+            decision = allowed ? best.c : -2;
+          } else if (stay < 0.0 && Ka_wo > 0.0 && L.csize[v] == 0) {
+            decision = v;  // an empty community (its id = the node's own id) beats staying
+          }
+        }
+        if (lane == 0) {
+          L.dec[wv] = decision;
+          if (v >= 0) L.flag[v] = 0;  // (cleared BEFORE the barrier: flags set by this round's movers must survive)
+        }
+        __syncthreads();
+        if (v >= 0) {
+          const int d = L.dec[wv];
+          if (d == -2 && lane == 0) L.flag[v] = 1;  // blocked by the direction rule: stays active
+          if (d >= 0) {
+            if (lane == 0) {
+              const int ca = L.comm[v];
+              const unsigned long long kq = (unsigned long long)L.kk[v];
+              L.comm[v] = d;
+              atomicAdd(&L.Ktot[d], kq);
+              atomicAdd(&L.Ktot[ca], 0ull - kq);
+              atomicAdd(&L.csize[d], 1);
+              atomicSub(&L.csize[ca], 1);
+              atomicAdd(&L.s_moved, 1);
+            }
+            for (int e = L.ip[v] + lane; e < L.ip[v + 1]; e += 64) L.flag[ix[e]] = 1;
+          }
+        }
+        __syncthreads();
+      }
+      const int moved = L.s_moved;
+      tot_moves += moved;
+      __syncthreads();
+      if (moved == 0 && dir_round < 0) break;
+      quiet = moved == 0 ? quiet + 1 : 0;
+      if (quiet >= 2) break;
+      if (a.iter == 0 && sweep >= 1) {
+        if ((long long)moved * 1000 < (long long)n * a.lm_stop_permille) break;
+        if (sweep >= 2 && (long long)moved * 10 > (long long)moved_prev2 * 9) break;
+      }
+      moved_prev2 = moved;
+    }
+    __syncthreads();
+    // ================= refinement =================
+    for (int v0 = 0; v0 < n; v0 += SM_WAVES) {  // a_in[v] = w(v, C(v) - v)
+      const int v = v0 + wv;
+      if (v < n) {
+        const int ca = L.comm[v];
+        long long s = 0;
+        for (int e = L.ip[v] + lane; e < L.ip[v + 1]; e += 64) {
+          const int u = ix[e];
+          if (u != v && L.comm[u] == ca) s += wq[e];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) {
+          L.u.rf.a_in[v] = s;
+          L.ref[v] = v;
+          L.refsize[v] = 1;
+          L.u.rf.Kref[v] = (unsigned long long)L.kk[v];
+          L.u.rf.Eref[v] = (unsigned long long)s;
+          L.u.rf.stamp[v] = -1;
+        }
+      }
+    }
+    if (t == 0) L.s_merged = 0;
+    __syncthreads();
+    const unsigned int rseed = a.seed + 0x9E3779B9u * (unsigned int)a.iter;
+    const int n_cand = small_compact(n, [&](int v) {
+      const double kv = (double)L.kk[v];
+      const double KC = (double)(long long)L.Ktot[L.comm[v]];
+      return (double)L.u.rf.a_in[v] >= a.gg * kv * (KC - kv);
+    }, L.order, L.scan_w);
+    if (n_cand > 0) {
+      int m = 1;
+      while (m < n_cand) m <<= 1;
+      const unsigned int hs = hash32(rseed ^ (0x5bd1e995u + 0x27D4EB2Fu * (unsigned int)levels));
+      const unsigned int pa = hs | 1u, pb = hs >> 11;
+      int round = 0;
+      for (int r0 = 0; r0 < m; r0 += SM_WAVES, ++round) {
+        const int pos = (int)(((unsigned int)(r0 + wv) * pa + pb) & (unsigned int)(m - 1));
+        int v = pos < n_cand ? (int)L.order[pos] : -1;
+        if (v >= 0 && (L.refsize[v] != 1 || L.ref[v] != v)) v = -1;  // somebody joined it: no longer a singleton
+        if (lane == 0) L.rset[wv] = v;
+        __syncthreads();
+        int tgt = -1;
+        if (v >= 0) {
+          const int ca = L.comm[v];
+          const double kv = (double)L.kk[v];
+          const double KC = (double)(long long)L.Ktot[ca];
+          const int tc = gather_row(v, [&](int u) { return L.ref[u]; }, [&](int u) { return L.comm[u] == ca; });
+          Cand best;
+          best.val = 0.0;
+          best.c = -1;
+          best.pr = 0;
+          for (int i = lane; i < tc; i += 64) {
+            const int c = touched[i];
+            const long long sum = (long long)acc[c];
+            acc[c] = 0ull;
+            if (c == v) continue;
+            const double Kr = (double)(long long)L.u.rf.Kref[c];
+            bool ok = (double)(long long)L.u.rf.Eref[c] >= a.gg * Kr * (KC - Kr);  // target well connected
+            if (ok && L.refsize[c] == 1) {  // a singleton that proposes in this very round may leave: not a target
+#pragma unroll
+              for (int j = 0; j < SM_WAVES; ++j) ok = ok && L.rset[j] != c;
+            }
+            const double gain = (double)sum - a.gg * kv * Kr;
+            if (ok && gain >= 0.0) {
+              Cand x;
+              x.val = a.inv_beta > 0.0 ? gain * a.inv_beta + refine_noise(v, c, round, rseed) : gain;
+              x.c = c;
+              x.pr = prio(c, rseed);
+              if (cand_better(x, best)) best = x;
+            }
+          }
+          best = wave_best(best);
+          tgt = best.c;
+          if (a.inv_beta > 0.0 && tgt >= 0 && !(best.val > refine_noise(v, v, round, rseed))) tgt = -1;  // "stay" drawn
+        }
+        __syncthreads();  // every proposal of the round is made before any is applied
+        if (v >= 0 && tgt >= 0 && lane == 0) {
+          L.ref[v] = tgt;
+          atomicAdd(&L.refsize[tgt], 1);
+          atomicAdd(&L.u.rf.Kref[tgt], (unsigned long long)L.kk[v]);
+          L.refsize[v] = 0;
+          L.u.rf.Kref[v] = 0ull;
+          L.u.rf.Eref[v] = 0ull;
+          L.u.rf.stamp[v] = round;
+          atomicAdd(&L.s_merged, 1);
+        }
+        __syncthreads();
+        if (v >= 0 && tgt >= 0) {  // exact update of w(t, C - t): see ld_refine_cut_update_kernel
+          const int ca = L.comm[v];
+          long long s = 0;
+          for (int e = L.ip[v] + lane; e < L.ip[v + 1]; e += 64) {
+            const int u = ix[e];
+            if (u != v && L.comm[u] == ca && L.ref[u] == tgt) s += (L.u.rf.stamp[u] == round) ? wq[e] : 2 * wq[e];
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+          if (lane == 0) atomicAdd(&L.u.rf.Eref[tgt], (unsigned long long)(L.u.rf.a_in[v] - s));
+        }
+        __syncthreads();
+      }
+    }
+    __syncthreads();
+    const int merged = L.s_merged;
+    tot_merges += merged;
+    if (merged == 0) break;
+    // ================= aggregation =================
+    __syncthreads();
+    for (int r = t; r < n; r += SM_THREADS) L.u.ag.rowptr[r] = L.refsize[r] > 0 ? 1 : 0;  // (rowptr as scratch: new ids)
+    __syncthreads();
+    const int nn = small_scan(L.u.ag.rowptr, n, L.scan_w);
+    if (nn == n) break;
+    for (int v = t; v < n; v += SM_THREADS) L.u.ag.rep[v] = 0x7fffffff;
+    __syncthreads();
+    for (int v = t; v < n; v += SM_THREADS) {
+      const int c = L.u.ag.rowptr[L.ref[v]];
+      L.u.ag.cid[v] = c;
+      atomicMin(&L.u.ag.rep[L.comm[v]], c);
+    }
+    __syncthreads();
+    for (int r = t; r < n; r += SM_THREADS)
+      if (L.refsize[r] > 0) L.u.ag.moff[L.u.ag.rowptr[r]] = L.refsize[r];  // member counts per coarse node
+    for (int v = t; v < n; v += SM_THREADS) L.csize[L.u.ag.cid[v]] = L.u.ag.rep[L.comm[v]];  // partition of the coarse nodes
+    for (int i = t; i < n_in; i += SM_THREADS) L.tail_of[i] = (unsigned short)L.u.ag.cid[L.tail_of[i]];
+    __syncthreads();
+    small_scan(L.u.ag.moff, nn, L.scan_w);
+    if (t == 0) L.u.ag.moff[nn] = n;
+    __syncthreads();
+    // members of every coarse node in ascending node order: every node counts the members of its coarse node that
+    // precede it (n <= 1024: ~1000 LDS reads per thread) -- an atomic cursor would make the order run dependent
+    for (int v = t; v < n; v += SM_THREADS) {
+      const int c = L.u.ag.cid[v];
+      int before = 0;
+      for (int u = 0; u < v; ++u) before += L.u.ag.cid[u] == c ? 1 : 0;
+      L.u.ag.members[L.u.ag.moff[c] + before] = v;
+    }
+    __syncthreads();
+    int* nix = a.ix[dst];
+    long long* nw = a.w[dst];
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int c0 = 0; c0 < nn; c0 += SM_WAVES) {
+        const int c = c0 + wv;
+        if (c < nn) {
+          if (lane == 0) L.tcnt[wv] = 0;
+          for (int mi = L.u.ag.moff[c]; mi < L.u.ag.moff[c + 1]; ++mi) {
+            const int v = L.u.ag.members[mi];
+            for (int e = L.ip[v] + lane; e < L.ip[v + 1]; e += 64) {
+              const long long w = wq[e];
+              if (w != 0) {
+                const int key = L.u.ag.cid[ix[e]];
+                const unsigned long long old = atomicAdd(&acc[key], (unsigned long long)w);
+                if (old == 0ull) touched[atomicAdd(&L.tcnt[wv], 1)] = (unsigned short)key;
+              }
+            }
+          }
+          const int tc = __hip_atomic_load(&L.tcnt[wv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          long long ksum = 0;
+          const int p0 = pass ? L.u.ag.rowptr[c] : 0;
+          for (int i = lane; i < tc; i += 64) {
+            const int col = touched[i];
+            const unsigned long long s = acc[col];
+            acc[col] = 0ull;
+            if (pass) {
+              nix[p0 + i] = col;
+              nw[p0 + i] = (long long)s;
+              ksum += (long long)s;
+            }
+          }
+          if (pass) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ksum += __shfl_xor(ksum, o);
+            if (lane == 0) L.kk[c] = ksum;   // (kk of the OLD level is dead: nothing reads it during aggregation)
+          } else if (lane == 0) {
+            L.u.ag.rep[c] = tc;  // (rep is dead after the partition of the coarse nodes was written)
+          }
+        }
+      }
+      __syncthreads();
+      if (pass == 0) {
+        for (int c = t; c < nn; c += SM_THREADS) L.u.ag.rowptr[c] = L.u.ag.rep[c];
+        __syncthreads();
+        const int nnz_new = small_scan(L.u.ag.rowptr, nn, L.scan_w);
+        if (t == 0) L.u.ag.rowptr[nn] = nnz_new;
+        __syncthreads();
+      }
+    }
+    // switch to the coarse level
+    for (int c = t; c <= nn; c += SM_THREADS) L.ip[c] = L.u.ag.rowptr[c];
+    for (int c = t; c < nn; c += SM_THREADS) L.comm[c] = L.csize[c];
+    __threadfence();  // the rows just written are read through the vector cache from now on
+    __syncthreads();
+    ix = nix;
+    wq = nw;
+    dst ^= 1;
+    n = nn;
+  }
+  __syncthreads();
+  for (int i = t; i < n_in; i += SM_THREADS) a.comm[i] = L.comm[L.tail_of[i]];
+  if (t == 0) {
+    a.info[0] = levels;
+    a.info[1] = tot_moves;
+    a.info[2] = tot_merges;
+    a.info[3] = n;
+  }
+}
+
 // ---- quality ---------------------------------------------------------------------------------------
 // internal[0] += sum over stored entries inside a community (self loops included)
 // G lanes per vertex (16 on the kNN graph itself: four rows in flight per wave instead of one)
@@ -1595,6 +2069,7 @@ struct LeidenCtx {
   int lm_stop_permille = 20;  // local moving of a level stops once < 2 % of its vertices move in a sweep
   int lm_classes = 0;         // class sub-rounds per local-moving sweep (0 = by level size; SCAMD_LEIDEN_LM_CLASSES)
   int rf_classes = 0;         // class sub-rounds of the refinement (0 = by level size; SCAMD_LEIDEN_RF_CLASSES)
+  bool small_levels = true;   // levels of <= SMALL_N nodes in one workgroup (SCAMD_LEIDEN_SMALL=0: separate kernels)
   // coarse-row build tiers (distinct-neighbour bounds); the env overrides exist so the tests can push small graphs
   // through the workgroup and multi-pass tiers
   int agg_wave_max = WH_MAX_DEG;
@@ -1978,6 +2453,39 @@ static double dbg_now(LeidenCtx& cx) {  // debug trace only: drains the stream, 
   return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
+// all remaining levels in one workgroup (ld_small_levels_kernel); b.comm[i] = final community of entry node i
+static int small_levels(LeidenCtx& cx, const LevelGraph& g, int level) {
+  LeidenBuffers& b = cx.b;
+  SmallArgs a;
+  a.indptr = g.indptr;
+  a.indices = g.indices;
+  a.wq = g.wq;
+  a.k = g.k;
+  a.n = g.n;
+  for (int i = 0; i < 2; ++i) {
+    a.ix[i] = b.cb[i].indices;
+    a.w[i] = b.cb[i].wq;
+  }
+  a.first_dst = level & 1;  // level L >= 1 lives in cb[(L - 1) & 1]
+  a.comm = b.comm;
+  a.gg = cx.gamma / cx.m2;
+  a.inv_beta = cx.inv_beta;
+  a.seed = cx.seed;
+  a.iter = cx.iter;
+  a.lm_stop_permille = cx.lm_stop_permille;
+  a.info = b.counters + 12;
+  hipLaunchKernelGGL(ld_small_levels_kernel, dim3(1), dim3(SM_THREADS), sizeof(SmallLds), cx.s, a);
+  SCAMD_LAUNCH_CHECK();
+  if (leiden_debug()) {
+    int h[4];
+    SCAMD_HIP_CHECK(hipMemcpyAsync(h, b.counters + 12, sizeof(h), hipMemcpyDeviceToHost, cx.s));
+    SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+    fprintf(stderr, "[leiden] small levels from level %d (n=%d nnz=%lld): %d levels, %d moves, %d merges -> n=%d\n", level, g.n,
+            (long long)g.nnz, h[0], h[1], h[2], h[3]);
+  }
+  return SCAMD_OK;
+}
+
 static int leiden_iteration(LeidenCtx& cx, const LevelGraph& g0) {
   LeidenBuffers& b = cx.b;
   SCAMD_HIP_CHECK(hipMemcpyAsync(b.comm, b.memb, sizeof(int) * g0.n, hipMemcpyDeviceToDevice, cx.s));
@@ -1988,6 +2496,12 @@ static int leiden_iteration(LeidenCtx& cx, const LevelGraph& g0) {
     int moves = 0;
     const bool dbg = leiden_debug();
     const double t0 = dbg ? dbg_now(cx) : 0.0;
+    if (cx.small_levels && g.n <= SMALL_N && g.nnz <= SMALL_NNZ) {
+      const int rcs = small_levels(cx, g, level);
+      if (rcs != SCAMD_OK) return rcs;
+      if (dbg) fprintf(stderr, "[leiden] small levels %.2f ms\n", dbg_now(cx) - t0);
+      break;
+    }
     int rc = local_moving(cx, g, &moves);
     if (rc != SCAMD_OK) return rc;
     const double t1 = dbg ? dbg_now(cx) : 0.0;
@@ -2113,6 +2627,7 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
   };
   cx.lm_classes = classes_env("SCAMD_LEIDEN_LM_CLASSES");
   cx.rf_classes = classes_env("SCAMD_LEIDEN_RF_CLASSES");
+  if (const char* e = getenv("SCAMD_LEIDEN_SMALL")) cx.small_levels = e[0] != '0';
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_WAVE_MAX")) cx.agg_wave_max = std::min(atoi(e), (int)WH_MAX_DEG);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_MAX")) cx.agg_mid_max = std::min(atoi(e), (int)AGG_MID_MAX);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_PASS_KEYS"))
@@ -2125,6 +2640,8 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)HUB_LDS));
   SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ld_refine_propose_hub_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)HUB_LDS));
+  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ld_small_levels_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmallLds)));
   LevelGraph g0;
   int rc = setup_level0(cx, indptr, indices, weights, n, nnz, &g0);
   if (rc != SCAMD_OK) return rc;
