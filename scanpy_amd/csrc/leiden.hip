@@ -91,17 +91,28 @@ __global__ __launch_bounds__(256) void ld_sum_kernel(const long long* __restrict
 // row-length statistics of a level: out[0] = longest row, out[1 .. 3] = rows longer than 96 / 192 / 384 entries (the
 // bounds of the quarter- / half- / full-wave tables: levels without such rows skip the overflow / hub launches, the
 // others size those grids by the counts)
-__global__ void ld_degstats_kernel(const int64_t* __restrict__ indptr, int n, int* __restrict__ out) {
+__global__ __launch_bounds__(1024) void ld_degstats_kernel(const int64_t* __restrict__ indptr, int n, int* __restrict__ out) {
+  // (one set of atomics per 1024-row block: a million rows through four same-address atomics per WAVE took 0.3 ms)
+  __shared__ int sh[4];
+  if (threadIdx.x < 4) sh[threadIdx.x] = 0;
+  __syncthreads();
   int v = blockIdx.x * blockDim.x + threadIdx.x;
   int d = (v < n) ? (int)(indptr[v + 1] - indptr[v]) : 0;
   const unsigned long long m1 = __ballot(d > 96), m2 = __ballot(d > 192), m3 = __ballot(d > 384);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) d = max(d, __shfl_xor(d, o));
   if ((threadIdx.x & 63) == 0 && d > 0) {
-    atomicMax(out, d);
-    if (m1) atomicAdd(out + 1, __popcll(m1));
-    if (m2) atomicAdd(out + 2, __popcll(m2));
-    if (m3) atomicAdd(out + 3, __popcll(m3));
+    atomicMax(&sh[0], d);
+    if (m1) atomicAdd(&sh[1], __popcll(m1));
+    if (m2) atomicAdd(&sh[2], __popcll(m2));
+    if (m3) atomicAdd(&sh[3], __popcll(m3));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && sh[0] > 0) {
+    atomicMax(out, sh[0]);
+    if (sh[1]) atomicAdd(out + 1, sh[1]);
+    if (sh[2]) atomicAdd(out + 2, sh[2]);
+    if (sh[3]) atomicAdd(out + 3, sh[3]);
   }
 }
 
@@ -576,13 +587,10 @@ __global__ __launch_bounds__(256) void ld_move_hub_kernel(
   }
 }
 
-// One thread per active vertex: apply the decided moves in place (integer atomics on the community totals) and
-// flag every vertex that has to be looked at again (the mover, its neighbours, the blocked ones).
-// counters: [0] moved, [1] blocked
+// One thread per active vertex: apply the decided moves in place (integer atomics on the community totals); vertices
+// blocked by the direction rule stay active.  counters: [0] moved, [1] blocked
 __global__ __launch_bounds__(256) void ld_apply_kernel(int n_act, const int* __restrict__ list,
-                                                       const int* __restrict__ decision,
-                                                       const int64_t* __restrict__ indptr,
-                                                       const int* __restrict__ indices, const long long* __restrict__ k,
+                                                       const int* __restrict__ decision, const long long* __restrict__ k,
                                                        int* __restrict__ comm, unsigned long long* __restrict__ Ktot,
                                                        int* __restrict__ csize, int* __restrict__ flag,
                                                        int* __restrict__ counters) {
@@ -593,34 +601,54 @@ __global__ __launch_bounds__(256) void ld_apply_kernel(int n_act, const int* __r
   }
   __syncthreads();
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  int64_t beg = 0, end = 0;
-  bool mover = false;
   if (w < n_act) {
     const int d = decision[w];
-    if (d != -1) {
+    if (d >= 0) {
       const int v = list[w];
-      flag[v] = 1;
-      if (d >= 0) {
-        mover = true;
-        beg = indptr[v];
-        end = indptr[v + 1];
-        const int a = comm[v];
-        comm[v] = d;
-        const unsigned long long kq = (unsigned long long)k[v];
-        atomicAdd(&Ktot[d], kq);
-        atomicAdd(&Ktot[a], 0ull - kq);
-        atomicAdd(&csize[d], 1);
-        atomicSub(&csize[a], 1);
-        atomicAdd(&s_moved, 1);
-      } else {
-        atomicAdd(&s_blocked, 1);
-      }
+      const int a = comm[v];
+      comm[v] = d;
+      const unsigned long long kq = (unsigned long long)k[v];
+      atomicAdd(&Ktot[d], kq);
+      atomicAdd(&Ktot[a], 0ull - kq);
+      atomicAdd(&csize[d], 1);
+      atomicSub(&csize[a], 1);
+      atomicAdd(&s_moved, 1);
+    } else if (d == -2) {
+      flag[list[w]] = 1;
+      atomicAdd(&s_blocked, 1);
     }
   }
-  // the movers' neighbours are flagged by the whole wave, two movers at a time (32 lanes each, coalesced row reads): a
-  // thread per mover walked its row entry by entry, one load in flight, every lane on a different cache line
-  unsigned long long m = __ballot(mover);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_moved) atomicAdd(&counters[0], s_moved);
+    if (s_blocked) atomicAdd(&counters[1], s_blocked);
+  }
+}
+
+// After ALL moves of the sub-round are applied: every mover re-activates its neighbours that are NOT in its new
+// community (the queue rule of the sequential algorithm, leidenalg `move_nodes`: a neighbour inside the new community can
+// only have become more attached).  A separate launch, because the test reads the neighbours' communities and those
+// must be the sub-round's final ones for the flags to be reproducible.  Round 2 flagged every neighbour: after the first
+// sweep of a level most of the active list was vertices deep inside their community.
+// The rows are walked by the whole wave, two movers at a time (32 lanes each, coalesced row reads).
+__global__ __launch_bounds__(256) void ld_requeue_kernel(int n_act, const int* __restrict__ list,
+                                                         const int* __restrict__ decision,
+                                                         const int64_t* __restrict__ indptr,
+                                                         const int* __restrict__ indices, const int* __restrict__ comm,
+                                                         int* __restrict__ flag) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int64_t beg = 0, end = 0;
+  int d = -1;
+  if (w < n_act) {
+    d = decision[w];
+    if (d >= 0) {
+      const int v = list[w];
+      beg = indptr[v];
+      end = indptr[v + 1];
+    }
+  }
+  unsigned long long m = __ballot(d >= 0);
   while (m) {
     const int b0 = __ffsll((long long)m) - 1;
     m &= m - 1;
@@ -630,15 +658,14 @@ __global__ __launch_bounds__(256) void ld_apply_kernel(int n_act, const int* __r
       m &= m - 1;
     }
     const int src = lane < 32 ? b0 : b1;
-    // (both shuffles run with every lane active: a bpermute under a partial exec mask reads 0 from disabled lanes)
+    // (all shuffles run with every lane active: a bpermute under a partial exec mask reads 0 from disabled lanes)
     const int64_t rb = __shfl(beg, src), re_s = __shfl(end, src);
+    const int dd = __shfl(d, src);
     const int64_t re = (lane >= 32 && b1 == b0) ? rb : re_s;
-    for (int64_t e = rb + (lane & 31); e < re; e += 32) flag[indices[e]] = 1;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    if (s_moved) atomicAdd(&counters[0], s_moved);
-    if (s_blocked) atomicAdd(&counters[1], s_blocked);
+    for (int64_t e = rb + (lane & 31); e < re; e += 32) {
+      const int u = indices[e];
+      if (comm[u] != dd) flag[u] = 1;
+    }
   }
 }
 
@@ -1613,7 +1640,14 @@ __global__ __launch_bounds__(SM_THREADS) void ld_small_levels_kernel(SmallArgs a
               atomicSub(&L.csize[ca], 1);
               atomicAdd(&L.s_moved, 1);
             }
-            for (int e = L.ip[v] + lane; e < L.ip[v + 1]; e += 64) L.flag[ix[e]] = 1;
+          }
+        }
+        __syncthreads();
+        if (v >= 0 && L.dec[wv] >= 0) {  // after every move of the round: re-activate the neighbours outside the new community
+          const int d = L.dec[wv];
+          for (int e = L.ip[v] + lane; e < L.ip[v + 1]; e += 64) {
+            const int u = ix[e];
+            if (L.comm[u] != d) L.flag[u] = 1;
           }
         }
         __syncthreads();
@@ -1868,7 +1902,14 @@ __global__ __launch_bounds__(256) void ld_internal_kernel(int n, const int64_t* 
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if (lane == 0 && s != 0) atomicAdd(internal, (unsigned long long)s);
+  // (one global atomic per workgroup: the per-wave version serialised 8192 atomics on one address, 0.2 ms)
+  __shared__ long long sh_s[4];
+  if (lane == 0) sh_s[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const long long tot = sh_s[0] + sh_s[1] + sh_s[2] + sh_s[3];
+    if (tot != 0) atomicAdd(internal, (unsigned long long)tot);
+  }
 }
 
 // sumsq[0] = sum_c (Ktot[c] / 2m)^2 in a fixed order: SUMSQ_BLOCKS partial sums (fixed ranges, fixed tree), then one
@@ -2254,8 +2295,10 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
                            b.target, b.counters + 7);
         SCAMD_LAUNCH_CHECK();
       }
-      hipLaunchKernelGGL(ld_apply_kernel, GRID1(cnt), 0, cx.s, cnt, list, b.target, g.indptr, g.indices, g.k, b.comm,
-                         b.Ktot, b.csize, b.flag, b.counters);
+      hipLaunchKernelGGL(ld_apply_kernel, GRID1(cnt), 0, cx.s, cnt, list, b.target, g.k, b.comm, b.Ktot, b.csize, b.flag,
+                         b.counters);
+      SCAMD_LAUNCH_CHECK();
+      hipLaunchKernelGGL(ld_requeue_kernel, GRID1(cnt), 0, cx.s, cnt, list, b.target, g.indptr, g.indices, b.comm, b.flag);
       SCAMD_LAUNCH_CHECK();
     }
   }
@@ -2398,6 +2441,9 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   int htier[2] = {0, 0};
   SCAMD_HIP_CHECK(hipMemcpyAsync(htier, b.counters + 4, sizeof(int) * 2, hipMemcpyDeviceToHost, cx.s));
   SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  if (leiden_debug() && (htier[0] || htier[1]))
+    fprintf(stderr, "[leiden] aggregate n=%d -> %d: %d rows through the workgroup tier, %d through the 8192-slot tier\n", g.n, inn,
+            htier[0], htier[1]);
   if (htier[0] > 0) {
     hipLaunchKernelGGL((ld_agg_block_kernel<AGG_MID_SLOTS, 512>), dim3((unsigned)std::min(768, htier[0])), dim3(512),
                        (size_t)AGG_MID_SLOTS * 12, cx.s, b.mid_list, b.counters + 4, inn, b.moff, b.eoff, b.members, g.indptr,
@@ -2423,7 +2469,7 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   int agg_err = 0;
   SCAMD_HIP_CHECK(hipMemcpyAsync(&agg_err, b.counters + 7, sizeof(int), hipMemcpyDeviceToHost, cx.s));
   SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 8, 0, sizeof(int) * 4, cx.s));
-  hipLaunchKernelGGL(ld_degstats_kernel, GRID1(nn), 0, cx.s, cb.indptr, (int)nn, b.counters + 8);
+  hipLaunchKernelGGL(ld_degstats_kernel, GRIDK(nn), 0, cx.s, cb.indptr, (int)nn, b.counters + 8);
   SCAMD_LAUNCH_CHECK();
   SCAMD_HIP_CHECK(hipMemcpyAsync(dstat, b.counters + 8, sizeof(int) * 4, hipMemcpyDeviceToHost, cx.s));
   SCAMD_HIP_CHECK(hipMemcpyAsync(&nnz_new, cb.indptr + nn, sizeof(int64_t), hipMemcpyDeviceToHost, cx.s));
@@ -2568,7 +2614,7 @@ static int setup_level0(LeidenCtx& cx, const int64_t* indptr, const int32_t* ind
   hipLaunchKernelGGL(ld_sum_kernel, dim3(256), dim3(256), 0, cx.s, b.k0, (int)n, b.total);
   SCAMD_LAUNCH_CHECK();
   SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 8, 0, sizeof(int) * 4, cx.s));
-  hipLaunchKernelGGL(ld_degstats_kernel, GRID1(n), 0, cx.s, indptr, (int)n, b.counters + 8);
+  hipLaunchKernelGGL(ld_degstats_kernel, GRIDK(n), 0, cx.s, indptr, (int)n, b.counters + 8);
   SCAMD_LAUNCH_CHECK();
   unsigned long long tot = 0;
   int dstat[4] = {0, 0, 0, 0};

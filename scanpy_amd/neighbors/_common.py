@@ -51,8 +51,10 @@ def sparse_distances_from_device(idx, dist) -> sparse.csr_matrix:
         raise AssertionError(msg)
     nnz = n * (k - 1)
     itype = torch.int32 if max(nnz, n) < 2**31 else torch.int64
-    indices = idx[:, 1:].to(itype).contiguous().reshape(-1).cpu().numpy()
-    data = dist[:, 1:].contiguous().reshape(-1).cpu().numpy()
+    from .._device import to_host
+
+    indices = to_host(idx[:, 1:].to(itype).contiguous().reshape(-1))
+    data = to_host(dist[:, 1:].contiguous().reshape(-1))
     indptr = np.arange(0, nnz + 1, k - 1, dtype=indices.dtype) if k > 1 else np.zeros(n + 1, dtype=indices.dtype)
     return csr_from_trusted_arrays(data, indices, indptr, (n, n))
 
@@ -62,8 +64,9 @@ def graph_from_device(indptr, indices, data, n_obs: int) -> sparse.csr_matrix:
     import torch
 
     itype = torch.int32 if max(int(indices.numel()), n_obs) < 2**31 else torch.int64
-    m = csr_from_trusted_arrays(data.cpu().numpy(), indices.to(itype).cpu().numpy(), indptr.to(itype).cpu().numpy(),
-                                (n_obs, n_obs))
+    from .._device import to_host
+
+    m = csr_from_trusted_arrays(to_host(data), to_host(indices.to(itype)), to_host(indptr.to(itype)), (n_obs, n_obs))
     # the C ABI promises sorted, duplicate-free rows (include/scanpy_amd.h): recording it saves scipy (and tl.leiden)
     # an O(nnz) check per use
     m.has_canonical_format = True

@@ -165,7 +165,9 @@ def pca(  # noqa: PLR0912, PLR0913, PLR0915
     else:
         res = pca_fit(backend.upload(as_csr_f32(x)), n_comps, backend=backend, zero_center=zero_center,
                       svd_solver=svd_solver, seed=seed)
-    x_pca = res.scores.cpu().numpy()
+    from .._device import to_host
+
+    x_pca = to_host(res.scores)
     in_dtype = x.dtype if np.issubdtype(x.dtype, np.floating) else np.dtype("float64")
     components = res.components.astype(in_dtype, copy=False)
     variance = res.explained_variance.astype(in_dtype, copy=False)

@@ -87,9 +87,12 @@ class GpuBackend:
     upload_copies = True  # `upload` returns once the host arrays have been copied: the caller may overwrite them
 
     def upload(self, x_csr):
+        from .._device import pinned_uploader
+
         ip = torch.from_numpy(np.ascontiguousarray(x_csr.indptr, dtype=np.int64)).to(self.device)
-        ix = torch.from_numpy(np.ascontiguousarray(x_csr.indices, dtype=np.int32)).to(self.device)
-        dv = torch.from_numpy(np.ascontiguousarray(x_csr.data, dtype=np.float32)).to(self.device)
+        # the two big arrays go through page-locked staging buffers at PCIe rate (see _device._PinnedUploader)
+        ix = pinned_uploader.upload(np.ascontiguousarray(x_csr.indices, dtype=np.int32), self.device)
+        dv = pinned_uploader.upload(np.ascontiguousarray(x_csr.data, dtype=np.float32), self.device)
         return (ip, ix, dv, x_csr.shape[0], x_csr.shape[1])
 
     def host_buffers(self, n: int, index_dtype, value_dtype):

@@ -80,9 +80,11 @@ def leiden_partition(adjacency, *, resolution=1.0, n_iterations=-1, seed=0, use_
         adj = adj.sorted_indices()
     n = adj.shape[0]
     indptr = torch.from_numpy(np.ascontiguousarray(adj.indptr, dtype=np.int64)).to(dev)
-    indices = torch.from_numpy(np.ascontiguousarray(adj.indices, dtype=np.int32)).to(dev)
+    from .._device import pinned_uploader
+
+    indices = pinned_uploader.upload(np.ascontiguousarray(adj.indices, dtype=np.int32), dev)
     w = adj.data if use_weights else np.ones_like(adj.data)
-    weights = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).to(dev)
+    weights = pinned_uploader.upload(np.ascontiguousarray(w, dtype=np.float32), dev)
     memb, q, _ = _kernels.leiden(indptr, indices, weights, n, resolution=float(resolution),
                                  n_iterations=int(n_iterations), beta=beta, seed=int(seed))
     return memb.cpu().numpy(), q
