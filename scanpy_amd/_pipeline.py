@@ -113,21 +113,6 @@ def _all_to_all_rows(send: torch.Tensor, send_counts: list[int], group) -> torch
     return out.to(dev) if staged else out
 
 
-def _send(t: torch.Tensor, dst: int, group) -> None:
-    import torch.distributed as dist
-
-    dist.send(t.cpu() if _staged(t, group) else t.contiguous(), dst=dst, group=group)
-
-
-def _recv(shape, dtype, dev, src: int, group) -> torch.Tensor:
-    import torch.distributed as dist
-
-    staged = dev.type == "cuda" and dist.get_backend(group) == "gloo"
-    buf = torch.empty(shape, dtype=dtype, device="cpu" if staged else dev)
-    dist.recv(buf, src=src, group=group)
-    return buf.to(dev) if staged else buf
-
-
 def fixed_point_distance_sum(dist32: torch.Tensor, n_elements_total: int, comm) -> torch.Tensor:
     """Sum of ALL ranks' distances as a float64 [1] device tensor, bit-identical to the single-device kernels
     (csrc/fuzzy.hip: fss_max_kernel / fss_sum_kernel / fss_sum_final_kernel) for any sharding: the distances are added as
@@ -175,31 +160,23 @@ def sharded_fuzzy_rows(idx: torch.Tensor, dist32: torch.Tensor, comm, counts: li
 
 
 def _gather_csr_rows_to_root(indptr, indices, data, comm, n_total: int):
-    """rank 0 receives every rank's CSR rows and stitches the n_total-row matrix together; the others return None"""
-    import torch.distributed as dist
-
+    """rank 0 receives every rank's CSR rows and stitches the n_total-row matrix together; the others return None.
+    Two collectives (row lengths; entries as (column, weight-bits) int32 pairs), each an all-to-all in which only
+    rank 0 receives -- RCCL runs the P - 1 transfers concurrently over the point-to-point xGMI links, where round 2's
+    loop of blocking send / recv pairs took them one after the other."""
     group = getattr(comm, "group", None)
-    dev = indices.device
-    staged = _staged(indices, group)
-    nnz = torch.tensor([int(indices.numel())], dtype=torch.int64, device="cpu" if staged else dev)
-    all_nnz = [torch.zeros_like(nnz) for _ in range(comm.world_size)]
-    dist.all_gather(all_nnz, nnz, group=group)
-    rowcnt = (indptr[1:] - indptr[:-1]).to(torch.int32)
+    world = comm.world_size
+    rowcnt = (indptr[1:] - indptr[:-1]).to(torch.int32).reshape(-1, 1).contiguous()
+    ent = torch.stack([indices.to(torch.int32), data.to(torch.float32).view(torch.int32)], dim=1).contiguous()
+    to_root = lambda m: [int(m)] + [0] * (world - 1)  # noqa: E731  (everything goes to rank 0)
+    rc = _all_to_all_rows(rowcnt, to_root(rowcnt.shape[0]), group)
+    en = _all_to_all_rows(ent, to_root(ent.shape[0]), group)
     if comm.rank != 0:
-        _send(rowcnt, 0, group)
-        _send(indices, 0, group)
-        _send(data, 0, group)
         return None, None, None
-    rc, ix, dv = [rowcnt], [indices], [data]
-    for r in range(1, comm.world_size):
-        lo, hi = shard_bounds(n_total, comm.world_size, r)
-        m = int(all_nnz[r].item())
-        rc.append(_recv((hi - lo,), torch.int32, dev, r, group))
-        ix.append(_recv((m,), torch.int32, dev, r, group))
-        dv.append(_recv((m,), torch.float32, dev, r, group))
-    ci = torch.zeros(n_total + 1, dtype=torch.int64, device=dev)
-    ci[1:] = torch.cumsum(torch.cat(rc).to(torch.int64), dim=0)
-    return ci, torch.cat(ix), torch.cat(dv)
+    # all_to_all output is ordered by source rank = by row block
+    ci = torch.zeros(n_total + 1, dtype=torch.int64, device=indices.device)
+    ci[1:] = torch.cumsum(rc[:, 0].to(torch.int64), dim=0)
+    return ci, en[:, 0].contiguous(), en[:, 1].contiguous().view(torch.float32)
 
 
 def shard_bounds(n_total: int, world_size: int, rank: int) -> tuple[int, int]:
