@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 static thread_local float g_last_select_ms = -1.f;
@@ -32,6 +33,8 @@ namespace scamd {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 
 constexpr int FALLBACK_CAP = 2048;    // collected rows per uncertified query
 constexpr int FALLBACK_CHUNK = 1024;  // uncertified queries processed per launch
@@ -357,22 +360,78 @@ constexpr float KEY_BIG = 3.0e38f;
 // float32 bit patterns -> integers whose signed order is the float order (scalar unit: gfx950 has no SALU float compare)
 __device__ __forceinline__ int key_order(int bits) { return bits ^ ((bits >> 31) & 0x7fffffff); }
 
-template <int H, int TC_ = 64>
+// B3 = the "3 x bf16" scoring engine (d <= 50 only).  The f32-input MFMA of gfx950 runs at the f32 VECTOR rate (157 TFLOP/s),
+// the bf16 one sixteen times faster.  A float32 coordinate is written as hi + lo with hi = bf16(x), lo = bf16(x - hi)
+// (residual <= 2^-18 |x|) and q.c ~ qh.ch + qh.cl + ql.ch: three bf16 products instead of one f32 product, 12
+// v_mfma_f32_32x32x16_bf16 (32 cycles each) per 32 x 32 sub-tile instead of 26 v_mfma_f32_32x32x2_f32 (64 cycles each):
+// 4.3x less matrix time for scores that are off by <= 3 * 2^-18 ||q|| ||c|| -- which the float64 certificate of pass 2
+// prices in (factor CERT_K_B3), so the result is the exact kNN as before.  Image row = 68 dwords: 64 bf16 hi | 64 bf16 lo
+// | ||c||^2 (f32, for the stop rule) | pad.  Dims 50..55 of the hi part carry the threshold subtraction and the norm:
+// candidate rows hold [1, 1, 1, n1, n2, n3] (||c||^2 = n1 + n2 + n3 exactly: three bf16 pieces hold 24 bits), the query
+// operand [-t1, -t2, -t3, 1, 1, 1] -- the accumulator comes out as score - threshold, with no extra instruction.
+template <int H, int TC_ = 64, bool B3 = false>
 struct RegCfg {
   static constexpr int HP = (H + 1 + 3) / 4 * 4;  // dims of one half + the extra k slot, rounded up to 4
-  static constexpr int DPL = (2 * HP) % 8 == 4 ? 2 * HP : 2 * HP + 4;
+  static constexpr int DPL = B3 ? 68 : ((2 * HP) % 8 == 4 ? 2 * HP : 2 * HP + 4);
   static constexpr int TC = TC_, SUBS = TC_ / 32, NW = 4, QB = 128, NT = 256, KP = 32;
   static constexpr int TILE_BYTES = TC * DPL * 4;
   static constexpr int TILE_KB = TILE_BYTES / 1024;
   static constexpr size_t LDS_BYTES = 2 * (size_t)TILE_BYTES;
   static_assert(TILE_BYTES % 1024 == 0, "tile must be a whole number of 1 KiB pieces");
+  static_assert(!B3 || H == 25, "the bf16 engine is built for d <= 50");
 };
+constexpr int B3_DPL = 68;
+constexpr double CERT_K_F32 = 138.0, CERT_K_B3 = 476.0;
+constexpr float B3_PAD_NORM = 1.0e38f;  // ||c||^2 of padding rows: finite (0 * inf = NaN in the cross products)
+
+// float32 -> bf16 bits, round to nearest even (finite inputs)
+__device__ __forceinline__ unsigned int bf16_rn(float v) {
+  const unsigned int b = __float_as_uint(v);
+  return (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_f32(unsigned int h) { return __uint_as_float(h << 16); }
+// three bf16 pieces (by truncation) whose sum is v exactly
+__device__ __forceinline__ void split3_bf16(float v, unsigned int& p1, unsigned int& p2, unsigned int& p3) {
+  const float a = __uint_as_float(__float_as_uint(v) & 0xffff0000u);
+  const float r1 = v - a;
+  const float b = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+  const float r2 = r1 - b;
+  p1 = __float_as_uint(a) >> 16;
+  p2 = __float_as_uint(b) >> 16;
+  p3 = __float_as_uint(r2) >> 16;
+}
+// dword c (0..67) of the bf16 image row of a point with centred coordinates vc(dim) and squared norm nf
+template <typename F>
+__device__ __forceinline__ unsigned int b3_row_dword(int c, int d, float nf, F vc) {
+  if (c >= 64) return c == 64 ? __float_as_uint(nf) : 0u;
+  const bool lo = c >= 32;
+  const int d0 = 2 * (c & 31);
+  unsigned int w[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int dim = d0 + t;
+    unsigned int v = 0u;
+    if (dim < 50) {
+      if (dim < d) {
+        const float x = vc(dim);
+        const unsigned int h = bf16_rn(x);
+        v = lo ? bf16_rn(x - bf16_f32(h)) : h;
+      }
+    } else if (dim < 56 && !lo) {
+      unsigned int n1, n2, n3;
+      split3_bf16(nf, n1, n2, n3);
+      v = dim < 53 ? 0x3F80u : (dim == 53 ? n1 : (dim == 54 ? n2 : n3));
+    }
+    w[t] = v;
+  }
+  return w[0] | (w[1] << 16);
+}
 
 // packed image of x for the register-list kernel: [n_pad][DPL] float32 (layout above); rows >= n get
 // ||c||^2 = +inf so that they can never be selected.
 __global__ void knn_pack_image_kernel(const float* __restrict__ x, const float* __restrict__ mu, int64_t n, int d,
                                       int64_t ld, int H, int HP, int DPL, int64_t n_pad, float* __restrict__ xp,
-                                      unsigned int* __restrict__ cmax_bits) {
+                                      unsigned int* __restrict__ cmax_bits, int b3) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -386,6 +445,14 @@ __global__ void knn_pack_image_kernel(const float* __restrict__ x, const float* 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     const float nf = (r < n) ? (float)s : INFINITY;
+    if (b3) {  // bf16 hi / lo image (RegCfg: B3)
+      const float nb = (r < n) ? nf : B3_PAD_NORM;
+      unsigned int* xu = reinterpret_cast<unsigned int*>(xp);
+      for (int c = lane; c < B3_DPL; c += 64)
+        xu[r * B3_DPL + c] = b3_row_dword(c, d, nb, [&](int dim) { return r < n ? __fsub_rn(x[r * ld + dim], mu[dim]) : 0.f; });
+      if (r < n) wmax = fmaxf(wmax, nf);
+      continue;
+    }
     for (int c = lane; c < DPL; c += 64) {
       const int hh = c / HP, cc = c - hh * HP;  // hh == 2: trailing pad
       float v = 0.f;
@@ -430,13 +497,22 @@ struct IvfArgs {
 };
 
 // TC_ = candidates per LDS tile, WPS = resident blocks per CU (= waves per SIMD) the register budget is cut for
-template <int H, int TC_, int WPS, bool IVF>
+template <int HP>
+struct BFragF32 {
+  float v[HP];
+};
+struct BFragBf16 {
+  i32x4 h[4], l[4];  // k-steps of 16 dims: 8 bf16 of the hi part / of the lo part per lane
+};
+
+template <int H, int TC_, int WPS, bool IVF, bool B3 = false>
 __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* __restrict__ xp, int n_tiles_all,
                                                                   int64_t n_pad, int64_t q_begin,
                                                                   int thr_rank, int* __restrict__ cand_idx,
                                                                   float* __restrict__ cand_tau, IvfArgs iv) {
-  using C = RegCfg<H, TC_>;
+  using C = RegCfg<H, TC_, B3>;
   constexpr int HP = C::HP, DPL = C::DPL, TC = C::TC, SUBS = C::SUBS;
+  using BFrag = std::conditional_t<B3, BFragBf16, BFragF32<HP>>;
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][TC][DPL] (+ IVF: wmax[4])
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -447,7 +523,9 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
   if constexpr (IVF) blk = iv.block_perm[blockIdx.x];
 
   // A operand: lane l holds query (l&31), dims [half*H, half*H+H), pre-scaled by -2
-  float aq[H];
+  // (B3: k-step s, lane half h: dims 16 s + 8 h .. + 8 as four bf16 pairs, hi part in qh, lo part in ql)
+  float aq[B3 ? 1 : H];
+  i32x4 qh[B3 ? 4 : 1], ql[B3 ? 4 : 1];
   int64_t qrow;          // image row of this lane's query
   bool qvalid = true;
   if constexpr (IVF) {
@@ -458,14 +536,48 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     qrow = q_begin + (int64_t)blk * C::QB + wave * 32 + l31;
     if (qrow > n_pad - 1) qrow = n_pad - 1;  // padded query slot: results are never read
   }
-  {
+  if constexpr (!B3) {
     const float* qp = xp + qrow * DPL + half * HP;
 #pragma unroll
     for (int s = 0; s < H; ++s) aq[s] = -2.0f * qp[s];
+  } else {
+    // -2 q as bf16 pairs (the scaling is exact); dims 50..55 of the query side are [-t1, -t2, -t3, 1, 1, 1]
+    const i32x4* qp = reinterpret_cast<const i32x4*>(xp + qrow * DPL);
+    auto neg2 = [](int w) {
+      const float a = -2.0f * __uint_as_float((unsigned int)w << 16), b = -2.0f * __uint_as_float((unsigned int)w & 0xffff0000u);
+      return (int)((__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u));
+    };
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const i32x4 h4 = qp[2 * s + half], l4 = qp[8 + 2 * s + half];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        qh[s][j] = neg2(h4[j]);
+        ql[s][j] = neg2(l4[j]);
+      }
+    }
+    if (half == 0) {
+      qh[3][1] = 0;                      // dims 50, 51: -t1, -t2 (threshold 0 until the lists are filled)
+      qh[3][2] = 0x3F800000;             // dims 52, 53: -t3, 1
+      qh[3][3] = 0x3F803F80;             // dims 54, 55: 1, 1
+    }
   }
+
   // A operand of the extra k-pair: lanes 0..31 hold -thr of query (l&31), lanes 32..63 hold 1.0.
   // Until the lists are filled (sub-tile 0) the "threshold" is 0, i.e. the accumulator is the plain score.
   float athr = half ? 1.0f : 0.0f;
+  // B3: the threshold lives in dims 50..52 of the query operand as three bf16 pieces (their sum is -thr exactly); `athr`
+  // stays the float32 master copy, this re-derives the pieces of all 32 queries of the wave after it changed
+  auto sync_thr = [&]() {
+    if constexpr (B3) {
+      unsigned int t1, t2, t3;
+      split3_bf16(athr, t1, t2, t3);
+      if (half == 0) {
+        qh[3][1] = (int)(t1 | (t2 << 16));
+        qh[3][2] = (int)(t3 | 0x3F800000u);
+      }
+    }
+  };
   float key[16];
   int idx[16];
   // empty list: KEY_BIG with ascending slot numbers (ascending keys along the lanes of each half)
@@ -483,17 +595,51 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
   bool minima = false;
   // B operand of sub-tile g of the current sweep: lane l holds candidate (l&31), the same dim slice as A, then
   // the extra k slot
-  auto load_b = [&](int g, float (&b)[HP]) {
+  auto load_b = [&](int g, BFrag& b) {
     const float* tb = smem + ((g / SUBS) & 1) * TC * DPL;
-    const float4* p = reinterpret_cast<const float4*>(tb + ((g % SUBS) * 32 + l31) * DPL + half * HP);
+    if constexpr (B3) {
+      // row = 17 16-byte units: hi part units 0..7, lo part 8..15 (row stride 68 dwords = 4 mod 64: conflict free)
+      const i32x4* p = reinterpret_cast<const i32x4*>(tb + ((g % SUBS) * 32 + l31) * DPL);
 #pragma unroll
-    for (int s4 = 0; s4 < HP / 4; ++s4) {
-      const float4 v = p[s4];
-      b[4 * s4 + 0] = v.x;
-      b[4 * s4 + 1] = v.y;
-      b[4 * s4 + 2] = v.z;
-      b[4 * s4 + 3] = v.w;
+      for (int s = 0; s < 4; ++s) {
+        b.h[s] = p[2 * s + half];
+        b.l[s] = p[8 + 2 * s + half];
+      }
+    } else {
+      const float4* p = reinterpret_cast<const float4*>(tb + ((g % SUBS) * 32 + l31) * DPL + half * HP);
+#pragma unroll
+      for (int s4 = 0; s4 < HP / 4; ++s4) {
+        const float4 v = p[s4];
+        b.v[4 * s4 + 0] = v.x;
+        b.v[4 * s4 + 1] = v.y;
+        b.v[4 * s4 + 2] = v.z;
+        b.v[4 * s4 + 3] = v.w;
+      }
     }
+  };
+  // scores of one sub-tile minus the thresholds (the MFMA chain)
+  auto chain = [&](const BFrag& b, float athr_op) -> f32x16 {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if constexpr (B3) {
+      (void)athr_op;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qh[s]), __builtin_bit_cast(bf16x8, b.h[s]), acc, 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qh[s]), __builtin_bit_cast(bf16x8, b.l[s]), acc, 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ql[s]), __builtin_bit_cast(bf16x8, b.h[s]), acc, 0, 0, 0);
+    } else {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[0], b.v[0], acc, 0, 0, 0);
+#pragma unroll
+      for (int s = 1; s < H; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s], b.v[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(athr_op, b.v[H], acc, 0, 0, 0);
+    }
+    return acc;
   };
   // Insert the survivors of a sub-tile.  acc[r] = score - (threshold its chain used); that threshold is lane
   // i(r,h) of `athr_used` (negated).  all = true (very first sub-tile): every finite score is inserted.
@@ -539,21 +685,16 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
         if (hi) insert_half(acc, athr_used, cbase, r, 1, hi);
       }
     }
+    sync_thr();
   };
   int row0 = 0;  // image row of the current sweep's first candidate
   // One pipeline step = ONE scheduling region: chain of sub-tile g into acc_cur (with the thresholds in athr),
   // fragment reads of sub-tile g+1, sign test of the previous sub-tile's accumulator.
-  auto step = [&](int g, float (&b_cur)[HP], f32x16& acc_cur, float& athr_cur, const f32x16& acc_prev,
-                  float athr_prev, float (&b_nxt)[HP]) {
+  auto step = [&](int g, BFrag& b_cur, f32x16& acc_cur, float& athr_cur, const f32x16& acc_prev,
+                  float athr_prev, BFrag& b_nxt) {
     load_b(min(g + 1, n_sub - 1), b_nxt);  // (the clamp re-reads the last sub-tile: no branch in the region)
-    f32x16 zero;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
     athr_cur = athr;
-    acc_cur = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[0], b_cur[0], zero, 0, 0, 0);
-#pragma unroll
-    for (int s = 1; s < H; ++s) acc_cur = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s], b_cur[s], acc_cur, 0, 0, 0);
-    acc_cur = __builtin_amdgcn_mfma_f32_32x32x2f32(athr_cur, b_cur[H], acc_cur, 0, 0, 0);
+    acc_cur = chain(b_cur, athr_cur);
     // sign test: OR of the 16 accumulators of the previous sub-tile (3-input ORs)
     const int o0 = __float_as_int(acc_prev[0]) | __float_as_int(acc_prev[1]) | __float_as_int(acc_prev[2]);
     const int o1 = __float_as_int(acc_prev[3]) | __float_as_int(acc_prev[4]) | __float_as_int(acc_prev[5]);
@@ -564,7 +705,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     const bool hit = __any(o5 < 0);
     // pin the interleave: 1 MFMA, then 1 LDS read + up to 2 VALU in its shadow
 #pragma unroll
-    for (int s = 0; s <= H; ++s) {
+    for (int s = 0; s < (B3 ? 12 : H + 1); ++s) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
@@ -609,20 +750,14 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     lstore(0);
     if (n_tiles > 1) gload(1);
     __syncthreads();
-    float bA[HP], bB[HP];
+    BFrag bA, bB;
     f32x16 accA, accB;
     float athrA = athr, athrB = athr;
     load_b(0, bA);
     if (!IVF && first) {
       // sub-tile 0: plain scores (threshold 0), every finite one is inserted; afterwards all thresholds are
       // finite whenever the sub-tile holds at least thr_rank real rows
-      f32x16 zero;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-      accB = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[0], bA[0], zero, 0, 0, 0);
-#pragma unroll
-      for (int s = 1; s < H; ++s) accB = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s], bA[s], accB, 0, 0, 0);
-      accB = __builtin_amdgcn_mfma_f32_32x32x2f32(athr, bA[H], accB, 0, 0, 0);
+      accB = chain(bA, athr);
       insert(accB, athr, row0, true);
       load_b(1 < n_sub ? 1 : 0, bB);  // sub-tile 0 is done: prefetch sub-tile 1
     }
@@ -677,7 +812,8 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     const int* order = iv.order + (int64_t)a * iv.n_cells;
     const float* lb2 = iv.order_lb2 + (int64_t)a * iv.n_cells;
     // exact threshold distance^2 of a query = thr (score space) + ||q||^2; per wave the max over its real queries
-    const float qn = xp[qrow * DPL + HP + H];  // ||q||^2 sits in the extra k slot of the row's second half
+    // ||q||^2 sits in the extra k slot of the row's second half (B3: in the row's tail)
+    const float qn = B3 ? xp[qrow * DPL + 64] : xp[qrow * DPL + HP + H];
     // ---- pre-pass: a tight starting threshold from the own cell ----
     // A streaming top-k list with threshold "current thr_rank-th best" inserts ~thr_rank*(1 + ln(N/thr_rank))
     // candidates per query, most of them while the list warms up; each insertion costs ~30 VALU on the lanes the
@@ -715,6 +851,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
         const int tb = __float_as_int(fminf(half ? t1 : t0, KEY_BIG));  // (never +inf: its mantissa holds the slot)
         key[r] = __int_as_float((tb & ~KEY_SLOT_MASK) | (tb < 0 ? 31 - l31 : l31));
       }
+      sync_thr();
     }
     bool first = true;
     for (int ci = 0; ci < iv.n_cells; ++ci) {
@@ -894,7 +1031,7 @@ template <int KP>
 __global__ __launch_bounds__(256) void knn_rerank_kernel(
     const float* __restrict__ x, const float* __restrict__ mu, int64_t n, int d, int64_t ld, int64_t q_begin,
     int64_t n_query, int k, const int* __restrict__ cand_idx, const float* __restrict__ cand_tau,
-    const unsigned int* __restrict__ cmax_bits, double cert_scale, int32_t* __restrict__ out_idx,
+    const unsigned int* __restrict__ cmax_bits, double cert_scale, double cert_k, int32_t* __restrict__ out_idx,
     double* __restrict__ out_dist, double* __restrict__ kth_d2, int* __restrict__ flag_list,
     int* __restrict__ n_flag) {
   constexpr int PER = (KP + 63) / 64;
@@ -999,7 +1136,9 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
     // 5 low mantissa bits, i.e. each is off by < 32 ulp OF ITS OWN MAGNITUDE -- the threshold's, not cmax's (keys far
     // above the threshold cannot be confused with it): 128 u |tau| with a factor 2 for a binade boundary.  (Charging it
     // against cmax as well, factor 202, sent 4317 instead of 379 queries of the 10M x 50 run to the float64 scan: +3 s.)
-    double eps = cert_scale * 5.9604644775390625e-08 * (138.0 * (cmax + 2.0 * sqrt(qn * cmax)) + 128.0 * fabs(tau));
+    // 3 x bf16 engine (cert_k = CERT_K_B3): 198 accumulated terms instead of 2H + 2 = 52 (+146), and the dropped lo.lo
+    // products / residuals of the hi + lo split: 3 * 2^-18 = 192 u on the 2 q.c term -> 138 + 146 + 192 = 476.
+    double eps = cert_scale * 5.9604644775390625e-08 * (cert_k * (cmax + 2.0 * sqrt(qn * cmax)) + 128.0 * fabs(tau));
     bool certified = (tau >= 1e38f) || ((dk - qn) + eps < tau);
     kth_d2[qi] = dk;
     if (!certified) {
@@ -1245,7 +1384,7 @@ __global__ void ivf_pack_image_kernel(const float* __restrict__ x, const float* 
                                       int64_t n_img, const int* __restrict__ perm, const int* __restrict__ labels,
                                       const int* __restrict__ cell_map, const float* __restrict__ cent,
                                       float* __restrict__ xp, unsigned int* __restrict__ cmax_bits,
-                                      unsigned int* __restrict__ radius_bits) {
+                                      unsigned int* __restrict__ radius_bits, int b3) {
   const int lane = threadIdx.x & 63, sub = lane & 15;
   const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
@@ -1271,6 +1410,13 @@ __global__ void ivf_pack_image_kernel(const float* __restrict__ x, const float* 
       dc2 += __shfl_xor(dc2, o);
     }
     const float nf = (src >= 0) ? (float)s : INFINITY;
+    if (b3) {  // bf16 hi / lo image (RegCfg: B3)
+      const float nb = (src >= 0) ? nf : B3_PAD_NORM;
+      unsigned int* xu = reinterpret_cast<unsigned int*>(xp);
+      for (int c = sub; c < B3_DPL; c += 16)
+        xu[r * B3_DPL + c] =
+            b3_row_dword(c, d, nb, [&](int dim) { return src >= 0 ? __fsub_rn(x[(int64_t)src * ld + dim], mu[dim]) : 0.f; });
+    } else
     for (int c = sub; c < DPL; c += 16) {
       const int hh = c / HP, cc = c - hh * HP;
       float v = 0.f;
@@ -1300,6 +1446,7 @@ __global__ void ivf_pack_image_kernel(const float* __restrict__ x, const float* 
 struct KnnPlan {
   int H, TC, NW, KP;
   bool reg;       // register-list kernel (knn_select_reg_kernel) instead of the LDS-list kernel
+  bool b3;        // ... with the 3 x bf16 scoring engine (RegCfg: B3)
   int thr_rank;   // register-list kernel: rank (1..32) of the list entry used as the filter threshold
   int row_dwords; // row stride of the packed copy
   int64_t n_pad, nq_pad;
@@ -1348,6 +1495,13 @@ static bool knn_plan(int64_t n, int d, int64_t n_query, int k, KnnPlan* p) {
       case 25: reg_plan<25>(p); break;
       default: reg_plan<32>(p); break;
     }
+  }
+  // 3 x bf16 engine: 32 < d <= 50 (the PCA embedding); SCAMD_KNN_B3=0 keeps the float32 MFMA engine (read per call)
+  p->b3 = false;
+  if (p->reg && p->H == 25) {
+    const char* e = getenv("SCAMD_KNN_B3");
+    p->b3 = !(e && e[0] == '0');
+    if (p->b3) p->row_dwords = B3_DPL;
   }
   const int QB = p->NW * 32;
   p->nq_pad = (n_query + QB - 1) / QB * QB;
@@ -1445,10 +1599,10 @@ static int dispatch_kp(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, h
   }
 }
 
-template <int H, int TC_, int WPS>
+template <int H, int TC_, int WPS, bool B3 = false>
 static int launch_select_reg_mode(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, hipStream_t s) {
-  using C = RegCfg<H, TC_>;
-  auto kern = knn_select_reg_kernel<H, TC_, WPS, false>;
+  using C = RegCfg<H, TC_, B3>;
+  auto kern = knn_select_reg_kernel<H, TC_, WPS, false, B3>;
   SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
   const int n_tiles = (int)(p.n_pad / C::TC);
@@ -1468,6 +1622,10 @@ static int launch_select_reg(const KnnPlan& p, const KnnBuffers& b, int64_t q_be
     const char* e = getenv("SCAMD_KNN_BIG_TILES");
     return e && e[0] == '1';
   }();
+  if constexpr (H == 25) {
+    if (p.b3) return big_tiles ? launch_select_reg_mode<25, 128, 2, true>(p, b, q_begin, s)
+                               : launch_select_reg_mode<25, 64, 2, true>(p, b, q_begin, s);
+  }
   if (big_tiles) return launch_select_reg_mode<H, 128, 2>(p, b, q_begin, s);
   return launch_select_reg_mode<H, 64, 3>(p, b, q_begin, s);
 }
@@ -1491,10 +1649,10 @@ static int dispatch_select(const KnnPlan& p, const KnnBuffers& b, int64_t q_begi
 }
 
 // ---- cell-pruned search: quantiser, cell-sorted image, launch -------------------------------------------
-template <int H>
+template <int H, bool B3 = false>
 static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x, int64_t n, int d, int64_t ld,
                           int64_t q_begin, int64_t n_query, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-  using C = RegCfg<H, 64>;
+  using C = RegCfg<H, 64, B3>;
   constexpr int MIN_CELL = 128;
   const int nc = p.n_cells;
   int* counts = b.cell_ints;
@@ -1606,7 +1764,7 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   {
     const int blocks = (int)std::min<int64_t>((rows + 3) / 4, 256 * 16);
     hipLaunchKernelGGL(ivf_pack_image_kernel, dim3(blocks), dim3(256), 0, s, x, b.mu, d, ld, H, C::HP, C::DPL, rows, b.perm,
-                       b.labels, cell_map, b.cent, b.xp, b.cmax, b.radius_bits);
+                       b.labels, cell_map, b.cent, b.xp, b.cmax, b.radius_bits, B3 ? 1 : 0);
     SCAMD_LAUNCH_CHECK();
   }
   // 5. sweep order of every cell (needs the radii the pack kernel just produced)
@@ -1629,8 +1787,9 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   // 96 / 236 bytes per lane to scratch, `-Rpass-analysis=kernel-resource-usage`); SCAMD_KNN_IVF_WPS=2 selects the
   // build cut for 2 blocks per CU (no spills) -- an A/B switch until both have been measured
   const char* wps_env = getenv("SCAMD_KNN_IVF_WPS");
-  auto kern = (wps_env && atoi(wps_env) == 2) ? knn_select_reg_kernel<H, 64, 2, true>
-                                               : knn_select_reg_kernel<H, 64, 3, true>;
+  auto kern = B3 ? knn_select_reg_kernel<H, 64, 2, true, B3>
+                 : ((wps_env && atoi(wps_env) == 2) ? knn_select_reg_kernel<H, 64, 2, true, false>
+                                                     : knn_select_reg_kernel<H, 64, 3, true, false>);
   const size_t lds = C::LDS_BYTES + 64;
   SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
@@ -1687,7 +1846,9 @@ static int dispatch_ivf(const KnnPlan& p, const KnnBuffers& b, const float* x, i
   switch (p.H) {
     case 8: return run_ivf_select<8>(p, b, x, n, d, ld, q_begin, n_query, s, ev0, ev1);
     case 16: return run_ivf_select<16>(p, b, x, n, d, ld, q_begin, n_query, s, ev0, ev1);
-    case 25: return run_ivf_select<25>(p, b, x, n, d, ld, q_begin, n_query, s, ev0, ev1);
+    case 25:
+      if (p.b3) return run_ivf_select<25, true>(p, b, x, n, d, ld, q_begin, n_query, s, ev0, ev1);
+      return run_ivf_select<25>(p, b, x, n, d, ld, q_begin, n_query, s, ev0, ev1);
     default: return run_ivf_select<32>(p, b, x, n, d, ld, q_begin, n_query, s, ev0, ev1);
   }
 }
@@ -1744,7 +1905,7 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
     if (p.reg) {
       const int HP = (p.H + 1 + 3) / 4 * 4;
       hipLaunchKernelGGL(knn_pack_image_kernel, dim3(blocks), dim3(256), 0, s, x, b.mu, n, d, ld_x, p.H, HP,
-                         p.row_dwords, p.n_pad, b.xp, b.cmax);
+                         p.row_dwords, p.n_pad, b.xp, b.cmax, p.b3 ? 1 : 0);
     } else {
       hipLaunchKernelGGL(knn_pack_kernel, dim3(blocks), dim3(256), 0, s, x, b.mu, n, d, ld_x, 2 * p.H,
                          p.n_pad, b.xp, b.cn, b.cmax);
@@ -1771,7 +1932,7 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
     int blocks = (int)((n_query + 3) / 4);
 #define RERANK(KP_)                                                                              \
   hipLaunchKernelGGL(knn_rerank_kernel<KP_>, dim3(blocks), dim3(256), 0, s, x, b.mu, n, d, ld_x, q_begin, \
-                     n_query, k, b.cand_idx, b.cand_tau, b.cmax, cert_scale, out_idx, out_dist,  \
+                     n_query, k, b.cand_idx, b.cand_tau, b.cmax, cert_scale, p.b3 ? CERT_K_B3 : CERT_K_F32, out_idx, out_dist,  \
                      b.kth_d2, b.flag_list, b.counters)
     if (p.KP == 32) RERANK(32);
     else if (p.KP == 64) RERANK(64);
