@@ -12,10 +12,14 @@ i.e. strong scaling of configs[3]).  The CSR shard is resident in HBM before the
 timed region ends with the labels on the device.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      knn_select_reg_kernel (FP32 MFMA): achieved = 2 * 50 flop per evaluated (query, candidate) pair
+  roofline      knn_select_reg_kernel, 3 x bf16 engine (v_mfma_f32_32x32x16_bf16 on the hi / lo split of the float32
+                coordinates, result certified in float64): achieved = 3 * 2 * 64 flop per evaluated (query, candidate)
+                pair -- the three split products over the 64-slot row are the arithmetic this engine's algorithm asks for
                 (scamd_knn_last_select_pairs: the pairs of the swept cells, WITHOUT the threshold pre-pass that re-scores
                 every block's own cell; the exact cell-pruned search skips provably empty cells) / its HIP-event
-                duration (scamd_knn_last_select_ms), peak = 157.3 TFLOP/s (MI355X_MICROARCH.md).
+                duration (scamd_knn_last_select_ms), peak = 2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md).  Beside it
+                `f32_equivalent_tflops` = 2 * 50 flop per pair (what the float32 engine of rounds 1-2 was priced on;
+                its peak was the 157.3 TFLOP/s of the f32-input MFMA).  SCAMD_KNN_B3=0 runs the float32 engine.
   value_host_to_host   the BASELINE metric at the drop-in boundary: AnnData with a host CSR in -> sc.pp.pca /
                 sc.pp.neighbors / sc.tl.leiden -> slots written on the host (H2D, kernels, D2H, scipy / pandas slot
                 construction), warm process, best of `--h2h-reps`; `value` is the device-resident figure.
@@ -355,8 +359,12 @@ def noise_variant(args, backend, kw) -> dict:
     pre = float(lib.scamd_knn_last_select_prepass_pairs())
     brute = float(args.n_obs) ** 2
     tf = 2.0 * pairs * args.n_comps / (sel * 1e-3) / 1e12 if sel > 0 else None
+    eng = int(lib.scamd_knn_last_select_engine())
+    tf_exec = (3.0 * 2.0 * 64.0 if eng == 1 else 2.0 * args.n_comps) * pairs / (sel * 1e-3) / 1e12 if sel > 0 else None
     return {"note": "same shape, p_programme = 0 (i.i.d. genes): PCA spectrum without a gap, kNN without prunable cells; "
                     "1 warm-up + 1 timed step, outside `value`",
+            "knn_engine": "bf16x3" if eng == 1 else "f32", "knn_select_engine_tflops": tf_exec,
+            "knn_select_frac_of_engine_peak": tf_exec / (2500.0 if eng == 1 else 157.3) if tf_exec else None,
             "ms_per_step": ms, "cells_per_s": args.n_obs / (ms * 1e-3), "stage_ms": res.stage_ms,
             "pairs_evaluated_fraction": pairs / brute, "prepass_pairs_fraction_of_useful": pre / pairs if pairs else None,
             "knn_select_ms": sel, "knn_select_tflops": tf,
@@ -551,9 +559,11 @@ def main() -> None:
         brute_pairs = float(n_query) * float(n)
         # algorithmic flop of the launch = 2 * d flop per EVALUATED pair: the exact cell-pruned search skips the
         # cells that provably hold no neighbour, what it does evaluate runs on the FP32 MFMA pipe
-        flops = 2.0 * pairs * args.n_comps
+        engine = int(lib.scamd_knn_last_select_engine())  # 1 = 3 x bf16 split products, 0 = float32 MFMA
+        flop_per_pair = 3.0 * 2.0 * 64.0 if engine == 1 else 2.0 * args.n_comps
+        flops = flop_per_pair * pairs
         achieved = flops / (sel * 1e-3) / 1e12 if sel > 0 else None
-        peak = 157.3
+        peak = 2500.0 if engine == 1 else 157.3
         out = {
             "metric": "cells/sec through pca+neighbors+leiden, 1M x 2k CSR" if (n, args.n_vars) == (1_000_000, 2000) else f"cells/sec through pca+neighbors+leiden, {n} x {args.n_vars} CSR",
             "value": value,
@@ -565,7 +575,7 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16x3" if int(lib.scamd_knn_last_select_engine()) == 1 else "f32",
             "data": "synthetic",
             "config": {
                 "workload": (f"synthetic {args.structure}-structure log-normal CSR {n} cells x {args.n_vars} genes (~5% nnz), PCA {args.n_comps} "
@@ -578,21 +588,30 @@ def main() -> None:
                                 "rank with an all-to-all of the directed edges; leiden on rank 0"),
             },
             "roofline": {
-                "kernel": "knn_select_reg_kernel<25,64,3> (v_mfma_f32_32x32x2_f32), exact cell-pruned sweep",
+                "kernel": ("knn_select_reg_kernel<25,64,2,IVF,B3> (v_mfma_f32_32x32x16_bf16 x 12 per 32x32 sub-tile: hi.hi + hi.lo + "
+                           "lo.hi of the bf16 split), exact cell-pruned sweep" if engine == 1 else
+                           "knn_select_reg_kernel<25,64,3> (v_mfma_f32_32x32x2_f32), exact cell-pruned sweep"),
+                "engine": "bf16x3" if engine == 1 else "f32",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": (achieved / peak) if achieved else None,
                 # the committed PMC passes are of the single-GPU 1M x 1M launch: not quoted for any other shape
+                # (the committed PMC passes are of the float32 engine; the bf16 engine's passes could not be taken this
+                # round -- rocprofv3 --pmc aborted with a device fault on the box, profiles/README.md -- hence null)
                 "traffic": (_profiled_traffic("ivf" if 0 < pairs < brute_pairs else "brute")
-                            if (n, args.n_comps, world) == (1_000_000, 50, 1) else None),
+                            if (n, args.n_comps, world) == (1_000_000, 50, 1) and engine == 0 else None),
                 "launch_ms": sel,
                 "algorithmic_flop_per_launch": flops,
+                "flop_per_pair": flop_per_pair,
+                # the same launch priced as rounds 1-2 priced the float32 engine: 2 * d flop per pair
+                "f32_equivalent_tflops": 2.0 * pairs * args.n_comps / (sel * 1e-3) / 1e12 if sel > 0 else None,
+                "f32_equivalent_frac_of_157.3": 2.0 * pairs * args.n_comps / (sel * 1e-3) / 1e12 / 157.3 if sel > 0 else None,
                 "pairs_evaluated_fraction": pairs / brute_pairs if brute_pairs > 0 else None,
                 # executed but not useful: the threshold pre-pass re-scores every block's own cell; NOT in `achieved`
                 "prepass_pairs_fraction_of_useful": (sum(prepass_pairs) / max(len(prepass_pairs), 1)) / pairs if pairs > 0 else None,
-                "executed_tflops_incl_prepass": (2.0 * (pairs + sum(prepass_pairs) / max(len(prepass_pairs), 1)) * args.n_comps
+                "executed_tflops_incl_prepass": (flop_per_pair * (pairs + sum(prepass_pairs) / max(len(prepass_pairs), 1))
                                                  / (sel * 1e-3) / 1e12) if sel > 0 else None,
                 "brute_force_equivalent_tflops": 2.0 * brute_pairs * args.n_comps / (sel * 1e-3) / 1e12 if sel > 0 else None,
             },

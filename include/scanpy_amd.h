@@ -82,6 +82,10 @@ double scamd_knn_last_select_pairs(void);
 /* Pairs the same kernel evaluated in its threshold pre-pass (the own cell of every block, scored once more only to seed
  * the list thresholds): executed by the kernel, NOT useful work -- kept out of the roofline's algorithmic flop. */
 double scamd_knn_last_select_prepass_pairs(void);
+/* Scoring engine of that call's selection kernel: 0 = float32 MFMA (v_mfma_f32_32x32x2_f32, 2 (d + 2) flop per pair),
+ * 1 = 3 x bf16 (v_mfma_f32_32x32x16_bf16 on the hi / lo split of the coordinates: 3 * 2 * 64 flop per pair; 32 < d <= 50,
+ * SCAMD_KNN_B3=0 disables it); -1 if none.  Either way pass 2 certifies the result in float64. */
+int scamd_knn_last_select_engine(void);
 
 /* ------------------------------------------------------------------------------------------
  * Fuzzy simplicial set -- umap connectivities from a kNN result.

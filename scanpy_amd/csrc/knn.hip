@@ -28,6 +28,7 @@
 static thread_local float g_last_select_ms = -1.f;
 static thread_local double g_last_select_pairs = -1.0;
 static thread_local double g_last_select_prepass_pairs = -1.0;
+static thread_local int g_last_select_engine = -1;
 
 namespace scamd {
 
@@ -1860,6 +1861,7 @@ using namespace scamd;
 extern "C" float scamd_knn_last_select_ms(void) { return g_last_select_ms; }
 extern "C" double scamd_knn_last_select_pairs(void) { return g_last_select_pairs; }
 extern "C" double scamd_knn_last_select_prepass_pairs(void) { return g_last_select_prepass_pairs; }
+extern "C" int scamd_knn_last_select_engine(void) { return g_last_select_engine; }
 
 extern "C" size_t scamd_knn_workspace_bytes(int64_t n, int d, int64_t n_query, int k) {
   KnnPlan p;
@@ -1955,6 +1957,7 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
     unsigned long long pre = 0;
     memcpy(&pre, &h_counters[4], 8);
     g_last_select_prepass_pairs = p.ivf ? (double)pre : 0.0;
+    g_last_select_engine = p.b3 ? 1 : 0;
   }
   const int n_flag = h_counters[0];
   if (n_fallback_host) *n_fallback_host = n_flag;
