@@ -1811,7 +1811,9 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   iv.block_perm = b.block_perm;
   {
     const char* e = getenv("SCAMD_KNN_PREPASS_TILES");
-    iv.prepass_tiles = e ? std::max(1, atoi(e)) : 16;  // measured at 1M: 48 -> 29.3 ms, 24 / 12 -> 29.0, 6 -> 29.6, 2 -> 30.2
+    // float32 engine, measured at 1M: 48 -> 29.3 ms, 24 / 12 -> 29.0, 6 -> 29.6, 2 -> 30.2; bf16 engine (the pre-pass
+    // costs a quarter): 8 -> 17.1, 16 -> 16.8, 32 -> 16.15, 64 -> 16.1
+    iv.prepass_tiles = e ? std::max(1, atoi(e)) : (B3 ? 32 : 16);
   }
   {
     const char* e = getenv("SCAMD_KNN_DEBUG_NO_INSERT");
