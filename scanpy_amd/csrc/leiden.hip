@@ -512,7 +512,10 @@ __global__ __launch_bounds__(256) void ld_move_kernel(
 }
 
 // Hub vertices of the active list (positions in hub_list[0 .. counters[4])): one workgroup each.
-__global__ __launch_bounds__(256) void ld_move_hub_kernel(
+// HUB_THREADS = 1024 (round 3; 256 before): a launch lasts as long as its longest row -- up to 20k entries on the coarse
+// levels of unstructured graphs, swept in 7 hash-class passes -- and the row is walked blockDim entries at a time.
+constexpr int HUB_THREADS = 1024;
+__global__ __launch_bounds__(HUB_THREADS) void ld_move_hub_kernel(
     const int* __restrict__ hub_list, int* __restrict__ counters, const int* __restrict__ list,
     const int64_t* __restrict__ indptr, const int* __restrict__ indices, const long long* __restrict__ wq,
     const long long* __restrict__ k, const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot,
@@ -520,8 +523,8 @@ __global__ __launch_bounds__(256) void ld_move_hub_kernel(
     int* __restrict__ err) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long hub_smem[];
   BlockHash bh{reinterpret_cast<int*>(hub_smem + BHUB_SLOTS), hub_smem, BHUB_SLOTS};
-  __shared__ Cand sh_c[4];
-  __shared__ long long sh_w[4];
+  __shared__ Cand sh_c[HUB_THREADS / 64];
+  __shared__ long long sh_w[HUB_THREADS / 64];
   const int n_hub = counters[4];
   for (int i = blockIdx.x; i < n_hub; i += gridDim.x) {
     const int w = hub_list[i];
@@ -1038,7 +1041,7 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
 }
 
 // Hub candidates (vertex ids in hub_list[0 .. counters[4])): one workgroup each; same rule as the wave kernel.
-__global__ __launch_bounds__(256) void ld_refine_propose_hub_kernel(
+__global__ __launch_bounds__(HUB_THREADS) void ld_refine_propose_hub_kernel(
     const int* __restrict__ hub_list, int* __restrict__ counters, const int64_t* __restrict__ indptr,
     const int* __restrict__ indices, const long long* __restrict__ wq, const long long* __restrict__ k,
     const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot, const int* __restrict__ ref,
@@ -1047,8 +1050,8 @@ __global__ __launch_bounds__(256) void ld_refine_propose_hub_kernel(
     unsigned int seed, int* __restrict__ target, int* __restrict__ err) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long hub_smem[];
   BlockHash bh{reinterpret_cast<int*>(hub_smem + BHUB_SLOTS), hub_smem, BHUB_SLOTS};
-  __shared__ Cand sh_c[4];
-  __shared__ long long sh_w[4];
+  __shared__ Cand sh_c[HUB_THREADS / 64];
+  __shared__ long long sh_w[HUB_THREADS / 64];
   const int n_hub = counters[4];
   for (int i = blockIdx.x; i < n_hub; i += gridDim.x) {
     const int v = hub_list[i];
@@ -2290,7 +2293,7 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
         SCAMD_LAUNCH_CHECK();
       }
       if (g.n_gt384 > 0) {
-        hipLaunchKernelGGL(ld_move_hub_kernel, dim3((unsigned)std::min(HUB_GRID, std::min(cnt, g.n_gt384))), dim3(256), HUB_LDS, cx.s, b.hub_list,
+        hipLaunchKernelGGL(ld_move_hub_kernel, dim3((unsigned)std::min(HUB_GRID, std::min(cnt, g.n_gt384))), dim3(HUB_THREADS), HUB_LDS, cx.s, b.hub_list,
                            ctr, list, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg, dir_round, cx.seed,
                            b.target, b.counters + 7);
         SCAMD_LAUNCH_CHECK();
@@ -2366,7 +2369,7 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
       LD_DBG_SYNC(cx, "rf propose<64> n=%d class=%d cnt=%d", g.n, c, cnt);
     }
     if (g.n_gt384 > 0) {
-      hipLaunchKernelGGL(ld_refine_propose_hub_kernel, dim3((unsigned)std::min(HUB_GRID, std::min(cnt, g.n_gt384))), dim3(256), HUB_LDS, cx.s,
+      hipLaunchKernelGGL(ld_refine_propose_hub_kernel, dim3((unsigned)std::min(HUB_GRID, std::min(cnt, g.n_gt384))), dim3(HUB_THREADS), HUB_LDS, cx.s,
                          b.hub_list, ctr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref,
                          gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.counters + 7);
       SCAMD_LAUNCH_CHECK();
