@@ -363,10 +363,10 @@ __device__ __forceinline__ int key_order(int bits) { return bits ^ ((bits >> 31)
 
 // B3 = the "3 x bf16" scoring engine (d <= 50 only).  The f32-input MFMA of gfx950 runs at the f32 VECTOR rate (157 TFLOP/s),
 // the bf16 one sixteen times faster.  A float32 coordinate is written as hi + lo with hi = bf16(x), lo = bf16(x - hi)
-// (residual <= 2^-18 |x|) and q.c ~ qh.ch + qh.cl + ql.ch: three bf16 products instead of one f32 product, 12
+// (residual <= 2^-16 |x|) and q.c ~ qh.ch + qh.cl + ql.ch: three bf16 products instead of one f32 product, 12
 // v_mfma_f32_32x32x16_bf16 (32 cycles each) per 32 x 32 sub-tile instead of 26 v_mfma_f32_32x32x2_f32 (64 cycles each):
-// 4.3x less matrix time for scores that are off by <= 3 * 2^-18 ||q|| ||c|| -- which the float64 certificate of pass 2
-// prices in (factor CERT_K_B3), so the result is the exact kNN as before.  Image row = 68 dwords: 64 bf16 hi | 64 bf16 lo
+// 4.3x less matrix time for scores that are off by <= 3 * 2^-16 * 2 ||q|| ||c|| -- which the float64 certificate of pass 2
+// prices in (CERT_K_B3, CERT_K2_B3), so the result is the exact kNN as before.  Image row = 68 dwords: 64 bf16 hi | 64 bf16 lo
 // | ||c||^2 (f32, for the stop rule) | pad.  Dims 50..55 of the hi part carry the threshold subtraction and the norm:
 // candidate rows hold [1, 1, 1, n1, n2, n3] (||c||^2 = n1 + n2 + n3 exactly: three bf16 pieces hold 24 bits), the query
 // operand [-t1, -t2, -t3, 1, 1, 1] -- the accumulator comes out as score - threshold, with no extra instruction.
@@ -382,7 +382,10 @@ struct RegCfg {
   static_assert(!B3 || H == 25, "the bf16 engine is built for d <= 50");
 };
 constexpr int B3_DPL = 68;
-constexpr double CERT_K_F32 = 138.0, CERT_K_B3 = 476.0;
+// certificate factors (units of u = 2^-24), see knn_rerank_kernel.  bf16 engine: 198 accumulated terms instead of 52
+// (+146 on both terms), and on the 2 q.c term the split's own error: bf16 carries 8 significant bits (unit roundoff 2^-8), so
+// |x - hi - lo| <= 2^-16 |x| and the three dropped pieces (ql.cl, q's residual, c's residual) sum to <= 3 * 2^-16 = 768 u.
+constexpr double CERT_K_F32 = 138.0, CERT_K_B3 = 284.0, CERT_K2_B3 = 768.0;
 constexpr float B3_PAD_NORM = 1.0e38f;  // ||c||^2 of padding rows: finite (0 * inf = NaN in the cross products)
 
 // float32 -> bf16 bits, round to nearest even (finite inputs)
@@ -1032,7 +1035,8 @@ template <int KP>
 __global__ __launch_bounds__(256) void knn_rerank_kernel(
     const float* __restrict__ x, const float* __restrict__ mu, int64_t n, int d, int64_t ld, int64_t q_begin,
     int64_t n_query, int k, const int* __restrict__ cand_idx, const float* __restrict__ cand_tau,
-    const unsigned int* __restrict__ cmax_bits, double cert_scale, double cert_k, int32_t* __restrict__ out_idx,
+    const unsigned int* __restrict__ cmax_bits, double cert_scale, double cert_k, double cert_k2,
+    int32_t* __restrict__ out_idx,
     double* __restrict__ out_dist, double* __restrict__ kth_d2, int* __restrict__ flag_list,
     int* __restrict__ n_flag) {
   constexpr int PER = (KP + 63) / 64;
@@ -1137,9 +1141,10 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
     // 5 low mantissa bits, i.e. each is off by < 32 ulp OF ITS OWN MAGNITUDE -- the threshold's, not cmax's (keys far
     // above the threshold cannot be confused with it): 128 u |tau| with a factor 2 for a binade boundary.  (Charging it
     // against cmax as well, factor 202, sent 4317 instead of 379 queries of the 10M x 50 run to the float64 scan: +3 s.)
-    // 3 x bf16 engine (cert_k = CERT_K_B3): 198 accumulated terms instead of 2H + 2 = 52 (+146), and the dropped lo.lo
-    // products / residuals of the hi + lo split: 3 * 2^-18 = 192 u on the 2 q.c term -> 138 + 146 + 192 = 476.
-    double eps = cert_scale * 5.9604644775390625e-08 * (cert_k * (cmax + 2.0 * sqrt(qn * cmax)) + 128.0 * fabs(tau));
+    // 3 x bf16 engine: cert_k = 138 + 146 (198 accumulated terms instead of 2H + 2 = 52) and cert_k2 = 768 on the 2 q.c
+    // term alone (the hi + lo split's dropped pieces, 3 * 2^-16: the norm and the threshold are split EXACTLY).
+    double eps = cert_scale * 5.9604644775390625e-08 *
+                 (cert_k * (cmax + 2.0 * sqrt(qn * cmax)) + cert_k2 * 2.0 * sqrt(qn * cmax) + 128.0 * fabs(tau));
     bool certified = (tau >= 1e38f) || ((dk - qn) + eps < tau);
     kth_d2[qi] = dk;
     if (!certified) {
@@ -1448,6 +1453,7 @@ struct KnnPlan {
   int H, TC, NW, KP;
   bool reg;       // register-list kernel (knn_select_reg_kernel) instead of the LDS-list kernel
   bool b3;        // ... with the 3 x bf16 scoring engine (RegCfg: B3)
+  bool thr_margin_env;
   int thr_rank;   // register-list kernel: rank (1..32) of the list entry used as the filter threshold
   int row_dwords; // row stride of the packed copy
   int64_t n_pad, nq_pad;
@@ -1485,6 +1491,7 @@ static bool knn_plan(int64_t n, int d, int64_t n_query, int k, KnnPlan* p) {
       return e ? atoi(e) : 6;
     }();
     p->thr_rank = std::min(32, std::max(1, k + margin));
+    p->thr_margin_env = getenv("SCAMD_KNN_THR_MARGIN") != nullptr;
   }
   p->row_dwords = 2 * p->H;
   if (p->reg) {
@@ -1502,7 +1509,15 @@ static bool knn_plan(int64_t n, int d, int64_t n_query, int k, KnnPlan* p) {
   if (p->reg && p->H == 25) {
     const char* e = getenv("SCAMD_KNN_B3");
     p->b3 = !(e && e[0] == '0');
-    if (p->b3) p->row_dwords = B3_DPL;
+    if (p->b3) {
+      p->row_dwords = B3_DPL;
+      // The engine's error bound is ~4x the float32 engine's (relative to ||q|| ||c||, which on clustered data is far
+      // larger than the neighbour distances): with the margin of 6 ranks, 508 queries of the planted 1M run failed the
+      // certificate under a bound that was still 2x too small, and the float64 scan of those cost 4.2 ms.  The failure
+      // probability falls like (bound / gap)^margin.  Measured with the correct bound, planted 1M: margin 8 -> select
+      // 16.5 ms + 200 fallbacks, 10 -> 17.0 ms + 5, 12 -> 18.0 ms + 1: 10 ranks (threshold = the 25th list entry at k = 15).
+      if (!p->thr_margin_env) p->thr_rank = std::min(32, std::max(1, k + 10));
+    }
   }
   const int QB = p->NW * 32;
   p->nq_pad = (n_query + QB - 1) / QB * QB;
@@ -1936,7 +1951,7 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
     int blocks = (int)((n_query + 3) / 4);
 #define RERANK(KP_)                                                                              \
   hipLaunchKernelGGL(knn_rerank_kernel<KP_>, dim3(blocks), dim3(256), 0, s, x, b.mu, n, d, ld_x, q_begin, \
-                     n_query, k, b.cand_idx, b.cand_tau, b.cmax, cert_scale, p.b3 ? CERT_K_B3 : CERT_K_F32, out_idx, out_dist,  \
+                     n_query, k, b.cand_idx, b.cand_tau, b.cmax, cert_scale, p.b3 ? CERT_K_B3 : CERT_K_F32, p.b3 ? CERT_K2_B3 : 0.0, out_idx, out_dist,  \
                      b.kth_d2, b.flag_list, b.counters)
     if (p.KP == 32) RERANK(32);
     else if (p.KP == 64) RERANK(64);
