@@ -617,7 +617,7 @@ def main() -> None:
             },
             "stage_ms_per_step": {kname: v / max(args.steps, 1) for kname, v in stage_acc.items()},
             "result": {"n_communities": res.n_communities, "modularity": res.modularity, "labels_sha": _sha(res.labels),
-                       **res.info},
+                       "knn_second_tier_queries": int(lib.scamd_knn_last_second_tier_queries()), **res.info},
             "setup_s": {"generate": t_gen, "h2d": t_h2d},
         }
         out["config"]["structure"] = args.structure

@@ -86,6 +86,10 @@ double scamd_knn_last_select_prepass_pairs(void);
  * 1 = 3 x bf16 (v_mfma_f32_32x32x16_bf16 on the hi / lo split of the coordinates: 3 * 2 * 64 flop per pair; 32 < d <= 50,
  * SCAMD_KNN_B3=0 disables it); -1 if none.  Either way pass 2 certifies the result in float64. */
 int scamd_knn_last_select_engine(void);
+/* Queries of that call that the bf16 engine's certificate rejected and the float32 engine re-did (second tier of the
+ * pruned search; 0 when the count stayed below SCAMD_KNN_TIER2_MIN, default 256, or the float32 engine ran anyway).
+ * `n_fallback_host` of scamd_knn_l2_f32 counts what went to the float64 scan after that. */
+int scamd_knn_last_second_tier_queries(void);
 
 /* ------------------------------------------------------------------------------------------
  * Fuzzy simplicial set -- umap connectivities from a kNN result.

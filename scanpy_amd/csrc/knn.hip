@@ -29,6 +29,7 @@ static thread_local float g_last_select_ms = -1.f;
 static thread_local double g_last_select_pairs = -1.0;
 static thread_local double g_last_select_prepass_pairs = -1.0;
 static thread_local int g_last_select_engine = -1;
+static thread_local int g_last_second_tier = 0;
 
 namespace scamd {
 
@@ -1038,15 +1039,17 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
     const unsigned int* __restrict__ cmax_bits, double cert_scale, double cert_k, double cert_k2,
     int32_t* __restrict__ out_idx,
     double* __restrict__ out_dist, double* __restrict__ kth_d2, int* __restrict__ flag_list,
-    int* __restrict__ n_flag) {
+    int* __restrict__ n_flag, const int* __restrict__ qlist, int n_list) {
   constexpr int PER = (KP + 63) / 64;
   __shared__ float qs[4][128];
   __shared__ double sd[4][KP];
   __shared__ int si[4][KP];
   __shared__ double skth[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t qi = (int64_t)blockIdx.x * 4 + w;
-  if (qi >= n_query) return;  // whole wave exits together (no block-level sync below)
+  // (qlist: only these queries -- the second tier of the bf16 engine re-ranks what its first certificate rejected)
+  const int64_t qj = (int64_t)blockIdx.x * 4 + w;
+  if (qj >= (qlist ? (int64_t)n_list : n_query)) return;  // whole wave exits together (no block-level sync below)
+  const int64_t qi = qlist ? (int64_t)qlist[qj] : qj;
   const int64_t q = q_begin + qi;
   for (int c = lane; c < d; c += 64) qs[w][c] = x[q * ld + c];
   if (lane == 0) skth[w] = INFINITY;
@@ -1372,13 +1375,39 @@ __global__ void ivf_update_kernel(const long long* __restrict__ sums, const int*
 __global__ void ivf_scatter_kernel(const int* __restrict__ labels, int64_t n, const int* __restrict__ cell_map,
                                    const int* __restrict__ row_off, int* __restrict__ row_cur, int64_t q0, int64_t q1,
                                    const int* __restrict__ slot_off, int* __restrict__ slot_cur, int* __restrict__ perm,
-                                   int* __restrict__ qpos) {
+                                   int* __restrict__ qpos, int* __restrict__ qrow) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int c = cell_map[labels[i]];
   const int pos = row_off[c] + atomicAdd(&row_cur[c], 1);
   perm[pos] = (int)i;
-  if (i >= q0 && i < q1) qpos[slot_off[c] + atomicAdd(&slot_cur[c], 1)] = pos;
+  if (i >= q0 && i < q1) {
+    qpos[slot_off[c] + atomicAdd(&slot_cur[c], 1)] = pos;
+    if (qrow) qrow[i - q0] = pos;  // image row of the query (second tier of the bf16 engine)
+  }
+}
+
+// second tier: the flagged queries, counted per (merged) cell ...
+__global__ void ivf_t2_count_kernel(const int* __restrict__ flag_list, int n_flag, int64_t q0, const int* __restrict__ labels,
+                                    const int* __restrict__ cell_map, int* __restrict__ cnt, int* __restrict__ cell_out,
+                                    int* __restrict__ pos_out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_flag) return;
+  const int c = cell_map[labels[q0 + flag_list[j]]];
+  cell_out[j] = c;
+  pos_out[j] = atomicAdd(&cnt[c], 1);
+}
+// ... and written into their cell's query blocks (slot -> image row; untouched slots stay -1)
+__global__ void ivf_t2_fill_kernel(const int* __restrict__ flag_list, int n_flag, const int* __restrict__ cell_in,
+                                   const int* __restrict__ pos_in, const int* __restrict__ slot_off,
+                                   const int* __restrict__ qrow, int* __restrict__ qpos) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_flag) return;
+  qpos[slot_off[cell_in[j]] + pos_in[j]] = qrow[flag_list[j]];
+}
+__global__ void knn_iota_kernel(int* __restrict__ a, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = i;
 }
 
 // image of the cell-sorted rows (layout of knn_pack_image_kernel); padding rows get ||c||^2 = +inf.  Also the
@@ -1552,6 +1581,8 @@ struct KnnBuffers {
   // cell-pruned search
   int* labels; int* perm; int* qpos; int* block_cell; float* cent; float* centp; long long* sums; int* cell_ints;
   unsigned int* radius_bits; int* cell_order; float* cell_lb2; int* cell_aux; int* block_perm;
+  // second tier of the bf16 engine (float32 engine on the queries its certificate rejected)
+  int* qrow; float* xp2; int* flag_list2; int* t2_cell; int* t2_pos; int* t2_ints;
 };
 
 static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffers* b) {
@@ -1589,6 +1620,16 @@ static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffe
     b->cell_lb2 = ws.take<float>((size_t)p.n_cells * p.n_cells);
     b->cell_aux = ws.take<int>((size_t)p.n_cells * 3);  // expected work, first block, block count of every cell
     b->block_perm = ws.take<int>((size_t)(p.n_slot_max / 128 + 1));
+  }
+  b->qrow = b->flag_list2 = b->t2_cell = b->t2_pos = b->t2_ints = nullptr;
+  b->xp2 = nullptr;
+  if (p.ivf && p.b3) {
+    b->qrow = ws.take<int>((size_t)n_query);
+    b->xp2 = ws.take<float>((size_t)p.n_img_max * RegCfg<25>::DPL);
+    b->flag_list2 = ws.take<int>((size_t)n_query);
+    b->t2_cell = ws.take<int>((size_t)n_query);
+    b->t2_pos = ws.take<int>((size_t)n_query);
+    b->t2_ints = ws.take<int>((size_t)p.n_cells * 2 + 8);  // per-cell counts, slot offsets; [2 nc ..] counters
   }
 }
 
@@ -1667,7 +1708,8 @@ static int dispatch_select(const KnnPlan& p, const KnnBuffers& b, int64_t q_begi
 // ---- cell-pruned search: quantiser, cell-sorted image, launch -------------------------------------------
 template <int H, bool B3 = false>
 static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x, int64_t n, int d, int64_t ld,
-                          int64_t q_begin, int64_t n_query, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+                          int64_t q_begin, int64_t n_query, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1,
+                          int64_t* rows_out) {
   using C = RegCfg<H, 64, B3>;
   constexpr int MIN_CELL = 128;
   const int nc = p.n_cells;
@@ -1758,6 +1800,7 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   }
   const int n_blocks = (int)h_block_cell.size();
   SCAMD_REQUIRE(rows <= p.n_img_max && slots <= p.n_slot_max, SCAMD_EWORKSPACE, "knn: cell layout exceeds its bound");
+  *rows_out = rows;
   if (n_blocks == 0) return SCAMD_OK;
   SCAMD_HIP_CHECK(hipMemcpyAsync(cell_map, h_map.data(), sizeof(int) * nc, hipMemcpyHostToDevice, s));
   SCAMD_HIP_CHECK(hipMemcpyAsync(row_off, h_row_off.data(), sizeof(int) * nc, hipMemcpyHostToDevice, s));
@@ -1775,7 +1818,7 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   SCAMD_HIP_CHECK(hipStreamSynchronize(s));  // the host vectors above must outlive their copies
   // 4. cell-sorted image
   hipLaunchKernelGGL(ivf_scatter_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, b.labels, n, cell_map, row_off,
-                     row_cur, q_begin, q_begin + n_query, slot_off, slot_cur, b.perm, b.qpos);
+                     row_cur, q_begin, q_begin + n_query, slot_off, slot_cur, b.perm, b.qpos, b.qrow);
   SCAMD_LAUNCH_CHECK();
   {
     const int blocks = (int)std::min<int64_t>((rows + 3) / 4, 256 * 16);
@@ -1860,15 +1903,116 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
 }
 
 static int dispatch_ivf(const KnnPlan& p, const KnnBuffers& b, const float* x, int64_t n, int d, int64_t ld,
-                        int64_t q_begin, int64_t n_query, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+                        int64_t q_begin, int64_t n_query, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1,
+                        int64_t* rows_out) {
   switch (p.H) {
-    case 8: return run_ivf_select<8>(p, b, x, n, d, ld, q_begin, n_query, s, ev0, ev1);
-    case 16: return run_ivf_select<16>(p, b, x, n, d, ld, q_begin, n_query, s, ev0, ev1);
+    case 8: return run_ivf_select<8>(p, b, x, n, d, ld, q_begin, n_query, s, ev0, ev1, rows_out);
+    case 16: return run_ivf_select<16>(p, b, x, n, d, ld, q_begin, n_query, s, ev0, ev1, rows_out);
     case 25:
-      if (p.b3) return run_ivf_select<25, true>(p, b, x, n, d, ld, q_begin, n_query, s, ev0, ev1);
-      return run_ivf_select<25>(p, b, x, n, d, ld, q_begin, n_query, s, ev0, ev1);
-    default: return run_ivf_select<32>(p, b, x, n, d, ld, q_begin, n_query, s, ev0, ev1);
+      if (p.b3) return run_ivf_select<25, true>(p, b, x, n, d, ld, q_begin, n_query, s, ev0, ev1, rows_out);
+      return run_ivf_select<25>(p, b, x, n, d, ld, q_begin, n_query, s, ev0, ev1, rows_out);
+    default: return run_ivf_select<32>(p, b, x, n, d, ld, q_begin, n_query, s, ev0, ev1, rows_out);
   }
+}
+
+// Second tier of the bf16 engine (pruned mode).  Its certificate is ~4x looser than the float32 engine's relative to
+// ||q|| ||c||; how many queries it rejects depends on the data (508 of 1M planted cells at a margin of 6 ranks, 76543 of
+// 10M x 4k at a margin of 10: 7 s of float64 cell scans).  The rejected queries alone -- grouped by cell into query
+// blocks of their own -- are swept again by the FLOAT32 engine over a float32 image of the same cell-sorted rows (same
+// cell tables, same sweep orders), re-ranked and certified with the float32 bound; what fails that too goes to the
+// float64 scan as before.  Cost: one image (0.7 ms per million rows) + the float32 sweep of < 1 % of the queries.
+#define T2_DBG(line)                                                                 \
+  do {                                                                               \
+    if (getenv("SCAMD_KNN_T2_DEBUG")) {                                              \
+      hipError_t e_ = hipStreamSynchronize(s);                                       \
+      fprintf(stderr, "[knn tier2] line %d done (%s)\n", (int)(line), hipGetErrorString(e_)); \
+      fflush(stderr);                                                                \
+    }                                                                                \
+  } while (0)
+static int run_ivf_tier2(const KnnPlan& p, const KnnBuffers& b, const float* x, int64_t n, int d, int64_t ld,
+                         int64_t q_begin, int64_t n_query, int k, double cert_scale, int n_flag, int64_t rows,
+                         int32_t* out_idx, double* out_dist, hipStream_t s, int* n_flag2_host) {
+  using C = RegCfg<25, 64, false>;
+  const int nc = p.n_cells;
+  int* cell_map = b.cell_ints + 2 * nc;
+  int* tile0 = b.cell_ints + 7 * nc;
+  int* ntiles = reinterpret_cast<int*>(b.sums);
+  int* cnt2 = b.t2_ints;
+  int* slot_off2 = b.t2_ints + nc;
+  int* ctr2 = b.t2_ints + 2 * nc;  // [0] still uncertified, [2..3] / [4..5] pair counters of the second sweep (not reported)
+  *n_flag2_host = 0;
+  SCAMD_HIP_CHECK(hipMemsetAsync(cnt2, 0, sizeof(int) * nc, s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(ctr2, 0, sizeof(int) * 8, s));
+  hipLaunchKernelGGL(ivf_t2_count_kernel, dim3((unsigned)ceil_div(n_flag, 256)), dim3(256), 0, s, b.flag_list, n_flag, q_begin,
+                     b.labels, cell_map, cnt2, b.t2_cell, b.t2_pos);
+  SCAMD_LAUNCH_CHECK();
+  T2_DBG(__LINE__);
+  std::vector<int> h_cnt(nc), h_slot_off(nc), h_block_cell;
+  SCAMD_HIP_CHECK(hipMemcpyAsync(h_cnt.data(), cnt2, sizeof(int) * nc, hipMemcpyDeviceToHost, s));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+  int64_t slots = 0;
+  for (int c = 0; c < nc; ++c) {
+    h_slot_off[c] = (int)slots;
+    const int nb = (h_cnt[c] + 127) / 128;
+    for (int t = 0; t < nb; ++t) h_block_cell.push_back(c);
+    slots += (int64_t)nb * 128;
+  }
+  const int n_blocks = (int)h_block_cell.size();
+  if (n_blocks == 0) return SCAMD_OK;
+  SCAMD_REQUIRE(slots <= p.n_slot_max, SCAMD_EWORKSPACE, "knn: second-tier query layout exceeds its bound");
+  SCAMD_HIP_CHECK(hipMemcpyAsync(slot_off2, h_slot_off.data(), sizeof(int) * nc, hipMemcpyHostToDevice, s));
+  SCAMD_HIP_CHECK(hipMemcpyAsync(b.block_cell, h_block_cell.data(), sizeof(int) * n_blocks, hipMemcpyHostToDevice, s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.qpos, 0xff, sizeof(int) * slots, s));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(s));  // the host vectors must outlive their copies
+  hipLaunchKernelGGL(ivf_t2_fill_kernel, dim3((unsigned)ceil_div(n_flag, 256)), dim3(256), 0, s, b.flag_list, n_flag, b.t2_cell,
+                     b.t2_pos, slot_off2, b.qrow, b.qpos);
+  SCAMD_LAUNCH_CHECK();
+  T2_DBG(__LINE__);
+  hipLaunchKernelGGL(knn_iota_kernel, dim3((unsigned)ceil_div(n_blocks, 256)), dim3(256), 0, s, b.block_perm, n_blocks);
+  SCAMD_LAUNCH_CHECK();
+  T2_DBG(__LINE__);
+  {
+    const int blocks = (int)std::min<int64_t>((rows + 3) / 4, 256 * 16);
+    hipLaunchKernelGGL(ivf_pack_image_kernel, dim3(blocks), dim3(256), 0, s, x, b.mu, d, ld, 25, C::HP, C::DPL, rows, b.perm,
+                       b.labels, cell_map, b.cent, b.xp2, b.cmax, b.radius_bits, 0);
+    SCAMD_LAUNCH_CHECK();
+  T2_DBG(__LINE__);
+  }
+  auto kern = knn_select_reg_kernel<25, 64, 3, true, false>;
+  const size_t lds = C::LDS_BYTES + 64;
+  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+  IvfArgs iv;
+  iv.qpos = b.qpos;
+  iv.block_cell = b.block_cell;
+  iv.cell_tile0 = tile0;
+  iv.cell_ntiles = ntiles;
+  iv.centers = b.cent;
+  iv.radius = reinterpret_cast<const float*>(b.radius_bits);
+  iv.order = b.cell_order;
+  iv.order_lb2 = b.cell_lb2;
+  iv.perm = b.perm;
+  iv.pairs = reinterpret_cast<unsigned long long*>(ctr2 + 2);
+  iv.n_cells = nc;
+  iv.dc = d;
+  iv.d = d;
+  iv.block_perm = b.block_perm;
+  iv.prepass_tiles = 16;
+  iv.debug_no_insert = 0;
+  iv.trace = nullptr;
+  const int thr_rank = std::min(32, std::max(1, k + 6));
+  hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(C::NT), lds, s, b.xp2, (int)(rows / 64), rows, q_begin, thr_rank, b.cand_idx,
+                     b.cand_tau, iv);
+  SCAMD_LAUNCH_CHECK();
+  T2_DBG(__LINE__);
+  hipLaunchKernelGGL(knn_rerank_kernel<32>, dim3((unsigned)ceil_div(n_flag, 4)), dim3(256), 0, s, x, b.mu, n, d, ld, q_begin,
+                     n_query, k, b.cand_idx, b.cand_tau, b.cmax, cert_scale, CERT_K_F32, 0.0, out_idx, out_dist, b.kth_d2,
+                     b.flag_list2, ctr2, (const int*)b.flag_list, n_flag);
+  SCAMD_LAUNCH_CHECK();
+  T2_DBG(__LINE__);
+  SCAMD_HIP_CHECK(hipMemcpyAsync(n_flag2_host, ctr2, sizeof(int), hipMemcpyDeviceToHost, s));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+  return SCAMD_OK;
 }
 
 }  // namespace scamd
@@ -1879,6 +2023,7 @@ extern "C" float scamd_knn_last_select_ms(void) { return g_last_select_ms; }
 extern "C" double scamd_knn_last_select_pairs(void) { return g_last_select_pairs; }
 extern "C" double scamd_knn_last_select_prepass_pairs(void) { return g_last_select_prepass_pairs; }
 extern "C" int scamd_knn_last_select_engine(void) { return g_last_select_engine; }
+extern "C" int scamd_knn_last_second_tier_queries(void) { return g_last_second_tier; }
 
 extern "C" size_t scamd_knn_workspace_bytes(int64_t n, int d, int64_t n_query, int k) {
   KnnPlan p;
@@ -1931,12 +2076,13 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
     }
     SCAMD_LAUNCH_CHECK();
   }
+  int64_t ivf_rows = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   SCAMD_HIP_CHECK(hipEventCreate(&ev0));
   SCAMD_HIP_CHECK(hipEventCreate(&ev1));
   int rc;
   if (p.ivf) {
-    rc = dispatch_ivf(p, b, x, n, d, ld_x, q_begin, n_query, s, ev0, ev1);
+    rc = dispatch_ivf(p, b, x, n, d, ld_x, q_begin, n_query, s, ev0, ev1, &ivf_rows);
   } else {
     SCAMD_HIP_CHECK(hipEventRecord(ev0, s));
     rc = dispatch_select(p, b, q_begin, s);
@@ -1952,7 +2098,7 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
 #define RERANK(KP_)                                                                              \
   hipLaunchKernelGGL(knn_rerank_kernel<KP_>, dim3(blocks), dim3(256), 0, s, x, b.mu, n, d, ld_x, q_begin, \
                      n_query, k, b.cand_idx, b.cand_tau, b.cmax, cert_scale, p.b3 ? CERT_K_B3 : CERT_K_F32, p.b3 ? CERT_K2_B3 : 0.0, out_idx, out_dist,  \
-                     b.kth_d2, b.flag_list, b.counters)
+                     b.kth_d2, b.flag_list, b.counters, (const int*)nullptr, 0)
     if (p.KP == 32) RERANK(32);
     else if (p.KP == 64) RERANK(64);
     else RERANK(128);
@@ -1976,7 +2122,24 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
     g_last_select_prepass_pairs = p.ivf ? (double)pre : 0.0;
     g_last_select_engine = p.b3 ? 1 : 0;
   }
-  const int n_flag = h_counters[0];
+  int n_flag = h_counters[0];
+  const int* flag_list = b.flag_list;
+  g_last_second_tier = 0;
+  if (p.ivf && p.b3) {
+    // second tier: the float32 engine on what the bf16 engine's certificate rejected (SCAMD_KNN_TIER2_MIN, default 256
+    // queries: below that the float64 scan of a few queries is cheaper than a second image)
+    const char* e = getenv("SCAMD_KNN_TIER2_MIN");
+    const int t2_min = e ? atoi(e) : 256;
+    if (n_flag > t2_min) {
+      int n_flag2 = 0;
+      rc = run_ivf_tier2(p, b, x, n, d, ld_x, q_begin, n_query, k, cert_scale, n_flag, ivf_rows, out_idx, out_dist, s,
+                         &n_flag2);
+      if (rc != SCAMD_OK) return rc;
+      g_last_second_tier = n_flag;
+      n_flag = n_flag2;
+      flag_list = b.flag_list2;
+    }
+  }
   if (n_fallback_host) *n_fallback_host = n_flag;
   for (int begin = 0; begin < n_flag; begin += FALLBACK_CHUNK) {
     int count = std::min(FALLBACK_CHUNK, n_flag - begin);
@@ -1985,16 +2148,16 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
       // cell tables of run_ivf_select (same carving): tile0 = cell_ints + 7 nc, ntiles = the recycled sums buffer
       const int nc = p.n_cells;
       hipLaunchKernelGGL(knn_fallback_scan_cells_kernel, dim3(std::min(nc, 64), count), dim3(256), 0, s, x, d, ld_x, q_begin,
-                         b.flag_list, begin, b.kth_d2, b.scratch_d, b.scratch_i, b.fb_counts, b.cent,
+                         flag_list, begin, b.kth_d2, b.scratch_d, b.scratch_i, b.fb_counts, b.cent,
                          reinterpret_cast<const float*>(b.radius_bits), b.cell_ints + 7 * nc,
                          reinterpret_cast<const int*>(b.sums), b.perm, nc);
     } else {
       const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(FALLBACK_ROW_CHUNKS, n / 2048));
       hipLaunchKernelGGL(knn_fallback_scan_kernel, dim3(chunks, count), dim3(256), 0, s, x, n, d, ld_x, q_begin,
-                         b.flag_list, begin, b.kth_d2, b.scratch_d, b.scratch_i, b.fb_counts);
+                         flag_list, begin, b.kth_d2, b.scratch_d, b.scratch_i, b.fb_counts);
     }
     SCAMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(knn_fallback_rank_kernel, dim3(count), dim3(256), 0, s, k, b.flag_list, begin, b.scratch_d,
+    hipLaunchKernelGGL(knn_fallback_rank_kernel, dim3(count), dim3(256), 0, s, k, flag_list, begin, b.scratch_d,
                        b.scratch_i, b.fb_counts, out_idx, out_dist, b.counters + 1);
     SCAMD_LAUNCH_CHECK();
   }

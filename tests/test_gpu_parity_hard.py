@@ -246,6 +246,38 @@ def test_chain_100k_vs_cpu_chain():
     assert par["knn_rows_equal_end_to_end"] > 0.999
 
 
+def test_knn_second_tier_of_the_bf16_engine(K, monkeypatch):
+    """pruned search, bf16 engine: queries its (looser) certificate rejects are re-done by the float32 engine before
+    anything reaches the float64 scan.  A small threshold margin and an offset embedding (norms far larger than the
+    neighbour distances) provoke thousands of rejections; the result must still be the brute-force one, bit for bit."""
+    from scanpy_amd import _lib
+    from scanpy_amd.datasets import blobs_embedding
+
+    lib = _lib.load()
+    n, k = 100_000, 15
+    x, _ = blobs_embedding(n, 50, n_types=20, seed=11)
+    x = x + np.float32(40.0)
+    xd = _dev(x)
+    monkeypatch.setenv("SCAMD_KNN_IVF", "0")
+    i0, d0, _ = K.knn(xd, k)
+    monkeypatch.setenv("SCAMD_KNN_IVF", "1")
+    monkeypatch.setenv("SCAMD_KNN_THR_MARGIN", "2")
+    monkeypatch.setenv("SCAMD_KNN_TIER2_MIN", "0")
+    i1, d1, nf1 = K.knn(xd, k)
+    t2 = int(lib.scamd_knn_last_second_tier_queries())
+    print(f"second tier: {t2} queries re-done by the float32 engine, {nf1} left for the float64 scan")
+    assert int(lib.scamd_knn_last_select_engine()) == 1 and t2 > 0 and nf1 < t2
+    np.testing.assert_array_equal(i0.cpu().numpy(), i1.cpu().numpy())
+    np.testing.assert_array_equal(d0.cpu().numpy(), d1.cpu().numpy())
+    # every query through both tiers and the float64 scan (cert_scale = 1e30 rejects everything twice)
+    m = 12000
+    i2, d2, n2 = K.knn(xd[:m].contiguous(), k, cert_scale=1e30)
+    i3, d3, _ = K.knn(xd[:m].contiguous(), k)
+    assert n2 == m and int(lib.scamd_knn_last_select_engine()) == 1
+    np.testing.assert_array_equal(i2.cpu().numpy(), i3.cpu().numpy())
+    np.testing.assert_array_equal(d2.cpu().numpy(), d3.cpu().numpy())
+
+
 def test_knn_forced_fallback_through_the_cell_scan(K, monkeypatch):
     """every query forced through the float64 fallback (cert_scale = 1e30) in cell-pruned mode: the fallback scans only
     the cells whose ball reaches the query's bound -- same lists as the certified run, bit for bit"""
