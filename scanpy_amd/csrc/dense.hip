@@ -529,7 +529,15 @@ static void dense_carve(Workspace& ws, int64_t g, int b, DenseBuffers* d) {
 
 static int dense_block_size(int64_t g, int k) {
   if (g <= DB_MAX) return (int)g;  // the whole space: one Rayleigh-Ritz is the full decomposition
-  int b = (std::max(k + 64, 2 * k) + 15) / 16 * 16;
+  // k + 32 vectors, rounded up to 16 (round 2: max(k + 64, 2 k) = 128 at k = 50).  The one-workgroup kernels of an outer
+  // iteration (Jacobi b^3, Cholesky b^3) dominate the solve; measured at 1M x 2k, k = 50: b = 128 / 112 / 96 -> fit
+  // 15.96 / 14.85 / 13.76 ms on the planted matrix (same 11 GEMMs, residual 2e-11 .. 4e-11, loadings equal to 1e-10)
+  // and 40.8 / 37.8 / 34.9 ms on the structure-less one (8 / 9 / 10 outer iterations, each cheaper).
+  int b = (k + 32 + 15) / 16 * 16;
+  if (const char* e = getenv("SCAMD_DENSE_BLOCK")) {  // experiments: block size of the subspace iteration (>= k + 32)
+    const int v = atoi(e);
+    if (v >= k + 32 && v % 16 == 0) b = v;
+  }
   b = std::min<int>(b, DB_MAX);
   return (int)std::min<int64_t>(b, g);
 }

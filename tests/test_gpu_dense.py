@@ -91,7 +91,7 @@ def test_eigh_topk_unsupported_shapes(K):
 
     a = _dev(np.eye(150))
     with pytest.raises(ScamdError):
-        K.eigh_topk(a, 20)  # 128 < g < 2 * block
+        K.eigh_topk(a, 50)  # 128 < g < 2 * block (block = k + 32 rounded up to 16 = 96)
     with pytest.raises(ScamdError):
         K.eigh_topk(_dev(np.eye(1000)), 110)  # k beyond the block
 
