@@ -68,8 +68,8 @@ class _PinnedUploader:
     staging buffers (numpy releases the GIL for the copy) while piece i is DMA'd out of the other on a copy stream.
     The staging buffers are allocated once per process (page-locking costs more than the copy)."""
 
-    PIECE = 32 << 20
-    THREADS = 8
+    PIECE = int(os.environ.get("SCAMD_UPLOAD_PIECE_MB", "32")) << 20
+    THREADS = int(os.environ.get("SCAMD_UPLOAD_THREADS", "8"))
 
     def __init__(self) -> None:
         self._stage = None
