@@ -117,7 +117,7 @@ class _PinnedUploader:
                 out_b[lo:hi].copy_(stage[:hi - lo], non_blocking=True)
                 self._events[slot].record(self._stream)
         cur.wait_stream(self._stream)
-        out.record_stream(cur)
+        out.record_stream(self._stream)  # written on the copy stream, allocated (and later freed) on the current one
         return out
 
 

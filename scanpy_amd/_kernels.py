@@ -8,9 +8,18 @@ import torch
 from . import _lib
 from ._device import ptr, require_gpu, stream_ptr, workspace_pool
 
+import os as _os
+
+# SCAMD_POISON_WORKSPACE=1: the shared scratch buffer is filled with 0xAB bytes before every C call, so that a kernel
+# which reads scratch it did not write fails the same way on every box (round 3: such a read showed up as a device
+# fault on some boxes only)
+_POISON = _os.environ.get("SCAMD_POISON_WORKSPACE") == "1"
+
 
 def _ws(nbytes: int, dev: torch.device):
     buf = workspace_pool.get(nbytes, dev)
+    if _POISON:  # debug: every entry point must initialise what it reads (a dirty workspace is the normal case)
+        buf.fill_(0xAB)
     return buf, C.c_size_t(buf.numel())
 
 
