@@ -443,44 +443,6 @@ __global__ __launch_bounds__(256) void ld_move_kernel(
           }
         }
       }
-    } else if (G == 64) {
-      // rows beyond the workgroup tables: all-pairs compare through readlane
-      const int lane = sub;
-      for (int cb = 0; cb < deg; cb += 64) {
-        const int e = cb + lane;
-        int u = (e < deg) ? indices[beg + e] : -1;
-        const int c = (u >= 0 && u != v) ? comm[u] : -1;
-        long long sum = 0;
-        for (int db = 0; db < deg; db += 64) {
-          const int e2 = db + lane;
-          int c2 = -1;
-          long long w2 = 0;
-          if (e2 < deg) {
-            const int u2 = indices[beg + e2];
-            if (u2 != v) {
-              c2 = (db == cb) ? c : comm[u2];
-              w2 = wq[beg + e2];
-            }
-          }
-          const int cnt = min(64, deg - db);
-          for (int t = 0; t < cnt; ++t) {
-            const int ct = __builtin_amdgcn_readlane(c2, t);
-            const long long wt = readlane_i64(w2, t);
-            if (ct == c) sum += wt;
-          }
-        }
-        if (c >= 0) {
-          if (c == a) {
-            w_own = sum;
-          } else {
-            Cand x;
-            x.val = (double)sum - g * kv * (double)(long long)Ktot[c];
-            x.c = c;
-            x.pr = prio(c, seed);
-            if (cand_better(x, best)) best = x;
-          }
-        }
-      }
     }
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) {
@@ -977,46 +939,6 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
             if (ok_target && gain >= 0.0) {
               Cand x;
               x.val = inv_beta > 0.0 ? gain * inv_beta + refine_noise(v, c, round, seed) : gain;
-              x.c = c;
-              x.pr = prio(c, seed);
-              if (cand_better(x, best)) best = x;
-            }
-          }
-        }
-      } else if (G == 64) {
-        const int lane = sub;
-        for (int cb = 0; cb < deg; cb += 64) {
-          const int e = cb + lane;
-          int u = (e < deg) ? indices[beg + e] : -1;
-          const int c = (u >= 0 && u != v && comm[u] == a) ? ref[u] : -1;
-          long long sum = 0;
-          for (int db = 0; db < deg; db += 64) {
-            const int e2 = db + lane;
-            int c2 = -1;
-            long long w2 = 0;
-            if (e2 < deg) {
-              const int u2 = indices[beg + e2];
-              if (u2 != v && comm[u2] == a) {
-                c2 = (db == cb) ? c : ref[u2];
-                w2 = wq[beg + e2];
-              }
-            }
-            const int cnt = min(64, deg - db);
-            for (int t = 0; t < cnt; ++t) {
-              const int ct = __builtin_amdgcn_readlane(c2, t);
-              const long long wt = readlane_i64(w2, t);
-              if (ct == c) sum += wt;
-            }
-          }
-          if (c >= 0 && c != v) {
-            const double Kr = (double)(long long)Kref[c];
-            const bool single = refsize[c] == 1;
-            const bool ok_target = (!single || lm_class(c, salt, n_cls) != round) &&
-                                   ((double)(long long)Eref[c] >= g * Kr * (KC - Kr));  // target well connected
-            const double gain = (double)sum - g * kv * Kr;
-            if (ok_target && gain >= 0.0) {
-              Cand x;
-              x.val = gain;
               x.c = c;
               x.pr = prio(c, seed);
               if (cand_better(x, best)) best = x;
@@ -2028,7 +1950,7 @@ struct CoarseBuf {
 struct LeidenBuffers {
   long long* wq0; long long* k0;
   CoarseBuf cb[2];
-  int* comm; int* comm_next; int* csize; int* csize_next; unsigned long long* Ktot; unsigned long long* Ktot_next;
+  int* comm; int* csize; unsigned long long* Ktot;
   int* cls_lists; int* rlist; int* touched; int* hub_list;
   int* ref; int* target; int* refsize; unsigned long long* Kref; unsigned long long* Eref; long long* a_in;
   int* flag; int64_t* newid; int64_t* scan_tmp; int* cid; int* rep; int* comm_tmp;
@@ -2051,11 +1973,8 @@ static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b
     b->cb[i].k = ws.take<long long>(N);
   }
   b->comm = ws.take<int>(N);
-  b->comm_next = ws.take<int>(N);
   b->csize = ws.take<int>(N);
-  b->csize_next = ws.take<int>(N);
   b->Ktot = ws.take<unsigned long long>(N);
-  b->Ktot_next = ws.take<unsigned long long>(N);
   b->cls_lists = ws.take<int>(MAX_CLASSES * N);  // class lists of a sweep (local moving) / of the refinement
   b->rlist = ws.take<int>(N);
   b->hub_list = ws.take<int>(N);

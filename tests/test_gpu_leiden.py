@@ -143,6 +143,25 @@ def test_leiden_coarse_row_tiers_agree(K, monkeypatch, env):
     assert np.array_equal(m0.cpu().numpy(), m1.cpu().numpy())
 
 
+def test_leiden_small_levels_in_one_workgroup_vs_separate_kernels(K, monkeypatch, pbmc68k):
+    """levels of <= 1024 nodes run in ONE workgroup (ld_small_levels_kernel: 8 nodes at a time) -- a different schedule
+    from the class sub-rounds of the separate kernels, so the partitions need not be equal; both must reach the oracle's
+    modularity on the fixture (which is such a level from the start) and both must be reproducible"""
+    adj = pbmc68k["connectivities"].astype(np.float32)
+    ip, ix, w, n = _graph_dev(adj)
+    _, q_oracle = ol.leiden(adj, seed=0)
+    out = {}
+    for small in ("1", "0"):
+        monkeypatch.setenv("SCAMD_LEIDEN_SMALL", small)
+        m0, q0, nc0 = K.leiden(ip, ix, w, n, seed=0)
+        m1, q1, _ = K.leiden(ip, ix, w, n, seed=0)
+        assert q0 == q1 and np.array_equal(m0.cpu().numpy(), m1.cpu().numpy())
+        assert abs(q0 - ol.modularity(adj, m0.cpu().numpy())) < 1e-8
+        out[small] = (q0, nc0)
+    print("one workgroup:", out["1"], "separate kernels:", out["0"], "oracle Q", q_oracle)
+    assert min(out["1"][0], out["0"][0]) > q_oracle - 3e-3
+
+
 def test_leiden_quarter_wave_kernels_agree(K, monkeypatch):
     """four-vertices-per-wave and wave-per-vertex decision kernels implement the same rule: same partition"""
     adj, _ = _blob_graph(6000, 12, seed=4)
