@@ -21,10 +21,37 @@ namespace scamd {
 // are sharded over ranks (the row-sharded path computes the same integers with torch and all-reduces them:
 // scanpy_amd/_pipeline.py:fixed_point_distance_sum) -- a float64 atomic sum made the sharded rows differ from the
 // single-device rows in the last bit whenever the floor was hit.
+// (both reductions read 16 B per lane with four loads in flight: the scalar grid-stride loops ran at 0.55 TB/s, one
+// dependent load per trip -- 109 us each for the 60 MB of the 1M x 15 problem)
+struct FssSpan {  // [0, head) and [tail, total) scalar, [head, tail) as float4 (the pointer need not be 16-byte aligned)
+  int64_t head, n4;
+};
+__device__ __forceinline__ FssSpan fss_span(const float* d, int64_t total) {
+  FssSpan sp;
+  sp.head = (int64_t)(((16u - (unsigned)(reinterpret_cast<uintptr_t>(d) & 15u)) & 15u) >> 2);
+  if (sp.head > total) sp.head = total;
+  sp.n4 = (total - sp.head) >> 2;
+  return sp;
+}
 __global__ void fss_max_kernel(const float* __restrict__ d, int64_t total, unsigned int* __restrict__ mx_bits) {
+  const FssSpan sp = fss_span(d, total);
+  const float4* d4 = reinterpret_cast<const float4*>(d + sp.head);
   float m = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
-    m = fmaxf(m, d[i]);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < sp.n4; i += 4 * stride) {
+    const float4 a = d4[i], b = d4[i + stride], c = d4[i + 2 * stride], e = d4[i + 3 * stride];
+    m = fmaxf(m, fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w))));
+    m = fmaxf(m, fmaxf(fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, c.w)), fmaxf(fmaxf(e.x, e.y), fmaxf(e.z, e.w))));
+  }
+  for (; i < sp.n4; i += stride) {
+    const float4 a = d4[i];
+    m = fmaxf(m, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+  }
+  if (blockIdx.x == 0) {  // the unaligned ends
+    for (int64_t q = threadIdx.x; q < sp.head; q += blockDim.x) m = fmaxf(m, d[q]);
+    for (int64_t q = sp.head + 4 * sp.n4 + threadIdx.x; q < total; q += blockDim.x) m = fmaxf(m, d[q]);
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   // (distances are >= 0: the bit patterns of non-negative floats order like the values)
@@ -41,9 +68,30 @@ __device__ __forceinline__ int fss_sum_scale_bits(float mx, int64_t total) {
 __global__ void fss_sum_kernel(const float* __restrict__ d, int64_t total, const unsigned int* __restrict__ mx_bits,
                                unsigned long long* __restrict__ isum) {
   const double scale = ldexp(1.0, fss_sum_scale_bits(__uint_as_float(*mx_bits), total));
+  const FssSpan sp = fss_span(d, total);
+  const float4* d4 = reinterpret_cast<const float4*>(d + sp.head);
   long long s = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
-    s += llrint((double)d[i] * scale);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+#define FSS_ADD4(v) \
+  s += llrint((double)(v).x * scale) + llrint((double)(v).y * scale) + llrint((double)(v).z * scale) + \
+       llrint((double)(v).w * scale)
+  for (; i + 3 * stride < sp.n4; i += 4 * stride) {
+    const float4 a = d4[i], b = d4[i + stride], c = d4[i + 2 * stride], e = d4[i + 3 * stride];
+    FSS_ADD4(a);
+    FSS_ADD4(b);
+    FSS_ADD4(c);
+    FSS_ADD4(e);
+  }
+  for (; i < sp.n4; i += stride) {
+    const float4 a = d4[i];
+    FSS_ADD4(a);
+  }
+#undef FSS_ADD4
+  if (blockIdx.x == 0) {
+    for (int64_t q = threadIdx.x; q < sp.head; q += blockDim.x) s += llrint((double)d[q] * scale);
+    for (int64_t q = sp.head + 4 * sp.n4 + threadIdx.x; q < total; q += blockDim.x) s += llrint((double)d[q] * scale);
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if ((threadIdx.x & 63) == 0 && s != 0) atomicAdd(isum, (unsigned long long)s);
@@ -56,6 +104,18 @@ __global__ void fss_sum_final_kernel(const unsigned long long* __restrict__ isum
 // one thread per row
 // (row shards: the rows are rows row_begin .. row_begin + n - 1 of an n_total-row problem; idx holds GLOBAL row ids and
 // *sum_all is the sum of all n_total * k distances)
+//
+// The bisection is umap's, decision for decision, but most of its exponentials are float32.  The reference evaluates
+// psum(mid) = sum_j exp(-(d_j - rho) / mid) in float64 and looks at two things only: |psum - target| < 1e-5 (stop) and
+// psum > target (direction).  A float32 evaluation with float64 accumulation is within E = (k - 1) * 1e-6 of the float64
+// one (per term: the rounded 1 / mid and the product move the argument x by 1.2e-7 relative, x e^-x <= 0.37; v_exp_f32 and
+// its log2(e) scaling add 2 ulp of a value <= 1: below 2e-7 in all), so whenever |psum32 - target| > 1e-5 + E both
+// answers are those of the float64 evaluation.  Phase 1 bisects on float32 sums until a row first comes closer than
+// that; phase 2 re-evaluates that step and every later one in float64 exactly as before.  Rows typically take 15-25
+// steps, the last one to three of them in phase 2: the kernel spent 0.99 ms in float64 exp at 1M x 15.
+// KREG > 0: k <= KREG and the row's d_j - rho live in registers (the loop re-read them through the L1, a 60-byte stride
+// between lanes: 30 cache lines per load instruction).
+template <int KREG>
 __global__ void fss_sigma_kernel(const int* __restrict__ idx, const float* __restrict__ dist, int64_t n,
                                  int k, const double* __restrict__ sum_all, float* __restrict__ sigma_out,
                                  float* __restrict__ rho_out, float* __restrict__ w,
@@ -68,24 +128,90 @@ __global__ void fss_sigma_kernel(const int* __restrict__ idx, const float* __res
   float rho = 0.f;
   double rowsum = 0.0;
   bool found = false;
-  for (int j = 0; j < k; ++j) {
-    float v = di[j];
-    rowsum += (double)v;
-    if (!found && v > 0.f) {
-      rho = v;
-      found = true;
+  float dreg[KREG > 0 ? KREG : 1];
+  if (KREG > 0) {
+#pragma unroll
+    for (int j = 0; j < KREG; ++j) {
+      const float v = j < k ? di[j] : 0.f;  // (a pad column adds 0 to the sum and is never the first positive one)
+      dreg[j] = v;
+      rowsum += (double)v;
+      if (!found && v > 0.f) {
+        rho = v;
+        found = true;
+      }
+    }
+  } else {
+    for (int j = 0; j < k; ++j) {
+      const float v = di[j];
+      rowsum += (double)v;
+      if (!found && v > 0.f) {
+        rho = v;
+        found = true;
+      }
     }
   }
-  const double target = log2((double)k);
-  double lo = 0.0, hi = INFINITY, mid = 1.0;
-  for (int it = 0; it < 64; ++it) {
-    double psum = 0.0;
-    for (int j = 1; j < k; ++j) {
-      float df = __fsub_rn(di[j], rho);
-      double dd = (double)df;
-      psum += (dd > 0.0) ? exp(-(dd / mid)) : 1.0;
+  float dmax = 0.f;  // largest d_j - rho of the row (j >= 1)
+  if (KREG > 0) {
+#pragma unroll
+    for (int j = 0; j < KREG; ++j) {
+      dreg[j] = j < k ? __fsub_rn(dreg[j], rho) : -1.f;  // (pad columns: never > 0, never counted -- see `j < k` below)
+      if (j >= 1 && j < k) dmax = fmaxf(dmax, dreg[j]);
     }
-    if (fabs(psum - target) < 1e-5) break;
+  } else {
+    for (int j = 1; j < k; ++j) dmax = fmaxf(dmax, __fsub_rn(di[j], rho));
+  }
+  const double target = log2((double)k);
+  const double undecided = 1e-5 + 1e-6 * (double)(k - 1);
+  double lo = 0.0, hi = INFINITY, mid = 1.0;
+  int it = 0;
+  bool done = false;
+  // phase 1: float32 terms
+  if (dmax < 1e30f) {
+    for (; it < 64; ++it) {
+      if (!(mid > 1e-30 && mid < 1e30)) break;
+      const float inv = (float)(1.0 / mid);
+      double psum = 0.0;
+      if (KREG > 0) {
+#pragma unroll
+        for (int j = 1; j < KREG; ++j)
+          if (j < k) psum += (double)(dreg[j] > 0.f ? __expf(-(dreg[j] * inv)) : 1.f);
+      } else {
+        for (int j = 1; j < k; ++j) {
+          const float df = __fsub_rn(di[j], rho);
+          psum += (double)(df > 0.f ? __expf(-(df * inv)) : 1.f);
+        }
+      }
+      if (fabs(psum - target) <= undecided) break;  // too close for float32: this step again, in float64
+      if (psum > target) {
+        hi = mid;
+        mid = (lo + hi) / 2.0;
+      } else {
+        lo = mid;
+        if (hi == INFINITY) mid *= 2.0;
+        else mid = (lo + hi) / 2.0;
+      }
+    }
+  }
+  // phase 2: float64, the reference's loop from step `it` on
+  for (; it < 64 && !done; ++it) {
+    double psum = 0.0;
+    if (KREG > 0) {
+#pragma unroll
+      for (int j = 1; j < KREG; ++j)
+        if (j < k) {
+          const double dd = (double)dreg[j];
+          psum += (dd > 0.0) ? exp(-(dd / mid)) : 1.0;
+        }
+    } else {
+      for (int j = 1; j < k; ++j) {
+        const double dd = (double)__fsub_rn(di[j], rho);
+        psum += (dd > 0.0) ? exp(-(dd / mid)) : 1.0;
+      }
+    }
+    if (fabs(psum - target) < 1e-5) {
+      done = true;
+      break;
+    }
     if (psum > target) {
       hi = mid;
       mid = (lo + hi) / 2.0;
@@ -118,10 +244,60 @@ __global__ void fss_sigma_kernel(const int* __restrict__ idx, const float* __res
   }
   outcnt[i] = cnt;
 }
+static void launch_sigma(const int* idx, const float* dist, int64_t n, int k, const double* sum_all, float* sigma_out,
+                         float* rho_out, float* w, int* outcnt, int64_t row_begin, int64_t n_total, hipStream_t s) {
+  if (k <= 16)
+    hipLaunchKernelGGL(fss_sigma_kernel<16>, dim3(ceil_div(n, 128)), dim3(128), 0, s, idx, dist, n, k, sum_all, sigma_out,
+                       rho_out, w, outcnt, row_begin, n_total);
+  else
+    hipLaunchKernelGGL(fss_sigma_kernel<0>, dim3(ceil_div(n, 128)), dim3(128), 0, s, idx, dist, n, k, sum_all, sigma_out,
+                       rho_out, w, outcnt, row_begin, n_total);
+}
 
-// 16 lanes per directed slot (i, j): weight of the reverse edge, in-only degree of the target.  The target's row of k
-// neighbours is ONE coalesced read of the group (a thread per slot walked it entry by entry: 15 serial gathers per
-// thread, every one of them 64 different cache lines per wave -- 1.6 ms at 1M x 15 against 0.35 now).
+// Records of the reverse-edge lookup: row t's neighbour list as KP (id, weight) pairs in ONE aligned block (128 B for
+// k <= 16, pad pairs hold id -1).  The lookup "is i among t's neighbours, with which weight" is a random gather per
+// directed slot and the kernel's duration was that of its cache-line traffic: the two k-long rows of idx and w, 60 B
+// each at a 60 B stride, touch 1.47 lines of 128 B each on average -- 44M lines for the 15M slots of 1M x 15, 0.98 ms;
+// one record per slot is a third of that.
+template <int KP>
+__global__ __launch_bounds__(256) void fss_pack_kernel(const int* __restrict__ idx, const float* __restrict__ w,
+                                                       int64_t n, int k, int2* __restrict__ rec) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = q / KP;
+  const int sub = (int)(q - row * KP);
+  if (row >= n) return;
+  int2 p = make_int2(-1, 0);
+  if (sub < k) p = make_int2(idx[row * k + sub], __float_as_int(w[row * k + sub]));
+  rec[q] = p;
+}
+
+// KP lanes per directed slot (i, j): weight of the reverse edge, in-only degree of the target.  (A thread per slot
+// walked the target's list entry by entry: 15 serial gathers per thread, every one of them 64 different cache lines
+// per wave -- 1.6 ms at 1M x 15.)
+template <int KP>
+__global__ __launch_bounds__(256) void fss_recip_rec_kernel(const int* __restrict__ idx, const float* __restrict__ w,
+                                                            const int2* __restrict__ rec, int64_t n, int k,
+                                                            float* __restrict__ recw, int* __restrict__ in_only) {
+  const int sub = threadIdx.x & (KP - 1);
+  const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / KP;
+  const bool live = e < n * k;
+  const float we = live ? w[e] : 0.f;
+  const int t = live ? idx[e] : 0;
+  float r = 0.f;
+  if (we > 0.f) {
+    const int i = (int)(e / k);
+    const int2 p = rec[(int64_t)t * KP + sub];
+    if (p.x == i) r = __int_as_float(p.y);
+  }
+#pragma unroll
+  for (int o = KP / 2; o > 0; o >>= 1) r = fmaxf(r, __shfl_xor(r, o));
+  if (live && sub == 0) {
+    if (we > 0.f && r == 0.f) atomicAdd(&in_only[t], 1);
+    recw[e] = r;
+  }
+}
+
+// lists longer than a record (k > 32): 16 lanes per slot walk the target's rows of idx and w
 __global__ __launch_bounds__(256) void fss_recip_kernel(const int* __restrict__ idx, const float* __restrict__ w,
                                                         int64_t n, int k, float* __restrict__ recw,
                                                         int* __restrict__ in_only) {
@@ -152,10 +328,19 @@ __global__ void fss_rowcount_kernel(const int* __restrict__ outcnt, const int* _
   if (i < n) rowcnt[i] = outcnt[i] + in_only[i];
 }
 
+// where the next in-only entry of row t goes: after the row's own (out) entries.  One 64-bit counter per row, so that
+// the slot that appends to row t needs one atomic and nothing else of row t (it used to gather indptr[t], outcnt[t] and
+// a 32-bit cursor: three random reads per appended entry).
+__global__ void fss_cursor_kernel(const int64_t* __restrict__ indptr, const int* __restrict__ outcnt, int64_t n,
+                                  unsigned long long* __restrict__ cursor) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) cursor[i] = (unsigned long long)(indptr[i] + outcnt[i]);
+}
+
+// unsorted rows: (column, value bits) pairs, so that an appended entry is one 8-byte store
 __global__ void fss_fill_kernel(const int* __restrict__ idx, const float* __restrict__ w,
-                                const float* __restrict__ recw, const int* __restrict__ outcnt,
-                                const int64_t* __restrict__ indptr, int64_t n, int k, int* __restrict__ cursor,
-                                int* __restrict__ tmp_col, float* __restrict__ tmp_val, int mode) {
+                                const float* __restrict__ recw, const int64_t* __restrict__ indptr, int64_t n, int k,
+                                unsigned long long* __restrict__ cursor, int2* __restrict__ tmp, int mode) {
   // position of the slot among the stored (w > 0) slots of its row: a ballot over the wave's 64 consecutive slots, plus
   // -- for the row cut by the wave's first lane -- a ballot over the 64 slots before them (rows longer than that: the
   // entry-by-entry count).  The count used to be a loop of up to k - 1 serial loads per thread.
@@ -187,52 +372,33 @@ __global__ void fss_fill_kernel(const int* __restrict__ idx, const float* __rest
   // mode 2 (jaccard): (w + w^T) / 2
   const float val = mode == 0 ? __fsub_rn(__fadd_rn(we, r), __fmul_rn(we, r))
                               : (mode == 1 ? fmaxf(we, r) : 0.5f * (we + r));
-  tmp_col[p] = t;
-  tmp_val[p] = val;
+  tmp[p] = make_int2(t, __float_as_int(val));
   if (r == 0.f) {
-    const int slot = atomicAdd(&cursor[t], 1);
-    const int64_t pt = indptr[t] + outcnt[t] + slot;
-    tmp_col[pt] = (int)i;
-    tmp_val[pt] = mode == 2 ? 0.5f * we : we;
+    const int64_t pt = (int64_t)atomicAdd(&cursor[t], 1ull);
+    tmp[pt] = make_int2((int)i, __float_as_int(mode == 2 ? 0.5f * we : we));
   }
 }
 
-// one wave per row: rank sort by column index (columns are unique within a row).  Rows of up to 64 entries (all of them
-// on a kNN graph without hubs) are ranked from registers through readlane; the first version re-read the row from memory
-// once per entry, one serial load each.
-__global__ void fss_sortrows_kernel(const int64_t* __restrict__ indptr, int64_t n, const int* __restrict__ tmp_col,
-                                    const float* __restrict__ tmp_val, int* __restrict__ out_col,
-                                    float* __restrict__ out_val) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= n) return;
-  const int64_t base = indptr[row];
-  const int len = (int)(indptr[row + 1] - base);
-  if (len <= 64) {
-    const int c = lane < len ? tmp_col[base + lane] : 0x7fffffff;
-    const float v = lane < len ? tmp_val[base + lane] : 0.f;
-    int rank = 0;
-    for (int u = 0; u < len; ++u) {
-      const int cu = __builtin_amdgcn_readlane(c, u);
-      rank += (cu < c || (cu == c && u < lane)) ? 1 : 0;
-    }
-    if (lane < len) {
-      out_col[base + rank] = c;
-      out_val[base + rank] = v;
-    }
-    return;
-  }
-  // hub rows (the symmetrised kNN graph of the 1M planted matrix has rows of 1.4k entries): 64 elements are ranked at a
-  // time against the row read in coalesced chunks of 64, compared from registers.  Ranking them against the row read
-  // entry by entry from memory (len^2 / 64 dependent loads in ONE wave) WAS this kernel's duration: 1.4 ms, the other
-  // 999,990 rows done long before (11 waves per CU in flight on average, profiles/r02f_fuzzy_pmc1.csv).
+// Rows -> ascending column order (columns are unique within a row): every entry counts the entries of its row with a
+// smaller column.  A workgroup takes SR_ROWS consecutive rows; when their entries fit the LDS block (all but the
+// workgroups that hold a hub row) they are loaded once, coalesced, and ranked a THREAD PER ENTRY against the row in LDS
+// (neighbouring lanes sit in the same row and read the same word: broadcasts).  The kernel was a wave per row ranking
+// through readlane -- 25 of 64 lanes busy and a million waves of three dependent memory round trips each: 1.36 ms at
+// 1M x 15, the longest of the five kernels of the stage.
+constexpr int SR_ROWS = 32;
+constexpr int SR_CAP = 2048;
+
+// one wave, one row (hub rows: the symmetrised kNN graph of the 1M planted matrix has rows of 1.4k entries): 64 entries
+// are ranked at a time against the row read in coalesced chunks of 64, compared from registers
+__device__ __forceinline__ void fss_sort_row_wave(int64_t base, int len, int lane, const int2* __restrict__ tmp,
+                                                  int* __restrict__ out_col, float* __restrict__ out_val) {
   for (int e0 = 0; e0 < len; e0 += 64) {
     const int e = e0 + lane;
-    const int c = e < len ? tmp_col[base + e] : 0x7fffffff;
-    const float v = e < len ? tmp_val[base + e] : 0.f;
+    const int2 ce = e < len ? tmp[base + e] : make_int2(0x7fffffff, 0);
+    const int c = ce.x;
     int rank = 0;
     for (int u0 = 0; u0 < len; u0 += 64) {
-      const int cu_l = u0 + lane < len ? tmp_col[base + u0 + lane] : 0x7fffffff;
+      const int cu_l = u0 + lane < len ? tmp[base + u0 + lane].x : 0x7fffffff;
       const int cnt = min(64, len - u0);
       for (int t = 0; t < cnt; ++t) {
         const int cu = __builtin_amdgcn_readlane(cu_l, t);
@@ -241,8 +407,53 @@ __global__ void fss_sortrows_kernel(const int64_t* __restrict__ indptr, int64_t 
     }
     if (e < len) {
       out_col[base + rank] = c;
-      out_val[base + rank] = v;
+      out_val[base + rank] = __int_as_float(ce.y);
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void fss_sortrows_kernel(const int64_t* __restrict__ indptr, int64_t n,
+                                                           const int2* __restrict__ tmp, int* __restrict__ out_col,
+                                                           float* __restrict__ out_val) {
+  __shared__ int s_col[SR_CAP];
+  __shared__ int s_val[SR_CAP];
+  __shared__ int s_start[SR_ROWS + 1];
+  const int64_t r0 = (int64_t)blockIdx.x * SR_ROWS;
+  const int nr = n - r0 < SR_ROWS ? (int)(n - r0) : SR_ROWS;
+  const int64_t base = indptr[r0];
+  const int64_t total64 = indptr[r0 + nr] - base;
+  if (total64 <= SR_CAP) {  // (uniform over the workgroup)
+    const int total = (int)total64;
+    if ((int)threadIdx.x <= nr) s_start[threadIdx.x] = (int)(indptr[r0 + threadIdx.x] - base);
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+      const int2 ce = tmp[base + e];
+      s_col[e] = ce.x;
+      s_val[e] = ce.y;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+      int lo = 0, hi = nr;  // s_start[lo] <= e < s_start[hi]
+      while (hi - lo > 1) {
+        const int m = (lo + hi) >> 1;
+        if (s_start[m] <= e) lo = m;
+        else hi = m;
+      }
+      const int b = s_start[lo], en = s_start[lo + 1];
+      const int c = s_col[e];
+      int rank = 0;
+      for (int u = b; u < en; ++u) {
+        const int cu = s_col[u];
+        rank += (cu < c || (cu == c && u < e)) ? 1 : 0;
+      }
+      out_col[base + b + rank] = c;
+      out_val[base + b + rank] = __int_as_float(s_val[e]);
+    }
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  for (int r = threadIdx.x >> 6; r < nr; r += (int)(blockDim.x >> 6)) {
+    const int64_t rb = indptr[r0 + r];
+    fss_sort_row_wave(rb, (int)(indptr[r0 + r + 1] - rb), lane, tmp, out_col, out_val);
   }
 }
 
@@ -325,42 +536,60 @@ __global__ void count_positive_rows_kernel(const float* __restrict__ w, int64_t 
 }
 
 struct FuzzyBuffers {
-  float* w; float* recw; int* outcnt; int* in_only; int* cursor; int* rowcnt; int64_t* scan_tmp;
-  int* tmp_col; float* tmp_val; double* sum;
+  float* w; float* recw; int* outcnt; int* in_only; unsigned long long* cursor; int* rowcnt; int64_t* scan_tmp;
+  int2* tmp; double* sum;
 };
 
+// pairs per record of the reverse-edge lookup (0: lists too long for records)
+static int fuzzy_record_pairs(int k) { return k <= 16 ? 16 : (k <= 32 ? 32 : 0); }
+
 static void fuzzy_carve(Workspace& ws, int64_t n, int k, FuzzyBuffers* b) {
-  const size_t cap = (size_t)2 * n * (k > 1 ? k - 1 : 1);
+  // `tmp`: the unsorted rows, <= 2 n (k - 1) entries -- and, before they are written, the n records of the lookup
+  const size_t cap = std::max((size_t)2 * n * (k > 1 ? k - 1 : 1), (size_t)n * fuzzy_record_pairs(k));
   b->w = ws.take<float>((size_t)n * k);
   b->recw = ws.take<float>((size_t)n * k);
   b->outcnt = ws.take<int>((size_t)n);
   b->in_only = ws.take<int>((size_t)n);
-  b->cursor = ws.take<int>((size_t)n);
+  b->cursor = ws.take<unsigned long long>((size_t)n);
   b->rowcnt = ws.take<int>((size_t)n);
   b->scan_tmp = ws.take<int64_t>((size_t)scan_num_blocks(n) + 2);
-  b->tmp_col = ws.take<int>(cap);
-  b->tmp_val = ws.take<float>(cap);
+  b->tmp = ws.take<int2>(cap);
   b->sum = ws.take<double>(4);
 }
 
 // directed weights w (> 0 = present) on the kNN pattern -> symmetric CSR with sorted rows; mode = combine rule of
-// fss_fill_kernel
+// fss_fill_kernel.  b.in_only must be zero.
 static int symmetrise(const FuzzyBuffers& b, const int32_t* knn_idx, int64_t n, int k, int mode, int64_t* out_indptr,
                       int32_t* out_indices, float* out_data, int64_t* nnz_host, hipStream_t s) {
   const int64_t total = n * k;
-  hipLaunchKernelGGL(fss_recip_kernel, dim3(ceil_div(total, 16)), dim3(256), 0, s, knn_idx, b.w, n, k, b.recw,
-                     b.in_only);
+  const int kp = fuzzy_record_pairs(k);
+  if (kp == 16) {
+    hipLaunchKernelGGL(fss_pack_kernel<16>, dim3(ceil_div(n * 16, 256)), dim3(256), 0, s, knn_idx, b.w, n, k, b.tmp);
+    SCAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fss_recip_rec_kernel<16>, dim3(ceil_div(total * 16, 256)), dim3(256), 0, s, knn_idx, b.w, b.tmp, n,
+                       k, b.recw, b.in_only);
+  } else if (kp == 32) {
+    hipLaunchKernelGGL(fss_pack_kernel<32>, dim3(ceil_div(n * 32, 256)), dim3(256), 0, s, knn_idx, b.w, n, k, b.tmp);
+    SCAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fss_recip_rec_kernel<32>, dim3(ceil_div(total * 32, 256)), dim3(256), 0, s, knn_idx, b.w, b.tmp, n,
+                       k, b.recw, b.in_only);
+  } else {
+    hipLaunchKernelGGL(fss_recip_kernel, dim3(ceil_div(total, 16)), dim3(256), 0, s, knn_idx, b.w, n, k, b.recw,
+                       b.in_only);
+  }
   SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(fss_rowcount_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, b.outcnt, b.in_only, n,
                      b.rowcnt);
   SCAMD_LAUNCH_CHECK();
   int rc = exclusive_scan_i32_i64(b.rowcnt, n, out_indptr, b.scan_tmp, s);
   if (rc != SCAMD_OK) return rc;
-  hipLaunchKernelGGL(fss_fill_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, knn_idx, b.w, b.recw,
-                     b.outcnt, out_indptr, n, k, b.cursor, b.tmp_col, b.tmp_val, mode);
+  hipLaunchKernelGGL(fss_cursor_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, out_indptr, b.outcnt, n, b.cursor);
   SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(fss_sortrows_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, out_indptr, n, b.tmp_col,
-                     b.tmp_val, out_indices, out_data);
+  hipLaunchKernelGGL(fss_fill_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, knn_idx, b.w, b.recw, out_indptr, n,
+                     k, b.cursor, b.tmp, mode);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(fss_sortrows_kernel, dim3(ceil_div(n, SR_ROWS)), dim3(256), 0, s, out_indptr, n, b.tmp,
+                     out_indices, out_data);
   SCAMD_LAUNCH_CHECK();
   int64_t nnz = 0;
   SCAMD_HIP_CHECK(hipMemcpyAsync(&nnz, out_indptr + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
@@ -402,7 +631,6 @@ extern "C" int scamd_fuzzy_simplicial_set_f32(const int32_t* knn_idx, const floa
   const int64_t total = n * k;
   SCAMD_HIP_CHECK(hipMemsetAsync(b.sum, 0, 32, s));  // [0] sum (double), [1] fixed-point sum, [2] bits of the max
   SCAMD_HIP_CHECK(hipMemsetAsync(b.in_only, 0, sizeof(int) * n, s));
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.cursor, 0, sizeof(int) * n, s));
   {
     int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
     unsigned long long* isum = reinterpret_cast<unsigned long long*>(b.sum + 1);
@@ -414,8 +642,7 @@ extern "C" int scamd_fuzzy_simplicial_set_f32(const int32_t* knn_idx, const floa
     hipLaunchKernelGGL(fss_sum_final_kernel, dim3(1), dim3(1), 0, s, isum, mx_bits, total, b.sum);
     SCAMD_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(fss_sigma_kernel, dim3(ceil_div(n, 128)), dim3(128), 0, s, knn_idx, knn_dist, n, k, b.sum,
-                     out_sigma, out_rho, b.w, b.outcnt, (int64_t)0, n);
+  launch_sigma(knn_idx, knn_dist, n, k, b.sum, out_sigma, out_rho, b.w, b.outcnt, (int64_t)0, n, s);
   SCAMD_LAUNCH_CHECK();
   return symmetrise(b, knn_idx, n, k, 0, out_indptr, out_indices, out_data, nnz_host, s);
 }
@@ -434,8 +661,8 @@ extern "C" int scamd_fuzzy_weights_f32(const int32_t* knn_idx, const float* knn_
                     n_total < ((int64_t)1 << 31),
                 SCAMD_EINVAL, "fuzzy_weights: bad shape");
   if (n_local == 0) return SCAMD_OK;
-  hipLaunchKernelGGL(fss_sigma_kernel, dim3(ceil_div(n_local, 128)), dim3(128), 0, stream, knn_idx, knn_dist, n_local, k,
-                     sum_all_dev, out_sigma, out_rho, w, out_count, row_begin, n_total);
+  scamd::launch_sigma(knn_idx, knn_dist, n_local, k, sum_all_dev, out_sigma, out_rho, w, out_count, row_begin, n_total,
+                      stream);
   SCAMD_LAUNCH_CHECK();
   return SCAMD_OK;
 }
@@ -460,7 +687,7 @@ __global__ void fss_merge_count_kernel(const int* __restrict__ idx, const float*
 __global__ void fss_merge_fill_kernel(const int* __restrict__ idx, const float* __restrict__ w, int64_t n, int k,
                                       const int64_t* __restrict__ in_indptr, const int* __restrict__ in_src,
                                       const float* __restrict__ in_w, const int64_t* __restrict__ out_indptr,
-                                      int* __restrict__ tmp_col, float* __restrict__ tmp_val) {
+                                      int2* __restrict__ tmp) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int64_t p = out_indptr[i];
@@ -477,8 +704,7 @@ __global__ void fss_merge_fill_kernel(const int* __restrict__ idx, const float* 
       else hi = mid;
     }
     if (lo < e1 && in_src[lo] == t) r = in_w[lo];
-    tmp_col[p] = t;
-    tmp_val[p] = __fsub_rn(__fadd_rn(we, r), __fmul_rn(we, r));
+    tmp[p] = make_int2(t, __float_as_int(__fsub_rn(__fadd_rn(we, r), __fmul_rn(we, r))));
     ++p;
   }
   for (int64_t e = e0; e < e1; ++e) {
@@ -486,8 +712,7 @@ __global__ void fss_merge_fill_kernel(const int* __restrict__ idx, const float* 
     bool found = false;
     for (int j = 0; j < k; ++j) found |= (w[i * k + j] > 0.f && idx[i * k + j] == src);
     if (!found) {
-      tmp_col[p] = src;
-      tmp_val[p] = in_w[e];
+      tmp[p] = make_int2(src, __float_as_int(in_w[e]));
       ++p;
     }
   }
@@ -499,8 +724,7 @@ extern "C" size_t scamd_fuzzy_merge_workspace_bytes(int64_t n_local, int64_t cap
   Workspace ws(nullptr, 0);
   (void)ws.take<int>((size_t)n_local + 1);
   (void)ws.take<int64_t>((size_t)scan_num_blocks(std::max<int64_t>(n_local, 1)) + 2);
-  (void)ws.take<int>((size_t)cap);
-  (void)ws.take<float>((size_t)cap);
+  (void)ws.take<int2>((size_t)cap);
   return ws.used();
 }
 
@@ -521,8 +745,7 @@ extern "C" int scamd_fuzzy_merge_rows_f32(const int32_t* knn_idx, const float* w
   Workspace ws(workspace, workspace_bytes);
   int* rowcnt = ws.take<int>((size_t)n_local + 1);
   int64_t* scan_tmp = ws.take<int64_t>((size_t)scan_num_blocks(n_local) + 2);
-  int* tmp_col = ws.take<int>((size_t)cap);
-  float* tmp_val = ws.take<float>((size_t)cap);
+  int2* tmp = ws.take<int2>((size_t)cap);
   SCAMD_REQUIRE(workspace && ws.ok, SCAMD_EWORKSPACE, "fuzzy_merge: workspace %zu < required %zu", workspace_bytes, ws.used());
   hipStream_t s = stream;
   hipLaunchKernelGGL(fss_merge_count_kernel, dim3(ceil_div(n_local, 128)), dim3(128), 0, s, knn_idx, w, n_local, k,
@@ -536,10 +759,10 @@ extern "C" int scamd_fuzzy_merge_rows_f32(const int32_t* knn_idx, const float* w
   SCAMD_REQUIRE(nnz <= cap, SCAMD_ECAPACITY, "fuzzy_merge: %lld entries exceed the capacity %lld", (long long)nnz,
                 (long long)cap);
   hipLaunchKernelGGL(fss_merge_fill_kernel, dim3(ceil_div(n_local, 128)), dim3(128), 0, s, knn_idx, w, n_local, k,
-                     in_indptr, in_src, in_w, out_indptr, tmp_col, tmp_val);
+                     in_indptr, in_src, in_w, out_indptr, tmp);
   SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(fss_sortrows_kernel, dim3(ceil_div(n_local, 4)), dim3(256), 0, s, out_indptr, n_local, tmp_col,
-                     tmp_val, out_indices, out_data);
+  hipLaunchKernelGGL(fss_sortrows_kernel, dim3(ceil_div(n_local, SR_ROWS)), dim3(256), 0, s, out_indptr, n_local, tmp,
+                     out_indices, out_data);
   SCAMD_LAUNCH_CHECK();
   *nnz_host = nnz;
   SCAMD_HIP_CHECK(hipStreamSynchronize(s));
@@ -571,7 +794,6 @@ extern "C" int scamd_gauss_connectivities_f32(const int32_t* knn_idx, const floa
   SCAMD_REQUIRE(workspace && ws.ok, SCAMD_EWORKSPACE, "gauss: workspace %zu < required %zu", workspace_bytes, ws.used());
   hipStream_t s = stream;
   SCAMD_HIP_CHECK(hipMemsetAsync(b.in_only, 0, sizeof(int) * n, s));
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.cursor, 0, sizeof(int) * n, s));
   hipLaunchKernelGGL(gauss_sigma_kernel, dim3(ceil_div(n, 128)), dim3(128), 0, s, knn_idx, knn_dist, n, k, sigma_sq);
   SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(gauss_weight_kernel, dim3(ceil_div(n, 128)), dim3(128), 0, s, knn_idx, knn_dist, n, k, sigma_sq, b.w,
@@ -593,7 +815,6 @@ extern "C" int scamd_jaccard_connectivities_f32(const int32_t* knn_idx, int64_t 
   hipStream_t s = stream;
   const int64_t total = n * k;
   SCAMD_HIP_CHECK(hipMemsetAsync(b.in_only, 0, sizeof(int) * n, s));
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.cursor, 0, sizeof(int) * n, s));
   hipLaunchKernelGGL(jaccard_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, knn_idx, n, k, b.w);
   SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(count_positive_rows_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, b.w, n, k, b.outcnt);
