@@ -70,10 +70,11 @@ def smooth_knn_dist(distances: np.ndarray, k: float, local_connectivity: float =
     return result, rho
 
 
-def smooth_knn_dist_vec(distances: np.ndarray, k: float):
+def smooth_knn_dist_vec(distances: np.ndarray, k: float, mean_all: float | None = None):
     """Vectorised (all rows at once) version of `smooth_knn_dist` for local_connectivity=1.
 
-    Same arithmetic (float64 bisection on float32 inputs); used for n up to ~1e6 on the host.
+    Same arithmetic (float64 bisection on float32 inputs); used for n up to ~1e6 on the host.  `mean_all`: the mean of
+    ALL distances of the problem when `distances` holds a subset of its rows (bench.py's sampled full-size check).
     """
     d32 = np.asarray(distances, dtype=np.float32)
     n, kk = d32.shape
@@ -108,7 +109,7 @@ def smooth_knn_dist_vec(distances: np.ndarray, k: float):
         mid[fin] = (lo[fin] + hi[fin]) / 2.0
         active[idx[done]] = False
     result = mid.astype(np.float32)
-    mean_all = float(np.mean(d32))
+    mean_all = float(np.mean(d32)) if mean_all is None else float(mean_all)
     mean_ith = d32.mean(axis=1, dtype=np.float64)
     floor = np.where(rho > 0, MIN_K_DIST_SCALE * mean_ith, MIN_K_DIST_SCALE * mean_all)
     result = np.where(result < floor, floor, result).astype(np.float32)

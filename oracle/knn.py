@@ -81,3 +81,30 @@ def knn_exact_f64(x: np.ndarray, queries: np.ndarray, k: int, block: int = 2048)
         idx[s : s + block] = np.take_along_axis(part, order, axis=1)
         dist[s : s + block] = np.sqrt(np.take_along_axis(pd, order, axis=1))
     return idx, dist
+
+
+def knn_exact_f64_sample(x: np.ndarray, queries: np.ndarray, k: int, chunk: int = 131072):
+    """Float64 brute force for a SAMPLE of query rows of a large x (the full-size check of bench.py): the candidates are
+    streamed in chunks (|q|^2 + |c|^2 - 2 q.c in float64 to pick k + 8 per chunk), the survivors re-evaluated as direct
+    (q - c)^2 sums and ordered by (distance, index).  -> (idx int64 [m, k], dist float64 [m, k])"""
+    queries = np.asarray(queries, dtype=np.int64)
+    n, m = x.shape[0], len(queries)
+    q = np.asarray(x[queries], dtype=np.float64)
+    qq = (q * q).sum(1)
+    keep = min(n, k + 8)
+    best_i = np.empty((m, 0), dtype=np.int64)
+    best_d = np.empty((m, 0), dtype=np.float64)
+    for s0 in range(0, n, chunk):
+        c = np.asarray(x[s0:s0 + chunk], dtype=np.float64)
+        d2 = qq[:, None] + (c * c).sum(1)[None, :] - 2.0 * (q @ c.T)
+        kk = min(keep, c.shape[0])
+        part = np.argpartition(d2, kk - 1, axis=1)[:, :kk] if kk < c.shape[0] else np.broadcast_to(np.arange(c.shape[0]), (m, c.shape[0]))
+        best_i = np.hstack([best_i, part + s0])
+        best_d = np.hstack([best_d, np.take_along_axis(d2, part, axis=1)])
+        if best_i.shape[1] > 4 * keep:
+            sel = np.argpartition(best_d, keep - 1, axis=1)[:, :keep]
+            best_i, best_d = np.take_along_axis(best_i, sel, 1), np.take_along_axis(best_d, sel, 1)
+    x64 = np.asarray(x[best_i.ravel()], dtype=np.float64).reshape(m, best_i.shape[1], -1)
+    exact = ((q[:, None, :] - x64) ** 2).sum(-1)
+    order = np.lexsort((best_i, exact), axis=1)[:, :k]
+    return np.take_along_axis(best_i, order, 1), np.sqrt(np.take_along_axis(exact, order, 1))
