@@ -1,0 +1,99 @@
+"""TEST INFRASTRUCTURE: numpy-level callers of the C ABI of the HOST-EMULATED kernel library
+(tests/emu/_build/*/libscanpy_amd_emu.so).  The emulated library takes host pointers where the product takes device
+pointers; prototypes come from scanpy_amd._lib.SIGNATURES (the same table the product binds with)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+from functools import lru_cache
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+sys.path.insert(0, str(ROOT))
+from scanpy_amd._lib import SIGNATURES  # noqa: E402
+
+
+@lru_cache(maxsize=2)
+def load(asan: bool = False) -> C.CDLL:
+    sys.path.insert(0, str(HERE))
+    import build as emu_build
+
+    lib = C.CDLL(str(emu_build.build(asan=asan)))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    for name in ("emu_launches", "emu_partial_collectives", "emu_mixed_collectives", "emu_reads_of_inactive_lanes"):
+        getattr(lib, name).restype = C.c_longlong
+    return lib
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what}: rc={rc}: {lib.scamd_last_error().decode()}")
+
+
+def _ws(nbytes: int):
+    # exact size, its own allocation: an over-run past the workspace is an over-run of a heap block
+    return np.full(max(int(nbytes), 1), 0xAB, dtype=np.uint8)
+
+
+def stats(lib) -> dict:
+    return {"launches": lib.emu_launches(), "partial_collectives": lib.emu_partial_collectives(),
+            "mixed_collectives": lib.emu_mixed_collectives(), "reads_of_inactive_lanes": lib.emu_reads_of_inactive_lanes()}
+
+
+def fuzzy_simplicial_set(lib, idx, dist):
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    dist = np.ascontiguousarray(dist, dtype=np.float32)
+    n, k = idx.shape
+    cap = 2 * n * (k - 1)
+    indptr = np.empty(n + 1, dtype=np.int64)
+    indices = np.empty(cap, dtype=np.int32)
+    data = np.empty(cap, dtype=np.float32)
+    sigma = np.empty(n, dtype=np.float32)
+    rho = np.empty(n, dtype=np.float32)
+    ws = _ws(lib.scamd_fuzzy_workspace_bytes(n, k))
+    nnz = C.c_int64(0)
+    rc = lib.scamd_fuzzy_simplicial_set_f32(_p(idx), _p(dist), n, k, _p(indptr), _p(indices), _p(data), cap, _p(sigma), _p(rho),
+                                            C.byref(nnz), _p(ws), ws.size, None)
+    _check(lib, rc, "fuzzy")
+    m = int(nnz.value)
+    return indptr, indices[:m].copy(), data[:m].copy(), sigma, rho
+
+
+def leiden(lib, adj, *, resolution=1.0, n_iterations=-1, beta=0.01, seed=0):
+    adj = adj.tocsr()
+    adj.sort_indices()
+    n = adj.shape[0]
+    indptr = np.ascontiguousarray(adj.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(adj.indices, dtype=np.int32)
+    w = np.ascontiguousarray(adj.data, dtype=np.float32)
+    memb = np.empty(n, dtype=np.int32)
+    q = C.c_double(0)
+    nc = C.c_int32(0)
+    ws = _ws(lib.scamd_leiden_workspace_bytes(n, adj.nnz))
+    rc = lib.scamd_leiden_csr_f32(_p(indptr), _p(indices), _p(w), n, adj.nnz, float(resolution), int(n_iterations), float(beta),
+                                  int(seed), _p(memb), C.byref(q), C.byref(nc), _p(ws), ws.size, None)
+    _check(lib, rc, "leiden")
+    return memb, float(q.value), int(nc.value)
+
+
+def knn(lib, x, k, *, q_begin=0, n_query=None, cert_scale=1.0):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n, d = x.shape
+    nq = n if n_query is None else n_query
+    idx = np.empty((nq, k), dtype=np.int32)
+    dist = np.empty((nq, k), dtype=np.float64)
+    ws = _ws(lib.scamd_knn_workspace_bytes(n, d, nq, k))
+    nfb = C.c_int64(0)
+    rc = lib.scamd_knn_l2_f32(_p(x), n, d, d, q_begin, nq, k, _p(idx), _p(dist), float(cert_scale), C.byref(nfb), _p(ws), ws.size, None)
+    _check(lib, rc, "knn")
+    return idx, dist, int(nfb.value)
