@@ -13,7 +13,10 @@
 //  * everything the kernels index is ordinary host memory: build with EMU_ASAN=1 and AddressSanitizer sees every access.
 #include <hip/hip_runtime.h>
 
+#include <execinfo.h>
+#include <signal.h>
 #include <sys/mman.h>
+#include <unistd.h>
 
 #include <vector>
 
@@ -142,13 +145,13 @@ void complete_wave(int w, bool partial, int leader = -1) {
   for (int l = 0; l < n; ++l) {
     if (base[l].state != WAIT_WAVE) continue;
     if (base[l].kind != base[first].kind || base[l].fn != base[first].fn || base[l].site != base[first].site) {
-      mixed = mixed || (base[l].kind != K_SOFT && base[first].kind != K_SOFT);
+      mixed = mixed || (base[l].kind < K_SOFT_RMW && base[first].kind < K_SOFT_RMW);
       continue;
     }
     arr[l] = base[l].arr;
     active |= 1ull << l;
   }
-  if (base[first].kind != K_SOFT) {
+  if (base[first].kind < K_SOFT_RMW) {
     if (partial) ++g_stats.partial_collectives;
     if (mixed) ++g_stats.mixed_collectives;
   }
@@ -199,8 +202,6 @@ void wave_collective(int kind, const void* opnd, void* res, ComputeAll fn, const
   to_scheduler();
 }
 
-void soft_sync() { wave_collective(K_SOFT, nullptr, nullptr, barrier_all); }
-
 void block_barrier() {
   Lane* me = g_cur;
   me->state = WAIT_BLOCK;
@@ -214,7 +215,29 @@ void block_barrier() {
 
 void* dyn_lds() { return g_dyn_lds.data(); }
 
+static void segv_backtrace(int sig, siginfo_t* si, void*) {
+  void* frames[48];
+  const int n = backtrace(frames, 48);
+  dprintf(2, "emu: signal %d at address %p, lane %d of wave %d, workgroup (%u,%u,%u)\n", sig, si->si_addr,
+          g_cur ? g_cur->lane : -1, g_cur ? g_cur->wave : -1, g_cur ? g_cur->bidx.x : 0, g_cur ? g_cur->bidx.y : 0,
+          g_cur ? g_cur->bidx.z : 0);
+  backtrace_symbols_fd(frames, n, 2);
+  _exit(139);
+}
+
 void launch_body(dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* closure) {
+  static bool handler = false;
+  if (!handler && getenv("EMU_SEGV_BACKTRACE")) {
+    handler = true;
+    static char alt[1 << 16];
+    stack_t ss{alt, 0, sizeof(alt)};
+    sigaltstack(&ss, nullptr);
+    struct sigaction sa {};
+    sa.sa_sigaction = segv_backtrace;
+    sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
+    sigaction(SIGSEGV, &sa, nullptr);
+    sigaction(SIGBUS, &sa, nullptr);
+  }
   const int nthreads = (int)(block.x * block.y * block.z);
   if (nthreads <= 0 || nthreads > MAX_THREADS) {
     fprintf(stderr, "emu: workgroup of %d threads\n", nthreads);
@@ -273,21 +296,24 @@ void launch_body(dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void
           if (ran) continue;
           // nothing can run: some wave holds lanes in a collective the rest of it will not reach (they wait in the
           // workgroup barrier or in another collective) -- the hardware executes it with the lanes that are there
-          // (lock-step points first, the most recently blocked lane's group first: a lane that still loops over an
-          // atomic -- a hash probe that collided -- must finish before the lanes that wait further down go on)
+          // Lock-step points first: pending read-modify-writes, then pending atomic loads (a lane that skipped a loop
+          // of inserts waits at the load behind the loop until the lanes inside it are done -- the hardware's
+          // reconvergence at the loop exit); within a class the lowest call site (deterministic; the order of two
+          // independent read-modify-writes does not matter).
           bool resolved = false;
-          int best_w = -1, best_l = -1;
-          long long best_seq = -1;
-          for (int t = 0; t < nthreads; ++t)
-            if (g_lanes[t].state == WAIT_WAVE && g_lanes[t].kind == K_SOFT && g_lanes[t].seq > best_seq) {
-              best_seq = g_lanes[t].seq;
-              best_w = t >> 6;
-              best_l = t & 63;
-            }
-          if (best_w >= 0) {
-            complete_wave(best_w, true, best_l);
+          int best_t = -1;
+          for (int pass_kind : {(int)K_SOFT_RMW, (int)K_SOFT_LOAD}) {
+            for (int t = 0; t < nthreads; ++t)
+              if (g_lanes[t].state == WAIT_WAVE && g_lanes[t].kind == pass_kind &&
+                  (best_t < 0 || g_lanes[t].site < g_lanes[best_t].site))
+                best_t = t;
+            if (best_t >= 0) break;
+          }
+          if (best_t >= 0) {
+            complete_wave(best_t >> 6, true, best_t & 63);
             resolved = true;
           }
+          // no lock-step point is pending: a shuffle / ballot / ... that part of its wave will not reach (counted)
           for (int w = 0; w < g_nwaves && !resolved; ++w)
             if (g_wave_arrived[w] > 0) {
               complete_wave(w, true, -1);
@@ -351,6 +377,13 @@ void ballot_all(unsigned long long active, const Arrived* l, const void*) {
     if (active >> i & 1) set64(l[i].res, m);
 }
 void barrier_all(unsigned long long, const Arrived*, const void*) {}
+void thunks_all(unsigned long long active, const Arrived* l, const void*) {
+  for (int i = 0; i < 64; ++i)
+    if (active >> i & 1) {
+      const Thunk* t = static_cast<const Thunk*>(l[i].opnd);
+      t->run(t->ctx);
+    }
+}
 
 // D = A x B + C on the 64 lanes of a wave; register layouts of the CDNA3/4 ISA guide (MI355X_MICROARCH.md):
 //  32x32 results: lane l holds column j = l % 32, register r holds row i = 8 * (r / 4) + 4 * (l / 32) + r % 4

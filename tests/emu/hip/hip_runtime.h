@@ -27,6 +27,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
+#define EMU_INL static inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __shared__ static
 #define __constant__ static
@@ -111,7 +112,6 @@ struct Lane {
 extern Lane* g_cur;
 void wave_collective(int kind, const void* opnd, void* res, ComputeAll fn, const void* uniform = nullptr);
 void block_barrier();
-void soft_sync();  // lock-step point: see the atomics below
 void* dyn_lds();
 void launch_body(dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* closure);
 
@@ -123,7 +123,7 @@ static inline void launch_ggl(void (*kernel)(KArgs...), dim3 grid, dim3 block, s
 }
 
 enum Kind { K_SHFL = 1, K_BALLOT, K_READLANE, K_READFIRST, K_DPP, K_SWIZZLE, K_MFMA_F32_32X32X2, K_MFMA_BF16_32X32X16,
-            K_MFMA_F64_16X16X4, K_WAVE_BARRIER, K_ANY, K_SOFT };
+            K_MFMA_F64_16X16X4, K_WAVE_BARRIER, K_ANY, K_SOFT_RMW, K_SOFT_LOAD };
 
 // ---- generic helpers: a 64-bit payload per lane covers every shuffled type used
 template <typename T> static inline unsigned long long to_bits(T v) {
@@ -146,8 +146,16 @@ void barrier_all(unsigned long long active, const Arrived* l, const void*);
 void mfma_f32_32x32x2_all(unsigned long long active, const Arrived* l, const void*);
 void mfma_bf16_32x32x16_all(unsigned long long active, const Arrived* l, const void*);
 void mfma_f64_16x16x4_all(unsigned long long active, const Arrived* l, const void*);
+void thunks_all(unsigned long long active, const Arrived* l, const void*);
+struct Thunk { void (*run)(void*); void* ctx; };
+// `f` of every lane that reached this point runs when the LAST of them arrives, in lane order: one instruction of a wave
+template <int KIND, typename F> EMU_INL void lockstep(F&& f) {
+  using Fn = typename std::remove_reference<F>::type;
+  Thunk t{[](void* c) { (*static_cast<Fn*>(c))(); }, &f};
+  wave_collective(KIND, &t, nullptr, thunks_all);
+}
 
-template <typename T> static inline T shfl_from(T v, int src_lane) {  // src_lane: absolute lane 0..63 (or < 0: own value)
+template <typename T> EMU_INL T shfl_from(T v, int src_lane) {  // src_lane: absolute lane 0..63 (or < 0: own value)
   ShflOp op{to_bits(v), src_lane};
   unsigned long long r = 0;
   wave_collective(K_SHFL, &op, &r, shfl_all);
@@ -169,33 +177,33 @@ static inline void __threadfence() {}
 static inline void __threadfence_block() {}
 
 // ---- shuffles (width = power of two <= 64; the sub-wave forms address lanes inside the caller's own segment)
-template <typename T> static inline T __shfl(T v, int src, int width = 64) {
+template <typename T> EMU_INL T __shfl(T v, int src, int width = 64) {
   const int me = ::emu::g_cur->lane;
   return ::emu::shfl_from(v, (me & ~(width - 1)) | (src & (width - 1)));
 }
-template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64) {
+template <typename T> EMU_INL T __shfl_xor(T v, int mask, int width = 64) {
   const int me = ::emu::g_cur->lane;
   const int s = me ^ mask;
   return ::emu::shfl_from(v, (s & ~(width - 1)) == (me & ~(width - 1)) ? s : me);
 }
-template <typename T> static inline T __shfl_down(T v, unsigned d, int width = 64) {
+template <typename T> EMU_INL T __shfl_down(T v, unsigned d, int width = 64) {
   const int me = ::emu::g_cur->lane;
   const int s = me + (int)d;
   return ::emu::shfl_from(v, (s & ~(width - 1)) == (me & ~(width - 1)) ? s : me);
 }
-template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64) {
+template <typename T> EMU_INL T __shfl_up(T v, unsigned d, int width = 64) {
   const int me = ::emu::g_cur->lane;
   const int s = me - (int)d;
   return ::emu::shfl_from(v, s >= 0 && (s & ~(width - 1)) == (me & ~(width - 1)) ? s : me);
 }
-static inline unsigned long long __ballot(int pred) {
+EMU_INL unsigned long long __ballot(int pred) {
   int p = pred != 0;
   unsigned long long r = 0;
   ::emu::wave_collective(::emu::K_BALLOT, &p, &r, ::emu::ballot_all);
   return r;
 }
-static inline int __any(int pred) { return __ballot(pred) != 0ull; }
-static inline int __all(int pred) { return __ballot(!pred) == 0ull; }
+EMU_INL int __any(int pred) { return __ballot(pred) != 0ull; }
+EMU_INL int __all(int pred) { return __ballot(!pred) == 0ull; }
 
 // ---- bit / conversion intrinsics
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
@@ -247,19 +255,31 @@ static inline long max(int a, long b) { return a < b ? b : a; }
 // plain stores, every lane inserts with atomicCAS / atomicAdd, every lane reads slots with __hip_atomic_load): correct on
 // the hardware because a wave executes its LDS instructions in program order for all lanes at once.  Fibres do not run
 // in lock step, so every atomic is a LOCK-STEP POINT here: the lanes of the wave that reach it wait for each other
-// first (lanes that took another path are not waited for -- emu_runtime.cpp, `soft` groups).
-#define EMU_SYNC ::emu::soft_sync()
-template <typename T, typename U> static inline T atomicAdd(T* p, U v) { EMU_SYNC; T o = *p; *p = (T)(o + (T)v); return o; }
-template <typename T, typename U> static inline T atomicSub(T* p, U v) { EMU_SYNC; T o = *p; *p = (T)(o - (T)v); return o; }
-template <typename T, typename U> static inline T atomicMax(T* p, U v) { EMU_SYNC; T o = *p; if ((T)v > o) *p = (T)v; return o; }
-template <typename T, typename U> static inline T atomicMin(T* p, U v) { EMU_SYNC; T o = *p; if ((T)v < o) *p = (T)v; return o; }
-template <typename T, typename U> static inline T atomicOr(T* p, U v) { EMU_SYNC; T o = *p; *p = (T)(o | (T)v); return o; }
-template <typename T, typename U> static inline T atomicAnd(T* p, U v) { EMU_SYNC; T o = *p; *p = (T)(o & (T)v); return o; }
-template <typename T, typename U> static inline T atomicXor(T* p, U v) { EMU_SYNC; T o = *p; *p = (T)(o ^ (T)v); return o; }
-template <typename T, typename U> static inline T atomicExch(T* p, U v) { EMU_SYNC; T o = *p; *p = (T)v; return o; }
-template <typename T, typename U, typename V> static inline T atomicCAS(T* p, U cmp, V v) { EMU_SYNC; T o = *p; if (o == (T)cmp) *p = (T)v; return o; }
-template <typename T> static inline T emu_atomic_load(T* p) { EMU_SYNC; return *p; }
-template <typename T, typename V> static inline void emu_atomic_store(T* p, V v) { EMU_SYNC; *p = (T)v; }
+// first, and the operations of all of them are carried out at that moment, in lane order.  Lanes that took another path
+// are not waited for, with one rule of precedence when the wave is stuck (emu_runtime.cpp): pending read-modify-writes
+// are carried out before pending atomic LOADS, and those before shuffles -- the lanes that skipped a loop of inserts and
+// wait at the load behind it see the table only after the lanes inside the loop are done, as on the hardware.
+#define EMU_ATOMIC(NAME, BODY) \
+  template <typename T, typename U> EMU_INL T NAME(T* p, U v) { T o; ::emu::lockstep<::emu::K_SOFT_RMW>([&]() { o = *p; BODY; }); return o; }
+EMU_ATOMIC(atomicAdd, *p = (T)(o + (T)v))
+EMU_ATOMIC(atomicSub, *p = (T)(o - (T)v))
+EMU_ATOMIC(atomicMax, if ((T)v > o) *p = (T)v)
+EMU_ATOMIC(atomicMin, if ((T)v < o) *p = (T)v)
+EMU_ATOMIC(atomicOr, *p = (T)(o | (T)v))
+EMU_ATOMIC(atomicAnd, *p = (T)(o & (T)v))
+EMU_ATOMIC(atomicXor, *p = (T)(o ^ (T)v))
+EMU_ATOMIC(atomicExch, *p = (T)v)
+template <typename T, typename U, typename V> EMU_INL T atomicCAS(T* p, U cmp, V v) {
+  T o;
+  ::emu::lockstep<::emu::K_SOFT_RMW>([&]() { o = *p; if (o == (T)cmp) *p = (T)v; });
+  return o;
+}
+template <typename T> EMU_INL T emu_atomic_load(T* p) {
+  T o;
+  ::emu::lockstep<::emu::K_SOFT_LOAD>([&]() { o = *p; });
+  return o;
+}
+template <typename T, typename V> EMU_INL void emu_atomic_store(T* p, V v) { ::emu::lockstep<::emu::K_SOFT_RMW>([&]() { *p = (T)v; }); }
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 2
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3
@@ -271,13 +291,13 @@ template <typename T, typename V> static inline void emu_atomic_store(T* p, V v)
 
 // ---- amdgcn builtins
 namespace emu {
-static inline int readlane_i(int v, int lane) {
+EMU_INL int readlane_i(int v, int lane) {
   ShflOp op{to_bits(v), lane};
   unsigned long long r = 0;
   wave_collective(K_READLANE, &op, &r, readlane_all);
   return from_bits<int>(r);
 }
-static inline int readfirstlane_i(int v) {
+EMU_INL int readfirstlane_i(int v) {
   unsigned long long b = to_bits(v), r = 0;
   wave_collective(K_READFIRST, &b, &r, readfirst_all);
   return from_bits<int>(r);
@@ -300,7 +320,7 @@ static inline int dpp_source(int lane, int ctrl) {
   fprintf(stderr, "emu: unsupported DPP control 0x%x\n", ctrl);
   abort();
 }
-static inline int update_dpp_i(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+EMU_INL int update_dpp_i(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
   const int me = g_cur->lane;
   int s = dpp_source(me, ctrl);
   const bool enabled = ((row_mask >> (me >> 4)) & 1) && ((bank_mask >> ((me >> 2) & 3)) & 1);
@@ -310,7 +330,7 @@ static inline int update_dpp_i(int old, int src, int ctrl, int row_mask, int ban
   if (s == -1) return bound_ctrl ? 0 : old;
   return got;
 }
-static inline int ds_swizzle_i(int v, int pattern) {
+EMU_INL int ds_swizzle_i(int v, int pattern) {
   const int me = g_cur->lane;
   if (pattern & 0x8000) {  // quad-perm mode
     return shfl_from(v, (me & ~3) | ((pattern >> (2 * (me & 3))) & 3));
@@ -319,19 +339,19 @@ static inline int ds_swizzle_i(int v, int pattern) {
   const int j = (((me & 31) & and_mask) | or_mask) ^ xor_mask;
   return shfl_from(v, (me & 32) | j);
 }
-static inline void wave_barrier() { wave_collective(K_WAVE_BARRIER, nullptr, nullptr, barrier_all); }
+EMU_INL void wave_barrier() { wave_collective(K_WAVE_BARRIER, nullptr, nullptr, barrier_all); }
 
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef double f64x4_t __attribute__((ext_vector_type(4)));
 struct MfmaF32Op { float a, b; f32x16_t c; };
-static inline f32x16_t mfma_f32_32x32x2(float a, float b, f32x16_t c) {
+EMU_INL f32x16_t mfma_f32_32x32x2(float a, float b, f32x16_t c) {
   MfmaF32Op op{a, b, c};
   f32x16_t d;
   wave_collective(K_MFMA_F32_32X32X2, &op, &d, mfma_f32_32x32x2_all);
   return d;
 }
 struct MfmaBf16Op { unsigned short a[8], b[8]; f32x16_t c; };
-template <typename V> static inline f32x16_t mfma_bf16_32x32x16(V a, V b, f32x16_t c) {
+template <typename V> EMU_INL f32x16_t mfma_bf16_32x32x16(V a, V b, f32x16_t c) {
   static_assert(sizeof(V) == 16, "8 bf16 per lane");
   MfmaBf16Op op;
   memcpy(op.a, &a, 16);
@@ -342,7 +362,7 @@ template <typename V> static inline f32x16_t mfma_bf16_32x32x16(V a, V b, f32x16
   return d;
 }
 struct MfmaF64Op { double a, b; f64x4_t c; };
-static inline f64x4_t mfma_f64_16x16x4(double a, double b, f64x4_t c) {
+EMU_INL f64x4_t mfma_f64_16x16x4(double a, double b, f64x4_t c) {
   MfmaF64Op op{a, b, c};
   f64x4_t d;
   wave_collective(K_MFMA_F64_16X16X4, &op, &d, mfma_f64_16x16x4_all);
