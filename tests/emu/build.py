@@ -61,7 +61,10 @@ def build(asan: bool = False, force: bool = False) -> Path:
     shutil.copy(ROOT / "include" / "scanpy_amd.h", out_dir / "include" / "scanpy_amd.h")
     for f in list(CSRC.glob("*.hip")) + list(CSRC.glob("*.cpp")) + list(CSRC.glob("*.h")):
         (work / f.name).write_text(transform(f.name, f.read_text(), asan))
-    flags = ["-std=c++17", "-O1", "-g", "-fPIC", "-ffp-contract=off", "-fno-strict-aliasing", "-Wno-everything", f"-I{HERE}", "-DSCAMD_EMU=1"]
+    # -Og, not -O1: at -O1 clang clones a rendezvous into the two arms of a lane-dependent branch although the callee is
+    # declared convergent + noduplicate (seen in chol_factor_kernel: 18 instead of 12 calls) -- two call sites, and the
+    # lanes of the two arms stop meeting
+    flags = ["-std=c++17", "-Og", "-g", "-fPIC", "-ffp-contract=off", "-fno-strict-aliasing", "-Wno-everything", f"-I{HERE}", "-DSCAMD_EMU=1"]
     if asan:
         flags += ["-fsanitize=address", "-fno-omit-frame-pointer", "-shared-libasan"]
     objs = []

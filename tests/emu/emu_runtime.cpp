@@ -13,6 +13,7 @@
 //  * everything the kernels index is ordinary host memory: build with EMU_ASAN=1 and AddressSanitizer sees every access.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
 #include <execinfo.h>
 #include <signal.h>
 #include <sys/mman.h>
@@ -154,6 +155,27 @@ void complete_wave(int w, bool partial, int leader = -1) {
   if (base[first].kind < K_SOFT_RMW) {
     if (partial) ++g_stats.partial_collectives;
     if (mixed) ++g_stats.mixed_collectives;
+    static int trace = getenv("EMU_TRACE_PARTIAL") ? atoi(getenv("EMU_TRACE_PARTIAL")) : 0;
+    if ((partial || mixed) && trace > 0) {
+      --trace;
+      Dl_info di{};
+      dladdr(base[first].site, &di);
+      fprintf(stderr, "emu: %s%s collective kind %d at %s+0x%lx, wave %d of workgroup (%u,%u,%u), lanes %016llx; the others:",
+              partial ? "partial " : "", mixed ? "mixed " : "", base[first].kind, di.dli_fname ? di.dli_fname : "?",
+              (unsigned long)((const char*)base[first].site - (const char*)di.dli_fbase), w, base[first].bidx.x,
+              base[first].bidx.y, base[first].bidx.z, active);
+      for (int l = 0; l < n; ++l)
+        if (!(active >> l & 1))
+          fprintf(stderr, " %d:%s", l,
+                  base[l].state == DONE ? "done" : base[l].state == WAIT_BLOCK ? "barrier" : base[l].state == WAIT_WAVE ? "other-site" : "runnable");
+      for (int l = 0; l < n; ++l)
+        if (!(active >> l & 1) && base[l].state == WAIT_WAVE) {
+          fprintf(stderr, " [lane %d waits in kind %d at +0x%lx]", l, base[l].kind,
+                  (unsigned long)((const char*)base[l].site - (const char*)di.dli_fbase));
+          break;
+        }
+      fprintf(stderr, "\n");
+    }
   }
   base[first].fn(active, arr, base[first].uniform);
   for (int l = 0; l < n; ++l)
@@ -456,7 +478,8 @@ void mfma_f64_16x16x4_all(unsigned long long active, const Arrived* l, const voi
     f64x4_t d = op->c;
     const int j = i % 16;
     for (int r = 0; r < 4; ++r) {
-      const int row = 4 * (i / 16) + r;  // D: lane l holds column l % 16, rows 4 * (l / 16) + r
+      const int row = (i / 16) + 4 * r;  // D: lane l holds column l % 16, rows (l / 16) + 4 r (pinned on the GPU by
+                                         // tests/test_gpu_dense.py::test_dgemm_tn; NOT the float32 16x16x4 layout)
       double acc = d[r];
       for (int k = 0; k < 4; ++k) acc = fma(a[row][k], b[k][j], acc);
       d[r] = acc;

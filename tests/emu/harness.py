@@ -97,3 +97,59 @@ def knn(lib, x, k, *, q_begin=0, n_query=None, cert_scale=1.0):
     rc = lib.scamd_knn_l2_f32(_p(x), n, d, d, q_begin, nq, k, _p(idx), _p(dist), float(cert_scale), C.byref(nfb), _p(ws), ws.size, None)
     _check(lib, rc, "knn")
     return idx, dist, int(nfb.value)
+
+
+def pca_csr(lib, x, n_comps, *, zero_center=True, seed=0, tol=2e-8):
+    """scamd_pca_csr_f32 on a scipy CSR float32 matrix -> dict(scores, components, variance, variance_ratio, mean, info)"""
+    x = x.tocsr()
+    x.sort_indices()
+    n, g = x.shape
+    indptr = np.ascontiguousarray(x.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(x.indices, dtype=np.int32)
+    data = np.ascontiguousarray(x.data, dtype=np.float32)
+    scores = np.empty((n, n_comps), dtype=np.float32)
+    comps = np.empty((n_comps, g), dtype=np.float64)
+    var = np.empty(n_comps, dtype=np.float64)
+    ratio = np.empty(n_comps, dtype=np.float64)
+    mean = np.empty(g, dtype=np.float64)
+    info = np.zeros(8, dtype=np.int32)
+    ws = _ws(lib.scamd_pca_csr_workspace_bytes(n, g, n_comps))
+    rc = lib.scamd_pca_csr_f32(_p(indptr), _p(indices), _p(data), n, g, x.nnz, n_comps, int(zero_center), int(seed), float(tol),
+                               _p(scores), _p(comps), _p(var), _p(ratio), _p(mean), _p(info), _p(ws), ws.size, None)
+    _check(lib, rc, "pca_csr")
+    return dict(scores=scores, components=comps, variance=var, variance_ratio=ratio, mean=mean, info=info)
+
+
+def csr_gram(lib, x, scale_bits=None):
+    x = x.tocsr()
+    x.sort_indices()
+    n, g = x.shape
+    indptr = np.ascontiguousarray(x.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(x.indices, dtype=np.int32)
+    data = np.ascontiguousarray(x.data, dtype=np.float32)
+    ws = _ws(lib.scamd_csr_gram_workspace_bytes(n, g))
+    absmax = C.c_float(0)
+    rc = lib.scamd_csr_gram_f32(_p(indptr), _p(indices), _p(data), n, g, x.nnz, 0, None, 0, None, C.byref(absmax), _p(ws), ws.size, None)
+    _check(lib, rc, "gram absmax")
+    if scale_bits is None:
+        scale_bits = int(np.floor(62 - np.log2(n * float(absmax.value) ** 2))) - 1
+    g_pad = (g + 127) // 128 * 128
+    gram = np.zeros((g_pad, g_pad), dtype=np.int64)
+    colsum = np.zeros(g_pad, dtype=np.int64)
+    rc = lib.scamd_csr_gram_f32(_p(indptr), _p(indices), _p(data), n, g, x.nnz, scale_bits, _p(gram), g_pad, _p(colsum), None, _p(ws), ws.size, None)
+    _check(lib, rc, "gram")
+    return gram, colsum, scale_bits, float(absmax.value)
+
+
+def modularity(lib, adj, membership, resolution=1.0):
+    adj = adj.tocsr()
+    n = adj.shape[0]
+    indptr = np.ascontiguousarray(adj.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(adj.indices, dtype=np.int32)
+    w = np.ascontiguousarray(adj.data, dtype=np.float32)
+    memb = np.ascontiguousarray(membership, dtype=np.int32)
+    q = C.c_double(0)
+    ws = _ws(lib.scamd_leiden_workspace_bytes(n, adj.nnz))
+    rc = lib.scamd_modularity_csr_f32(_p(indptr), _p(indices), _p(w), n, adj.nnz, _p(memb), float(resolution), C.byref(q), _p(ws), ws.size, None)
+    _check(lib, rc, "modularity")
+    return float(q.value)

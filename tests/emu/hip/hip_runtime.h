@@ -110,8 +110,12 @@ struct Lane {
   Arrived arr;
 };
 extern Lane* g_cur;
-void wave_collective(int kind, const void* opnd, void* res, ComputeAll fn, const void* uniform = nullptr);
-void block_barrier();
+// (convergent + noduplicate: the host compiler must treat a rendezvous as the device compiler treats a cross-lane
+// instruction -- never clone it into the two arms of a branch: each clone would be a call site of its own and the lanes of
+// the two arms would stop meeting)
+__attribute__((convergent, noduplicate)) void wave_collective(int kind, const void* opnd, void* res, ComputeAll fn,
+                                                              const void* uniform = nullptr);
+__attribute__((convergent, noduplicate)) void block_barrier();
 void* dyn_lds();
 void launch_body(dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* closure);
 
