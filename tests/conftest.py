@@ -12,6 +12,15 @@ if str(ROOT) not in sys.path:
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
 
+import os  # noqa: E402
+
+if os.environ.get("SCAMD_TESTS_ON_EMULATOR") == "1":
+    # the `-m gpu` tests against the host-emulated kernel library (tests/emu/README.md); never set in a normal run
+    sys.path.insert(0, str(Path(__file__).resolve().parent / "emu"))
+    import patch_torch  # noqa: E402
+
+    patch_torch.activate()
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -1,0 +1,65 @@
+"""TEST INFRASTRUCTURE: run the `-m gpu` tests against the HOST-EMULATED kernel library (tests/emu/README.md).
+
+`SCAMD_TESTS_ON_EMULATOR=1 python -m pytest tests -m gpu -k ...` -- tests/conftest.py then calls `activate()` before
+anything imports scanpy_amd: the C ABI of the emulated library takes host pointers, so "device" tensors are CPU tensors
+that claim to be CUDA ones.  This is a way to exercise the kernels' logic (and, with SCAMD_EMU_ASAN=1 under an
+LD_PRELOADed ASan runtime, their indexing) when no GPU minute is left; it is never active in a normal run, the product
+has no such switch, and a test that passes here has said nothing about the GPU build."""
+from __future__ import annotations
+
+import os
+import sys
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+
+
+def activate() -> None:
+    import torch
+
+    sys.path.insert(0, str(HERE))
+    import harness
+
+    emu = harness.load(asan=os.environ.get("SCAMD_EMU_ASAN") == "1")
+
+    class _Stream:
+        cuda_stream = 0
+
+        def synchronize(self):
+            pass
+
+        def wait_stream(self, other):
+            pass
+
+    cpu = torch.device("cpu")
+    torch.cuda.is_available = lambda: True
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.current_stream = lambda *a, **k: _Stream()
+    torch.cuda.current_device = lambda: 0
+    torch.cuda.device_count = lambda: 1
+    torch.cuda.set_device = lambda *a, **k: None
+    torch.cuda.mem_get_info = lambda *a, **k: (64 << 30, 64 << 30)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.Tensor.is_cuda = property(lambda self: True)
+    torch.Tensor.record_stream = lambda self, s: None
+
+    from scanpy_amd import _device, _lib
+
+    import numpy as np
+
+    import scanpy_amd  # noqa: F401  (imports every submodule)
+
+    patched = {
+        "require_gpu": lambda: cpu,
+        "set_device_from_env": lambda: cpu,
+        "stream_ptr": lambda: None,
+        "to_host": lambda t: t.detach().numpy(),
+    }
+    _lib.load = lambda: emu
+    _device.pinned_uploader.upload = lambda arr, device: torch.from_numpy(np.ascontiguousarray(arr))
+    # (`from ._device import require_gpu, ...` copied the originals into the importing modules)
+    for name, mod in list(sys.modules.items()):
+        if name == "scanpy_amd" or name.startswith("scanpy_amd."):
+            for attr, fn in patched.items():
+                if hasattr(mod, attr):
+                    setattr(mod, attr, fn)

@@ -70,3 +70,112 @@ def test_fuzzy_set_hub_rows(emu):
     assert np.diff(ip).max() > 2048, np.diff(ip).max()
     assert np.array_equal(ip, ref.indptr) and np.array_equal(ix, ref.indices)
     assert np.abs(dat - ref.data).max() <= 1e-6
+
+
+def _blobs(n, d, n_c, seed, spread=4.0):
+    rng = np.random.default_rng(seed)
+    cent = rng.standard_normal((n_c, d)) * spread
+    return (cent[rng.integers(0, n_c, n)] + rng.standard_normal((n, d))).astype(np.float32)
+
+
+@pytest.mark.parametrize(("n", "d", "env"), [(1500, 20, {}), (1500, 50, {}), (4500, 50, {"SCAMD_KNN_IVF": "1", "SCAMD_KNN_CELL_ROWS": "512"}),
+                                             (1200, 50, {"SCAMD_KNN_B3": "0"})])
+def test_knn_both_engines_brute_and_pruned(emu, monkeypatch, n, d, env):
+    """float32 MFMA engine (d <= 32 or SCAMD_KNN_B3=0), bf16x3 engine (d in (32, 50]), cell-pruned sweep: index sets and
+    float64 distances of a float64 brute force, no query left to the float64 fallback scan"""
+    from oracle import compare as cmp
+
+    H, lib = emu
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    x = _blobs(n, d, 8, n + d, spread=3.0)
+    lib.emu_reset_stats()
+    idx, dist, n_fallback = H.knn(lib, x, 15)
+    ei, ed = oknn.knn_exact_f64(x, np.arange(n), 15)
+    bad, _ = cmp.knn_rows_differing_beyond_ties(idx, dist, ei, ed)
+    assert bad == 0 and n_fallback == 0
+    assert np.max(np.abs(dist - ed) / np.maximum(ed, 1e-30)) < 1e-12
+    assert lib.scamd_knn_last_select_engine() == (1 if d > 32 and env.get("SCAMD_KNN_B3") != "0" else 0)
+    st = H.stats(lib)
+    assert st["partial_collectives"] == st["mixed_collectives"] == st["reads_of_inactive_lanes"] == 0, st
+
+
+def test_knn_float64_fallback_scan(emu):
+    """cert_scale = 1e30: no query can be certified, every one goes through the float64 scan"""
+    from oracle import compare as cmp
+
+    H, lib = emu
+    x = _blobs(700, 20, 4, 3)
+    idx, dist, n_fallback = H.knn(lib, x, 10, cert_scale=1e30)
+    ei, ed = oknn.knn_exact_f64(x, np.arange(700), 10)
+    assert n_fallback == 700
+    assert cmp.knn_rows_differing_beyond_ties(idx, dist, ei, ed)[0] == 0
+
+
+@pytest.mark.parametrize("small", ["1", "0"])
+def test_leiden_reaches_the_oracles_modularity(emu, monkeypatch, small):
+    """every Leiden kernel on the host (n = 1500: two levels through the big kernels, then -- SCAMD_LEIDEN_SMALL=1 -- the
+    one-workgroup small levels): reported modularity == modularity of the labels, not below the oracle's own run, identical
+    on repetition, no cross-lane operation by a partial wave"""
+    from oracle import leiden as ol
+
+    H, lib = emu
+    monkeypatch.setenv("SCAMD_LEIDEN_SMALL", small)
+    x = _blobs(1500, 10, 12, 0)
+    idx, dist = oknn.knn_exact_f64(x, np.arange(1500), 15)
+    conn, _, _ = oconn.fuzzy_simplicial_set(idx, dist, 1500, 15)
+    lib.emu_reset_stats()
+    memb, q, nc = H.leiden(lib, conn, seed=0)
+    assert abs(q - ol.modularity(conn, memb)) < 1e-9 and nc == int(memb.max()) + 1
+    assert q > ol.leiden(conn, seed=0)[1] - 2e-3
+    memb2, q2, _ = H.leiden(lib, conn, seed=0)
+    assert q2 == q and np.array_equal(memb, memb2)
+    assert abs(H.modularity(lib, conn, memb) - q) < 1e-12
+    st = H.stats(lib)
+    assert st["partial_collectives"] == st["mixed_collectives"] == st["reads_of_inactive_lanes"] == 0, st
+
+
+def test_leiden_hub_rows(emu):
+    """a vertex with 2500 neighbours (multi-pass hub tables) and vertices of 150 .. 1200 (overflow list, hub list tiers)"""
+    from scipy import sparse
+
+    from oracle import leiden as ol
+
+    H, lib = emu
+    rng = np.random.default_rng(2)
+    n, deg = 3000, 8
+    m = sparse.coo_matrix((rng.random(n * deg).astype(np.float32) * 0.9 + 0.1, (np.repeat(np.arange(n), deg), rng.integers(0, n, n * deg))),
+                          shape=(n, n)).tocsr()
+    for h, dh in ((0, 150), (1, 250), (2, 500), (3, 1200), (4, 2500)):
+        t = rng.choice(n, dh, replace=False)
+        m = m + sparse.coo_matrix((rng.random(dh).astype(np.float32) * 0.5 + 0.1, (np.full(dh, h), t)), shape=(n, n)).tocsr()
+    m.setdiag(0)
+    m.eliminate_zeros()
+    m = m.maximum(m.T).tocsr().astype(np.float32)
+    memb, q, _ = H.leiden(lib, m, seed=0)
+    assert abs(q - ol.modularity(m, memb)) < 1e-9
+    assert q > ol.leiden(m, seed=0)[1] - 0.01
+
+
+def test_pca_chain(emu):
+    """exact fixed-point Gram (bit for bit), then scamd_pca_csr_f32 (float64 MFMA GEMM, CholeskyQR2, Jacobi) against
+    sklearn PCA(arpack)"""
+    import bench
+    from oracle import compare as cmp
+    from oracle import pca as opca
+
+    H, lib = emu
+    n, g, k = 900, 200, 12
+    x, _ = bench.make_matrix(n, g, 0, "planted")
+    gram, colsum, sb, _ = H.csr_gram(lib, x)
+    xd = np.asarray(x.todense(), dtype=np.float64)
+    ref = np.zeros((g, g), dtype=np.int64)
+    for r in range(n):
+        ref += np.rint(np.outer(xd[r], xd[r]) * 2.0**sb).astype(np.int64)
+    assert np.array_equal(gram[:g, :g], ref) and not gram[g:].any() and not gram[:, g:].any()
+    assert np.array_equal(colsum[:g], np.rint(xd * 2.0**sb).astype(np.int64).sum(0))
+    out = H.pca_csr(lib, x, k)
+    r = opca.pca_reference(x, k)
+    assert cmp.pca_loading_err(out["components"], r["components"]) < 1e-4
+    assert np.abs(out["variance"] - r["variance"]).max() / r["variance"][0] < 1e-5
+    assert np.abs(np.abs(out["scores"]) - np.abs(r["X_pca"])).max() < 1e-3
