@@ -54,8 +54,15 @@ __global__ void fss_max_kernel(const float* __restrict__ d, int64_t total, unsig
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  // (distances are >= 0: the bit patterns of non-negative floats order like the values)
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(mx_bits, __float_as_uint(m));
+  // one atomic per WORKGROUP (a same-address atomic per wave -- 8k of them -- was the kernel's duration, not its loads)
+  __shared__ float wm[16];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, wm[w]);
+    // (distances are >= 0: the bit patterns of non-negative floats order like the values)
+    if (m > 0.f) atomicMax(mx_bits, __float_as_uint(m));
+  }
 }
 // S = 61 - e - ceil(log2(total)) with max < 2^e: every term is < 2^(61 - ceil(log2 total)), the sum < 2^61
 __device__ __forceinline__ int fss_sum_scale_bits(float mx, int64_t total) {
@@ -94,7 +101,13 @@ __global__ void fss_sum_kernel(const float* __restrict__ d, int64_t total, const
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if ((threadIdx.x & 63) == 0 && s != 0) atomicAdd(isum, (unsigned long long)s);
+  __shared__ long long ws[16];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) s += ws[w];
+    if (s != 0) atomicAdd(isum, (unsigned long long)s);
+  }
 }
 __global__ void fss_sum_final_kernel(const unsigned long long* __restrict__ isum, const unsigned int* __restrict__ mx_bits,
                                      int64_t total, double* __restrict__ sum) {
@@ -632,7 +645,7 @@ extern "C" int scamd_fuzzy_simplicial_set_f32(const int32_t* knn_idx, const floa
   SCAMD_HIP_CHECK(hipMemsetAsync(b.sum, 0, 32, s));  // [0] sum (double), [1] fixed-point sum, [2] bits of the max
   SCAMD_HIP_CHECK(hipMemsetAsync(b.in_only, 0, sizeof(int) * n, s));
   {
-    int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
+    int blocks = (int)std::min<int64_t>((total + 255) / 256, 1024);
     unsigned long long* isum = reinterpret_cast<unsigned long long*>(b.sum + 1);
     unsigned int* mx_bits = reinterpret_cast<unsigned int*>(b.sum + 2);
     hipLaunchKernelGGL(fss_max_kernel, dim3(blocks), dim3(256), 0, s, knn_dist, total, mx_bits);
