@@ -18,6 +18,14 @@ for p in (str(ROOT), str(ROOT / "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+import os as _os  # noqa: E402
+
+if _os.environ.get("SCAMD_TESTS_ON_EMULATOR") == "1":  # the host-emulated kernel library, tests/emu/README.md
+    sys.path.insert(0, str(ROOT / "tests" / "emu"))
+    import patch_torch  # noqa: E402
+
+    patch_torch.activate()
+
 
 def run(rank: int, world: int, init_file: str, out_dir: str, n: int, g: int, n_comps: int):
     import torch.distributed as dist

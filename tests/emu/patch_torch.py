@@ -40,6 +40,64 @@ def activate() -> None:
     torch.cuda.set_device = lambda *a, **k: None
     torch.cuda.mem_get_info = lambda *a, **k: (64 << 30, 64 << 30)
     torch.Tensor.cuda = lambda self, *a, **k: self
+
+    class _Event:
+        def __init__(self, *a, **k):
+            pass
+
+        def record(self, *a, **k):
+            pass
+
+        def synchronize(self):
+            pass
+
+        def wait(self, *a, **k):
+            pass
+
+        def elapsed_time(self, other):
+            return 0.0
+
+    class _StreamCtx(_Stream):
+        def __init__(self, *a, **k):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    torch.cuda.Stream = _StreamCtx
+    torch.cuda.Event = _Event
+    torch.cuda.stream = lambda s: _StreamCtx()
+    _orig_device = torch.device
+
+    class _DeviceMeta(type):
+        def __instancecheck__(cls, obj):
+            return isinstance(obj, _orig_device)
+
+    class _Device(metaclass=_DeviceMeta):  # torch.device("cuda"[, i]) -> the cpu device; everything else unchanged
+        def __new__(cls, *a, **k):
+            if a and isinstance(a[0], str) and a[0].startswith("cuda"):
+                return cpu
+            return _orig_device(*a, **k)
+
+    torch.device = _Device
+    _orig_to = torch.Tensor.to
+
+    def _to(self, *a, **k):
+        a = tuple(cpu if (isinstance(x, str) and x.startswith("cuda")) else x for x in a)
+        if isinstance(k.get("device"), str) and k["device"].startswith("cuda"):
+            k["device"] = cpu
+        return _orig_to(self, *a, **k)
+
+    torch.Tensor.to = _to
+    _orig_empty = torch.empty
+
+    def _empty(*a, pin_memory=False, **k):  # (no page-locked memory without a GPU)
+        return _orig_empty(*a, **k)
+
+    torch.empty = _empty
     torch.Tensor.is_cuda = property(lambda self: True)
     torch.Tensor.record_stream = lambda self, s: None
 

@@ -11,6 +11,14 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
+import os as _os  # noqa: E402
+
+if _os.environ.get("SCAMD_TESTS_ON_EMULATOR") == "1":  # the host-emulated kernel library, tests/emu/README.md
+    sys.path.insert(0, str(ROOT / "tests" / "emu"))
+    import patch_torch  # noqa: E402
+
+    patch_torch.activate()
+
 VARIANTS = [
     {},                                                        # default kernels
     {},                                                        # again: dirty workspace, same process
