@@ -284,29 +284,80 @@ __global__ __launch_bounds__(256) void fss_pack_kernel(const int* __restrict__ i
   rec[q] = p;
 }
 
-// KP lanes per directed slot (i, j): weight of the reverse edge, in-only degree of the target.  (A thread per slot
-// walked the target's list entry by entry: 15 serial gathers per thread, every one of them 64 different cache lines
-// per wave -- 1.6 ms at 1M x 15.)
-template <int KP>
+// KP lanes per group, SPG consecutive directed slots (i, j) per group: weight of the reverse edge, in-only degree of the
+// target.  The kernel is bound by latency x occupancy, not by traffic (one 128-byte record per slot instead of two
+// 60-byte rows did not change its 1.0 ms): with one slot per group a wave made two dependent round trips (w / idx, then
+// the record) for 4 slots, and 3.75M such waves at 8 per SIMD take ~3 us each.  Now the SPG slot loads of a group are
+// issued together, then its SPG record gathers: a quarter of the waves, four gathers in flight per lane.
+// (Before records: a thread per slot walked the target's list entry by entry -- 15 serial gathers per thread, every one
+// of them 64 different cache lines per wave: 1.6 ms at 1M x 15.)
+// value of the lane CTRL & 15 places to the left in the same row of 16 lanes (DPP row_ror)
+template <int CTRL>
+__device__ __forceinline__ float row_ror_f32(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+template <int KP, int SPG>
 __global__ __launch_bounds__(256) void fss_recip_rec_kernel(const int* __restrict__ idx, const float* __restrict__ w,
                                                             const int2* __restrict__ rec, int64_t n, int k,
                                                             float* __restrict__ recw, int* __restrict__ in_only) {
   const int sub = threadIdx.x & (KP - 1);
-  const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / KP;
-  const bool live = e < n * k;
-  const float we = live ? w[e] : 0.f;
-  const int t = live ? idx[e] : 0;
-  float r = 0.f;
-  if (we > 0.f) {
-    const int i = (int)(e / k);
-    const int2 p = rec[(int64_t)t * KP + sub];
-    if (p.x == i) r = __int_as_float(p.y);
-  }
+  const int64_t e0 = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / KP) * SPG;
+  const int64_t total = n * k;
+  float we[SPG];
+  int t[SPG];
 #pragma unroll
-  for (int o = KP / 2; o > 0; o >>= 1) r = fmaxf(r, __shfl_xor(r, o));
-  if (live && sub == 0) {
-    if (we > 0.f && r == 0.f) atomicAdd(&in_only[t], 1);
-    recw[e] = r;
+  for (int q = 0; q < SPG; ++q) {
+    const bool live = e0 + q < total;
+    we[q] = live ? w[e0 + q] : 0.f;
+    t[q] = live ? idx[e0 + q] : 0;
+  }
+  int2 p[SPG];
+#pragma unroll
+  for (int q = 0; q < SPG; ++q)  // (absent slots read record 0: no branch around the gather)
+    p[q] = rec[(int64_t)(we[q] > 0.f ? t[q] : 0) * KP + sub];
+  // row of slot e0 by ONE division (32-bit when the slot count allows: a 64-bit division is ~100 instructions, four of
+  // them per lane were a third of the kernel's instruction count), rows of the following slots by counting up
+  int i0, j0;
+  if (total < ((int64_t)1 << 31)) {
+    i0 = (int)((unsigned int)e0 / (unsigned int)k);
+    j0 = (int)((unsigned int)e0 - (unsigned int)i0 * (unsigned int)k);
+  } else {
+    i0 = (int)(e0 / k);
+    j0 = (int)(e0 - (int64_t)i0 * k);
+  }
+  float r[SPG];
+#pragma unroll
+  for (int q = 0; q < SPG; ++q) {
+    int i = i0, j = j0 + q;
+    while (j >= k) {  // (k >= 2, q < SPG: at most SPG / 2 + 1 trips)
+      j -= k;
+      ++i;
+    }
+    r[q] = (we[q] > 0.f && p[q].x == i) ? __int_as_float(p[q].y) : 0.f;
+  }
+  // maximum over the KP lanes of the group, in every lane: rotations inside a row of 16 lanes are DPP modifiers of the
+  // v_max itself (one instruction each; __shfl_xor is a ds_bpermute round trip through the LDS crossbar)
+#pragma unroll
+  for (int q = 0; q < SPG; ++q) {
+    if (KP == 32) r[q] = fmaxf(r[q], __shfl_xor(r[q], 16));
+    r[q] = fmaxf(r[q], row_ror_f32<0x128>(r[q]));
+    r[q] = fmaxf(r[q], row_ror_f32<0x124>(r[q]));
+    r[q] = fmaxf(r[q], row_ror_f32<0x122>(r[q]));
+    r[q] = fmaxf(r[q], row_ror_f32<0x121>(r[q]));
+  }
+  // lane q of the group writes slot q
+  float my_r = 0.f, my_w = 0.f;
+  int my_t = 0;
+#pragma unroll
+  for (int q = 0; q < SPG; ++q)
+    if (sub == q) {
+      my_r = r[q];
+      my_w = we[q];
+      my_t = t[q];
+    }
+  if (sub < SPG && e0 + sub < total) {
+    if (my_w > 0.f && my_r == 0.f) atomicAdd(&in_only[my_t], 1);
+    recw[e0 + sub] = my_r;
   }
 }
 
@@ -579,13 +630,13 @@ static int symmetrise(const FuzzyBuffers& b, const int32_t* knn_idx, int64_t n, 
   if (kp == 16) {
     hipLaunchKernelGGL(fss_pack_kernel<16>, dim3(ceil_div(n * 16, 256)), dim3(256), 0, s, knn_idx, b.w, n, k, b.tmp);
     SCAMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fss_recip_rec_kernel<16>, dim3(ceil_div(total * 16, 256)), dim3(256), 0, s, knn_idx, b.w, b.tmp, n,
-                       k, b.recw, b.in_only);
+    hipLaunchKernelGGL((fss_recip_rec_kernel<16, 4>), dim3(ceil_div(ceil_div(total, 4) * (int64_t)16, 256)), dim3(256), 0, s,
+                       knn_idx, b.w, b.tmp, n, k, b.recw, b.in_only);
   } else if (kp == 32) {
     hipLaunchKernelGGL(fss_pack_kernel<32>, dim3(ceil_div(n * 32, 256)), dim3(256), 0, s, knn_idx, b.w, n, k, b.tmp);
     SCAMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fss_recip_rec_kernel<32>, dim3(ceil_div(total * 32, 256)), dim3(256), 0, s, knn_idx, b.w, b.tmp, n,
-                       k, b.recw, b.in_only);
+    hipLaunchKernelGGL((fss_recip_rec_kernel<32, 4>), dim3(ceil_div(ceil_div(total, 4) * (int64_t)32, 256)), dim3(256), 0, s,
+                       knn_idx, b.w, b.tmp, n, k, b.recw, b.in_only);
   } else {
     hipLaunchKernelGGL(fss_recip_kernel, dim3(ceil_div(total, 16)), dim3(256), 0, s, knn_idx, b.w, n, k, b.recw,
                        b.in_only);

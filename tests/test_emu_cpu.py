@@ -179,3 +179,22 @@ def test_pca_chain(emu):
     assert cmp.pca_loading_err(out["components"], r["components"]) < 1e-4
     assert np.abs(out["variance"] - r["variance"]).max() / r["variance"][0] < 1e-5
     assert np.abs(np.abs(out["scores"]) - np.abs(r["X_pca"])).max() < 1e-3
+
+
+def test_knn_second_tier(emu, monkeypatch):
+    """pruned sweep on the bf16 engine with a widened certificate (cert_scale 10): ~1000 of 5000 queries are rejected by
+    the first tier and re-done by the float32 engine, a handful reach the float64 scan; the lists stay the brute-force ones"""
+    from scanpy_amd.datasets import blobs_embedding
+
+    H, lib = emu
+    n, k = 5000, 15
+    x, _ = blobs_embedding(n, 50, n_types=12, seed=11)
+    x = (x + np.float32(40.0)).astype(np.float32)
+    monkeypatch.setenv("SCAMD_KNN_IVF", "0")
+    i0, d0, _ = H.knn(lib, x, k)
+    for k_, v_ in (("SCAMD_KNN_IVF", "1"), ("SCAMD_KNN_CELL_ROWS", "512"), ("SCAMD_KNN_THR_MARGIN", "2"), ("SCAMD_KNN_TIER2_MIN", "0")):
+        monkeypatch.setenv(k_, v_)
+    i1, d1, n_scan = H.knn(lib, x, k, cert_scale=10.0)
+    t2 = int(lib.scamd_knn_last_second_tier_queries())
+    assert int(lib.scamd_knn_last_select_engine()) == 1 and t2 > 100 and n_scan < t2, (t2, n_scan)
+    assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
