@@ -114,6 +114,20 @@ def activate() -> None:
         "to_host": lambda t: t.detach().numpy(),
     }
     _lib.load = lambda: emu
+    # ASan build: the gaps between the carve-outs of a call stay poisoned in the pooled workspace; entry points that do
+    # not carve (scamd_colsum_f32_f64 takes the raw pointer) would trip over the previous call's gaps
+    from scanpy_amd import _kernels
+
+    _orig_ws = _kernels._ws
+
+    def _ws(nbytes, dev):
+        import ctypes as C
+
+        buf, size = _orig_ws(nbytes, dev)
+        emu.emu_unpoison(C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()))
+        return buf, size
+
+    _kernels._ws = _ws
     _device.pinned_uploader.upload = lambda arr, device: torch.from_numpy(np.ascontiguousarray(arr))
     # (`from ._device import require_gpu, ...` copied the originals into the importing modules)
     for name, mod in list(sys.modules.items()):
