@@ -1344,6 +1344,7 @@ struct SmallArgs {
   unsigned int seed;
   int iter;
   int lm_stop_permille;
+  int seq_n;               // levels of at most this many vertices move one vertex at a time
   int* info;               // [0] levels, [1] moves, [2] merges, [3] nodes of the last level
 };
 
@@ -1433,6 +1434,7 @@ __device__ __forceinline__ int small_compact(int n, P pred, unsigned short* orde
   return base;
 }
 
+constexpr int SMALL_SEQ_N = 16;   // levels of at most this many vertices: local moving one vertex at a time (SCAMD_LEIDEN_SMALL_SEQ)
 __global__ __launch_bounds__(SM_THREADS) void ld_small_levels_kernel(SmallArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char small_smem[];
   SmallLds& L = *reinterpret_cast<SmallLds*>(small_smem);
@@ -1502,9 +1504,15 @@ __global__ __launch_bounds__(SM_THREADS) void ld_small_levels_kernel(SmallArgs a
       const unsigned int pa = hs | 1u, pb = hs >> 11;
       const int dir_round = sweep >= LM_DIR_AFTER ? sweep : -1;
       __syncthreads();
-      for (int r0 = 0; r0 < m; r0 += SM_WAVES) {
+      // Vertices that decide in the same round do not see each other's moves.  Eight at a time is harmless among
+      // hundreds of vertices; on the small DENSE graphs of the upper levels (every pair adjacent) it made neighbours swap
+      // communities round after round -- found on the host emulator: a 2-vertex graph ended as two singletons
+      // (Q = -0.5), 21 of 60 random graphs of <= 40 vertices below the CPU oracle.  There the vertices decide one at a
+      // time, as in the sequential algorithm (a round is three barriers: 128 rounds cost less than one launch).
+      const int par = n <= a.seq_n ? 1 : SM_WAVES;
+      for (int r0 = 0; r0 < m; r0 += par) {
         const int pos = (int)(((unsigned int)(r0 + wv) * pa + pb) & (unsigned int)(m - 1));
-        const int v = pos < n_act ? (int)L.order[pos] : -1;
+        const int v = (wv < par && pos < n_act) ? (int)L.order[pos] : -1;
         int decision = -1;
         if (v >= 0) {
           const int ca = L.comm[v];
@@ -2033,6 +2041,7 @@ struct LeidenCtx {
   int lm_classes = 0;         // class sub-rounds per local-moving sweep (0 = by level size; SCAMD_LEIDEN_LM_CLASSES)
   int rf_classes = 0;         // class sub-rounds of the refinement (0 = by level size; SCAMD_LEIDEN_RF_CLASSES)
   bool small_levels = true;   // levels of <= SMALL_N nodes in one workgroup (SCAMD_LEIDEN_SMALL=0: separate kernels)
+  int small_seq_n = SMALL_SEQ_N;  // ... of which those of <= small_seq_n vertices move one vertex at a time (SCAMD_LEIDEN_SMALL_SEQ)
   // coarse-row build tiers (distinct-neighbour bounds); the env overrides exist so the tests can push small graphs
   // through the workgroup and multi-pass tiers
   int agg_wave_max = WH_MAX_DEG;
@@ -2441,6 +2450,7 @@ static int small_levels(LeidenCtx& cx, const LevelGraph& g, int level) {
   a.seed = cx.seed;
   a.iter = cx.iter;
   a.lm_stop_permille = cx.lm_stop_permille;
+  a.seq_n = cx.small_seq_n;
   a.info = b.counters + 12;
   hipLaunchKernelGGL(ld_small_levels_kernel, dim3(1), dim3(SM_THREADS), sizeof(SmallLds), cx.s, a);
   SCAMD_LAUNCH_CHECK();
@@ -2596,6 +2606,7 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
   cx.lm_classes = classes_env("SCAMD_LEIDEN_LM_CLASSES");
   cx.rf_classes = classes_env("SCAMD_LEIDEN_RF_CLASSES");
   if (const char* e = getenv("SCAMD_LEIDEN_SMALL")) cx.small_levels = e[0] != '0';
+  if (const char* e = getenv("SCAMD_LEIDEN_SMALL_SEQ")) cx.small_seq_n = atoi(e);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_WAVE_MAX")) cx.agg_wave_max = std::min(atoi(e), (int)WH_MAX_DEG);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_MAX")) cx.agg_mid_max = std::min(atoi(e), (int)AGG_MID_MAX);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_PASS_KEYS"))

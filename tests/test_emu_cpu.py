@@ -198,3 +198,29 @@ def test_knn_second_tier(emu, monkeypatch):
     t2 = int(lib.scamd_knn_last_second_tier_queries())
     assert int(lib.scamd_knn_last_select_engine()) == 1 and t2 > 100 and n_scan < t2, (t2, n_scan)
     assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+
+
+def test_leiden_tiny_graphs(emu):
+    """levels of <= 16 vertices move one vertex at a time: a single edge must end as ONE community (eight vertices deciding
+    at once made its two ends swap communities for ever: two singletons, Q = -0.5), nothing ends below Q = 0"""
+    from scipy import sparse
+
+    from oracle import leiden as ol
+
+    H, lib = emu
+    rng = np.random.default_rng(1)
+    graphs = [sparse.csr_matrix(np.array([[0, 1], [1, 0]], dtype=np.float32)),
+              sparse.csr_matrix(np.array([[0, 1, 0], [1, 0, 0], [0, 0, 0]], dtype=np.float32))]
+    while len(graphs) < 25:
+        n = int(rng.integers(3, 24))
+        a = (rng.random((n, n)) < rng.choice([0.1, 0.3, 0.6, 1.0])).astype(np.float32) * rng.random((n, n)).astype(np.float32)
+        a = np.triu(a, 1)
+        if a.sum() > 0:
+            graphs.append(sparse.csr_matrix(a + a.T))
+    memb, q, nc = H.leiden(lib, graphs[0], seed=0)
+    assert nc == 1 and q == 0.0
+    for g in graphs:
+        for seed in (0, 1):
+            memb, q, _ = H.leiden(lib, g, seed=seed)
+            assert q > -1e-12 and abs(q - ol.modularity(g, memb)) < 1e-9
+            assert q > min(ol.leiden(g, seed=s)[1] for s in range(3)) - 0.05

@@ -162,6 +162,38 @@ def test_leiden_small_levels_in_one_workgroup_vs_separate_kernels(K, monkeypatch
     assert min(out["1"][0], out["0"][0]) > q_oracle - 3e-3
 
 
+def _tiny_graphs():
+    from scipy import sparse
+
+    rng = np.random.default_rng(1)
+    out = [sparse.csr_matrix(np.array([[0, 1], [1, 0]], dtype=np.float32)),                       # one edge
+           sparse.csr_matrix(np.array([[0, 1, 0], [1, 0, 0], [0, 0, 0]], dtype=np.float32))]      # an edge and a loner
+    while len(out) < 40:
+        n = int(rng.integers(3, 24))
+        a = (rng.random((n, n)) < rng.choice([0.1, 0.3, 0.6, 1.0])).astype(np.float32) * rng.random((n, n)).astype(np.float32)
+        a = np.triu(a, 1)
+        if a.sum() > 0:
+            out.append(sparse.csr_matrix(a + a.T))
+    return out
+
+
+def test_leiden_tiny_graphs(K):
+    """Levels of <= 16 vertices move one vertex at a time (ld_small_levels_kernel, SMALL_SEQ_N): with eight vertices deciding
+    at once on such graphs neighbours swapped communities for ever -- a single edge ended as two singletons (Q = -0.5).
+    Found on the host emulation of the kernels (tests/emu), which also showed the rule costs larger levels nothing."""
+    worst = 0.0
+    for adj in _tiny_graphs():
+        ip, ix, w, n = _graph_dev(adj)
+        q_oracle = min(ol.leiden(adj, seed=s)[1] for s in range(5))  # the oracle's worst of five seeds
+        for seed in (0, 1):
+            m, q, _ = K.leiden(ip, ix, w, n, seed=seed)
+            assert abs(q - ol.modularity(adj, m.cpu().numpy())) < 1e-9
+            assert q > -1e-12, (n, adj.nnz, q)  # (the one-community partition has Q = 0: nothing may end below it)
+            worst = min(worst, q - q_oracle)
+    print("largest shortfall against the oracle's worst seed", worst)
+    assert worst > -0.05  # (a 13-vertex graph ends in a local optimum 0.036 below the oracle for two seeds: visiting order)
+
+
 def test_leiden_quarter_wave_kernels_agree(K, monkeypatch):
     """four-vertices-per-wave and wave-per-vertex decision kernels implement the same rule: same partition"""
     adj, _ = _blob_graph(6000, 12, seed=4)
