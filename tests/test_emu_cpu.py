@@ -224,3 +224,28 @@ def test_leiden_tiny_graphs(emu):
             memb, q, _ = H.leiden(lib, g, seed=seed)
             assert q > -1e-12 and abs(q - ol.modularity(g, memb)) < 1e-9
             assert q > min(ol.leiden(g, seed=s)[1] for s in range(3)) - 0.05
+
+
+def test_front_ends_and_widening_kernels_on_the_emulator(emu):
+    """A subset of the `-m gpu` tests themselves, run in a child process against the emulated library
+    (SCAMD_TESTS_ON_EMULATOR=1, tests/emu/patch_torch.py): the drop-in front ends (sc.pp.pca goldens, sc.pp.neighbors
+    options incl. the transformer plug-in route and gauss / jaccard, sc.tl.leiden parameters and errors), the
+    normalize / log1p / HVG / scale kernels against the reference's goldens and the UMAP layout kernel against its
+    synchronous restatement -- the cases a lane-by-lane executor finishes in a minute."""
+    import os
+    import re
+    import subprocess
+
+    keep = ("pca_transform_golden or pca_no_zero_center_golden or pca_shapes_and_errors or neighbors_key_added or leiden_errors or "
+            "neighbors_precomputed_distances or neighbors_fixture_vs_oracle or gauss_and_jaccard or neighbors_cosine_metric or "
+            "transformer_plugin_route or leiden_restrict_to or leiden_basic_and_params or normalize_total or rep_mutation or "
+            "test_scale or test_filters or chain_goldens or random_against_oracle or col_stats_clip or hvg_ or global-atomics or "
+            "kernel_matches_synchronous_oracle or device_pruning or empty_matrix_and_bad_arguments")
+    env = dict(os.environ, SCAMD_TESTS_ON_EMULATOR="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_gpu_pipeline.py"),
+                          str(ROOT / "tests" / "test_gpu_preprocess.py"), str(ROOT / "tests" / "test_gpu_umap.py"), "-m", "gpu", "-q",
+                          "-p", "no:cacheprovider", "-k", keep], env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=1500)
+    tail = out.stdout[-1500:]
+    assert out.returncode == 0, tail
+    m = re.search(r"(\d+) passed", tail)
+    assert m and int(m.group(1)) >= 40, tail
