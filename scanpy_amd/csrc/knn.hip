@@ -1074,22 +1074,32 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
       if (idx >= 0 && idx < n && idx != q) {
         const float* cp = x + (int64_t)idx * ld;
         double s = 0.0;
-        // eight coordinates of the candidate's row requested at a time, summed in the same order as one by one (every
-        // lane walks its own row: one load in flight per lane made this kernel 50 serial cache round trips per query)
-        int c = 0;
-        for (; c + 8 <= d; c += 8) {
-          float t[8];
+        // RB coordinates of the candidate's row requested at a time, summed in the same order as one by one (every lane
+        // walks its own row: one load in flight per lane made this kernel 50 serial cache round trips per query; eight at
+        // a time plus a one-by-one tail were still 8 trips for d = 50 in a kernel of a wave per query -- a million waves,
+        // latency x occupancy bound).  The tail is a partial batch: clamped addresses, products of the pad not added.
+        constexpr int RB = 12;
+        // two batches in flight: the loads of batch b + 1 are issued before batch b is consumed
+        float ta[RB], tb[RB];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) t[u] = cp[c + u];
+        for (int u = 0; u < RB; ++u) ta[u] = cp[min(u, d - 1)];
+        for (int c = 0; c < d; c += 2 * RB) {
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const double df = (double)qs[w][c + u] - (double)t[u];
+          for (int u = 0; u < RB; ++u) tb[u] = cp[min(c + RB + u, d - 1)];
+#pragma unroll
+          for (int u = 0; u < RB; ++u) {
+            // (no branch: a pad coordinate contributes fma(0, 0, s) = s; with `if (c + u < d)` the compiler loaded one
+            // element of the batch inside the branch and waited for ALL of them there)
+            const double df = c + u < d ? (double)qs[w][min(c + u, d - 1)] - (double)ta[u] : 0.0;
             s = fma(df, df, s);
           }
-        }
-        for (; c < d; ++c) {
-          const double df = (double)qs[w][c] - (double)cp[c];
-          s = fma(df, df, s);
+#pragma unroll
+          for (int u = 0; u < RB; ++u) ta[u] = cp[min(c + 2 * RB + u, d - 1)];
+#pragma unroll
+          for (int u = 0; u < RB; ++u) {
+            const double df = c + RB + u < d ? (double)qs[w][min(c + RB + u, d - 1)] - (double)tb[u] : 0.0;
+            s = fma(df, df, s);
+          }
         }
         myd[p] = s;
         myi[p] = idx;
