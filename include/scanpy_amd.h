@@ -90,6 +90,18 @@ int scamd_knn_last_select_engine(void);
  * pruned search; 0 when the count stayed below SCAMD_KNN_TIER2_MIN, default 256, or the float32 engine ran anyway).
  * `n_fallback_host` of scamd_knn_l2_f32 counts what went to the float64 scan after that. */
 int scamd_knn_last_second_tier_queries(void);
+/* The certificate's error-bound factors of an engine (0 = float32, 1 = 3 x bf16), in units of u = 2^-24:
+ *   |score_engine - score_exact| <= u * (cert_k * (||c||^2 + 2 ||q|| ||c||) + cert_k2 * 2 ||q|| ||c||) (+ key_slack * u * |tau|
+ * for the slot bits of the list keys).  Read by the test that measures the bound (tests/test_gpu_knn_certificate.py). */
+void scamd_knn_cert_factors(int engine, double* cert_k, double* cert_k2, double* key_slack);
+/* Test entry: raw scores ||c||^2 - 2 q.c (centred frame) of the bf16 engine for queries [q0, q0 + nq) x candidates
+ * [c0, c0 + nc) of x [n, d <= 50] (both counts multiples of 32), through the select kernel's own image packing, operand
+ * construction and MFMA chain.  out_scores [nq, nc] float32; out_mu [128] (the column means the image was centred with) and
+ * out_cmax [1] (largest ||x - mu||^2) may be NULL.  Not part of the search; measures the engine's arithmetic error. */
+size_t scamd_knn_debug_b3_scores_workspace_bytes(int64_t n);
+int scamd_knn_debug_b3_scores_f32(const float* x, int64_t n, int d, int64_t ld_x, int64_t q0, int nq, int64_t c0, int nc,
+                                  float* out_scores, float* out_mu, float* out_cmax, void* workspace,
+                                  size_t workspace_bytes, scamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fuzzy simplicial set -- umap connectivities from a kNN result.

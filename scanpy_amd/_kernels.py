@@ -49,6 +49,32 @@ def knn(x: torch.Tensor, k: int, *, q_begin: int = 0, n_query: int | None = None
     return idx, dist, int(nfb.value)
 
 
+def knn_cert_factors(engine: int = 1):
+    """the certificate's error-bound factors (cert_k, cert_k2, key_slack) of an engine, in units of u = 2^-24"""
+    a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
+    _lib.load().scamd_knn_cert_factors(int(engine), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def knn_debug_b3_scores(x: torch.Tensor, q0: int, nq: int, c0: int, nc: int):
+    """TEST entry: raw scores ||c||^2 - 2 q.c (centred frame) of the bf16 engine for queries [q0, q0 + nq) x candidates
+    [c0, c0 + nc) (multiples of 32), through the select kernel's own packing and MFMA chain.
+    -> (scores float32 [nq, nc], mu float32 [d], cmax float)"""
+    dev = require_gpu()
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.is_cuda
+    x = x.contiguous()
+    n, d = x.shape
+    out = torch.empty((nq, nc), dtype=torch.float32, device=dev)
+    mu = torch.empty(128, dtype=torch.float32, device=dev)
+    cmax = torch.empty(1, dtype=torch.float32, device=dev)
+    ws, wsz = _ws(lib.scamd_knn_debug_b3_scores_workspace_bytes(n), dev)
+    rc = lib.scamd_knn_debug_b3_scores_f32(ptr(x), n, d, x.stride(0), q0, nq, c0, nc, ptr(out), ptr(mu), ptr(cmax),
+                                           ptr(ws), wsz, stream_ptr())
+    _lib.check(rc, "scamd_knn_debug_b3_scores_f32")
+    return out, mu[:d], float(cmax.item())
+
+
 def fuzzy_simplicial_set(knn_idx: torch.Tensor, knn_dist: torch.Tensor):
     """-> (indptr int64 [n+1], indices int32 [nnz], data float32 [nnz], sigma [n], rho [n])."""
     dev = require_gpu()

@@ -38,6 +38,14 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 
+// destination operand of __builtin_amdgcn_global_load_lds (an LDS-address-space pointer; the host emulation of the kernels,
+// tests/emu, has one address space)
+#ifdef SCAMD_EMU
+#define SCAMD_LDS_PTR(p) (p)
+#else
+#define SCAMD_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#endif
+
 constexpr int FALLBACK_CAP = 2048;    // collected rows per uncertified query
 constexpr int FALLBACK_CHUNK = 1024;  // uncertified queries processed per launch
 
@@ -494,6 +502,7 @@ struct IvfArgs {
   const int* perm;          // [n_image_rows] original row id of an image row (-1 = padding)
   unsigned long long* pairs; // (query, candidate) pairs evaluated, for the roofline figure
   const int* block_perm;     // [n_blocks] launch slot -> block: cells with the longest expected sweep first (LPT)
+  int* qorder;               // [n_blocks * 128] out (may be null): query number (row - q_begin) of every query slot, -1 = padding
   int prepass_tiles;         // tiles of the own cell the threshold pre-pass scores (SCAMD_KNN_PREPASS_TILES, default 16)
   int debug_no_insert;       // debug (SCAMD_KNN_DEBUG_NO_INSERT=1): survivors are dropped -- WRONG results, MFMA-side ceiling
   unsigned long long* trace; // debug (SCAMD_KNN_TRACE=<file>): per block {start, end (100 MHz clock), tiles swept, hw id}
@@ -510,6 +519,49 @@ struct BFragBf16 {
   i32x4 h[4], l[4];  // k-steps of 16 dims: 8 bf16 of the hi part / of the lo part per lane
 };
 
+// The bf16 engine's arithmetic, shared by the select kernel and by the debug entry that returns raw scores
+// (scamd_knn_debug_b3_scores_f32: the test of the certificate's error bound measures THESE instructions).
+// Query operand of lane (half, l31): k-step s holds dims 16 s + 8 half .. + 8 of -2 q as four bf16 pairs, hi part in qh,
+// lo part in ql (the scaling by -2 is exact); dims 50..55 of the query side are [-t1, -t2, -t3, 1, 1, 1] (threshold 0 here).
+__device__ __forceinline__ void b3_query_operand(const float* __restrict__ xp, int64_t qrow, int half, i32x4 (&qh)[4],
+                                                 i32x4 (&ql)[4]) {
+  const i32x4* qp = reinterpret_cast<const i32x4*>(xp + qrow * B3_DPL);
+  auto neg2 = [](int w) {
+    const float a = -2.0f * __uint_as_float((unsigned int)w << 16), b = -2.0f * __uint_as_float((unsigned int)w & 0xffff0000u);
+    return (int)((__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u));
+  };
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const i32x4 h4 = qp[2 * s + half], l4 = qp[8 + 2 * s + half];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      qh[s][j] = neg2(h4[j]);
+      ql[s][j] = neg2(l4[j]);
+    }
+  }
+  if (half == 0) {
+    qh[3][1] = 0;                      // dims 50, 51: -t1, -t2 (threshold 0 until the lists are filled)
+    qh[3][2] = 0x3F800000;             // dims 52, 53: -t3, 1
+    qh[3][3] = 0x3F803F80;             // dims 54, 55: 1, 1
+  }
+}
+// scores of one 32 x 32 sub-tile minus the thresholds: qh.ch, then qh.cl, then ql.ch, 4 k-steps of 16 dims each
+__device__ __forceinline__ f32x16 b3_chain(const i32x4 (&qh)[4], const i32x4 (&ql)[4], const BFragBf16& b) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qh[s]), __builtin_bit_cast(bf16x8, b.h[s]), acc, 0, 0, 0);
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qh[s]), __builtin_bit_cast(bf16x8, b.l[s]), acc, 0, 0, 0);
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ql[s]), __builtin_bit_cast(bf16x8, b.h[s]), acc, 0, 0, 0);
+  return acc;
+}
+
 template <int H, int TC_, int WPS, bool IVF, bool B3 = false>
 __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* __restrict__ xp, int n_tiles_all,
                                                                   int64_t n_pad, int64_t q_begin,
@@ -525,7 +577,10 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
   const int thr_lane = thr_rank - 1;
   // block id: the pruned sweep hands out its blocks longest-expected-sweep first (block_perm)
   int blk = blockIdx.x;
-  if constexpr (IVF) blk = iv.block_perm[blockIdx.x];
+  if constexpr (IVF) {
+    blk = iv.block_perm[blockIdx.x];
+    if (blk < 0) return;  // launch slot without a block (XCD-aware order: ivf_block_order_kernel)
+  }
 
   // A operand: lane l holds query (l&31), dims [half*H, half*H+H), pre-scaled by -2
   // (B3: k-step s, lane half h: dims 16 s + 8 h .. + 8 as four bf16 pairs, hi part in qh, lo part in ql)
@@ -546,26 +601,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
 #pragma unroll
     for (int s = 0; s < H; ++s) aq[s] = -2.0f * qp[s];
   } else {
-    // -2 q as bf16 pairs (the scaling is exact); dims 50..55 of the query side are [-t1, -t2, -t3, 1, 1, 1]
-    const i32x4* qp = reinterpret_cast<const i32x4*>(xp + qrow * DPL);
-    auto neg2 = [](int w) {
-      const float a = -2.0f * __uint_as_float((unsigned int)w << 16), b = -2.0f * __uint_as_float((unsigned int)w & 0xffff0000u);
-      return (int)((__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u));
-    };
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const i32x4 h4 = qp[2 * s + half], l4 = qp[8 + 2 * s + half];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        qh[s][j] = neg2(h4[j]);
-        ql[s][j] = neg2(l4[j]);
-      }
-    }
-    if (half == 0) {
-      qh[3][1] = 0;                      // dims 50, 51: -t1, -t2 (threshold 0 until the lists are filled)
-      qh[3][2] = 0x3F800000;             // dims 52, 53: -t3, 1
-      qh[3][3] = 0x3F803F80;             // dims 54, 55: 1, 1
-    }
+    b3_query_operand(xp, qrow, half, qh, ql);
   }
 
   // A operand of the extra k-pair: lanes 0..31 hold -thr of query (l&31), lanes 32..63 hold 1.0.
@@ -624,27 +660,19 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
   };
   // scores of one sub-tile minus the thresholds (the MFMA chain)
   auto chain = [&](const BFrag& b, float athr_op) -> f32x16 {
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     if constexpr (B3) {
       (void)athr_op;
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qh[s]), __builtin_bit_cast(bf16x8, b.h[s]), acc, 0, 0, 0);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qh[s]), __builtin_bit_cast(bf16x8, b.l[s]), acc, 0, 0, 0);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ql[s]), __builtin_bit_cast(bf16x8, b.h[s]), acc, 0, 0, 0);
+      return b3_chain(qh, ql, b);
     } else {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[0], b.v[0], acc, 0, 0, 0);
 #pragma unroll
       for (int s = 1; s < H; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s], b.v[s], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(athr_op, b.v[H], acc, 0, 0, 0);
+      return acc;
     }
-    return acc;
   };
   // Insert the survivors of a sub-tile.  acc[r] = score - (threshold its chain used); that threshold is lane
   // i(r,h) of `athr_used` (negated).  all = true (very first sub-tile): every finite score is inserted.
@@ -801,10 +829,13 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
 
   if constexpr (!IVF) {
     sweep(0, n_tiles_all, true);
+    // the lists leave in SORTED order (entry l31 = the l31-th smallest key; its row id sits in the slot named by the key's
+    // low bits): pass 2 re-ranks the entries below the threshold only (knn_rerank_rows_kernel)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t q = (int64_t)blk * C::QB + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      cand_idx[q * C::KP + l31] = idx[r];
+      const int sid = __shfl(idx[r], 32 * half + (__float_as_int(key[r]) & KEY_SLOT_MASK));
+      cand_idx[q * C::KP + l31] = sid;
       if (l31 == thr_lane) cand_tau[q] = key[r];
     }
   } else {
@@ -897,17 +928,22 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
       tr[3] = ((unsigned long long)xcc << 32) | hw;
     }
     // results go to the ORIGINAL query / row ids
+    // (sorted order: see the brute-force branch; the shuffle sits outside the branch on qp -- every lane takes part)
     const int qbase = (int64_t)blk * C::QB + wave * 32;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qslot = qbase + (r & 3) + 8 * (r >> 2) + 4 * half;
       const int qp = iv.qpos[qslot];
+      const int sid = __shfl(idx[r], 32 * half + (__float_as_int(key[r]) & KEY_SLOT_MASK));
+      // final threshold = min(list entry, pre-pass threshold): everything below it is in the list
+      // (cross-lane reads before the branch on qp: the two halves of the wave may part there)
+      const int i0 = (r & 3) + 8 * (r >> 2), i1 = i0 + 4;
+      const float tf0 = -readlane_f32(athr, i0), tf1 = -readlane_f32(athr, i1);
+      // pass 2 walks the queries in slot order (= cell order: neighbouring queries share their candidates' rows)
+      if (iv.qorder && l31 == 0) iv.qorder[qslot] = qp >= 0 ? iv.perm[qp] - (int)q_begin : -1;
       if (qp >= 0) {
         const int64_t qi = (int64_t)iv.perm[qp] - q_begin;
-        cand_idx[qi * C::KP + l31] = idx[r] >= 0 ? iv.perm[idx[r]] : -1;
-        // final threshold = min(list entry, pre-pass threshold): everything below it is in the list
-        const int i0 = (r & 3) + 8 * (r >> 2), i1 = i0 + 4;
-        const float tf0 = -readlane_f32(athr, i0), tf1 = -readlane_f32(athr, i1);
+        cand_idx[qi * C::KP + l31] = sid >= 0 ? iv.perm[sid] : -1;
         if (l31 == thr_lane) cand_tau[qi] = half ? tf1 : tf0;
       }
     }
@@ -987,12 +1023,13 @@ __global__ __launch_bounds__(256) void ivf_cell_order_kernel(const float* __rest
 // last ~12 % of a launch ran with most CUs idle (SCAMD_KNN_TRACE timeline, round 2).
 __global__ __launch_bounds__(1024) void ivf_block_order_kernel(const int* __restrict__ work, const int* __restrict__ blk_off,
                                                                const int* __restrict__ blk_cnt, int n_cells,
-                                                               int* __restrict__ block_perm) {
+                                                               int* __restrict__ block_perm, int n_slots, int xcd_mode) {
   __shared__ long long key[IVF_MAX_CELLS];
   __shared__ int start[IVF_MAX_CELLS];
   const int tid = threadIdx.x;
   // descending work, ascending cell: key = (~work << 32) | cell, sorted ascending
   key[tid] = tid < n_cells ? (((long long)(0x7fffffff - work[tid])) << 32) | (unsigned int)tid : 0x7fffffffffffffffll;
+  for (int t = tid; t < n_slots; t += 1024) block_perm[t] = -1;  // launch slots without a block (xcd_mode) exit at once
   __syncthreads();
   for (int kk = 2; kk <= IVF_MAX_CELLS; kk <<= 1) {
     for (int j = kk >> 1; j > 0; j >>= 1) {
@@ -1008,20 +1045,38 @@ __global__ __launch_bounds__(1024) void ivf_block_order_kernel(const int* __rest
       __syncthreads();
     }
   }
-  // exclusive scan of the block counts in sorted order (serial: 1024 entries)
+  // xcd_mode: workgroup s of a launch runs on XCD s mod 8 (eight L2 caches that do not share).  The blocks of ONE cell
+  // sweep the same cells in the same order, so they go to ONE XCD -- launch slots x, x + 8, x + 16, ... -- and pull each
+  // tile through that L2 once instead of through all eight (round 4 counters of the block-id order: 35 GB fetched from
+  // the memory side for 59 GB staged into LDS per launch).  Cells are handed, longest expected sweep first, to the XCD
+  // with the fewest blocks so far: every XCD's queue is still longest-first, and the queue lengths differ by less than
+  // one cell's blocks.  Otherwise: exclusive scan of the block counts in sorted order (serial: 1024 entries)
   if (tid == 0) {
     int run = 0;
+    int len[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < n_cells; ++i) {
       const int c = (int)(key[i] & 0xffffffffll);
-      start[i] = run;
-      run += blk_cnt[c];
+      const int cnt = blk_cnt[c];
+      if (xcd_mode) {
+        int xb = 0;
+        for (int x = 1; x < 8; ++x)
+          if (len[x] < len[xb]) xb = x;
+        start[i] = len[xb] * 8 + xb;
+        len[xb] += cnt;
+      } else {
+        start[i] = run;
+        run += cnt;
+      }
     }
   }
   __syncthreads();
   if (tid < n_cells) {
     const int c = (int)(key[tid] & 0xffffffffll);
     const int o = blk_off[c], cnt = blk_cnt[c], st = start[tid];
-    for (int t = 0; t < cnt; ++t) block_perm[st + t] = o + t;
+    for (int t = 0; t < cnt; ++t) {
+      const int slot = xcd_mode ? st + 8 * t : st + t;
+      if (slot < n_slots) block_perm[slot] = o + t;
+    }
   }
 }
 
@@ -1156,6 +1211,16 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
     // against cmax as well, factor 202, sent 4317 instead of 379 queries of the 10M x 50 run to the float64 scan: +3 s.)
     // 3 x bf16 engine: cert_k = 138 + 146 (198 accumulated terms instead of 2H + 2 = 52) and cert_k2 = 768 on the 2 q.c
     // term alone (the hi + lo split's dropped pieces, 3 * 2^-16: the norm and the threshold are split EXACTLY).
+    // Which candidates does the bound have to hold for?  Only for rows that could be a missed neighbour, i.e. rows within
+    // sqrt(dk) of the query: their norm is at most ||q|| + sqrt(dk) (triangle inequality; 1e-3 relative slack for the
+    // centring perturbation of the image rows).  The global maximum norm is only the cap: one far outlier row no longer
+    // inflates the bound of every query (round 4; before, a single row with a huge coordinate sent ALL queries to the
+    // float64 scan).
+    {
+      const double rq = sqrt(qn) + sqrt(dk);
+      const double cq = rq * rq * (1.0 + 1e-3);
+      if (cq < cmax) cmax = cq;
+    }
     double eps = cert_scale * 5.9604644775390625e-08 *
                  (cert_k * (cmax + 2.0 * sqrt(qn * cmax)) + cert_k2 * 2.0 * sqrt(qn * cmax) + 128.0 * fabs(tau));
     bool certified = (tau >= 1e38f) || ((dk - qn) + eps < tau);
@@ -1165,6 +1230,143 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
       flag_list[slot] = (int)qi;
     }
   }
+}
+
+// Pass 2 for the register-list kernels (lists of 32 in sorted order, d <= 64): two queries per wave, and the candidates'
+// rows travel ROW-WISE.  The kernel above lets every lane walk its own candidate's row: each of its load instructions
+// touches 32 different cache lines, 50 instructions per query -- 1600 line look-ups per query in the vector L1, which
+// serves about one per cycle: 1M queries = 6.2M cycles per CU = the measured 2.0 ms (and 3.5 ms for the variant that
+// issued 72 clamped loads instead of 50: profiles/r04a_bench_kernel_stats.csv).  Here one load instruction fetches one
+// candidate's whole row (lanes = coordinates: 2-3 lines), straight into LDS (global_load_lds_dword, no staging
+// registers, all rows of both queries in flight at once); then lane j reads row j back from LDS (odd row stride: no bank
+// conflict) and sums (q - c)^2 in float64 in coordinate order -- the same operations in the same order as above, so the
+// distances are bit for bit the same.  Only the entries BELOW the threshold entry are candidates (n_rank = thr_rank - 1:
+// a certified query has its k - 1 neighbours there; an uncertified one is redone by the float64 scan whatever this
+// kernel reports), and the queries come in the select kernel's slot order (qlist = IvfArgs::qorder: queries of one
+// cell after another, whose candidate rows are the same few thousand rows of x).
+// LDS per wave: [2 n_rank + 2][RS] floats (RS = d | 1), then n_rank-entry (double, int) tables per half.
+__global__ __launch_bounds__(256) void knn_rerank_rows_kernel(
+    const float* __restrict__ x, const float* __restrict__ mu, int64_t n, int d, int64_t ld, int64_t q_begin,
+    int64_t n_query, int k, int n_rank, const int* __restrict__ cand_idx, const float* __restrict__ cand_tau,
+    const unsigned int* __restrict__ cmax_bits, double cert_scale, double cert_k, double cert_k2,
+    int32_t* __restrict__ out_idx, double* __restrict__ out_dist, double* __restrict__ kth_d2,
+    int* __restrict__ flag_list, int* __restrict__ n_flag, const int* __restrict__ qlist, int64_t n_list) {
+  extern __shared__ __attribute__((aligned(16))) float rsm[];
+  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int RS = d | 1;
+  const int wave_floats = (2 * n_rank + 2) * RS + 2 + 2 * n_rank * 3 + 4;  // rows, query rows, (pad,) sd (double) + si, skth (double)
+  float* rows = rsm + (size_t)w * ((wave_floats + 3) & ~3);
+  float* qrows = rows + 2 * n_rank * RS;
+  double* sd = reinterpret_cast<double*>(rows + (((2 * n_rank + 2) * RS + 1) & ~1));  // [2][n_rank]
+  double* skth = sd + 2 * n_rank;                                                    // [2]
+  int* si = reinterpret_cast<int*>(skth + 2);                                          // [2][n_rank]
+  const int64_t nq_list = qlist ? n_list : n_query;
+  const int64_t pair = (int64_t)blockIdx.x * 4 + w;
+  if (2 * pair >= nq_list) return;  // whole wave (no block-level sync below)
+  const int64_t qj = 2 * pair + half;
+  int qi = -1;
+  if (qj < nq_list) qi = qlist ? qlist[qj] : (int)qj;
+  const bool qv = qi >= 0;
+  const int q = (int)q_begin + (qv ? qi : 0);
+  int ci = -1;
+  if (qv && l31 < n_rank) {
+    ci = cand_idx[(int64_t)qi * 32 + l31];
+    if (ci < 0 || ci >= n || ci == q) ci = -1;
+  }
+  // the two query rows, then every candidate row: one instruction per row, lanes = coordinates
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int qh = __builtin_amdgcn_readlane(q, 32 * h);
+    const int vh = __builtin_amdgcn_readlane(qv ? 1 : 0, 32 * h);
+    if (vh && lane < d)  // (d <= 64: one instruction per row)
+      __builtin_amdgcn_global_load_lds(x + (int64_t)qh * ld + lane, SCAMD_LDS_PTR(qrows + h * RS), 4, 0, 0);
+  }
+  for (int j = 0; j < 2 * n_rank; ++j) {
+    const int sl = j >= n_rank ? 32 + (j - n_rank) : j;
+    const int cj = __builtin_amdgcn_readlane(ci, sl);
+    if (cj >= 0 && lane < d)
+      __builtin_amdgcn_global_load_lds(x + (int64_t)cj * ld + lane, SCAMD_LDS_PTR(rows + j * RS), 4, 0, 0);
+  }
+  if (l31 < 1) skth[half] = INFINITY;
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+
+  const float* myq = qrows + half * RS;
+  double qn = 0.0;  // ||fl(q - mu)||^2: the norm of the query's image row (the thresholds live in that frame)
+  for (int c = 0; c < d; ++c) {
+    const double qc = (double)__fsub_rn(myq[c], mu[c]);
+    qn += qc * qc;
+  }
+  double myd = INFINITY;
+  int myi = -1;
+  if (ci >= 0) {
+    const float* myrow = rows + (half * n_rank + l31) * RS;
+    double s = 0.0;
+    for (int c = 0; c < d; ++c) {
+      const double df = (double)myq[c] - (double)myrow[c];
+      s = fma(df, df, s);
+    }
+    myd = s;
+    myi = ci;
+    if (!(myd == myd)) {  // NaN distances sort last and are reported as missing
+      myd = INFINITY;
+      myi = -1;
+    }
+  }
+  if (l31 < n_rank) {
+    sd[half * n_rank + l31] = myd;
+    si[half * n_rank + l31] = myi;
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+
+  const int kk = k - 1;  // neighbours besides self
+  if (qv && l31 == 0) {
+    out_idx[(int64_t)qi * k] = (int32_t)q;
+    out_dist[(int64_t)qi * k] = 0.0;
+  }
+  if (qv && l31 < n_rank) {
+    int rank = 0;
+    for (int v = 0; v < n_rank; ++v) {
+      const double dv = sd[half * n_rank + v];
+      const int iv = si[half * n_rank + v];
+      // missing entries (idx -1, +inf) order after everything, ties among them by position
+      const bool less = (iv >= 0) ? (myi < 0 || key_less(dv, iv, myd, myi)) : (myi < 0 && v < l31);
+      rank += less ? 1 : 0;
+    }
+    if (rank < kk) {
+      out_idx[(int64_t)qi * k + 1 + rank] = myi;
+      out_dist[(int64_t)qi * k + 1 + rank] = (myi >= 0) ? sqrt(myd) : INFINITY;
+      if (rank == kk - 1) skth[half] = myd;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  if (qv && l31 == 0) {
+    // the certificate: see knn_rerank_kernel (same expressions)
+    const double dk = (kk > 0) ? skth[half] : 0.0;
+    const double tau = (double)cand_tau[qi];
+    double cmax = (double)__uint_as_float(*cmax_bits);
+    {
+      const double rq = sqrt(qn) + sqrt(dk);
+      const double cq = rq * rq * (1.0 + 1e-3);
+      if (cq < cmax) cmax = cq;
+    }
+    const double eps = cert_scale * 5.9604644775390625e-08 *
+                       (cert_k * (cmax + 2.0 * sqrt(qn * cmax)) + cert_k2 * 2.0 * sqrt(qn * cmax) + 128.0 * fabs(tau));
+    const bool certified = (tau >= 1e38f) || ((dk - qn) + eps < tau);
+    kth_d2[qi] = dk;
+    if (!certified) {
+      const int slot = atomicAdd(n_flag, 1);
+      flag_list[slot] = qi;
+    }
+  }
+}
+static size_t rerank_rows_lds_bytes(int d, int n_rank) {
+  const int RS = d | 1;
+  const int wave_floats = (2 * n_rank + 2) * RS + 2 + 2 * n_rank * 3 + 4;
+  return (size_t)4 * ((wave_floats + 3) & ~3) * sizeof(float);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1591,6 +1793,7 @@ struct KnnBuffers {
   // cell-pruned search
   int* labels; int* perm; int* qpos; int* block_cell; float* cent; float* centp; long long* sums; int* cell_ints;
   unsigned int* radius_bits; int* cell_order; float* cell_lb2; int* cell_aux; int* block_perm;
+  int* qorder;  // [n_slot_max] query number of every query slot of the pruned sweep (-1 = padding): pass 2's order
   // second tier of the bf16 engine (float32 engine on the queries its certificate rejected)
   int* qrow; float* xp2; int* flag_list2; int* t2_cell; int* t2_pos; int* t2_ints;
 };
@@ -1615,7 +1818,7 @@ static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffe
   b->radius_bits = nullptr;
   b->cell_order = nullptr;
   b->cell_lb2 = nullptr;
-  b->cell_aux = b->block_perm = nullptr;
+  b->cell_aux = b->block_perm = b->qorder = nullptr;
   if (p.ivf) {
     b->labels = ws.take<int>((size_t)p.n_pad);  // sample labels, then labels of all rows
     b->perm = ws.take<int>((size_t)p.n_img_max);
@@ -1629,7 +1832,8 @@ static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffe
     b->cell_order = ws.take<int>((size_t)p.n_cells * p.n_cells);
     b->cell_lb2 = ws.take<float>((size_t)p.n_cells * p.n_cells);
     b->cell_aux = ws.take<int>((size_t)p.n_cells * 3);  // expected work, first block, block count of every cell
-    b->block_perm = ws.take<int>((size_t)(p.n_slot_max / 128 + 1));
+    b->block_perm = ws.take<int>((size_t)(p.n_slot_max / 128 + 1) * 2 + 64);  // (XCD-aware order: up to 8 x the longest queue)
+    b->qorder = ws.take<int>((size_t)p.n_slot_max);
   }
   b->qrow = b->flag_list2 = b->t2_cell = b->t2_pos = b->t2_ints = nullptr;
   b->xp2 = nullptr;
@@ -1810,7 +2014,22 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   }
   const int n_blocks = (int)h_block_cell.size();
   SCAMD_REQUIRE(rows <= p.n_img_max && slots <= p.n_slot_max, SCAMD_EWORKSPACE, "knn: cell layout exceeds its bound");
-  *rows_out = rows;
+  // launch slots: block-id order = n_blocks; XCD-aware order (SCAMD_KNN_XCD_ORDER=0 disables it) = 8 queues of at most
+  // ceil(n_blocks / 8) + (blocks of the largest cell) slots, if the table has room
+  int n_launch = n_blocks, xcd_mode = 0;
+  {
+    const char* e = getenv("SCAMD_KNN_XCD_ORDER");
+    int maxb = 0;
+    for (int c = 0; c < nc; ++c) maxb = std::max(maxb, h_blk[nc + c]);
+    const int64_t want = (int64_t)8 * ((n_blocks + 7) / 8 + maxb);
+    const int64_t cap = (int64_t)(p.n_slot_max / 128 + 1) * 2 + 64;
+    if (!(e && e[0] == '0') && n_blocks >= 64 && want <= cap) {
+      xcd_mode = 1;
+      n_launch = (int)want;
+    }
+  }
+  rows_out[0] = rows;
+  rows_out[1] = slots;
   if (n_blocks == 0) return SCAMD_OK;
   SCAMD_HIP_CHECK(hipMemcpyAsync(cell_map, h_map.data(), sizeof(int) * nc, hipMemcpyHostToDevice, s));
   SCAMD_HIP_CHECK(hipMemcpyAsync(row_off, h_row_off.data(), sizeof(int) * nc, hipMemcpyHostToDevice, s));
@@ -1848,7 +2067,7 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
     SCAMD_LAUNCH_CHECK();
     // launch order: longest expected sweeps first
     hipLaunchKernelGGL(ivf_block_order_kernel, dim3(1), dim3(1024), 0, s, b.cell_aux, b.cell_aux + nc, b.cell_aux + 2 * nc,
-                       nc, b.block_perm);
+                       nc, b.block_perm, n_launch, xcd_mode);
     SCAMD_LAUNCH_CHECK();
   }
   // 6. pruned sweep
@@ -1877,6 +2096,7 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   iv.dc = d;
   iv.d = d;
   iv.block_perm = b.block_perm;
+  iv.qorder = b.qorder;
   {
     const char* e = getenv("SCAMD_KNN_PREPASS_TILES");
     // float32 engine, measured at 1M: 48 -> 29.3 ms, 24 / 12 -> 29.0, 6 -> 29.6, 2 -> 30.2; bf16 engine (the pre-pass
@@ -1894,7 +2114,7 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
     SCAMD_HIP_CHECK(hipMemsetAsync(iv.trace, 0, sizeof(unsigned long long) * 4 * n_blocks, s));
   }
   SCAMD_HIP_CHECK(hipEventRecord(ev0, s));
-  hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(C::NT), lds, s, b.xp, (int)(rows / 64), rows, q_begin, p.thr_rank,
+  hipLaunchKernelGGL(kern, dim3(n_launch), dim3(C::NT), lds, s, b.xp, (int)(rows / 64), rows, q_begin, p.thr_rank,
                      b.cand_idx, b.cand_tau, iv);
   SCAMD_LAUNCH_CHECK();
   SCAMD_HIP_CHECK(hipEventRecord(ev1, s));
@@ -2007,6 +2227,7 @@ static int run_ivf_tier2(const KnnPlan& p, const KnnBuffers& b, const float* x, 
   iv.dc = d;
   iv.d = d;
   iv.block_perm = b.block_perm;
+  iv.qorder = nullptr;
   iv.prepass_tiles = 16;
   iv.debug_no_insert = 0;
   iv.trace = nullptr;
@@ -2015,9 +2236,14 @@ static int run_ivf_tier2(const KnnPlan& p, const KnnBuffers& b, const float* x, 
                      b.cand_tau, iv);
   SCAMD_LAUNCH_CHECK();
   T2_DBG(__LINE__);
-  hipLaunchKernelGGL(knn_rerank_kernel<32>, dim3((unsigned)ceil_div(n_flag, 4)), dim3(256), 0, s, x, b.mu, n, d, ld, q_begin,
-                     n_query, k, b.cand_idx, b.cand_tau, b.cmax, cert_scale, CERT_K_F32, 0.0, out_idx, out_dist, b.kth_d2,
-                     b.flag_list2, ctr2, (const int*)b.flag_list, n_flag);
+  {
+    const size_t rlds = rerank_rows_lds_bytes(d, thr_rank - 1);
+    SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_rerank_rows_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+    hipLaunchKernelGGL(knn_rerank_rows_kernel, dim3((unsigned)ceil_div(n_flag, 8)), dim3(256), rlds, s, x, b.mu, n, d, ld,
+                       q_begin, n_query, k, std::max(1, thr_rank - 1), b.cand_idx, b.cand_tau, b.cmax, cert_scale, CERT_K_F32,
+                       0.0, out_idx, out_dist, b.kth_d2, b.flag_list2, ctr2, (const int*)b.flag_list, (int64_t)n_flag);
+  }
   SCAMD_LAUNCH_CHECK();
   T2_DBG(__LINE__);
   SCAMD_HIP_CHECK(hipMemcpyAsync(n_flag2_host, ctr2, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -2086,13 +2312,13 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
     }
     SCAMD_LAUNCH_CHECK();
   }
-  int64_t ivf_rows = 0;
+  int64_t ivf_layout[2] = {0, 0};  // image rows, query slots of the pruned sweep
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   SCAMD_HIP_CHECK(hipEventCreate(&ev0));
   SCAMD_HIP_CHECK(hipEventCreate(&ev1));
   int rc;
   if (p.ivf) {
-    rc = dispatch_ivf(p, b, x, n, d, ld_x, q_begin, n_query, s, ev0, ev1, &ivf_rows);
+    rc = dispatch_ivf(p, b, x, n, d, ld_x, q_begin, n_query, s, ev0, ev1, ivf_layout);
   } else {
     SCAMD_HIP_CHECK(hipEventRecord(ev0, s));
     rc = dispatch_select(p, b, q_begin, s);
@@ -2103,7 +2329,19 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
     (void)hipEventDestroy(ev1);
     return rc;
   }
-  {
+  if (p.reg && p.KP == 32 && d <= 64) {
+    // register-list kernels: sorted lists, row-wise re-rank of the entries below the threshold, in slot order when pruned
+    const int n_rank = std::max(1, p.thr_rank - 1);
+    const int64_t n_list = p.ivf ? ivf_layout[1] : n_query;
+    const size_t lds = rerank_rows_lds_bytes(d, n_rank);
+    SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_rerank_rows_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(knn_rerank_rows_kernel, dim3((unsigned)ceil_div(n_list, 8)), dim3(256), lds, s, x, b.mu, n, d, ld_x,
+                       q_begin, n_query, k, n_rank, b.cand_idx, b.cand_tau, b.cmax, cert_scale,
+                       p.b3 ? CERT_K_B3 : CERT_K_F32, p.b3 ? CERT_K2_B3 : 0.0, out_idx, out_dist, b.kth_d2, b.flag_list,
+                       b.counters, p.ivf ? (const int*)b.qorder : (const int*)nullptr, n_list);
+    SCAMD_LAUNCH_CHECK();
+  } else {
     int blocks = (int)((n_query + 3) / 4);
 #define RERANK(KP_)                                                                              \
   hipLaunchKernelGGL(knn_rerank_kernel<KP_>, dim3(blocks), dim3(256), 0, s, x, b.mu, n, d, ld_x, q_begin, \
@@ -2142,7 +2380,7 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
     const int t2_min = e ? atoi(e) : 256;
     if (n_flag > t2_min) {
       int n_flag2 = 0;
-      rc = run_ivf_tier2(p, b, x, n, d, ld_x, q_begin, n_query, k, cert_scale, n_flag, ivf_rows, out_idx, out_dist, s,
+      rc = run_ivf_tier2(p, b, x, n, d, ld_x, q_begin, n_query, k, cert_scale, n_flag, ivf_layout[0], out_idx, out_dist, s,
                          &n_flag2);
       if (rc != SCAMD_OK) return rc;
       g_last_second_tier = n_flag;
@@ -2178,6 +2416,82 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
                   "knn: %d queries have more than %d rows tied within their k-th distance",
                   h_counters[1], FALLBACK_CAP);
   }
+  return SCAMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Test entry for the certificate of the bf16 engine: the RAW scores ||c||^2 - 2 q.c of a block of (query, candidate)
+// pairs, produced by the select kernel's own image packing (knn_colsum / knn_colmean / knn_pack_image_kernel) and its own
+// operand construction and MFMA chain (b3_query_operand, b3_chain) -- one wave per 32 x 32 sub-tile, no lists, threshold 0.
+// tests/test_gpu_knn_certificate.py compares them with float64 and reports max |error| / bound; the bound's factors are
+// exported by scamd_knn_cert_factors so that the test cannot drift from the kernel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void knn_debug_b3_scores_kernel(const float* __restrict__ xp, int64_t q0, int nq,
+                                                                  int64_t c0, int nc, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int ctiles = nc / 32;
+  if (wid >= (int64_t)(nq / 32) * ctiles) return;
+  const int qt = (int)(wid / ctiles), ct = (int)(wid % ctiles);
+  i32x4 qh[4], ql[4];
+  b3_query_operand(xp, q0 + (int64_t)qt * 32 + l31, half, qh, ql);
+  BFragBf16 b;
+  const i32x4* p = reinterpret_cast<const i32x4*>(xp + (c0 + (int64_t)ct * 32 + l31) * B3_DPL);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    b.h[s] = p[2 * s + half];
+    b.l[s] = p[8 + 2 * s + half];
+  }
+  const f32x16 acc = b3_chain(qh, ql, b);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * half;  // query of accumulator register r in this half (select kernel's map)
+    out[((int64_t)qt * 32 + i) * nc + (int64_t)ct * 32 + l31] = acc[r];
+  }
+}
+
+extern "C" void scamd_knn_cert_factors(int engine, double* cert_k, double* cert_k2, double* key_slack) {
+  if (cert_k) *cert_k = engine == 1 ? CERT_K_B3 : CERT_K_F32;
+  if (cert_k2) *cert_k2 = engine == 1 ? CERT_K2_B3 : 0.0;
+  if (key_slack) *key_slack = 128.0;
+}
+
+extern "C" size_t scamd_knn_debug_b3_scores_workspace_bytes(int64_t n) {
+  Workspace ws(nullptr, 0);
+  ws.take<float>((size_t)n * B3_DPL);
+  ws.take<float>(128);
+  ws.take<double>((size_t)MEAN_BLOCKS * 128);
+  ws.take<unsigned int>(4);
+  return ws.used();
+}
+
+extern "C" int scamd_knn_debug_b3_scores_f32(const float* x, int64_t n, int d, int64_t ld_x, int64_t q0, int nq,
+                                             int64_t c0, int nc, float* out_scores, float* out_mu, float* out_cmax,
+                                             void* workspace, size_t workspace_bytes, scamd_stream_t stream) {
+  SCAMD_REQUIRE(x && out_scores, SCAMD_EINVAL, "knn debug scores: null pointer");
+  SCAMD_REQUIRE(n >= 1 && d >= 1 && d <= 50 && ld_x >= d, SCAMD_EUNSUPPORTED, "knn debug scores: the bf16 engine takes d <= 50 (d=%d)", d);
+  SCAMD_REQUIRE(nq > 0 && nc > 0 && nq % 32 == 0 && nc % 32 == 0 && q0 >= 0 && c0 >= 0 && q0 + nq <= n && c0 + nc <= n,
+                SCAMD_EINVAL, "knn debug scores: query / candidate blocks must be multiples of 32 inside [0, n)");
+  Workspace ws(workspace, workspace_bytes);
+  float* xp = ws.take<float>((size_t)n * B3_DPL);
+  float* mu = ws.take<float>(128);
+  double* partial = ws.take<double>((size_t)MEAN_BLOCKS * 128);
+  unsigned int* cmax = ws.take<unsigned int>(4);
+  SCAMD_REQUIRE(workspace && ws.ok, SCAMD_EWORKSPACE, "knn debug scores: workspace %zu < required %zu", workspace_bytes, ws.used());
+  hipStream_t s = stream;
+  SCAMD_HIP_CHECK(hipMemsetAsync(cmax, 0, 16, s));
+  hipLaunchKernelGGL(knn_colsum_kernel, dim3(MEAN_BLOCKS), dim3(1024), 0, s, x, n, d, ld_x, partial);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(knn_colmean_kernel, dim3(1), dim3(128), 0, s, partial, n, d, mu);
+  SCAMD_LAUNCH_CHECK();
+  const int blocks = (int)std::min<int64_t>((n + 3) / 4, 256 * 16);
+  hipLaunchKernelGGL(knn_pack_image_kernel, dim3(blocks), dim3(256), 0, s, x, mu, n, d, ld_x, 25, 28, B3_DPL, n, xp, cmax, 1);
+  SCAMD_LAUNCH_CHECK();
+  const int64_t waves = (int64_t)(nq / 32) * (nc / 32);
+  hipLaunchKernelGGL(knn_debug_b3_scores_kernel, dim3((unsigned int)((waves + 3) / 4)), dim3(256), 0, s, xp, q0, nq, c0, nc, out_scores);
+  SCAMD_LAUNCH_CHECK();
+  if (out_mu) SCAMD_HIP_CHECK(hipMemcpyAsync(out_mu, mu, sizeof(float) * 128, hipMemcpyDeviceToDevice, s));
+  if (out_cmax) SCAMD_HIP_CHECK(hipMemcpyAsync(out_cmax, cmax, sizeof(float), hipMemcpyDeviceToDevice, s));
   return SCAMD_OK;
 }
 

@@ -383,6 +383,10 @@ EMU_INL f64x4_t mfma_f64_16x16x4(double a, double b, f64x4_t c) {
 #define __builtin_amdgcn_sched_barrier(a) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(a) ((void)0)
 #define __builtin_amdgcn_s_setprio(a) ((void)0)
+// LDS-DMA: lane l's `size` bytes land at the wave-uniform base + l * size (the destination pointer of the first lane is
+// the base; every lane passes the same one)
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) \
+  ((void)memcpy(reinterpret_cast<char*>(l) + (off) + ::emu::g_cur->lane * (size), reinterpret_cast<const char*>(g), (size)))
 #define __builtin_amdgcn_logf(x) log2f(x)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_fmed3f(a, b, c) fmaxf(fminf((a), (b)), fminf(fmaxf((a), (b)), (c)))
