@@ -267,9 +267,13 @@ def parity_block(x_full, truth, chain: dict, n_comps: int, k: int) -> dict:
 
 def parity_weak(args, n_s: int = 100_000, n_seeds: int = 5) -> dict:
     """`parity.weak`: Leiden where the answer is NOT unambiguous -- a `weak` sample (overlapping gene programmes, the
-    CPU oracle's own seeds agree only partly).  The oracle's seeds 0 .. n_seeds-1 on the CPU chain's graph define the
-    distribution; gates: the GPU modularity (same graph, seed 0) is not below the oracle's worst seed, and the GPU
-    partition agrees with the oracle's seed-0 partition at least as well as the oracle's other seeds do (- 0.01)."""
+    CPU oracle's own seeds agree only partly).  On the CPU chain's graph the oracle's seeds 0 .. n_seeds-1 and the GPU's
+    seeds 0 .. n_seeds-1 are two samples of partitions; reported for BOTH: modularity, ARI against the planted truth,
+    pairwise ARI.  Gates (reference bar: cross-implementation agreement,
+    tests/test_clustering.py:130-163): GPU modularity not below the oracle's worst seed; median GPU ARI-vs-truth >= the
+    oracle's median - 0.05; median GPU-vs-oracle ARI (all seed pairs) >= the oracle's median PAIRWISE ARI - 0.02."""
+    import itertools
+
     import numpy as np
 
     import scanpy_amd as sc
@@ -281,28 +285,44 @@ def parity_weak(args, n_s: int = 100_000, n_seeds: int = 5) -> dict:
     seeds = [(chain["labels"], chain["modularity"])] + [ol.leiden(chain["conn"], resolution=1.0, n_iterations=-1, seed=s)
                                                         for s in range(1, n_seeds)]
     q_or = np.array([q for _, q in seeds])
-    floor = min(cmp.ari(seeds[0][0], m) for m, _ in seeds[1:])
-    c = sc.AnnData(x[:, :1])
-    sc.tl.leiden(c, adjacency=chain["conn"], flavor="igraph", n_iterations=-1)
-    g_lab = c.obs["leiden"].cat.codes.to_numpy()
-    q_gpu = float(c.uns["leiden"]["modularity"])
+    o_pair = [cmp.ari(a[0], b[0]) for a, b in itertools.combinations(seeds, 2)]
+    o_truth = [cmp.ari(m, truth) for m, _ in seeds]
+    gpu = []
+    for s_ in range(n_seeds):
+        c = sc.AnnData(x[:, :1])
+        sc.tl.leiden(c, adjacency=chain["conn"], flavor="igraph", n_iterations=-1, random_state=s_)
+        gpu.append((c.obs["leiden"].cat.codes.to_numpy(), float(c.uns["leiden"]["modularity"])))
+    q_gpu = np.array([q for _, q in gpu])
+    g_truth = [cmp.ari(m, truth) for m, _ in gpu]
+    g_cross = [cmp.ari(m, o[0]) for m, _ in gpu for o in seeds]
+    g_pair = [cmp.ari(a[0], b[0]) for a, b in itertools.combinations(gpu, 2)]
     a = sc.AnnData(x)
     sc.pp.pca(a, n_comps=args.n_comps)
     sc.pp.neighbors(a, n_neighbors=args.n_neighbors)
     sc.tl.leiden(a, flavor="igraph", n_iterations=-1)
     e_lab = a.obs["leiden"].cat.codes.to_numpy()
-    out = {"sample_cells": n_s, "structure": "weak", "oracle_seeds": n_seeds,
-           "oracle_modularity_range": [float(q_or.min()), float(q_or.max())], "gpu_modularity_same_graph": q_gpu,
-           "oracle_seed_floor_ari": floor, "gpu_vs_oracle_seed0_ari": cmp.ari(g_lab, seeds[0][0]),
+    out = {"sample_cells": n_s, "structure": "weak", "seeds": n_seeds,
+           "modularity": {"oracle": [float(v) for v in q_or], "gpu": [float(v) for v in q_gpu]},
+           "oracle_modularity_range": [float(q_or.min()), float(q_or.max())], "gpu_modularity_same_graph": float(q_gpu[0]),
+           "ari_vs_truth": {"oracle": [float(v) for v in o_truth], "gpu": [float(v) for v in g_truth],
+                            "oracle_median": float(np.median(o_truth)), "gpu_median": float(np.median(g_truth))},
+           "pairwise_ari": {"oracle_median": float(np.median(o_pair)), "oracle_min": float(min(o_pair)),
+                            "gpu_vs_oracle_median": float(np.median(g_cross)), "gpu_vs_oracle_min": float(min(g_cross)),
+                            "gpu_median": float(np.median(g_pair))},
+           "gpu_vs_oracle_seed0_ari": cmp.ari(gpu[0][0], seeds[0][0]),
            "gpu_end_to_end_vs_oracle_seed0_ari": cmp.ari(e_lab, seeds[0][0]),
-           "n_clusters": {"gpu": int(g_lab.max()) + 1, "oracle": [int(m.max()) + 1 for m, _ in seeds]},
-           "ari_vs_truth": {"gpu": cmp.ari(g_lab, truth), "oracle_seed0": cmp.ari(seeds[0][0], truth)},
-           "gates": {"modularity": "gpu >= oracle minimum - 1e-4", "ari": "gpu_vs_oracle_seed0_ari >= oracle_seed_floor_ari - 0.01"}}
+           "gpu_end_to_end_ari_vs_truth": cmp.ari(e_lab, truth),
+           "n_clusters": {"gpu": [int(m.max()) + 1 for m, _ in gpu], "oracle": [int(m.max()) + 1 for m, _ in seeds]},
+           "gates": {"modularity": "every gpu seed >= oracle minimum - 1e-4",
+                     "ari_vs_truth": "gpu median >= oracle median - 0.05",
+                     "ari_vs_oracle": "median over all (gpu seed, oracle seed) pairs >= oracle median pairwise ARI - 0.02"}}
     fails = []
-    if q_gpu < q_or.min() - 1e-4:
+    if q_gpu.min() < q_or.min() - 1e-4:
         fails.append("weak_modularity_below_oracle_range")
-    if out["gpu_vs_oracle_seed0_ari"] < floor - 0.01:
-        fails.append("weak_ari_below_oracle_seed_floor")
+    if np.median(g_truth) < np.median(o_truth) - 0.05:
+        fails.append("weak_ari_vs_truth_below_oracle_median")
+    if np.median(g_cross) < np.median(o_pair) - 0.02:
+        fails.append("weak_ari_vs_oracle_below_oracle_pairwise_median")
     out["failed_gates"] = fails
     return out
 
@@ -728,7 +748,9 @@ def main() -> None:
             "config": {
                 "workload": (f"synthetic {args.structure}-structure log-normal CSR {n} cells x {args.n_vars} genes (~5% nnz), PCA {args.n_comps} "
                              f"(exact Gram + dense eigensolve, arpack accuracy) + exact kNN k={args.n_neighbors} (cell-pruned brute force) + umap "
-                             "connectivities + Leiden res=1.0 n_iterations=-1 (" + _baseline_config(n, args.n_vars, world) + ")"),
+                             "connectivities + Leiden res=1.0 n_iterations=-1 (" + _baseline_config(n, args.n_vars, world) + "); `value` is the "
+                             "device-resident rate: the CSR is in HBM when the timed region starts and the results stay there "
+                             "(no H2D / D2H inside it); host AnnData in -> slots written on the host = value_host_to_host"),
                 "n_obs": n,
                 "n_vars": args.n_vars,
                 "nnz_per_rank": int(nnz_local),
@@ -775,13 +797,12 @@ def main() -> None:
                 out["upstream_chain"] = upstream_chain(handle)
                 out["umap_layout"] = umap_layout(res, n)
             if not args.no_properties:
-                # the result of the LAST timed step, at the full size of the run.  First shipped without a GPU run of
-                # its own (the round's GPU minutes were spent): its gates are reported, not yet part of the exit code
-                try:
-                    out["full_size_properties"] = full_size_properties(res, x, n, args.n_neighbors)
-                    out["full_size_properties"]["enforced"] = False
-                except Exception as exc:  # noqa: BLE001 -- a checker bug must not cost the measurement
-                    out["full_size_properties"] = {"error": repr(exc)}
+                # the result of the LAST timed step, at the full size of the run; its gates are part of the exit code
+                # (round 4; a checker error propagates like any other error)
+                out["full_size_properties"] = full_size_properties(res, x, n, args.n_neighbors)
+                out["full_size_properties"]["enforced"] = True
+                if out["full_size_properties"]["failed_gates"]:
+                    rc = 1
             del handle, res
             if args.h2h_reps > 0:
                 h2h = host_to_host(x, args.n_comps, args.n_neighbors, args.h2h_reps)
@@ -803,10 +824,11 @@ def main() -> None:
                         par["weak"] = parity_weak(args)
                         par["failed_gates"] = par["failed_gates"] + par["weak"]["failed_gates"]
                     out["parity"] = par
-                    rc = 1 if par["failed_gates"] else 0
+                    rc = 1 if par["failed_gates"] else rc
         print(json.dumps(out), flush=True)
         if rc:
-            print(f"PARITY GATES FAILED: {out['parity']['failed_gates']}", file=sys.stderr, flush=True)
+            print(f"GATES FAILED: parity {out.get('parity', {}).get('failed_gates')}, full-size properties "
+                  f"{out.get('full_size_properties', {}).get('failed_gates')}", file=sys.stderr, flush=True)
             if world > 1:
                 dist.destroy_process_group()
             raise SystemExit(2)

@@ -14,9 +14,64 @@ import os as _os
 # which reads scratch it did not write fails the same way on every box (round 3: such a read showed up as a device
 # fault on some boxes only)
 _POISON = _os.environ.get("SCAMD_POISON_WORKSPACE") == "1"
+# SCAMD_GUARD=1 (debug; round 4's hunt for the unreproduced device faults): every output tensor and every workspace handed
+# to a C entry point sits between two 4 KiB guards filled with a canary byte; after the call (and a stream sync) the guards
+# are read back -- a kernel that WRITES past either end of a buffer it was given raises here, naming the entry point.
+_GUARD = _os.environ.get("SCAMD_GUARD") == "1"
+_GUARD_BYTES = 4096
+_CANARY = 0xC5
+_guards: list = []  # (label, raw uint8 buffer, payload bytes) of the call in progress
+
+
+def _guarded(nbytes: int, dev: torch.device, label: str) -> torch.Tensor:
+    pay = (int(nbytes) + 255) // 256 * 256
+    raw = torch.empty(pay + 2 * _GUARD_BYTES, dtype=torch.uint8, device=dev)
+    raw[:_GUARD_BYTES] = _CANARY
+    raw[_GUARD_BYTES + int(nbytes):] = _CANARY  # (the slack up to the 256-byte boundary belongs to the guard)
+    _guards.append((label, raw, int(nbytes)))
+    return raw[_GUARD_BYTES:_GUARD_BYTES + int(nbytes)]
+
+
+def _empty(shape, *, dtype, device):
+    if not _GUARD:
+        return torch.empty(shape, dtype=dtype, device=device)
+    shape = (int(shape),) if not isinstance(shape, (tuple, list, torch.Size)) else tuple(int(v) for v in shape)
+    numel = 1
+    for v in shape:
+        numel *= v
+    item = torch.empty((), dtype=dtype).element_size()
+    return _guarded(numel * item, device, f"{dtype} {shape}").view(dtype).view(shape)
+
+
+def _zeros(shape, *, dtype, device):
+    t = _empty(shape, dtype=dtype, device=device)
+    if _GUARD:
+        t.zero_()
+        return t
+    return torch.zeros(shape, dtype=dtype, device=device)
+
+
+def _check(rc: int, what: str = "") -> None:
+    _lib.check(rc, what)
+    if _GUARD and _guards:
+        torch.cuda.synchronize()
+        bad = []
+        for label, raw, nbytes in _guards:
+            lo_ok = bool((raw[:_GUARD_BYTES] == _CANARY).all())
+            hi_ok = bool((raw[_GUARD_BYTES + nbytes:] == _CANARY).all())
+            if not (lo_ok and hi_ok):
+                bad.append(f"{label} ({nbytes} B): {'below' if not lo_ok else ''}{' above' if not hi_ok else ''}")
+        _guards.clear()
+        if bad:
+            raise _lib.ScamdError(f"SCAMD_GUARD: {what} wrote outside " + "; ".join(bad))
 
 
 def _ws(nbytes: int, dev: torch.device):
+    if _GUARD:
+        buf = _guarded(max(int(nbytes), 1), dev, "workspace")
+        if _POISON:
+            buf.fill_(0xAB)
+        return buf, C.c_size_t(buf.numel())
     buf = workspace_pool.get(nbytes, dev)
     if _POISON:  # debug: every entry point must initialise what it reads (a dirty workspace is the normal case)
         buf.fill_(0xAB)
@@ -25,7 +80,7 @@ def _ws(nbytes: int, dev: torch.device):
 
 def mfma_selftest() -> None:
     require_gpu()
-    _lib.check(_lib.load().scamd_selftest_mfma_layout(stream_ptr()), "mfma selftest")
+    _check(_lib.load().scamd_selftest_mfma_layout(stream_ptr()), "mfma selftest")
 
 
 def knn(x: torch.Tensor, k: int, *, q_begin: int = 0, n_query: int | None = None, cert_scale: float = 1.0):
@@ -36,8 +91,8 @@ def knn(x: torch.Tensor, k: int, *, q_begin: int = 0, n_query: int | None = None
     x = x.contiguous()
     n, d = x.shape
     nq = n - q_begin if n_query is None else n_query
-    idx = torch.empty((nq, k), dtype=torch.int32, device=dev)
-    dist = torch.empty((nq, k), dtype=torch.float64, device=dev)
+    idx = _empty((nq, k), dtype=torch.int32, device=dev)
+    dist = _empty((nq, k), dtype=torch.float64, device=dev)
     need = lib.scamd_knn_workspace_bytes(n, d, nq, k)
     if need == 0 and nq > 0:
         raise _lib.ScamdError(f"knn: unsupported shape d={d} (max 128) / k={k} (max 120)")
@@ -45,7 +100,7 @@ def knn(x: torch.Tensor, k: int, *, q_begin: int = 0, n_query: int | None = None
     nfb = C.c_int64(0)
     rc = lib.scamd_knn_l2_f32(ptr(x), n, d, x.stride(0), q_begin, nq, k, ptr(idx), ptr(dist),
                               float(cert_scale), C.byref(nfb), ptr(ws), wsz, stream_ptr())
-    _lib.check(rc, "scamd_knn_l2_f32")
+    _check(rc, "scamd_knn_l2_f32")
     return idx, dist, int(nfb.value)
 
 
@@ -65,13 +120,13 @@ def knn_debug_b3_scores(x: torch.Tensor, q0: int, nq: int, c0: int, nc: int):
     assert x.dtype == torch.float32 and x.dim() == 2 and x.is_cuda
     x = x.contiguous()
     n, d = x.shape
-    out = torch.empty((nq, nc), dtype=torch.float32, device=dev)
-    mu = torch.empty(128, dtype=torch.float32, device=dev)
-    cmax = torch.empty(1, dtype=torch.float32, device=dev)
+    out = _empty((nq, nc), dtype=torch.float32, device=dev)
+    mu = _empty(128, dtype=torch.float32, device=dev)
+    cmax = _empty(1, dtype=torch.float32, device=dev)
     ws, wsz = _ws(lib.scamd_knn_debug_b3_scores_workspace_bytes(n), dev)
     rc = lib.scamd_knn_debug_b3_scores_f32(ptr(x), n, d, x.stride(0), q0, nq, c0, nc, ptr(out), ptr(mu), ptr(cmax),
                                            ptr(ws), wsz, stream_ptr())
-    _lib.check(rc, "scamd_knn_debug_b3_scores_f32")
+    _check(rc, "scamd_knn_debug_b3_scores_f32")
     return out, mu[:d], float(cmax.item())
 
 
@@ -83,16 +138,16 @@ def fuzzy_simplicial_set(knn_idx: torch.Tensor, knn_dist: torch.Tensor):
     knn_idx = knn_idx.to(torch.int32).contiguous()
     knn_dist = knn_dist.to(torch.float32).contiguous()
     cap = 2 * n * (k - 1)
-    indptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
-    indices = torch.empty(cap, dtype=torch.int32, device=dev)
-    data = torch.empty(cap, dtype=torch.float32, device=dev)
-    sigma = torch.empty(n, dtype=torch.float32, device=dev)
-    rho = torch.empty(n, dtype=torch.float32, device=dev)
+    indptr = _empty(n + 1, dtype=torch.int64, device=dev)
+    indices = _empty(cap, dtype=torch.int32, device=dev)
+    data = _empty(cap, dtype=torch.float32, device=dev)
+    sigma = _empty(n, dtype=torch.float32, device=dev)
+    rho = _empty(n, dtype=torch.float32, device=dev)
     ws, wsz = _ws(lib.scamd_fuzzy_workspace_bytes(n, k), dev)
     nnz = C.c_int64(0)
     rc = lib.scamd_fuzzy_simplicial_set_f32(ptr(knn_idx), ptr(knn_dist), n, k, ptr(indptr), ptr(indices), ptr(data),
                                             cap, ptr(sigma), ptr(rho), C.byref(nnz), ptr(ws), wsz, stream_ptr())
-    _lib.check(rc, "scamd_fuzzy_simplicial_set_f32")
+    _check(rc, "scamd_fuzzy_simplicial_set_f32")
     m = int(nnz.value)
     return indptr, indices[:m], data[:m], sigma, rho
 
@@ -105,9 +160,9 @@ def fuzzy_weights(knn_idx: torch.Tensor, knn_dist: torch.Tensor, row_begin: int,
     knn_idx = knn_idx.to(torch.int32).contiguous()
     knn_dist = knn_dist.to(torch.float32).contiguous()
     sum_all = sum_all.to(torch.float64).contiguous()
-    w = torch.empty((n, k), dtype=torch.float32, device=dev)
-    cnt = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-    _lib.check(_lib.load().scamd_fuzzy_weights_f32(ptr(knn_idx), ptr(knn_dist), n, k, int(row_begin), int(n_total),
+    w = _empty((n, k), dtype=torch.float32, device=dev)
+    cnt = _empty(max(n, 1), dtype=torch.int32, device=dev)
+    _check(_lib.load().scamd_fuzzy_weights_f32(ptr(knn_idx), ptr(knn_dist), n, k, int(row_begin), int(n_total),
                                                    ptr(sum_all), ptr(w), None, None, ptr(cnt), stream_ptr()),
                "scamd_fuzzy_weights_f32")
     return w
@@ -126,14 +181,14 @@ def fuzzy_merge_rows(knn_idx: torch.Tensor, w: torch.Tensor, in_indptr: torch.Te
     in_src = in_src.to(torch.int32).contiguous()
     in_w = in_w.to(torch.float32).contiguous()
     cap = n * (k - 1) + int(in_src.numel())
-    indptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
-    indices = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
-    data = torch.empty(max(cap, 1), dtype=torch.float32, device=dev)
+    indptr = _empty(n + 1, dtype=torch.int64, device=dev)
+    indices = _empty(max(cap, 1), dtype=torch.int32, device=dev)
+    data = _empty(max(cap, 1), dtype=torch.float32, device=dev)
     ws, wsz = _ws(lib.scamd_fuzzy_merge_workspace_bytes(n, cap), dev)
     nnz = C.c_int64(0)
     rc = lib.scamd_fuzzy_merge_rows_f32(ptr(knn_idx), ptr(w), n, k, ptr(in_indptr), ptr(in_src), ptr(in_w), ptr(indptr),
                                         ptr(indices), ptr(data), cap, C.byref(nnz), ptr(ws), wsz, stream_ptr())
-    _lib.check(rc, "scamd_fuzzy_merge_rows_f32")
+    _check(rc, "scamd_fuzzy_merge_rows_f32")
     return indptr, indices[: nnz.value], data[: nnz.value]
 
 
@@ -144,9 +199,9 @@ def _knn_graph(entry: str, knn_idx: torch.Tensor, knn_dist: torch.Tensor | None)
     n, k = knn_idx.shape
     knn_idx = knn_idx.to(torch.int32).contiguous()
     cap = 2 * n * (k - 1)
-    indptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
-    indices = torch.empty(cap, dtype=torch.int32, device=dev)
-    data = torch.empty(cap, dtype=torch.float32, device=dev)
+    indptr = _empty(n + 1, dtype=torch.int64, device=dev)
+    indices = _empty(cap, dtype=torch.int32, device=dev)
+    data = _empty(cap, dtype=torch.float32, device=dev)
     ws, wsz = _ws(lib.scamd_fuzzy_workspace_bytes(n, k), dev)
     nnz = C.c_int64(0)
     if entry == "gauss":
@@ -156,7 +211,7 @@ def _knn_graph(entry: str, knn_idx: torch.Tensor, knn_dist: torch.Tensor | None)
     else:
         rc = lib.scamd_jaccard_connectivities_f32(ptr(knn_idx), n, k, ptr(indptr), ptr(indices), ptr(data), cap,
                                                   C.byref(nnz), ptr(ws), wsz, stream_ptr())
-    _lib.check(rc, f"scamd_{entry}_connectivities_f32")
+    _check(rc, f"scamd_{entry}_connectivities_f32")
     m = int(nnz.value)
     return indptr, indices[:m], data[:m]
 
@@ -173,21 +228,21 @@ def csr_transpose(indptr: torch.Tensor, indices: torch.Tensor, data: torch.Tenso
     dev = require_gpu()
     lib = _lib.load()
     nnz = data.numel()
-    t_indptr = torch.empty(g + 1, dtype=torch.int64, device=dev)
-    t_indices = torch.empty(nnz, dtype=torch.int32, device=dev)
-    t_data = torch.empty(nnz, dtype=torch.float32, device=dev)
+    t_indptr = _empty(g + 1, dtype=torch.int64, device=dev)
+    t_indices = _empty(nnz, dtype=torch.int32, device=dev)
+    t_data = _empty(nnz, dtype=torch.float32, device=dev)
     ws, wsz = _ws(lib.scamd_csr_transpose_workspace_bytes(n, g, nnz), dev)
     rc = lib.scamd_csr_transpose_f32(ptr(indptr), ptr(indices), ptr(data), n, g, nnz, ptr(t_indptr), ptr(t_indices),
                                      ptr(t_data), ptr(ws), wsz, stream_ptr())
-    _lib.check(rc, "scamd_csr_transpose_f32")
+    _check(rc, "scamd_csr_transpose_f32")
     return t_indptr, t_indices, t_data
 
 
 def csr_row_stats(indptr: torch.Tensor, data: torch.Tensor, n_rows: int):
     dev = require_gpu()
-    s = torch.empty(n_rows, dtype=torch.float64, device=dev)
-    q = torch.empty(n_rows, dtype=torch.float64, device=dev)
-    _lib.check(_lib.load().scamd_csr_row_stats_f32(ptr(indptr), ptr(data), n_rows, ptr(s), ptr(q), stream_ptr()),
+    s = _empty(n_rows, dtype=torch.float64, device=dev)
+    q = _empty(n_rows, dtype=torch.float64, device=dev)
+    _check(_lib.load().scamd_csr_row_stats_f32(ptr(indptr), ptr(data), n_rows, ptr(s), ptr(q), stream_ptr()),
                "scamd_csr_row_stats_f32")
     return s, q
 
@@ -200,7 +255,7 @@ def csr_absmax(indptr, indices, data, n: int, g: int) -> float:
     mx = C.c_float(0.0)
     rc = lib.scamd_csr_gram_f32(ptr(indptr), ptr(indices), ptr(data), n, g, data.numel(), 0, None, 0, None,
                                 C.byref(mx), ptr(ws), wsz, stream_ptr())
-    _lib.check(rc, "scamd_csr_gram_f32 (absmax)")
+    _check(rc, "scamd_csr_gram_f32 (absmax)")
     return float(mx.value)
 
 
@@ -209,12 +264,12 @@ def csr_gram(indptr, indices, data, n: int, g: int, scale_bits: int):
     dev = require_gpu()
     lib = _lib.load()
     gp = (g + 127) // 128 * 128
-    gram = torch.empty((gp, gp), dtype=torch.int64, device=dev)
-    colsum = torch.empty(gp, dtype=torch.int64, device=dev)
+    gram = _empty((gp, gp), dtype=torch.int64, device=dev)
+    colsum = _empty(gp, dtype=torch.int64, device=dev)
     ws, wsz = _ws(lib.scamd_csr_gram_workspace_bytes(n, g), dev)
     rc = lib.scamd_csr_gram_f32(ptr(indptr), ptr(indices), ptr(data), n, g, data.numel(), int(scale_bits), ptr(gram),
                                 gp, ptr(colsum), None, ptr(ws), wsz, stream_ptr())
-    _lib.check(rc, "scamd_csr_gram_f32")
+    _check(rc, "scamd_csr_gram_f32")
     return gram, colsum
 
 
@@ -224,10 +279,10 @@ def spmm(indptr, indices, data, n: int, g: int, b: torch.Tensor, shift: torch.Te
     b = b.to(torch.float32).contiguous()
     assert b.shape[0] == g
     l = b.shape[1]
-    y = torch.empty((n, l), dtype=torch.float32, device=dev)
+    y = _empty((n, l), dtype=torch.float32, device=dev)
     if shift is not None:
         shift = shift.to(torch.float32).contiguous()
-    _lib.check(_lib.load().scamd_spmm_csr_f32(ptr(indptr), ptr(indices), ptr(data), n, g, ptr(b), l, ptr(shift),
+    _check(_lib.load().scamd_spmm_csr_f32(ptr(indptr), ptr(indices), ptr(data), n, g, ptr(b), l, ptr(shift),
                                               ptr(y), stream_ptr()), "scamd_spmm_csr_f32")
     return y
 
@@ -240,11 +295,11 @@ def spmm_f64acc(indptr, indices, data, n_rows: int, b: torch.Tensor, scale: torc
     assert b.dtype == torch.float32 and b.is_contiguous()
     l = b.shape[1]
     nnz = data.numel()
-    w = torch.empty((n_rows, l), dtype=torch.float64, device=dev)
+    w = _empty((n_rows, l), dtype=torch.float64, device=dev)
     ws, wsz = _ws(lib.scamd_spmm_f64acc_workspace_bytes(n_rows, nnz, l), dev)
     rc = lib.scamd_spmm_csr_f32_f64acc(ptr(indptr), ptr(indices), ptr(data), n_rows, nnz, ptr(b), l, ptr(scale),
                                        ptr(colsum), ptr(w), ptr(ws), wsz, stream_ptr())
-    _lib.check(rc, "scamd_spmm_csr_f32_f64acc")
+    _check(rc, "scamd_spmm_csr_f32_f64acc")
     return w
 
 
@@ -259,15 +314,15 @@ def dense_debug(op: int, in0: torch.Tensor, in1: torch.Tensor | None = None):
         in1 = in1.to(torch.float64).contiguous()
         kdim, m = in0.shape
         n = in1.shape[1]
-        out = torch.empty((m, n), dtype=torch.float64, device=dev)
+        out = _empty((m, n), dtype=torch.float64, device=dev)
         rc = lib.scamd_dense_debug_f64(1, ptr(in0), ptr(in1), m, n, kdim, ptr(out), None, C.byref(flag), stream_ptr())
-        _lib.check(rc, "scamd_dense_debug_f64")
+        _check(rc, "scamd_dense_debug_f64")
         return out
     m = in0.shape[0]
-    out0 = torch.empty((m, m) if op == 2 else (m,), dtype=torch.float64, device=dev)
-    out1 = torch.empty((m, m), dtype=torch.float64, device=dev)
+    out0 = _empty((m, m) if op == 2 else (m,), dtype=torch.float64, device=dev)
+    out1 = _empty((m, m), dtype=torch.float64, device=dev)
     rc = lib.scamd_dense_debug_f64(op, ptr(in0), None, m, m, m, ptr(out0), ptr(out1), C.byref(flag), stream_ptr())
-    _lib.check(rc, "scamd_dense_debug_f64")
+    _check(rc, "scamd_dense_debug_f64")
     return (out0, int(flag.value)) if op == 2 else (out0, out1, int(flag.value))
 
 
@@ -279,14 +334,14 @@ def eigh_topk(a: torch.Tensor, k: int, *, seed: int = 0, tol: float = 2e-8):
     assert a.dtype == torch.float64 and a.dim() == 2 and a.shape[0] == a.shape[1] and a.is_cuda
     a = a.contiguous()
     g = a.shape[0]
-    lam = torch.empty(k, dtype=torch.float64, device=dev)
-    v = torch.empty((g, k), dtype=torch.float64, device=dev)
+    lam = _empty(k, dtype=torch.float64, device=dev)
+    v = _empty((g, k), dtype=torch.float64, device=dev)
     info = (C.c_int32 * 8)()
     need = lib.scamd_eigh_topk_workspace_bytes(g, k)
     ws, wsz = _ws(need, dev)
     rc = lib.scamd_eigh_topk_f64(ptr(a), g, a.stride(0), k, int(seed) & (2**64 - 1), float(tol), ptr(lam), ptr(v), info,
                                  ptr(ws), wsz, stream_ptr())
-    _lib.check(rc, "scamd_eigh_topk_f64")
+    _check(rc, "scamd_eigh_topk_f64")
     resid = C.cast(C.byref(info, 16), C.POINTER(C.c_double))[0]
     return lam, v, {"n_outer": info[0], "n_gemm": info[1], "block_size": info[2], "chol_retries": info[3], "residual": resid}
 
@@ -298,18 +353,18 @@ def pca_csr(indptr, indices, data, n: int, g: int, n_comps: int, *, zero_center:
     dev = require_gpu()
     lib = _lib.load()
     k = int(n_comps)
-    scores = torch.empty((n, k), dtype=torch.float32, device=dev)
-    comps = torch.empty((k, g), dtype=torch.float64, device=dev)
-    var = torch.empty(k, dtype=torch.float64, device=dev)
-    ratio = torch.empty(k, dtype=torch.float64, device=dev)
-    mean = torch.empty(g, dtype=torch.float64, device=dev)
+    scores = _empty((n, k), dtype=torch.float32, device=dev)
+    comps = _empty((k, g), dtype=torch.float64, device=dev)
+    var = _empty(k, dtype=torch.float64, device=dev)
+    ratio = _empty(k, dtype=torch.float64, device=dev)
+    mean = _empty(g, dtype=torch.float64, device=dev)
     info = (C.c_int32 * 8)()
     need = lib.scamd_pca_csr_workspace_bytes(n, g, k)
     ws, wsz = _ws(need, dev)
     rc = lib.scamd_pca_csr_f32(ptr(indptr), ptr(indices), ptr(data), n, g, data.numel(), k, 1 if zero_center else 0,
                                int(seed) & (2**64 - 1), float(tol), ptr(scores), ptr(comps), ptr(var), ptr(ratio), ptr(mean),
                                info, ptr(ws), wsz, stream_ptr())
-    _lib.check(rc, "scamd_pca_csr_f32")
+    _check(rc, "scamd_pca_csr_f32")
     resid = C.cast(C.byref(info, 16), C.POINTER(C.c_double))[0]
     return scores, comps, var, ratio, mean, {"n_outer": info[0], "n_gemm": info[1], "block_size": info[2],
                                              "chol_retries": info[3], "residual": resid, "scale_bits": info[6]}
@@ -320,9 +375,9 @@ def colsum(y: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     assert y.dtype == torch.float32 and y.is_contiguous()
     n, l = y.shape
-    out = torch.empty(l, dtype=torch.float64, device=dev)
+    out = _empty(l, dtype=torch.float64, device=dev)
     ws, wsz = _ws(lib.scamd_colsum_workspace_bytes(l), dev)
-    _lib.check(lib.scamd_colsum_f32_f64(ptr(y), n, l, ptr(out), ptr(ws), wsz, stream_ptr()), "scamd_colsum_f32_f64")
+    _check(lib.scamd_colsum_f32_f64(ptr(y), n, l, ptr(out), ptr(ws), wsz, stream_ptr()), "scamd_colsum_f32_f64")
     return out
 
 
@@ -335,14 +390,14 @@ def leiden(indptr: torch.Tensor, indices: torch.Tensor, weights: torch.Tensor, n
     indices = indices.to(torch.int32).contiguous()
     weights = weights.to(torch.float32).contiguous()
     nnz = weights.numel()
-    memb = torch.empty(n, dtype=torch.int32, device=dev)
+    memb = _empty(n, dtype=torch.int32, device=dev)
     ws, wsz = _ws(lib.scamd_leiden_workspace_bytes(n, nnz), dev)
     q = C.c_double(0.0)
     nc = C.c_int32(0)
     rc = lib.scamd_leiden_csr_f32(ptr(indptr), ptr(indices), ptr(weights), n, nnz, float(resolution),
                                   int(n_iterations), float(beta), int(seed) & (2**64 - 1), ptr(memb), C.byref(q),
                                   C.byref(nc), ptr(ws), wsz, stream_ptr())
-    _lib.check(rc, "scamd_leiden_csr_f32")
+    _check(rc, "scamd_leiden_csr_f32")
     return memb, float(q.value), int(nc.value)
 
 
@@ -359,47 +414,47 @@ def modularity(indptr: torch.Tensor, indices: torch.Tensor, weights: torch.Tenso
     q = C.c_double(0.0)
     rc = lib.scamd_modularity_csr_f32(ptr(indptr), ptr(indices), ptr(weights), n, nnz, ptr(membership),
                                       float(resolution), C.byref(q), ptr(ws), wsz, stream_ptr())
-    _lib.check(rc, "scamd_modularity_csr_f32")
+    _check(rc, "scamd_modularity_csr_f32")
     return float(q.value)
 
 
 # ---- upstream normalisation chain (csrc/preprocess.hip) ---------------------------------------------------------
 def pp_row_sums(indptr, indices, data, n: int, col_skip: torch.Tensor | None = None) -> torch.Tensor:
     dev = require_gpu()
-    out = torch.empty(n, dtype=torch.float32, device=dev)
+    out = _empty(n, dtype=torch.float32, device=dev)
     rc = _lib.load().scamd_pp_row_sums_f32(ptr(indptr), ptr(indices), ptr(data), n, data.numel(), ptr(col_skip), ptr(out), stream_ptr())
-    _lib.check(rc, "scamd_pp_row_sums_f32")
+    _check(rc, "scamd_pp_row_sums_f32")
     return out
 
 
 def pp_row_count_positive(indptr, data, n: int) -> torch.Tensor:
     dev = require_gpu()
-    out = torch.empty(n, dtype=torch.int32, device=dev)
-    _lib.check(_lib.load().scamd_pp_row_count_positive_f32(ptr(indptr), ptr(data), n, data.numel(), ptr(out), stream_ptr()),
+    out = _empty(n, dtype=torch.int32, device=dev)
+    _check(_lib.load().scamd_pp_row_count_positive_f32(ptr(indptr), ptr(data), n, data.numel(), ptr(out), stream_ptr()),
                "scamd_pp_row_count_positive_f32")
     return out
 
 
 def pp_count_high(indptr, indices, data, n: int, g: int, row_total: torch.Tensor, max_fraction: float) -> torch.Tensor:
     dev = require_gpu()
-    counts = torch.empty(g, dtype=torch.int32, device=dev)
+    counts = _empty(g, dtype=torch.int32, device=dev)
     rc = _lib.load().scamd_pp_count_high_f32(ptr(indptr), ptr(indices), ptr(data), n, g, data.numel(), ptr(row_total),
                                              float(max_fraction), ptr(counts), stream_ptr())
-    _lib.check(rc, "scamd_pp_count_high_f32")
+    _check(rc, "scamd_pp_count_high_f32")
     return counts
 
 
 def pp_row_divide_(indptr, data, n: int, factor: torch.Tensor) -> None:
     require_gpu()
     assert factor.dtype == torch.float32 and factor.numel() == n
-    _lib.check(_lib.load().scamd_pp_row_divide_f32(ptr(indptr), ptr(data), n, data.numel(), ptr(factor), stream_ptr()),
+    _check(_lib.load().scamd_pp_row_divide_f32(ptr(indptr), ptr(data), n, data.numel(), ptr(factor), stream_ptr()),
                "scamd_pp_row_divide_f32")
 
 
 def pp_log1p_(data: torch.Tensor, base: float | None = None) -> None:
     require_gpu()
     assert data.dtype == torch.float32 and data.is_contiguous()
-    _lib.check(_lib.load().scamd_pp_log1p_f32(ptr(data), data.numel(), 0.0 if base is None else float(base), stream_ptr()),
+    _check(_lib.load().scamd_pp_log1p_f32(ptr(data), data.numel(), 0.0 if base is None else float(base), stream_ptr()),
                "scamd_pp_log1p_f32")
 
 
@@ -408,15 +463,15 @@ def pp_col_stats(indptr, indices, data, n: int, g: int, *, row_mask: torch.Tenso
     """-> (sum float64 [g], sumsq float64 [g], npos int64 [g] or None) over the masked rows; expm1_scale = s: of
     expm1(x * s)."""
     dev = require_gpu()
-    s = torch.empty(g, dtype=torch.float64, device=dev)
-    sq = torch.empty(g, dtype=torch.float64, device=dev)
-    npos = torch.empty(g, dtype=torch.int64, device=dev) if count_positive else None
+    s = _empty(g, dtype=torch.float64, device=dev)
+    sq = _empty(g, dtype=torch.float64, device=dev)
+    npos = _empty(g, dtype=torch.int64, device=dev) if count_positive else None
     if row_mask is not None:
         assert row_mask.dtype == torch.uint8 and row_mask.numel() == n
     rc = _lib.load().scamd_pp_col_stats_f32(ptr(indptr), ptr(indices), ptr(data), n, g, data.numel(), ptr(row_mask),
                                             0 if expm1_scale is None else 1, 1.0 if expm1_scale is None else float(expm1_scale),
                                             ptr(s), ptr(sq), ptr(npos), stream_ptr())
-    _lib.check(rc, "scamd_pp_col_stats_f32")
+    _check(rc, "scamd_pp_col_stats_f32")
     return s, sq, npos
 
 
@@ -425,13 +480,13 @@ def pp_col_stats_clip(indptr, indices, data, n: int, g: int, clip: torch.Tensor,
     dev = require_gpu()
     clip = clip.to(torch.float64).contiguous()
     assert clip.numel() == g
-    s = torch.empty(g, dtype=torch.float64, device=dev)
-    sq = torch.empty(g, dtype=torch.float64, device=dev)
+    s = _empty(g, dtype=torch.float64, device=dev)
+    sq = _empty(g, dtype=torch.float64, device=dev)
     if row_mask is not None:
         assert row_mask.dtype == torch.uint8 and row_mask.numel() == n
     rc = _lib.load().scamd_pp_col_stats_clip_f32(ptr(indptr), ptr(indices), ptr(data), n, g, data.numel(), ptr(row_mask),
                                                  ptr(clip), ptr(s), ptr(sq), stream_ptr())
-    _lib.check(rc, "scamd_pp_col_stats_clip_f32")
+    _check(rc, "scamd_pp_col_stats_clip_f32")
     return s, sq
 
 
@@ -442,7 +497,7 @@ def pp_scale_csr_(indptr, indices, data, n: int, std: torch.Tensor, *, max_value
     rc = _lib.load().scamd_pp_scale_csr_f32(ptr(indptr), ptr(indices), ptr(data), n, data.numel(), ptr(std),
                                             0.0 if max_value is None else float(max_value), 0 if max_value is None else 1,
                                             ptr(row_mask), stream_ptr())
-    _lib.check(rc, "scamd_pp_scale_csr_f32")
+    _check(rc, "scamd_pp_scale_csr_f32")
 
 
 def pp_scale_dense(indptr, indices, data, n: int, g: int, mean: torch.Tensor, std: torch.Tensor, *,
@@ -450,11 +505,11 @@ def pp_scale_dense(indptr, indices, data, n: int, g: int, mean: torch.Tensor, st
                    out_dtype: torch.dtype = torch.float64) -> torch.Tensor:
     dev = require_gpu()
     assert mean.dtype == torch.float64 and std.dtype == torch.float64 and out_dtype in (torch.float32, torch.float64)
-    out = torch.empty((n, g), dtype=out_dtype, device=dev)
+    out = _empty((n, g), dtype=out_dtype, device=dev)
     rc = _lib.load().scamd_pp_scale_dense_f32(ptr(indptr), ptr(indices), ptr(data), n, g, data.numel(), ptr(mean), ptr(std),
                                               0.0 if max_value is None else float(max_value), 0 if max_value is None else 1,
                                               ptr(row_mask), ptr(out), 1 if out_dtype == torch.float64 else 0, stream_ptr())
-    _lib.check(rc, "scamd_pp_scale_dense_f32")
+    _check(rc, "scamd_pp_scale_dense_f32")
     return out
 
 
@@ -474,4 +529,4 @@ def umap_optimize_(indptr, indices, epochs_per_sample, n: int, y: torch.Tensor, 
     rc = lib.scamd_umap_optimize_f32(ptr(indptr), ptr(indices), ptr(epochs_per_sample), n, nnz, dim, int(n_epochs),
                                      float(a), float(b), float(gamma), float(initial_alpha), float(negative_sample_rate),
                                      int(seed) & (2**64 - 1), ptr(y), ptr(ws), wsz, stream_ptr())
-    _lib.check(rc, "scamd_umap_optimize_f32")
+    _check(rc, "scamd_umap_optimize_f32")

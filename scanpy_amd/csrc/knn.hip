@@ -1048,25 +1048,23 @@ __global__ __launch_bounds__(1024) void ivf_block_order_kernel(const int* __rest
   // xcd_mode: workgroup s of a launch runs on XCD s mod 8 (eight L2 caches that do not share).  The blocks of ONE cell
   // sweep the same cells in the same order, so they go to ONE XCD -- launch slots x, x + 8, x + 16, ... -- and pull each
   // tile through that L2 once instead of through all eight (round 4 counters of the block-id order: 35 GB fetched from
-  // the memory side for 59 GB staged into LDS per launch).  Cells are handed, longest expected sweep first, to the XCD
-  // with the fewest blocks so far: every XCD's queue is still longest-first, and the queue lengths differ by less than
-  // one cell's blocks.  Otherwise: exclusive scan of the block counts in sorted order (serial: 1024 entries)
-  if (tid == 0) {
-    int run = 0;
-    int len[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < n_cells; ++i) {
-      const int c = (int)(key[i] & 0xffffffffll);
-      const int cnt = blk_cnt[c];
-      if (xcd_mode) {
-        int xb = 0;
-        for (int x = 1; x < 8; ++x)
-          if (len[x] < len[xb]) xb = x;
-        start[i] = len[xb] * 8 + xb;
-        len[xb] += cnt;
-      } else {
-        start[i] = run;
-        run += cnt;
+  // the memory side for 59 GB staged into LDS per launch).  The cells, longest expected sweep first, are dealt round
+  // robin: cell i of the sorted order joins the queue of XCD i mod 8 -- every queue is still longest-first and holds
+  // every eighth cell of the order (thread x builds queue x).  Otherwise: exclusive scan of the block counts in sorted
+  // order (serial: 1024 entries)
+  if (xcd_mode) {
+    if (tid < 8) {
+      int len = 0;
+      for (int i = tid; i < n_cells; i += 8) {
+        start[i] = len * 8 + tid;
+        len += blk_cnt[(int)(key[i] & 0xffffffffll)];
       }
+    }
+  } else if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i < n_cells; ++i) {
+      start[i] = run;
+      run += blk_cnt[(int)(key[i] & 0xffffffffll)];
     }
   }
   __syncthreads();
@@ -1465,27 +1463,33 @@ __global__ __launch_bounds__(256) void knn_fallback_scan_cells_kernel(
 __global__ __launch_bounds__(256) void knn_fallback_rank_kernel(
     int k, const int* __restrict__ flag_list, int flag_begin, const double* __restrict__ scratch_d,
     const int* __restrict__ scratch_i, const int* __restrict__ counts, int32_t* __restrict__ out_idx,
-    double* __restrict__ out_dist, int* __restrict__ overflow) {
+    double* __restrict__ out_dist, double* __restrict__ kth_d2, int* __restrict__ retry_list, int* __restrict__ n_retry) {
   const int fb = blockIdx.x;
   const int64_t qi = flag_list[flag_begin + fb];
   const double* bd = scratch_d + (int64_t)fb * FALLBACK_CAP;
   const int* bi = scratch_i + (int64_t)fb * FALLBACK_CAP;
   int m = counts[fb];
-  if (m > FALLBACK_CAP) {
-    if (threadIdx.x == 0) atomicAdd(overflow, 1);
-    m = FALLBACK_CAP;
-  }
+  // More rows within the bound than the table holds: the bound came from a list the scoring engine could not order
+  // (norms far larger than the neighbour distances: clusters at +-3000 with unit spread -- tests/test_gpu_knn_certificate.py).
+  // The k-1 smallest of ANY FALLBACK_CAP rows bound the true (k-1)-th distance from above: tighten the bound to that and scan
+  // again (each round keeps about (k - 1) / FALLBACK_CAP of the rows; only more than FALLBACK_CAP rows tied AT the k-th
+  // distance cannot be resolved, which the host reports after a few rounds).
+  const bool overflow = m > FALLBACK_CAP;
+  if (overflow) m = FALLBACK_CAP;
   const int kk = k - 1;
   for (int u = threadIdx.x; u < m; u += blockDim.x) {
     double du = bd[u];
     int iu = bi[u];
     int rank = 0;
     for (int v = 0; v < m; ++v) rank += key_less(bd[v], bi[v], du, iu) ? 1 : 0;
-    if (rank < kk) {
+    if (overflow) {
+      if (rank == kk - 1) kth_d2[qi] = du;
+    } else if (rank < kk) {
       out_idx[qi * k + 1 + rank] = iu;
       out_dist[qi * k + 1 + rank] = sqrt(du);
     }
   }
+  if (overflow && threadIdx.x == 0) retry_list[atomicAdd(n_retry, 1)] = (int)qi;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1790,6 +1794,7 @@ static bool knn_plan(int64_t n, int d, int64_t n_query, int k, KnnPlan* p) {
 struct KnnBuffers {
   float* xp; float* cn; float* mu; double* mean_partial; unsigned int* cmax; int* cand_idx; float* cand_tau; double* kth_d2;
   int* flag_list; int* counters; double* scratch_d; int* scratch_i; int* fb_counts;
+  int* fb_retry[2];  // queries whose float64 scan overflowed its table: scanned again with a tighter bound
   // cell-pruned search
   int* labels; int* perm; int* qpos; int* block_cell; float* cent; float* centp; long long* sums; int* cell_ints;
   unsigned int* radius_bits; int* cell_order; float* cell_lb2; int* cell_aux; int* block_perm;
@@ -1812,6 +1817,8 @@ static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffe
   b->scratch_d = ws.take<double>((size_t)FALLBACK_CHUNK * FALLBACK_CAP);
   b->scratch_i = ws.take<int>((size_t)FALLBACK_CHUNK * FALLBACK_CAP);
   b->fb_counts = ws.take<int>((size_t)FALLBACK_CHUNK);
+  b->fb_retry[0] = ws.take<int>((size_t)n_query);
+  b->fb_retry[1] = ws.take<int>((size_t)n_query);
   b->labels = b->perm = b->qpos = b->block_cell = b->cell_ints = nullptr;
   b->cent = b->centp = nullptr;
   b->sums = nullptr;
@@ -2018,19 +2025,20 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   // ceil(n_blocks / 8) + (blocks of the largest cell) slots, if the table has room
   int n_launch = n_blocks, xcd_mode = 0;
   {
+    // (the queues are built on the device from the device's work estimates: the host only knows that a queue holds every
+    // eighth cell of some order, i.e. at most the ceil(nc / 8) cells with the most blocks)
     const char* e = getenv("SCAMD_KNN_XCD_ORDER");
-    int maxb = 0;
-    for (int c = 0; c < nc; ++c) maxb = std::max(maxb, h_blk[nc + c]);
-    const int64_t want = (int64_t)8 * ((n_blocks + 7) / 8 + maxb);
+    std::vector<int> nb(h_blk.begin() + nc, h_blk.begin() + 2 * nc);
+    std::sort(nb.begin(), nb.end(), std::greater<int>());
+    int64_t longest = 0;
+    for (int i = 0; i < (nc + 7) / 8; ++i) longest += nb[i];
+    const int64_t want = 8 * longest;
     const int64_t cap = (int64_t)(p.n_slot_max / 128 + 1) * 2 + 64;
     if (!(e && e[0] == '0') && n_blocks >= 64 && want <= cap) {
       xcd_mode = 1;
       n_launch = (int)want;
     }
   }
-  rows_out[0] = rows;
-  rows_out[1] = slots;
-  if (n_blocks == 0) return SCAMD_OK;
   SCAMD_HIP_CHECK(hipMemcpyAsync(cell_map, h_map.data(), sizeof(int) * nc, hipMemcpyHostToDevice, s));
   SCAMD_HIP_CHECK(hipMemcpyAsync(row_off, h_row_off.data(), sizeof(int) * nc, hipMemcpyHostToDevice, s));
   SCAMD_HIP_CHECK(hipMemcpyAsync(slot_off, h_slot_off.data(), sizeof(int) * nc, hipMemcpyHostToDevice, s));
@@ -2389,32 +2397,38 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
     }
   }
   if (n_fallback_host) *n_fallback_host = n_flag;
-  for (int begin = 0; begin < n_flag; begin += FALLBACK_CHUNK) {
-    int count = std::min(FALLBACK_CHUNK, n_flag - begin);
-    SCAMD_HIP_CHECK(hipMemsetAsync(b.fb_counts, 0, sizeof(int) * count, s));
-    if (p.ivf) {
-      // cell tables of run_ivf_select (same carving): tile0 = cell_ints + 7 nc, ntiles = the recycled sums buffer
-      const int nc = p.n_cells;
-      hipLaunchKernelGGL(knn_fallback_scan_cells_kernel, dim3(std::min(nc, 64), count), dim3(256), 0, s, x, d, ld_x, q_begin,
-                         flag_list, begin, b.kth_d2, b.scratch_d, b.scratch_i, b.fb_counts, b.cent,
-                         reinterpret_cast<const float*>(b.radius_bits), b.cell_ints + 7 * nc,
-                         reinterpret_cast<const int*>(b.sums), b.perm, nc);
-    } else {
-      const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(FALLBACK_ROW_CHUNKS, n / 2048));
-      hipLaunchKernelGGL(knn_fallback_scan_kernel, dim3(chunks, count), dim3(256), 0, s, x, n, d, ld_x, q_begin,
-                         flag_list, begin, b.kth_d2, b.scratch_d, b.scratch_i, b.fb_counts);
+  // float64 scan of what is left; a query whose table overflowed comes back with a tighter bound (knn_fallback_rank_kernel)
+  int n_todo = n_flag;
+  const int* todo = flag_list;
+  for (int round = 0; n_todo > 0; ++round) {
+    SCAMD_REQUIRE(round < 8, SCAMD_EUNSUPPORTED, "knn: %d queries have more than %d rows tied within their k-th distance",
+                  n_todo, FALLBACK_CAP);
+    int* retry = b.fb_retry[round & 1];
+    SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 1, 0, sizeof(int), s));
+    for (int begin = 0; begin < n_todo; begin += FALLBACK_CHUNK) {
+      int count = std::min(FALLBACK_CHUNK, n_todo - begin);
+      SCAMD_HIP_CHECK(hipMemsetAsync(b.fb_counts, 0, sizeof(int) * count, s));
+      if (p.ivf) {
+        // cell tables of run_ivf_select (same carving): tile0 = cell_ints + 7 nc, ntiles = the recycled sums buffer
+        const int nc = p.n_cells;
+        hipLaunchKernelGGL(knn_fallback_scan_cells_kernel, dim3(std::min(nc, 64), count), dim3(256), 0, s, x, d, ld_x, q_begin,
+                           todo, begin, b.kth_d2, b.scratch_d, b.scratch_i, b.fb_counts, b.cent,
+                           reinterpret_cast<const float*>(b.radius_bits), b.cell_ints + 7 * nc,
+                           reinterpret_cast<const int*>(b.sums), b.perm, nc);
+      } else {
+        const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(FALLBACK_ROW_CHUNKS, n / 2048));
+        hipLaunchKernelGGL(knn_fallback_scan_kernel, dim3(chunks, count), dim3(256), 0, s, x, n, d, ld_x, q_begin,
+                           todo, begin, b.kth_d2, b.scratch_d, b.scratch_i, b.fb_counts);
+      }
+      SCAMD_LAUNCH_CHECK();
+      hipLaunchKernelGGL(knn_fallback_rank_kernel, dim3(count), dim3(256), 0, s, k, todo, begin, b.scratch_d,
+                         b.scratch_i, b.fb_counts, out_idx, out_dist, b.kth_d2, retry, b.counters + 1);
+      SCAMD_LAUNCH_CHECK();
     }
-    SCAMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(knn_fallback_rank_kernel, dim3(count), dim3(256), 0, s, k, flag_list, begin, b.scratch_d,
-                       b.scratch_i, b.fb_counts, out_idx, out_dist, b.counters + 1);
-    SCAMD_LAUNCH_CHECK();
-  }
-  if (n_flag > 0) {
     SCAMD_HIP_CHECK(hipMemcpyAsync(h_counters, b.counters, 16, hipMemcpyDeviceToHost, s));
     SCAMD_HIP_CHECK(hipStreamSynchronize(s));
-    SCAMD_REQUIRE(h_counters[1] == 0, SCAMD_EUNSUPPORTED,
-                  "knn: %d queries have more than %d rows tied within their k-th distance",
-                  h_counters[1], FALLBACK_CAP);
+    n_todo = h_counters[1];
+    todo = retry;
   }
   return SCAMD_OK;
 }
