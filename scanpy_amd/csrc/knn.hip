@@ -2039,6 +2039,9 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
       n_launch = (int)want;
     }
   }
+  rows_out[0] = rows;
+  rows_out[1] = slots;
+  if (n_blocks == 0) return SCAMD_OK;
   SCAMD_HIP_CHECK(hipMemcpyAsync(cell_map, h_map.data(), sizeof(int) * nc, hipMemcpyHostToDevice, s));
   SCAMD_HIP_CHECK(hipMemcpyAsync(row_off, h_row_off.data(), sizeof(int) * nc, hipMemcpyHostToDevice, s));
   SCAMD_HIP_CHECK(hipMemcpyAsync(slot_off, h_slot_off.data(), sizeof(int) * nc, hipMemcpyHostToDevice, s));

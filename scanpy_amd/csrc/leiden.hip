@@ -643,8 +643,30 @@ __device__ __forceinline__ int lm_class(int v, unsigned int salt, int n_cls) {
 // flags -> n_cls class lists (lists[c * n ..]), counts in cls_count[0 .. n_cls); clears the flags.  flag == nullptr:
 // every vertex is active (first sweep of a level).  The order inside a list is irrelevant (every decision of a
 // sub-round reads the same snapshot).  One atomic per class and 1024-vertex block.
+// Long rows of a class, counted while its list is built (round 4): sub-round c's counter block gets the number of its
+// vertices whose rows the main decision kernel hands on -- longer than thr_mid (the lanes-per-vertex table) / longer than
+// thr_hub (the wave table) -- so that the host launches the overflow / hub kernels of a sub-round only when it has any
+// (they were launched blind: ~300 near-empty launches of ~10 us per call at 1M cells).  thr_mid < 0: no such tier.
+constexpr int CTR_N_MID = 8, CTR_N_HUB = 9;
+// tier of a vertex's row: bit 0 = longer than thr_mid, bit 1 = longer than thr_hub (0 for inactive vertices)
+__device__ __forceinline__ int long_row_tier(int cls, int v, const int64_t* __restrict__ indptr, int thr_mid, int thr_hub) {
+  if (cls < 0 || !indptr) return 0;
+  const int deg = (int)(indptr[v + 1] - indptr[v]);
+  return ((thr_mid >= 0 && deg > thr_mid) ? 1 : 0) | (deg > thr_hub ? 2 : 0);
+}
+// one atomic per wave, class and tier (inside the class loop of the list builders; every lane of the wave calls it)
+__device__ __forceinline__ void count_long_rows(int c, int cls, int tier, int lane, int* __restrict__ cls_count) {
+  const unsigned long long mm = __ballot(cls == c && (tier & 1)), mh = __ballot(cls == c && (tier & 2));
+  if (lane == 0) {
+    int* ctr = cls_count + MAX_CLASSES + CTR_STRIDE * c;
+    if (mm) atomicAdd(&ctr[CTR_N_MID], __popcll(mm));
+    if (mh) atomicAdd(&ctr[CTR_N_HUB], __popcll(mh));
+  }
+}
+
 __global__ __launch_bounds__(1024) void ld_compact_cls_kernel(int n, int* __restrict__ flag, int* __restrict__ lists,
-                                                              int* __restrict__ cls_count, int n_cls, unsigned int salt) {
+                                                              int* __restrict__ cls_count, int n_cls, unsigned int salt,
+                                                              const int64_t* __restrict__ indptr, int thr_mid, int thr_hub) {
   __shared__ int wcnt[16][MAX_CLASSES];
   __shared__ int base[MAX_CLASSES];
   const int v = blockIdx.x * 1024 + threadIdx.x;
@@ -658,11 +680,13 @@ __global__ __launch_bounds__(1024) void ld_compact_cls_kernel(int n, int* __rest
     }
     if (f) cls = lm_class(v, salt, n_cls);
   }
+  const int tier = long_row_tier(cls, v, indptr, thr_mid, thr_hub);
   int rank = 0;
   for (int c = 0; c < n_cls; ++c) {
     const unsigned long long m = __ballot(cls == c);
     if (cls == c) rank = __popcll(m & ((1ull << lane) - 1ull));
     if (lane == 0) wcnt[wv][c] = __popcll(m);
+    count_long_rows(c, cls, tier, lane, cls_count);
   }
   __syncthreads();
   if ((int)threadIdx.x < n_cls) {
@@ -720,7 +744,7 @@ __global__ __launch_bounds__(256) void ld_within_kernel(int n, const int64_t* __
 __global__ __launch_bounds__(1024) void ld_refine_candidates_kernel(
     int n, const long long* __restrict__ k, const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot,
     const long long* __restrict__ a_in, double g, int* __restrict__ lists, int* __restrict__ cls_count, int n_cls,
-    unsigned int salt) {
+    unsigned int salt, const int64_t* __restrict__ indptr, int thr_mid, int thr_hub) {
   __shared__ int wcnt[16][MAX_CLASSES];
   __shared__ int base[MAX_CLASSES];
   const int v = blockIdx.x * 1024 + threadIdx.x;
@@ -731,11 +755,13 @@ __global__ __launch_bounds__(1024) void ld_refine_candidates_kernel(
     const double KC = (double)(long long)Ktot[comm[v]];
     if ((double)a_in[v] >= g * kv * (KC - kv)) cls = lm_class(v, salt, n_cls);
   }
+  const int tier = long_row_tier(cls, v, indptr, thr_mid, thr_hub);
   int rank = 0;
   for (int c = 0; c < n_cls; ++c) {
     const unsigned long long m = __ballot(cls == c);
     if (cls == c) rank = __popcll(m & ((1ull << lane) - 1ull));
     if (lane == 0) wcnt[wv][c] = __popcll(m);
+    count_long_rows(c, cls, tier, lane, cls_count);
   }
   __syncthreads();
   if ((int)threadIdx.x < n_cls) {
@@ -2143,6 +2169,7 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
   SCAMD_HIP_CHECK(hipMemsetAsync(b.flag, 0, sizeof(int) * n, cx.s));
   SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));  // [0] moved, [1] blocked (cumulative), [7] error
   const int lanes = level_lanes(g);
+  const int thr_mid = lanes == 16 ? (int)(WH_SLOTS / 4 * 3 / 4) : (lanes == 32 ? (int)(WH_SLOTS / 2 * 3 / 4) : -1);
   const int n_cls = lm_classes(cx, g.n);
   int* sw = b.rcounters;  // [0, MAX_CLASSES): class list lengths of the sweep; then one block per sub-round: hub / overflow counts
   int moved_before = 0, quiet = 0, moved_prev2 = 0;
@@ -2150,10 +2177,10 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
     SCAMD_HIP_CHECK(hipMemsetAsync(sw, 0, sizeof(int) * (MAX_CLASSES + CTR_STRIDE * n_cls), cx.s));
     const unsigned int salt = hash32(cx.seed + 0x85EBCA77u * (unsigned int)(sweep + 1) + 0xC2B2AE3Du * (unsigned int)cx.iter);
     hipLaunchKernelGGL(ld_compact_cls_kernel, dim3((unsigned)ceil_div(g.n, 1024)), dim3(1024), 0, cx.s, g.n,
-                       sweep == 0 ? (int*)nullptr : b.flag, b.cls_lists, sw, n_cls, salt);
+                       sweep == 0 ? (int*)nullptr : b.flag, b.cls_lists, sw, n_cls, salt, g.indptr, thr_mid, (int)WH_MAX_DEG);
     SCAMD_LAUNCH_CHECK();
-    int hc[MAX_CLASSES], ht[8];
-    SCAMD_HIP_CHECK(hipMemcpyAsync(hc, sw, sizeof(int) * n_cls, hipMemcpyDeviceToHost, cx.s));
+    int hc[CTR_AREA], ht[8];  // class list lengths, then per sub-round [CTR_N_MID] / [CTR_N_HUB]: long rows of the class
+    SCAMD_HIP_CHECK(hipMemcpyAsync(hc, sw, sizeof(int) * (MAX_CLASSES + CTR_STRIDE * n_cls), hipMemcpyDeviceToHost, cx.s));
     SCAMD_HIP_CHECK(hipMemcpyAsync(ht, b.counters, sizeof(int) * 8, hipMemcpyDeviceToHost, cx.s));
     SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
     SCAMD_REQUIRE(ht[7] == 0, SCAMD_EINTERNAL, "leiden: hub table overflow (local moving)");
@@ -2192,13 +2219,15 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
       if (cnt == 0) continue;
       const int* list = b.cls_lists + (size_t)c * n;
       int* ctr = sw + MAX_CLASSES + CTR_STRIDE * c;
+      // long rows among THIS sub-round's vertices (counted by ld_compact_cls_kernel): no launch for an empty tier
+      const int n_mid = hc[MAX_CLASSES + CTR_STRIDE * c + CTR_N_MID], n_hub = hc[MAX_CLASSES + CTR_STRIDE * c + CTR_N_HUB];
       if (lanes == 32) {
         hipLaunchKernelGGL(ld_move_kernel<32>, dim3((unsigned)ceil_div(cnt, 8)), dim3(256), 0, cx.s, cnt, list,
                            (const int*)nullptr, (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
                            b.csize, gg, dir_round, cx.seed, b.target, b.mid_list, b.hub_list, ctr);
         SCAMD_LAUNCH_CHECK();
-        if (g.n_gt192 > 0) {
-          hipLaunchKernelGGL(ld_move_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(std::min(cnt, g.n_gt192), 4))), dim3(256), 0, cx.s,
+        if (n_mid > 0) {
+          hipLaunchKernelGGL(ld_move_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(n_mid, 4))), dim3(256), 0, cx.s,
                              cnt, list, (const int*)b.mid_list, (const int*)(ctr + 5), g.indptr, g.indices, g.wq, g.k,
                              b.comm, b.Ktot, b.csize, gg, dir_round, cx.seed, b.target, b.mid_list, b.hub_list, ctr);
           SCAMD_LAUNCH_CHECK();
@@ -2208,8 +2237,8 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
                            (const int*)nullptr, (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
                            b.csize, gg, dir_round, cx.seed, b.target, b.mid_list, b.hub_list, ctr);
         SCAMD_LAUNCH_CHECK();
-        if (g.n_gt96 > 0) {
-          hipLaunchKernelGGL(ld_move_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(std::min(cnt, g.n_gt96), 4))), dim3(256), 0, cx.s,
+        if (n_mid > 0) {
+          hipLaunchKernelGGL(ld_move_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(n_mid, 4))), dim3(256), 0, cx.s,
                              cnt, list, (const int*)b.mid_list, (const int*)(ctr + 5), g.indptr, g.indices, g.wq, g.k,
                              b.comm, b.Ktot, b.csize, gg, dir_round, cx.seed, b.target, b.mid_list, b.hub_list, ctr);
           SCAMD_LAUNCH_CHECK();
@@ -2220,8 +2249,8 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
                            b.mid_list, b.hub_list, ctr);
         SCAMD_LAUNCH_CHECK();
       }
-      if (g.n_gt384 > 0) {
-        hipLaunchKernelGGL(ld_move_hub_kernel, dim3((unsigned)std::min(HUB_GRID, std::min(cnt, g.n_gt384))), dim3(HUB_THREADS), HUB_LDS, cx.s, b.hub_list,
+      if (n_hub > 0) {
+        hipLaunchKernelGGL(ld_move_hub_kernel, dim3((unsigned)std::min(HUB_GRID, n_hub)), dim3(HUB_THREADS), HUB_LDS, cx.s, b.hub_list,
                            ctr, list, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg, dir_round, cx.seed,
                            b.target, b.counters + 7);
         SCAMD_LAUNCH_CHECK();
@@ -2258,11 +2287,12 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
   SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
   SCAMD_HIP_CHECK(hipMemsetAsync(b.touched, 0xff, sizeof(int) * n, cx.s));  // join sub-round stamps: -1 = never
   hipLaunchKernelGGL(ld_refine_candidates_kernel, dim3((unsigned)ceil_div(g.n, 1024)), dim3(1024), 0, cx.s, g.n, g.k,
-                     b.comm, b.Ktot, b.a_in, gg, b.cls_lists, rc0, n_cls, salt);
+                     b.comm, b.Ktot, b.a_in, gg, b.cls_lists, rc0, n_cls, salt, g.indptr,
+                     quad ? (int)(WH_SLOTS / 4 * 3 / 4) : -1, (int)WH_MAX_DEG);
   SCAMD_LAUNCH_CHECK();
   LD_DBG_SYNC(cx, "rf candidates n=%d classes=%d", g.n, n_cls);
-  int hc[MAX_CLASSES];
-  SCAMD_HIP_CHECK(hipMemcpyAsync(hc, rc0, sizeof(int) * n_cls, hipMemcpyDeviceToHost, cx.s));
+  int hc[CTR_AREA];  // class list lengths, then per sub-round [CTR_N_MID] / [CTR_N_HUB] (ld_refine_candidates_kernel)
+  SCAMD_HIP_CHECK(hipMemcpyAsync(hc, rc0, sizeof(int) * (MAX_CLASSES + CTR_STRIDE * n_cls), hipMemcpyDeviceToHost, cx.s));
   SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
   *n_merged = 0;
   // ONE sweep of n_cls sub-rounds, no host round trip in between: every candidate is considered exactly once (see
@@ -2272,6 +2302,7 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
     if (cnt == 0) continue;
     const int* list = b.cls_lists + (size_t)c * n;
     int* ctr = rc0 + MAX_CLASSES + CTR_STRIDE * c;
+    const int n_mid = hc[MAX_CLASSES + CTR_STRIDE * c + CTR_N_MID], n_hub = hc[MAX_CLASSES + CTR_STRIDE * c + CTR_N_HUB];
     const unsigned wgrid = (unsigned)std::min(32768, ceil_div(cnt, 4));
     const unsigned tgrid = (unsigned)std::min(32768, ceil_div(cnt, 256));
     const unsigned qgrid = (unsigned)std::min(32768, ceil_div(cnt, 16));
@@ -2281,8 +2312,8 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
                          b.Eref, gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.mid_list, b.hub_list, ctr, cnt);
       SCAMD_LAUNCH_CHECK();
       LD_DBG_SYNC(cx, "rf propose<16> n=%d class=%d cnt=%d", g.n, c, cnt);
-      if (g.n_gt96 > 0) {
-        hipLaunchKernelGGL(ld_refine_propose_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(std::min(cnt, g.n_gt96), 4))), dim3(256), 0, cx.s, list,
+      if (n_mid > 0) {
+        hipLaunchKernelGGL(ld_refine_propose_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(n_mid, 4))), dim3(256), 0, cx.s, list,
                            (const int*)b.mid_list, (const int*)(ctr + 5), g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
                            b.ref, b.refsize, b.Kref, b.Eref, gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.mid_list,
                            b.hub_list, ctr, cnt);
@@ -2296,8 +2327,8 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
       SCAMD_LAUNCH_CHECK();
       LD_DBG_SYNC(cx, "rf propose<64> n=%d class=%d cnt=%d", g.n, c, cnt);
     }
-    if (g.n_gt384 > 0) {
-      hipLaunchKernelGGL(ld_refine_propose_hub_kernel, dim3((unsigned)std::min(HUB_GRID, std::min(cnt, g.n_gt384))), dim3(HUB_THREADS), HUB_LDS, cx.s,
+    if (n_hub > 0) {
+      hipLaunchKernelGGL(ld_refine_propose_hub_kernel, dim3((unsigned)std::min(HUB_GRID, n_hub)), dim3(HUB_THREADS), HUB_LDS, cx.s,
                          b.hub_list, ctr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref,
                          gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.counters + 7);
       SCAMD_LAUNCH_CHECK();
