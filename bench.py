@@ -542,14 +542,14 @@ def noise_variant(args, backend, kw) -> dict:
             "pca_info": {k: v for k, v in res.info.items() if k != "knn_fallback_queries"}}
 
 
-def _profiled_traffic(mode: str):
+def _profiled_traffic(mode: str, engine: str):
     """HBM-side bytes per launch of the roofline kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE are separate profiling runs, they cannot be taken inside this process); None if the committed passes
-    are of a different sweep mode than the one that ran (or absent)."""
+    are of a different sweep mode or scoring engine than the one that ran (or absent)."""
     f = ROOT / "profiles" / "knn_select_traffic.json"
     try:
         d = json.loads(f.read_text())
-        return d["bytes_per_launch"] if d.get("mode") == mode else None
+        return d["bytes_per_launch"] if d.get("mode") == mode and d.get("engine", "f32") == engine else None
     except (OSError, KeyError, ValueError):
         return None
 
@@ -767,11 +767,13 @@ def main() -> None:
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": (achieved / peak) if achieved else None,
-                # the committed PMC passes are of the single-GPU 1M x 1M launch: not quoted for any other shape
-                # (the committed PMC passes are of the float32 engine; the bf16 engine's passes could not be taken this
-                # round -- rocprofv3 --pmc aborted with a device fault on the box, profiles/README.md -- hence null)
-                "traffic": (_profiled_traffic("ivf" if 0 < pairs < brute_pairs else "brute")
-                            if (n, args.n_comps, world) == (1_000_000, 50, 1) and engine == 0 else None),
+                # the committed PMC passes (profiles/knn_select_traffic.json, separate FETCH_SIZE / WRITE_SIZE passes restricted
+                # to this kernel) are of the single-GPU 1M x 1M launch of the planted matrix: not quoted for any other shape
+                "traffic": (_profiled_traffic("ivf" if 0 < pairs < brute_pairs else "brute", "bf16x3" if engine == 1 else "f32")
+                            if (n, args.n_comps, world, args.structure) == (1_000_000, 50, 1, "planted") else None),
+                # algorithmic bytes of the launch: the image once (272 B per row, bf16 engine; 240 B float32) + the candidate
+                # lists out (32 ids + threshold per query)
+                "algorithmic_bytes_per_launch": float(n) * (272.0 if engine == 1 else 240.0) + float(n_query) * (32 * 4 + 4),
                 "launch_ms": sel,
                 "algorithmic_flop_per_launch": flops,
                 "flop_per_pair": flop_per_pair,

@@ -1053,11 +1053,30 @@ __global__ __launch_bounds__(1024) void ivf_block_order_kernel(const int* __rest
   // every eighth cell of the order (thread x builds queue x).  Otherwise: exclusive scan of the block counts in sorted
   // order (serial: 1024 entries)
   if (xcd_mode) {
-    if (tid < 8) {
+    // cell i of the sorted order goes to the XCD whose queue holds the least work so far (blocks x expected sweep per
+    // block; dealing the cells round robin left the queues up to 10 % apart: 18.99 vs 17.42 ms, profiles/r04d).  The
+    // eight running totals live in lanes 0..7 of the first wave, the minimum is found with three shuffles.
+    if (tid < 64) {
+      long long load = 0ll;
       int len = 0;
-      for (int i = tid; i < n_cells; i += 8) {
-        start[i] = len * 8 + tid;
-        len += blk_cnt[(int)(key[i] & 0xffffffffll)];
+      for (int i = 0; i < n_cells; ++i) {
+        const int c = (int)(key[i] & 0xffffffffll);
+        const int cnt = blk_cnt[c];
+        const long long wk = (long long)cnt * (long long)max(work[c], 1);
+        // (a queue may not outgrow its share of the launch slots; the slots are sized so that some queue always has room)
+        const bool room = tid < 8 && (len + cnt) * 8 <= n_slots;
+        long long best = room ? (load << 3) | (long long)(tid & 7) : 0x7fffffffffffffffll;  // (totals stay far below 2^60)
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) {
+          const long long other = __shfl_xor(best, o);
+          best = other < best ? other : best;
+        }
+        const int xb = (int)(best & 7);
+        if (tid == xb && best != 0x7fffffffffffffffll) {
+          start[i] = len * 8 + xb;
+          len += cnt;
+          load += wk;
+        }
       }
     }
   } else if (tid == 0) {
@@ -2025,14 +2044,13 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   // ceil(n_blocks / 8) + (blocks of the largest cell) slots, if the table has room
   int n_launch = n_blocks, xcd_mode = 0;
   {
-    // (the queues are built on the device from the device's work estimates: the host only knows that a queue holds every
-    // eighth cell of some order, i.e. at most the ceil(nc / 8) cells with the most blocks)
+    // (the queues are built on the device from the device's work estimates; the host sizes the launch for queues of twice
+    // the mean length plus the largest cell -- slots beyond a queue's end hold -1 and exit at once, a queue that would
+    // not fit is cut off by `slot < n_slots` in ivf_block_order_kernel ... which must not happen: checked there)
     const char* e = getenv("SCAMD_KNN_XCD_ORDER");
-    std::vector<int> nb(h_blk.begin() + nc, h_blk.begin() + 2 * nc);
-    std::sort(nb.begin(), nb.end(), std::greater<int>());
-    int64_t longest = 0;
-    for (int i = 0; i < (nc + 7) / 8; ++i) longest += nb[i];
-    const int64_t want = 8 * longest;
+    int maxb = 0;
+    for (int c = 0; c < nc; ++c) maxb = std::max(maxb, h_blk[nc + c]);
+    const int64_t want = (int64_t)8 * (2 * ((n_blocks + 7) / 8) + maxb);
     const int64_t cap = (int64_t)(p.n_slot_max / 128 + 1) * 2 + 64;
     if (!(e && e[0] == '0') && n_blocks >= 64 && want <= cap) {
       xcd_mode = 1;
@@ -2086,7 +2104,8 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   // 96 / 236 bytes per lane to scratch, `-Rpass-analysis=kernel-resource-usage`); SCAMD_KNN_IVF_WPS=2 selects the
   // build cut for 2 blocks per CU (no spills) -- an A/B switch until both have been measured
   const char* wps_env = getenv("SCAMD_KNN_IVF_WPS");
-  auto kern = B3 ? knn_select_reg_kernel<H, 64, 2, true, B3>
+  // (bf16 engine: 193 VGPRs = 2 blocks per CU by default; SCAMD_KNN_IVF_WPS=3 selects the build cut for 3)
+  auto kern = B3 ? ((wps_env && atoi(wps_env) == 3) ? knn_select_reg_kernel<H, 64, 3, true, B3> : knn_select_reg_kernel<H, 64, 2, true, B3>)
                  : ((wps_env && atoi(wps_env) == 2) ? knn_select_reg_kernel<H, 64, 2, true, false>
                                                      : knn_select_reg_kernel<H, 64, 3, true, false>);
   const size_t lds = C::LDS_BYTES + 64;

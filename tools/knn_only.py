@@ -40,7 +40,7 @@ def main():
         pairs, pre = float(lib.scamd_knn_last_select_pairs()), float(lib.scamd_knn_last_select_prepass_pairs())
         print(f"knn n={n} d={d} k={k} ({src}): select {ms:.2f} ms, swept pairs {pairs:.4e} (+ pre-pass {pre:.3e}) = "
               f"{2.0 * pairs * d / ms / 1e9:.1f} useful TFLOP/s, {2.0 * (pairs + pre) * d / ms / 1e9:.1f} executed; "
-              f"brute-force equivalent {2.0 * n * n * d / ms / 1e9:.1f}; fallback={nfb}", flush=True)
+              f"brute-force equivalent {2.0 * n * n * d / ms / 1e9:.1f}; fallback={nfb} tier2={int(lib.scamd_knn_last_second_tier_queries())}", flush=True)
 
 
 if __name__ == "__main__":
