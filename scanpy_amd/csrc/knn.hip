@@ -1779,8 +1779,12 @@ static bool knn_plan(int64_t n, int d, int64_t n_query, int k, KnnPlan* p) {
       // larger than the neighbour distances): with the margin of 6 ranks, 508 queries of the planted 1M run failed the
       // certificate under a bound that was still 2x too small, and the float64 scan of those cost 4.2 ms.  The failure
       // probability falls like (bound / gap)^margin.  Measured with the correct bound, planted 1M: margin 8 -> select
-      // 16.5 ms + 200 fallbacks, 10 -> 17.0 ms + 5, 12 -> 18.0 ms + 1: 10 ranks (threshold = the 25th list entry at k = 15).
-      if (!p->thr_margin_env) p->thr_rank = std::min(32, std::max(1, k + 10));
+      // 16.5 ms + 200 fallbacks, 10 -> 17.0 ms + 5, 12 -> 18.0 ms + 1.  Round 4: the bound prices the norms a missed
+      // neighbour can have instead of the largest norm of the data set (knn_rerank_rows_kernel), which rejects fewer
+      // queries at every margin -- one box, planted 1M: margin 10 -> 16.97 ms + 1 float64 scan, 8 -> 16.30 ms + 58,
+      // 6 -> 15.89 ms + 1423 queries through the second tier (which costs what the margin saved), 4 -> 15.41 ms + 25764
+      // (profiles/r04e_knn_knobs.log): 8 ranks (threshold = the 23rd list entry at k = 15).
+      if (!p->thr_margin_env) p->thr_rank = std::min(32, std::max(1, k + 8));
     }
   }
   const int QB = p->NW * 32;
