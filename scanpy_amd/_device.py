@@ -61,29 +61,49 @@ class _WorkspacePool:
 workspace_pool = _WorkspacePool()
 
 
-class _PinnedUploader:
-    """Host array -> HBM at PCIe rate.  `tensor.to(device)` of a PAGEABLE numpy array goes through the runtime's own
+class _PinnedTransfer:
+    """Host array <-> HBM at PCIe rate.  `tensor.to(device)` of a PAGEABLE numpy array goes through the runtime's own
     bounce buffer, one memcpy thread deep: 0.8 GB of CSR took 30 ms warm (27 GB/s), more than the whole PCA that waits
     for it.  Here the array is cut into 32 MB pieces; a small thread pool copies piece i + 1 into one of two page-locked
-    staging buffers (numpy releases the GIL for the copy) while piece i is DMA'd out of the other on a copy stream.
-    The staging buffers are allocated once per process (page-locking costs more than the copy)."""
+    staging buffers (numpy releases the GIL for the copy) while piece i is DMA'd out of the other on a copy stream;
+    downloads run the same pipeline backwards, so the arrays handed to the user (`.obsm` / `.obsp` slots) live in ordinary
+    pageable memory and nothing stays page-locked beyond the two staging buffers.
+    Staging buffers, events and the copy stream are kept PER DEVICE (a stream belongs to one device: a singleton created
+    for the first device would record its events on the wrong stream for the second); one transfer at a time (lock)."""
 
     PIECE = int(os.environ.get("SCAMD_UPLOAD_PIECE_MB", "32")) << 20
     THREADS = int(os.environ.get("SCAMD_UPLOAD_THREADS", "8"))
 
     def __init__(self) -> None:
-        self._stage = None
-        self._events = None
-        self._pool = None
-        self._stream = None
+        import threading
 
-    def _setup(self, device: torch.device) -> None:
+        self._per_device: dict[int, tuple] = {}
+        self._pool = None
+        self._lock = threading.Lock()
+
+    def _state(self, device: torch.device):
         from concurrent.futures import ThreadPoolExecutor
 
-        self._stage = [torch.empty(self.PIECE, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
-        self._events = [torch.cuda.Event() for _ in range(2)]
-        self._pool = ThreadPoolExecutor(max_workers=self.THREADS)
-        self._stream = torch.cuda.Stream(device=device)
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        st = self._per_device.get(key)
+        if st is None:
+            if self._pool is None:
+                self._pool = ThreadPoolExecutor(max_workers=self.THREADS)
+            dev = torch.device("cuda", key)
+            st = ([torch.empty(self.PIECE, dtype=torch.uint8, pin_memory=True) for _ in range(2)],
+                  [torch.cuda.Event() for _ in range(2)], torch.cuda.Stream(device=dev))
+            self._per_device[key] = st
+        return st
+
+    def _host_copy(self, dst, src) -> None:
+        """dst[:] = src for two flat uint8 numpy views of equal length, split over the thread pool"""
+        import numpy as np
+
+        n = dst.shape[0]
+        step = (n + self.THREADS - 1) // self.THREADS
+        futs = [self._pool.submit(np.copyto, dst[a:min(a + step, n)], src[a:min(a + step, n)]) for a in range(0, n, step)]
+        for f in futs:
+            f.result()
 
     def upload(self, arr, device: torch.device) -> torch.Tensor:
         import numpy as np
@@ -91,48 +111,73 @@ class _PinnedUploader:
         arr = np.ascontiguousarray(arr)
         src = torch.from_numpy(arr)
         nbytes = arr.nbytes
-        # (small arrays, and arrays that already live in page-locked memory -- e.g. the slots `to_host` produced: direct DMA)
+        # (small arrays, and arrays that already live in page-locked memory: direct DMA)
         if nbytes < (8 << 20) or os.environ.get("SCAMD_PINNED_UPLOAD") == "0" or src.is_pinned():
             return src.to(device)
-        if self._stage is None:
-            self._setup(device)
-        out = torch.empty(arr.shape, dtype=src.dtype, device=device)
-        out_b = out.view(torch.uint8).reshape(-1)
-        src_b = arr.view(np.uint8).reshape(-1)
-        cur = torch.cuda.current_stream(device)
-        self._stream.wait_stream(cur)  # `out` was allocated on the current stream
-        n_piece = (nbytes + self.PIECE - 1) // self.PIECE
-        for i in range(n_piece):
-            lo, hi = i * self.PIECE, min(nbytes, (i + 1) * self.PIECE)
-            slot = i & 1
-            stage = self._stage[slot]
-            self._events[slot].synchronize()  # the last DMA out of this staging buffer (this call's or an earlier one's)
-            dst = stage.numpy()
-            step = (hi - lo + self.THREADS - 1) // self.THREADS
-            futs = [self._pool.submit(np.copyto, dst[a - lo:min(a + step, hi) - lo], src_b[a:min(a + step, hi)])
-                    for a in range(lo, hi, step)]
-            for f in futs:
-                f.result()
-            with torch.cuda.stream(self._stream):
-                out_b[lo:hi].copy_(stage[:hi - lo], non_blocking=True)
-                self._events[slot].record(self._stream)
-        cur.wait_stream(self._stream)
-        out.record_stream(self._stream)  # written on the copy stream, allocated (and later freed) on the current one
-        return out
+        with self._lock:
+            stages, events, stream = self._state(device)
+            out = torch.empty(arr.shape, dtype=src.dtype, device=device)
+            out_b = out.view(torch.uint8).reshape(-1)
+            src_b = arr.view(np.uint8).reshape(-1)
+            cur = torch.cuda.current_stream(device)
+            stream.wait_stream(cur)  # `out` was allocated on the current stream
+            n_piece = (nbytes + self.PIECE - 1) // self.PIECE
+            for i in range(n_piece):
+                lo, hi = i * self.PIECE, min(nbytes, (i + 1) * self.PIECE)
+                slot = i & 1
+                stage = stages[slot]
+                events[slot].synchronize()  # the last DMA out of this staging buffer (this call's or an earlier one's)
+                self._host_copy(stage.numpy()[:hi - lo], src_b[lo:hi])
+                with torch.cuda.stream(stream):
+                    out_b[lo:hi].copy_(stage[:hi - lo], non_blocking=True)
+                    events[slot].record(stream)
+            cur.wait_stream(stream)
+            out.record_stream(stream)  # written on the copy stream, allocated (and later freed) on the current one
+            return out
+
+    def download(self, t: torch.Tensor):
+        """device tensor -> numpy array in pageable memory: DMA of piece i + 1 into one staging buffer while the thread
+        pool copies piece i out of the other"""
+        import numpy as np
+
+        t = t.contiguous()
+        nbytes = t.numel() * t.element_size()
+        with self._lock:
+            stages, events, stream = self._state(t.device)
+            out = np.empty(tuple(t.shape), dtype=torch.empty((), dtype=t.dtype).numpy().dtype)
+            out_b = out.view(np.uint8).reshape(-1)
+            src_b = t.view(torch.uint8).reshape(-1)
+            cur = torch.cuda.current_stream(t.device)
+            stream.wait_stream(cur)  # `t` was produced on the current stream
+            n_piece = (nbytes + self.PIECE - 1) // self.PIECE
+
+            def issue(i):
+                lo, hi = i * self.PIECE, min(nbytes, (i + 1) * self.PIECE)
+                events[i & 1].synchronize()  # (an earlier upload may still be reading this staging buffer)
+                with torch.cuda.stream(stream):
+                    stages[i & 1][:hi - lo].copy_(src_b[lo:hi], non_blocking=True)
+                    events[i & 1].record(stream)
+
+            if n_piece:
+                issue(0)
+            for i in range(n_piece):
+                lo, hi = i * self.PIECE, min(nbytes, (i + 1) * self.PIECE)
+                events[i & 1].synchronize()  # piece i has arrived
+                if i + 1 < n_piece:
+                    issue(i + 1)  # (its staging buffer was drained in step i - 1)
+                self._host_copy(out_b[lo:hi], stages[i & 1].numpy()[:hi - lo])
+            t.record_stream(stream)
+            return out
 
 
-pinned_uploader = _PinnedUploader()
+pinned_uploader = _PinnedTransfer()
 
 
 def to_host(t: torch.Tensor):
-    """Device tensor -> numpy array.  Large results (the 120 MB of kNN distances, the 200 MB of connectivities at 1M
-    cells) land in PAGE-LOCKED host memory: `t.cpu()` into pageable memory goes through the runtime's bounce buffer at
-    less than half the PCIe rate.  The page-locked block comes from torch's caching host allocator (allocated once per
-    size, recycled when the array is released); the numpy array keeps it alive.  SCAMD_PINNED_DOWNLOAD=0: plain `.cpu()`."""
+    """Device tensor -> numpy array (pageable memory).  Large results (the 120 MB of kNN distances, the 200 MB of
+    connectivities at 1M cells) go through the page-locked staging pipeline of `_PinnedTransfer.download`: `t.cpu()`
+    into pageable memory uses the runtime's bounce buffer at less than half the PCIe rate.  SCAMD_PINNED_DOWNLOAD=0:
+    plain `.cpu()`."""
     if not t.is_cuda or t.numel() * t.element_size() < (8 << 20) or os.environ.get("SCAMD_PINNED_DOWNLOAD") == "0":
         return t.cpu().numpy()
-    t = t.contiguous()
-    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-    host.copy_(t, non_blocking=True)
-    torch.cuda.current_stream(t.device).synchronize()
-    return host.numpy()
+    return pinned_uploader.download(t)

@@ -395,7 +395,11 @@ constexpr int B3_DPL = 68;
 // (+146 on both terms), and on the 2 q.c term the split's own error: bf16 carries 8 significant bits (unit roundoff 2^-8), so
 // |x - hi - lo| <= 2^-16 |x| and the three dropped pieces (ql.cl, q's residual, c's residual) sum to <= 3 * 2^-16 = 768 u.
 constexpr double CERT_K_F32 = 138.0, CERT_K_B3 = 284.0, CERT_K2_B3 = 768.0;
-constexpr float B3_PAD_NORM = 1.0e38f;  // ||c||^2 of padding rows: finite (0 * inf = NaN in the cross products)
+// ||c||^2 of padding rows: finite (0 * inf = NaN in the cross products) but ABOVE KEY_BIG, the "threshold" of a list that is
+// not filled yet: the largest bf16 value (0x7F7F = 3.3895e38; one bf16 piece, the other two are 0).  With 1e38 (round 3) a pad
+// row scored below KEY_BIG, passed the sign test of an unfilled list and was inserted -- harmless (its row id is filtered in
+// pass 2) but insertion work in small cells, and exactness hung on 1e38 - 3e38 + 3e38 rounding the right way.
+constexpr float B3_PAD_NORM = 3.3895313892515355e38f;
 
 // float32 -> bf16 bits, round to nearest even (finite inputs)
 __device__ __forceinline__ unsigned int bf16_rn(float v) {
@@ -711,7 +715,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
   auto insert = [&](const f32x16& acc, float athr_used, int cbase, bool all) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const unsigned long long m = all ? __ballot(acc[r] < INFINITY) : __ballot(acc[r] < 0.f);
+      const unsigned long long m = all ? __ballot(acc[r] < KEY_BIG) : __ballot(acc[r] < 0.f);  // (all: plain scores; pad rows score >= KEY_BIG)
       if (m) {
         const unsigned int lo = (unsigned int)m, hi = (unsigned int)(m >> 32);
         if (lo) insert_half(acc, athr_used, cbase, r, 0, lo);

@@ -1996,6 +1996,15 @@ struct LeidenBuffers {
   unsigned long long* ckeys; int* cids; int* newlabel; int* minmember;
 };
 
+// class sub-rounds the SCAMD_LEIDEN_LM_CLASSES / SCAMD_LEIDEN_RF_CLASSES overrides can ask for on a level of any size
+static int classes_env(const char* name) {
+  const char* e = getenv(name);
+  const int v = e ? atoi(e) : 0;
+  return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) ? v : 0;
+}
+static int carve_classes() {
+  return std::max((int)DEF_CLASSES, std::max(classes_env("SCAMD_LEIDEN_LM_CLASSES"), classes_env("SCAMD_LEIDEN_RF_CLASSES")));
+}
 static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b) {
   const size_t N = (size_t)n, E = (size_t)std::max<int64_t>(nnz, 1);
   b->wq0 = ws.take<long long>(E);
@@ -2009,7 +2018,11 @@ static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b
   b->comm = ws.take<int>(N);
   b->csize = ws.take<int>(N);
   b->Ktot = ws.take<unsigned long long>(N);
-  b->cls_lists = ws.take<int>(MAX_CLASSES * N);  // class lists of a sweep (local moving) / of the refinement
+  // class lists of a sweep (local moving) / of the refinement: lists[c * n_level ..].  Levels above 4096 vertices use
+  // DEF_CLASSES lists unless the SCAMD_LEIDEN_*_CLASSES overrides ask for more (resolved here, so that the workspace query
+  // and the run agree); only levels of <= 4096 vertices take MAX_CLASSES refinement sub-rounds.  (Round 3 carved
+  // MAX_CLASSES x N: 1.28 GB at 10M cells for lists of which 8 were ever used)
+  b->cls_lists = ws.take<int>(std::max((size_t)carve_classes() * N, (size_t)MAX_CLASSES * std::min<size_t>(N, 4096)));
   b->rlist = ws.take<int>(N);
   b->hub_list = ws.take<int>(N);
   b->touched = ws.take<int>(N);
@@ -2629,11 +2642,6 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
   cx.inv_beta = beta > 0.0 ? 1.0 / (beta * WSCALE) : 0.0;  // beta <= 0: the greedy limit (largest gain, no "stay")
   cx.seed = (unsigned int)(seed ^ (seed >> 32)) * 0x9E3779B1u + 0x632BE5ABu;
   if (const char* e = getenv("SCAMD_LEIDEN_LM_STOP_PERMILLE")) cx.lm_stop_permille = atoi(e);
-  auto classes_env = [](const char* name) {
-    const char* e = getenv(name);
-    const int v = e ? atoi(e) : 0;
-    return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) ? v : 0;
-  };
   cx.lm_classes = classes_env("SCAMD_LEIDEN_LM_CLASSES");
   cx.rf_classes = classes_env("SCAMD_LEIDEN_RF_CLASSES");
   if (const char* e = getenv("SCAMD_LEIDEN_SMALL")) cx.small_levels = e[0] != '0';

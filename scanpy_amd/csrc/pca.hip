@@ -144,6 +144,11 @@ __global__ __launch_bounds__(64) void tr_scatter_kernel(const int64_t* __restric
 // in flight per wave, 80 % of the wave-cycles parked on s_waitcnt: profiles/r02p_pca_stage_pmc1.csv).  Now GU = 8 B rows
 // are requested back to back and consumed in the same order (the sum is bit for bit the old one), the next 64 entries
 // of the row and the next row's extent are requested before the current ones are used.
+// Round 4 tried the other mapping -- a workgroup owns 256 rows (one per thread, accumulators in registers), the rows of B
+// staged through LDS in gene tiles, bit-identical sums: 14.05 vs 14.05 ms for the PCA stage (profiles/r04f_bench_spmm_lds*.json).
+// A thread per row reads its entries 4 bytes at a time from 64 different cache lines per load instruction, and 12 waves
+// of such rows do not fit the 32 KB vector L1: the L2 traffic this kernel spends on B rows came back as CSR sectors.
+// Removed again; what would help is a row-major staging of the CSR block itself, i.e. a different storage order.
 // ------------------------------------------------------------------------------------------------
 template <int CPL>
 __global__ __launch_bounds__(256) void spmm_rows_f32_kernel(const int64_t* __restrict__ indptr,
@@ -218,96 +223,6 @@ __global__ __launch_bounds__(256) void spmm_rows_f32_kernel(const int64_t* __res
     rb = nrb;
     re = nre;
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Y = A * B - 1 shift^T for l <= 64, B staged through LDS (round 4).  The wave-per-row kernel above reads one B row
-// (l * 4 bytes) from L2 per stored entry: 1e8 entries x 256 B = 25.6 GB through L2 per 1M x 2k pass -- that, not HBM,
-// is its 2.0 ms (0.06 of the HBM roofline).  Here a workgroup owns 256 rows (one per thread, its l accumulators in
-// registers) and walks the genes in tiles of TG: the tile's B rows are staged once per workgroup (0.4 GB of L2 traffic
-// per pass in all), every thread consumes its row's entries of the tile -- the entries of a row are sorted by gene, so a
-// cursor per thread is all the bookkeeping -- reading B from LDS as NQ 16-byte pieces.  Per output the products are
-// added in CSR order with the same fmaf as above: the result is bit for bit the wave-per-row kernel's.
-// ------------------------------------------------------------------------------------------------
-template <int NQ /* 16-byte pieces per B row: l <= 4 NQ */, int TG /* genes per tile */>
-__global__ __launch_bounds__(256) void spmm_lds_f32_kernel(const int64_t* __restrict__ indptr,
-                                                          const int32_t* __restrict__ indices,
-                                                          const float* __restrict__ data, int64_t n, int64_t g,
-                                                          const float* __restrict__ b, int l,
-                                                          const float* __restrict__ shift, float* __restrict__ y) {
-  constexpr int LP = 4 * NQ;
-  using f4 = __attribute__((ext_vector_type(4))) float;
-  extern __shared__ __attribute__((aligned(16))) float bt[];  // [TG][LP]
-  const int tid = threadIdx.x;
-  const int64_t row = (int64_t)blockIdx.x * 256 + tid;
-  const bool live = row < n;
-  int64_t p = live ? indptr[row] : 0;
-  const int64_t re = live ? indptr[row + 1] : 0;
-  float acc[LP];
-#pragma unroll
-  for (int k = 0; k < LP; ++k) acc[k] = 0.f;
-  // The row's entries are requested TWO steps ahead of their use, from addresses that are always valid (past the end of
-  // the row: its last entry again -- no branch around a load, hipcc waits for every outstanding load at the first use
-  // behind a conditional one); what was read past the end is replaced by the sentinel "no entry left".
-  const int64_t last = re > 0 ? re - 1 : 0;  // (nnz > 0 whenever a row is not empty; empty matrix: never dereferenced by a live row)
-  const bool any = re > p;
-  int c0 = any ? indices[p] : 0x7fffffff, c1 = 0x7fffffff;
-  float v0 = any ? data[p] : 0.f, v1 = 0.f;
-  if (any) {
-    const int64_t p1 = p + 1 < re ? p + 1 : last;
-    const int cc = indices[p1];
-    const float vv = data[p1];
-    c1 = p + 1 < re ? cc : 0x7fffffff;
-    v1 = vv;
-  }
-  p += 2;  // position of the entry requested next
-  for (int64_t g0 = 0; g0 < g; g0 += TG) {
-    __syncthreads();  // the previous tile has been consumed
-    // stage B[g0 .. g0 + TG) (rows past g and columns past l are zero)
-    for (int e = tid; e < TG * LP; e += 256) {
-      const int r = e / LP, k = e - r * LP;
-      bt[e] = (g0 + r < g && k < l) ? b[(g0 + r) * l + k] : 0.f;
-    }
-    __syncthreads();
-    const int g1 = (int)std::min<int64_t>(g, g0 + TG);
-    while (c0 < g1) {
-      const int c = c0;
-      const float v = v0;
-      const int64_t pn = p < re ? p : last;
-      const int cn = indices[pn];  // (inside the loop the row has entries: pn is a valid position)
-      const float vn = data[pn];
-      c0 = c1;
-      v0 = v1;
-      const f4* br = reinterpret_cast<const f4*>(bt + (c - (int)g0) * LP);
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const f4 bv = br[q];
-        acc[4 * q + 0] = fmaf(v, bv.x, acc[4 * q + 0]);
-        acc[4 * q + 1] = fmaf(v, bv.y, acc[4 * q + 1]);
-        acc[4 * q + 2] = fmaf(v, bv.z, acc[4 * q + 2]);
-        acc[4 * q + 3] = fmaf(v, bv.w, acc[4 * q + 3]);
-      }
-      c1 = p < re ? cn : 0x7fffffff;
-      v1 = vn;
-      ++p;
-    }
-  }
-  if (live) {
-#pragma unroll
-    for (int k = 0; k < LP; ++k)
-      if (k < l) y[row * l + k] = acc[k] - (shift ? shift[k] : 0.f);
-  }
-}
-
-template <int NQ, int TG>
-static int launch_spmm_lds(const int64_t* indptr, const int32_t* indices, const float* data, int64_t n, int64_t g,
-                           const float* b, int l, const float* shift, float* y, hipStream_t s) {
-  auto kern = spmm_lds_f32_kernel<NQ, TG>;
-  const size_t lds = (size_t)TG * 4 * NQ * sizeof(float);
-  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(n, 256)), dim3(256), lds, s, indptr, indices, data, n, g, b, l, shift, y);
-  SCAMD_LAUNCH_CHECK();
-  return SCAMD_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -528,15 +443,6 @@ extern "C" int scamd_spmm_csr_f32(const int64_t* indptr, const int32_t* indices,
   SCAMD_REQUIRE(n >= 0 && g >= 1 && l >= 1 && l <= 128, SCAMD_EINVAL, "spmm: bad shape n=%lld g=%lld l=%d",
                 (long long)n, (long long)g, l);
   if (n == 0) return SCAMD_OK;
-  // many rows, few columns (the scores pass of the PCA): B through LDS; SCAMD_SPMM_LDS=0 keeps the wave-per-row kernel
-  {
-    const char* e = getenv("SCAMD_SPMM_LDS");
-    if (!(e && e[0] == '0') && l <= 64 && n >= 65536 && g <= 65536) {
-      if (l <= 32) return launch_spmm_lds<8, 384>(indptr, indices, data, n, g, b, l, shift, y, stream);
-      if (l <= 52) return launch_spmm_lds<13, 256>(indptr, indices, data, n, g, b, l, shift, y, stream);
-      return launch_spmm_lds<16, 192>(indptr, indices, data, n, g, b, l, shift, y, stream);
-    }
-  }
   const int blocks = (int)std::min<int64_t>((n + 3) / 4, 256 * 32);
   if (l <= 64)
     hipLaunchKernelGGL(spmm_rows_f32_kernel<1>, dim3(blocks), dim3(256), 0, stream, indptr, indices, data, n, b, l,

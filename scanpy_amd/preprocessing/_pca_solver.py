@@ -90,7 +90,7 @@ class GpuBackend:
         from .._device import pinned_uploader
 
         ip = torch.from_numpy(np.ascontiguousarray(x_csr.indptr, dtype=np.int64)).to(self.device)
-        # the two big arrays go through page-locked staging buffers at PCIe rate (see _device._PinnedUploader)
+        # the two big arrays go through page-locked staging buffers at PCIe rate (see _device._PinnedTransfer)
         ix = pinned_uploader.upload(np.ascontiguousarray(x_csr.indices, dtype=np.int32), self.device)
         dv = pinned_uploader.upload(np.ascontiguousarray(x_csr.data, dtype=np.float32), self.device)
         return (ip, ix, dv, x_csr.shape[0], x_csr.shape[1])
