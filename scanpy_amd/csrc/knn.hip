@@ -508,6 +508,7 @@ struct IvfArgs {
   const int* block_perm;     // [n_blocks] launch slot -> block: cells with the longest expected sweep first (LPT)
   int* qorder;               // [n_blocks * 128] out (may be null): query number (row - q_begin) of every query slot, -1 = padding
   int prepass_tiles;         // tiles of the own cell the threshold pre-pass scores (SCAMD_KNN_PREPASS_TILES, default 16)
+  int prepass_cells;         // cells (own cell first, then by ascending lower bound) the pre-pass covers (SCAMD_KNN_PREPASS_CELLS, default 1)
   int debug_no_insert;       // debug (SCAMD_KNN_DEBUG_NO_INSERT=1): survivors are dropped -- WRONG results, MFMA-side ceiling
   unsigned long long* trace; // debug (SCAMD_KNN_TRACE=<file>): per block {start, end (100 MHz clock), tiles swept, hw id}
   int n_cells, dc;          // dc = stride of `centers` (>= d)
@@ -866,6 +867,16 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
       const int pre_tiles = min(iv.cell_ntiles[a], iv.prepass_tiles);
       if (tid == 0) atomicAdd(iv.pairs + 1, (unsigned long long)pre_tiles * TC * C::QB);  // counted apart: not useful work
       sweep(iv.cell_tile0[a], pre_tiles, false);
+      // round 4: the pre-pass may go on over the next nearest cells (iv.prepass_cells - 1 of them, whole cells).  The sweep
+      // is bound by the instructions of the list insertions, not by the matrix pipe (counters: profiles/r04a_knn_pmc*.csv),
+      // and an insertion-free pass over more candidates starts the lists nearer their final thresholds.
+      for (int ci = 1; ci < iv.prepass_cells && ci < iv.n_cells; ++ci) {
+        if (!(lb2[ci] < INFINITY)) break;
+        const int pb = order[ci];
+        __syncthreads();
+        if (tid == 0) atomicAdd(iv.pairs + 1, (unsigned long long)iv.cell_ntiles[pb] * TC * C::QB);
+        sweep(iv.cell_tile0[pb], iv.cell_ntiles[pb], false);
+      }
       minima = false;
       __syncthreads();
 #pragma unroll
@@ -2140,6 +2151,8 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
     // float32 engine, measured at 1M: 48 -> 29.3 ms, 24 / 12 -> 29.0, 6 -> 29.6, 2 -> 30.2; bf16 engine (the pre-pass
     // costs a quarter): 8 -> 17.1, 16 -> 16.8, 32 -> 16.15, 64 -> 16.1
     iv.prepass_tiles = e ? std::max(1, atoi(e)) : (B3 ? 32 : 16);
+    const char* e2 = getenv("SCAMD_KNN_PREPASS_CELLS");
+    iv.prepass_cells = e2 ? std::max(1, atoi(e2)) : 1;
   }
   {
     const char* e = getenv("SCAMD_KNN_DEBUG_NO_INSERT");
@@ -2267,6 +2280,7 @@ static int run_ivf_tier2(const KnnPlan& p, const KnnBuffers& b, const float* x, 
   iv.block_perm = b.block_perm;
   iv.qorder = nullptr;
   iv.prepass_tiles = 16;
+  iv.prepass_cells = 1;
   iv.debug_no_insert = 0;
   iv.trace = nullptr;
   const int thr_rank = std::min(32, std::max(1, k + 6));

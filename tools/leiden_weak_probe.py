@@ -71,6 +71,9 @@ def main():
         "rf_classes=32": {"SCAMD_LEIDEN_RF_CLASSES": "32"},
         "rf_classes=1": {"SCAMD_LEIDEN_RF_CLASSES": "1"},
         "lm_stop=0": {"SCAMD_LEIDEN_LM_STOP_PERMILLE": "0"},
+        "lm_stop=2": {"SCAMD_LEIDEN_LM_STOP_PERMILLE": "2"},
+        "lm_stop=5": {"SCAMD_LEIDEN_LM_STOP_PERMILLE": "5"},
+        "lm_stop=10": {"SCAMD_LEIDEN_LM_STOP_PERMILLE": "10"},
         "lm32+rf32+stop0": {"SCAMD_LEIDEN_LM_CLASSES": "32", "SCAMD_LEIDEN_RF_CLASSES": "32", "SCAMD_LEIDEN_LM_STOP_PERMILLE": "0"},
     }
     if len(sys.argv) > 3:
