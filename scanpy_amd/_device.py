@@ -173,11 +173,27 @@ class _PinnedTransfer:
 pinned_uploader = _PinnedTransfer()
 
 
+_PINNED_RESULT_MAX = int(os.environ.get("SCAMD_PINNED_RESULT_MAX_MB", "256")) << 20
+
+
 def to_host(t: torch.Tensor):
-    """Device tensor -> numpy array (pageable memory).  Large results (the 120 MB of kNN distances, the 200 MB of
-    connectivities at 1M cells) go through the page-locked staging pipeline of `_PinnedTransfer.download`: `t.cpu()`
-    into pageable memory uses the runtime's bounce buffer at less than half the PCIe rate.  SCAMD_PINNED_DOWNLOAD=0:
-    plain `.cpu()`."""
-    if not t.is_cuda or t.numel() * t.element_size() < (8 << 20) or os.environ.get("SCAMD_PINNED_DOWNLOAD") == "0":
+    """Device tensor -> numpy array.  `t.cpu()` into pageable memory uses the runtime's bounce buffer at less than half the
+    PCIe rate, so results of 8 MB and more take one of two routes:
+    * up to SCAMD_PINNED_RESULT_MAX_MB (default 256: the 120 MB of kNN distances and the 2 x 90 MB of connectivities at
+      1M cells) they land in a PAGE-LOCKED block of torch's caching host allocator by one DMA -- the numpy array keeps the
+      block alive, which bounds what one result can pin;
+    * larger ones (10M cells: gigabytes) go through the staging pipeline of `_PinnedTransfer.download` into ordinary
+      pageable memory: nothing stays page-locked beyond the two staging buffers (the pipeline costs ~4 ms per
+      320 MB against the direct route -- first-touch page faults of the fresh array -- measured in bench.py's host-to-host
+      leg: 116.8 vs 112.5 ms).
+    SCAMD_PINNED_DOWNLOAD=0: plain `.cpu()`."""
+    nbytes = t.numel() * t.element_size()
+    if not t.is_cuda or nbytes < (8 << 20) or os.environ.get("SCAMD_PINNED_DOWNLOAD") == "0":
         return t.cpu().numpy()
+    if nbytes <= _PINNED_RESULT_MAX:
+        t = t.contiguous()
+        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        host.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+        return host.numpy()
     return pinned_uploader.download(t)
