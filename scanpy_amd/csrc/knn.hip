@@ -391,6 +391,18 @@ struct RegCfg {
   static_assert(!B3 || H == 25, "the bf16 engine is built for d <= 50");
 };
 constexpr int B3_DPL = 68;
+// Deferred insertion of the pruned sweep (round 4): survivors of the sign test are appended -- by vector code, one LDS atomic
+// and one 8-byte store per survivor lane, no scalar loop -- to a small queue per query and merged into the register lists
+// in bulk whenever a queue has grown to QUEUE_MERGE_AT entries and at the end of every cell.  The sorted insertion straight from the accumulators
+// was a chain of ~25 dependent instructions alternating between the scalar and the vector unit per survivor (~315
+// cycles, ~130 per query: 10 of the 16 ms of the 1M sweep), inside the tile loop, where the barrier of
+// every tile then made three waves wait for the fourth.
+constexpr int QUEUE_CAP = 40;          // entries per query ((score, image row): 8 bytes)
+constexpr int QUEUE_MERGE_AT = 8;      // a query with this many queued entries triggers a merge at the end of the sub-tile
+// (no query can overflow: at the start of a sub-tile's append every queue holds < QUEUE_MERGE_AT entries, a sub-tile adds
+// at most 32 to one query, QUEUE_MERGE_AT + 32 <= QUEUE_CAP)
+static_assert(QUEUE_MERGE_AT + 32 <= QUEUE_CAP, "a sub-tile must always fit the queues");
+constexpr size_t QUEUE_LDS_BYTES = (size_t)4 * (32 * 4 + 32 * QUEUE_CAP * 8);  // per workgroup: counters + entries of 4 waves x 32 queries
 // certificate factors (units of u = 2^-24), see knn_rerank_kernel.  bf16 engine: 198 accumulated terms instead of 52
 // (+146 on both terms), and on the 2 q.c term the split's own error: bf16 carries 8 significant bits (unit roundoff 2^-8), so
 // |x - hi - lo| <= 2^-16 |x| and the three dropped pieces (ql.cl, q's residual, c's residual) sum to <= 3 * 2^-16 = 768 u.
@@ -567,7 +579,7 @@ __device__ __forceinline__ f32x16 b3_chain(const i32x4 (&qh)[4], const i32x4 (&q
   return acc;
 }
 
-template <int H, int TC_, int WPS, bool IVF, bool B3 = false>
+template <int H, int TC_, int WPS, bool IVF, bool B3 = false, bool QUEUE = IVF>
 __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* __restrict__ xp, int n_tiles_all,
                                                                   int64_t n_pad, int64_t q_begin,
                                                                   int thr_rank, int* __restrict__ cand_idx,
@@ -580,6 +592,16 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int thr_lane = thr_rank - 1;
+  // deferred-insertion queues of this wave (pruned mode only; behind the two tiles and the four stop-rule words)
+  int* qcnt = nullptr;
+  uint2* qbuf = nullptr;
+  int lost = 0;  // lane q < 32: query q of this wave lost survivors to a full queue -> its threshold is withdrawn at the end
+  if constexpr (QUEUE) {
+    char* qbase = reinterpret_cast<char*>(smem) + 2 * C::TILE_BYTES + 64;
+    qcnt = reinterpret_cast<int*>(qbase) + wave * 32;
+    qbuf = reinterpret_cast<uint2*>(qbase + 4 * 32 * 4) + (size_t)wave * 32 * QUEUE_CAP;
+    if (lane < 32) qcnt[lane] = 0;
+  }
   // block id: the pruned sweep hands out its blocks longest-expected-sweep first (block_perm)
   int blk = blockIdx.x;
   if constexpr (IVF) {
@@ -688,7 +710,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
   // The row ids stay where they are (slot = low 5 key bits).  On gfx950 the f32 MFMA shares the VALU lanes, and a
   // streaming top-k list takes ~100 insertions per query at 1M rows: this path, not the filter, is what the MFMA
   // stream competes with (round 1: 16 VALU per survivor + 15 per register with a hit, 147 VALU per sub-tile in all).
-  auto insert_half = [&](const f32x16& acc, float athr_used, int cbase, const int r, const int h, unsigned int bits) {
+  auto insert_half = [&](const f32x16& acc, float athr_used, int cbase, const int r, const int h, unsigned int bits) __attribute__((always_inline)) {
     const int ih = (r & 3) + 8 * (r >> 2) + 4 * h;      // this half's query = its lane of the threshold operand
     const float tu = -readlane_f32(athr_used, ih);
     const float sc = acc[r] + tu;                        // the float32 score again (+- 1 ulp)
@@ -713,7 +735,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     const float t = readlane_f32(key[r], 32 * h + thr_lane);
     athr = __int_as_float(scamd_llvm_writelane(__float_as_int(-t), ih, __float_as_int(athr)));
   };
-  auto insert = [&](const f32x16& acc, float athr_used, int cbase, bool all) {
+  auto insert = [&](const f32x16& acc, float athr_used, int cbase, bool all) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const unsigned long long m = all ? __ballot(acc[r] < KEY_BIG) : __ballot(acc[r] < 0.f);  // (all: plain scores; pad rows score >= KEY_BIG)
@@ -725,11 +747,89 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     }
     sync_thr();
   };
+  // ---- deferred insertion (pruned mode, QUEUE) ----
+  // append: every lane with acc < 0 puts (plain score, image row) into the queue of its query.  q(r, half) is a constant
+  // per register and half, so the counter address is one of two constants; the atomic returns the entry's position.
+  auto append = [&](const f32x16& acc, float athr_used, int cbase) __attribute__((always_inline)) -> bool {
+    bool full = false;  // some queue has reached QUEUE_MERGE_AT entries: the caller merges
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool neg = acc[r] < 0.f;
+      if (__any(neg)) {
+        const int i0 = (r & 3) + 8 * (r >> 2), i1 = i0 + 4;
+        const float t0 = readlane_f32(athr_used, i0), t1 = readlane_f32(athr_used, i1);
+        const float sc = acc[r] - (half ? t1 : t0);  // athr holds -thr: score = acc + thr
+        const int qi = half ? i1 : i0;
+        int pos = 0;
+        if (neg) {
+          pos = atomicAdd(&qcnt[qi], 1);
+          if (pos < QUEUE_CAP) qbuf[qi * QUEUE_CAP + pos] = make_uint2(__float_as_uint(sc), (unsigned int)(cbase + l31));
+        }
+        full |= __any(pos >= QUEUE_MERGE_AT - 1);
+      }
+    }
+    return full;
+  };
+  // merge: the queued entries of the wave's 32 queries go into the sorted lists -- the two queries of a register side by
+  // side (lanes of half h handle query (r, h)), entry after entry; an entry that no longer beats the list's last key is
+  // dropped.  Vector code throughout: the list's last key by two readlanes, the evicted slot's row id by a compare on the
+  // lane's own slot number, the sorted insertion by DPP shift + v_med3 as in insert_half.
+  // (one register per call, the register number a compile-time constant: with the entry loop inside a `#pragma unroll`
+  // loop over the registers hipcc left that loop rolled and moved key[] / idx[] to scratch memory)
+  auto merge_reg = [&](auto rc, int cntv) __attribute__((always_inline)) {
+    constexpr int r = decltype(rc)::value;
+    constexpr int i0 = (r & 3) + 8 * (r >> 2), i1 = i0 + 4;
+    const int c0 = min(__builtin_amdgcn_readlane(cntv, i0), QUEUE_CAP), c1 = min(__builtin_amdgcn_readlane(cntv, i1), QUEUE_CAP);
+    const int cm = max(c0, c1);
+    if (cm > 0) {
+      const int myc = half ? c1 : c0;
+      const uint2* qe = qbuf + (half ? i1 : i0) * QUEUE_CAP;
+      for (int e = 0; e < cm; ++e) {
+        const uint2 ent = qe[e];
+        const float last = half ? readlane_f32(key[r], 63) : readlane_f32(key[r], 31);
+        const float v = __uint_as_float(ent.x);
+        const bool ins = e < myc && v < last;
+        const int slot = __float_as_int(last) & KEY_SLOT_MASK;
+        idx[r] = (ins && l31 == slot) ? (int)ent.y : idx[r];
+        const float kv = __int_as_float((int)(ent.x & ~(unsigned int)KEY_SLOT_MASK) | slot);
+        float upk = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(key[r]), 0x138, 0xf, 0xf, true));
+        upk = (l31 == 0) ? -INFINITY : upk;
+        const float nk = __builtin_amdgcn_fmed3f(upk, key[r], kv);
+        key[r] = ins ? nk : key[r];
+      }
+      const float t0 = readlane_f32(key[r], thr_lane), t1 = readlane_f32(key[r], 32 + thr_lane);
+      athr = __int_as_float(scamd_llvm_writelane(__float_as_int(-t0), i0, __float_as_int(athr)));
+      athr = __int_as_float(scamd_llvm_writelane(__float_as_int(-t1), i1, __float_as_int(athr)));
+    }
+  };
+  auto merge = [&]() __attribute__((always_inline)) {
+    const int cntv = lane < 32 ? qcnt[lane] : 0;
+    if (!__any(cntv > 0)) return;
+    lost |= cntv > QUEUE_CAP ? 1 : 0;
+    merge_reg(std::integral_constant<int, 0>{}, cntv);
+    merge_reg(std::integral_constant<int, 1>{}, cntv);
+    merge_reg(std::integral_constant<int, 2>{}, cntv);
+    merge_reg(std::integral_constant<int, 3>{}, cntv);
+    merge_reg(std::integral_constant<int, 4>{}, cntv);
+    merge_reg(std::integral_constant<int, 5>{}, cntv);
+    merge_reg(std::integral_constant<int, 6>{}, cntv);
+    merge_reg(std::integral_constant<int, 7>{}, cntv);
+    merge_reg(std::integral_constant<int, 8>{}, cntv);
+    merge_reg(std::integral_constant<int, 9>{}, cntv);
+    merge_reg(std::integral_constant<int, 10>{}, cntv);
+    merge_reg(std::integral_constant<int, 11>{}, cntv);
+    merge_reg(std::integral_constant<int, 12>{}, cntv);
+    merge_reg(std::integral_constant<int, 13>{}, cntv);
+    merge_reg(std::integral_constant<int, 14>{}, cntv);
+    merge_reg(std::integral_constant<int, 15>{}, cntv);
+    if (lane < 32) qcnt[lane] = 0;
+    sync_thr();
+  };
   int row0 = 0;  // image row of the current sweep's first candidate
   // One pipeline step = ONE scheduling region: chain of sub-tile g into acc_cur (with the thresholds in athr),
   // fragment reads of sub-tile g+1, sign test of the previous sub-tile's accumulator.
   auto step = [&](int g, BFrag& b_cur, f32x16& acc_cur, float& athr_cur, const f32x16& acc_prev,
-                  float athr_prev, BFrag& b_nxt) {
+                  float athr_prev, BFrag& b_nxt) __attribute__((always_inline)) {
     load_b(min(g + 1, n_sub - 1), b_nxt);  // (the clamp re-reads the last sub-tile: no branch in the region)
     athr_cur = athr;
     acc_cur = chain(b_cur, athr_cur);
@@ -758,7 +858,13 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     if constexpr (IVF) {
       if (iv.debug_no_insert) return;
     }
-    if (hit) insert(acc_prev, athr_prev, row0 + (g - 1) * 32, false);
+    if (hit) {
+      if constexpr (QUEUE) {
+        if (append(acc_prev, athr_prev, row0 + (g - 1) * 32)) merge();
+      } else {
+        insert(acc_prev, athr_prev, row0 + (g - 1) * 32, false);
+      }
+    }
   };
 
   // staging registers: every wave moves NP 1-KiB pieces per tile; out-of-range piece ids are clamped (a duplicate
@@ -780,7 +886,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
   // Sweep over `n_tiles` consecutive tiles of the image starting at tile `t0`.  first = the block's very first
   // sweep: its sub-tile 0 fills the lists (every finite score is inserted).  All four waves call it together; on
   // entry nobody reads the LDS tiles any more (the caller's barrier / kernel start guarantees it).
-  auto sweep = [&](int t0, int n_tiles, bool first) {
+  auto sweep = [&](int t0, int n_tiles, bool first) __attribute__((always_inline)) {
     tile0 = t0;
     row0 = t0 * TC;
     n_sub = n_tiles * SUBS;
@@ -826,8 +932,11 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
       if (IVF && minima) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) key[r] = fminf(key[r], accB[r]);
-      } else if (__any(neg)) {
-        insert(accB, athrB, row0 + (n_sub - 1) * 32, false);
+      } else if constexpr (QUEUE) {
+        if (__any(neg)) (void)append(accB, athrB, row0 + (n_sub - 1) * 32);
+        merge();  // the lists and thresholds are current at the end of every cell (the stop rule reads them)
+      } else {
+        if (__any(neg)) insert(accB, athrB, row0 + (n_sub - 1) * 32, false);
       }
     }
   };
@@ -855,80 +964,75 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     // exact threshold distance^2 of a query = thr (score space) + ||q||^2; per wave the max over its real queries
     // ||q||^2 sits in the extra k slot of the row's second half (B3: in the row's tail)
     const float qn = B3 ? xp[qrow * DPL + 64] : xp[qrow * DPL + HP + H];
-    // ---- pre-pass: a tight starting threshold from the own cell ----
-    // A streaming top-k list with threshold "current thr_rank-th best" inserts ~thr_rank*(1 + ln(N/thr_rank))
-    // candidates per query, most of them while the list warms up; each insertion costs ~30 VALU on the lanes the
-    // MFMA chain needs.  The pre-pass sweeps the own cell once with threshold 0 (acc = plain score) and only
-    // keeps lane-wise minima (16 v_min per sub-tile, no branches): 32 distinct candidates per query, whose
-    // thr_rank-th smallest bounds the final threshold from above (~ the 34th nearest of the cell for rank 21).
-    // The real sweep then starts with that threshold: about half as many insertions in total.
-    {
-      minima = true;
-      const int pre_tiles = min(iv.cell_ntiles[a], iv.prepass_tiles);
-      if (tid == 0) atomicAdd(iv.pairs + 1, (unsigned long long)pre_tiles * TC * C::QB);  // counted apart: not useful work
-      sweep(iv.cell_tile0[a], pre_tiles, false);
-      // round 4: the pre-pass may go on over the next nearest cells (iv.prepass_cells - 1 of them, whole cells).  The sweep
-      // is bound by the instructions of the list insertions, not by the matrix pipe (counters: profiles/r04a_knn_pmc*.csv),
-      // and an insertion-free pass over more candidates starts the lists nearer their final thresholds.
-      for (int ci = 1; ci < iv.prepass_cells && ci < iv.n_cells; ++ci) {
-        if (!(lb2[ci] < INFINITY)) break;
-        const int pb = order[ci];
-        __syncthreads();
-        if (tid == 0) atomicAdd(iv.pairs + 1, (unsigned long long)iv.cell_ntiles[pb] * TC * C::QB);
-        sweep(iv.cell_tile0[pb], iv.cell_ntiles[pb], false);
-      }
-      minima = false;
-      __syncthreads();
+    // ---- jobs of the block: the threshold pre-pass, then the cells in order of their lower bound ----
+    // Pre-pass: a streaming top-k list with threshold "current thr_rank-th best" inserts ~thr_rank*(1 + ln(N/thr_rank))
+    // candidates per query, most of them while the list warms up.  The pre-pass sweeps the own cell (its first
+    // iv.prepass_tiles tiles; and, if asked for, iv.prepass_cells - 1 further cells) with threshold 0 (acc = plain score)
+    // and only keeps lane-wise minima (16 v_min per sub-tile, no branches): 32 distinct candidates per query, whose
+    // thr_rank-th smallest bounds the final threshold from above.  The real sweep then starts with that threshold.
+    // Both kinds of sweep are jobs of ONE loop so that the sweep's code exists once (three inlined copies of it, each with
+    // the insertion code twice, had grown to 16k instructions with the deferred insertion: more than the instruction cache).
+    int n_pre = 1;
+    while (n_pre < iv.prepass_cells && n_pre < iv.n_cells && lb2[n_pre] < INFINITY) ++n_pre;
+    for (int job = 0;; ++job) {
+      const bool pre = job < n_pre;
+      const int ci = pre ? job : job - n_pre;
+      if (ci >= iv.n_cells) break;
+      if (job == n_pre) {
+        // ---- end of the pre-pass: thresholds and placeholder lists from the lane-wise minima ----
+        minima = false;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float x = key[r];
-        // bitonic sort along the 32 lanes of each half (ascending in l31)
+        for (int r = 0; r < 16; ++r) {
+          float x = key[r];
+          // bitonic sort along the 32 lanes of each half (ascending in l31)
 #pragma unroll
-        for (int kk = 2; kk <= 32; kk <<= 1) {
+          for (int kk = 2; kk <= 32; kk <<= 1) {
 #pragma unroll
-          for (int j = kk >> 1; j > 0; j >>= 1) {
-            const float y = __shfl_xor(x, j);
-            const bool up = (l31 & kk) == 0;
-            const bool lower = (l31 & j) == 0;
-            x = (lower == up) ? fminf(x, y) : fmaxf(x, y);
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+              const float y = __shfl_xor(x, j);
+              const bool up = (l31 & kk) == 0;
+              const bool lower = (l31 & j) == 0;
+              x = (lower == up) ? fminf(x, y) : fmaxf(x, y);
+            }
           }
+          const int i0 = (r & 3) + 8 * (r >> 2), i1 = i0 + 4;
+          const float t0 = readlane_f32(x, thr_lane), t1 = readlane_f32(x, 32 + thr_lane);
+          athr = (lane == i0) ? -t0 : ((lane == i1) ? -t1 : athr);
+          // the list starts out as 32 placeholders AT the pre-pass threshold (row id -1): the list's thr_rank-th entry
+          // can then never exceed that proven bound, and real entries (all below it) displace the placeholders from
+          // the top.  Slot numbers ascend with the key: l31 for a positive threshold, 31 - l31 for a negative one.
+          const int tb = __float_as_int(fminf(half ? t1 : t0, KEY_BIG));  // (never +inf: its mantissa holds the slot)
+          key[r] = __int_as_float((tb & ~KEY_SLOT_MASK) | (tb < 0 ? 31 - l31 : l31));
         }
-        const int i0 = (r & 3) + 8 * (r >> 2), i1 = i0 + 4;
-        const float t0 = readlane_f32(x, thr_lane), t1 = readlane_f32(x, 32 + thr_lane);
-        athr = (lane == i0) ? -t0 : ((lane == i1) ? -t1 : athr);
-        // the list starts out as 32 placeholders AT the pre-pass threshold (row id -1): the list's thr_rank-th entry
-        // can then never exceed that proven bound, and real entries (all below it) displace the placeholders from
-        // the top.  Slot numbers ascend with the key: l31 for a positive threshold, 31 - l31 for a negative one.
-        const int tb = __float_as_int(fminf(half ? t1 : t0, KEY_BIG));  // (never +inf: its mantissa holds the slot)
-        key[r] = __int_as_float((tb & ~KEY_SLOT_MASK) | (tb < 0 ? 31 - l31 : l31));
+        sync_thr();
       }
-      sync_thr();
-    }
-    bool first = true;
-    for (int ci = 0; ci < iv.n_cells; ++ci) {
       const float lb = lb2[ci];
-      if (!(lb < INFINITY)) break;  // empty cells sort last
-      if (ci > 0) {
-        // athr = -thr on lanes 0..31.  thr lives in score space (||c||^2 - 2 q.c), where float32 carries an absolute
-        // error of ~(d + 14) 2^-24 ||q||^2 (the rounding of ||q||^2 itself, of the sum below and of the scores the
-        // threshold was taken from); far from the origin (||q||^2 >> d^2) that exceeds the 1e-3 relative slack of
-        // the test below, so it is added per query: 1e-5 >= 142 * 2^-24 covers d <= 128
-        float dthr = (half == 0 && qvalid) ? (qn - athr) + 1e-5f * qn : -INFINITY;
+      if (!pre) {
+        if (!(lb < INFINITY)) break;  // empty cells sort last
+        if (ci > 0) {
+          // athr = -thr on lanes 0..31.  thr lives in score space (||c||^2 - 2 q.c), where float32 carries an absolute
+          // error of ~(d + 14) 2^-24 ||q||^2 (the rounding of ||q||^2 itself, of the sum below and of the scores the
+          // threshold was taken from); far from the origin (||q||^2 >> d^2) that exceeds the 1e-3 relative slack of
+          // the test below, so it is added per query: 1e-5 >= 142 * 2^-24 covers d <= 128
+          float dthr = (half == 0 && qvalid) ? (qn - athr) + 1e-5f * qn : -INFINITY;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) dthr = fmaxf(dthr, __shfl_xor(dthr, o));
-        if (lane == 0) wmax[wave] = dthr;
-        __syncthreads();
-        const float tmax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-        __syncthreads();  // wmax is rewritten at the next cell
-        // every remaining cell is at least this far: done once the bound clears every threshold (with slack for
-        // the float32 rounding of thresholds and bounds)
-        if (lb * (1.0f - 1e-3f) > tmax + 1e-3f * fabsf(tmax)) break;
+          for (int o = 32; o > 0; o >>= 1) dthr = fmaxf(dthr, __shfl_xor(dthr, o));
+          if (lane == 0) wmax[wave] = dthr;
+          __syncthreads();
+          const float tmax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+          __syncthreads();  // wmax is rewritten at the next cell
+          // every remaining cell is at least this far: done once the bound clears every threshold (with slack for
+          // the float32 rounding of thresholds and bounds)
+          if (lb * (1.0f - 1e-3f) > tmax + 1e-3f * fabsf(tmax)) break;
+        }
       }
       const int b = order[ci];
-      if (tid == 0) atomicAdd(iv.pairs, (unsigned long long)iv.cell_ntiles[b] * TC * C::QB);
-      trace_tiles += iv.cell_ntiles[b];
-      sweep(iv.cell_tile0[b], iv.cell_ntiles[b], first);
-      first = false;
+      const int nt = (pre && ci == 0) ? min(iv.cell_ntiles[b], iv.prepass_tiles) : iv.cell_ntiles[b];
+      // (pre-pass pairs are counted apart: not useful work)
+      if (tid == 0) atomicAdd(iv.pairs + (pre ? 1 : 0), (unsigned long long)nt * TC * C::QB);
+      if (!pre) trace_tiles += nt;
+      minima = pre;
+      sweep(iv.cell_tile0[b], nt, false);
       __syncthreads();  // all fragment reads of this cell are done before the next sweep restages the tiles
     }
     if (iv.trace && tid == 0) {
@@ -953,7 +1057,9 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
       // final threshold = min(list entry, pre-pass threshold): everything below it is in the list
       // (cross-lane reads before the branch on qp: the two halves of the wave may part there)
       const int i0 = (r & 3) + 8 * (r >> 2), i1 = i0 + 4;
-      const float tf0 = -readlane_f32(athr, i0), tf1 = -readlane_f32(athr, i1);
+      float tf0 = -readlane_f32(athr, i0), tf1 = -readlane_f32(athr, i1);
+      if (__builtin_amdgcn_readlane(lost, i0)) tf0 = -KEY_BIG;  // (no threshold: pass 2 cannot certify the query, it is redone exactly)
+      if (__builtin_amdgcn_readlane(lost, i1)) tf1 = -KEY_BIG;
       // pass 2 walks the queries in slot order (= cell order: neighbouring queries share their candidates' rows)
       if (iv.qorder && l31 == 0) iv.qorder[qslot] = qp >= 0 ? iv.perm[qp] - (int)q_begin : -1;
       if (qp >= 0) {
@@ -1612,6 +1718,102 @@ __global__ __launch_bounds__(256) void ivf_assign_kernel(const float* __restrict
   if (qcounts && row >= q0 && row < q1) atomicAdd(&qcounts[bi], 1);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The assignment of ALL rows on the bf16 matrix cores (round 4; d <= 50).  Any assignment of rows to cells gives a correct
+// search -- cells only steer the pruning, the radii are computed from the rows a cell actually received -- so the nearest
+// centroid may be taken from bf16 products: score(x, c) = bf16(x) . bf16(c) - |c|^2 / 2 (the half norm exact: three bf16
+// pieces in the padding dimensions, as the thresholds of the select kernel).  A wave owns 32 rows as the A operand, the
+// centroids are the B operand from an LDS table: 4 MFMAs + 48 VALU per 32 x 32 scores instead of 26 packed fmas per score
+// (ivf_assign_kernel: 1.5 ms at 1M x 512; kept for the sampled Lloyd iterations, which also accumulate the sums).
+// ------------------------------------------------------------------------------------------------
+constexpr int CENT_DPL = 36;  // dwords per centroid row in LDS: 32 of bf16 pairs + 4 (stride 36 = 4 mod 32: conflict-free b128 reads)
+__global__ void ivf_centpad_bf16_kernel(const float* __restrict__ cent, int n_cells, int n_cells_pad, int d,
+                                        unsigned int* __restrict__ centb /* [n_cells_pad][32] */) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_cells_pad * 32) return;
+  const int c = e >> 5, w = e & 31;
+  if (c >= n_cells) {  // padding centroid: can never win (score -> -1.7e38)
+    centb[e] = w == 26 ? (0xFF00u << 16) : (w == 25 ? 0x3F803F80u : 0u);  // dims 50..52 = 1, dim 53 = most negative bf16 exponent below inf
+    return;
+  }
+  float hn = 0.f;
+  for (int u = 0; u < d; ++u) hn = fmaf(cent[c * d + u], cent[c * d + u], hn);
+  centb[e] = b3_row_dword(w, d, -0.5f * hn, [&](int dim) { return cent[c * d + dim]; });
+}
+
+__global__ __launch_bounds__(256) void ivf_assign_mfma_kernel(const float* __restrict__ x, int d, int64_t ld, int64_t n,
+                                                              const unsigned int* __restrict__ centb, int n_cells_pad,
+                                                              int* __restrict__ labels, int* __restrict__ counts,
+                                                              int64_t q0, int64_t q1, int* __restrict__ qcounts) {
+  extern __shared__ __attribute__((aligned(16))) unsigned int ctab[];  // [n_cells_pad][CENT_DPL]
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = tid >> 6;
+  for (int e = tid; e < n_cells_pad * 32; e += 256) ctab[(e >> 5) * CENT_DPL + (e & 31)] = centb[e];
+  // A operand: row (l31) of this wave, dims 16 s + 8 half .. + 8 of k-step s as four bf16 pairs (hi part only)
+  const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
+  const int64_t row = std::min<int64_t>(row0 + l31, n - 1);
+  const float* xr = x + row * ld;
+  i32x4 qa[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int dim = 16 * s4 + 8 * half + 2 * j;
+      const float v0 = dim < d ? xr[dim] : 0.f, v1 = dim + 1 < d ? xr[dim + 1] : 0.f;
+      qa[s4][j] = (int)(bf16_rn(v0) | (bf16_rn(v1) << 16));
+    }
+  }
+  if (half == 0) {  // dims 50..52 (the centroid side holds 1, 1, 1): 0; dims 53..55 (the half norm's three pieces): 1
+    qa[3][1] = 0;
+    qa[3][2] = 0x3F800000;
+    qa[3][3] = 0x3F803F80;
+  }
+  __syncthreads();
+  float best[16];
+  int bg[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    best[r] = -INFINITY;
+    bg[r] = 0;
+  }
+  const int n_sub = n_cells_pad / 32;
+  for (int g = 0; g < n_sub; ++g) {
+    const i32x4* p = reinterpret_cast<const i32x4*>(ctab + (g * 32 + l31) * CENT_DPL);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qa[s4]), __builtin_bit_cast(bf16x8, p[2 * s4 + half]), acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool better = acc[r] > best[r];  // (strict: the first sub-tile wins a tie)
+      best[r] = better ? acc[r] : best[r];
+      bg[r] = better ? g : bg[r];
+    }
+  }
+  // per row (register r, half): the best of the 32 lanes' centroids (ties: the smallest centroid id)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = best[r];
+    int id = bg[r] * 32 + l31;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o);
+      const int oid = __shfl_xor(id, o);
+      const bool take = ov > v || (ov == v && oid < id);
+      v = take ? ov : v;
+      id = take ? oid : id;
+    }
+    const int64_t rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (l31 == 0 && rr < n) {
+      labels[rr] = id;
+      atomicAdd(&counts[id], 1);
+      if (qcounts && rr >= q0 && rr < q1) atomicAdd(&qcounts[id], 1);
+    }
+  }
+}
+
 __global__ void ivf_update_kernel(const long long* __restrict__ sums, const int* __restrict__ counts, int n_cells, int d,
                                   float* __restrict__ cent) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2007,9 +2209,26 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   hipLaunchKernelGGL(ivf_centpad_kernel, dim3((unsigned)ceil_div((int64_t)nc * DPA, 256)), dim3(256), 0, s, b.cent, nc, d,
                      DPA, b.centp);
   SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(assign, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, x, d, ld,
-                     (int64_t)0, (int64_t)1, n, b.centp, nc, b.labels, 0, (long long*)nullptr, counts, q_begin,
-                     q_begin + n_query, qcounts);
+  {
+    // (d <= 50: the full assignment on the bf16 matrix cores; SCAMD_KNN_ASSIGN_MFMA=0 keeps the float32 kernel)
+    const char* e = getenv("SCAMD_KNN_ASSIGN_MFMA");
+    const int ncp = (nc + 31) / 32 * 32;
+    const size_t lds_a = (size_t)ncp * CENT_DPL * sizeof(unsigned int);
+    if (H == 25 && !(e && e[0] == '0') && lds_a <= 150 * 1024) {
+      unsigned int* centb = reinterpret_cast<unsigned int*>(b.centp);  // [ncp][32] dwords <= the float table's nc x 136 floats
+      hipLaunchKernelGGL(ivf_centpad_bf16_kernel, dim3((unsigned)ceil_div((int64_t)ncp * 32, 256)), dim3(256), 0, s, b.cent, nc, ncp, d,
+                         centb);
+      SCAMD_LAUNCH_CHECK();
+      SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_assign_mfma_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+      hipLaunchKernelGGL(ivf_assign_mfma_kernel, dim3((unsigned)ceil_div(n, 128)), dim3(256), lds_a, s, x, d, ld, n, centb, ncp,
+                         b.labels, counts, q_begin, q_begin + n_query, qcounts);
+    } else {
+      hipLaunchKernelGGL(assign, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, x, d, ld,
+                         (int64_t)0, (int64_t)1, n, b.centp, nc, b.labels, 0, (long long*)nullptr, counts, q_begin,
+                         q_begin + n_query, qcounts);
+    }
+  }
   SCAMD_LAUNCH_CHECK();
   std::vector<int> h_cnt(2 * nc);
   std::vector<float> h_cent((size_t)nc * d);
@@ -2124,10 +2343,14 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   // build cut for 2 blocks per CU (no spills) -- an A/B switch until both have been measured
   const char* wps_env = getenv("SCAMD_KNN_IVF_WPS");
   // (bf16 engine: 193 VGPRs = 2 blocks per CU by default; SCAMD_KNN_IVF_WPS=3 selects the build cut for 3)
-  auto kern = B3 ? ((wps_env && atoi(wps_env) == 3) ? knn_select_reg_kernel<H, 64, 3, true, B3> : knn_select_reg_kernel<H, 64, 2, true, B3>)
-                 : ((wps_env && atoi(wps_env) == 2) ? knn_select_reg_kernel<H, 64, 2, true, false>
-                                                     : knn_select_reg_kernel<H, 64, 3, true, false>);
-  const size_t lds = C::LDS_BYTES + 64;
+  // (SCAMD_KNN_QUEUE=0: the bf16 sweep with the sorted insertion straight from the accumulators, rounds 1-3, for A/B runs)
+  const char* q_env = getenv("SCAMD_KNN_QUEUE");
+  const bool direct = q_env && q_env[0] == '0';
+  auto kern = B3 ? ((wps_env && atoi(wps_env) == 3) ? knn_select_reg_kernel<H, 64, 3, true, B3>
+                                                     : (direct ? knn_select_reg_kernel<H, 64, 2, true, B3, false> : knn_select_reg_kernel<H, 64, 2, true, B3>))
+                 : ((wps_env && atoi(wps_env) == 3) ? knn_select_reg_kernel<H, 64, 3, true, false>
+                                                     : knn_select_reg_kernel<H, 64, 2, true, false>);
+  const size_t lds = C::LDS_BYTES + 64 + QUEUE_LDS_BYTES;
   SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
   IvfArgs iv;
@@ -2259,8 +2482,8 @@ static int run_ivf_tier2(const KnnPlan& p, const KnnBuffers& b, const float* x, 
     SCAMD_LAUNCH_CHECK();
   T2_DBG(__LINE__);
   }
-  auto kern = knn_select_reg_kernel<25, 64, 3, true, false>;
-  const size_t lds = C::LDS_BYTES + 64;
+  auto kern = knn_select_reg_kernel<25, 64, 2, true, false>;  // (two blocks per CU: the queues' LDS, see QUEUE_CAP)
+  const size_t lds = C::LDS_BYTES + 64 + QUEUE_LDS_BYTES;
   SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
   IvfArgs iv;
@@ -2281,6 +2504,8 @@ static int run_ivf_tier2(const KnnPlan& p, const KnnBuffers& b, const float* x, 
   iv.qorder = nullptr;
   iv.prepass_tiles = 16;
   iv.prepass_cells = 1;
+  {
+  }
   iv.debug_no_insert = 0;
   iv.trace = nullptr;
   const int thr_rank = std::min(32, std::max(1, k + 6));
