@@ -391,18 +391,6 @@ struct RegCfg {
   static_assert(!B3 || H == 25, "the bf16 engine is built for d <= 50");
 };
 constexpr int B3_DPL = 68;
-// Deferred insertion of the pruned sweep (round 4): survivors of the sign test are appended -- by vector code, one LDS atomic
-// and one 8-byte store per survivor lane, no scalar loop -- to a small queue per query and merged into the register lists
-// in bulk whenever a queue has grown to QUEUE_MERGE_AT entries and at the end of every cell.  The sorted insertion straight from the accumulators
-// was a chain of ~25 dependent instructions alternating between the scalar and the vector unit per survivor (~315
-// cycles, ~130 per query: 10 of the 16 ms of the 1M sweep), inside the tile loop, where the barrier of
-// every tile then made three waves wait for the fourth.
-constexpr int QUEUE_CAP = 40;          // entries per query ((score, image row): 8 bytes)
-constexpr int QUEUE_MERGE_AT = 8;      // a query with this many queued entries triggers a merge at the end of the sub-tile
-// (no query can overflow: at the start of a sub-tile's append every queue holds < QUEUE_MERGE_AT entries, a sub-tile adds
-// at most 32 to one query, QUEUE_MERGE_AT + 32 <= QUEUE_CAP)
-static_assert(QUEUE_MERGE_AT + 32 <= QUEUE_CAP, "a sub-tile must always fit the queues");
-constexpr size_t QUEUE_LDS_BYTES = (size_t)4 * (32 * 4 + 32 * QUEUE_CAP * 8);  // per workgroup: counters + entries of 4 waves x 32 queries
 // certificate factors (units of u = 2^-24), see knn_rerank_kernel.  bf16 engine: 198 accumulated terms instead of 52
 // (+146 on both terms), and on the 2 q.c term the split's own error: bf16 carries 8 significant bits (unit roundoff 2^-8), so
 // |x - hi - lo| <= 2^-16 |x| and the three dropped pieces (ql.cl, q's residual, c's residual) sum to <= 3 * 2^-16 = 768 u.
@@ -579,7 +567,7 @@ __device__ __forceinline__ f32x16 b3_chain(const i32x4 (&qh)[4], const i32x4 (&q
   return acc;
 }
 
-template <int H, int TC_, int WPS, bool IVF, bool B3 = false, bool QUEUE = IVF>
+template <int H, int TC_, int WPS, bool IVF, bool B3 = false>
 __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* __restrict__ xp, int n_tiles_all,
                                                                   int64_t n_pad, int64_t q_begin,
                                                                   int thr_rank, int* __restrict__ cand_idx,
@@ -592,16 +580,6 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int thr_lane = thr_rank - 1;
-  // deferred-insertion queues of this wave (pruned mode only; behind the two tiles and the four stop-rule words)
-  int* qcnt = nullptr;
-  uint2* qbuf = nullptr;
-  int lost = 0;  // lane q < 32: query q of this wave lost survivors to a full queue -> its threshold is withdrawn at the end
-  if constexpr (QUEUE) {
-    char* qbase = reinterpret_cast<char*>(smem) + 2 * C::TILE_BYTES + 64;
-    qcnt = reinterpret_cast<int*>(qbase) + wave * 32;
-    qbuf = reinterpret_cast<uint2*>(qbase + 4 * 32 * 4) + (size_t)wave * 32 * QUEUE_CAP;
-    if (lane < 32) qcnt[lane] = 0;
-  }
   // block id: the pruned sweep hands out its blocks longest-expected-sweep first (block_perm)
   int blk = blockIdx.x;
   if constexpr (IVF) {
@@ -710,7 +688,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
   // The row ids stay where they are (slot = low 5 key bits).  On gfx950 the f32 MFMA shares the VALU lanes, and a
   // streaming top-k list takes ~100 insertions per query at 1M rows: this path, not the filter, is what the MFMA
   // stream competes with (round 1: 16 VALU per survivor + 15 per register with a hit, 147 VALU per sub-tile in all).
-  auto insert_half = [&](const f32x16& acc, float athr_used, int cbase, const int r, const int h, unsigned int bits) __attribute__((always_inline)) {
+  auto insert_half = [&](const f32x16& acc, float athr_used, int cbase, const int r, const int h, unsigned int bits) {
     const int ih = (r & 3) + 8 * (r >> 2) + 4 * h;      // this half's query = its lane of the threshold operand
     const float tu = -readlane_f32(athr_used, ih);
     const float sc = acc[r] + tu;                        // the float32 score again (+- 1 ulp)
@@ -735,7 +713,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     const float t = readlane_f32(key[r], 32 * h + thr_lane);
     athr = __int_as_float(scamd_llvm_writelane(__float_as_int(-t), ih, __float_as_int(athr)));
   };
-  auto insert = [&](const f32x16& acc, float athr_used, int cbase, bool all) __attribute__((always_inline)) {
+  auto insert = [&](const f32x16& acc, float athr_used, int cbase, bool all) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const unsigned long long m = all ? __ballot(acc[r] < KEY_BIG) : __ballot(acc[r] < 0.f);  // (all: plain scores; pad rows score >= KEY_BIG)
@@ -747,89 +725,11 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     }
     sync_thr();
   };
-  // ---- deferred insertion (pruned mode, QUEUE) ----
-  // append: every lane with acc < 0 puts (plain score, image row) into the queue of its query.  q(r, half) is a constant
-  // per register and half, so the counter address is one of two constants; the atomic returns the entry's position.
-  auto append = [&](const f32x16& acc, float athr_used, int cbase) __attribute__((always_inline)) -> bool {
-    bool full = false;  // some queue has reached QUEUE_MERGE_AT entries: the caller merges
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const bool neg = acc[r] < 0.f;
-      if (__any(neg)) {
-        const int i0 = (r & 3) + 8 * (r >> 2), i1 = i0 + 4;
-        const float t0 = readlane_f32(athr_used, i0), t1 = readlane_f32(athr_used, i1);
-        const float sc = acc[r] - (half ? t1 : t0);  // athr holds -thr: score = acc + thr
-        const int qi = half ? i1 : i0;
-        int pos = 0;
-        if (neg) {
-          pos = atomicAdd(&qcnt[qi], 1);
-          if (pos < QUEUE_CAP) qbuf[qi * QUEUE_CAP + pos] = make_uint2(__float_as_uint(sc), (unsigned int)(cbase + l31));
-        }
-        full |= __any(pos >= QUEUE_MERGE_AT - 1);
-      }
-    }
-    return full;
-  };
-  // merge: the queued entries of the wave's 32 queries go into the sorted lists -- the two queries of a register side by
-  // side (lanes of half h handle query (r, h)), entry after entry; an entry that no longer beats the list's last key is
-  // dropped.  Vector code throughout: the list's last key by two readlanes, the evicted slot's row id by a compare on the
-  // lane's own slot number, the sorted insertion by DPP shift + v_med3 as in insert_half.
-  // (one register per call, the register number a compile-time constant: with the entry loop inside a `#pragma unroll`
-  // loop over the registers hipcc left that loop rolled and moved key[] / idx[] to scratch memory)
-  auto merge_reg = [&](auto rc, int cntv) __attribute__((always_inline)) {
-    constexpr int r = decltype(rc)::value;
-    constexpr int i0 = (r & 3) + 8 * (r >> 2), i1 = i0 + 4;
-    const int c0 = min(__builtin_amdgcn_readlane(cntv, i0), QUEUE_CAP), c1 = min(__builtin_amdgcn_readlane(cntv, i1), QUEUE_CAP);
-    const int cm = max(c0, c1);
-    if (cm > 0) {
-      const int myc = half ? c1 : c0;
-      const uint2* qe = qbuf + (half ? i1 : i0) * QUEUE_CAP;
-      for (int e = 0; e < cm; ++e) {
-        const uint2 ent = qe[e];
-        const float last = half ? readlane_f32(key[r], 63) : readlane_f32(key[r], 31);
-        const float v = __uint_as_float(ent.x);
-        const bool ins = e < myc && v < last;
-        const int slot = __float_as_int(last) & KEY_SLOT_MASK;
-        idx[r] = (ins && l31 == slot) ? (int)ent.y : idx[r];
-        const float kv = __int_as_float((int)(ent.x & ~(unsigned int)KEY_SLOT_MASK) | slot);
-        float upk = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(key[r]), 0x138, 0xf, 0xf, true));
-        upk = (l31 == 0) ? -INFINITY : upk;
-        const float nk = __builtin_amdgcn_fmed3f(upk, key[r], kv);
-        key[r] = ins ? nk : key[r];
-      }
-      const float t0 = readlane_f32(key[r], thr_lane), t1 = readlane_f32(key[r], 32 + thr_lane);
-      athr = __int_as_float(scamd_llvm_writelane(__float_as_int(-t0), i0, __float_as_int(athr)));
-      athr = __int_as_float(scamd_llvm_writelane(__float_as_int(-t1), i1, __float_as_int(athr)));
-    }
-  };
-  auto merge = [&]() __attribute__((always_inline)) {
-    const int cntv = lane < 32 ? qcnt[lane] : 0;
-    if (!__any(cntv > 0)) return;
-    lost |= cntv > QUEUE_CAP ? 1 : 0;
-    merge_reg(std::integral_constant<int, 0>{}, cntv);
-    merge_reg(std::integral_constant<int, 1>{}, cntv);
-    merge_reg(std::integral_constant<int, 2>{}, cntv);
-    merge_reg(std::integral_constant<int, 3>{}, cntv);
-    merge_reg(std::integral_constant<int, 4>{}, cntv);
-    merge_reg(std::integral_constant<int, 5>{}, cntv);
-    merge_reg(std::integral_constant<int, 6>{}, cntv);
-    merge_reg(std::integral_constant<int, 7>{}, cntv);
-    merge_reg(std::integral_constant<int, 8>{}, cntv);
-    merge_reg(std::integral_constant<int, 9>{}, cntv);
-    merge_reg(std::integral_constant<int, 10>{}, cntv);
-    merge_reg(std::integral_constant<int, 11>{}, cntv);
-    merge_reg(std::integral_constant<int, 12>{}, cntv);
-    merge_reg(std::integral_constant<int, 13>{}, cntv);
-    merge_reg(std::integral_constant<int, 14>{}, cntv);
-    merge_reg(std::integral_constant<int, 15>{}, cntv);
-    if (lane < 32) qcnt[lane] = 0;
-    sync_thr();
-  };
   int row0 = 0;  // image row of the current sweep's first candidate
   // One pipeline step = ONE scheduling region: chain of sub-tile g into acc_cur (with the thresholds in athr),
   // fragment reads of sub-tile g+1, sign test of the previous sub-tile's accumulator.
   auto step = [&](int g, BFrag& b_cur, f32x16& acc_cur, float& athr_cur, const f32x16& acc_prev,
-                  float athr_prev, BFrag& b_nxt) __attribute__((always_inline)) {
+                  float athr_prev, BFrag& b_nxt) {
     load_b(min(g + 1, n_sub - 1), b_nxt);  // (the clamp re-reads the last sub-tile: no branch in the region)
     athr_cur = athr;
     acc_cur = chain(b_cur, athr_cur);
@@ -858,13 +758,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     if constexpr (IVF) {
       if (iv.debug_no_insert) return;
     }
-    if (hit) {
-      if constexpr (QUEUE) {
-        if (append(acc_prev, athr_prev, row0 + (g - 1) * 32)) merge();
-      } else {
-        insert(acc_prev, athr_prev, row0 + (g - 1) * 32, false);
-      }
-    }
+    if (hit) insert(acc_prev, athr_prev, row0 + (g - 1) * 32, false);
   };
 
   // staging registers: every wave moves NP 1-KiB pieces per tile; out-of-range piece ids are clamped (a duplicate
@@ -886,7 +780,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
   // Sweep over `n_tiles` consecutive tiles of the image starting at tile `t0`.  first = the block's very first
   // sweep: its sub-tile 0 fills the lists (every finite score is inserted).  All four waves call it together; on
   // entry nobody reads the LDS tiles any more (the caller's barrier / kernel start guarantees it).
-  auto sweep = [&](int t0, int n_tiles, bool first) __attribute__((always_inline)) {
+  auto sweep = [&](int t0, int n_tiles, bool first) {
     tile0 = t0;
     row0 = t0 * TC;
     n_sub = n_tiles * SUBS;
@@ -932,11 +826,8 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
       if (IVF && minima) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) key[r] = fminf(key[r], accB[r]);
-      } else if constexpr (QUEUE) {
-        if (__any(neg)) (void)append(accB, athrB, row0 + (n_sub - 1) * 32);
-        merge();  // the lists and thresholds are current at the end of every cell (the stop rule reads them)
-      } else {
-        if (__any(neg)) insert(accB, athrB, row0 + (n_sub - 1) * 32, false);
+      } else if (__any(neg)) {
+        insert(accB, athrB, row0 + (n_sub - 1) * 32, false);
       }
     }
   };
@@ -964,75 +855,80 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     // exact threshold distance^2 of a query = thr (score space) + ||q||^2; per wave the max over its real queries
     // ||q||^2 sits in the extra k slot of the row's second half (B3: in the row's tail)
     const float qn = B3 ? xp[qrow * DPL + 64] : xp[qrow * DPL + HP + H];
-    // ---- jobs of the block: the threshold pre-pass, then the cells in order of their lower bound ----
-    // Pre-pass: a streaming top-k list with threshold "current thr_rank-th best" inserts ~thr_rank*(1 + ln(N/thr_rank))
-    // candidates per query, most of them while the list warms up.  The pre-pass sweeps the own cell (its first
-    // iv.prepass_tiles tiles; and, if asked for, iv.prepass_cells - 1 further cells) with threshold 0 (acc = plain score)
-    // and only keeps lane-wise minima (16 v_min per sub-tile, no branches): 32 distinct candidates per query, whose
-    // thr_rank-th smallest bounds the final threshold from above.  The real sweep then starts with that threshold.
-    // Both kinds of sweep are jobs of ONE loop so that the sweep's code exists once (three inlined copies of it, each with
-    // the insertion code twice, had grown to 16k instructions with the deferred insertion: more than the instruction cache).
-    int n_pre = 1;
-    while (n_pre < iv.prepass_cells && n_pre < iv.n_cells && lb2[n_pre] < INFINITY) ++n_pre;
-    for (int job = 0;; ++job) {
-      const bool pre = job < n_pre;
-      const int ci = pre ? job : job - n_pre;
-      if (ci >= iv.n_cells) break;
-      if (job == n_pre) {
-        // ---- end of the pre-pass: thresholds and placeholder lists from the lane-wise minima ----
-        minima = false;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float x = key[r];
-          // bitonic sort along the 32 lanes of each half (ascending in l31)
-#pragma unroll
-          for (int kk = 2; kk <= 32; kk <<= 1) {
-#pragma unroll
-            for (int j = kk >> 1; j > 0; j >>= 1) {
-              const float y = __shfl_xor(x, j);
-              const bool up = (l31 & kk) == 0;
-              const bool lower = (l31 & j) == 0;
-              x = (lower == up) ? fminf(x, y) : fmaxf(x, y);
-            }
-          }
-          const int i0 = (r & 3) + 8 * (r >> 2), i1 = i0 + 4;
-          const float t0 = readlane_f32(x, thr_lane), t1 = readlane_f32(x, 32 + thr_lane);
-          athr = (lane == i0) ? -t0 : ((lane == i1) ? -t1 : athr);
-          // the list starts out as 32 placeholders AT the pre-pass threshold (row id -1): the list's thr_rank-th entry
-          // can then never exceed that proven bound, and real entries (all below it) displace the placeholders from
-          // the top.  Slot numbers ascend with the key: l31 for a positive threshold, 31 - l31 for a negative one.
-          const int tb = __float_as_int(fminf(half ? t1 : t0, KEY_BIG));  // (never +inf: its mantissa holds the slot)
-          key[r] = __int_as_float((tb & ~KEY_SLOT_MASK) | (tb < 0 ? 31 - l31 : l31));
-        }
-        sync_thr();
+    // ---- pre-pass: a tight starting threshold from the own cell ----
+    // A streaming top-k list with threshold "current thr_rank-th best" inserts ~thr_rank*(1 + ln(N/thr_rank))
+    // candidates per query, most of them while the list warms up; each insertion costs ~30 VALU on the lanes the
+    // MFMA chain needs.  The pre-pass sweeps the own cell once with threshold 0 (acc = plain score) and only
+    // keeps lane-wise minima (16 v_min per sub-tile, no branches): 32 distinct candidates per query, whose
+    // thr_rank-th smallest bounds the final threshold from above (~ the 34th nearest of the cell for rank 21).
+    // The real sweep then starts with that threshold: about half as many insertions in total.
+    {
+      minima = true;
+      const int pre_tiles = min(iv.cell_ntiles[a], iv.prepass_tiles);
+      if (tid == 0) atomicAdd(iv.pairs + 1, (unsigned long long)pre_tiles * TC * C::QB);  // counted apart: not useful work
+      sweep(iv.cell_tile0[a], pre_tiles, false);
+      // round 4: the pre-pass may go on over the next nearest cells (iv.prepass_cells - 1 of them, whole cells).  The sweep
+      // is bound by the instructions of the list insertions, not by the matrix pipe (counters: profiles/r04a_knn_pmc*.csv),
+      // and an insertion-free pass over more candidates starts the lists nearer their final thresholds.
+      for (int ci = 1; ci < iv.prepass_cells && ci < iv.n_cells; ++ci) {
+        if (!(lb2[ci] < INFINITY)) break;
+        const int pb = order[ci];
+        __syncthreads();
+        if (tid == 0) atomicAdd(iv.pairs + 1, (unsigned long long)iv.cell_ntiles[pb] * TC * C::QB);
+        sweep(iv.cell_tile0[pb], iv.cell_ntiles[pb], false);
       }
-      const float lb = lb2[ci];
-      if (!pre) {
-        if (!(lb < INFINITY)) break;  // empty cells sort last
-        if (ci > 0) {
-          // athr = -thr on lanes 0..31.  thr lives in score space (||c||^2 - 2 q.c), where float32 carries an absolute
-          // error of ~(d + 14) 2^-24 ||q||^2 (the rounding of ||q||^2 itself, of the sum below and of the scores the
-          // threshold was taken from); far from the origin (||q||^2 >> d^2) that exceeds the 1e-3 relative slack of
-          // the test below, so it is added per query: 1e-5 >= 142 * 2^-24 covers d <= 128
-          float dthr = (half == 0 && qvalid) ? (qn - athr) + 1e-5f * qn : -INFINITY;
+      minima = false;
+      __syncthreads();
 #pragma unroll
-          for (int o = 32; o > 0; o >>= 1) dthr = fmaxf(dthr, __shfl_xor(dthr, o));
-          if (lane == 0) wmax[wave] = dthr;
-          __syncthreads();
-          const float tmax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-          __syncthreads();  // wmax is rewritten at the next cell
-          // every remaining cell is at least this far: done once the bound clears every threshold (with slack for
-          // the float32 rounding of thresholds and bounds)
-          if (lb * (1.0f - 1e-3f) > tmax + 1e-3f * fabsf(tmax)) break;
+      for (int r = 0; r < 16; ++r) {
+        float x = key[r];
+        // bitonic sort along the 32 lanes of each half (ascending in l31)
+#pragma unroll
+        for (int kk = 2; kk <= 32; kk <<= 1) {
+#pragma unroll
+          for (int j = kk >> 1; j > 0; j >>= 1) {
+            const float y = __shfl_xor(x, j);
+            const bool up = (l31 & kk) == 0;
+            const bool lower = (l31 & j) == 0;
+            x = (lower == up) ? fminf(x, y) : fmaxf(x, y);
+          }
         }
+        const int i0 = (r & 3) + 8 * (r >> 2), i1 = i0 + 4;
+        const float t0 = readlane_f32(x, thr_lane), t1 = readlane_f32(x, 32 + thr_lane);
+        athr = (lane == i0) ? -t0 : ((lane == i1) ? -t1 : athr);
+        // the list starts out as 32 placeholders AT the pre-pass threshold (row id -1): the list's thr_rank-th entry
+        // can then never exceed that proven bound, and real entries (all below it) displace the placeholders from
+        // the top.  Slot numbers ascend with the key: l31 for a positive threshold, 31 - l31 for a negative one.
+        const int tb = __float_as_int(fminf(half ? t1 : t0, KEY_BIG));  // (never +inf: its mantissa holds the slot)
+        key[r] = __int_as_float((tb & ~KEY_SLOT_MASK) | (tb < 0 ? 31 - l31 : l31));
+      }
+      sync_thr();
+    }
+    bool first = true;
+    for (int ci = 0; ci < iv.n_cells; ++ci) {
+      const float lb = lb2[ci];
+      if (!(lb < INFINITY)) break;  // empty cells sort last
+      if (ci > 0) {
+        // athr = -thr on lanes 0..31.  thr lives in score space (||c||^2 - 2 q.c), where float32 carries an absolute
+        // error of ~(d + 14) 2^-24 ||q||^2 (the rounding of ||q||^2 itself, of the sum below and of the scores the
+        // threshold was taken from); far from the origin (||q||^2 >> d^2) that exceeds the 1e-3 relative slack of
+        // the test below, so it is added per query: 1e-5 >= 142 * 2^-24 covers d <= 128
+        float dthr = (half == 0 && qvalid) ? (qn - athr) + 1e-5f * qn : -INFINITY;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dthr = fmaxf(dthr, __shfl_xor(dthr, o));
+        if (lane == 0) wmax[wave] = dthr;
+        __syncthreads();
+        const float tmax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        __syncthreads();  // wmax is rewritten at the next cell
+        // every remaining cell is at least this far: done once the bound clears every threshold (with slack for
+        // the float32 rounding of thresholds and bounds)
+        if (lb * (1.0f - 1e-3f) > tmax + 1e-3f * fabsf(tmax)) break;
       }
       const int b = order[ci];
-      const int nt = (pre && ci == 0) ? min(iv.cell_ntiles[b], iv.prepass_tiles) : iv.cell_ntiles[b];
-      // (pre-pass pairs are counted apart: not useful work)
-      if (tid == 0) atomicAdd(iv.pairs + (pre ? 1 : 0), (unsigned long long)nt * TC * C::QB);
-      if (!pre) trace_tiles += nt;
-      minima = pre;
-      sweep(iv.cell_tile0[b], nt, false);
+      if (tid == 0) atomicAdd(iv.pairs, (unsigned long long)iv.cell_ntiles[b] * TC * C::QB);
+      trace_tiles += iv.cell_ntiles[b];
+      sweep(iv.cell_tile0[b], iv.cell_ntiles[b], first);
+      first = false;
       __syncthreads();  // all fragment reads of this cell are done before the next sweep restages the tiles
     }
     if (iv.trace && tid == 0) {
@@ -1057,9 +953,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
       // final threshold = min(list entry, pre-pass threshold): everything below it is in the list
       // (cross-lane reads before the branch on qp: the two halves of the wave may part there)
       const int i0 = (r & 3) + 8 * (r >> 2), i1 = i0 + 4;
-      float tf0 = -readlane_f32(athr, i0), tf1 = -readlane_f32(athr, i1);
-      if (__builtin_amdgcn_readlane(lost, i0)) tf0 = -KEY_BIG;  // (no threshold: pass 2 cannot certify the query, it is redone exactly)
-      if (__builtin_amdgcn_readlane(lost, i1)) tf1 = -KEY_BIG;
+      const float tf0 = -readlane_f32(athr, i0), tf1 = -readlane_f32(athr, i1);
       // pass 2 walks the queries in slot order (= cell order: neighbouring queries share their candidates' rows)
       if (iv.qorder && l31 == 0) iv.qorder[qslot] = qp >= 0 ? iv.perm[qp] - (int)q_begin : -1;
       if (qp >= 0) {
@@ -1741,77 +1635,101 @@ __global__ void ivf_centpad_bf16_kernel(const float* __restrict__ cent, int n_ce
   centb[e] = b3_row_dword(w, d, -0.5f * hn, [&](int dim) { return cent[c * d + dim]; });
 }
 
-__global__ __launch_bounds__(256) void ivf_assign_mfma_kernel(const float* __restrict__ x, int d, int64_t ld, int64_t n,
+// rows j = 0 .. count-1 are x[start + j * step]; labels[j] = the row's cell.  A workgroup stages the centroid table once
+// and assigns ASSIGN_ROWS rows (a first version staged it per 128 rows: 0.73 ms at 1M x 512, slower than the float32
+// kernel's 0.67 -- the 74 KB table load was the kernel).
+constexpr int ASSIGN_ROWS = 512;
+__global__ __launch_bounds__(256) void ivf_assign_mfma_kernel(const float* __restrict__ x, int d, int64_t ld, int64_t start,
+                                                              int64_t step, int64_t count,
                                                               const unsigned int* __restrict__ centb, int n_cells_pad,
                                                               int* __restrict__ labels, int* __restrict__ counts,
                                                               int64_t q0, int64_t q1, int* __restrict__ qcounts) {
   extern __shared__ __attribute__((aligned(16))) unsigned int ctab[];  // [n_cells_pad][CENT_DPL]
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave = tid >> 6;
-  for (int e = tid; e < n_cells_pad * 32; e += 256) ctab[(e >> 5) * CENT_DPL + (e & 31)] = centb[e];
-  // A operand: row (l31) of this wave, dims 16 s + 8 half .. + 8 of k-step s as four bf16 pairs (hi part only)
-  const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
-  const int64_t row = std::min<int64_t>(row0 + l31, n - 1);
-  const float* xr = x + row * ld;
-  i32x4 qa[4];
-#pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int dim = 16 * s4 + 8 * half + 2 * j;
-      const float v0 = dim < d ? xr[dim] : 0.f, v1 = dim + 1 < d ? xr[dim + 1] : 0.f;
-      qa[s4][j] = (int)(bf16_rn(v0) | (bf16_rn(v1) << 16));
-    }
-  }
-  if (half == 0) {  // dims 50..52 (the centroid side holds 1, 1, 1): 0; dims 53..55 (the half norm's three pieces): 1
-    qa[3][1] = 0;
-    qa[3][2] = 0x3F800000;
-    qa[3][3] = 0x3F803F80;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(centb);
+    uint4* dst = reinterpret_cast<uint4*>(ctab);
+    for (int e = tid; e < n_cells_pad * 8; e += 256) dst[(e >> 3) * (CENT_DPL / 4) + (e & 7)] = src[e];
   }
   __syncthreads();
-  float best[16];
-  int bg[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    best[r] = -INFINITY;
-    bg[r] = 0;
-  }
   const int n_sub = n_cells_pad / 32;
-  for (int g = 0; g < n_sub; ++g) {
-    const i32x4* p = reinterpret_cast<const i32x4*>(ctab + (g * 32 + l31) * CENT_DPL);
-    f32x16 acc;
+  for (int grp = 0; grp < ASSIGN_ROWS / 128; ++grp) {
+    // A operand: row (l31) of this wave, dims 16 s + 8 half .. + 8 of k-step s as four bf16 pairs (hi part only)
+    const int64_t j0 = (int64_t)blockIdx.x * ASSIGN_ROWS + grp * 128 + wave * 32;
+    if (j0 >= count) break;  // (whole wave)
+    const int64_t jr = std::min<int64_t>(j0 + l31, count - 1);
+    const float* xr = x + (start + jr * step) * ld;
+    i32x4 qa[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4)
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qa[s4]), __builtin_bit_cast(bf16x8, p[2 * s4 + half]), acc, 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        const int dim = 16 * s4 + 8 * half + 2 * j;
+        const float v0 = dim < d ? xr[dim] : 0.f, v1 = dim + 1 < d ? xr[dim + 1] : 0.f;
+        qa[s4][j] = (int)(bf16_rn(v0) | (bf16_rn(v1) << 16));
+      }
+    }
+    if (half == 0) {  // dims 50..52 (the centroid side holds 1, 1, 1): 0; dims 53..55 (the half norm's three pieces): 1
+      qa[3][1] = 0;
+      qa[3][2] = 0x3F800000;
+      qa[3][3] = 0x3F803F80;
+    }
+    float best[16];
+    int bg[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const bool better = acc[r] > best[r];  // (strict: the first sub-tile wins a tie)
-      best[r] = better ? acc[r] : best[r];
-      bg[r] = better ? g : bg[r];
+      best[r] = -INFINITY;
+      bg[r] = 0;
+    }
+    for (int g = 0; g < n_sub; ++g) {
+      const i32x4* p = reinterpret_cast<const i32x4*>(ctab + (g * 32 + l31) * CENT_DPL);
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qa[s4]), __builtin_bit_cast(bf16x8, p[2 * s4 + half]), acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool better = acc[r] > best[r];  // (strict: the first sub-tile wins a tie)
+        best[r] = better ? acc[r] : best[r];
+        bg[r] = better ? g : bg[r];
+      }
+    }
+    // per row (register r, half): the best of the 32 lanes' centroids (ties: the smallest centroid id)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = best[r];
+      int id = bg[r] * 32 + l31;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o);
+        const int oid = __shfl_xor(id, o);
+        const bool take = ov > v || (ov == v && oid < id);
+        v = take ? ov : v;
+        id = take ? oid : id;
+      }
+      const int64_t jj = j0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (l31 == 0 && jj < count) {
+        const int64_t row = start + jj * step;
+        labels[jj] = id;
+        atomicAdd(&counts[id], 1);
+        if (qcounts && row >= q0 && row < q1) atomicAdd(&qcounts[id], 1);
+      }
     }
   }
-  // per row (register r, half): the best of the 32 lanes' centroids (ties: the smallest centroid id)
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float v = best[r];
-    int id = bg[r] * 32 + l31;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(v, o);
-      const int oid = __shfl_xor(id, o);
-      const bool take = ov > v || (ov == v && oid < id);
-      v = take ? ov : v;
-      id = take ? oid : id;
-    }
-    const int64_t rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (l31 == 0 && rr < n) {
-      labels[rr] = id;
-      atomicAdd(&counts[id], 1);
-      if (qcounts && rr >= q0 && rr < q1) atomicAdd(&qcounts[id], 1);
-    }
-  }
+}
+
+// fixed-point coordinate sums of the Lloyd update from the labels of the sampled rows (order-independent atomics)
+__global__ void ivf_sums_kernel(const float* __restrict__ x, int d, int64_t ld, int64_t start, int64_t step, int64_t count,
+                                const int* __restrict__ labels, long long* __restrict__ sums) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= count * d) return;
+  const int64_t j = e / d;
+  const int t = (int)(e - j * d);
+  atomicAdd(reinterpret_cast<unsigned long long*>(&sums[(int64_t)labels[j] * d + t]),
+            (unsigned long long)llrint((double)x[(start + j * step) * ld + t] * IVF_FIX));
 }
 
 __global__ void ivf_update_kernel(const long long* __restrict__ sums, const int* __restrict__ counts, int n_cells, int d,
@@ -2186,6 +2104,45 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   // 1. quantiser: Lloyd on a strided sample
   auto assign = ivf_assign_kernel<H>;
   constexpr int DPA = (2 * H + 1 + 3) / 4 * 4;  // row length of the padded centroid table (ivf_assign_kernel)
+  // d <= 50: the assignments run on the bf16 matrix cores (any assignment gives a correct search; SCAMD_KNN_ASSIGN_MFMA=0
+  // keeps the float32 kernel, which at 32768 sampled rows x 512 centroids was 0.34 ms per Lloyd iteration -- a grid of
+  // 128 workgroups each looping over all centroids)
+  const int ncp = (nc + 31) / 32 * 32;
+  const size_t lds_a = (size_t)ncp * CENT_DPL * sizeof(unsigned int);
+  bool mfma_assign = false;
+  {
+    const char* e = getenv("SCAMD_KNN_ASSIGN_MFMA");
+    mfma_assign = H == 25 && !(e && e[0] == '0') && lds_a <= 150 * 1024;
+  }
+  unsigned int* centb = reinterpret_cast<unsigned int*>(b.centp);  // [ncp][32] dwords <= the float table's nc x 136 floats
+  if (mfma_assign)
+    SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_assign_mfma_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+  auto run_assign = [&](int64_t a_start, int64_t a_step, int64_t a_count, int accumulate, int64_t aq0, int64_t aq1,
+                        int* a_qcounts) -> int {
+    if (mfma_assign) {
+      hipLaunchKernelGGL(ivf_centpad_bf16_kernel, dim3((unsigned)ceil_div((int64_t)ncp * 32, 256)), dim3(256), 0, s, b.cent, nc, ncp, d,
+                         centb);
+      SCAMD_LAUNCH_CHECK();
+      hipLaunchKernelGGL(ivf_assign_mfma_kernel, dim3((unsigned)ceil_div(a_count, ASSIGN_ROWS)), dim3(256), lds_a, s, x, d, ld, a_start,
+                         a_step, a_count, centb, ncp, b.labels, counts, aq0, aq1, a_qcounts);
+      SCAMD_LAUNCH_CHECK();
+      if (accumulate) {
+        hipLaunchKernelGGL(ivf_sums_kernel, dim3((unsigned)ceil_div(a_count * d, 256)), dim3(256), 0, s, x, d, ld, a_start, a_step,
+                           a_count, b.labels, b.sums);
+        SCAMD_LAUNCH_CHECK();
+      }
+    } else {
+      hipLaunchKernelGGL(ivf_centpad_kernel, dim3((unsigned)ceil_div((int64_t)nc * DPA, 256)), dim3(256), 0, s, b.cent, nc, d,
+                         DPA, b.centp);
+      SCAMD_LAUNCH_CHECK();
+      hipLaunchKernelGGL(assign, dim3((unsigned)ceil_div(a_count, 256)), dim3(256), 0, s, x, d, ld, a_start, a_step, a_count,
+                         b.centp, nc, b.labels, accumulate, accumulate ? b.sums : (long long*)nullptr, counts, aq0, aq1,
+                         a_qcounts);
+      SCAMD_LAUNCH_CHECK();
+    }
+    return SCAMD_OK;
+  };
   hipLaunchKernelGGL(ivf_init_kernel, dim3(nc), dim3(64), 0, s, x, n, d, ld, nc, b.cent);
   SCAMD_LAUNCH_CHECK();
   const int64_t n_sample = std::min<int64_t>(n, (int64_t)64 * nc);
@@ -2193,43 +2150,18 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   for (int it = 0; it < 3; ++it) {
     SCAMD_HIP_CHECK(hipMemsetAsync(b.sums, 0, sizeof(long long) * nc * d, s));
     SCAMD_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * nc, s));
-    hipLaunchKernelGGL(ivf_centpad_kernel, dim3((unsigned)ceil_div((int64_t)nc * DPA, 256)), dim3(256), 0, s, b.cent, nc, d,
-                       DPA, b.centp);
-    SCAMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(assign, dim3((unsigned)ceil_div(n_sample, 256)), dim3(256), 0, s, x, d, ld,
-                       (int64_t)0, step, n_sample, b.centp, nc, b.labels, 1, b.sums, counts, (int64_t)0, (int64_t)0,
-                       (int*)nullptr);
-    SCAMD_LAUNCH_CHECK();
+    const int rca = run_assign(0, step, n_sample, 1, 0, 0, nullptr);
+    if (rca != SCAMD_OK) return rca;
     hipLaunchKernelGGL(ivf_update_kernel, dim3((unsigned)ceil_div((int64_t)nc * d, 256)), dim3(256), 0, s, b.sums,
                        counts, nc, d, b.cent);
     SCAMD_LAUNCH_CHECK();
   }
   // 2. every row to its cell
   SCAMD_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * 2 * nc, s));
-  hipLaunchKernelGGL(ivf_centpad_kernel, dim3((unsigned)ceil_div((int64_t)nc * DPA, 256)), dim3(256), 0, s, b.cent, nc, d,
-                     DPA, b.centp);
-  SCAMD_LAUNCH_CHECK();
   {
-    // (d <= 50: the full assignment on the bf16 matrix cores; SCAMD_KNN_ASSIGN_MFMA=0 keeps the float32 kernel)
-    const char* e = getenv("SCAMD_KNN_ASSIGN_MFMA");
-    const int ncp = (nc + 31) / 32 * 32;
-    const size_t lds_a = (size_t)ncp * CENT_DPL * sizeof(unsigned int);
-    if (H == 25 && !(e && e[0] == '0') && lds_a <= 150 * 1024) {
-      unsigned int* centb = reinterpret_cast<unsigned int*>(b.centp);  // [ncp][32] dwords <= the float table's nc x 136 floats
-      hipLaunchKernelGGL(ivf_centpad_bf16_kernel, dim3((unsigned)ceil_div((int64_t)ncp * 32, 256)), dim3(256), 0, s, b.cent, nc, ncp, d,
-                         centb);
-      SCAMD_LAUNCH_CHECK();
-      SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_assign_mfma_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
-      hipLaunchKernelGGL(ivf_assign_mfma_kernel, dim3((unsigned)ceil_div(n, 128)), dim3(256), lds_a, s, x, d, ld, n, centb, ncp,
-                         b.labels, counts, q_begin, q_begin + n_query, qcounts);
-    } else {
-      hipLaunchKernelGGL(assign, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, x, d, ld,
-                         (int64_t)0, (int64_t)1, n, b.centp, nc, b.labels, 0, (long long*)nullptr, counts, q_begin,
-                         q_begin + n_query, qcounts);
-    }
+    const int rca = run_assign(0, 1, n, 0, q_begin, q_begin + n_query, qcounts);
+    if (rca != SCAMD_OK) return rca;
   }
-  SCAMD_LAUNCH_CHECK();
   std::vector<int> h_cnt(2 * nc);
   std::vector<float> h_cent((size_t)nc * d);
   SCAMD_HIP_CHECK(hipMemcpyAsync(h_cnt.data(), counts, sizeof(int) * 2 * nc, hipMemcpyDeviceToHost, s));
@@ -2343,14 +2275,10 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   // build cut for 2 blocks per CU (no spills) -- an A/B switch until both have been measured
   const char* wps_env = getenv("SCAMD_KNN_IVF_WPS");
   // (bf16 engine: 193 VGPRs = 2 blocks per CU by default; SCAMD_KNN_IVF_WPS=3 selects the build cut for 3)
-  // (SCAMD_KNN_QUEUE=0: the bf16 sweep with the sorted insertion straight from the accumulators, rounds 1-3, for A/B runs)
-  const char* q_env = getenv("SCAMD_KNN_QUEUE");
-  const bool direct = q_env && q_env[0] == '0';
-  auto kern = B3 ? ((wps_env && atoi(wps_env) == 3) ? knn_select_reg_kernel<H, 64, 3, true, B3>
-                                                     : (direct ? knn_select_reg_kernel<H, 64, 2, true, B3, false> : knn_select_reg_kernel<H, 64, 2, true, B3>))
-                 : ((wps_env && atoi(wps_env) == 3) ? knn_select_reg_kernel<H, 64, 3, true, false>
-                                                     : knn_select_reg_kernel<H, 64, 2, true, false>);
-  const size_t lds = C::LDS_BYTES + 64 + QUEUE_LDS_BYTES;
+  auto kern = B3 ? ((wps_env && atoi(wps_env) == 3) ? knn_select_reg_kernel<H, 64, 3, true, B3> : knn_select_reg_kernel<H, 64, 2, true, B3>)
+                 : ((wps_env && atoi(wps_env) == 2) ? knn_select_reg_kernel<H, 64, 2, true, false>
+                                                     : knn_select_reg_kernel<H, 64, 3, true, false>);
+  const size_t lds = C::LDS_BYTES + 64;
   SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
   IvfArgs iv;
@@ -2482,8 +2410,8 @@ static int run_ivf_tier2(const KnnPlan& p, const KnnBuffers& b, const float* x, 
     SCAMD_LAUNCH_CHECK();
   T2_DBG(__LINE__);
   }
-  auto kern = knn_select_reg_kernel<25, 64, 2, true, false>;  // (two blocks per CU: the queues' LDS, see QUEUE_CAP)
-  const size_t lds = C::LDS_BYTES + 64 + QUEUE_LDS_BYTES;
+  auto kern = knn_select_reg_kernel<25, 64, 3, true, false>;
+  const size_t lds = C::LDS_BYTES + 64;
   SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
   IvfArgs iv;
@@ -2504,8 +2432,6 @@ static int run_ivf_tier2(const KnnPlan& p, const KnnBuffers& b, const float* x, 
   iv.qorder = nullptr;
   iv.prepass_tiles = 16;
   iv.prepass_cells = 1;
-  {
-  }
   iv.debug_no_insert = 0;
   iv.trace = nullptr;
   const int thr_rank = std::min(32, std::max(1, k + 6));

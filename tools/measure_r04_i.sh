@@ -7,7 +7,7 @@ OUT="$R/gpurun_out/$TAG"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-for mode in 1 0 1; do
+for mode in 1 0 1 0; do
   SCAMD_KNN_ASSIGN_MFMA=$mode timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kn_${TAG}_$mode -o knn -- python "$R/tools/knn_only.py" 1000000 4 > "$OUT/knn_only_assign$mode.log" 2>&1 < /dev/null
   echo "assign_mfma=$mode rc=$?"; grep "knn n=" "$OUT/knn_only_assign$mode.log" | tail -2 | sed 's/.*select/select/' | cut -c1-200
   find /tmp/kn_${TAG}_$mode -name '*kernel_stats.csv' -exec cp {} "$OUT/knn_only_assign${mode}_kernel_stats.csv" \;
