@@ -509,6 +509,7 @@ struct IvfArgs {
   int* qorder;               // [n_blocks * 128] out (may be null): query number (row - q_begin) of every query slot, -1 = padding
   int prepass_tiles;         // tiles of the own cell the threshold pre-pass scores (SCAMD_KNN_PREPASS_TILES, default 16)
   int prepass_cells;         // cells (own cell first, then by ascending lower bound) the pre-pass covers (SCAMD_KNN_PREPASS_CELLS, default 1)
+  int prepass_min2;          // 1: the starting threshold is taken from the two smallest scores per lane (SCAMD_KNN_PREPASS_MIN2, default 1)
   int debug_no_insert;       // debug (SCAMD_KNN_DEBUG_NO_INSERT=1): survivors are dropped -- WRONG results, MFMA-side ceiling
   unsigned long long* trace; // debug (SCAMD_KNN_TRACE=<file>): per block {start, end (100 MHz clock), tiles swept, hw id}
   int n_cells, dc;          // dc = stride of `centers` (>= d)
@@ -751,7 +752,10 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     if constexpr (IVF) {
       if (minima) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) key[r] = fminf(key[r], acc_prev[r]);
+        for (int r = 0; r < 16; ++r) {  // the two smallest scores of the lane's candidate class: (key[r], idx[r] as float bits)
+          idx[r] = __float_as_int(__builtin_amdgcn_fmed3f(key[r], __int_as_float(idx[r]), acc_prev[r]));
+          key[r] = fminf(key[r], acc_prev[r]);
+        }
         return;
       }
     }
@@ -825,7 +829,10 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
       for (int r = 0; r < 16; ++r) neg |= accB[r] < 0.f;
       if (IVF && minima) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) key[r] = fminf(key[r], accB[r]);
+        for (int r = 0; r < 16; ++r) {
+          idx[r] = __float_as_int(__builtin_amdgcn_fmed3f(key[r], __int_as_float(idx[r]), accB[r]));
+          key[r] = fminf(key[r], accB[r]);
+        }
       } else if (__any(neg)) {
         insert(accB, athrB, row0 + (n_sub - 1) * 32, false);
       }
@@ -864,6 +871,12 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     // The real sweep then starts with that threshold: about half as many insertions in total.
     {
       minima = true;
+      // round 4: the pre-pass keeps the TWO smallest scores per lane (64 distinct candidates per query instead of 32; the
+      // second one in idx[r], unused until the lists start): the thr_rank-th smallest of 64 is about the 27th best
+      // candidate of the cell, that of 32 lane minima about the 49th -- and every candidate below the starting threshold
+      // costs an insertion when the real sweep meets it
+#pragma unroll
+      for (int r = 0; r < 16; ++r) idx[r] = __float_as_int(KEY_BIG);
       const int pre_tiles = min(iv.cell_ntiles[a], iv.prepass_tiles);
       if (tid == 0) atomicAdd(iv.pairs + 1, (unsigned long long)pre_tiles * TC * C::QB);  // counted apart: not useful work
       sweep(iv.cell_tile0[a], pre_tiles, false);
@@ -881,17 +894,29 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float x = key[r];
-        // bitonic sort along the 32 lanes of each half (ascending in l31)
+        // bitonic sort of the 64 values of each half's query: element e = 32 j + l31, j = 0 in x (smallest per lane), j = 1
+        // in y (second smallest).  Stages kk = 2 .. 32 sort both registers along the lanes -- x ascending, y descending at
+        // kk = 32 (bit 5 of e is j) -- then the kk = 64 merge: its first step compares x with y in the lane and leaves
+        // the 32 smallest of the 64 in x, which its remaining five steps put in ascending order (y is done with).
+        float x = key[r], y = iv.prepass_min2 ? __int_as_float(idx[r]) : KEY_BIG;  // (SCAMD_KNN_PREPASS_MIN2=0: lane minima only, rounds 1-3)
+        idx[r] = -1;
 #pragma unroll
         for (int kk = 2; kk <= 32; kk <<= 1) {
 #pragma unroll
           for (int j = kk >> 1; j > 0; j >>= 1) {
-            const float y = __shfl_xor(x, j);
-            const bool up = (l31 & kk) == 0;
+            const float xo = __shfl_xor(x, j), yo = __shfl_xor(y, j);
             const bool lower = (l31 & j) == 0;
-            x = (lower == up) ? fminf(x, y) : fmaxf(x, y);
+            const bool upx = kk == 32 ? true : (l31 & kk) == 0;
+            const bool upy = kk == 32 ? false : (l31 & kk) == 0;
+            x = (lower == upx) ? fminf(x, xo) : fmaxf(x, xo);
+            y = (lower == upy) ? fminf(y, yo) : fmaxf(y, yo);
           }
+        }
+        x = fminf(x, y);
+#pragma unroll
+        for (int j = 16; j > 0; j >>= 1) {
+          const float xo = __shfl_xor(x, j);
+          x = ((l31 & j) == 0) ? fminf(x, xo) : fmaxf(x, xo);
         }
         const int i0 = (r & 3) + 8 * (r >> 2), i1 = i0 + 4;
         const float t0 = readlane_f32(x, thr_lane), t1 = readlane_f32(x, 32 + thr_lane);
@@ -1067,6 +1092,16 @@ __global__ __launch_bounds__(1024) void ivf_block_order_kernel(const int* __rest
   // robin: cell i of the sorted order joins the queue of XCD i mod 8 -- every queue is still longest-first and holds
   // every eighth cell of the order (thread x builds queue x).  Otherwise: exclusive scan of the block counts in sorted
   // order (serial: 1024 entries)
+  // (block counts and work estimates in sorted order, staged in LDS: the serial loops below then wait for LDS, not for a
+  // dependent global load per cell -- 175 -> ~50 us for 512 cells)
+  __shared__ int s_cnt[IVF_MAX_CELLS];
+  __shared__ int s_work[IVF_MAX_CELLS];
+  if (tid < n_cells) {
+    const int c = (int)(key[tid] & 0xffffffffll);
+    s_cnt[tid] = blk_cnt[c];
+    s_work[tid] = max(work[c], 1);
+  }
+  __syncthreads();
   if (xcd_mode) {
     // cell i of the sorted order goes to the XCD whose queue holds the least work so far (blocks x expected sweep per
     // block; dealing the cells round robin left the queues up to 10 % apart: 18.99 vs 17.42 ms, profiles/r04d).  The
@@ -1075,9 +1110,8 @@ __global__ __launch_bounds__(1024) void ivf_block_order_kernel(const int* __rest
       long long load = 0ll;
       int len = 0;
       for (int i = 0; i < n_cells; ++i) {
-        const int c = (int)(key[i] & 0xffffffffll);
-        const int cnt = blk_cnt[c];
-        const long long wk = (long long)cnt * (long long)max(work[c], 1);
+        const int cnt = s_cnt[i];
+        const long long wk = (long long)cnt * (long long)s_work[i];
         // (a queue may not outgrow its share of the launch slots; the slots are sized so that some queue always has room)
         const bool room = tid < 8 && (len + cnt) * 8 <= n_slots;
         long long best = room ? (load << 3) | (long long)(tid & 7) : 0x7fffffffffffffffll;  // (totals stay far below 2^60)
@@ -1098,7 +1132,7 @@ __global__ __launch_bounds__(1024) void ivf_block_order_kernel(const int* __rest
     int run = 0;
     for (int i = 0; i < n_cells; ++i) {
       start[i] = run;
-      run += blk_cnt[(int)(key[i] & 0xffffffffll)];
+      run += s_cnt[i];
     }
   }
   __syncthreads();
@@ -1479,7 +1513,20 @@ __global__ __launch_bounds__(256) void knn_fallback_scan_cells_kernel(
       if (orig < 0 || orig == q) continue;
       const float* cp = x + (int64_t)orig * ld;
       double s = 0.0;
-      for (int t = 0; t < d; ++t) {
+      // ten coordinates requested at a time, summed in the same order as one by one (one load in flight per thread made a
+      // cell of 2048 rows 400 serial round trips per thread: 0.9 ms for the 58 queries of the 1M bench)
+      int t = 0;
+      for (; t + 10 <= d; t += 10) {
+        float v[10];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) v[u] = cp[t + u];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) {
+          const double df = (double)qs[t + u] - (double)v[u];
+          s = fma(df, df, s);
+        }
+      }
+      for (; t < d; ++t) {
         const double df = (double)qs[t] - (double)cp[t];
         s = fma(df, df, s);
       }
@@ -2304,6 +2351,8 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
     iv.prepass_tiles = e ? std::max(1, atoi(e)) : (B3 ? 32 : 16);
     const char* e2 = getenv("SCAMD_KNN_PREPASS_CELLS");
     iv.prepass_cells = e2 ? std::max(1, atoi(e2)) : 1;
+    const char* e3 = getenv("SCAMD_KNN_PREPASS_MIN2");
+    iv.prepass_min2 = (e3 && e3[0] == '0') ? 0 : 1;
   }
   {
     const char* e = getenv("SCAMD_KNN_DEBUG_NO_INSERT");
@@ -2432,6 +2481,7 @@ static int run_ivf_tier2(const KnnPlan& p, const KnnBuffers& b, const float* x, 
   iv.qorder = nullptr;
   iv.prepass_tiles = 16;
   iv.prepass_cells = 1;
+  iv.prepass_min2 = 1;
   iv.debug_no_insert = 0;
   iv.trace = nullptr;
   const int thr_rank = std::min(32, std::max(1, k + 6));
@@ -2606,7 +2656,8 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
       if (p.ivf) {
         // cell tables of run_ivf_select (same carving): tile0 = cell_ints + 7 nc, ntiles = the recycled sums buffer
         const int nc = p.n_cells;
-        hipLaunchKernelGGL(knn_fallback_scan_cells_kernel, dim3(std::min(nc, 64), count), dim3(256), 0, s, x, d, ld_x, q_begin,
+        // (few queries: one workgroup per cell and query -- a launch lasts as long as its busiest workgroup)
+        hipLaunchKernelGGL(knn_fallback_scan_cells_kernel, dim3(count <= 128 ? nc : std::min(nc, 64), count), dim3(256), 0, s, x, d, ld_x, q_begin,
                            todo, begin, b.kth_d2, b.scratch_d, b.scratch_i, b.fb_counts, b.cent,
                            reinterpret_cast<const float*>(b.radius_bits), b.cell_ints + 7 * nc,
                            reinterpret_cast<const int*>(b.sums), b.perm, nc);
