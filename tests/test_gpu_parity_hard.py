@@ -278,6 +278,33 @@ def test_knn_second_tier_of_the_bf16_engine(K, monkeypatch):
     np.testing.assert_array_equal(d2.cpu().numpy(), d3.cpu().numpy())
 
 
+def test_knn_quantiser_and_prepass_variants_give_the_same_lists(K, monkeypatch):
+    """round 4: the quantiser assigns on the bf16 matrix cores and the threshold pre-pass keeps two minima per lane -- both
+    only steer the pruning / the insertions.  The result must be bit for bit that of the float32 assignment and of the
+    one-minimum pre-pass, and the bf16 assignment must not cost pruning (evaluated pairs within 5 %)."""
+    from scanpy_amd import _lib
+    from scanpy_amd.datasets import blobs_embedding
+
+    lib = _lib.load()
+    x, _ = blobs_embedding(150_000, 50, n_types=24, seed=19)
+    xd = _dev(x)
+    ref = None
+    pairs = {}
+    for assign, min2 in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+        monkeypatch.setenv("SCAMD_KNN_ASSIGN_MFMA", assign)
+        monkeypatch.setenv("SCAMD_KNN_PREPASS_MIN2", min2)
+        i, d, _ = K.knn(xd, 15)
+        pairs[(assign, min2)] = float(lib.scamd_knn_last_select_pairs())
+        assert int(lib.scamd_knn_last_select_engine()) == 1
+        if ref is None:
+            ref = (i.cpu().numpy(), d.cpu().numpy())
+        else:
+            np.testing.assert_array_equal(ref[0], i.cpu().numpy())
+            np.testing.assert_array_equal(ref[1], d.cpu().numpy())
+    print("evaluated pairs:", pairs)
+    assert pairs[("1", "1")] <= 1.05 * pairs[("0", "1")]
+
+
 def test_knn_forced_fallback_through_the_cell_scan(K, monkeypatch):
     """every query forced through the float64 fallback (cert_scale = 1e30) in cell-pruned mode: the fallback scans only
     the cells whose ball reaches the query's bound -- same lists as the certified run, bit for bit"""
