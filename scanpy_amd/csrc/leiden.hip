@@ -329,13 +329,48 @@ __device__ __forceinline__ Cand block_best(Cand x, long long& w_own, Cand* sh_c,
 //           vertices per wave put four times as many gathers in flight per wave slot.  Longer rows go to
 //           ovf_list (counters[5]) and are decided by the G = 64 instantiation in indirect mode
 //           (sub_list / sub_count = positions in `list`, grid-strided).
+struct MoveArgs {
+  int n_act;
+  const int* list;
+  const int* sub_list;
+  const int* sub_count;
+  const int64_t* indptr;
+  const int* indices;
+  const long long* wq;
+  const long long* k;
+  const int* comm;
+  const unsigned long long* Ktot;
+  const int* csize;
+  double g;  // gamma / 2m
+  int round;
+  unsigned int seed;
+  int* decision;
+  int* ovf_list;
+  int* hub_list;
+  int* counters;
+};
+// (the body takes its workgroup number and the number of workgroups as arguments: ld_requeue_move_kernel runs it on the
+// tail of a grid whose head re-queues the previous sub-round's movers)
 template <int G>
-__global__ __launch_bounds__(256) void ld_move_kernel(
-    int n_act, const int* __restrict__ list, const int* __restrict__ sub_list, const int* __restrict__ sub_count,
-    const int64_t* __restrict__ indptr, const int* __restrict__ indices, const long long* __restrict__ wq,
-    const long long* __restrict__ k, const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot,
-    const int* __restrict__ csize, double g /* gamma / 2m */, int round, unsigned int seed,
-    int* __restrict__ decision, int* __restrict__ ovf_list, int* __restrict__ hub_list, int* __restrict__ counters) {
+__device__ __forceinline__ void ld_move_body(int bid, int nblk, const MoveArgs& ma) {
+  const int n_act = ma.n_act;
+  const int* __restrict__ list = ma.list;
+  const int* __restrict__ sub_list = ma.sub_list;
+  const int* __restrict__ sub_count = ma.sub_count;
+  const int64_t* __restrict__ indptr = ma.indptr;
+  const int* __restrict__ indices = ma.indices;
+  const long long* __restrict__ wq = ma.wq;
+  const long long* __restrict__ k = ma.k;
+  const int* __restrict__ comm = ma.comm;
+  const unsigned long long* __restrict__ Ktot = ma.Ktot;
+  const int* __restrict__ csize = ma.csize;
+  const double g = ma.g;
+  const int round = ma.round;
+  const unsigned int seed = ma.seed;
+  int* __restrict__ decision = ma.decision;
+  int* __restrict__ ovf_list = ma.ovf_list;
+  int* __restrict__ hub_list = ma.hub_list;
+  int* __restrict__ counters = ma.counters;
   constexpr int GROUPS = 256 / G;            // vertices per workgroup
   constexpr int GSLOTS = WH_SLOTS * G / 64;  // table slots per vertex
   constexpr int GMAX = GSLOTS * 3 / 4;       // longest row the table takes
@@ -344,7 +379,7 @@ __global__ __launch_bounds__(256) void ld_move_kernel(
   const int sub = threadIdx.x % G;
   const int grp = threadIdx.x / G;
   const int n_items = sub_list ? *sub_count : n_act;
-  for (int item = blockIdx.x * GROUPS + grp; item < n_items; item += gridDim.x * GROUPS) {
+  for (int item = bid * GROUPS + grp; item < n_items; item += nblk * GROUPS) {
     // The decision of one vertex is a chain of dependent gathers (list -> indptr -> indices -> comm -> Ktot) and the
     // kernel is bound by its length: everything that depends on the same address is requested together, before the
     // first branch that needs any of it (written the obvious way the compiler keeps seven round trips in series:
@@ -472,6 +507,17 @@ __global__ __launch_bounds__(256) void ld_move_kernel(
     if (sub == 0) decision[w] = (wants && allowed) ? target : (wants ? -2 : -1);
   }
 }
+template <int G>
+__global__ __launch_bounds__(256) void ld_move_kernel(
+    int n_act, const int* __restrict__ list, const int* __restrict__ sub_list, const int* __restrict__ sub_count,
+    const int64_t* __restrict__ indptr, const int* __restrict__ indices, const long long* __restrict__ wq,
+    const long long* __restrict__ k, const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot,
+    const int* __restrict__ csize, double g /* gamma / 2m */, int round, unsigned int seed,
+    int* __restrict__ decision, int* __restrict__ ovf_list, int* __restrict__ hub_list, int* __restrict__ counters) {
+  const MoveArgs ma{n_act, list, sub_list, sub_count, indptr, indices, wq, k, comm, Ktot, csize, g, round, seed,
+                    decision, ovf_list, hub_list, counters};
+  ld_move_body<G>((int)blockIdx.x, (int)gridDim.x, ma);
+}
 
 // Hub vertices of the active list (positions in hub_list[0 .. counters[4])): one workgroup each.
 // HUB_THREADS = 1024 (round 3; 256 before): a launch lasts as long as its longest row -- up to 20k entries on the coarse
@@ -596,12 +642,11 @@ __global__ __launch_bounds__(256) void ld_apply_kernel(int n_act, const int* __r
 // must be the sub-round's final ones for the flags to be reproducible.  Round 2 flagged every neighbour: after the first
 // sweep of a level most of the active list was vertices deep inside their community.
 // The rows are walked by the whole wave, two movers at a time (32 lanes each, coalesced row reads).
-__global__ __launch_bounds__(256) void ld_requeue_kernel(int n_act, const int* __restrict__ list,
-                                                         const int* __restrict__ decision,
-                                                         const int64_t* __restrict__ indptr,
-                                                         const int* __restrict__ indices, const int* __restrict__ comm,
-                                                         int* __restrict__ flag) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void ld_requeue_body(int bid, int n_act, const int* __restrict__ list,
+                                                const int* __restrict__ decision, const int64_t* __restrict__ indptr,
+                                                const int* __restrict__ indices, const int* __restrict__ comm,
+                                                int* __restrict__ flag) {
+  const int w = bid * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
   int64_t beg = 0, end = 0;
   int d = -1;
@@ -632,6 +677,27 @@ __global__ __launch_bounds__(256) void ld_requeue_kernel(int n_act, const int* _
       if (comm[u] != dd) flag[u] = 1;
     }
   }
+}
+__global__ __launch_bounds__(256) void ld_requeue_kernel(int n_act, const int* __restrict__ list,
+                                                         const int* __restrict__ decision,
+                                                         const int64_t* __restrict__ indptr,
+                                                         const int* __restrict__ indices, const int* __restrict__ comm,
+                                                         int* __restrict__ flag) {
+  ld_requeue_body((int)blockIdx.x, n_act, list, decision, indptr, indices, comm, flag);
+}
+// Sub-round c's re-queue and sub-round c + 1's decisions in ONE launch (round 4).  They are independent: the re-queue
+// reads the decisions of class c (their own buffer: `decision` alternates between two buffers from sub-round to
+// sub-round) and the communities after apply(c), and writes flags; the decisions of class c + 1 read the same state and
+// write their own buffer and lists.  The first nb_rq workgroups re-queue, the rest decide.  One launch of ~16 us less per
+// sub-round (152 per call at 1M cells).
+template <int G>
+__global__ __launch_bounds__(256) void ld_requeue_move_kernel(int nb_rq, int rq_n_act, const int* __restrict__ rq_list,
+                                                              const int* __restrict__ rq_decision,
+                                                              const int64_t* __restrict__ indptr,
+                                                              const int* __restrict__ indices, const int* __restrict__ comm,
+                                                              int* __restrict__ flag, MoveArgs ma) {
+  if ((int)blockIdx.x < nb_rq) ld_requeue_body((int)blockIdx.x, rq_n_act, rq_list, rq_decision, indptr, indices, comm, flag);
+  else ld_move_body<G>((int)blockIdx.x - nb_rq, (int)gridDim.x - nb_rq, ma);
 }
 
 // Class of a vertex in a sweep: a fresh hash per sweep (salt), so two neighbours that shared a class -- and could
@@ -1986,7 +2052,7 @@ struct LeidenBuffers {
   CoarseBuf cb[2];
   int* comm; int* csize; unsigned long long* Ktot;
   int* cls_lists; int* rlist; int* touched; int* hub_list;
-  int* ref; int* target; int* refsize; unsigned long long* Kref; unsigned long long* Eref; long long* a_in;
+  int* ref; int* target; int* target2; int* refsize; unsigned long long* Kref; unsigned long long* Eref; long long* a_in;
   int* flag; int64_t* newid; int64_t* scan_tmp; int* cid; int* rep; int* comm_tmp;
   int* node_of; int* memb; int* memb_best;
   int* agg_col; long long* agg_w;  // scratch CSR of the coarse-graph build (rows at upper-bound offsets)
@@ -2028,6 +2094,7 @@ static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b
   b->touched = ws.take<int>(N);
   b->ref = ws.take<int>(N);
   b->target = ws.take<int>(N);
+  b->target2 = ws.take<int>(N);  // decisions of alternate sub-rounds (ld_requeue_move_kernel)
   b->refsize = ws.take<int>(N);
   b->Kref = ws.take<unsigned long long>(N);
   b->Eref = ws.take<unsigned long long>(N);
@@ -2080,6 +2147,7 @@ struct LeidenCtx {
   int lm_classes = 0;         // class sub-rounds per local-moving sweep (0 = by level size; SCAMD_LEIDEN_LM_CLASSES)
   int rf_classes = 0;         // class sub-rounds of the refinement (0 = by level size; SCAMD_LEIDEN_RF_CLASSES)
   bool small_levels = true;   // levels of <= SMALL_N nodes in one workgroup (SCAMD_LEIDEN_SMALL=0: separate kernels)
+  bool no_fuse = false;       // SCAMD_LEIDEN_FUSE=0: re-queue and the next sub-round's decisions as separate launches (A/B)
   int small_seq_n = SMALL_SEQ_N;  // ... of which those of <= small_seq_n vertices move one vertex at a time (SCAMD_LEIDEN_SMALL_SEQ)
   // coarse-row build tiers (distinct-neighbour bounds); the env overrides exist so the tests can push small graphs
   // through the workgroup and multi-pass tiers
@@ -2227,52 +2295,92 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
     // the direction rule is the termination guarantee only: synchronous sub-rounds without it converge in a few sweeps
     // on every graph tried, with it (round 2's scheme) about half of the wanted moves of a round were blocked
     const int dir_round = sweep >= LM_DIR_AFTER ? sweep : -1;
-    for (int c = 0; c < n_cls; ++c) {
+    // the non-empty classes of the sweep, in order; the main decision kernel of sub-round i + 1 shares a launch with the
+    // re-queue of sub-round i (ld_requeue_move_kernel), the decisions alternate between two buffers
+    int cls[MAX_CLASSES], ncl = 0;
+    for (int c = 0; c < n_cls; ++c)
+      if (hc[c] > 0) cls[ncl++] = c;
+    int* tgt[2] = {b.target, b.target2};
+    auto move_args = [&](int c, int* decision) {
+      return MoveArgs{hc[c], b.cls_lists + (size_t)c * n, nullptr, nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
+                      b.csize, gg, dir_round, cx.seed, decision, b.mid_list, b.hub_list, sw + MAX_CLASSES + CTR_STRIDE * c};
+    };
+    auto move_blocks = [&](int cnt) { return lanes == 16 ? ceil_div(cnt, 16) : (lanes == 32 ? ceil_div(cnt, 8) : ceil_div(cnt, 4)); };
+    for (int i = 0; i < ncl; ++i) {
+      const int c = cls[i];
       const int cnt = hc[c];
-      if (cnt == 0) continue;
       const int* list = b.cls_lists + (size_t)c * n;
       int* ctr = sw + MAX_CLASSES + CTR_STRIDE * c;
+      int* tg = tgt[i & 1];
       // long rows among THIS sub-round's vertices (counted by ld_compact_cls_kernel): no launch for an empty tier
       const int n_mid = hc[MAX_CLASSES + CTR_STRIDE * c + CTR_N_MID], n_hub = hc[MAX_CLASSES + CTR_STRIDE * c + CTR_N_HUB];
-      if (lanes == 32) {
-        hipLaunchKernelGGL(ld_move_kernel<32>, dim3((unsigned)ceil_div(cnt, 8)), dim3(256), 0, cx.s, cnt, list,
-                           (const int*)nullptr, (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
-                           b.csize, gg, dir_round, cx.seed, b.target, b.mid_list, b.hub_list, ctr);
+      if (i == 0) {  // (later sub-rounds: decided in the launch that re-queued the sub-round before)
+        const MoveArgs ma = move_args(c, tg);
+        if (lanes == 32)
+          hipLaunchKernelGGL(ld_move_kernel<32>, dim3((unsigned)move_blocks(cnt)), dim3(256), 0, cx.s, ma.n_act, ma.list, ma.sub_list,
+                             ma.sub_count, ma.indptr, ma.indices, ma.wq, ma.k, ma.comm, ma.Ktot, ma.csize, ma.g, ma.round, ma.seed,
+                             ma.decision, ma.ovf_list, ma.hub_list, ma.counters);
+        else if (lanes == 16)
+          hipLaunchKernelGGL(ld_move_kernel<16>, dim3((unsigned)move_blocks(cnt)), dim3(256), 0, cx.s, ma.n_act, ma.list, ma.sub_list,
+                             ma.sub_count, ma.indptr, ma.indices, ma.wq, ma.k, ma.comm, ma.Ktot, ma.csize, ma.g, ma.round, ma.seed,
+                             ma.decision, ma.ovf_list, ma.hub_list, ma.counters);
+        else
+          hipLaunchKernelGGL(ld_move_kernel<64>, dim3((unsigned)move_blocks(cnt)), dim3(256), 0, cx.s, ma.n_act, ma.list, ma.sub_list,
+                             ma.sub_count, ma.indptr, ma.indices, ma.wq, ma.k, ma.comm, ma.Ktot, ma.csize, ma.g, ma.round, ma.seed,
+                             ma.decision, ma.ovf_list, ma.hub_list, ma.counters);
         SCAMD_LAUNCH_CHECK();
-        if (n_mid > 0) {
-          hipLaunchKernelGGL(ld_move_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(n_mid, 4))), dim3(256), 0, cx.s,
-                             cnt, list, (const int*)b.mid_list, (const int*)(ctr + 5), g.indptr, g.indices, g.wq, g.k,
-                             b.comm, b.Ktot, b.csize, gg, dir_round, cx.seed, b.target, b.mid_list, b.hub_list, ctr);
-          SCAMD_LAUNCH_CHECK();
-        }
-      } else if (lanes == 16) {
-        hipLaunchKernelGGL(ld_move_kernel<16>, dim3((unsigned)ceil_div(cnt, 16)), dim3(256), 0, cx.s, cnt, list,
-                           (const int*)nullptr, (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
-                           b.csize, gg, dir_round, cx.seed, b.target, b.mid_list, b.hub_list, ctr);
-        SCAMD_LAUNCH_CHECK();
-        if (n_mid > 0) {
-          hipLaunchKernelGGL(ld_move_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(n_mid, 4))), dim3(256), 0, cx.s,
-                             cnt, list, (const int*)b.mid_list, (const int*)(ctr + 5), g.indptr, g.indices, g.wq, g.k,
-                             b.comm, b.Ktot, b.csize, gg, dir_round, cx.seed, b.target, b.mid_list, b.hub_list, ctr);
-          SCAMD_LAUNCH_CHECK();
-        }
-      } else {
-        hipLaunchKernelGGL(ld_move_kernel<64>, GRIDW(cnt), 0, cx.s, cnt, list, (const int*)nullptr, (const int*)nullptr,
-                           g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg, dir_round, cx.seed, b.target,
-                           b.mid_list, b.hub_list, ctr);
+      }
+      if (lanes != 64 && n_mid > 0) {
+        hipLaunchKernelGGL(ld_move_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(n_mid, 4))), dim3(256), 0, cx.s,
+                           cnt, list, (const int*)b.mid_list, (const int*)(ctr + 5), g.indptr, g.indices, g.wq, g.k,
+                           b.comm, b.Ktot, b.csize, gg, dir_round, cx.seed, tg, b.mid_list, b.hub_list, ctr);
         SCAMD_LAUNCH_CHECK();
       }
       if (n_hub > 0) {
         hipLaunchKernelGGL(ld_move_hub_kernel, dim3((unsigned)std::min(HUB_GRID, n_hub)), dim3(HUB_THREADS), HUB_LDS, cx.s, b.hub_list,
                            ctr, list, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg, dir_round, cx.seed,
-                           b.target, b.counters + 7);
+                           tg, b.counters + 7);
         SCAMD_LAUNCH_CHECK();
       }
-      hipLaunchKernelGGL(ld_apply_kernel, GRID1(cnt), 0, cx.s, cnt, list, b.target, g.k, b.comm, b.Ktot, b.csize, b.flag,
+      hipLaunchKernelGGL(ld_apply_kernel, GRID1(cnt), 0, cx.s, cnt, list, tg, g.k, b.comm, b.Ktot, b.csize, b.flag,
                          b.counters);
       SCAMD_LAUNCH_CHECK();
-      hipLaunchKernelGGL(ld_requeue_kernel, GRID1(cnt), 0, cx.s, cnt, list, b.target, g.indptr, g.indices, b.comm, b.flag);
-      SCAMD_LAUNCH_CHECK();
+      if (i + 1 < ncl && !cx.no_fuse) {
+        const int cn = cls[i + 1];
+        const MoveArgs ma = move_args(cn, tgt[(i + 1) & 1]);
+        const int nb_rq = ceil_div(cnt, 256);
+        const dim3 grid((unsigned)(nb_rq + move_blocks(hc[cn])));
+        if (lanes == 32)
+          hipLaunchKernelGGL(ld_requeue_move_kernel<32>, grid, dim3(256), 0, cx.s, nb_rq, cnt, list, (const int*)tg, g.indptr,
+                             g.indices, (const int*)b.comm, b.flag, ma);
+        else if (lanes == 16)
+          hipLaunchKernelGGL(ld_requeue_move_kernel<16>, grid, dim3(256), 0, cx.s, nb_rq, cnt, list, (const int*)tg, g.indptr,
+                             g.indices, (const int*)b.comm, b.flag, ma);
+        else
+          hipLaunchKernelGGL(ld_requeue_move_kernel<64>, grid, dim3(256), 0, cx.s, nb_rq, cnt, list, (const int*)tg, g.indptr,
+                             g.indices, (const int*)b.comm, b.flag, ma);
+        SCAMD_LAUNCH_CHECK();
+      } else {
+        hipLaunchKernelGGL(ld_requeue_kernel, GRID1(cnt), 0, cx.s, cnt, list, tg, g.indptr, g.indices, b.comm, b.flag);
+        SCAMD_LAUNCH_CHECK();
+        if (i + 1 < ncl) {  // (SCAMD_LEIDEN_FUSE=0: the next sub-round's decisions as a launch of their own)
+          const MoveArgs ma = move_args(cls[i + 1], tgt[(i + 1) & 1]);
+          const unsigned nbm = (unsigned)move_blocks(hc[cls[i + 1]]);
+          if (lanes == 32)
+            hipLaunchKernelGGL(ld_move_kernel<32>, dim3(nbm), dim3(256), 0, cx.s, ma.n_act, ma.list, ma.sub_list, ma.sub_count,
+                               ma.indptr, ma.indices, ma.wq, ma.k, ma.comm, ma.Ktot, ma.csize, ma.g, ma.round, ma.seed, ma.decision,
+                               ma.ovf_list, ma.hub_list, ma.counters);
+          else if (lanes == 16)
+            hipLaunchKernelGGL(ld_move_kernel<16>, dim3(nbm), dim3(256), 0, cx.s, ma.n_act, ma.list, ma.sub_list, ma.sub_count,
+                               ma.indptr, ma.indices, ma.wq, ma.k, ma.comm, ma.Ktot, ma.csize, ma.g, ma.round, ma.seed, ma.decision,
+                               ma.ovf_list, ma.hub_list, ma.counters);
+          else
+            hipLaunchKernelGGL(ld_move_kernel<64>, dim3(nbm), dim3(256), 0, cx.s, ma.n_act, ma.list, ma.sub_list, ma.sub_count,
+                               ma.indptr, ma.indices, ma.wq, ma.k, ma.comm, ma.Ktot, ma.csize, ma.g, ma.round, ma.seed, ma.decision,
+                               ma.ovf_list, ma.hub_list, ma.counters);
+          SCAMD_LAUNCH_CHECK();
+        }
+      }
     }
   }
   return SCAMD_OK;
@@ -2645,6 +2753,7 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
   cx.lm_classes = classes_env("SCAMD_LEIDEN_LM_CLASSES");
   cx.rf_classes = classes_env("SCAMD_LEIDEN_RF_CLASSES");
   if (const char* e = getenv("SCAMD_LEIDEN_SMALL")) cx.small_levels = e[0] != '0';
+  if (const char* e = getenv("SCAMD_LEIDEN_FUSE")) cx.no_fuse = e[0] == '0';
   if (const char* e = getenv("SCAMD_LEIDEN_SMALL_SEQ")) cx.small_seq_n = atoi(e);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_WAVE_MAX")) cx.agg_wave_max = std::min(atoi(e), (int)WH_MAX_DEG);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_MAX")) cx.agg_mid_max = std::min(atoi(e), (int)AGG_MID_MAX);
