@@ -56,7 +56,8 @@ def build(verbose: bool = True, force: bool = False) -> Path:
     LIBDIR.mkdir(exist_ok=True)
     if force:
         for f in LIBDIR.glob("*"):
-            f.unlink()
+            if f.is_file():
+                f.unlink()
     headers = sorted(CSRC.glob("*.h")) + [PKG.parent / "include" / "scanpy_amd.h"]
     srcs = [CSRC / s for s in SOURCES if (CSRC / s).exists()]
     objs = [LIBDIR / (s.stem + ".o") for s in srcs]

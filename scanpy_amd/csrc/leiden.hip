@@ -769,6 +769,21 @@ __global__ __launch_bounds__(1024) void ld_compact_cls_kernel(int n, int* __rest
   if (cls >= 0) lists[(size_t)cls * n + base[cls] + wcnt[wv][cls] + rank] = v;
 }
 
+// Packed mirrors of the refinement's state (round 4).  Counters of the decision kernels (profiles/r04n_leiden_kernels_pmc*.csv):
+// ld_refine_propose_kernel<16> waits 55 % of its wave-cycles on memory and moves 0.7 GB through the memory side of L2 per
+// launch of ~90k candidates -- 7.7 KB per candidate, i.e. a 64-byte sector for every 4- or 8-byte gather of comm[u], ref[u]
+// (two per neighbour) and Kref[c], refsize[c], Eref[c] (three per distinct target), at an L2 hit rate of 24 %: the kernels
+// run at the fabric's bandwidth, fetching sectors of which they use a sixteenth.  The proposing kernels and the cut update
+// therefore read ONE record per neighbour and ONE per target; the plain arrays stay the authoritative copy for everything
+// else (aggregation, coarse ids), every writer of the refinement updates both.  All fields are integers: same results.
+struct alignas(16) VertRec {  // per vertex: phase-1 community, refined community, sub-round in which it joined (-1: never)
+  int comm, ref, stamp, pad;
+};
+struct alignas(32) TargRec {  // per refined community (indexed by its representative vertex)
+  unsigned long long Kref, Eref;
+  int refsize, pad0, pad1, pad2;
+};
+
 // ---- phase 2: refinement ---------------------------------------------------------------------------
 // a_in[v] = w(v, C(v) - v): weight from v to the rest of its (phase-1) community
 template <int G>
@@ -854,7 +869,8 @@ __global__ __launch_bounds__(256) void ld_refine_cut_update_kernel(
     int n_join, const int* __restrict__ jlist, const int64_t* __restrict__ indptr, const int* __restrict__ indices,
     const long long* __restrict__ wq, const int* __restrict__ comm, const int* __restrict__ ref,
     const int* __restrict__ stamp, const long long* __restrict__ a_in, int round,
-    unsigned long long* __restrict__ Eref, const int* __restrict__ n_join_dev) {
+    unsigned long long* __restrict__ Eref, const int* __restrict__ n_join_dev, const VertRec* __restrict__ vr,
+    TargRec* __restrict__ tr) {
   const int sub = threadIdx.x % G;
   n_join = *n_join_dev;
   for (int w = blockIdx.x * (256 / G) + threadIdx.x / G; w < n_join; w += gridDim.x * (256 / G)) {
@@ -875,10 +891,11 @@ __global__ __launch_bounds__(256) void ld_refine_cut_update_kernel(
       we[j] = ee < end ? wq[ee] : 0ll;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      cu[j] = comm[u[j]];
-      ru[j] = ref[u[j]];
-      su[j] = stamp[u[j]];
+    for (int j = 0; j < 2; ++j) {  // one 16-byte record per neighbour instead of three gathers
+      const VertRec r = vr[u[j]];
+      cu[j] = r.comm;
+      ru[j] = r.ref;
+      su[j] = r.stamp;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -886,7 +903,10 @@ __global__ __launch_bounds__(256) void ld_refine_cut_update_kernel(
   }
 #pragma unroll
   for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if (sub == 0) atomicAdd(&Eref[t], (unsigned long long)(av - s));
+  if (sub == 0) {
+    atomicAdd(&Eref[t], (unsigned long long)(av - s));
+    atomicAdd(&tr[t].Eref, (unsigned long long)(av - s));
+  }
   }
 }
 
@@ -921,7 +941,8 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
     const int* __restrict__ ref, const int* __restrict__ refsize, const unsigned long long* __restrict__ Kref,
     const unsigned long long* __restrict__ Eref, double g, double inv_beta /* 1 / (beta * 2^32); 0 = greedy */,
     int round, int n_cls, unsigned int salt, unsigned int seed, int* __restrict__ target,
-    int* __restrict__ ovf_list, int* __restrict__ hub_list, int* __restrict__ counters, int n_cand) {
+    int* __restrict__ ovf_list, int* __restrict__ hub_list, int* __restrict__ counters, int n_cand,
+    const VertRec* __restrict__ vr, const TargRec* __restrict__ tr) {
   constexpr int GROUPS = 256 / G;
   constexpr int GSLOTS = WH_SLOTS * G / 64;
   constexpr int GMAX = GSLOTS * 3 / 4;
@@ -958,8 +979,9 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
       int cm_pre[2], rf_pre[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        cm_pre[t] = comm[u_pre[t]];
-        rf_pre[t] = ref[u_pre[t]];
+        const VertRec r = vr[u_pre[t]];
+        cm_pre[t] = r.comm;
+        rf_pre[t] = r.ref;
       }
       const double kv = (double)kq;
       if (G < 64) {
@@ -997,7 +1019,8 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
           if (sub + t * G < deg && u_pre[t] != v && cm_pre[t] == a) insert(rf_pre[t], w_pre[t]);
         for (int e = sub + 2 * G; e < deg; e += G) {
           const int u = indices[beg + e];
-          if (u != v && comm[u] == a) insert(ref[u], wq[beg + e]);
+          const VertRec r = vr[u];
+          if (u != v && r.comm == a) insert(r.ref, wq[beg + e]);
         }
         constexpr int MAXSL = GSLOTS / G;
         int cs[MAXSL], rsz[MAXSL];
@@ -1012,9 +1035,10 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
             if (c == v) c = WH_EMPTY;
             cs[t] = c;
             const int ci = c != WH_EMPTY ? c : v;
-            kr[t] = Kref[ci];
-            rsz[t] = refsize[ci];
-            er[t] = Eref[ci];
+            const TargRec x = tr[ci];  // one 32-byte record per target instead of three gathers
+            kr[t] = x.Kref;
+            rsz[t] = x.refsize;
+            er[t] = x.Eref;
           }
         }
 #pragma unroll
@@ -1061,7 +1085,8 @@ __global__ __launch_bounds__(HUB_THREADS) void ld_refine_propose_hub_kernel(
     const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot, const int* __restrict__ ref,
     const int* __restrict__ refsize, const unsigned long long* __restrict__ Kref,
     const unsigned long long* __restrict__ Eref, double g, double inv_beta, int round, int n_cls, unsigned int salt,
-    unsigned int seed, int* __restrict__ target, int* __restrict__ err) {
+    unsigned int seed, int* __restrict__ target, int* __restrict__ err, const VertRec* __restrict__ vr,
+    const TargRec* __restrict__ tr) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long hub_smem[];
   BlockHash bh{reinterpret_cast<int*>(hub_smem + BHUB_SLOTS), hub_smem, BHUB_SLOTS};
   __shared__ Cand sh_c[HUB_THREADS / 64];
@@ -1086,8 +1111,9 @@ __global__ __launch_bounds__(HUB_THREADS) void ld_refine_propose_hub_kernel(
       __syncthreads();
       for (int e = threadIdx.x; e < deg; e += blockDim.x) {
         const int u = indices[beg + e];
-        if (u == v || comm[u] != a) continue;
-        const int c = ref[u];
+        const VertRec r = vr[u];
+        if (u == v || r.comm != a) continue;
+        const int c = r.ref;
         if (n_pass == 1) bh.add(c, wq[beg + e]);
         else if (bhub_class(c, n_pass) == pass && !bh.add_bounded(c, wq[beg + e])) *err = 1;
       }
@@ -1096,10 +1122,11 @@ __global__ __launch_bounds__(HUB_THREADS) void ld_refine_propose_hub_kernel(
         const int c = bh.keys[sl];
         if (c != WH_EMPTY && c != v) {
           const long long sum = (long long)bh.vals[sl];
-          const double Kr = (double)(long long)Kref[c];
-          const bool single = refsize[c] == 1;
+          const TargRec x = tr[c];
+          const double Kr = (double)(long long)x.Kref;
+          const bool single = x.refsize == 1;
           const bool ok_target = (!single || lm_class(c, salt, n_cls) != round) &&
-                                 ((double)(long long)Eref[c] >= g * Kr * (KC - Kr));
+                                 ((double)(long long)x.Eref >= g * Kr * (KC - Kr));
           const double gain = (double)sum - g * kv * Kr;
           if (ok_target && gain >= 0.0) {
             Cand x;
@@ -1124,7 +1151,8 @@ __global__ void ld_refine_apply_kernel(int n_cand, const int* __restrict__ list,
                                        const long long* __restrict__ k, int* __restrict__ ref,
                                        int* __restrict__ refsize, unsigned long long* __restrict__ Kref,
                                        unsigned long long* __restrict__ Eref, int* __restrict__ stamp, int round,
-                                       int* __restrict__ jlist, int* __restrict__ counters) {
+                                       int* __restrict__ jlist, int* __restrict__ counters, VertRec* __restrict__ vr,
+                                       TargRec* __restrict__ tr) {
   const int lane = threadIdx.x & 63;
   for (int w0 = blockIdx.x * blockDim.x; w0 < n_cand; w0 += gridDim.x * blockDim.x) {
     const int w = w0 + threadIdx.x;
@@ -1144,20 +1172,31 @@ __global__ void ld_refine_apply_kernel(int n_cand, const int* __restrict__ list,
       Kref[v] = 0;
       Eref[v] = 0;
       stamp[v] = round;
+      // the packed mirrors (v's community field does not change during the refinement)
+      vr[v].ref = t;
+      vr[v].stamp = round;
+      atomicAdd(&tr[t].refsize, 1);
+      atomicAdd(&tr[t].Kref, (unsigned long long)k[v]);
+      tr[v].Kref = 0;
+      tr[v].Eref = 0;
+      tr[v].refsize = 0;
       jlist[bj + __popcll(mj & ((1ull << lane) - 1ull))] = v;
     }
   }
 }
 
 __global__ void ld_refine_init_kernel(int n, const long long* __restrict__ k, const long long* __restrict__ a_in,
-                                      int* __restrict__ ref, int* __restrict__ refsize,
-                                      unsigned long long* __restrict__ Kref, unsigned long long* __restrict__ Eref) {
+                                      const int* __restrict__ comm, int* __restrict__ ref, int* __restrict__ refsize,
+                                      unsigned long long* __restrict__ Kref, unsigned long long* __restrict__ Eref,
+                                      VertRec* __restrict__ vr, TargRec* __restrict__ tr) {
   int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v < n) {
     ref[v] = v;
     refsize[v] = 1;
     Kref[v] = (unsigned long long)k[v];
     Eref[v] = (unsigned long long)a_in[v];  // singleton: w(v, C - v)
+    vr[v] = VertRec{comm[v], v, -1, 0};
+    tr[v] = TargRec{(unsigned long long)k[v], (unsigned long long)a_in[v], 1, 0, 0, 0};
   }
 }
 
@@ -2053,6 +2092,7 @@ struct LeidenBuffers {
   int* comm; int* csize; unsigned long long* Ktot;
   int* cls_lists; int* rlist; int* touched; int* hub_list;
   int* ref; int* target; int* target2; int* refsize; unsigned long long* Kref; unsigned long long* Eref; long long* a_in;
+  VertRec* vrec; TargRec* trec;  // packed mirrors of {comm, ref, stamp} and {Kref, Eref, refsize} for the refinement's gathers
   int* flag; int64_t* newid; int64_t* scan_tmp; int* cid; int* rep; int* comm_tmp;
   int* node_of; int* memb; int* memb_best;
   int* agg_col; long long* agg_w;  // scratch CSR of the coarse-graph build (rows at upper-bound offsets)
@@ -2099,6 +2139,8 @@ static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b
   b->Kref = ws.take<unsigned long long>(N);
   b->Eref = ws.take<unsigned long long>(N);
   b->a_in = ws.take<long long>(N);
+  b->vrec = ws.take<VertRec>(N);
+  b->trec = ws.take<TargRec>(N);
   b->flag = ws.take<int>(N);
   b->newid = ws.take<int64_t>(N + 1);
   b->scan_tmp = ws.take<int64_t>((size_t)scan_num_blocks(n) + 2);
@@ -2400,7 +2442,8 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
   else
     hipLaunchKernelGGL(ld_within_kernel<64>, GRIDW(g.n), 0, cx.s, g.n, g.indptr, g.indices, g.wq, b.comm, b.a_in);
   SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ld_refine_init_kernel, GRID1(g.n), 0, cx.s, g.n, g.k, b.a_in, b.ref, b.refsize, b.Kref, b.Eref);
+  hipLaunchKernelGGL(ld_refine_init_kernel, GRID1(g.n), 0, cx.s, g.n, g.k, b.a_in, b.comm, b.ref, b.refsize, b.Kref,
+                     b.Eref, b.vrec, b.trec);
   SCAMD_LAUNCH_CHECK();
   const int n_cls = rf_classes(cx, g.n);
   int* rc0 = b.rcounters;  // [0, MAX_CLASSES): class list lengths; then per sub-round c: [0] joiners, [4] hubs, [5] overflow
@@ -2430,41 +2473,45 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
     if (quad) {
       hipLaunchKernelGGL(ld_refine_propose_kernel<16>, dim3(qgrid), dim3(256), 0, cx.s, list, (const int*)nullptr,
                          (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref,
-                         b.Eref, gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.mid_list, b.hub_list, ctr, cnt);
+                         b.Eref, gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.mid_list, b.hub_list, ctr, cnt,
+                         b.vrec, b.trec);
       SCAMD_LAUNCH_CHECK();
       LD_DBG_SYNC(cx, "rf propose<16> n=%d class=%d cnt=%d", g.n, c, cnt);
       if (n_mid > 0) {
         hipLaunchKernelGGL(ld_refine_propose_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(n_mid, 4))), dim3(256), 0, cx.s, list,
                            (const int*)b.mid_list, (const int*)(ctr + 5), g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot,
                            b.ref, b.refsize, b.Kref, b.Eref, gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.mid_list,
-                           b.hub_list, ctr, cnt);
+                           b.hub_list, ctr, cnt, b.vrec, b.trec);
         SCAMD_LAUNCH_CHECK();
         LD_DBG_SYNC(cx, "rf propose<64> overflow n=%d class=%d", g.n, c);
       }
     } else {
       hipLaunchKernelGGL(ld_refine_propose_kernel<64>, dim3(wgrid), dim3(256), 0, cx.s, list, (const int*)nullptr,
                          (const int*)nullptr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref,
-                         b.Eref, gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.mid_list, b.hub_list, ctr, cnt);
+                         b.Eref, gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.mid_list, b.hub_list, ctr, cnt,
+                         b.vrec, b.trec);
       SCAMD_LAUNCH_CHECK();
       LD_DBG_SYNC(cx, "rf propose<64> n=%d class=%d cnt=%d", g.n, c, cnt);
     }
     if (n_hub > 0) {
       hipLaunchKernelGGL(ld_refine_propose_hub_kernel, dim3((unsigned)std::min(HUB_GRID, n_hub)), dim3(HUB_THREADS), HUB_LDS, cx.s,
                          b.hub_list, ctr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref,
-                         gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.counters + 7);
+                         gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.counters + 7, b.vrec, b.trec);
       SCAMD_LAUNCH_CHECK();
       LD_DBG_SYNC(cx, "rf propose hub n=%d class=%d", g.n, c);
     }
     hipLaunchKernelGGL(ld_refine_apply_kernel, dim3(tgrid), dim3(256), 0, cx.s, cnt, list, b.target, g.k, b.ref,
-                       b.refsize, b.Kref, b.Eref, b.touched, c, b.rlist, ctr);
+                       b.refsize, b.Kref, b.Eref, b.touched, c, b.rlist, ctr, b.vrec, b.trec);
     SCAMD_LAUNCH_CHECK();
     LD_DBG_SYNC(cx, "rf apply n=%d class=%d", g.n, c);
     if (quad)
       hipLaunchKernelGGL(ld_refine_cut_update_kernel<16>, dim3(qgrid), dim3(256), 0, cx.s, cnt, b.rlist, g.indptr,
-                         g.indices, g.wq, b.comm, b.ref, b.touched, b.a_in, c, b.Eref, (const int*)ctr);
+                         g.indices, g.wq, b.comm, b.ref, b.touched, b.a_in, c, b.Eref, (const int*)ctr,
+                         b.vrec, b.trec);
     else
       hipLaunchKernelGGL(ld_refine_cut_update_kernel<64>, dim3(wgrid), dim3(256), 0, cx.s, cnt, b.rlist, g.indptr,
-                         g.indices, g.wq, b.comm, b.ref, b.touched, b.a_in, c, b.Eref, (const int*)ctr);
+                         g.indices, g.wq, b.comm, b.ref, b.touched, b.a_in, c, b.Eref, (const int*)ctr,
+                         b.vrec, b.trec);
     SCAMD_LAUNCH_CHECK();
     LD_DBG_SYNC(cx, "rf cut update n=%d class=%d", g.n, c);
   }
