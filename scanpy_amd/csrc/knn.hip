@@ -45,6 +45,41 @@ typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 #else
 #define SCAMD_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #endif
+// event counters of the host emulation (tools/emu_knn_insertions.py counts what a query of the sweep costs in list
+// insertions -- no hardware counter sees that); nothing in the product build
+#ifdef SCAMD_EMU
+#define SCAMD_EMU_COUNT(i, n) (emu_user_counters[i] += (n))
+#else
+#define SCAMD_EMU_COUNT(i, n) ((void)0)
+#endif
+// Workgroup barrier that leaves LDS-DMA requests in flight: `__syncthreads()` carries a fence that waits for vmcnt(0), which
+// drains them.  SCAMD_BARRIER_VM(k): this wave's requests except the k youngest have landed (s_waitcnt vmcnt(k)), its LDS
+// reads and writes are done (lgkmcnt(0)), then the barrier -- what the OTHER waves requested and waited for the same way is
+// visible behind it.  SCAMD_BARRIER_LDS(): LDS traffic only.  The empty asm statements keep the compiler from moving memory
+// accesses across (the barrier builtin alone is not a memory barrier to it).  gfx9 s_waitcnt immediate: vmcnt in bits 3:0
+// (and 15:14), expcnt 6:4, lgkmcnt 11:8.  The host emulation of the tests (tests/emu/hip/hip_runtime.h: dma_issue) models
+// both extremes of when a request may land.
+#ifdef SCAMD_EMU
+#define SCAMD_BARRIER_VM(k) emu_barrier_vm(k)
+#define SCAMD_BARRIER_LDS() emu_barrier_lds()
+#define SCAMD_WAIT_VM0() ::emu::dma_land(0)
+#else
+#define SCAMD_BARRIER_VM(k)                          \
+  do {                                               \
+    asm volatile("" ::: "memory");                   \
+    __builtin_amdgcn_s_waitcnt(0x0070 | (k));        \
+    __builtin_amdgcn_s_barrier();                    \
+    asm volatile("" ::: "memory");                   \
+  } while (0)
+#define SCAMD_BARRIER_LDS()                          \
+  do {                                               \
+    asm volatile("" ::: "memory");                   \
+    __builtin_amdgcn_s_waitcnt(0xC07F);              \
+    __builtin_amdgcn_s_barrier();                    \
+    asm volatile("" ::: "memory");                   \
+  } while (0)
+#define SCAMD_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
+#endif
 
 constexpr int FALLBACK_CAP = 2048;    // collected rows per uncertified query
 constexpr int FALLBACK_CHUNK = 1024;  // uncertified queries processed per launch
@@ -386,7 +421,11 @@ struct RegCfg {
   static constexpr int TC = TC_, SUBS = TC_ / 32, NW = 4, QB = 128, NT = 256, KP = 32;
   static constexpr int TILE_BYTES = TC * DPL * 4;
   static constexpr int TILE_KB = TILE_BYTES / 1024;
-  static constexpr size_t LDS_BYTES = 2 * (size_t)TILE_BYTES;
+  // tile buffers in LDS: the float32 engine stages through registers into two; the bf16 engine's tiles arrive by LDS-DMA
+  // into a ring of three, two requests in flight behind the tile being scored (round 4: see `sweep`)
+  static constexpr bool GLDS = B3 && TC_ == 64;  // (the 128-candidate tiles of SCAMD_KNN_BIG_TILES keep the register staging)
+  static constexpr int NBUF = GLDS ? 3 : 2;
+  static constexpr size_t LDS_BYTES = NBUF * (size_t)TILE_BYTES;
   static_assert(TILE_BYTES % 1024 == 0, "tile must be a whole number of 1 KiB pieces");
   static_assert(!B3 || H == 25, "the bf16 engine is built for d <= 50");
 };
@@ -493,6 +532,14 @@ __global__ void knn_pack_image_kernel(const float* __restrict__ x, const float* 
 // More cells than this did not cut the evaluated pairs at 10M x 50 (isotropic 50-d blobs: the ball bound prunes at the
 // granularity of a blob, not of a cell) and the quantiser grows with the cell count; the order tables are n_cells^2 x 8 B
 constexpr int IVF_MAX_CELLS = 1024;
+// entries of a block's cell order whose tile range and lower bound are copied to LDS when the block starts (the sweep loop
+// then depends on no load but its tiles'; later entries are read from the tables)
+#ifdef SCAMD_EMU
+constexpr int IVF_META_CELLS = 4;   // (the host emulation of the tests refills often: its blocks sweep 5 - 16 cells)
+#else
+constexpr int IVF_META_CELLS = 64;
+#endif
+constexpr size_t IVF_META_BYTES = (size_t)IVF_META_CELLS * 3 * 4;
 
 struct IvfArgs {
   const int* qpos;          // [n_blocks * 128] image row of every query slot (-1 = padding)
@@ -511,7 +558,10 @@ struct IvfArgs {
   int prepass_cells;         // cells (own cell first, then by ascending lower bound) the pre-pass covers (SCAMD_KNN_PREPASS_CELLS, default 1)
   int prepass_min2;          // 1: the starting threshold is taken from the two smallest scores per lane (SCAMD_KNN_PREPASS_MIN2, default 1)
   int debug_no_insert;       // debug (SCAMD_KNN_DEBUG_NO_INSERT=1): survivors are dropped -- WRONG results, MFMA-side ceiling
-  unsigned long long* trace; // debug (SCAMD_KNN_TRACE=<file>): per block {start, end (100 MHz clock), tiles swept, hw id}
+  int cell_preload;          // 1: (bf16 engine) the tile requests run on into the next cell of the block's order while the
+                             // current cell's last tiles are scored (SCAMD_KNN_CELL_PRELOAD, default 1; 0: every cell starts cold)
+  unsigned long long* trace; // debug (SCAMD_KNN_TRACE=<file>): per block {start, end (100 MHz clock), tiles swept, hw id,
+                             // end of the prologue, end of the pre-pass, ticks inside the sweeps of the cells, cells swept}
   int n_cells, dc;          // dc = stride of `centers` (>= d)
   int d;
 };
@@ -640,10 +690,14 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
   // candidates j = lane (mod 32): 32 distinct candidates per query); the threshold derived from it seeds the list,
   // which the list threshold can only tighten (same lane layout as athr)
   bool minima = false;
+  // LDS buffer of tile t of the current sweep: the two buffers alternate / the ring of three goes round across sweeps
+  constexpr bool GLDS = C::GLDS;
+  int ring = 0;
+  auto buf_of = [&](int t) -> int { return GLDS ? (ring + t) % 3 : (t & 1); };
   // B operand of sub-tile g of the current sweep: lane l holds candidate (l&31), the same dim slice as A, then
   // the extra k slot
   auto load_b = [&](int g, BFrag& b) {
-    const float* tb = smem + ((g / SUBS) & 1) * TC * DPL;
+    const float* tb = smem + buf_of(g / SUBS) * TC * DPL;
     if constexpr (B3) {
       // row = 17 16-byte units: hi part units 0..7, lo part 8..15 (row stride 68 dwords = 4 mod 64: conflict free)
       const i32x4* p = reinterpret_cast<const i32x4*>(tb + ((g % SUBS) * 32 + l31) * DPL);
@@ -693,12 +747,15 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     const int ih = (r & 3) + 8 * (r >> 2) + 4 * h;      // this half's query = its lane of the threshold operand
     const float tu = -readlane_f32(athr_used, ih);
     const float sc = acc[r] + tu;                        // the float32 score again (+- 1 ulp)
+    if (lane == 0) SCAMD_EMU_COUNT(2, 1);                // [2] (register, half) groups with a survivor
     do {
       const int s = __builtin_ctz(bits);
+      if (lane == 0) SCAMD_EMU_COUNT(0, 1);              // [0] survivors of the sign test
       const int vb = __builtin_amdgcn_readlane(__float_as_int(sc), 32 * h + s);
       const int lastb = __builtin_amdgcn_readlane(__float_as_int(key[r]), 32 * h + 31);
       // (a survivor of a threshold one sub-tile old may no longer beat the list's largest entry)
       if (key_order(vb) < key_order(lastb)) {
+        if (lane == 0) SCAMD_EMU_COUNT(1, 1);            // [1] insertions
         const int slot = lastb & KEY_SLOT_MASK;          // the evicted entry's slot is reused
         const float kv = __int_as_float((vb & ~KEY_SLOT_MASK) | slot);
         idx[r] = scamd_llvm_writelane(cbase + s, 32 * h + slot, idx[r]);
@@ -751,6 +808,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     }
     if constexpr (IVF) {
       if (minima) {
+        if (lane == 0) SCAMD_EMU_COUNT(5, 1);  // [5] sub-tiles of the threshold pre-pass
 #pragma unroll
         for (int r = 0; r < 16; ++r) {  // the two smallest scores of the lane's candidate class: (key[r], idx[r] as float bits)
           idx[r] = __float_as_int(__builtin_amdgcn_fmed3f(key[r], __int_as_float(idx[r]), acc_prev[r]));
@@ -762,23 +820,56 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     if constexpr (IVF) {
       if (iv.debug_no_insert) return;
     }
+    if (lane == 0) {
+      SCAMD_EMU_COUNT(3, 1);              // [3] sub-tiles tested by a wave (32 queries x 32 candidates)
+      if (hit) SCAMD_EMU_COUNT(4, 1);     // [4] ... with at least one survivor
+    }
     if (hit) insert(acc_prev, athr_prev, row0 + (g - 1) * 32, false);
   };
 
   // staging registers: every wave moves NP 1-KiB pieces per tile; out-of-range piece ids are clamped (a duplicate
   // copy of the last piece) so that no load sits behind a branch (hipcc waits vmcnt(0) after a conditional load)
   constexpr int NP = (C::TILE_KB + C::NW - 1) / C::NW;
-  f32x4 st[NP];
+  f32x4 st[GLDS ? 1 : NP];
   int tile0 = 0;  // first tile of the current sweep
   auto gload = [&](int t) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xp) + (int64_t)(tile0 + t) * C::TILE_BYTES) + lane;
+    if constexpr (!GLDS) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xp) + (int64_t)(tile0 + t) * C::TILE_BYTES) + lane;
 #pragma unroll
-    for (int j = 0; j < NP; ++j) st[j] = src[min(wave + C::NW * j, C::TILE_KB - 1) * 64];
+      for (int j = 0; j < NP; ++j) st[j] = src[min(wave + C::NW * j, C::TILE_KB - 1) * 64];
+    }
   };
   auto lstore = [&](int buf) {
-    f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + buf * C::TILE_BYTES) + lane;
+    if constexpr (!GLDS) {
+      f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + buf * C::TILE_BYTES) + lane;
 #pragma unroll
-    for (int j = 0; j < NP; ++j) dst[min(wave + C::NW * j, C::TILE_KB - 1) * 64] = st[j];
+      for (int j = 0; j < NP; ++j) dst[min(wave + C::NW * j, C::TILE_KB - 1) * 64] = st[j];
+    }
+  };
+  // ---- bf16 engine: tiles by LDS-DMA into a ring of three buffers (round 4) ----
+  // The per-block trace of the pruned sweep (tools/knn_trace.py, profiles/r04r_*) put a block at 1.4-1.5 us per tile with the
+  // insertions dropped, against 0.8 us in the pre-pass over its own cell: with register staging a tile is requested at the
+  // barrier before the one it is stored at -- ONE request in flight per block, one tile per memory round trip when the tile
+  // comes from beyond L2 (other cells), the matrix pipe idle for the difference.  Here the image of a tile (global and LDS
+  // layouts are the same bytes) is requested by `global_load_lds_dwordx4` (1 KiB per wave instruction, NP per wave and tile)
+  // THREE tiles ahead of the one being scored: requested after barrier t - 3, waited for (this wave's NP youngest requests
+  // may stay outstanding) before barrier t - 1, read after it.  The stream does not stop at the end of a cell: the caller
+  // announces the next cell of the block's order (`next_tile0`, `next_n`) and its first tiles are requested behind this
+  // cell's last ones -- speculatively, the stopping rule may end the block first (the requests are drained before the
+  // block writes its results).  No staging registers, no ds_write pass.
+  int n_ahead = 0;                  // leading tiles of the sweep about to start that the previous sweep requested
+  int next_tile0 = -1, next_n = 0;  // the cell the caller sweeps next (-1: none announced)
+  auto request = [&](int tile, int buf) {
+    if constexpr (GLDS) {
+      static_assert(!GLDS || 2 * NP < 16, "the counted waits use the low vmcnt field only");
+      const char* src = reinterpret_cast<const char*>(xp) + (int64_t)tile * C::TILE_BYTES + lane * 16;
+      char* dst = reinterpret_cast<char*>(smem) + buf * C::TILE_BYTES;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int piece = min(wave + C::NW * j, C::TILE_KB - 1);  // (the clamp repeats the last piece: no branch)
+        __builtin_amdgcn_global_load_lds(src + piece * 1024, SCAMD_LDS_PTR(dst + piece * 1024), 16, 0, 0);
+      }
+    }
   };
 
   // Sweep over `n_tiles` consecutive tiles of the image starting at tile `t0`.  first = the block's very first
@@ -788,10 +879,32 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
     tile0 = t0;
     row0 = t0 * TC;
     n_sub = n_tiles * SUBS;
-    gload(0);
-    lstore(0);
-    if (n_tiles > 1) gload(1);
-    __syncthreads();
+    // (GLDS) stream position s of this sweep: its own tile s, or tile s - n_tiles of the announced next cell
+    auto exists = [&](int sp) -> bool { return sp < n_tiles || (next_tile0 >= 0 && sp - n_tiles < next_n); };
+    auto req = [&](int sp) {
+      if (exists(sp)) request(sp < n_tiles ? tile0 + sp : next_tile0 + (sp - n_tiles), (ring + sp) % 3);
+    };
+    if constexpr (GLDS) {
+      static_assert(!GLDS || SUBS == 2, "one barrier per tile");
+      if (n_ahead == 0) {
+        // nothing of this sweep is under way (the buffers are free: the caller's barrier): positions 0 .. 2, then tile 0
+        req(0);
+        req(1);
+        req(2);
+        if (exists(2)) SCAMD_BARRIER_VM(2 * NP);
+        else if (exists(1)) SCAMD_BARRIER_VM(NP);
+        else SCAMD_BARRIER_VM(0);
+      } else {
+        // tile 0 landed before the previous sweep's last barrier; what it did not request of positions 1 and 2 goes out now
+        if (n_ahead < 2) req(1);
+        if (n_ahead < 3) req(2);
+      }
+    } else {
+      gload(0);
+      lstore(0);
+      if (n_tiles > 1) gload(1);
+      __syncthreads();
+    }
     BFrag bA, bB;
     f32x16 accA, accB;
     float athrA = athr, athrB = athr;
@@ -815,11 +928,20 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
       if (IVF || h > 0 || !first) step(g, bA, accA, athrA, accB, athrB, bB);
       if ((h % HPT) == HPT - 1) {
         const int t = h / HPT;
-        if (t + 1 < n_tiles) lstore((t + 1) & 1);  // buffer of tile t-1: free since the previous barrier
-        // every wave has completed its reads of tile t except the last sub-tile (already in bB): after the barrier
-        // tile t+1 is visible and the staging registers are free for tile t+2
-        __syncthreads();
-        if (t + 2 < n_tiles) gload(t + 2);
+        if constexpr (GLDS) {
+          // position t + 1 has landed once this wave's requests for position t + 2 are the only ones outstanding; every wave
+          // has completed its reads of tile t except the last sub-tile (in bB): behind the barrier position t + 1 is
+          // visible and tile t's buffer takes position t + 3
+          if (exists(t + 2)) SCAMD_BARRIER_VM(NP);
+          else SCAMD_BARRIER_VM(0);
+          req(t + 3);
+        } else {
+          if (t + 1 < n_tiles) lstore((t + 1) & 1);  // buffer of tile t-1: free since the previous barrier
+          // every wave has completed its reads of tile t except the last sub-tile (already in bB): after the barrier
+          // tile t+1 is visible and the staging registers are free for tile t+2
+          __syncthreads();
+          if (t + 2 < n_tiles) gload(t + 2);
+        }
       }
       step(g + 1, bB, accB, athrB, accA, athrA, bA);
     }
@@ -837,6 +959,15 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
         insert(accB, athrB, row0 + (n_sub - 1) * 32, false);
       }
     }
+    if constexpr (GLDS) {  // the ring goes on where this sweep ends; positions n_tiles .. n_tiles + 2 are under way
+      ring = (ring + n_tiles) % 3;
+      n_ahead = next_tile0 >= 0 ? min(3, next_n) : 0;
+    }
+  };
+  // barrier between sweeps (LDS traffic only in the bf16 engine: requests for the next cell's tiles stay in flight)
+  auto block_sync = [&]() {
+    if constexpr (GLDS) SCAMD_BARRIER_LDS();
+    else __syncthreads();
   };
 
   if constexpr (!IVF) {
@@ -853,12 +984,35 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
   } else {
     // ---- cell order of this block: row a of the per-cell tables (ascending lower bound, own cell first), built once
     // per cell by ivf_cell_order_kernel instead of once per block ----
-    float* wmax = smem + 2 * TC * DPL;  // [4]
+    float* wmax = smem + C::NBUF * TC * DPL;  // [4]
     const unsigned long long trace_t0 = iv.trace ? wall_clock64() : 0ull;
     unsigned long long trace_tiles = 0;
     const int a = iv.block_cell[blk];
     const int* order = iv.order + (int64_t)a * iv.n_cells;
     const float* lb2 = iv.order_lb2 + (int64_t)a * iv.n_cells;
+    // the head of the order with its tile ranges -> LDS (one gather by wave 0, under the latency of the query operand's)
+    int* s_t0 = reinterpret_cast<int*>(wmax + 16);
+    int* s_nt = s_t0 + IVF_META_CELLS;
+    float* s_lb = reinterpret_cast<float*>(s_nt + IVF_META_CELLS);
+    // (entries c0 .. c0 + 63; the rare block that sweeps more than 64 cells refills the table -- the loop itself holds no
+    // pointer into the tables: they cost 20 scalar registers, spilled, when the loop could fall back to them)
+    auto meta_fill = [&](int c0) {
+      if (tid < IVF_META_CELLS) {
+        const int ci = c0 + tid;
+        const bool in = ci < iv.n_cells;
+        const int cb = in ? iv.order[(int64_t)a * iv.n_cells + ci] : 0;
+        s_lb[tid] = in ? iv.order_lb2[(int64_t)a * iv.n_cells + ci] : INFINITY;
+        s_t0[tid] = iv.cell_tile0[cb];
+        s_nt[tid] = iv.cell_ntiles[cb];
+      }
+      block_sync();
+    };
+    meta_fill(0);
+    auto meta_lb = [&](int ci) -> float { return s_lb[ci & (IVF_META_CELLS - 1)]; };
+    auto meta_t0 = [&](int ci) -> int { return s_t0[ci & (IVF_META_CELLS - 1)]; };
+    auto meta_nt = [&](int ci) -> int { return s_nt[ci & (IVF_META_CELLS - 1)]; };
+    // (the trace's intermediate stamps go straight to memory: no registers held across the sweeps for a debug mode)
+    if (iv.trace && tid == 0) iv.trace[(size_t)blk * 8 + 4] = wall_clock64();
     // exact threshold distance^2 of a query = thr (score space) + ||q||^2; per wave the max over its real queries
     // ||q||^2 sits in the extra k slot of the row's second half (B3: in the row's tail)
     const float qn = B3 ? xp[qrow * DPL + 64] : xp[qrow * DPL + HP + H];
@@ -879,19 +1033,23 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
       for (int r = 0; r < 16; ++r) idx[r] = __float_as_int(KEY_BIG);
       const int pre_tiles = min(iv.cell_ntiles[a], iv.prepass_tiles);
       if (tid == 0) atomicAdd(iv.pairs + 1, (unsigned long long)pre_tiles * TC * C::QB);  // counted apart: not useful work
+      // (the real sweep starts with the own cell's first tile again: requested under the pre-pass's last tile)
+      next_tile0 = (iv.cell_preload && iv.prepass_cells <= 1) ? meta_t0(0) : -1;
+      next_n = meta_nt(0);
       sweep(iv.cell_tile0[a], pre_tiles, false);
+      next_tile0 = -1;
       // round 4: the pre-pass may go on over the next nearest cells (iv.prepass_cells - 1 of them, whole cells).  The sweep
       // is bound by the instructions of the list insertions, not by the matrix pipe (counters: profiles/r04a_knn_pmc*.csv),
       // and an insertion-free pass over more candidates starts the lists nearer their final thresholds.
       for (int ci = 1; ci < iv.prepass_cells && ci < iv.n_cells; ++ci) {
         if (!(lb2[ci] < INFINITY)) break;
         const int pb = order[ci];
-        __syncthreads();
+        block_sync();
         if (tid == 0) atomicAdd(iv.pairs + 1, (unsigned long long)iv.cell_ntiles[pb] * TC * C::QB);
         sweep(iv.cell_tile0[pb], iv.cell_ntiles[pb], false);
       }
       minima = false;
-      __syncthreads();
+      block_sync();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         // bitonic sort of the 64 values of each half's query: element e = 32 j + l31, j = 0 in x (smallest per lane), j = 1
@@ -929,9 +1087,11 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
       }
       sync_thr();
     }
+    if (iv.trace && tid == 0) iv.trace[(size_t)blk * 8 + 5] = wall_clock64();
     bool first = true;
     for (int ci = 0; ci < iv.n_cells; ++ci) {
-      const float lb = lb2[ci];
+      if (ci > 0 && (ci & (IVF_META_CELLS - 1)) == 0) meta_fill(ci);  // (the sweep's closing barrier: nobody reads the old entries)
+      const float lb = meta_lb(ci);
       if (!(lb < INFINITY)) break;  // empty cells sort last
       if (ci > 0) {
         // athr = -thr on lanes 0..31.  thr lives in score space (||c||^2 - 2 q.c), where float32 carries an absolute
@@ -942,26 +1102,35 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) dthr = fmaxf(dthr, __shfl_xor(dthr, o));
         if (lane == 0) wmax[wave] = dthr;
-        __syncthreads();
+        block_sync();
         const float tmax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-        __syncthreads();  // wmax is rewritten at the next cell
+        block_sync();  // wmax is rewritten at the next cell
         // every remaining cell is at least this far: done once the bound clears every threshold (with slack for
         // the float32 rounding of thresholds and bounds)
         if (lb * (1.0f - 1e-3f) > tmax + 1e-3f * fabsf(tmax)) break;
       }
-      const int b = order[ci];
-      if (tid == 0) atomicAdd(iv.pairs, (unsigned long long)iv.cell_ntiles[b] * TC * C::QB);
-      trace_tiles += iv.cell_ntiles[b];
-      sweep(iv.cell_tile0[b], iv.cell_ntiles[b], first);
+      const int c_t0 = meta_t0(ci), c_nt = meta_nt(ci);
+      trace_tiles += c_nt;  // (also the block's count of evaluated pairs: one atomic when it is done)
+      // (no request across a refill of the table, nor past the last cell: the table's entries beyond n_cells are INF)
+      next_tile0 = (iv.cell_preload && ((ci + 1) & (IVF_META_CELLS - 1)) != 0 && meta_lb(ci + 1) < INFINITY) ? meta_t0(ci + 1) : -1;
+      next_n = meta_nt((ci + 1) & (IVF_META_CELLS - 1));
+      const unsigned long long ts = iv.trace ? wall_clock64() : 0ull;
+      sweep(c_t0, c_nt, first);
       first = false;
-      __syncthreads();  // all fragment reads of this cell are done before the next sweep restages the tiles
+      block_sync();  // all fragment reads of this cell are done before the next sweep restages the tiles
+      if (iv.trace && tid == 0) {
+        iv.trace[(size_t)blk * 8 + 6] += wall_clock64() - ts;
+        iv.trace[(size_t)blk * 8 + 7] += 1ull;
+      }
     }
+    if constexpr (GLDS) SCAMD_WAIT_VM0();  // (requests for a cell the stopping rule skipped)
+    if (tid == 0) atomicAdd(iv.pairs, trace_tiles * TC * C::QB);
     if (iv.trace && tid == 0) {
       unsigned int hw;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
       unsigned int xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      unsigned long long* tr = iv.trace + (size_t)blk * 4;
+      unsigned long long* tr = iv.trace + (size_t)blk * 8;
       tr[0] = trace_t0;
       tr[1] = wall_clock64();
       tr[2] = trace_tiles;
@@ -2321,11 +2490,14 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   // 96 / 236 bytes per lane to scratch, `-Rpass-analysis=kernel-resource-usage`); SCAMD_KNN_IVF_WPS=2 selects the
   // build cut for 2 blocks per CU (no spills) -- an A/B switch until both have been measured
   const char* wps_env = getenv("SCAMD_KNN_IVF_WPS");
-  // (bf16 engine: 193 VGPRs = 2 blocks per CU by default; SCAMD_KNN_IVF_WPS=3 selects the build cut for 3)
-  auto kern = B3 ? ((wps_env && atoi(wps_env) == 3) ? knn_select_reg_kernel<H, 64, 3, true, B3> : knn_select_reg_kernel<H, 64, 2, true, B3>)
+  // (bf16 engine, round 4: with its tiles arriving by LDS-DMA the staging registers are gone -- 175 VGPRs uncut, 5 of them
+  // spilled in the build cut for 3 blocks per CU (was 47), and 3 x 53 KB of LDS just fit the CU's 160: 13.31 ms against
+  // 16.11 with 2 blocks on one box, profiles/r04s_knn_lds_dma_ring_ab.log -- a third block covers the other two's insertion
+  // stalls.  SCAMD_KNN_IVF_WPS=2 selects the uncut build)
+  auto kern = B3 ? ((wps_env && atoi(wps_env) == 2) ? knn_select_reg_kernel<H, 64, 2, true, B3> : knn_select_reg_kernel<H, 64, 3, true, B3>)
                  : ((wps_env && atoi(wps_env) == 2) ? knn_select_reg_kernel<H, 64, 2, true, false>
                                                      : knn_select_reg_kernel<H, 64, 3, true, false>);
-  const size_t lds = C::LDS_BYTES + 64;
+  const size_t lds = C::LDS_BYTES + 64 + IVF_META_BYTES;
   SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
   IvfArgs iv;
@@ -2358,11 +2530,15 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
     const char* e = getenv("SCAMD_KNN_DEBUG_NO_INSERT");
     iv.debug_no_insert = (e && e[0] == '1') ? 1 : 0;
   }
+  {
+    const char* e = getenv("SCAMD_KNN_CELL_PRELOAD");  // A/B switch: 0 = every cell's sweep requests its first tile itself
+    iv.cell_preload = (e && e[0] == '0') ? 0 : 1;
+  }
   iv.trace = nullptr;
   const char* trace_path = getenv("SCAMD_KNN_TRACE");  // debug: per-block timeline of the sweep, dumped to this file
   if (trace_path && trace_path[0]) {
-    SCAMD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&iv.trace), sizeof(unsigned long long) * 4 * n_blocks));
-    SCAMD_HIP_CHECK(hipMemsetAsync(iv.trace, 0, sizeof(unsigned long long) * 4 * n_blocks, s));
+    SCAMD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&iv.trace), sizeof(unsigned long long) * 8 * n_blocks));
+    SCAMD_HIP_CHECK(hipMemsetAsync(iv.trace, 0, sizeof(unsigned long long) * 8 * n_blocks, s));
   }
   SCAMD_HIP_CHECK(hipEventRecord(ev0, s));
   hipLaunchKernelGGL(kern, dim3(n_launch), dim3(C::NT), lds, s, b.xp, (int)(rows / 64), rows, q_begin, p.thr_rank,
@@ -2370,7 +2546,7 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   SCAMD_LAUNCH_CHECK();
   SCAMD_HIP_CHECK(hipEventRecord(ev1, s));
   if (iv.trace) {
-    std::vector<unsigned long long> h((size_t)4 * n_blocks);
+    std::vector<unsigned long long> h((size_t)8 * n_blocks);
     SCAMD_HIP_CHECK(hipMemcpyAsync(h.data(), iv.trace, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, s));
     SCAMD_HIP_CHECK(hipStreamSynchronize(s));
     SCAMD_HIP_CHECK(hipFree(iv.trace));
@@ -2460,7 +2636,7 @@ static int run_ivf_tier2(const KnnPlan& p, const KnnBuffers& b, const float* x, 
   T2_DBG(__LINE__);
   }
   auto kern = knn_select_reg_kernel<25, 64, 3, true, false>;
-  const size_t lds = C::LDS_BYTES + 64;
+  const size_t lds = C::LDS_BYTES + 64 + IVF_META_BYTES;
   SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
   IvfArgs iv;
@@ -2483,6 +2659,7 @@ static int run_ivf_tier2(const KnnPlan& p, const KnnBuffers& b, const float* x, 
   iv.prepass_cells = 1;
   iv.prepass_min2 = 1;
   iv.debug_no_insert = 0;
+  iv.cell_preload = 1;
   iv.trace = nullptr;
   const int thr_rank = std::min(32, std::max(1, k + 6));
   hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(C::NT), lds, s, b.xp2, (int)(rows / 64), rows, q_begin, thr_rank, b.cand_idx,

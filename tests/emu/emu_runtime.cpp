@@ -36,6 +36,7 @@ extern "C" void __asan_unpoison_memory_region(void const volatile* addr, size_t 
 namespace emu {
 
 Lane* g_cur = nullptr;
+int g_dma_late = 0;
 
 namespace {
 enum State { RUNNABLE = 0, WAIT_WAVE = 1, WAIT_BLOCK = 2, DONE = 3 };
@@ -90,6 +91,7 @@ void fibre_main() {
   __sanitizer_finish_switch_fiber(nullptr, &g_sched_bottom, &g_sched_size);
 #endif
   g_tramp(g_closure);
+  dma_land(0);  // (a wave does not end with memory operations outstanding)
   Lane* me = g_cur;
   me->state = DONE;
   --g_live_block;
@@ -297,6 +299,7 @@ void launch_body(dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void
           l.wave = t >> 6;
           l.lane = t & 63;
           l.state = RUNNABLE;
+          l.n_dma = 0;
           init_fibre(&l, t);
         }
         while (g_live_block > 0) {
@@ -506,5 +509,13 @@ long long emu_launches() { return emu::g_stats.launches; }
 long long emu_partial_collectives() { return emu::g_stats.partial_collectives; }
 long long emu_mixed_collectives() { return emu::g_stats.mixed_collectives; }
 long long emu_reads_of_inactive_lanes() { return emu::g_stats.reads_of_inactive; }
-void emu_reset_stats() { emu::g_stats = emu::Stats{}; }
+// event counters a kernel may bump under `#ifdef SCAMD_EMU` (tests/emu/hip/hip_runtime.h declares the array): what the
+// hardware counters cannot say, e.g. how many list insertions a query of the kNN sweep costs (tools/emu_knn_insertions.py)
+void emu_set_dma_late(int late) { emu::g_dma_late = late; }
+long long emu_user_counters[16] = {0};
+long long emu_user_counter(int i) { return i >= 0 && i < 16 ? emu_user_counters[i] : -1; }
+void emu_reset_stats() {
+  emu::g_stats = emu::Stats{};
+  for (long long& c : emu_user_counters) c = 0;
+}
 }

@@ -28,6 +28,8 @@ def load(asan: bool = False) -> C.CDLL:
         fn.restype, fn.argtypes = res, args
     for name in ("emu_launches", "emu_partial_collectives", "emu_mixed_collectives", "emu_reads_of_inactive_lanes"):
         getattr(lib, name).restype = C.c_longlong
+    lib.emu_user_counter.restype, lib.emu_user_counter.argtypes = C.c_longlong, (C.c_int,)
+    lib.emu_set_dma_late.restype, lib.emu_set_dma_late.argtypes = None, (C.c_int,)
     return lib
 
 
@@ -48,6 +50,11 @@ def _ws(nbytes: int):
 def stats(lib) -> dict:
     return {"launches": lib.emu_launches(), "partial_collectives": lib.emu_partial_collectives(),
             "mixed_collectives": lib.emu_mixed_collectives(), "reads_of_inactive_lanes": lib.emu_reads_of_inactive_lanes()}
+
+
+def user_counters(lib, n: int = 16) -> list:
+    """the event counters the kernels bump under SCAMD_EMU (emu_runtime.cpp: emu_user_counters)"""
+    return [int(lib.emu_user_counter(i)) for i in range(n)]
 
 
 def fuzzy_simplicial_set(lib, idx, dist):

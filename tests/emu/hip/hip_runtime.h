@@ -108,8 +108,36 @@ struct Lane {
   ComputeAll fn;
   const void* uniform;
   Arrived arr;
+  // LDS-DMA requests of this lane that have not landed yet (EMU_DMA=late, see dma_issue)
+  struct Dma { void* dst; const void* src; int size; } dma[96];
+  int n_dma;
 };
 extern Lane* g_cur;
+// LDS-DMA (`__builtin_amdgcn_global_load_lds`): on the hardware the bytes land some time between the request and the
+// `s_waitcnt vmcnt(k)` that covers it.  Two legal extremes are emulated: EMU_DMA=early (default) copies at the request --
+// a request into a buffer somebody still reads corrupts that read (write-after-read hazards show); EMU_DMA=late
+// (emu_set_dma_late(1)) copies at the wait that retires the request -- SCAMD_BARRIER_VM(k) lands all but the lane's k
+// youngest, `__syncthreads()` (whose fence waits for vmcnt(0)) and the end of the kernel land everything -- so that a read
+// placed before its wait sees the OLD bytes (read-after-write hazards show).  The tests run the kNN both ways.
+extern int g_dma_late;
+static inline void dma_land(int keep) {
+  Lane* me = g_cur;
+  const int n = me->n_dma - keep;
+  for (int i = 0; i < n; ++i) memcpy(me->dma[i].dst, me->dma[i].src, (size_t)me->dma[i].size);
+  if (n > 0) {
+    for (int i = n; i < me->n_dma; ++i) me->dma[i - n] = me->dma[i];
+    me->n_dma -= n;
+  }
+}
+static inline void dma_issue(void* dst, const void* src, int size) {
+  Lane* me = g_cur;
+  if (!g_dma_late) {
+    memcpy(dst, src, (size_t)size);
+    return;
+  }
+  if (me->n_dma == 96) dma_land(95);  // (more outstanding requests than the counter could hold: the oldest has landed)
+  me->dma[me->n_dma++] = Lane::Dma{dst, src, size};
+}
 // (convergent + noduplicate: the host compiler must treat a rendezvous as the device compiler treats a cross-lane
 // instruction -- never clone it into the two arms of a branch: each clone would be a call site of its own and the lanes of
 // the two arms would stop meeting)
@@ -167,6 +195,9 @@ template <typename T> EMU_INL T shfl_from(T v, int src_lane) {  // src_lane: abs
 }
 }  // namespace emu
 
+// event counters of the kernels (emu_runtime.cpp); SCAMD_EMU_COUNT(i, n) in kernel code, a no-op in the product build
+extern "C" long long emu_user_counters[16];
+
 #define threadIdx (::emu::g_cur->tidx)
 #define blockIdx (::emu::g_cur->bidx)
 #define blockDim (::emu::g_cur->bdim)
@@ -174,7 +205,16 @@ template <typename T> EMU_INL T shfl_from(T v, int src_lane) {  // src_lane: abs
 #define warpSize 64
 #define hipLaunchKernelGGL(...) ::emu::launch_ggl(__VA_ARGS__)
 
-static inline void __syncthreads() { ::emu::block_barrier(); }
+static inline void __syncthreads() {
+  ::emu::dma_land(0);  // (the fence of __syncthreads waits for vmcnt(0): pending LDS-DMA lands first)
+  ::emu::block_barrier();
+}
+// barrier that leaves the lane's `keep` youngest LDS-DMA requests in flight / LDS traffic only (csrc: SCAMD_BARRIER_VM / _LDS)
+static inline void emu_barrier_vm(int keep) {
+  ::emu::dma_land(keep);
+  ::emu::block_barrier();
+}
+static inline void emu_barrier_lds() { ::emu::block_barrier(); }
 static inline unsigned long long wall_clock64() { return 0ull; }
 static inline long long clock64() { return 0ll; }
 static inline void __threadfence() {}
@@ -381,12 +421,13 @@ EMU_INL f64x4_t mfma_f64_16x16x4(double a, double b, f64x4_t c) {
 #define __builtin_amdgcn_wave_barrier() ::emu::wave_barrier()
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_sched_barrier(a) ((void)0)
-#define __builtin_amdgcn_s_waitcnt(a) ((void)0)
+// (gfx9 encoding: vmcnt = bits 3:0 and 15:14 -- the lane's LDS-DMA requests beyond that many youngest have landed)
+#define __builtin_amdgcn_s_waitcnt(a) ::emu::dma_land(((a) & 0xF) | ((((a) >> 14) & 3) << 4))
 #define __builtin_amdgcn_s_setprio(a) ((void)0)
 // LDS-DMA: lane l's `size` bytes land at the wave-uniform base + l * size (the destination pointer of the first lane is
 // the base; every lane passes the same one)
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) \
-  ((void)memcpy(reinterpret_cast<char*>(l) + (off) + ::emu::g_cur->lane * (size), reinterpret_cast<const char*>(g), (size)))
+  ::emu::dma_issue(reinterpret_cast<char*>(l) + (off) + ::emu::g_cur->lane * (size), reinterpret_cast<const char*>(g), (size))
 #define __builtin_amdgcn_logf(x) log2f(x)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_fmed3f(a, b, c) fmaxf(fminf((a), (b)), fminf(fmaxf((a), (b)), (c)))

@@ -100,6 +100,31 @@ def test_knn_both_engines_brute_and_pruned(emu, monkeypatch, n, d, env):
     assert st["partial_collectives"] == st["mixed_collectives"] == st["reads_of_inactive_lanes"] == 0, st
 
 
+@pytest.mark.parametrize("ivf", ["1", "0"])
+def test_knn_lds_dma_ring_with_late_landing(emu, monkeypatch, ivf):
+    """the bf16 engine's tile ring (three LDS buffers filled by LDS-DMA, two requests in flight across the barrier): the
+    emulator lands every request as LATE as the kernel's counted waits allow (a read placed before its wait sees the old
+    bytes) -- the default run of the other tests lands them at once (a request into a buffer still being read corrupts it).
+    Both must give the float64 brute force; cells of 512 rows and a 4-entry order table make the blocks cross many cells"""
+    from oracle import compare as cmp
+
+    H, lib = emu
+    monkeypatch.setenv("SCAMD_KNN_IVF", ivf)
+    monkeypatch.setenv("SCAMD_KNN_CELL_ROWS", "512")
+    n = 4500 if ivf == "1" else 1700
+    x = _blobs(n, 50, 8, 77, spread=3.0)
+    ei, ed = oknn.knn_exact_f64(x, np.arange(n), 15)
+    try:
+        for late in (1, 0):
+            lib.emu_set_dma_late(late)
+            idx, dist, n_fallback = H.knn(lib, x, 15)
+            assert lib.scamd_knn_last_select_engine() == 1
+            bad, _ = cmp.knn_rows_differing_beyond_ties(idx, dist, ei, ed)
+            assert bad == 0 and n_fallback == 0, (late, bad, n_fallback)
+    finally:
+        lib.emu_set_dma_late(0)
+
+
 def test_knn_float64_fallback_scan(emu):
     """cert_scale = 1e30: no query can be certified, every one goes through the float64 scan"""
     from oracle import compare as cmp

@@ -42,9 +42,9 @@ def main():
     lib = _lib.load()
     sel_ms, pairs = float(lib.scamd_knn_last_select_ms()), float(lib.scamd_knn_last_select_pairs())
     raw = np.fromfile(path, dtype=np.uint8)
-    nb = raw.size // 36
-    tr = raw[: nb * 32].view(np.uint64).reshape(nb, 4)
-    cell = raw[nb * 32: nb * 36].view(np.int32)
+    nb = raw.size // 68  # per block 8 x uint64 (knn.hip: IvfArgs::trace), then the block's cell as int32
+    tr = raw[: nb * 64].view(np.uint64).reshape(nb, 8)
+    cell = raw[nb * 64: nb * 68].view(np.int32)
     t0, t1, tiles = tr[:, 0].astype(np.int64), tr[:, 1].astype(np.int64), tr[:, 2].astype(np.int64)
     xcc = (tr[:, 3] >> np.uint64(32)).astype(np.int64) & 0xF
     base = t0.min()
@@ -80,6 +80,22 @@ def main():
     # order of work: are long blocks late?
     order = np.argsort(t0)
     q = np.array_split(order, 10)
+    # where a block's time goes: prologue (query operand, order table), pre-pass + sort, the cells' sweeps, the rest
+    # (stopping rule between the cells, final write)
+    pro = (tr[:, 4].astype(np.int64) - tr[:, 0].astype(np.int64)) / 100.0
+    pre = (tr[:, 5].astype(np.int64) - tr[:, 4].astype(np.int64)) / 100.0
+    swp = tr[:, 6].astype(np.int64) / 100.0
+    ncell = tr[:, 7].astype(np.int64)
+    rest = dur - pro - pre - swp
+    print(f"per block (median / mean, us): prologue {np.median(pro):.1f} / {pro.mean():.1f}, pre-pass + sort {np.median(pre):.1f} / {pre.mean():.1f}, "
+          f"sweeps {np.median(swp):.1f} / {swp.mean():.1f}, rest {np.median(rest):.1f} / {rest.mean():.1f}; cells swept {np.median(ncell):.0f} / {ncell.mean():.1f} "
+          f"(tiles per cell {tiles.sum() / max(ncell.sum(), 1):.1f})")
+    print(f"share of the blocks' time: prologue {pro.sum() / dur.sum():.3f}, pre-pass {pre.sum() / dur.sum():.3f}, sweeps {swp.sum() / dur.sum():.3f}, "
+          f"rest {rest.sum() / dur.sum():.3f}; tiles per us inside the sweeps {tiles.sum() / swp.sum():.3f}")
+    # a sweep's fixed cost: least squares of the per-block sweep time on (cells, tiles)
+    A = np.stack([ncell.astype(np.float64), tiles.astype(np.float64)], axis=1)
+    coef, *_ = np.linalg.lstsq(A, swp, rcond=None)
+    print(f"sweep time ~ {coef[0]:.2f} us per cell + {coef[1]:.3f} us per tile ({1.0 / coef[1]:.3f} tiles per us once a sweep runs)")
     print("median tiles per block by start-time decile:", [int(np.median(tiles[i])) for i in q])
     print("median duration (us) by start-time decile:", [int(np.median(dur[i])) for i in q])
 
