@@ -12,8 +12,9 @@ PMC1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_
 PMC2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE"
 cd /tmp
 i=0
-for P in "$PMC1" "$PMC2" "FETCH_SIZE" "WRITE_SIZE"; do
+for P in "$PMC1" "SKIP" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
+  [ "$P" = "SKIP" ] && continue
   timeout -k 5 200 rocprofv3 --kernel-trace --output-format csv --kernel-include-regex 'knn_select_reg' --pmc $P -d /tmp/pmc_${TAG}_$i -o knn -- python "$R/tools/knn_only.py" 1000000 1 > "$OUT/pmc$i.log" 2>&1 < /dev/null
   echo "pmc$i rc=$? $(grep 'knn n=' "$OUT/pmc$i.log" | tail -1 | sed 's/.*select/select/' | cut -c1-40)"
   find /tmp/pmc_${TAG}_$i -name '*counter_collection.csv' -exec cp {} "$OUT/knn_pmc$i.csv" \;
@@ -33,16 +34,17 @@ for f in sorted(glob.glob(sys.argv[1] + "/knn_pmc*.csv")):
             acc[r["Counter_Name"]] += float(r["Counter_Value"])
     print(f.split("/")[-1], gmax, {k: f"{v:.4g}" for k, v in acc.items()})
 PY
-timeout -k 5 900 python -m pytest tests -m gpu -q -p no:faulthandler > "$OUT/pytest_gpu.log" 2>&1 < /dev/null
-echo "pytest rc=$?"; tail -2 "$OUT/pytest_gpu.log" | cut -c1-200
-timeout -k 5 120 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1 < /dev/null
-echo "smoke rc=$?"; tail -1 "$OUT/smoke.log"
 timeout -k 5 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err" < /dev/null
 echo "bench rc=$?"; tail -2 "$OUT/bench.err" | cut -c1-300
 cd /tmp
 timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python "$R/bench.py" --steps 3 --warmup 1 --cpu-sizes 0 --no-noise-variant --h2h-reps 0 --no-side > "$OUT/bench_prof.log" 2>&1 < /dev/null
 echo "bench prof rc=$?"
 find /tmp/prof_$TAG -name '*kernel_stats.csv' -exec cp {} "$OUT/bench_kernel_stats.csv" \;
+cd "$R"
+timeout -k 5 900 python -m pytest tests -m gpu -q -p no:faulthandler > "$OUT/pytest_gpu.log" 2>&1 < /dev/null
+echo "pytest rc=$?"; tail -2 "$OUT/pytest_gpu.log" | cut -c1-200
+timeout -k 5 120 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1 < /dev/null
+echo "smoke rc=$?"; tail -1 "$OUT/smoke.log"
 cd "$R"
 python - "$OUT" <<'PY'
 import json, sys
@@ -59,3 +61,8 @@ try:
 except Exception as exc:  # noqa: BLE001
     print("no bench line:", exc)
 PY
+
+# informational A/Bs with whatever GPU time is left (every run bounded; nothing below feeds the numbers above)
+for K in "SCAMD_KNN_THR_MARGIN=6" "SCAMD_KNN_THR_MARGIN=10" "SCAMD_KNN_PREPASS_TILES=32" "SCAMD_KNN_PREPASS_TILES=8" "SCAMD_KNN_IVF_WPS=2" ""; do
+  echo "[$K] $(env $K timeout -k 5 60 python tools/knn_only.py 1000000 3 2>&1 | grep 'knn n=' | tail -1 | cut -c1-200)" | tee -a "$OUT/knn_knobs.log"
+done
