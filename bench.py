@@ -758,7 +758,7 @@ def main() -> None:
                                 "rank with an all-to-all of the directed edges; leiden on rank 0"),
             },
             "roofline": {
-                "kernel": ("knn_select_reg_kernel<25,64,2,IVF,B3> (v_mfma_f32_32x32x16_bf16 x 12 per 32x32 sub-tile: hi.hi + hi.lo + "
+                "kernel": ("knn_select_reg_kernel<25,64,3,IVF,B3> (v_mfma_f32_32x32x16_bf16 x 12 per 32x32 sub-tile: hi.hi + hi.lo + "
                            "lo.hi of the bf16 split), exact cell-pruned sweep" if engine == 1 else
                            "knn_select_reg_kernel<25,64,3> (v_mfma_f32_32x32x2_f32), exact cell-pruned sweep"),
                 "engine": "bf16x3" if engine == 1 else "f32",
