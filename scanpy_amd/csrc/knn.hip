@@ -554,7 +554,7 @@ struct IvfArgs {
   unsigned long long* pairs; // (query, candidate) pairs evaluated, for the roofline figure
   const int* block_perm;     // [n_blocks] launch slot -> block: cells with the longest expected sweep first (LPT)
   int* qorder;               // [n_blocks * 128] out (may be null): query number (row - q_begin) of every query slot, -1 = padding
-  int prepass_tiles;         // tiles of the own cell the threshold pre-pass scores (SCAMD_KNN_PREPASS_TILES, default 16)
+  int prepass_tiles;         // tiles of the own cell the threshold pre-pass scores (SCAMD_KNN_PREPASS_TILES, default 32 bf16 / 16 float32)
   int prepass_cells;         // cells (own cell first, then by ascending lower bound) the pre-pass covers (SCAMD_KNN_PREPASS_CELLS, default 1)
   int prepass_min2;          // 1: the starting threshold is taken from the two smallest scores per lane (SCAMD_KNN_PREPASS_MIN2, default 1)
   int debug_no_insert;       // debug (SCAMD_KNN_DEBUG_NO_INSERT=1): survivors are dropped -- WRONG results, MFMA-side ceiling
