@@ -770,12 +770,14 @@ __global__ __launch_bounds__(1024) void ld_compact_cls_kernel(int n, int* __rest
 }
 
 // Packed mirrors of the refinement's state (round 4).  Counters of the decision kernels (profiles/r04n_leiden_kernels_pmc*.csv):
-// ld_refine_propose_kernel<16> waits 55 % of its wave-cycles on memory and moves 0.7 GB through the memory side of L2 per
-// launch of ~90k candidates -- 7.7 KB per candidate, i.e. a 64-byte sector for every 4- or 8-byte gather of comm[u], ref[u]
-// (two per neighbour) and Kref[c], refsize[c], Eref[c] (three per distinct target), at an L2 hit rate of 24 %: the kernels
-// run at the fabric's bandwidth, fetching sectors of which they use a sixteenth.  The proposing kernels and the cut update
-// therefore read ONE record per neighbour and ONE per target; the plain arrays stay the authoritative copy for everything
-// else (aggregation, coarse ids), every writer of the refinement updates both.  All fields are integers: same results.
+// ld_refine_propose_kernel<16> waits 55 % of its wave-cycles on memory and moves 0.7 GB (FETCH_SIZE with the gfx950
+// correction) through the memory side of L2 per launch of ~100k candidates -- ~7 KB per candidate: a 64-byte sector for every
+// 4- or 8-byte gather of comm[u], ref[u] (two per neighbour) and Kref[c], refsize[c], Eref[c] (three per distinct target),
+// at an L2 hit rate of 24 %.  The proposing kernels and the cut update therefore read ONE record per neighbour and ONE per
+// target; the plain arrays stay the authoritative copy for everything else (aggregation, coarse ids), every writer of
+// the refinement updates both.  All fields are integers: same results.  Measured: 31.3 -> 30.6 ms on the planted 1M graph
+// (profiles/r04p_leiden_packed_records_ab.log) -- less than the sector count promised: the kernels wait on the length of
+// their dependency chain as much as on the bytes.
 struct alignas(16) VertRec {  // per vertex: phase-1 community, refined community, sub-round in which it joined (-1: never)
   int comm, ref, stamp, pad;
 };
