@@ -6,6 +6,7 @@ from pathlib import Path
 from types import SimpleNamespace
 
 import numpy as np
+from scipy import sparse
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
@@ -46,6 +47,7 @@ def test_clean_result_passes_every_gate(chain):
     assert out["knn"]["rows_differing_beyond_ties"] == 0 and out["knn"]["self_first_rows"] == 1.0
     assert out["connectivities"]["sample_max_abs"] <= 1e-6 and out["connectivities"]["sample_entries"] > 1000
     assert out["leiden"]["disconnected_communities"] == 0 and out["leiden"]["modularity_abs_err"] < 1e-9
+    assert out["leiden"]["improving_moves"] == 0 and out["leiden"]["mergeable_pairs"] == 0  # (the oracle's stable partition)
     assert out["pca"]["scores_sample_rel_err"] < 1e-4
 
 
@@ -87,6 +89,13 @@ def test_each_corruption_is_named(chain):
             break
     got = _run(_copy(res, labels=lab), x, n, k)["failed_gates"]
     assert "disconnected_communities" in got
+    # a community cut in two halves (relabelled consistently, modularity recomputed): the halves are mergeable with a gain
+    lab = res.labels.copy()
+    big = np.flatnonzero(lab == 0)
+    lab[big[: big.size // 2]] = lab.max() + 1
+    got = _run(_copy(res, labels=lab, n_communities=int(lab.max()) + 1, modularity=ol.modularity(
+        sparse.csr_matrix((res.conn_data, res.conn_indices, res.conn_indptr), shape=(n, n)), lab)), x, n, k)["failed_gates"]
+    assert "leiden_mergeable_pairs" in got and "leiden_improving_moves" in got
     # loadings scaled: not orthonormal, scores no longer theirs
     got = _run(_copy(res, components=res.components * 1.01), x, n, k)["failed_gates"]
     assert "pca_orthonormality_err" in got and "pca_scores_sample_rel_err" in got

@@ -158,6 +158,10 @@ def test_leiden_reaches_the_oracles_modularity(emu, monkeypatch, small):
     assert abs(H.modularity(lib, conn, memb) - q) < 1e-12
     st = H.stats(lib)
     assert st["partial_collectives"] == st["mixed_collectives"] == st["reads_of_inactive_lanes"] == 0, st
+    # the paper's guarantees for a stable partition (oracle/leiden_guarantees.py): no vertex move, no merge improves it
+    from oracle import leiden_guarantees as lg
+
+    assert lg.improving_moves(conn, memb)["count"] == 0 and lg.mergeable_pairs(conn, memb)["count"] == 0
 
 
 def test_leiden_hub_rows(emu):
