@@ -15,6 +15,8 @@ Pinning status (see DESIGN.md "Oracle"):
   * connectivities  -- PINNED: restatement of umap-learn 0.5.x fuzzy_simplicial_set (not in the
                        container) anchored on tests/test_neighbors.py:43-48 and on the bundled
                        pbmc68k_reduced fixture (stored distances -> stored connectivities).
+  * leiden_guarantees -- checkers for what the Leiden paper proves of a stable partition (node optimality,
+                       g-separation); the oracle meets both exactly (tests/test_leiden_guarantees_cpu.py).
   * leiden          -- PARITY UNPINNED at label level: igraph/leidenalg are absent and the
                        reference ships no golden labels (tests/test_clustering.py only pins
                        determinism, NMI>0.9 across flavors, and modularity).  `oracle/leiden.c`

@@ -16,6 +16,9 @@
  *   Q = 1/(2m) sum_ij (A_ij - gamma k_i k_j / (2m)) delta(c_i, c_j)
  * PARITY UNPINNED at label level: the reference ships no golden labels
  * (tests/test_clustering.py:67-163 pin determinism, seed sensitivity and NMI > 0.9 only).
+ * Pinned instead to what the paper PROVES of any correct implementation (section "Guarantees"): after a stable
+ * iteration no single vertex move and no merge of two communities improves the quality, every community is connected --
+ * oracle/leiden_guarantees.py, tests/test_leiden_guarantees_cpu.py (0 violations on every graph tried).
  * Output ids are consecutive and ordered by decreasing community size (leidenalg convention).
  *
  * Input: symmetric CSR (both (i,j) and (j,i) stored) as src/scanpy/_utils/__init__.py:278-304
