@@ -2,6 +2,7 @@
 library built from the same sources -- the product library and `scanpy_amd` are not involved.  Asserted here: the
 entry points that run correctly under the emulator agree with the oracle, and no cross-lane operation was executed by
 a partial wave."""
+import ctypes as C
 import sys
 from pathlib import Path
 
@@ -123,6 +124,26 @@ def test_knn_lds_dma_ring_with_late_landing(emu, monkeypatch, ivf):
             assert bad == 0 and n_fallback == 0, (late, bad, n_fallback)
     finally:
         lib.emu_set_dma_late(0)
+
+
+def test_knn_trace_dump_matches_its_parser(emu, monkeypatch, tmp_path):
+    """SCAMD_KNN_TRACE: the per-block records the pruned sweep dumps and `tools/knn_trace.py` reads (the measurement behind
+    DESIGN 3.1 "What binds it") -- record size, tiles swept == the launch's own count of evaluated pairs, cells per block"""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import knn_trace
+
+    H, lib = emu
+    path = tmp_path / "trace.bin"
+    monkeypatch.setenv("SCAMD_KNN_IVF", "1")
+    monkeypatch.setenv("SCAMD_KNN_CELL_ROWS", "512")
+    monkeypatch.setenv("SCAMD_KNN_TRACE", str(path))
+    x = _blobs(4500, 50, 8, 5, spread=3.0)
+    H.knn(lib, x, 15)
+    tr, cell = knn_trace.parse_trace(path)
+    lib.scamd_knn_last_select_pairs.restype = C.c_double
+    assert tr.shape[0] == cell.size and tr.shape[0] >= 4500 // 128
+    assert int(tr[:, 2].sum()) * 64 * 128 == int(lib.scamd_knn_last_select_pairs())  # tiles x 64 candidates x 128 queries
+    assert (tr[:, 7] >= 1).all() and (tr[:, 7] <= 16).all() and cell.min() >= 0 and cell.max() < 16
 
 
 def test_knn_float64_fallback_scan(emu):

@@ -14,6 +14,17 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
+def parse_trace(path):
+    """the dump of SCAMD_KNN_TRACE (csrc/knn.hip, IvfArgs::trace): per block 8 x uint64 {start, end (100 MHz ticks), tiles
+    swept, xcc << 32 | hw id, end of the prologue, end of the pre-pass, ticks inside the cells' sweeps, cells swept}, then
+    the blocks' cells as int32 -> (uint64 [n_blocks, 8], int32 [n_blocks])"""
+    raw = np.fromfile(path, dtype=np.uint8)
+    nb = raw.size // 68
+    if nb * 68 != raw.size:
+        raise ValueError(f"{path}: {raw.size} bytes is not a whole number of 68-byte block records")
+    return raw[: nb * 64].view(np.uint64).reshape(nb, 8), raw[nb * 64:].view(np.int32)
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     structure = sys.argv[2] if len(sys.argv) > 2 else "planted"
@@ -41,10 +52,8 @@ def main():
     os.environ.pop("SCAMD_KNN_TRACE")
     lib = _lib.load()
     sel_ms, pairs = float(lib.scamd_knn_last_select_ms()), float(lib.scamd_knn_last_select_pairs())
-    raw = np.fromfile(path, dtype=np.uint8)
-    nb = raw.size // 68  # per block 8 x uint64 (knn.hip: IvfArgs::trace), then the block's cell as int32
-    tr = raw[: nb * 64].view(np.uint64).reshape(nb, 8)
-    cell = raw[nb * 64: nb * 68].view(np.int32)
+    tr, cell = parse_trace(path)
+    nb = tr.shape[0]
     t0, t1, tiles = tr[:, 0].astype(np.int64), tr[:, 1].astype(np.int64), tr[:, 2].astype(np.int64)
     xcc = (tr[:, 3] >> np.uint64(32)).astype(np.int64) & 0xF
     base = t0.min()
