@@ -72,6 +72,19 @@ int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x,
                      int32_t* out_idx, double* out_dist,
                      double cert_scale, int64_t* n_fallback_host,
                      void* workspace, size_t workspace_bytes, scamd_stream_t stream);
+/* Approximate variant -- BASELINE.json configs[4] ("IVF-tiled approximate kNN"); the reference's own default above 8192
+ * cells is approximate as well (pynndescent, src/scanpy/neighbors/__init__.py:734-739, 769-781).  Same arguments and
+ * output conventions as scamd_knn_l2_f32, plus
+ *   nprobe   every query sees the rows of the nprobe cells of the k-means quantiser nearest (centroid distance) to its
+ *            own cell -- ~2048 rows per cell, at most 1024 cells.  Inside the probed cells the search IS the exact one
+ *            (same kernels, float64 re-rank, certificate): the lists are the true nearest neighbours among the probed
+ *            rows, recall < 1 comes from unprobed cells only.  nprobe <= 0 or >= the cell count: the exact search.
+ * Answered exactly as well: n < 4096, k > 24, d > 64 (shapes outside the register-list kernel).  Workspace:
+ * scamd_knn_workspace_bytes (one figure for both entry points). */
+int scamd_knn_l2_ivf_f32(const float* x, int64_t n, int d, int64_t ld_x,
+                         int64_t q_begin, int64_t n_query, int k, int nprobe,
+                         int32_t* out_idx, double* out_dist, int64_t* n_fallback_host,
+                         void* workspace, size_t workspace_bytes, scamd_stream_t stream);
 /* Duration (ms, HIP events on `stream`) of the FP32-MFMA selection kernel of the calling thread's most
  * recent scamd_knn_l2_f32 call; -1 if none.  Used by bench.py for the roofline figure. */
 float scamd_knn_last_select_ms(void);
@@ -249,6 +262,14 @@ int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indices, const fl
                          double beta, uint64_t seed,
                          int32_t* membership, double* modularity_host, int32_t* n_communities_host,
                          void* workspace, size_t workspace_bytes, scamd_stream_t stream);
+/* Statistics of the last scamd_leiden_csr_f32 call on this thread, out[0 .. min(n, 8)):
+ *   [0] outer iterations run, [1] kernel launches, [2] blocking host round trips,
+ *   [3] full sweeps / [4] rounds / [5] vertices moved by the final polish (n_iterations < 0: strictly monotone
+ *       single-vertex moves until a sweep over ALL vertices finds no improving one -- the node optimality a stable
+ *       partition of leidenalg / igraph has, src/scanpy/tools/_leiden.py:166-196 with n_iterations=-1),
+ *   [6] 1 if the polish was skipped because the last iteration itself had proven node optimality,
+ *   [7] levels of the first iteration.  Diagnostics only (bench.py, tools/). */
+void scamd_leiden_last_stats(int32_t* out, int n);
 /* Modularity of a given membership (replaces igraph Graph.modularity as used by
  * src/scanpy/metrics/_metrics.py:202-214). */
 int scamd_modularity_csr_f32(const int64_t* indptr, const int32_t* indices, const float* weights,

@@ -52,16 +52,19 @@ def _zeros(shape, *, dtype, device):
 
 
 def _check(rc: int, what: str = "") -> None:
+    # the guard list is taken and cleared FIRST: when the C entry point reports an error the guarded buffers must not
+    # stay referenced (device memory held) nor be attributed to the next, unrelated call
+    pending = list(_guards)
+    _guards.clear()
     _lib.check(rc, what)
-    if _GUARD and _guards:
+    if _GUARD and pending:
         torch.cuda.synchronize()
         bad = []
-        for label, raw, nbytes in _guards:
+        for label, raw, nbytes in pending:
             lo_ok = bool((raw[:_GUARD_BYTES] == _CANARY).all())
             hi_ok = bool((raw[_GUARD_BYTES + nbytes:] == _CANARY).all())
             if not (lo_ok and hi_ok):
                 bad.append(f"{label} ({nbytes} B): {'below' if not lo_ok else ''}{' above' if not hi_ok else ''}")
-        _guards.clear()
         if bad:
             raise _lib.ScamdError(f"SCAMD_GUARD: {what} wrote outside " + "; ".join(bad))
 
@@ -83,8 +86,12 @@ def mfma_selftest() -> None:
     _check(_lib.load().scamd_selftest_mfma_layout(stream_ptr()), "mfma selftest")
 
 
-def knn(x: torch.Tensor, k: int, *, q_begin: int = 0, n_query: int | None = None, cert_scale: float = 1.0):
-    """x [n, d] float32 (device).  -> (idx int32 [nq, k], dist float64 [nq, k], n_fallback)."""
+def knn(x: torch.Tensor, k: int, *, q_begin: int = 0, n_query: int | None = None, cert_scale: float = 1.0,
+        nprobe: int | None = None):
+    """x [n, d] float32 (device).  -> (idx int32 [nq, k], dist float64 [nq, k], n_fallback).
+
+    nprobe: None / 0 = the exact search (scamd_knn_l2_f32); > 0 = the approximate IVF mode (scamd_knn_l2_ivf_f32): every
+    query sees the rows of the `nprobe` cells nearest to its own cell only."""
     dev = require_gpu()
     lib = _lib.load()
     assert x.dtype == torch.float32 and x.dim() == 2 and x.is_cuda
@@ -98,9 +105,16 @@ def knn(x: torch.Tensor, k: int, *, q_begin: int = 0, n_query: int | None = None
         raise _lib.ScamdError(f"knn: unsupported shape d={d} (max 128) / k={k} (max 120)")
     ws, wsz = _ws(need, dev)
     nfb = C.c_int64(0)
-    rc = lib.scamd_knn_l2_f32(ptr(x), n, d, x.stride(0), q_begin, nq, k, ptr(idx), ptr(dist),
-                              float(cert_scale), C.byref(nfb), ptr(ws), wsz, stream_ptr())
-    _check(rc, "scamd_knn_l2_f32")
+    if nprobe:
+        if cert_scale != 1.0:
+            raise ValueError("knn: cert_scale is a test knob of the exact entry point")
+        rc = lib.scamd_knn_l2_ivf_f32(ptr(x), n, d, x.stride(0), q_begin, nq, k, int(nprobe), ptr(idx), ptr(dist),
+                                      C.byref(nfb), ptr(ws), wsz, stream_ptr())
+        _check(rc, "scamd_knn_l2_ivf_f32")
+    else:
+        rc = lib.scamd_knn_l2_f32(ptr(x), n, d, x.stride(0), q_begin, nq, k, ptr(idx), ptr(dist),
+                                  float(cert_scale), C.byref(nfb), ptr(ws), wsz, stream_ptr())
+        _check(rc, "scamd_knn_l2_f32")
     return idx, dist, int(nfb.value)
 
 
@@ -399,6 +413,15 @@ def leiden(indptr: torch.Tensor, indices: torch.Tensor, weights: torch.Tensor, n
                                   C.byref(nc), ptr(ws), wsz, stream_ptr())
     _check(rc, "scamd_leiden_csr_f32")
     return memb, float(q.value), int(nc.value)
+
+
+def leiden_last_stats() -> dict:
+    """Diagnostics of this thread's last `leiden` call (scamd_leiden_last_stats)."""
+    out = (C.c_int32 * 8)()
+    _lib.load().scamd_leiden_last_stats(out, 8)
+    keys = ("iterations", "launches", "host_round_trips", "polish_full_sweeps", "polish_rounds", "polish_moves",
+            "polish_skipped_proven", "levels_first_iteration")
+    return dict(zip(keys, (int(v) for v in out)))
 
 
 def modularity(indptr: torch.Tensor, indices: torch.Tensor, weights: torch.Tensor, n: int, membership: torch.Tensor,

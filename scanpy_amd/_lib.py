@@ -20,6 +20,7 @@ SIGNATURES = {
     "scamd_device_count": (_i32, []),
     "scamd_knn_workspace_bytes": (_sz, [_i64, _i32, _i64, _i32]),
     "scamd_knn_l2_f32": (_i32, [_vp, _i64, _i32, _i64, _i64, _i64, _i32, _vp, _vp, _f64, C.POINTER(_i64), _vp, _sz, _vp]),
+    "scamd_knn_l2_ivf_f32": (_i32, [_vp, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _vp, C.POINTER(_i64), _vp, _sz, _vp]),
     "scamd_knn_last_select_ms": (C.c_float, []),
     "scamd_knn_last_select_pairs": (_f64, []),
     "scamd_knn_last_select_prepass_pairs": (_f64, []),
@@ -52,6 +53,7 @@ SIGNATURES = {
     "scamd_colsum_f32_f64": (_i32, [_vp, _i64, _i32, _vp, _vp, _sz, _vp]),
     "scamd_leiden_workspace_bytes": (_sz, [_i64, _i64]),
     "scamd_leiden_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _f64, _i32, _f64, _u64, _vp, C.POINTER(_f64), C.POINTER(_i32), _vp, _sz, _vp]),
+    "scamd_leiden_last_stats": (None, [C.POINTER(_i32), _i32]),
     "scamd_modularity_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _f64, C.POINTER(_f64), _vp, _sz, _vp]),
     "scamd_pp_row_sums_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "scamd_pp_row_count_positive_f32": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),

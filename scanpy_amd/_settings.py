@@ -12,6 +12,9 @@ class Settings:
     # Default Leiden flavor.  The reference's V1 preset says 'leidenalg' (presets.py:271-277); both flavors
     # optimise the same objective and map onto the same GPU kernel here.
     leiden_flavor: str = "leidenalg"
+    # cells every query block probes when `pp.neighbors(transformer='ivf')` asks for the approximate search
+    # (scamd_knn_l2_ivf_f32; ~2048 rows per cell).  The recall / work curve is data dependent: DESIGN.md 3.1.
+    knn_nprobe: int = 32
 
 
 settings = Settings()

@@ -1162,11 +1162,15 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
 // Per-cell sweep order of the cell-pruned search: block a sorts all cells by the lower bound
 // LB(a,b) = max(0, |c_a - c_b| (1 - 1e-4) - r_a - r_b) on the distance between any member of a and any member of b
 // (own cell first, empty cells last with LB = INF) and writes row a of order / order_lb2 (LB squared).
+// nprobe > 0 -- the APPROXIMATE mode (scamd_knn_l2_ivf_f32): the cells are sorted by the distance between the centroids
+// instead (the ball bound says nothing when the balls overlap, which on data without separated clusters is every pair
+// of cells), the first nprobe non-empty cells get the bound 0 (always swept) and every later one INF -- the sweep
+// kernel stops at the first INF, so it needs no change: a query block sees the rows of its cell's nprobe nearest cells.
 __global__ __launch_bounds__(256) void ivf_cell_order_kernel(const float* __restrict__ centers, int d,
                                                              const float* __restrict__ radius,
                                                              const int* __restrict__ cell_ntiles, int n_cells,
                                                              int* __restrict__ order_out, float* __restrict__ lb2_out,
-                                                             int* __restrict__ work_out) {
+                                                             int* __restrict__ work_out, int nprobe) {
   extern __shared__ __attribute__((aligned(16))) float co_smem[];
   int npow = 1;
   while (npow < n_cells) npow <<= 1;
@@ -1183,7 +1187,7 @@ __global__ __launch_bounds__(256) void ivf_cell_order_kernel(const float* __rest
         d2 += df * df;
       }
       const float lb = fmaxf(0.f, sqrtf(d2) * (1.0f - 1e-4f) - ra - radius[b]);
-      v = (b == a) ? -1.0f : lb * lb;
+      v = (b == a) ? -1.0f : (nprobe > 0 ? d2 : lb * lb);
     }
     lb2[b] = v;
     order[b] = b;
@@ -1209,6 +1213,11 @@ __global__ __launch_bounds__(256) void ivf_cell_order_kernel(const float* __rest
       __syncthreads();
     }
   }
+  if (nprobe > 0) {  // (every thread rewrites its own entries; the own cell keeps -1)
+    for (int i = tid; i < npow; i += 256)
+      if (i > 0) lb2[i] = (i < nprobe && lb2[i] < INFINITY) ? 0.f : INFINITY;
+    __syncthreads();
+  }
   for (int i = tid; i < n_cells; i += 256) {
     order_out[(int64_t)a * n_cells + i] = order[i];
     lb2_out[(int64_t)a * n_cells + i] = lb2[i];
@@ -1216,6 +1225,7 @@ __global__ __launch_bounds__(256) void ivf_cell_order_kernel(const float* __rest
   // expected sweep length of a block of this cell (a ranking, not a bound: only the launch order uses it): the tiles
   // of the cells whose lower bound is within the cell's own radius -- in a clustered embedding, the cells of the same
   // cluster.  Neighbour distances are of the order of the radius of a ~2000-row cell in 50 dimensions.
+  // (approximate mode: the tiles of the nprobe cells, exactly)
   __shared__ int s_work;
   if (tid == 0) s_work = 0;
   __syncthreads();
@@ -2073,6 +2083,7 @@ struct KnnPlan {
   int row_dwords; // row stride of the packed copy
   int64_t n_pad, nq_pad;
   bool ivf;       // cell-pruned exact search (register-list kernel only)
+  int nprobe;     // > 0: approximate mode, every query block sweeps its cell's nprobe nearest cells only
   int n_cells;    // coarse cells
   int64_t n_img_max, n_slot_max;  // upper bounds of the padded image rows / query slots
 };
@@ -2082,7 +2093,8 @@ static void reg_plan(KnnPlan* p) {
   p->row_dwords = RegCfg<H>::DPL;
 }
 
-static bool knn_plan(int64_t n, int d, int64_t n_query, int k, KnnPlan* p) {
+static bool knn_plan(int64_t n, int d, int64_t n_query, int k, KnnPlan* p, int nprobe = 0) {
+  p->nprobe = 0;
   if (d <= 16) p->H = 8;
   else if (d <= 32) p->H = 16;
   else if (d <= 50) p->H = 25;
@@ -2147,6 +2159,12 @@ static bool knn_plan(int64_t n, int d, int64_t n_query, int k, KnnPlan* p) {
     return e ? atoi(e) : -1;
   }();
   p->ivf = p->reg && ivf_env != 0 && (n >= 65536 || ivf_env == 1) && n >= 4096;
+  // approximate mode: always through the cell tables (register-list kernel: k <= 24, d <= 64, and n >= 4096 rows -- below
+  // that, and for the other shapes, the call is answered exactly)
+  if (nprobe > 0 && p->reg && n >= 4096) {
+    p->ivf = true;
+    p->nprobe = nprobe;
+  }
   p->n_cells = 0;
   p->n_img_max = p->n_slot_max = 0;
   if (p->ivf) {
@@ -2478,7 +2496,8 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
     SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_cell_order_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)olds));
     hipLaunchKernelGGL(ivf_cell_order_kernel, dim3(nc), dim3(256), olds, s, b.cent, d,
-                       reinterpret_cast<const float*>(b.radius_bits), ntiles, nc, b.cell_order, b.cell_lb2, b.cell_aux);
+                       reinterpret_cast<const float*>(b.radius_bits), ntiles, nc, b.cell_order, b.cell_lb2, b.cell_aux,
+                       p.nprobe);
     SCAMD_LAUNCH_CHECK();
     // launch order: longest expected sweeps first
     hipLaunchKernelGGL(ivf_block_order_kernel, dim3(1), dim3(1024), 0, s, b.cell_aux, b.cell_aux + nc, b.cell_aux + 2 * nc,
@@ -2692,18 +2711,49 @@ extern "C" int scamd_knn_last_select_engine(void) { return g_last_select_engine;
 extern "C" int scamd_knn_last_second_tier_queries(void) { return g_last_second_tier; }
 
 extern "C" size_t scamd_knn_workspace_bytes(int64_t n, int d, int64_t n_query, int k) {
-  KnnPlan p;
-  if (!knn_plan(n, d, n_query, k, &p)) return 0;
-  Workspace ws(nullptr, 0);
-  KnnBuffers b;
-  knn_carve(ws, p, n_query, &b);
-  return ws.used();
+  // one figure for the exact and the approximate entry point: the approximate plan goes through the cell tables at
+  // sizes where the exact one sweeps by brute force (4096 <= n < 65536)
+  size_t need = 0;
+  for (int nprobe = 0; nprobe <= 1; ++nprobe) {
+    KnnPlan p;
+    if (!knn_plan(n, d, n_query, k, &p, nprobe)) return 0;
+    Workspace ws(nullptr, 0);
+    KnnBuffers b;
+    knn_carve(ws, p, n_query, &b);
+    need = std::max(need, ws.used());
+  }
+  return need;
 }
+
+static int knn_l2_impl(const float* x, int64_t n, int d, int64_t ld_x, int64_t q_begin, int64_t n_query, int k,
+                       int32_t* out_idx, double* out_dist, double cert_scale, int64_t* n_fallback_host, void* workspace,
+                       size_t workspace_bytes, scamd_stream_t stream, int nprobe);
 
 extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, int64_t q_begin,
                                 int64_t n_query, int k, int32_t* out_idx, double* out_dist,
                                 double cert_scale, int64_t* n_fallback_host, void* workspace,
                                 size_t workspace_bytes, scamd_stream_t stream) {
+  return knn_l2_impl(x, n, d, ld_x, q_begin, n_query, k, out_idx, out_dist, cert_scale, n_fallback_host, workspace,
+                     workspace_bytes, stream, 0);
+}
+
+// Approximate variant (BASELINE configs[4]: "IVF-tiled approximate kNN"; the reference's own default above 8192 cells is
+// approximate too, src/scanpy/neighbors/__init__.py:734-739, 769-781): every query sees the rows of the nprobe cells
+// nearest to its own cell (centroid distance) of the same k-means quantiser the exact search prunes with.  Inside those
+// cells the search is the exact one (same kernels, same float64 re-rank and certificate), so the lists are the true
+// nearest neighbours AMONG THE PROBED ROWS: recall < 1 comes from unprobed cells only.  nprobe <= 0 or >= the cell count:
+// the exact search.  Shapes the register-list kernel does not take (k > 24, d > 64) and n < 4096 are answered exactly.
+extern "C" int scamd_knn_l2_ivf_f32(const float* x, int64_t n, int d, int64_t ld_x, int64_t q_begin,
+                                    int64_t n_query, int k, int nprobe, int32_t* out_idx, double* out_dist,
+                                    int64_t* n_fallback_host, void* workspace, size_t workspace_bytes,
+                                    scamd_stream_t stream) {
+  return knn_l2_impl(x, n, d, ld_x, q_begin, n_query, k, out_idx, out_dist, 1.0, n_fallback_host, workspace,
+                     workspace_bytes, stream, nprobe > 0 ? nprobe : 0);
+}
+
+static int knn_l2_impl(const float* x, int64_t n, int d, int64_t ld_x, int64_t q_begin, int64_t n_query, int k,
+                       int32_t* out_idx, double* out_dist, double cert_scale, int64_t* n_fallback_host, void* workspace,
+                       size_t workspace_bytes, scamd_stream_t stream, int nprobe) {
   SCAMD_REQUIRE(x && out_idx && out_dist, SCAMD_EINVAL, "knn: null pointer");
   SCAMD_REQUIRE(n >= 1 && d >= 1 && ld_x >= d, SCAMD_EINVAL, "knn: bad shape n=%lld d=%d ld=%lld",
                 (long long)n, d, (long long)ld_x);
@@ -2713,7 +2763,7 @@ extern "C" int scamd_knn_l2_f32(const float* x, int64_t n, int d, int64_t ld_x, 
                 (long long)(q_begin + n_query), (long long)n);
   SCAMD_REQUIRE(k >= 1, SCAMD_EINVAL, "knn: k=%d", k);
   KnnPlan p;
-  SCAMD_REQUIRE(knn_plan(n, d, n_query, k, &p), SCAMD_EUNSUPPORTED,
+  SCAMD_REQUIRE(knn_plan(n, d, n_query, k, &p, nprobe), SCAMD_EUNSUPPORTED,
                 "knn: unsupported d=%d (max 128) or k=%d (max 120)", d, k);
   if (n_fallback_host) *n_fallback_host = 0;
   if (n_query == 0) return SCAMD_OK;

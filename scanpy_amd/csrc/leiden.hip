@@ -29,6 +29,22 @@
 
 namespace scamd {
 
+// per-call statistics of the last scamd_leiden_csr_f32 on this thread (scamd_leiden_last_stats): [0] outer iterations,
+// [1] kernel launches, [2] blocking host round trips, [3] full sweeps / [4] rounds / [5] moves of the final polish,
+// [6] 1 if the polish was skipped because the last iteration had already proven node optimality, [7] levels of iteration 0
+static thread_local int g_ld_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#undef SCAMD_LAUNCH_CHECK
+#define SCAMD_LAUNCH_CHECK()                \
+  do {                                      \
+    ++g_ld_stats[1];                        \
+    SCAMD_HIP_CHECK(hipGetLastError());     \
+  } while (0)
+#define LD_SYNC(stream)                               \
+  do {                                                \
+    ++g_ld_stats[2];                                  \
+    SCAMD_HIP_CHECK(hipStreamSynchronize(stream));    \
+  } while (0)
+
 constexpr double WSCALE = 4294967296.0;  // 2^32
 constexpr int MAX_LM_SWEEPS = 96;
 constexpr int LM_DIR_AFTER = 32;  // sweeps after which the direction rule (termination guarantee) is switched on
@@ -698,6 +714,70 @@ __global__ __launch_bounds__(256) void ld_requeue_move_kernel(int nb_rq, int rq_
                                                               int* __restrict__ flag, MoveArgs ma) {
   if ((int)blockIdx.x < nb_rq) ld_requeue_body((int)blockIdx.x, rq_n_act, rq_list, rq_decision, indptr, indices, comm, flag);
   else ld_move_body<G>((int)blockIdx.x - nb_rq, (int)gridDim.x - nb_rq, ma);
+}
+
+// ---- final polish (n_iterations < 0): strictly monotone single-vertex moves ----------------------------------------
+// The class sub-rounds above apply many moves decided on ONE snapshot: fast, but not monotone, and the outer loop keeps the
+// best partition it saw -- which, on ambiguous graphs, may be one whose last coarse-level moves left a few level-0
+// vertices improvable (round 4: 9 / 186 of 300k vertices, gains < 1e-6 Q; the paper's "node optimality" of a stable
+// partition, oracle/leiden_guarantees.py, violated by that residue).  The polish decides on a snapshot as before, but
+// applies a move v: A -> B only if v holds the locks of BOTH communities: lock[c] = max over this round's movers touching
+// c of (round << 32 | ~v) -- the smallest vertex id wins, stale rounds lose to the current one, nothing is ever reset.
+// The gain of v's move depends on k_v(A), k_v(B), K_A, K_B only; moves with disjoint community pairs leave those four
+// untouched, so every applied move realises exactly the gain it was decided on: Q rises strictly, round after round,
+// and at least one mover (the smallest id) wins per round.  Losers stay flagged.
+__global__ __launch_bounds__(256) void ld_polish_lock_kernel(int n_act, const int* __restrict__ list,
+                                                             const int* __restrict__ decision, const int* __restrict__ comm,
+                                                             unsigned long long* __restrict__ lock, unsigned int round) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_act) return;
+  const int d = decision[w];
+  if (d < 0) return;
+  const int v = list[w];
+  const unsigned long long key = ((unsigned long long)round << 32) | (unsigned long long)(0xffffffffu - (unsigned int)v);
+  atomicMax(&lock[comm[v]], key);
+  atomicMax(&lock[d], key);
+}
+// winners move (as ld_apply_kernel), losers keep their flag and their decision becomes "stay" (the re-queue that follows
+// reads decision >= 0 as "moved").  counters: [0] moved, [1] lost a lock
+__global__ __launch_bounds__(256) void ld_polish_apply_kernel(int n_act, const int* __restrict__ list, int* __restrict__ decision,
+                                                              const long long* __restrict__ k, int* __restrict__ comm,
+                                                              unsigned long long* __restrict__ Ktot, int* __restrict__ csize,
+                                                              const unsigned long long* __restrict__ lock, unsigned int round,
+                                                              int* __restrict__ flag, int* __restrict__ counters) {
+  __shared__ int s_moved, s_lost;
+  if (threadIdx.x == 0) {
+    s_moved = 0;
+    s_lost = 0;
+  }
+  __syncthreads();
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < n_act) {
+    const int d = decision[w];
+    if (d >= 0) {
+      const int v = list[w];
+      const int a = comm[v];
+      const unsigned long long key = ((unsigned long long)round << 32) | (unsigned long long)(0xffffffffu - (unsigned int)v);
+      if (lock[a] == key && lock[d] == key) {
+        comm[v] = d;
+        const unsigned long long kq = (unsigned long long)k[v];
+        atomicAdd(&Ktot[d], kq);
+        atomicAdd(&Ktot[a], 0ull - kq);
+        atomicAdd(&csize[d], 1);
+        atomicSub(&csize[a], 1);
+        atomicAdd(&s_moved, 1);
+      } else {
+        decision[w] = -1;
+        flag[v] = 1;
+        atomicAdd(&s_lost, 1);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_moved) atomicAdd(&counters[0], s_moved);
+    if (s_lost) atomicAdd(&counters[1], s_lost);
+  }
 }
 
 // Class of a vertex in a sweep: a fresh hash per sweep (salt), so two neighbours that shared a class -- and could
@@ -2191,6 +2271,9 @@ struct LeidenCtx {
   int lm_classes = 0;         // class sub-rounds per local-moving sweep (0 = by level size; SCAMD_LEIDEN_LM_CLASSES)
   int rf_classes = 0;         // class sub-rounds of the refinement (0 = by level size; SCAMD_LEIDEN_RF_CLASSES)
   bool small_levels = true;   // levels of <= SMALL_N nodes in one workgroup (SCAMD_LEIDEN_SMALL=0: separate kernels)
+  int l0_moves = -1;          // moves of the last iteration's level-0 local moving (0: its input was node optimal)
+  int n_levels = 0;           // levels the last iteration went through
+  bool polish = true;         // SCAMD_LEIDEN_POLISH=0: no final polish (A/B; the round-4 behaviour)
   bool no_fuse = false;       // SCAMD_LEIDEN_FUSE=0: re-queue and the next sub-round's decisions as separate launches (A/B)
   int small_seq_n = SMALL_SEQ_N;  // ... of which those of <= small_seq_n vertices move one vertex at a time (SCAMD_LEIDEN_SMALL_SEQ)
   // coarse-row build tiers (distinct-neighbour bounds); the env overrides exist so the tests can push small graphs
@@ -2218,7 +2301,7 @@ static bool g_leiden_debug_sync = false;
 
 static int read_counters(LeidenCtx& cx, int* h, int cnt) {
   SCAMD_HIP_CHECK(hipMemcpyAsync(h, cx.b.counters, sizeof(int) * cnt, hipMemcpyDeviceToHost, cx.s));
-  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  LD_SYNC(cx.s);
   return SCAMD_OK;
 }
 
@@ -2248,7 +2331,7 @@ static int quality(LeidenCtx& cx, const LevelGraph& g, const int* comm, double* 
   double sumsq = 0;
   SCAMD_HIP_CHECK(hipMemcpyAsync(&internal, cx.b.total + 1, sizeof(internal), hipMemcpyDeviceToHost, cx.s));
   SCAMD_HIP_CHECK(hipMemcpyAsync(&sumsq, cx.b.dscratch, sizeof(double), hipMemcpyDeviceToHost, cx.s));
-  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  LD_SYNC(cx.s);
   *q = (double)(long long)internal / cx.m2 - cx.gamma * sumsq;
   return SCAMD_OK;
 }
@@ -2307,7 +2390,7 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
     int hc[CTR_AREA], ht[8];  // class list lengths, then per sub-round [CTR_N_MID] / [CTR_N_HUB]: long rows of the class
     SCAMD_HIP_CHECK(hipMemcpyAsync(hc, sw, sizeof(int) * (MAX_CLASSES + CTR_STRIDE * n_cls), hipMemcpyDeviceToHost, cx.s));
     SCAMD_HIP_CHECK(hipMemcpyAsync(ht, b.counters, sizeof(int) * 8, hipMemcpyDeviceToHost, cx.s));
-    SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+    LD_SYNC(cx.s);
     SCAMD_REQUIRE(ht[7] == 0, SCAMD_EINTERNAL, "leiden: hub table overflow (local moving)");
     int n_act = 0;
     for (int c = 0; c < n_cls; ++c) n_act += hc[c];
@@ -2430,6 +2513,100 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
   return SCAMD_OK;
 }
 
+// Final polish of the level-0 partition in b.memb (see ld_polish_lock_kernel): full sweeps of lock-arbitrated moves until
+// a sweep over ALL vertices finds no improving move -- node optimality by construction.  b.memb is updated in place;
+// stats[0] = full sweeps, [1] = rounds, [2] = moves.  Needs b.Kref (the refinement's scratch) as the lock table.
+constexpr int MAX_POLISH_ROUNDS = 1 << 16;
+constexpr int MAX_POLISH_PASSES = 6;  // polish -> verifying iteration -> polish ... (each accepted pass raises Q)
+static int polish_level0(LeidenCtx& cx, const LevelGraph& g, int* stats) {
+  LeidenBuffers& b = cx.b;
+  const double gg = cx.gamma / cx.m2;
+  const size_t n = (size_t)g.n;
+  stats[0] = stats[1] = stats[2] = 0;
+  SCAMD_HIP_CHECK(hipMemcpyAsync(b.comm, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+  int rc = compute_totals(cx, g, b.comm);
+  if (rc != SCAMD_OK) return rc;
+  unsigned long long* lock = b.Kref;
+  SCAMD_HIP_CHECK(hipMemsetAsync(lock, 0, sizeof(unsigned long long) * n, cx.s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.flag, 0, sizeof(int) * n, cx.s));
+  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
+  const int lanes = level_lanes(g);
+  const int thr_mid = lanes == 16 ? (int)(WH_SLOTS / 4 * 3 / 4) : (lanes == 32 ? (int)(WH_SLOTS / 2 * 3 / 4) : -1);
+  int* sw = b.rcounters;
+  int* ctr = sw + MAX_CLASSES;  // counter block of the one class
+  unsigned int round = 0;
+  int moved_before = 0, moved_at_full = 0;
+  bool full = true;  // the next round decides for every vertex (else: for the flagged ones)
+  for (;;) {
+    SCAMD_HIP_CHECK(hipMemsetAsync(sw, 0, sizeof(int) * (MAX_CLASSES + CTR_STRIDE), cx.s));
+    hipLaunchKernelGGL(ld_compact_cls_kernel, dim3((unsigned)ceil_div(g.n, 1024)), dim3(1024), 0, cx.s, g.n,
+                       full ? (int*)nullptr : b.flag, b.cls_lists, sw, 1, 0u, g.indptr, thr_mid, (int)WH_MAX_DEG);
+    SCAMD_LAUNCH_CHECK();
+    int hc[MAX_CLASSES + CTR_STRIDE], ht[8];
+    SCAMD_HIP_CHECK(hipMemcpyAsync(hc, sw, sizeof(hc), hipMemcpyDeviceToHost, cx.s));
+    SCAMD_HIP_CHECK(hipMemcpyAsync(ht, b.counters, sizeof(ht), hipMemcpyDeviceToHost, cx.s));
+    LD_SYNC(cx.s);
+    SCAMD_REQUIRE(ht[7] == 0, SCAMD_EINTERNAL, "leiden: hub table overflow (polish)");
+    const int cnt = hc[0];
+    const int moved_last = ht[0] - moved_before;  // moves of the previous round
+    moved_before = ht[0];
+    stats[2] = ht[0];
+    if (leiden_debug())
+      fprintf(stderr, "[leiden] polish round=%u %s act=%d moved_prev=%d lost_total=%d\n", round, full ? "full" : "flagged", cnt,
+              moved_last, ht[1]);
+    if (round >= MAX_POLISH_ROUNDS) break;  // (every round moves at least one vertex and raises Q: a cap, not a rule)
+    if (cnt == 0) {
+      // nobody is flagged any more.  If nothing moved since the last sweep over ALL vertices, that sweep was the proof
+      // of node optimality; otherwise another full sweep has to give it.
+      if (ht[0] == moved_at_full) break;
+      full = true;
+      continue;
+    }
+    if (full) {
+      ++stats[0];
+      moved_at_full = ht[0];
+    }
+    full = false;
+    ++round;
+    ++stats[1];
+    const int* list = b.cls_lists;
+    const int n_mid = hc[MAX_CLASSES + CTR_N_MID], n_hub = hc[MAX_CLASSES + CTR_N_HUB];
+    const unsigned nbm = (unsigned)(lanes == 16 ? ceil_div(cnt, 16) : (lanes == 32 ? ceil_div(cnt, 8) : ceil_div(cnt, 4)));
+    if (lanes == 32)
+      hipLaunchKernelGGL(ld_move_kernel<32>, dim3(nbm), dim3(256), 0, cx.s, cnt, list, (const int*)nullptr, (const int*)nullptr,
+                         g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg, -1, cx.seed, b.target, b.mid_list, b.hub_list, ctr);
+    else if (lanes == 16)
+      hipLaunchKernelGGL(ld_move_kernel<16>, dim3(nbm), dim3(256), 0, cx.s, cnt, list, (const int*)nullptr, (const int*)nullptr,
+                         g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg, -1, cx.seed, b.target, b.mid_list, b.hub_list, ctr);
+    else
+      hipLaunchKernelGGL(ld_move_kernel<64>, dim3(nbm), dim3(256), 0, cx.s, cnt, list, (const int*)nullptr, (const int*)nullptr,
+                         g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg, -1, cx.seed, b.target, b.mid_list, b.hub_list, ctr);
+    SCAMD_LAUNCH_CHECK();
+    if (lanes != 64 && n_mid > 0) {
+      hipLaunchKernelGGL(ld_move_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(n_mid, 4))), dim3(256), 0, cx.s, cnt, list,
+                         (const int*)b.mid_list, (const int*)(ctr + 5), g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg,
+                         -1, cx.seed, b.target, b.mid_list, b.hub_list, ctr);
+      SCAMD_LAUNCH_CHECK();
+    }
+    if (n_hub > 0) {
+      hipLaunchKernelGGL(ld_move_hub_kernel, dim3((unsigned)std::min(HUB_GRID, n_hub)), dim3(HUB_THREADS), HUB_LDS, cx.s, b.hub_list,
+                         ctr, list, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg, -1, cx.seed, b.target,
+                         b.counters + 7);
+      SCAMD_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(ld_polish_lock_kernel, GRID1(cnt), 0, cx.s, cnt, list, (const int*)b.target, (const int*)b.comm, lock, round);
+    SCAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ld_polish_apply_kernel, GRID1(cnt), 0, cx.s, cnt, list, b.target, g.k, b.comm, b.Ktot, b.csize,
+                       (const unsigned long long*)lock, round, b.flag, b.counters);
+    SCAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ld_requeue_kernel, GRID1(cnt), 0, cx.s, cnt, list, (const int*)b.target, g.indptr, g.indices,
+                       (const int*)b.comm, b.flag);
+    SCAMD_LAUNCH_CHECK();
+  }
+  if (stats[2] > 0) SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb, b.comm, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+  return SCAMD_OK;
+}
+
 static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
   LeidenBuffers& b = cx.b;
   const double gg = cx.gamma / cx.m2;
@@ -2459,7 +2636,7 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
   LD_DBG_SYNC(cx, "rf candidates n=%d classes=%d", g.n, n_cls);
   int hc[CTR_AREA];  // class list lengths, then per sub-round [CTR_N_MID] / [CTR_N_HUB] (ld_refine_candidates_kernel)
   SCAMD_HIP_CHECK(hipMemcpyAsync(hc, rc0, sizeof(int) * (MAX_CLASSES + CTR_STRIDE * n_cls), hipMemcpyDeviceToHost, cx.s));
-  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  LD_SYNC(cx.s);
   *n_merged = 0;
   // ONE sweep of n_cls sub-rounds, no host round trip in between: every candidate is considered exactly once (see
   // ld_refine_propose_kernel); the joiner counts stay on the device until the end
@@ -2520,7 +2697,7 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
   int hr[CTR_AREA], herr = 0;
   SCAMD_HIP_CHECK(hipMemcpyAsync(hr, rc0, sizeof(int) * (MAX_CLASSES + CTR_STRIDE * n_cls), hipMemcpyDeviceToHost, cx.s));
   SCAMD_HIP_CHECK(hipMemcpyAsync(&herr, b.counters + 7, sizeof(int), hipMemcpyDeviceToHost, cx.s));
-  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  LD_SYNC(cx.s);
   SCAMD_REQUIRE(herr == 0, SCAMD_EINTERNAL, "leiden: hub table overflow (refinement)");
   for (int c = 0; c < n_cls; ++c) {
     *n_merged += hr[MAX_CLASSES + CTR_STRIDE * c];
@@ -2540,7 +2717,7 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   if (rc != SCAMD_OK) return rc;
   int64_t nn = 0;
   SCAMD_HIP_CHECK(hipMemcpyAsync(&nn, b.newid + g.n, sizeof(int64_t), hipMemcpyDeviceToHost, cx.s));
-  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  LD_SYNC(cx.s);
   *n_new = (int)nn;
   if (nn == g.n) return SCAMD_OK;
   SCAMD_HIP_CHECK(hipMemsetAsync(b.rep, 0x7f, sizeof(int) * g.n, cx.s));
@@ -2572,7 +2749,7 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   // 48 / 96 KB of LDS each), a host round trip 15 -- and most levels of a clustered graph have no such rows at all.
   int htier[2] = {0, 0};
   SCAMD_HIP_CHECK(hipMemcpyAsync(htier, b.counters + 4, sizeof(int) * 2, hipMemcpyDeviceToHost, cx.s));
-  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  LD_SYNC(cx.s);
   if (leiden_debug() && (htier[0] || htier[1]))
     fprintf(stderr, "[leiden] aggregate n=%d -> %d: %d rows through the workgroup tier, %d through the 8192-slot tier\n", g.n, inn,
             htier[0], htier[1]);
@@ -2608,7 +2785,7 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   hipLaunchKernelGGL(ld_strength_kernel, GRIDW(nn), 0, cx.s, cb.indptr, cb.wq, (int)nn, cb.k);
   SCAMD_LAUNCH_CHECK();
   SCAMD_HIP_CHECK(hipMemcpyAsync(b.comm, b.comm_tmp, sizeof(int) * nn, hipMemcpyDeviceToDevice, cx.s));
-  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  LD_SYNC(cx.s);
   SCAMD_REQUIRE(agg_err == 0, SCAMD_EINTERNAL, "leiden: coarse-row table overflow");
   out->n = (int)nn;
   out->max_deg = dstat[0];
@@ -2658,7 +2835,7 @@ static int small_levels(LeidenCtx& cx, const LevelGraph& g, int level) {
   if (leiden_debug()) {
     int h[4];
     SCAMD_HIP_CHECK(hipMemcpyAsync(h, b.counters + 12, sizeof(h), hipMemcpyDeviceToHost, cx.s));
-    SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+    LD_SYNC(cx.s);
     fprintf(stderr, "[leiden] small levels from level %d (n=%d nnz=%lld): %d levels, %d moves, %d merges -> n=%d\n", level, g.n,
             (long long)g.nnz, h[0], h[1], h[2], h[3]);
   }
@@ -2671,6 +2848,7 @@ static int leiden_iteration(LeidenCtx& cx, const LevelGraph& g0) {
   hipLaunchKernelGGL(ld_iota_kernel, GRID1(g0.n), 0, cx.s, b.node_of, g0.n);
   SCAMD_LAUNCH_CHECK();
   LevelGraph g = g0;
+  cx.l0_moves = -1;  // (a graph small enough to start in the one-workgroup kernel reports no level-0 count)
   for (int level = 0; level < MAX_LEVELS; ++level) {
     int moves = 0;
     const bool dbg = leiden_debug();
@@ -2683,6 +2861,8 @@ static int leiden_iteration(LeidenCtx& cx, const LevelGraph& g0) {
     }
     int rc = local_moving(cx, g, &moves);
     if (rc != SCAMD_OK) return rc;
+    if (level == 0) cx.l0_moves = moves;
+    cx.n_levels = level + 1;
     const double t1 = dbg ? dbg_now(cx) : 0.0;
     int merged = 0;
     rc = refinement(cx, g, &merged);
@@ -2718,7 +2898,7 @@ static int renumber(LeidenCtx& cx, int n, int* n_comm) {
   if (rc != SCAMD_OK) return rc;
   int64_t nc = 0;
   SCAMD_HIP_CHECK(hipMemcpyAsync(&nc, b.newid + n, sizeof(int64_t), hipMemcpyDeviceToHost, cx.s));
-  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  LD_SYNC(cx.s);
   hipLaunchKernelGGL(ld_commkeys_kernel, GRID1(n), 0, cx.s, n, b.csize, b.minmember, b.newid, b.ckeys, b.cids);
   SCAMD_LAUNCH_CHECK();
   if (nc <= 131072) {
@@ -2753,7 +2933,7 @@ static int setup_level0(LeidenCtx& cx, const int64_t* indptr, const int32_t* ind
   int dstat[4] = {0, 0, 0, 0};
   SCAMD_HIP_CHECK(hipMemcpyAsync(&tot, b.total, sizeof(tot), hipMemcpyDeviceToHost, cx.s));
   SCAMD_HIP_CHECK(hipMemcpyAsync(dstat, b.counters + 8, sizeof(int) * 4, hipMemcpyDeviceToHost, cx.s));
-  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  LD_SYNC(cx.s);
   cx.m2 = (double)tot;
   g0->max_deg = dstat[0];
   g0->n_gt96 = dstat[1];
@@ -2803,6 +2983,8 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
   cx.rf_classes = classes_env("SCAMD_LEIDEN_RF_CLASSES");
   if (const char* e = getenv("SCAMD_LEIDEN_SMALL")) cx.small_levels = e[0] != '0';
   if (const char* e = getenv("SCAMD_LEIDEN_FUSE")) cx.no_fuse = e[0] == '0';
+  if (const char* e = getenv("SCAMD_LEIDEN_POLISH")) cx.polish = e[0] != '0';
+  for (int i = 0; i < 8; ++i) g_ld_stats[i] = 0;
   if (const char* e = getenv("SCAMD_LEIDEN_SMALL_SEQ")) cx.small_seq_n = atoi(e);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_WAVE_MAX")) cx.agg_wave_max = std::min(atoi(e), (int)WH_MAX_DEG);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_MAX")) cx.agg_mid_max = std::min(atoi(e), (int)AGG_MID_MAX);
@@ -2830,12 +3012,20 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
     if (rc == SCAMD_OK) rc = quality(cx, g0, b.memb, &q_best);
     if (rc != SCAMD_OK) return rc;
     SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb_best, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
-    const int max_iter = n_iterations < 0 ? MAX_OUTER_ITERS : n_iterations;
+    int max_iter = n_iterations < 0 ? MAX_OUTER_ITERS : n_iterations;
+    // (test knob: caps the outer loop of an n_iterations < 0 run, so that the polish meets an unfinished partition)
+    if (const char* e = getenv("SCAMD_LEIDEN_MAX_ITERS"))
+      if (n_iterations < 0 && atoi(e) > 0) max_iter = std::min(max_iter, atoi(e));
     int bad_iters = 0;
+    // true once b.memb_best has been the INPUT of an iteration whose level-0 local moving found nothing to move: its
+    // first sweep decides for every vertex on the final state, so that is a proof of node optimality
+    bool best_is_clean = false;
     for (int it = 0; it < max_iter; ++it) {
       cx.iter = it;
+      g_ld_stats[0] = it + 1;
       rc = leiden_iteration(cx, g0);
       if (rc != SCAMD_OK) return rc;
+      if (it == 0) g_ld_stats[7] = cx.n_levels;
       double q = 0.0;
       rc = compute_totals(cx, g0, b.memb);
       if (rc == SCAMD_OK) rc = quality(cx, g0, b.memb, &q);
@@ -2846,8 +3036,10 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
       if (improved) {
         q_best = q;
         bad_iters = 0;
+        best_is_clean = false;
         SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb_best, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
       } else {
+        if (cx.l0_moves == 0) best_is_clean = true;
         // synchronous moves and the randomised refinement are not monotone: keep the best partition seen
         SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb, b.memb_best, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
       }
@@ -2860,15 +3052,65 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
         if (!worse || ++bad_iters >= 2) break;
       }
     }
+    // n_iterations < 0 promises a STABLE partition (leidenalg iterates until an iteration changes nothing; such a
+    // partition is node optimal and g-separated).  Ours is the best of a run of non-monotone iterations.  Unless the last
+    // iteration proved it (best_is_clean): strictly monotone single-vertex moves until a sweep over all vertices finds
+    // none (polish_level0), then -- the moved vertices may have made two communities mergeable, or cut one in two -- ONE
+    // ordinary iteration from the polished partition: its level-0 moving finds nothing, its refinement and coarse levels
+    // re-examine everything else.  No gain: stable, done.  A gain: accepted, and the polish runs again.
+    int n_iter_total = g_ld_stats[0];
+    for (int pr = 0; n_iterations < 0 && cx.polish && pr <= MAX_POLISH_PASSES; ++pr) {
+      if (best_is_clean) {
+        if (pr == 0) g_ld_stats[6] = 1;
+        break;
+      }
+      // (b.memb == b.memb_best here: every iteration ends with one copied onto the other)
+      int ps[3] = {0, 0, 0};
+      rc = polish_level0(cx, g0, ps);
+      if (rc != SCAMD_OK) return rc;
+      g_ld_stats[3] += ps[0];
+      g_ld_stats[4] += ps[1];
+      g_ld_stats[5] += ps[2];
+      if (ps[2] == 0) break;  // the full sweep found no improving move: node optimal as it stands
+      double q = 0.0;
+      rc = compute_totals(cx, g0, b.memb);
+      if (rc == SCAMD_OK) rc = quality(cx, g0, b.memb, &q);
+      if (rc != SCAMD_OK) return rc;
+      if (leiden_debug())
+        fprintf(stderr, "[leiden] polish %d: %d full sweeps, %d rounds, %d moves: Q %.10f -> %.10f\n", pr, ps[0], ps[1], ps[2], q_best, q);
+      SCAMD_REQUIRE(q >= q_best - 1e-12, SCAMD_EINTERNAL, "leiden: the monotone polish lowered the quality (%.12f -> %.12f)", q_best, q);
+      q_best = q;
+      SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb_best, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+      if (pr == MAX_POLISH_PASSES) break;  // (the last pass only polishes what the last accepted iteration left)
+      cx.iter = n_iter_total++;
+      g_ld_stats[0] = n_iter_total;
+      rc = leiden_iteration(cx, g0);
+      if (rc != SCAMD_OK) return rc;
+      rc = compute_totals(cx, g0, b.memb);
+      if (rc == SCAMD_OK) rc = quality(cx, g0, b.memb, &q);
+      if (rc != SCAMD_OK) return rc;
+      if (leiden_debug()) fprintf(stderr, "[leiden] iteration after polish %d: Q = %.10f (polished %.10f), level-0 moves %d\n", pr, q, q_best, cx.l0_moves);
+      if (q > q_best + 1e-12) {
+        q_best = q;
+        SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb_best, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+      } else {
+        SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb, b.memb_best, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+        break;  // stable: the polished partition stands
+      }
+    }
   }
   int nc = 0;
   rc = renumber(cx, (int)n, &nc);
   if (rc != SCAMD_OK) return rc;
   SCAMD_HIP_CHECK(hipMemcpyAsync(membership, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
-  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  LD_SYNC(cx.s);
   if (modularity_host) *modularity_host = q_best;
   if (n_communities_host) *n_communities_host = nc;
   return SCAMD_OK;
+}
+
+extern "C" void scamd_leiden_last_stats(int32_t* out, int n) {
+  for (int i = 0; i < n && i < 8; ++i) out[i] = g_ld_stats[i];
 }
 
 extern "C" int scamd_modularity_csr_f32(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n,

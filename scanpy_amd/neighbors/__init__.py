@@ -4,7 +4,10 @@ kNN search and the umap connectivities run in HIP kernels (`scamd_knn_l2_f32`,
 `scamd_fuzzy_simplicial_set_f32`); slot names, `uns[...]['params']`, the self-column conventions of
 src/scanpy/neighbors/_common.py and the error behaviour follow the reference.  The search is EXACT
 (the reference's `transformer='sklearn'` semantics) for every n -- where the reference would switch to
-approximate NN-descent at n >= 8192 (neighbors/__init__.py:734-739) this path stays exact.
+approximate NN-descent at n >= 8192 (neighbors/__init__.py:734-739) this path stays exact, also for
+`transformer='pynndescent'`.  The approximate search is opt-in: `transformer='ivf'` (probes
+`settings.knn_nprobe` cells of the k-means quantiser, `scamd_knn_l2_ivf_f32`) or an
+`MI355XKNNTransformer(nprobe=...)` instance.
 """
 from __future__ import annotations
 
@@ -146,7 +149,7 @@ class Neighbors:
         if conn_method == "gauss" and not knn:
             msg = "method='gauss' with knn=False builds a dense n x n kernel matrix: not offered on the MI355X path."
             raise NotImplementedError(msg)
-        if isinstance(transformer, str) and transformer not in {"sklearn", "pynndescent", "mi355x"}:
+        if isinstance(transformer, str) and transformer not in {"sklearn", "pynndescent", "mi355x", "ivf"}:
             msg = f"Unknown transformer: {transformer}. Try passing a class or one of {{'pynndescent', 'sklearn'}}"
             raise ValueError(msg)
         self.n_neighbors = n_neighbors
@@ -161,7 +164,12 @@ class Neighbors:
             # exact 0 (what the reference gets after zeroing the diagonal, neighbors/__init__.py:639-648)
             k = min(n_neighbors, self._adata.n_obs)
             # (the lists stay on the device: they feed the connectivity kernel as they are)
-            knn_indices, knn_distances = knn_search_device(x, k, metric=metric)
+            nprobe = None
+            if transformer == "ivf":  # approximate: the cells of the quantiser nearest to the query's own
+                from .._settings import settings
+
+                nprobe = int(settings.knn_nprobe)
+            knn_indices, knn_distances = knn_search_device(x, k, metric=metric, nprobe=nprobe)
             self._distances = sparse_distances_from_device(knn_indices, knn_distances)
         else:  # user-supplied estimator instance: the reference's plug-in route, used as-is (:788, :638)
             self._distances = transformer.fit_transform(x)

@@ -17,9 +17,11 @@ from scipy import sparse
 METRICS = ("euclidean", "l2", "cosine")
 
 
-def knn_search_device(x, k: int, *, q_begin: int = 0, n_query: int | None = None, metric: str = "euclidean"):
-    """Exact kNN on the GPU, results left on the device: (indices int32 [nq, k], distances float64 [nq, k]); column 0
-    is the row itself with distance exactly 0.
+def knn_search_device(x, k: int, *, q_begin: int = 0, n_query: int | None = None, metric: str = "euclidean",
+                      nprobe: int | None = None):
+    """kNN on the GPU, results left on the device: (indices int32 [nq, k], distances float64 [nq, k]); column 0
+    is the row itself with distance exactly 0.  Exact unless `nprobe` > 0 (the approximate IVF mode: every query sees
+    the rows of the `nprobe` quantiser cells nearest to its own; exact among those).
 
     metric 'cosine' (sklearn: 1 - x.y / (|x||y|)): on unit-length rows the Euclidean order IS the cosine order and
     1 - cos = |x^ - y^|^2 / 2, so the rows are normalised on the device and the Euclidean kernel does the search."""
@@ -39,37 +41,43 @@ def knn_search_device(x, k: int, *, q_begin: int = 0, n_query: int | None = None
         if bool((norm == 0).any()):
             raise ValueError("metric='cosine' is undefined for all-zero rows")
         xd = (xd.to(torch.float64) / norm).to(torch.float32).contiguous()
-    idx, dist, _ = _kernels.knn(xd, k, q_begin=q_begin, n_query=n_query)
+    idx, dist, _ = _kernels.knn(xd, k, q_begin=q_begin, n_query=n_query, nprobe=nprobe)
     if metric == "cosine":
         dist = 0.5 * dist * dist
     return idx, dist
 
 
-def knn_search(x, k: int, *, q_begin: int = 0, n_query: int | None = None, metric: str = "euclidean"):
+def knn_search(x, k: int, *, q_begin: int = 0, n_query: int | None = None, metric: str = "euclidean",
+               nprobe: int | None = None):
     """`knn_search_device` with the results on the host: (indices int64 [nq, k], distances float64 [nq, k])."""
-    idx, dist = knn_search_device(x, k, q_begin=q_begin, n_query=n_query, metric=metric)
+    idx, dist = knn_search_device(x, k, q_begin=q_begin, n_query=n_query, metric=metric, nprobe=nprobe)
     return idx.cpu().numpy().astype(np.int64), dist.cpu().numpy()
 
 
 class MI355XKNNTransformer:
-    """sklearn-estimator-shaped exact kNN on MI355X (`fit`, `transform`, `fit_transform`, `get_params`,
-    `set_params`)."""
+    """sklearn-estimator-shaped kNN on MI355X (`fit`, `transform`, `fit_transform`, `get_params`, `set_params`): exact
+    by default; `nprobe=p` selects the approximate IVF mode (every query sees the `p` quantiser cells nearest to its
+    own -- what the reference's `transformer='pynndescent'` default above 8192 cells trades, recall for time)."""
 
-    def __init__(self, n_neighbors: int = 15, *, metric: str = "euclidean", include_self: bool = False):
+    def __init__(self, n_neighbors: int = 15, *, metric: str = "euclidean", include_self: bool = False,
+                 nprobe: int | None = None):
         if metric not in METRICS:
             msg = f"metric={metric!r}: the MI355X kNN kernel offers {METRICS}"
             raise ValueError(msg)
         self.n_neighbors = n_neighbors
         self.metric = metric
         self.include_self = include_self
+        if nprobe is not None and int(nprobe) < 0:
+            raise ValueError(f"nprobe={nprobe!r}: expected None (exact) or a positive number of cells")
+        self.nprobe = nprobe
         self._fit_x = None
 
     def get_params(self, deep: bool = True) -> dict:
-        return dict(n_neighbors=self.n_neighbors, metric=self.metric, include_self=self.include_self)
+        return dict(n_neighbors=self.n_neighbors, metric=self.metric, include_self=self.include_self, nprobe=self.nprobe)
 
     def set_params(self, **params):
         for k, v in params.items():
-            if k not in ("n_neighbors", "metric", "include_self"):
+            if k not in ("n_neighbors", "metric", "include_self", "nprobe"):
                 raise ValueError(f"Invalid parameter {k!r}")
             setattr(self, k, v)
         return self
@@ -87,10 +95,10 @@ class MI355XKNNTransformer:
         n = x.shape[0]
         if self.include_self:  # sklearn style: self + n_neighbors others
             k = min(self.n_neighbors + 1, n)
-            idx, dist = knn_search(x, k, metric=self.metric)
+            idx, dist = knn_search(x, k, metric=self.metric, nprobe=self.nprobe)
         else:  # RAPIDS style: n_neighbors - 1 others, no self
             k = min(self.n_neighbors, n)
-            idx, dist = knn_search(x, k, metric=self.metric)
+            idx, dist = knn_search(x, k, metric=self.metric, nprobe=self.nprobe)
             idx, dist = idx[:, 1:], dist[:, 1:]
         kk = idx.shape[1]
         indptr = np.arange(0, n * kk + 1, kk)

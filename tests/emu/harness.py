@@ -93,7 +93,7 @@ def leiden(lib, adj, *, resolution=1.0, n_iterations=-1, beta=0.01, seed=0):
     return memb, float(q.value), int(nc.value)
 
 
-def knn(lib, x, k, *, q_begin=0, n_query=None, cert_scale=1.0):
+def knn(lib, x, k, *, q_begin=0, n_query=None, cert_scale=1.0, nprobe=0):
     x = np.ascontiguousarray(x, dtype=np.float32)
     n, d = x.shape
     nq = n if n_query is None else n_query
@@ -101,9 +101,20 @@ def knn(lib, x, k, *, q_begin=0, n_query=None, cert_scale=1.0):
     dist = np.empty((nq, k), dtype=np.float64)
     ws = _ws(lib.scamd_knn_workspace_bytes(n, d, nq, k))
     nfb = C.c_int64(0)
-    rc = lib.scamd_knn_l2_f32(_p(x), n, d, d, q_begin, nq, k, _p(idx), _p(dist), float(cert_scale), C.byref(nfb), _p(ws), ws.size, None)
+    if nprobe:
+        rc = lib.scamd_knn_l2_ivf_f32(_p(x), n, d, d, q_begin, nq, k, int(nprobe), _p(idx), _p(dist), C.byref(nfb), _p(ws), ws.size, None)
+    else:
+        rc = lib.scamd_knn_l2_f32(_p(x), n, d, d, q_begin, nq, k, _p(idx), _p(dist), float(cert_scale), C.byref(nfb), _p(ws), ws.size, None)
     _check(lib, rc, "knn")
     return idx, dist, int(nfb.value)
+
+
+def leiden_stats(lib) -> dict:
+    out = (C.c_int32 * 8)()
+    lib.scamd_leiden_last_stats(out, 8)
+    keys = ("iterations", "launches", "host_round_trips", "polish_full_sweeps", "polish_rounds", "polish_moves",
+            "polish_skipped_proven", "levels_first_iteration")
+    return dict(zip(keys, (int(v) for v in out)))
 
 
 def pca_csr(lib, x, n_comps, *, zero_center=True, seed=0, tol=2e-8):

@@ -185,6 +185,63 @@ def test_leiden_reaches_the_oracles_modularity(emu, monkeypatch, small):
     assert lg.improving_moves(conn, memb)["count"] == 0 and lg.mergeable_pairs(conn, memb)["count"] == 0
 
 
+def test_leiden_polish_finishes_an_unfinished_partition(emu, monkeypatch):
+    """n_iterations = -1 promises a stable partition.  With the outer loop cut after two iterations (test knob) the best
+    partition still has improvable vertices (SCAMD_LEIDEN_POLISH=0: the round-4 behaviour); the final polish -- monotone,
+    lock-arbitrated single-vertex moves, then a verifying iteration -- leaves none, merges nothing that should not be,
+    and only ever raises the quality"""
+    from oracle import leiden as ol
+    from oracle import leiden_guarantees as lg
+
+    H, lib = emu
+    n = 2500
+    x = np.random.default_rng(5).standard_normal((n, 10)).astype(np.float32)
+    idx, dist = oknn.knn_exact_f64(x, np.arange(n), 15)
+    conn, _, _ = oconn.fuzzy_simplicial_set(idx, dist, n, 15)
+    monkeypatch.setenv("SCAMD_LEIDEN_MAX_ITERS", "2")
+    monkeypatch.setenv("SCAMD_LEIDEN_POLISH", "0")
+    memb0, q0, _ = H.leiden(lib, conn, seed=0)
+    assert lg.improving_moves(conn, memb0)["count"] > 0 and H.leiden_stats(lib)["polish_rounds"] == 0
+    monkeypatch.setenv("SCAMD_LEIDEN_POLISH", "1")
+    lib.emu_reset_stats()
+    memb, q, nc = H.leiden(lib, conn, seed=0)
+    st = H.leiden_stats(lib)
+    assert st["polish_moves"] > 0 and st["polish_full_sweeps"] >= 2 and st["iterations"] > 2, st
+    assert q > q0 and abs(q - ol.modularity(conn, memb)) < 1e-9 and nc == int(memb.max()) + 1
+    assert lg.improving_moves(conn, memb)["count"] == 0 and lg.mergeable_pairs(conn, memb)["count"] == 0
+    es = H.stats(lib)
+    assert es["partial_collectives"] == es["mixed_collectives"] == es["reads_of_inactive_lanes"] == 0, es
+    # a finite n_iterations promises nothing of the kind and is left alone
+    H.leiden(lib, conn, seed=0, n_iterations=2)
+    assert H.leiden_stats(lib)["polish_rounds"] == 0
+
+
+def test_knn_approximate_mode(emu, monkeypatch):
+    """scamd_knn_l2_ivf_f32: self first, exact float64 distances of whatever it returns, recall rising with nprobe, and the
+    exact lists once every cell is probed"""
+    from oracle import compare as cmp
+
+    H, lib = emu
+    n, d, k = 4096, 50, 15
+    rng = np.random.default_rng(0)
+    cent = rng.standard_normal((12, d))
+    x = (cent[rng.integers(0, 12, n)] + rng.standard_normal((n, d))).astype(np.float32)  # overlapping clusters
+    monkeypatch.setenv("SCAMD_KNN_CELL_ROWS", "256")  # 16 cells
+    ei, ed = oknn.knn_exact_f64(x, np.arange(n), k)
+    recall = {}
+    for nprobe in (1, 3, 16):
+        idx, dist, _ = H.knn(lib, x, k, nprobe=nprobe)
+        assert np.array_equal(idx[:, 0], np.arange(n)) and not dist[:, 0].any() and (np.diff(dist, axis=1) >= 0).all()
+        dd = np.sqrt(((x[idx[:, 1:]].astype(np.float64) - x[:, None, :].astype(np.float64)) ** 2).sum(-1))
+        assert np.abs(dd - dist[:, 1:]).max() < 1e-12
+        recall[nprobe] = float((idx[:, 1:, None] == ei[:, None, 1:]).any(1).mean())
+        if nprobe == 16:
+            assert cmp.knn_rows_differing_beyond_ties(idx, dist, ei, ed)[0] == 0
+        else:
+            assert lib.scamd_knn_last_select_pairs() < 0.5 * n * n
+    assert 0.5 < recall[1] < recall[3] <= recall[16] == 1.0, recall
+
+
 def test_leiden_hub_rows(emu):
     """a vertex with 2500 neighbours (multi-pass hub tables) and vertices of 150 .. 1200 (overflow list, hub list tiers)"""
     from scipy import sparse
