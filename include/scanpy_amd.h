@@ -262,13 +262,16 @@ int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indices, const fl
                          double beta, uint64_t seed,
                          int32_t* membership, double* modularity_host, int32_t* n_communities_host,
                          void* workspace, size_t workspace_bytes, scamd_stream_t stream);
-/* Statistics of the last scamd_leiden_csr_f32 call on this thread, out[0 .. min(n, 8)):
+/* Statistics of the last scamd_leiden_csr_f32 call on this thread, out[0 .. min(n, 12)):
  *   [0] outer iterations run, [1] kernel launches, [2] blocking host round trips,
  *   [3] full sweeps / [4] rounds / [5] vertices moved by the final polish (n_iterations < 0: strictly monotone
  *       single-vertex moves until a sweep over ALL vertices finds no improving one -- the node optimality a stable
  *       partition of leidenalg / igraph has, src/scanpy/tools/_leiden.py:166-196 with n_iterations=-1),
  *   [6] 1 if the polish was skipped because the last iteration itself had proven node optimality,
- *   [7] levels of the first iteration.  Diagnostics only (bench.py, tools/). */
+ *   [7] levels of the first iteration,
+ *   [8] local-moving sweeps of the levels that run as separate kernels, [9] their algorithmic traffic in MB (active rows
+ *       x (12 B per entry + 16 B per vertex): SURVEY.md 8(d)'s per-sweep figure over the rows a sweep visits), [10..11] 0.
+ * Diagnostics only (bench.py, tools/). */
 void scamd_leiden_last_stats(int32_t* out, int n);
 /* Modularity of a given membership (replaces igraph Graph.modularity as used by
  * src/scanpy/metrics/_metrics.py:202-214). */

@@ -350,7 +350,7 @@ def eigh_topk(a: torch.Tensor, k: int, *, seed: int = 0, tol: float = 2e-8):
     g = a.shape[0]
     lam = _empty(k, dtype=torch.float64, device=dev)
     v = _empty((g, k), dtype=torch.float64, device=dev)
-    info = (C.c_int32 * 8)()
+    info = (C.c_int32 * 12)()
     need = lib.scamd_eigh_topk_workspace_bytes(g, k)
     ws, wsz = _ws(need, dev)
     rc = lib.scamd_eigh_topk_f64(ptr(a), g, a.stride(0), k, int(seed) & (2**64 - 1), float(tol), ptr(lam), ptr(v), info,
@@ -372,7 +372,7 @@ def pca_csr(indptr, indices, data, n: int, g: int, n_comps: int, *, zero_center:
     var = _empty(k, dtype=torch.float64, device=dev)
     ratio = _empty(k, dtype=torch.float64, device=dev)
     mean = _empty(g, dtype=torch.float64, device=dev)
-    info = (C.c_int32 * 8)()
+    info = (C.c_int32 * 12)()
     need = lib.scamd_pca_csr_workspace_bytes(n, g, k)
     ws, wsz = _ws(need, dev)
     rc = lib.scamd_pca_csr_f32(ptr(indptr), ptr(indices), ptr(data), n, g, data.numel(), k, 1 if zero_center else 0,
@@ -417,10 +417,10 @@ def leiden(indptr: torch.Tensor, indices: torch.Tensor, weights: torch.Tensor, n
 
 def leiden_last_stats() -> dict:
     """Diagnostics of this thread's last `leiden` call (scamd_leiden_last_stats)."""
-    out = (C.c_int32 * 8)()
-    _lib.load().scamd_leiden_last_stats(out, 8)
+    out = (C.c_int32 * 12)()
+    _lib.load().scamd_leiden_last_stats(out, 12)
     keys = ("iterations", "launches", "host_round_trips", "polish_full_sweeps", "polish_rounds", "polish_moves",
-            "polish_skipped_proven", "levels_first_iteration")
+            "polish_skipped_proven", "levels_first_iteration", "lm_sweeps", "lm_sweep_algorithmic_MB")
     return dict(zip(keys, (int(v) for v in out)))
 
 

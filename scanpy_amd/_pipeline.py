@@ -188,10 +188,11 @@ def shard_bounds(n_total: int, world_size: int, rank: int) -> tuple[int, int]:
 
 def run_path(a_handle, n_total: int, *, comm=None, backend=None, n_comps: int = 50, n_neighbors: int = 15,
              resolution: float = 1.0, n_iterations: int = -1, seed: int = 0, svd_solver: str = "arpack",
-             timing: bool = False) -> PathResult:
+             timing: bool = False, nprobe: int | None = None) -> PathResult:
     """`a_handle` = `GpuBackend.upload(csr_rows_of_this_rank)`; rows of rank r are shard_bounds(n_total, W, r).
     Out of core: a `_ChunkedRows` over this rank's rows instead (e.g. `BackedCsr.row_chunks(step, row_begin, row_end)`
-    of an on-disk matrix: every rank streams only its own block from the store)."""
+    of an on-disk matrix: every rank streams only its own block from the store).
+    `nprobe`: None = exact kNN; p > 0 = the approximate IVF search (`pp.neighbors(transformer='ivf')`)."""
     comm = comm or NoComm()
     backend = backend or GpuBackend()
     tm = _Timer(timing)
@@ -206,11 +207,12 @@ def run_path(a_handle, n_total: int, *, comm=None, backend=None, n_comps: int = 
     tm.mark("pca")
     emb = _all_gather_rows(res.scores, comm, counts)  # [n_total, n_comps] float32 on every rank
     k = min(n_neighbors, n_total)
-    idx, dist, n_fallback = _kernels.knn(emb, k, q_begin=row_begin, n_query=row_end - row_begin)
+    idx, dist, n_fallback = _kernels.knn(emb, k, q_begin=row_begin, n_query=row_end - row_begin, nprobe=nprobe)
     tm.mark("knn")
     dev = emb.device
     labels = torch.empty(n_total, dtype=torch.int32, device=dev)
     q, nc = 0.0, 0
+    leiden_stats = None
     ci = cx = cd = None
     if world == 1:
         ci, cx, cd, _, _ = _kernels.fuzzy_simplicial_set(idx, dist.to(torch.float32))
@@ -220,6 +222,7 @@ def run_path(a_handle, n_total: int, *, comm=None, backend=None, n_comps: int = 
     tm.mark("connectivities")
     if rank == 0:
         labels, q, nc = _kernels.leiden(ci, cx, cd, n_total, resolution=resolution, n_iterations=n_iterations, seed=seed)
+        leiden_stats = _kernels.leiden_last_stats()
         tm.mark("leiden")
     if world > 1:
         import torch.distributed as tdist
@@ -238,5 +241,7 @@ def run_path(a_handle, n_total: int, *, comm=None, backend=None, n_comps: int = 
         tm.mark("broadcast")
     info = dict(res.info)
     info["knn_fallback_queries"] = n_fallback
+    if leiden_stats is not None:
+        info["leiden_stats"] = leiden_stats
     return PathResult(res.scores, res.components, res.explained_variance, res.explained_variance_ratio, idx, dist,
                       ci, cx, cd, labels, q, nc, tm.result(), info)

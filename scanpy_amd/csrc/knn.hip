@@ -1242,10 +1242,12 @@ __global__ __launch_bounds__(256) void ivf_cell_order_kernel(const float* __rest
 // last ~12 % of a launch ran with most CUs idle (SCAMD_KNN_TRACE timeline, round 2).
 __global__ __launch_bounds__(1024) void ivf_block_order_kernel(const int* __restrict__ work, const int* __restrict__ blk_off,
                                                                const int* __restrict__ blk_cnt, int n_cells,
-                                                               int* __restrict__ block_perm, int n_slots, int xcd_mode) {
+                                                               int* __restrict__ block_perm, int n_slots, int xcd_mode,
+                                                               int* __restrict__ err) {
   __shared__ long long key[IVF_MAX_CELLS];
   __shared__ int start[IVF_MAX_CELLS];
   const int tid = threadIdx.x;
+  start[tid] = -1;  // (a cell no queue had room for keeps -1: reported through *err, never a silent skip)
   // descending work, ascending cell: key = (~work << 32) | cell, sorted ascending
   key[tid] = tid < n_cells ? (((long long)(0x7fffffff - work[tid])) << 32) | (unsigned int)tid : 0x7fffffffffffffffll;
   for (int t = tid; t < n_slots; t += 1024) block_perm[t] = -1;  // launch slots without a block (xcd_mode) exit at once
@@ -1318,9 +1320,13 @@ __global__ __launch_bounds__(1024) void ivf_block_order_kernel(const int* __rest
   if (tid < n_cells) {
     const int c = (int)(key[tid] & 0xffffffffll);
     const int o = blk_off[c], cnt = blk_cnt[c], st = start[tid];
-    for (int t = 0; t < cnt; ++t) {
+    // a block without a launch slot would leave its queries unanswered: the host sizes the slots so that this cannot
+    // happen (run_ivf_select) and turns the flag into an error if it ever does
+    if (cnt > 0 && st < 0) atomicOr(err, 1);
+    for (int t = 0; t < cnt && st >= 0; ++t) {
       const int slot = xcd_mode ? st + 8 * t : st + t;
       if (slot < n_slots) block_perm[slot] = o + t;
+      else atomicOr(err, 1);
     }
   }
 }
@@ -1868,7 +1874,7 @@ constexpr int ASSIGN_ROWS = 512;
 __global__ __launch_bounds__(256) void ivf_assign_mfma_kernel(const float* __restrict__ x, int d, int64_t ld, int64_t start,
                                                               int64_t step, int64_t count,
                                                               const unsigned int* __restrict__ centb, int n_cells_pad,
-                                                              int* __restrict__ labels, int* __restrict__ counts,
+                                                              int n_cells, int* __restrict__ labels, int* __restrict__ counts,
                                                               int64_t q0, int64_t q1, int* __restrict__ qcounts) {
   extern __shared__ __attribute__((aligned(16))) unsigned int ctab[];  // [n_cells_pad][CENT_DPL]
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
@@ -1937,6 +1943,9 @@ __global__ __launch_bounds__(256) void ivf_assign_mfma_kernel(const float* __res
         id = take ? oid : id;
       }
       const int64_t jj = j0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      // (padding centroids score a finite -1.7e38: rows whose scores against every real centroid overflow to -inf --
+      // magnitudes around 1e19 -- would elect one; any real cell gives a correct search, an id past the tables does not)
+      id = min(id, n_cells - 1);
       if (l31 == 0 && jj < count) {
         const int64_t row = start + jj * step;
         labels[jj] = id;
@@ -2205,7 +2214,7 @@ static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffe
   b->cand_tau = ws.take<float>((size_t)p.nq_pad);
   b->kth_d2 = ws.take<double>((size_t)n_query);
   b->flag_list = ws.take<int>((size_t)n_query);
-  b->counters = ws.take<int>(8);  // [0] uncertified, [1] overflow, [2..3] swept pairs, [4..5] pre-pass pairs (u64)
+  b->counters = ws.take<int>(8);  // [0] uncertified, [1] overflow, [2..3] swept pairs, [4..5] pre-pass pairs (u64), [6] launch-order error
   b->scratch_d = ws.take<double>((size_t)FALLBACK_CHUNK * FALLBACK_CAP);
   b->scratch_i = ws.take<int>((size_t)FALLBACK_CHUNK * FALLBACK_CAP);
   b->fb_counts = ws.take<int>((size_t)FALLBACK_CHUNK);
@@ -2359,7 +2368,7 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
                          centb);
       SCAMD_LAUNCH_CHECK();
       hipLaunchKernelGGL(ivf_assign_mfma_kernel, dim3((unsigned)ceil_div(a_count, ASSIGN_ROWS)), dim3(256), lds_a, s, x, d, ld, a_start,
-                         a_step, a_count, centb, ncp, b.labels, counts, aq0, aq1, a_qcounts);
+                         a_step, a_count, centb, ncp, nc, b.labels, counts, aq0, aq1, a_qcounts);
       SCAMD_LAUNCH_CHECK();
       if (accumulate) {
         hipLaunchKernelGGL(ivf_sums_kernel, dim3((unsigned)ceil_div(a_count * d, 256)), dim3(256), 0, s, x, d, ld, a_start, a_step,
@@ -2501,7 +2510,7 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
     SCAMD_LAUNCH_CHECK();
     // launch order: longest expected sweeps first
     hipLaunchKernelGGL(ivf_block_order_kernel, dim3(1), dim3(1024), 0, s, b.cell_aux, b.cell_aux + nc, b.cell_aux + 2 * nc,
-                       nc, b.block_perm, n_launch, xcd_mode);
+                       nc, b.block_perm, n_launch, xcd_mode, b.counters + 6);
     SCAMD_LAUNCH_CHECK();
   }
   // 6. pruned sweep
@@ -2850,6 +2859,7 @@ static int knn_l2_impl(const float* x, int64_t n, int d, int64_t ld_x, int64_t q
     g_last_select_prepass_pairs = p.ivf ? (double)pre : 0.0;
     g_last_select_engine = p.b3 ? 1 : 0;
   }
+  SCAMD_REQUIRE(h_counters[6] == 0, SCAMD_EINTERNAL, "knn: a query block of the pruned sweep got no launch slot (XCD-aware order)");
   int n_flag = h_counters[0];
   const int* flag_list = b.flag_list;
   g_last_second_tier = 0;

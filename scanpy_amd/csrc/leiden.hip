@@ -31,8 +31,11 @@ namespace scamd {
 
 // per-call statistics of the last scamd_leiden_csr_f32 on this thread (scamd_leiden_last_stats): [0] outer iterations,
 // [1] kernel launches, [2] blocking host round trips, [3] full sweeps / [4] rounds / [5] moves of the final polish,
-// [6] 1 if the polish was skipped because the last iteration had already proven node optimality, [7] levels of iteration 0
-static thread_local int g_ld_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// [6] 1 if the polish was skipped because the last iteration had already proven node optimality, [7] levels of iteration 0,
+// [8] local-moving sweeps of the levels that run as separate kernels (all iterations), [9] their algorithmic traffic in MB:
+//     active rows x (12 B per entry + 16 B per vertex), SURVEY.md 8(d)'s per-sweep figure restricted to the rows a sweep visits
+static thread_local int g_ld_stats[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static thread_local double g_ld_sweep_bytes = 0.0;  // -> stats[9] (MB)
 #undef SCAMD_LAUNCH_CHECK
 #define SCAMD_LAUNCH_CHECK()                \
   do {                                      \
@@ -2401,6 +2404,8 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
       fprintf(stderr, "[leiden] lm n=%d sweep=%d classes=%d act=%d moved_prev=%d blocked_total=%d\n", g.n, sweep, n_cls, n_act,
               moved_last, ht[1]);
     if (n_act == 0) break;
+    ++g_ld_stats[8];
+    g_ld_sweep_bytes += (double)n_act * (12.0 * (double)g.nnz / (double)std::max(g.n, 1) + 16.0);
     if (sweep > 0) {
       // (with the direction rule on, blocked vertices stay active without anybody moving: two such sweeps end the level)
       quiet = (moved_last == 0) ? quiet + 1 : 0;
@@ -2984,7 +2989,8 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
   if (const char* e = getenv("SCAMD_LEIDEN_SMALL")) cx.small_levels = e[0] != '0';
   if (const char* e = getenv("SCAMD_LEIDEN_FUSE")) cx.no_fuse = e[0] == '0';
   if (const char* e = getenv("SCAMD_LEIDEN_POLISH")) cx.polish = e[0] != '0';
-  for (int i = 0; i < 8; ++i) g_ld_stats[i] = 0;
+  for (int i = 0; i < 12; ++i) g_ld_stats[i] = 0;
+  g_ld_sweep_bytes = 0.0;
   if (const char* e = getenv("SCAMD_LEIDEN_SMALL_SEQ")) cx.small_seq_n = atoi(e);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_WAVE_MAX")) cx.agg_wave_max = std::min(atoi(e), (int)WH_MAX_DEG);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_MAX")) cx.agg_mid_max = std::min(atoi(e), (int)AGG_MID_MAX);
@@ -3110,7 +3116,8 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
 }
 
 extern "C" void scamd_leiden_last_stats(int32_t* out, int n) {
-  for (int i = 0; i < n && i < 8; ++i) out[i] = g_ld_stats[i];
+  g_ld_stats[9] = (int)std::min(2.0e9, g_ld_sweep_bytes / 1.0e6);
+  for (int i = 0; i < n && i < 12; ++i) out[i] = g_ld_stats[i];
 }
 
 extern "C" int scamd_modularity_csr_f32(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n,

@@ -110,10 +110,10 @@ def knn(lib, x, k, *, q_begin=0, n_query=None, cert_scale=1.0, nprobe=0):
 
 
 def leiden_stats(lib) -> dict:
-    out = (C.c_int32 * 8)()
-    lib.scamd_leiden_last_stats(out, 8)
+    out = (C.c_int32 * 12)()
+    lib.scamd_leiden_last_stats(out, 12)
     keys = ("iterations", "launches", "host_round_trips", "polish_full_sweeps", "polish_rounds", "polish_moves",
-            "polish_skipped_proven", "levels_first_iteration")
+            "polish_skipped_proven", "levels_first_iteration", "lm_sweeps", "lm_sweep_algorithmic_MB")
     return dict(zip(keys, (int(v) for v in out)))
 
 

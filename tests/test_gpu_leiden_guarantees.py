@@ -1,12 +1,11 @@
 """The GPU Leiden's stable partitions against what the Leiden paper guarantees (oracle/leiden_guarantees.py), at a size the
 CPU oracle does not reach in a test: 300k cells, the three structures of the bench.
 
-Connected communities and g-separation (no merge of two communities improves the quality) hold exactly.  Node optimality
-(no single vertex move improves it) holds exactly on the planted matrix; on the ambiguous ones the GPU optimiser stops
-its local-moving sweeps early and leaves a residue, measured on the hardware (`tools/leiden_guarantees_probe.py`,
-profiles/r04v_leiden_guarantees.log: weak 9 of 300 000 vertices, structure-less 186, every gain below 1e-6 of a unit of
-modularity; the CPU oracle's residue is 0, tests/test_leiden_guarantees_cpu.py) and bounded here at three times that.
-Runs are bitwise reproducible across boxes (tests/test_gpu_leiden_determinism.py), so the counts are properties of the code.
+Connected communities, g-separation (no merge of two communities improves the quality) and node optimality (no single
+vertex move improves it) hold EXACTLY on all three.  (Round 4 left a residue on the ambiguous graphs -- weak 9 of 300 000
+vertices, structure-less 186, gains below 1e-6 Q, profiles/r04v_leiden_guarantees.log -- because the best partition of a
+run of non-monotone iterations need not be a stable one; round 5 ends an n_iterations = -1 run with a strictly monotone
+polish and a verifying iteration, csrc/leiden.hip `polish_level0`.)
 """
 from __future__ import annotations
 
@@ -23,12 +22,10 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 N = 300_000
-# structure -> (largest fraction of improvable vertices, largest gain of one move in units of Q)
-BOUNDS = {"planted": (0.0, 0.0), "weak": (1e-4, 1e-5), "none": (2e-3, 1e-5)}
 
 
 @pytest.mark.parametrize("structure", ["planted", "weak", "none"])
-def test_stable_partition_is_separated_connected_and_almost_node_optimal(structure):
+def test_stable_partition_is_separated_connected_and_node_optimal(structure):
     import torch
 
     import bench
@@ -43,6 +40,7 @@ def test_stable_partition_is_separated_connected_and_almost_node_optimal(structu
     ip, ix, w = res.conn_indptr, res.conn_indices, res.conn_data
     labels, q, nc = K.leiden(ip, ix, w, N)
     torch.cuda.synchronize()
+    st = K.leiden_last_stats()
     conn = sparse.csr_matrix((w.cpu().numpy(), ix.cpu().numpy(), ip.cpu().numpy()), shape=(N, N))
     lab = labels.cpu().numpy()
     im = lg.improving_moves(conn, lab)
@@ -52,9 +50,9 @@ def test_stable_partition_is_separated_connected_and_almost_node_optimal(structu
     inner.eliminate_zeros()
     n_comp, _ = connected_components(inner, directed=False)
     print(f"{structure}: Q {q:.6f}, {nc} communities, improving moves {im['count']} (max gain {im['max_gain']:.3e} Q), "
-          f"mergeable pairs {mp['count']} (max gain {mp['max_gain']:.3e})")
+          f"mergeable pairs {mp['count']} (max gain {mp['max_gain']:.3e}); {st}")
     assert nc > 1 and n_comp == nc
     assert mp["count"] == 0, mp
-    frac, gain = BOUNDS[structure]
-    assert im["fraction"] <= frac, im
-    assert im["count"] == 0 or im["max_gain"] <= gain, im
+    assert im["count"] == 0, im
+    # either the last iteration proved node optimality itself or the polish ran its proving full sweep
+    assert st["polish_skipped_proven"] == 1 or st["polish_full_sweeps"] >= 1, st

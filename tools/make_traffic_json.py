@@ -21,9 +21,14 @@ def main():
     fetch, name, grid = total(sys.argv[1], "FETCH_SIZE")
     write, _, _ = total(sys.argv[2], "WRITE_SIZE")
     out = {
-        "kernel": name, "engine": "bf16x3" if "true, true" in name or ", true>" in name and name.count("true") == 2 else "f32",
+        "kernel": name, "engine": "bf16x3" if ("true, true" in name or (", true>" in name and name.count("true") == 2)) else "f32",
         "mode": "ivf", "grid_threads": grid, "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
+        # raw = the counters as reported; corrected = FETCH_SIZE doubled (MI355X_MICROARCH.md, "HBM [CDNA4]": on gfx950
+        # FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read -- 16 B per lane, global_load and
+        # buffer_load ... lds alike, which is what this kernel's tile stream is; WRITE_SIZE is uncalibrated and left as is)
+        "bytes_per_launch_raw": (fetch + write) * 1024.0,
         "bytes_per_launch": (2.0 * fetch + write) * 1024.0,
+        "fetch_correction": {"factor": 2.0, "source": "/opt/skills/guides/MI355X_MICROARCH.md, section 'HBM [CDNA4]'"},
         "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (counters restricted to the select kernel: --kernel-include-regex) "
                 "of tools/knn_only.py 1000000 1 on the bench's own embedding (cell-pruned sweep, XCD-aware launch order, one launch, summed "
                 "over the dispatch's rows = all XCDs); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced "
