@@ -270,9 +270,18 @@ int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indices, const fl
  *   [6] 1 if the polish was skipped because the last iteration itself had proven node optimality,
  *   [7] levels of the first iteration,
  *   [8] local-moving sweeps of the levels that run as separate kernels, [9] their algorithmic traffic in MB (active rows
- *       x (12 B per entry + 16 B per vertex): SURVEY.md 8(d)'s per-sweep figure over the rows a sweep visits), [10..11] 0.
+ *       x (12 B per entry + 16 B per vertex): SURVEY.md 8(d)'s per-sweep figure over the rows a sweep visits),
+ *   [10] communities the polish split off (a departing vertex had cut them in two), [11] 1 if the cap on the outer iterations
+ *        (32) ended an n_iterations < 0 run instead of convergence.
  * Diagnostics only (bench.py, tools/). */
 void scamd_leiden_last_stats(int32_t* out, int n);
+/* Test entry: the component split the polish applies after its moves -- every connected component (over the stored
+ * entries) of a community of `membership` (ids in [0, n), device, rewritten in place) becomes a community of its own, id =
+ * its smallest vertex; *n_split_host = components - communities (0: membership untouched).  Workspace:
+ * scamd_leiden_workspace_bytes. */
+int scamd_leiden_debug_split_f32(const int64_t* indptr, const int32_t* indices, const float* weights,
+                                 int64_t n, int64_t nnz, int32_t* membership, int32_t* n_split_host,
+                                 void* workspace, size_t workspace_bytes, scamd_stream_t stream);
 /* Modularity of a given membership (replaces igraph Graph.modularity as used by
  * src/scanpy/metrics/_metrics.py:202-214). */
 int scamd_modularity_csr_f32(const int64_t* indptr, const int32_t* indices, const float* weights,

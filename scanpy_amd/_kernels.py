@@ -102,7 +102,7 @@ def knn(x: torch.Tensor, k: int, *, q_begin: int = 0, n_query: int | None = None
     dist = _empty((nq, k), dtype=torch.float64, device=dev)
     need = lib.scamd_knn_workspace_bytes(n, d, nq, k)
     if need == 0 and nq > 0:
-        raise _lib.ScamdError(f"knn: unsupported shape d={d} (max 128) / k={k} (max 120)")
+        raise _lib.ScamdError(f"knn: unsupported shape d={d} (max 256) / k={k} (max 256)")
     ws, wsz = _ws(need, dev)
     nfb = C.c_int64(0)
     if nprobe:
@@ -420,7 +420,7 @@ def leiden_last_stats() -> dict:
     out = (C.c_int32 * 12)()
     _lib.load().scamd_leiden_last_stats(out, 12)
     keys = ("iterations", "launches", "host_round_trips", "polish_full_sweeps", "polish_rounds", "polish_moves",
-            "polish_skipped_proven", "levels_first_iteration", "lm_sweeps", "lm_sweep_algorithmic_MB")
+            "polish_skipped_proven", "levels_first_iteration", "lm_sweeps", "lm_sweep_algorithmic_MB", "polish_splits", "ended_by_iteration_cap")
     return dict(zip(keys, (int(v) for v in out)))
 
 

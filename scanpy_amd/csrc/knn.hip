@@ -93,12 +93,13 @@ constexpr int FALLBACK_CHUNK = 1024;  // uncertified queries processed per launc
 // read the caller's x.  Two stages, fixed summation order: the same mu for the same input, run to run.
 // ------------------------------------------------------------------------------------------------
 constexpr int MEAN_BLOCKS = 256;
+constexpr int KNN_MAX_D = 256;  // widest row the search takes (stride of the column-mean tables)
 __global__ __launch_bounds__(1024) void knn_colsum_kernel(const float* __restrict__ x, int64_t n, int d, int64_t ld,
-                                                          double* __restrict__ partial /* [MEAN_BLOCKS][128] */) {
+                                                          double* __restrict__ partial /* [MEAN_BLOCKS][KNN_MAX_D] */) {
   // 1024 threads = 16 (8) rows at a time per workgroup, four independent loads in flight per thread (a 256-thread
   // workgroup with one load per thread in flight read the 200 MB of the 1M x 50 matrix at 0.5 TB/s)
   __shared__ double sh[1024];
-  const int cols = d <= 64 ? 64 : 128, rpar = 1024 / cols;
+  const int cols = d <= 64 ? 64 : (d <= 128 ? 128 : 256), rpar = 1024 / cols;
   const int c = threadIdx.x % cols, rr = threadIdx.x / cols;
   const int64_t chunk = (n + MEAN_BLOCKS - 1) / MEAN_BLOCKS;
   const int64_t r0 = (int64_t)blockIdx.x * chunk, r1 = std::min<int64_t>(n, r0 + chunk);
@@ -119,15 +120,16 @@ __global__ __launch_bounds__(1024) void knn_colsum_kernel(const float* __restric
   __syncthreads();
   if (rr == 0) {
     for (int j = 1; j < rpar; ++j) s += sh[j * cols + c];
-    if (c < 128) partial[(int64_t)blockIdx.x * 128 + c] = (c < d) ? s : 0.0;
+    partial[(int64_t)blockIdx.x * KNN_MAX_D + c] = (c < d) ? s : 0.0;
   }
-  if (cols == 64 && threadIdx.x >= 64 && threadIdx.x < 128) partial[(int64_t)blockIdx.x * 128 + threadIdx.x] = 0.0;
+  // (columns beyond the ones this launch's layout covers: zero)
+  if ((int)threadIdx.x >= cols && (int)threadIdx.x < KNN_MAX_D) partial[(int64_t)blockIdx.x * KNN_MAX_D + threadIdx.x] = 0.0;
 }
-__global__ __launch_bounds__(128) void knn_colmean_kernel(const double* __restrict__ partial, int64_t n, int d,
-                                                          float* __restrict__ mu /* [128] */) {
+__global__ __launch_bounds__(KNN_MAX_D) void knn_colmean_kernel(const double* __restrict__ partial, int64_t n, int d,
+                                                                float* __restrict__ mu /* [KNN_MAX_D] */) {
   const int c = threadIdx.x;
   double s = 0.0;
-  for (int b = 0; b < MEAN_BLOCKS; ++b) s += partial[(int64_t)b * 128 + c];
+  for (int b = 0; b < MEAN_BLOCKS; ++b) s += partial[(int64_t)b * KNN_MAX_D + c];
   mu[c] = (c < d && n > 0) ? (float)(s / (double)n) : 0.f;
 }
 
@@ -173,6 +175,8 @@ struct SelectCfg {
   static constexpr int TILE_F4 = TC * DP / 4;
   static constexpr int F4_PER_THREAD = (TILE_F4 + NT - 1) / NT;
   static constexpr size_t LDS_BYTES = (size_t)(2 * TC * DPL + 2 * TC + 2 * KP * QB + 2 * QB) * 4;
+  static_assert(TC <= NT, "thread t stages the norm of candidate t of a tile");
+  static_assert(LDS_BYTES <= 160 * 1024, "tiles + lists must fit the 160 KB of LDS");
 };
 
 template <int H, int TC, int NW, int KP>
@@ -1347,7 +1351,7 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
     double* __restrict__ out_dist, double* __restrict__ kth_d2, int* __restrict__ flag_list,
     int* __restrict__ n_flag, const int* __restrict__ qlist, int n_list) {
   constexpr int PER = (KP + 63) / 64;
-  __shared__ float qs[4][128];
+  __shared__ float qs[4][KNN_MAX_D];
   __shared__ double sd[4][KP];
   __shared__ int si[4][KP];
   __shared__ double skth[4];
@@ -1633,7 +1637,7 @@ __global__ __launch_bounds__(256) void knn_fallback_scan_kernel(
     const float* __restrict__ x, int64_t n, int d, int64_t ld, int64_t q_begin,
     const int* __restrict__ flag_list, int flag_begin, const double* __restrict__ kth_d2,
     double* __restrict__ scratch_d, int* __restrict__ scratch_i, int* __restrict__ counts) {
-  __shared__ float qs[128];
+  __shared__ float qs[KNN_MAX_D];
   const int fb = blockIdx.y;
   const int64_t qi = flag_list[flag_begin + fb];
   const int64_t q = q_begin + qi;
@@ -1671,7 +1675,7 @@ __global__ __launch_bounds__(256) void knn_fallback_scan_cells_kernel(
     const double* __restrict__ kth_d2, double* __restrict__ scratch_d, int* __restrict__ scratch_i, int* __restrict__ counts,
     const float* __restrict__ cent, const float* __restrict__ radius, const int* __restrict__ cell_tile0,
     const int* __restrict__ cell_ntiles, const int* __restrict__ perm, int n_cells) {
-  __shared__ float qs[128];
+  __shared__ float qs[KNN_MAX_D];
   const int fb = blockIdx.y;
   const int64_t qi = flag_list[flag_begin + fb];
   const int64_t q = q_begin + qi;
@@ -2109,12 +2113,19 @@ static bool knn_plan(int64_t n, int d, int64_t n_query, int k, KnnPlan* p, int n
   else if (d <= 50) p->H = 25;
   else if (d <= 64) p->H = 32;
   else if (d <= 128) p->H = 64;
+  else if (d <= 256) p->H = 128;
   else return false;
-  p->TC = (p->H == 64) ? 64 : 128;
+  p->TC = (p->H == 128) ? 32 : ((p->H == 64) ? 64 : 128);
   if (k <= 24) { p->KP = 32; p->NW = 8; }
   else if (k <= 56) { p->KP = 64; p->NW = 4; }
   else if (k <= 120) { p->KP = 128; p->NW = 2; }
+  else if (k <= 256) { p->KP = 288; p->NW = 1; }  // (one wave per block: the lists of 32 queries take 72 KB of LDS)
   else return false;
+  // d > 128: the query operand and one fragment take 256 registers -- blocks of at most two waves (512 VGPRs per lane)
+  if (p->H == 128 && p->NW > 2) {
+    p->NW = 2;
+    p->KP = std::max(p->KP, 128);
+  }
   static const bool legacy = [] {
     const char* e = getenv("SCAMD_KNN_LEGACY");
     return e && e[0] == '1';
@@ -2207,8 +2218,8 @@ struct KnnBuffers {
 static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffers* b) {
   b->xp = ws.take<float>((size_t)p.n_pad * p.row_dwords);
   b->cn = ws.take<float>((size_t)p.n_pad);
-  b->mu = ws.take<float>(128);
-  b->mean_partial = ws.take<double>((size_t)MEAN_BLOCKS * 128);
+  b->mu = ws.take<float>(KNN_MAX_D);
+  b->mean_partial = ws.take<double>((size_t)MEAN_BLOCKS * KNN_MAX_D);
   b->cmax = ws.take<unsigned int>(4);
   b->cand_idx = ws.take<int>((size_t)p.nq_pad * p.KP);
   b->cand_tau = ws.take<float>((size_t)p.nq_pad);
@@ -2274,8 +2285,15 @@ static int dispatch_kp(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, h
   switch (p.KP) {
     case 32: return launch_select<H, TC, 8, 32>(p, b, q_begin, s);
     case 64: return launch_select<H, TC, 4, 64>(p, b, q_begin, s);
-    default: return launch_select<H, TC, 2, 128>(p, b, q_begin, s);
+    case 128: return launch_select<H, TC, 2, 128>(p, b, q_begin, s);
+    default: return launch_select<H, (TC < 64 ? TC : 64), 1, 288>(p, b, q_begin, s);  // (one wave stages at most 64 norms per tile)
   }
+}
+// d > 128: two shapes only (see knn_plan)
+template <>
+int dispatch_kp<128, 32>(const KnnPlan& p, const KnnBuffers& b, int64_t q_begin, hipStream_t s) {
+  if (p.KP == 128) return launch_select<128, 32, 2, 128>(p, b, q_begin, s);
+  return launch_select<128, 32, 1, 288>(p, b, q_begin, s);
 }
 
 template <int H, int TC_, int WPS, bool B3 = false>
@@ -2323,7 +2341,8 @@ static int dispatch_select(const KnnPlan& p, const KnnBuffers& b, int64_t q_begi
     case 16: return dispatch_kp<16, 128>(p, b, q_begin, s);
     case 25: return dispatch_kp<25, 128>(p, b, q_begin, s);
     case 32: return dispatch_kp<32, 128>(p, b, q_begin, s);
-    default: return dispatch_kp<64, 64>(p, b, q_begin, s);
+    case 64: return dispatch_kp<64, 64>(p, b, q_begin, s);
+    default: return dispatch_kp<128, 32>(p, b, q_begin, s);
   }
 }
 
@@ -2773,7 +2792,7 @@ static int knn_l2_impl(const float* x, int64_t n, int d, int64_t ld_x, int64_t q
   SCAMD_REQUIRE(k >= 1, SCAMD_EINVAL, "knn: k=%d", k);
   KnnPlan p;
   SCAMD_REQUIRE(knn_plan(n, d, n_query, k, &p, nprobe), SCAMD_EUNSUPPORTED,
-                "knn: unsupported d=%d (max 128) or k=%d (max 120)", d, k);
+                "knn: unsupported d=%d (max 256) or k=%d (max 256)", d, k);
   if (n_fallback_host) *n_fallback_host = 0;
   if (n_query == 0) return SCAMD_OK;
   Workspace ws(workspace, workspace_bytes);
@@ -2787,7 +2806,7 @@ static int knn_l2_impl(const float* x, int64_t n, int d, int64_t ld_x, int64_t q
   SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, 32, s));
   hipLaunchKernelGGL(knn_colsum_kernel, dim3(MEAN_BLOCKS), dim3(1024), 0, s, x, n, d, ld_x, b.mean_partial);
   SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(knn_colmean_kernel, dim3(1), dim3(128), 0, s, b.mean_partial, n, d, b.mu);
+  hipLaunchKernelGGL(knn_colmean_kernel, dim3(1), dim3(KNN_MAX_D), 0, s, b.mean_partial, n, d, b.mu);
   SCAMD_LAUNCH_CHECK();
   if (!p.ivf) {
     int blocks = (int)std::min<int64_t>((p.n_pad + 3) / 4, 256 * 16);
@@ -2834,11 +2853,12 @@ static int knn_l2_impl(const float* x, int64_t n, int d, int64_t ld_x, int64_t q
     int blocks = (int)((n_query + 3) / 4);
 #define RERANK(KP_)                                                                              \
   hipLaunchKernelGGL(knn_rerank_kernel<KP_>, dim3(blocks), dim3(256), 0, s, x, b.mu, n, d, ld_x, q_begin, \
-                     n_query, k, b.cand_idx, b.cand_tau, b.cmax, cert_scale, p.b3 ? CERT_K_B3 : CERT_K_F32, p.b3 ? CERT_K2_B3 : 0.0, out_idx, out_dist,  \
+                     n_query, k, b.cand_idx, b.cand_tau, b.cmax, cert_scale, p.b3 ? CERT_K_B3 : CERT_K_F32 + (p.H > 64 ? 2.0 * (p.H - 64) : 0.0), p.b3 ? CERT_K2_B3 : 0.0, out_idx, out_dist,  \
                      b.kth_d2, b.flag_list, b.counters, (const int*)nullptr, 0)
     if (p.KP == 32) RERANK(32);
     else if (p.KP == 64) RERANK(64);
-    else RERANK(128);
+    else if (p.KP == 128) RERANK(128);
+    else RERANK(288);
 #undef RERANK
     SCAMD_LAUNCH_CHECK();
   }
@@ -2956,8 +2976,8 @@ extern "C" void scamd_knn_cert_factors(int engine, double* cert_k, double* cert_
 extern "C" size_t scamd_knn_debug_b3_scores_workspace_bytes(int64_t n) {
   Workspace ws(nullptr, 0);
   ws.take<float>((size_t)n * B3_DPL);
-  ws.take<float>(128);
-  ws.take<double>((size_t)MEAN_BLOCKS * 128);
+  ws.take<float>(KNN_MAX_D);
+  ws.take<double>((size_t)MEAN_BLOCKS * KNN_MAX_D);
   ws.take<unsigned int>(4);
   return ws.used();
 }
@@ -2971,15 +2991,15 @@ extern "C" int scamd_knn_debug_b3_scores_f32(const float* x, int64_t n, int d, i
                 SCAMD_EINVAL, "knn debug scores: query / candidate blocks must be multiples of 32 inside [0, n)");
   Workspace ws(workspace, workspace_bytes);
   float* xp = ws.take<float>((size_t)n * B3_DPL);
-  float* mu = ws.take<float>(128);
-  double* partial = ws.take<double>((size_t)MEAN_BLOCKS * 128);
+  float* mu = ws.take<float>(KNN_MAX_D);
+  double* partial = ws.take<double>((size_t)MEAN_BLOCKS * KNN_MAX_D);
   unsigned int* cmax = ws.take<unsigned int>(4);
   SCAMD_REQUIRE(workspace && ws.ok, SCAMD_EWORKSPACE, "knn debug scores: workspace %zu < required %zu", workspace_bytes, ws.used());
   hipStream_t s = stream;
   SCAMD_HIP_CHECK(hipMemsetAsync(cmax, 0, 16, s));
   hipLaunchKernelGGL(knn_colsum_kernel, dim3(MEAN_BLOCKS), dim3(1024), 0, s, x, n, d, ld_x, partial);
   SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(knn_colmean_kernel, dim3(1), dim3(128), 0, s, partial, n, d, mu);
+  hipLaunchKernelGGL(knn_colmean_kernel, dim3(1), dim3(KNN_MAX_D), 0, s, partial, n, d, mu);
   SCAMD_LAUNCH_CHECK();
   const int blocks = (int)std::min<int64_t>((n + 3) / 4, 256 * 16);
   hipLaunchKernelGGL(knn_pack_image_kernel, dim3(blocks), dim3(256), 0, s, x, mu, n, d, ld_x, 25, 28, B3_DPL, n, xp, cmax, 1);

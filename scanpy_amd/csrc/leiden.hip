@@ -33,7 +33,8 @@ namespace scamd {
 // [1] kernel launches, [2] blocking host round trips, [3] full sweeps / [4] rounds / [5] moves of the final polish,
 // [6] 1 if the polish was skipped because the last iteration had already proven node optimality, [7] levels of iteration 0,
 // [8] local-moving sweeps of the levels that run as separate kernels (all iterations), [9] their algorithmic traffic in MB:
-//     active rows x (12 B per entry + 16 B per vertex), SURVEY.md 8(d)'s per-sweep figure restricted to the rows a sweep visits
+//     active rows x (12 B per entry + 16 B per vertex), SURVEY.md 8(d)'s per-sweep figure restricted to the rows a sweep visits,
+// [10] communities the polish split off because a departure had cut them in two, [11] 1 if the iteration cap ended the run
 static thread_local int g_ld_stats[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 static thread_local double g_ld_sweep_bytes = 0.0;  // -> stats[9] (MB)
 #undef SCAMD_LAUNCH_CHECK
@@ -780,6 +781,39 @@ __global__ __launch_bounds__(256) void ld_polish_apply_kernel(int n_act, const i
   if (threadIdx.x == 0) {
     if (s_moved) atomicAdd(&counters[0], s_moved);
     if (s_lost) atomicAdd(&counters[1], s_lost);
+  }
+}
+
+// A vertex that leaves may have been the only link between two parts of its community.  After a polish that moved
+// anything: connected components INSIDE the communities by min-label propagation (comp[v] -> the smallest vertex id of
+// its component; in place, monotone, with one pointer jump per visit), and every component becomes a community of its
+// own (splitting a community along a cut without edges raises Q by 2 g K1 K2 / (2m)^2 > 0).
+__global__ void ld_cc_prop_kernel(int n, const int64_t* __restrict__ indptr, const int* __restrict__ indices,
+                                  const int* __restrict__ comm, int* __restrict__ comp, int* __restrict__ changed) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  const int c = comm[v];
+  const int old = __hip_atomic_load(&comp[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int m = old;
+  for (int64_t e = indptr[v]; e < indptr[v + 1]; ++e) {
+    const int u = indices[e];
+    if (comm[u] == c) m = min(m, __hip_atomic_load(&comp[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  }
+  m = min(m, __hip_atomic_load(&comp[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));  // (comp[m] <= m, same component)
+  if (m < old) {
+    atomicMin(&comp[v], m);
+    *changed = 1;
+  }
+}
+// out[0] += components (roots), out[1] += non-empty communities
+__global__ __launch_bounds__(256) void ld_cc_count_kernel(int n, const int* __restrict__ comp, const int* __restrict__ csize,
+                                                          int* __restrict__ out) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool root = v < n && comp[v] == v, alive = v < n && csize[v] > 0;
+  const unsigned long long mr = __ballot(root), ma = __ballot(alive);
+  if ((threadIdx.x & 63) == 0) {
+    if (mr) atomicAdd(&out[0], __popcll(mr));
+    if (ma) atomicAdd(&out[1], __popcll(ma));
   }
 }
 
@@ -2520,14 +2554,48 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
 
 // Final polish of the level-0 partition in b.memb (see ld_polish_lock_kernel): full sweeps of lock-arbitrated moves until
 // a sweep over ALL vertices finds no improving move -- node optimality by construction.  b.memb is updated in place;
-// stats[0] = full sweeps, [1] = rounds, [2] = moves.  Needs b.Kref (the refinement's scratch) as the lock table.
+// stats[0] = full sweeps, [1] = rounds, [2] = moves, [3] = communities split off (split_disconnected).  Needs b.Kref (the
+// refinement's scratch) as the lock table.
+// b.comm: every connected component of a community becomes its own community (ids = smallest member); totals recomputed.
+// *n_split = components - communities (0: nothing changed).  Scratch: b.cid, b.counters[2..4].
+static int split_disconnected(LeidenCtx& cx, const LevelGraph& g, int* n_split) {
+  LeidenBuffers& b = cx.b;
+  *n_split = 0;
+  hipLaunchKernelGGL(ld_iota_kernel, GRID1(g.n), 0, cx.s, b.cid, g.n);
+  SCAMD_LAUNCH_CHECK();
+  for (int it = 0; it < g.n; ++it) {
+    SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 2, 0, sizeof(int) * 3, cx.s));
+    // (several propagation steps per host round trip: the flag only says whether any of them changed something)
+    for (int rep = 0; rep < 4; ++rep) {
+      hipLaunchKernelGGL(ld_cc_prop_kernel, GRID1(g.n), 0, cx.s, g.n, g.indptr, g.indices, (const int*)b.comm, b.cid, b.counters + 2);
+      SCAMD_LAUNCH_CHECK();
+    }
+    int changed = 0;
+    SCAMD_HIP_CHECK(hipMemcpyAsync(&changed, b.counters + 2, sizeof(int), hipMemcpyDeviceToHost, cx.s));
+    LD_SYNC(cx.s);
+    if (!changed) break;
+  }
+  hipLaunchKernelGGL(ld_cc_count_kernel, GRID1(g.n), 0, cx.s, g.n, (const int*)b.cid, (const int*)b.csize, b.counters + 3);
+  SCAMD_LAUNCH_CHECK();
+  int cnt[2] = {0, 0};
+  SCAMD_HIP_CHECK(hipMemcpyAsync(cnt, b.counters + 3, sizeof(cnt), hipMemcpyDeviceToHost, cx.s));
+  LD_SYNC(cx.s);
+  *n_split = cnt[0] - cnt[1];
+  if (leiden_debug()) fprintf(stderr, "[leiden] components %d, communities %d\n", cnt[0], cnt[1]);
+  if (*n_split > 0) {
+    SCAMD_HIP_CHECK(hipMemcpyAsync(b.comm, b.cid, sizeof(int) * g.n, hipMemcpyDeviceToDevice, cx.s));
+    return compute_totals(cx, g, b.comm);
+  }
+  return SCAMD_OK;
+}
+
 constexpr int MAX_POLISH_ROUNDS = 1 << 16;
 constexpr int MAX_POLISH_PASSES = 6;  // polish -> verifying iteration -> polish ... (each accepted pass raises Q)
 static int polish_level0(LeidenCtx& cx, const LevelGraph& g, int* stats) {
   LeidenBuffers& b = cx.b;
   const double gg = cx.gamma / cx.m2;
   const size_t n = (size_t)g.n;
-  stats[0] = stats[1] = stats[2] = 0;
+  stats[0] = stats[1] = stats[2] = stats[3] = 0;
   SCAMD_HIP_CHECK(hipMemcpyAsync(b.comm, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
   int rc = compute_totals(cx, g, b.comm);
   if (rc != SCAMD_OK) return rc;
@@ -2541,6 +2609,7 @@ static int polish_level0(LeidenCtx& cx, const LevelGraph& g, int* stats) {
   int* ctr = sw + MAX_CLASSES;  // counter block of the one class
   unsigned int round = 0;
   int moved_before = 0, moved_at_full = 0;
+  int checked_at = 0;  // moves + splits when the communities were last known to be connected (the input is: an iteration's result)
   bool full = true;  // the next round decides for every vertex (else: for the flagged ones)
   for (;;) {
     SCAMD_HIP_CHECK(hipMemsetAsync(sw, 0, sizeof(int) * (MAX_CLASSES + CTR_STRIDE), cx.s));
@@ -2563,7 +2632,17 @@ static int polish_level0(LeidenCtx& cx, const LevelGraph& g, int* stats) {
     if (cnt == 0) {
       // nobody is flagged any more.  If nothing moved since the last sweep over ALL vertices, that sweep was the proof
       // of node optimality; otherwise another full sweep has to give it.
-      if (ht[0] == moved_at_full) break;
+      if (ht[0] == moved_at_full) {
+        // ... and if anything has moved since the communities were last known to be connected: split what a departure
+        // cut in two (the parts are communities of their own then, and the proof has to be given again)
+        if (ht[0] + stats[3] == checked_at) break;
+        int n_split = 0;
+        rc = split_disconnected(cx, g, &n_split);
+        if (rc != SCAMD_OK) return rc;
+        stats[3] += n_split;
+        checked_at = ht[0] + stats[3];
+        if (n_split == 0) break;
+      }
       full = true;
       continue;
     }
@@ -2608,7 +2687,7 @@ static int polish_level0(LeidenCtx& cx, const LevelGraph& g, int* stats) {
                        (const int*)b.comm, b.flag);
     SCAMD_LAUNCH_CHECK();
   }
-  if (stats[2] > 0) SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb, b.comm, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+  if (stats[2] + stats[3] > 0) SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb, b.comm, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
   return SCAMD_OK;
 }
 
@@ -3026,6 +3105,7 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
     // true once b.memb_best has been the INPUT of an iteration whose level-0 local moving found nothing to move: its
     // first sweep decides for every vertex on the final state, so that is a proof of node optimality
     bool best_is_clean = false;
+    bool ended_by_cap = true;  // the loop below ran out of iterations (n_iterations < 0: MAX_OUTER_ITERS) instead of converging
     for (int it = 0; it < max_iter; ++it) {
       cx.iter = it;
       g_ld_stats[0] = it + 1;
@@ -3055,7 +3135,9 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
       // the run as well -- without this patience a single unlucky iteration right after the first one froze the
       // result of ONE iteration (Q 0.8028 instead of 0.812 on the 700-cell fixture).
       if (n_iterations < 0 && !improved) {
+        ended_by_cap = false;
         if (!worse || ++bad_iters >= 2) break;
+        ended_by_cap = true;
       }
     }
     // n_iterations < 0 promises a STABLE partition (leidenalg iterates until an iteration changes nothing; such a
@@ -3065,18 +3147,21 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
     // ordinary iteration from the polished partition: its level-0 moving finds nothing, its refinement and coarse levels
     // re-examine everything else.  No gain: stable, done.  A gain: accepted, and the polish runs again.
     int n_iter_total = g_ld_stats[0];
+    ended_by_cap = ended_by_cap && max_iter == MAX_OUTER_ITERS;  // (not the test knob's cap: that one is followed up)
+    g_ld_stats[11] = (n_iterations < 0 && ended_by_cap) ? 1 : 0;
     for (int pr = 0; n_iterations < 0 && cx.polish && pr <= MAX_POLISH_PASSES; ++pr) {
       if (best_is_clean) {
         if (pr == 0) g_ld_stats[6] = 1;
         break;
       }
       // (b.memb == b.memb_best here: every iteration ends with one copied onto the other)
-      int ps[3] = {0, 0, 0};
+      int ps[4] = {0, 0, 0, 0};
       rc = polish_level0(cx, g0, ps);
       if (rc != SCAMD_OK) return rc;
       g_ld_stats[3] += ps[0];
       g_ld_stats[4] += ps[1];
       g_ld_stats[5] += ps[2];
+      g_ld_stats[10] += ps[3];
       if (ps[2] == 0) break;  // the full sweep found no improving move: node optimal as it stands
       double q = 0.0;
       rc = compute_totals(cx, g0, b.memb);
@@ -3087,7 +3172,10 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
       SCAMD_REQUIRE(q >= q_best - 1e-12, SCAMD_EINTERNAL, "leiden: the monotone polish lowered the quality (%.12f -> %.12f)", q_best, q);
       q_best = q;
       SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb_best, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
-      if (pr == MAX_POLISH_PASSES) break;  // (the last pass only polishes what the last accepted iteration left)
+      // (the last pass only polishes what the last accepted iteration left.  A run that the iteration cap ended was still
+      // gaining a little with every iteration -- structure-less graphs do that for dozens of iterations: there is no stable
+      // partition to verify, the polished one is node optimal and connected, and that is what is returned)
+      if (pr == MAX_POLISH_PASSES || ended_by_cap) break;
       cx.iter = n_iter_total++;
       g_ld_stats[0] = n_iter_total;
       rc = leiden_iteration(cx, g0);
@@ -3112,6 +3200,36 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
   LD_SYNC(cx.s);
   if (modularity_host) *modularity_host = q_best;
   if (n_communities_host) *n_communities_host = nc;
+  return SCAMD_OK;
+}
+
+// Test entry: the component split of the polish (split_disconnected) on a GIVEN membership (ids in [0, n)): every
+// connected component of a community becomes a community of its own (id = its smallest vertex); membership is rewritten
+// in place when anything was split, *n_split_host = components - communities.
+extern "C" int scamd_leiden_debug_split_f32(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n,
+                                            int64_t nnz, int32_t* membership, int32_t* n_split_host, void* workspace,
+                                            size_t workspace_bytes, scamd_stream_t stream) {
+  SCAMD_REQUIRE(indptr && membership && n_split_host && (nnz == 0 || (indices && weights)), SCAMD_EINVAL, "leiden split: null pointer");
+  SCAMD_REQUIRE(n >= 1 && n < ((int64_t)1 << 31) && nnz >= 0, SCAMD_EINVAL, "leiden split: bad shape");
+  LeidenCtx cx;
+  cx.s = stream;
+  cx.gamma = 1.0;
+  cx.seed = 0;
+  Workspace ws(workspace, workspace_bytes);
+  leiden_carve(ws, n, nnz, &cx.b);
+  SCAMD_REQUIRE(workspace && ws.ok, SCAMD_EWORKSPACE, "leiden split: workspace %zu < required %zu", workspace_bytes, ws.used());
+  LevelGraph g0;
+  int rc = setup_level0(cx, indptr, indices, weights, n, nnz, &g0);
+  if (rc != SCAMD_OK) return rc;
+  SCAMD_HIP_CHECK(hipMemcpyAsync(cx.b.comm, membership, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+  rc = compute_totals(cx, g0, cx.b.comm);
+  if (rc != SCAMD_OK) return rc;
+  int n_split = 0;
+  rc = split_disconnected(cx, g0, &n_split);
+  if (rc != SCAMD_OK) return rc;
+  if (n_split > 0) SCAMD_HIP_CHECK(hipMemcpyAsync(membership, cx.b.comm, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  *n_split_host = n_split;
   return SCAMD_OK;
 }
 

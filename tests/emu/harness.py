@@ -109,11 +109,27 @@ def knn(lib, x, k, *, q_begin=0, n_query=None, cert_scale=1.0, nprobe=0):
     return idx, dist, int(nfb.value)
 
 
+def leiden_split(lib, adj, membership):
+    """scamd_leiden_debug_split_f32 -> (membership after the split, components - communities)"""
+    adj = adj.tocsr()
+    adj.sort_indices()
+    n = adj.shape[0]
+    indptr = np.ascontiguousarray(adj.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(adj.indices, dtype=np.int32)
+    w = np.ascontiguousarray(adj.data, dtype=np.float32)
+    memb = np.ascontiguousarray(membership, dtype=np.int32).copy()
+    ns = C.c_int32(0)
+    ws = _ws(lib.scamd_leiden_workspace_bytes(n, adj.nnz))
+    rc = lib.scamd_leiden_debug_split_f32(_p(indptr), _p(indices), _p(w), n, adj.nnz, _p(memb), C.byref(ns), _p(ws), ws.size, None)
+    _check(lib, rc, "leiden split")
+    return memb, int(ns.value)
+
+
 def leiden_stats(lib) -> dict:
     out = (C.c_int32 * 12)()
     lib.scamd_leiden_last_stats(out, 12)
     keys = ("iterations", "launches", "host_round_trips", "polish_full_sweeps", "polish_rounds", "polish_moves",
-            "polish_skipped_proven", "levels_first_iteration", "lm_sweeps", "lm_sweep_algorithmic_MB")
+            "polish_skipped_proven", "levels_first_iteration", "lm_sweeps", "lm_sweep_algorithmic_MB", "polish_splits", "ended_by_iteration_cap")
     return dict(zip(keys, (int(v) for v in out)))
 
 

@@ -48,8 +48,9 @@ def test_workspace_queries_are_host_only(lib):
     a = lib.scamd_knn_workspace_bytes(100_000, 50, 100_000, 15)
     b = lib.scamd_knn_workspace_bytes(1_000_000, 50, 1_000_000, 15)
     assert 0 < a < b
-    assert lib.scamd_knn_workspace_bytes(1000, 129, 1000, 15) == 0  # d > 128 unsupported
-    assert lib.scamd_knn_workspace_bytes(1000, 50, 1000, 121) == 0  # k > 120 unsupported
+    assert lib.scamd_knn_workspace_bytes(1000, 256, 1000, 256) > 0
+    assert lib.scamd_knn_workspace_bytes(1000, 257, 1000, 15) == 0  # d > 256 unsupported
+    assert lib.scamd_knn_workspace_bytes(1000, 50, 1000, 257) == 0  # k > 256 unsupported
     assert lib.scamd_fuzzy_workspace_bytes(1000, 15) > 0
     assert lib.scamd_leiden_workspace_bytes(1000, 20000) > 0
     assert lib.scamd_csr_transpose_workspace_bytes(1000, 2000, 100000) > 0

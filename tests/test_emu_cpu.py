@@ -242,6 +242,51 @@ def test_knn_approximate_mode(emu, monkeypatch):
     assert 0.5 < recall[1] < recall[3] <= recall[16] == 1.0, recall
 
 
+def test_leiden_component_split(emu):
+    """the component split the polish applies after its moves (scamd_leiden_debug_split_f32): on a sparse random graph
+    under a coarse random labelling -- thousands of disconnected pieces -- the result is scipy's components of the
+    intra-label graph, ids = smallest member; a connected labelling is left alone"""
+    from scipy import sparse
+    from scipy.sparse.csgraph import connected_components
+
+    H, lib = emu
+    rng = np.random.default_rng(0)
+    n = 3000
+    r, c = rng.integers(0, n, 2600), rng.integers(0, n, 2600)
+    a = sparse.coo_matrix((rng.random(2600).astype(np.float32) + 0.1, (r, c)), shape=(n, n)).tocsr()
+    a = a.maximum(a.T).tocsr()
+    a.setdiag(0)
+    a.eliminate_zeros()
+    lab = (rng.integers(0, 7, n) * 11).astype(np.int32)
+    got, n_split = H.leiden_split(lib, a, lab)
+    same = lab[np.repeat(np.arange(n), np.diff(a.indptr))] == lab[a.indices]
+    inner = sparse.csr_matrix((same.astype(np.int8), a.indices.copy(), a.indptr.copy()), shape=a.shape)
+    inner.eliminate_zeros()
+    n_comp, comp = connected_components(inner, directed=False)
+    assert n_split == n_comp - np.unique(lab).size > 1000
+    first = np.full(n_comp, n)
+    np.minimum.at(first, comp, np.arange(n))
+    assert np.array_equal(got, first[comp])
+    again, n_split2 = H.leiden_split(lib, a, got)
+    assert n_split2 == 0 and np.array_equal(again, got)
+
+
+@pytest.mark.parametrize(("n", "d", "k"), [(700, 150, 15), (600, 256, 40), (500, 40, 200), (520, 200, 256), (300, 129, 121)])
+def test_knn_wide_rows_and_long_lists(emu, n, d, k):
+    """d in (128, 256] (knn_select_kernel<128, 32, ...>) and k in (120, 256] (lists of 288 in LDS, one wave per block):
+    the shapes the reference takes without a limit (src/scanpy/neighbors/__init__.py:88-103); duplicates included"""
+    from oracle import compare as cmp
+
+    H, lib = emu
+    rng = np.random.default_rng(n + d + k)
+    x = (rng.standard_normal((n, d)) + 3.0).astype(np.float32)
+    x[: n // 10] = x[n // 10: 2 * (n // 10)]
+    idx, dist, n_scan = H.knn(lib, x, k)
+    ei, ed = oknn.knn_exact_f64(x, np.arange(n), k)
+    assert cmp.knn_rows_differing_beyond_ties(idx, dist, ei, ed)[0] == 0
+    assert n_scan <= n // 10  # the MFMA pass certifies (nearly) every query itself: the float64 scan is the exception
+
+
 def test_leiden_hub_rows(emu):
     """a vertex with 2500 neighbours (multi-pass hub tables) and vertices of 150 .. 1200 (overflow list, hub list tiers)"""
     from scipy import sparse

@@ -62,7 +62,9 @@ def test_knn_toy_golden(K, neighbors_toy):
 @pytest.mark.parametrize(
     ("n", "d", "k"),
     [(1000, 50, 15), (5000, 10, 30), (3000, 64, 15), (2000, 100, 15), (777, 3, 5), (4000, 50, 100), (300, 128, 15), (2500, 33, 24),
-     (2000, 20, 15), (1500, 30, 10), (60000, 50, 15), (130, 50, 15), (33, 8, 4)],
+     (2000, 20, 15), (1500, 30, 10), (60000, 50, 15), (130, 50, 15), (33, 8, 4),
+     # round 5: d in (128, 256], k in (120, 256] -- the reference takes any (src/scanpy/neighbors/__init__.py:88-103)
+     (3000, 150, 15), (2500, 256, 30), (3000, 50, 200), (2000, 200, 256), (1500, 129, 121), (5000, 20, 130)],
 )
 def test_knn_vs_sklearn(K, n, d, k):
     rng = np.random.default_rng(n + d + k)
