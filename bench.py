@@ -817,6 +817,16 @@ def main() -> None:
     elapsed = float(t.item())
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
     value = n * args.steps / elapsed
+    # N > 1: every rank's stage times side by side (the first scaling run diagnoses itself: which stage stops scaling, how
+    # much of the step is the rank-0-only Leiden), gathered with one small collective outside the timed region
+    stage_names = ("pca", "knn", "connectivities", "leiden", "broadcast")
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([stage_acc.get(k_, 0.0) / max(args.steps, 1) for k_ in stage_names], dtype=torch.float64,
+                            device="cpu" if one_device else dev)
+        allr = torch.empty((world, len(stage_names)), dtype=torch.float64, device=mine.device)
+        dist.all_gather_into_tensor(allr, mine)
+        per_rank = [{k_: float(v) for k_, v in zip(stage_names, row)} for row in allr.cpu().tolist()]
 
     if rank == 0:
         sel = sum(select_ms) / max(len(select_ms), 1)
@@ -886,6 +896,19 @@ def main() -> None:
                 "brute_force_equivalent_tflops": 2.0 * brute_pairs * args.n_comps / (sel * 1e-3) / 1e12 if sel > 0 else None,
             },
             "stage_ms_per_step": {kname: v / max(args.steps, 1) for kname, v in stage_acc.items()},
+            **({} if per_rank is None else {"multi_gpu": {
+                "per_rank_stage_ms": per_rank,
+                # bytes every rank contributes to / receives from each collective of one step
+                "collective_bytes": {
+                    "gram_all_reduce_int64": 8.0 * (((args.n_vars + 127) // 128 * 128) ** 2 + args.n_vars),
+                    "embedding_all_gather_f32": 4.0 * n * args.n_comps,
+                    "directed_edges_all_to_all": 12.0 * (hi - lo) * (args.n_neighbors - 1) * (world - 1) / world,
+                    "graph_rows_to_rank0": 8.0 * 2 * (hi - lo) * (args.n_neighbors - 1) + 4.0 * (hi - lo),
+                    "labels_broadcast_i32": 4.0 * n},
+                "rank0_only_ms": stage_acc.get("leiden", 0.0) / max(args.steps, 1),
+                "rank0_only_share_of_step": stage_acc.get("leiden", 0.0) / max(args.steps, 1) / ms_per_step if ms_per_step > 0 else None,
+                "note": "Leiden runs on rank 0 (global community totals, order-dependent moves: SURVEY 8(e)); the other ranks "
+                        "wait in the label broadcast -- Amdahl: speed-up <= 1 / (share + (1 - share) / N) of the 1-GPU step"}}),
             "leiden": leiden_block(res.info.get("leiden_stats", {}), stage_acc.get("leiden", 0.0) / max(args.steps, 1)),
             "result": {"n_communities": res.n_communities, "modularity": res.modularity, "labels_sha": _sha(res.labels),
                        "knn_second_tier_queries": int(lib.scamd_knn_last_second_tier_queries()),

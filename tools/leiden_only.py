@@ -33,7 +33,8 @@ def main():
         labels, q, nc = K.leiden(ip, ix, w, n)
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) * 1e3)
-    print(f"leiden n={n} {structure}: best {min(ts):.2f} ms, mean {sum(ts) / len(ts):.2f} ms over {reps}; nc {nc} Q {q!r}", flush=True)
+    print(f"leiden n={n} {structure}: best {min(ts):.2f} ms, mean {sum(ts) / len(ts):.2f} ms over {reps}; nc {nc} Q {q!r}; "
+          f"{K.leiden_last_stats()}", flush=True)
 
 
 if __name__ == "__main__":
