@@ -9,7 +9,9 @@ What the reference delegates to umap-learn's `simplicial_set_embedding` is resta
   * `init_pos='spectral'` computes the leading eigenvectors of the symmetric normalised adjacency by block power
     iteration (50 steps) on the device (SpMM kernel of the PCA stage) instead of ARPACK; a disconnected graph is not laid out
     component by component -- the block iteration separates the components by itself;
-  * `init_pos='paga'` is outside the path (needs `sc.tl.paga`)."""
+  * `init_pos='paga'` places every cell around its group's node of a PAGA layout the caller brings along in
+    `adata.uns['paga']` (`pos`, `groups`, `connectivities`: written by upstream `sc.tl.paga` + `sc.pl.paga`, which stay
+    outside this path) -- `init_pos_from_paga`, after src/scanpy/tools/_utils.py:81-114."""
 from __future__ import annotations
 
 import logging
@@ -167,6 +169,37 @@ def umap_embedding(connectivities, *, n_components=2, n_epochs=None, a, b, gamma
     return y.cpu().numpy()
 
 
+def init_pos_from_paga(adata, *, seed: int = 0) -> np.ndarray:
+    """Initial 2-D coordinates from a PAGA layout (src/scanpy/tools/_utils.py:81-114): a cell of group i starts at the
+    group's node `pos[i]`, pulled half-way towards the node of the group i is most strongly connected to and jittered
+    along that same direction -- `pos[i] - 0.5 d + u * d`, d = pos[i] - pos[nearest], u ~ U[0, 1)^2 from a generator of
+    its own per group (`rng.spawn`) -- or exactly at the node when the group has no connection."""
+    paga = adata.uns.get("paga", {}) if hasattr(adata.uns, "get") else {}
+    if "pos" not in paga:
+        raise ValueError("Plot PAGA first, so that `adata.uns['paga']['pos']` exists.")
+    groups = adata.obs[paga["groups"]]
+    cats = list(groups.cat.categories)
+    codes = np.asarray(groups.cat.codes)
+    node = np.asarray(paga["pos"], dtype=np.float64)
+    coarse = paga["connectivities"]
+    coarse = coarse.tocsr() if hasattr(coarse, "tocsr") else np.asarray(coarse)
+    if len(cats) != node.shape[0]:
+        raise ValueError(f"uns['paga']['pos'] holds {node.shape[0]} nodes for {len(cats)} groups")
+    out = np.ones((adata.n_obs, 2), dtype=np.float64)
+    streams = np.random.default_rng(seed).spawn(node.shape[0])
+    for i, gen in enumerate(streams):
+        members = np.flatnonzero(codes == i)
+        row = coarse[i]
+        row = np.asarray(row.todense()).ravel() if hasattr(row, "todense") else np.asarray(row).ravel()
+        linked = np.flatnonzero(row)
+        if linked.size == 0:
+            out[members] = node[i]
+            continue
+        towards = node[i] - node[linked[np.argmax(row[linked])]]
+        out[members] = node[i] - 0.5 * towards + gen.random((members.size, 2)) * towards
+    return out
+
+
 def umap(  # noqa: PLR0913
     adata,
     *,
@@ -211,7 +244,9 @@ def umap(  # noqa: PLR0913
     if isinstance(init_pos, str) and init_pos in adata.obsm:
         init_coords = adata.obsm[init_pos]
     elif isinstance(init_pos, str) and init_pos == "paga":
-        raise NotImplementedError("init_pos='paga' needs sc.tl.paga, which is outside the MI355X path")
+        if n_components != 2:
+            raise ValueError("init_pos='paga' gives 2-D coordinates: n_components must be 2")
+        init_coords = init_pos_from_paga(adata, seed=seed)
     elif isinstance(init_pos, str) and init_pos not in {"spectral", "random"}:
         raise ValueError(f"init_pos={init_pos!r}: expected 'spectral', 'random', 'paga', a key of adata.obsm or an array")
     else:

@@ -83,6 +83,21 @@ def test_umap_init_variants_and_components(pbmc68k):
     conn = adata.obsp["connectivities"].copy()
     sc.tl.umap(adata, maxiter=5)
     assert (adata.obsp["connectivities"] != conn).nnz == 0  # tests/test_embedding.py:83-95
+    # init_pos='paga' (src/scanpy/tools/_umap.py:175-179): a PAGA layout brought along in uns['paga']; zero epochs return
+    # the initial coordinates themselves (rescaled to [0, 10] like every initial embedding), cells of a group next to its node
+    import pandas as pd
+
+    grp = pd.Categorical((np.arange(700) % 3).astype(str))
+    adata.obs["grp"] = grp
+    adata.uns["paga"] = dict(pos=np.array([[0.0, 0.0], [10.0, 0.0], [0.0, 10.0]]), groups="grp",
+                             connectivities=np.array([[0, 1.0, 0.2], [1.0, 0, 0], [0.2, 0, 0]]))
+    sc.tl.umap(adata, init_pos="paga", key_added="u_paga", maxiter=1)
+    y = adata.obsm["u_paga"]
+    assert y.shape == (700, 2) and np.isfinite(y).all()
+    cen = np.array([y[np.asarray(grp == c)].mean(0) for c in grp.categories])
+    assert np.linalg.norm(cen[0] - cen[1]) > 1.0 and np.linalg.norm(cen[0] - cen[2]) > 1.0  # the groups start apart
+    with pytest.raises(ValueError, match="n_components must be 2"):
+        sc.tl.umap(adata, init_pos="paga", n_components=3)
 
 
 def test_umap_separates_planted_clusters():

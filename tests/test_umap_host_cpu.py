@@ -36,10 +36,44 @@ def test_errors_without_gpu(pbmc68k):
         sc.tl.umap(adata)
     adata.obsp["connectivities"] = pbmc68k["connectivities"]
     adata.uns["neighbors"] = dict(connectivities_key="connectivities", distances_key="distances", params=dict(method="umap"))
-    with pytest.raises(NotImplementedError, match="paga"):
+    with pytest.raises(ValueError, match="Plot PAGA first"):  # (the reference's message, tools/_utils.py:91-93)
         sc.tl.umap(adata, init_pos="paga")
     with pytest.raises(ValueError, match="Unknown method"):
         sc.tl.umap(adata, method="rapids")
+
+
+def test_init_pos_from_paga_follows_the_reference(pbmc68k):
+    """`init_pos='paga'` (src/scanpy/tools/_umap.py:175-179 -> tools/_utils.py:81-114): cells start around their group's
+    PAGA node, shifted half-way towards the most strongly connected group's node and jittered along that direction from
+    the group's own spawned generator; isolated groups sit exactly on their node.  Checked against a mask-by-mask
+    transcription of that rule, with a dense and a sparse coarse matrix."""
+    import pandas as pd
+    from scipy import sparse
+
+    n = pbmc68k["X"].shape[0]
+    rng = np.random.default_rng(3)
+    labels = pd.Categorical(rng.integers(0, 5, n).astype(str))
+    pos = rng.standard_normal((5, 2)) * 4.0
+    coarse = np.array([[0, .3, .9, 0, 0], [.3, 0, .1, 0, 0], [.9, .1, 0, .5, 0], [0, 0, .5, 0, 0], [0, 0, 0, 0, 0]])  # group 4: isolated
+    for conn in (coarse, sparse.csr_matrix(coarse)):
+        adata = sc.AnnData(pbmc68k["X"].copy())
+        adata.obs["grp"] = labels
+        adata.uns["paga"] = dict(pos=pos, groups="grp", connectivities=conn)
+        got = _umap.init_pos_from_paga(adata, seed=7)
+        want = np.ones((n, 2))
+        for i, sub in enumerate(np.random.default_rng(7).spawn(5)):
+            mask = np.asarray(labels == labels.categories[i])
+            nb = np.nonzero(coarse[i])[0]
+            if nb.size:
+                d = pos[i] - pos[nb[np.argmax(coarse[i][nb])]]
+                want[mask] = pos[i] - 0.5 * d + sub.random((int(mask.sum()), 2)) * d
+            else:
+                want[mask] = pos[i]
+        np.testing.assert_array_equal(got, want)
+        assert (got[np.asarray(labels == "4")] == pos[4]).all()
+    adata.uns["paga"].pop("pos")
+    with pytest.raises(ValueError, match="Plot PAGA first"):
+        _umap.init_pos_from_paga(adata)
 
 
 def test_oracle_schemes_agree_in_quality(pbmc68k):
