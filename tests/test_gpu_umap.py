@@ -121,6 +121,48 @@ def test_umap_separates_planted_clusters():
     assert purity > 0.97
 
 
+def test_layout_preserves_the_graph_as_well_as_the_sequential_oracle_at_30k():
+    """UMAP's parity is unpinned (no umap-learn here, no golden embedding in the reference: tests/test_embedding.py only
+    smoke-tests it) -- this is the quality floor instead.  30 000 cells on a curved 2-D sheet in 50 dimensions (one
+    connected graph): the GPU layout keeps as many of a cell's GRAPH neighbours among its 30 nearest points of the plane,
+    and follows the sheet's own geometry as closely (correlation of plane distances with latent distances), as the CPU
+    restatement of the reference's sequential sweep does (oracle/umap.py, scheme 'sequential': 0.97 / 0.96), within 0.05."""
+    from oracle import connectivities as oc
+    from oracle import knn as oknn
+    from oracle import umap as ou
+    from sklearn.neighbors import NearestNeighbors
+
+    n, k = 30_000, 15
+    rng = np.random.default_rng(9)
+    uv = rng.random((n, 2))
+    feat = np.stack([uv[:, 0], uv[:, 1], np.sin(3 * uv[:, 0]), np.cos(3 * uv[:, 1]), uv[:, 0] * uv[:, 1],
+                     np.sin(2 * (uv[:, 0] + uv[:, 1]))], axis=1)
+    x = (feat @ rng.standard_normal((6, 50)) + 0.01 * rng.standard_normal((n, 50))).astype(np.float32)
+    idx, dist, _ = oknn.knn_sklearn(x, k, n_jobs=-1)
+    c, _, _ = oc.fuzzy_simplicial_set(idx, dist, n, k)
+    g = sparse.csr_matrix(c).astype(np.float32)
+    adata = sc.AnnData(x)
+    adata.obsp["connectivities"] = g
+    adata.uns["neighbors"] = dict(connectivities_key="connectivities", distances_key="distances",
+                                  params=dict(n_neighbors=k, method="umap"))
+    sc.tl.umap(adata)
+    y_gpu = adata.obsm["X_umap"]
+    y_cpu = ou.simplicial_set_embedding(g, seed=0, scheme="sequential")
+    sample = rng.choice(n, 2000, replace=False)
+    d_lat = np.linalg.norm(uv[sample][:, None] - uv[sample][None], axis=2).ravel()
+
+    def scores(y):
+        nb = NearestNeighbors(n_neighbors=31).fit(y).kneighbors(y, return_distance=False)[:, 1:]
+        kept = np.mean([np.isin(g.indices[g.indptr[i]:g.indptr[i + 1]], nb[i]).mean() for i in range(0, n, 3)])
+        d_y = np.linalg.norm(y[sample][:, None] - y[sample][None], axis=2).ravel()
+        return float(kept), float(np.corrcoef(d_lat, d_y)[0, 1])
+
+    (kept_g, corr_g), (kept_c, corr_c) = scores(y_gpu), scores(y_cpu)
+    print(f"graph neighbours kept among the 30 nearest in the plane: gpu {kept_g:.3f}, sequential oracle {kept_c:.3f}; "
+          f"distance correlation with the latent sheet: gpu {corr_g:.3f}, oracle {corr_c:.3f}")
+    assert np.isfinite(y_gpu).all() and kept_c > 0.9 and kept_g >= kept_c - 0.05 and corr_g >= corr_c - 0.05
+
+
 @pytest.mark.parametrize("n_epochs", [5, 200, 500])
 def test_device_pruning_equals_host_pruning(pbmc68k, n_epochs):
     import torch
