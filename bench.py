@@ -824,9 +824,9 @@ def main() -> None:
     if world > 1:
         mine = torch.tensor([stage_acc.get(k_, 0.0) / max(args.steps, 1) for k_ in stage_names], dtype=torch.float64,
                             device="cpu" if one_device else dev)
-        allr = torch.empty((world, len(stage_names)), dtype=torch.float64, device=mine.device)
+        allr = torch.empty(world * len(stage_names), dtype=torch.float64, device=mine.device)  # (flat: gloo insists)
         dist.all_gather_into_tensor(allr, mine)
-        per_rank = [{k_: float(v) for k_, v in zip(stage_names, row)} for row in allr.cpu().tolist()]
+        per_rank = [{k_: float(v) for k_, v in zip(stage_names, row)} for row in allr.view(world, len(stage_names)).cpu().tolist()]
 
     if rank == 0:
         sel = sum(select_ms) / max(len(select_ms), 1)

@@ -50,3 +50,23 @@ def test_ranks_sharing_one_gpu_match_single_rank(tmp_path, world):
     for r in many:
         np.testing.assert_array_equal(r["labels"], one["labels"])
         assert int(r["nc"]) == int(one["nc"]) and float(r["q"]) == float(one["q"])
+
+
+def test_bench_line_of_two_ranks_on_one_gpu(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), both ranks on cuda:0
+    with gloo collectives (SCAMD_BENCH_ONE_DEVICE=1: RCCL refuses two ranks on one device): the N > 1 code path of the
+    bench -- sharded generation, barriers, max-over-ranks timing, the per-rank stage table -- must produce its JSON line."""
+    import json
+
+    env = dict(os.environ, SCAMD_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", str(HERE.parent / "bench.py"), "--gpus", "2", "--n-obs", "70000", "--n-vars", "500",
+           "--steps", "2", "--warmup", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(HERE.parent))
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0 and line["scaling"] == "strong"
+    mg = line["multi_gpu"]
+    assert len(mg["per_rank_stage_ms"]) == 2 and all(r["knn"] > 0 and r["pca"] > 0 for r in mg["per_rank_stage_ms"])
+    assert mg["per_rank_stage_ms"][0]["leiden"] > 0 and mg["per_rank_stage_ms"][1]["leiden"] == 0  # rank 0 only
+    assert 0 < mg["rank0_only_share_of_step"] < 1 and mg["collective_bytes"]["embedding_all_gather_f32"] == 4.0 * 70000 * 50
