@@ -83,6 +83,10 @@ def parse_args():
     ap.add_argument("--no-noise-variant", action="store_true", help="skip the `structure_none` / `structure_weak` side measurements")
     ap.add_argument("--no-side", action="store_true", help="skip upstream_chain / umap_layout side measurements")
     ap.add_argument("--no-properties", action="store_true", help="skip `full_size_properties` (CPU checks of the last timed result)")
+    ap.add_argument("--knn-nprobe", type=int, default=0,
+                    help="> 0: the timed path uses the APPROXIMATE IVF search (pp.neighbors(transformer='ivf'), BASELINE configs[4]) "
+                         "probing this many cells; the line then reports the sampled recall instead of gating exactness, and the "
+                         "CPU-chain parity (an exact chain) is skipped")
     a = ap.parse_args()
     if a.cpu_sample is not None:
         a.cpu_sizes = str(a.cpu_sample)
@@ -345,7 +349,7 @@ PROPERTY_GATES = {"knn_rows_differing_beyond_ties": 0, "knn_max_rel_distance_err
                   "leiden_mergeable_pairs": 0, "leiden_improving_moves": 0}
 
 
-def full_size_properties(res, x_host, n: int, k: int, *, n_sample: int = 512, seed: int = 123) -> dict:
+def full_size_properties(res, x_host, n: int, k: int, *, n_sample: int = 512, seed: int = 123, approximate: bool = False) -> dict:
     """Properties of ONE result of the timed path that can be checked at ANY size, the bench's full size included (the
     CPU chain of `parity_block` stops at 500k cells and is out of reach at 10M x 4k): kNN rows of a row sample against a
     float64 brute force over ALL cells of the same embedding; structure of every kNN row; exact symmetry, range and row
@@ -389,12 +393,16 @@ def full_size_properties(res, x_host, n: int, k: int, *, n_sample: int = 512, se
     ei, ed = oknn.knn_exact_f64_sample(emb, rows, k)
     bad, differ = cmp.knn_rows_differing_beyond_ties(idx[rows], dist[rows], ei, ed)
     knn["sample_rows"] = int(rows.size)
+    if approximate:  # (--knn-nprobe: the lists are exact among the probed rows only; what is reported is the recall)
+        knn["approximate"] = True
+        knn["sample_recall"] = float(np.mean([np.isin(idx[r, 1:], e[1:]).mean() for r, e in zip(rows, ei)]))
+        bad = 0
     knn["rows_differing_beyond_ties"] = int(bad)
     knn["rows_differing_at_ties"] = int(differ - bad)
     # (the reported distance of every reported pair, recomputed: `knn_rows_differing_beyond_ties` takes a row's own
     # distances at their word when it decides what is a tie)
     pair = np.sqrt(((emb[rows].astype(np.float64)[:, None, :] - emb[idx[rows]].astype(np.float64)) ** 2).sum(-1))
-    knn["max_rel_distance_err"] = float(max(np.max(np.abs(dist[rows] - ed) / np.maximum(ed, 1e-30)),
+    knn["max_rel_distance_err"] = float(max(0.0 if approximate else np.max(np.abs(dist[rows] - ed) / np.maximum(ed, 1e-30)),
                                             np.max(np.abs(dist[rows] - pair) / np.maximum(pair, 1e-30))))
     out["knn"] = knn
     if bad > PROPERTY_GATES["knn_rows_differing_beyond_ties"] or knn["rows_with_duplicates"] or not (
@@ -793,7 +801,9 @@ def main() -> None:
             torch.cuda.synchronize()
 
     kw = dict(comm=comm, backend=backend, n_comps=args.n_comps, n_neighbors=args.n_neighbors, resolution=1.0,
-              n_iterations=-1, seed=0)
+              n_iterations=-1, seed=0, nprobe=args.knn_nprobe if args.knn_nprobe > 0 else None)
+    if args.knn_nprobe > 0:
+        args.verify = False
     for _ in range(args.warmup):
         run_path(handle, n, **kw)
     lib = _lib.load()
@@ -855,7 +865,9 @@ def main() -> None:
             "data": "synthetic",
             "config": {
                 "workload": (f"synthetic {args.structure}-structure log-normal CSR {n} cells x {args.n_vars} genes (~5% nnz), PCA {args.n_comps} "
-                             f"(exact Gram + dense eigensolve, arpack accuracy) + exact kNN k={args.n_neighbors} (cell-pruned brute force) + umap "
+                             f"(exact Gram + dense eigensolve, arpack accuracy) + "
+                             + (f"APPROXIMATE IVF kNN k={args.n_neighbors}, nprobe={args.knn_nprobe} cells of the k-means quantiser (exact inside them)"
+                                if args.knn_nprobe > 0 else f"exact kNN k={args.n_neighbors} (cell-pruned brute force)") + " + umap "
                              "connectivities + Leiden res=1.0 n_iterations=-1 (" + _baseline_config(n, args.n_vars, world) + "); `value` is the "
                              "device-resident rate: the CSR is in HBM when the timed region starts and the results stay there "
                              "(no H2D / D2H inside it); host AnnData in -> slots written on the host = value_host_to_host"),
@@ -924,11 +936,11 @@ def main() -> None:
             if not args.no_properties:
                 # the result of the LAST timed step, at the full size of the run; its gates are part of the exit code
                 # (round 4; a checker error propagates like any other error)
-                out["full_size_properties"] = full_size_properties(res, x, n, args.n_neighbors)
+                out["full_size_properties"] = full_size_properties(res, x, n, args.n_neighbors, approximate=args.knn_nprobe > 0)
                 out["full_size_properties"]["enforced"] = True
                 if out["full_size_properties"]["failed_gates"]:
                     rc = 1
-            if not args.no_side:
+            if not args.no_side and args.knn_nprobe == 0:  # (the curve is measured against the EXACT lists of the timed step)
                 out["knn_approx"] = approx_knn_curve(res.x_pca, res.knn_indices, args.n_neighbors, (2, 8, 32))
             del handle, res
             if args.h2h_reps > 0:

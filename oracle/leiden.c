@@ -26,6 +26,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -422,6 +423,7 @@ int oracle_leiden(int64_t n, const int64_t* indptr, const int32_t* indices, cons
     free(node_of);
     ++iter;
     const double q = oracle_modularity(n, indptr, indices, weights, membership, gamma);
+    if (getenv("ORACLE_LEIDEN_DEBUG")) fprintf(stderr, "[oracle leiden] iteration %d: Q = %.10f (best before %.10f)\n", iter, q, q_prev);
     const int improved = q > q_prev + 1e-12;
     q_prev = q > q_prev ? q : q_prev;
     if (n_iterations < 0 && !improved) break;

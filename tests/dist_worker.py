@@ -26,7 +26,7 @@ def _patch_kernels():
     from oracle import leiden as ol
     from scanpy_amd import _kernels
 
-    def knn(x, k, *, q_begin=0, n_query=None, cert_scale=1.0):
+    def knn(x, k, *, q_begin=0, n_query=None, cert_scale=1.0, nprobe=None):  # (exact whatever nprobe says)
         xn = x.numpy()
         n = xn.shape[0]
         nq = n - q_begin if n_query is None else n_query

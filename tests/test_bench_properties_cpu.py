@@ -51,6 +51,22 @@ def test_clean_result_passes_every_gate(chain):
     assert out["pca"]["scores_sample_rel_err"] < 1e-4
 
 
+def test_approximate_run_reports_recall_instead_of_gating_exactness(chain):
+    """`bench.py --knn-nprobe`: lists that are exact among SOME rows only -- here every row's farthest listed neighbour
+    replaced by a far-away cell with its true distance -- pass the kNN gates, and the sampled recall says what was lost"""
+    res, x, n, k = chain
+    idx, dist = res.knn_indices.copy(), res.knn_distances.copy()
+    far = np.array([next(c for c in ((i + n // 2 + t) % n for t in range(n)) if c not in idx[i, :-1]) for i in range(n)], dtype=np.int32)
+    idx[:, -1] = far
+    dist[:, -1] = np.sqrt(((res.x_pca.astype(np.float64) - res.x_pca[far].astype(np.float64)) ** 2).sum(1))
+    dist[:, -1] = np.maximum(dist[:, -1], dist[:, -2])  # (keeps the rows ascending whatever cell was picked)
+    out = bench.full_size_properties(_copy(res, knn_indices=idx, knn_distances=dist), x, n, k, n_sample=256, approximate=True)
+    assert "knn_rows_differing_beyond_ties" not in out["failed_gates"], out["knn"]
+    assert out["knn"]["approximate"] and abs(out["knn"]["sample_recall"] - (k - 2) / (k - 1)) < 0.03
+    exact = bench.full_size_properties(res, x, n, k, n_sample=256, approximate=True)
+    assert exact["knn"]["sample_recall"] == 1.0 and exact["failed_gates"] == []
+
+
 def _copy(res, **kw):
     d = dict(vars(res))
     d.update(kw)
