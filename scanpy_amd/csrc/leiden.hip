@@ -2318,6 +2318,10 @@ struct LeidenCtx {
   int agg_wave_max = WH_MAX_DEG;
   int agg_mid_max = AGG_MID_MAX;
   int agg_pass_keys = AGG_BIG_PASS;
+  // workgroups of the two workgroup tiers of the coarse-row builder (each loops over its share of the listed rows): a
+  // launch of N such workgroups costs ~0.27 us x N before any work is done (SCAMD_LEIDEN_AGG_MID_GRID / _BIG_GRID)
+  int agg_mid_grid = 768;
+  int agg_big_grid = HUB_GRID;
 };
 
 static bool g_leiden_debug = false;  // SCAMD_LEIDEN_DEBUG=1, read at every entry (tools switch it inside one process)
@@ -2838,13 +2842,13 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
     fprintf(stderr, "[leiden] aggregate n=%d -> %d: %d rows through the workgroup tier, %d through the 8192-slot tier\n", g.n, inn,
             htier[0], htier[1]);
   if (htier[0] > 0) {
-    hipLaunchKernelGGL((ld_agg_block_kernel<AGG_MID_SLOTS, 512>), dim3((unsigned)std::min(768, htier[0])), dim3(512),
+    hipLaunchKernelGGL((ld_agg_block_kernel<AGG_MID_SLOTS, 512>), dim3((unsigned)std::min(cx.agg_mid_grid, htier[0])), dim3(512),
                        (size_t)AGG_MID_SLOTS * 12, cx.s, b.mid_list, b.counters + 4, inn, b.moff, b.eoff, b.members, g.indptr,
                        g.indices, g.wq, b.cid, b.agg_col, b.agg_w, b.rowcnt, b.counters + 7, AGG_MID_MAX);
     SCAMD_LAUNCH_CHECK();
   }
   if (htier[1] > 0) {
-    hipLaunchKernelGGL((ld_agg_block_kernel<BHUB_SLOTS, 1024>), dim3((unsigned)std::min(HUB_GRID, htier[1])), dim3(1024),
+    hipLaunchKernelGGL((ld_agg_block_kernel<BHUB_SLOTS, 1024>), dim3((unsigned)std::min(cx.agg_big_grid, htier[1])), dim3(1024),
                        HUB_LDS, cx.s, b.big_list, b.counters + 5, inn, b.moff, b.eoff, b.members, g.indptr, g.indices, g.wq,
                        b.cid, b.agg_col, b.agg_w, b.rowcnt, b.counters + 7, cx.agg_pass_keys);
     SCAMD_LAUNCH_CHECK();
@@ -3073,6 +3077,8 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
   if (const char* e = getenv("SCAMD_LEIDEN_SMALL_SEQ")) cx.small_seq_n = atoi(e);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_WAVE_MAX")) cx.agg_wave_max = std::min(atoi(e), (int)WH_MAX_DEG);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_MAX")) cx.agg_mid_max = std::min(atoi(e), (int)AGG_MID_MAX);
+  if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_GRID")) cx.agg_mid_grid = std::max(1, atoi(e));
+  if (const char* e = getenv("SCAMD_LEIDEN_AGG_BIG_GRID")) cx.agg_big_grid = std::max(1, atoi(e));
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_PASS_KEYS"))
     cx.agg_pass_keys = std::max(16, std::min(atoi(e), (int)AGG_BIG_PASS));
   Workspace ws(workspace, workspace_bytes);

@@ -85,3 +85,38 @@ def test_oracle_schemes_agree_in_quality(pbmc68k):
     ce_seq, ce_syn = ou.fuzzy_cross_entropy(g, y_seq, a, b), ou.fuzzy_cross_entropy(g, y_syn, a, b)
     ce_init = ou.fuzzy_cross_entropy(g, ou.initial_embedding(ou.prune_graph(g, 500), 2, "spectral", np.random.RandomState(0)), a, b)
     assert ce_seq < 0.7 * ce_init and ce_syn < 0.7 * ce_init and abs(ce_syn - ce_seq) < 0.06 * ce_seq
+
+
+def test_spectral_solver_matches_arpack_on_a_graph_without_clusters():
+    """`init_pos='spectral'` (umap-learn: ARPACK on the normalised Laplacian): on a connected graph WITHOUT clusters -- a
+    curved sheet, eigenvalues 1 - O(1e-4) -- the Chebyshev-filtered subspace iteration returns the plane ARPACK returns
+    (round 4's fifty block power steps returned a random one there, and the layout test against the sequential oracle
+    showed it).  The operator is applied with float32 operands, as the device SpMM does."""
+    import torch
+    from scipy import sparse
+    from scipy.sparse.linalg import eigsh
+
+    from oracle import connectivities as oc
+    from oracle import knn as oknn
+
+    n = 8000
+    rng = np.random.default_rng(9)
+    uv = rng.random((n, 2))
+    feat = np.stack([uv[:, 0], uv[:, 1], np.sin(3 * uv[:, 0]), np.cos(3 * uv[:, 1]), uv[:, 0] * uv[:, 1],
+                     np.sin(2 * (uv[:, 0] + uv[:, 1]))], axis=1)
+    x = (feat @ rng.standard_normal((6, 50)) + 0.01 * rng.standard_normal((n, 50))).astype(np.float32)
+    idx, dist, _ = oknn.knn_sklearn(x, 15, n_jobs=-1)
+    g = sparse.csr_matrix(oc.fuzzy_simplicial_set(idx, dist, n, 15)[0]).astype(np.float64)
+    deg = np.asarray(g.sum(axis=1)).ravel()
+    s = (sparse.diags(1.0 / np.sqrt(deg)) @ g @ sparse.diags(1.0 / np.sqrt(deg))).tocsr()
+    s32 = s.astype(np.float32)
+    info = {}
+    v = _umap._top_eigenvectors_below_trivial(
+        lambda y: torch.from_numpy((s32 @ y.numpy().astype(np.float32)).astype(np.float64)), torch.from_numpy(np.sqrt(deg)), 2, 0,
+        info=info).numpy()
+    lam, vec = eigsh(s, k=3, which="LA", tol=1e-9)
+    ref = vec[:, np.argsort(-lam)[1:3]]
+    cosines = np.linalg.svd(np.linalg.qr(v)[0].T @ np.linalg.qr(ref)[0], compute_uv=False)
+    assert info["converged"] and info["residual"] < 2e-6 and info["operator_applications"] < 1500, info
+    assert cosines.min() > 0.9999, (cosines, info)
+    np.testing.assert_allclose(info["ritz_values"], np.sort(lam)[::-1][1:3], atol=1e-6)
