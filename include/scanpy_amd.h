@@ -262,6 +262,15 @@ int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indices, const fl
                          double beta, uint64_t seed,
                          int32_t* membership, double* modularity_host, int32_t* n_communities_host,
                          void* workspace, size_t workspace_bytes, scamd_stream_t stream);
+/* The same optimiser started from a given partition instead of singletons -- `initial_membership` of
+ * leidenalg.find_partition / igraph community_leiden, which the reference passes through `**clustering_args`
+ * (src/scanpy/tools/_leiden.py:66, 174-196).  initial_membership [n] int32 on the device, ids in [0, n) (SCAMD_EINVAL
+ * otherwise); n_iterations = 0 returns it renumbered (by decreasing size) with its modularity. */
+int scamd_leiden_csr_init_f32(const int64_t* indptr, const int32_t* indices, const float* weights,
+                              int64_t n, int64_t nnz, double resolution, int n_iterations,
+                              double beta, uint64_t seed, const int32_t* initial_membership,
+                              int32_t* membership, double* modularity_host, int32_t* n_communities_host,
+                              void* workspace, size_t workspace_bytes, scamd_stream_t stream);
 /* Statistics of the last scamd_leiden_csr_f32 call on this thread, out[0 .. min(n, 12)):
  *   [0] outer iterations run, [1] kernel launches, [2] blocking host round trips,
  *   [3] full sweeps / [4] rounds / [5] vertices moved by the final polish (n_iterations < 0: strictly monotone

@@ -1396,7 +1396,8 @@ __global__ __launch_bounds__(256) void ld_agg_wave_kernel(
     int nn, const int64_t* __restrict__ moff, const int64_t* __restrict__ eoff, const int* __restrict__ members,
     const int64_t* __restrict__ indptr, const int* __restrict__ indices, const long long* __restrict__ wq,
     const int* __restrict__ cid, int* __restrict__ s_col, long long* __restrict__ s_w, int* __restrict__ rowcnt,
-    int* __restrict__ mid_list, int* __restrict__ big_list, int* __restrict__ counters, int wave_max, int mid_max) {
+    int* __restrict__ mid_list, int* __restrict__ big_list, int* __restrict__ counters, int wave_max, int mid_max,
+    int wave_work, int mid_work) {
   __shared__ int hkeys[4][WH_SLOTS];
   __shared__ unsigned long long hvals[4][WH_SLOTS];
   const int lane = threadIdx.x & 63;
@@ -1406,9 +1407,13 @@ __global__ __launch_bounds__(256) void ld_agg_wave_kernel(
   const int64_t u0 = eoff[m0];
   const int64_t dsum = eoff[m1] - u0;
   const int64_t need = agg_need(dsum, nn);
-  if (need > wave_max) {
+  // tiers by table size (distinct neighbours: `need`) AND by work (member entries: `dsum`).  Round 5: on the coarse levels of
+  // a graph without clear clusters a coarse vertex has few distinct neighbours (need <= nn, a few hundred) but tens of
+  // thousands of member entries -- one wave walked them all (this kernel was 26 % of the Leiden time on the weak 1M graph,
+  // single launches of up to 7.9 ms); rows beyond wave_work entries go to a workgroup, beyond mid_work to the 1024-thread one
+  if (need > wave_max || dsum > wave_work) {
     if (lane == 0) {
-      if (need <= mid_max) mid_list[atomicAdd(&counters[4], 1)] = c;
+      if (need <= mid_max && dsum <= mid_work) mid_list[atomicAdd(&counters[4], 1)] = c;
       else big_list[atomicAdd(&counters[5], 1)] = c;
     }
     return;
@@ -2322,6 +2327,10 @@ struct LeidenCtx {
   // launch of N such workgroups costs ~0.27 us x N before any work is done (SCAMD_LEIDEN_AGG_MID_GRID / _BIG_GRID)
   int agg_mid_grid = 768;
   int agg_big_grid = HUB_GRID;
+  // member entries beyond which a coarse row leaves the wave tier / the 512-thread tier whatever its table size
+  // (SCAMD_LEIDEN_AGG_WAVE_WORK / _MID_WORK)
+  int agg_wave_work = 2048;
+  int agg_mid_work = 65536;
 };
 
 static bool g_leiden_debug = false;  // SCAMD_LEIDEN_DEBUG=1, read at every entry (tools switch it inside one process)
@@ -2830,7 +2839,7 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   const int inn = (int)nn;
   hipLaunchKernelGGL(ld_agg_wave_kernel, GRIDW(inn), 0, cx.s, inn, b.moff, b.eoff, b.members, g.indptr, g.indices, g.wq,
                      b.cid, b.agg_col, b.agg_w, b.rowcnt, b.mid_list, b.big_list, b.counters, cx.agg_wave_max,
-                     cx.agg_mid_max);
+                     cx.agg_mid_max, cx.agg_wave_work, cx.agg_mid_work);
   SCAMD_LAUNCH_CHECK();
   // workgroup tiers: 512 threads on the 48 KB tables (3 per CU), 1024 threads on the 96 KB table (1 per CU).  Their list
   // lengths are read back first: an empty launch of these shapes costs 40 / 140 us (768 x 512 / 512 x 1024 threads with
@@ -3048,10 +3057,49 @@ extern "C" size_t scamd_leiden_workspace_bytes(int64_t n, int64_t nnz) {
   return ws.used();
 }
 
+// memb[v] = init[v]; *err |= 1 when an id lies outside [0, n)
+__global__ void ld_copy_membership_kernel(int n, const int* __restrict__ init, int* __restrict__ memb, int* __restrict__ err) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  const int c = init[v];
+  if (c < 0 || c >= n) {
+    atomicOr(err, 1);
+    memb[v] = v;
+  } else {
+    memb[v] = c;
+  }
+}
+
+static int leiden_run(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n, int64_t nnz,
+                      double resolution, int n_iterations, double beta, uint64_t seed, const int32_t* initial_membership,
+                      int32_t* membership, double* modularity_host, int32_t* n_communities_host, void* workspace,
+                      size_t workspace_bytes, scamd_stream_t stream);
+
 extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n,
                                     int64_t nnz, double resolution, int n_iterations, double beta, uint64_t seed,
                                     int32_t* membership, double* modularity_host, int32_t* n_communities_host,
                                     void* workspace, size_t workspace_bytes, scamd_stream_t stream) {
+  return leiden_run(indptr, indices, weights, n, nnz, resolution, n_iterations, beta, seed, nullptr, membership,
+                    modularity_host, n_communities_host, workspace, workspace_bytes, stream);
+}
+
+// ... starting from a given partition instead of singletons (`initial_membership` of leidenalg.find_partition /
+// igraph community_leiden, passed through `**clustering_args` at src/scanpy/tools/_leiden.py:66, 174-196): ids in [0, n),
+// device pointer; n_iterations = 0 returns it renumbered with its modularity.
+extern "C" int scamd_leiden_csr_init_f32(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n,
+                                         int64_t nnz, double resolution, int n_iterations, double beta, uint64_t seed,
+                                         const int32_t* initial_membership, int32_t* membership,
+                                         double* modularity_host, int32_t* n_communities_host, void* workspace,
+                                         size_t workspace_bytes, scamd_stream_t stream) {
+  SCAMD_REQUIRE(initial_membership, SCAMD_EINVAL, "leiden: null initial membership");
+  return leiden_run(indptr, indices, weights, n, nnz, resolution, n_iterations, beta, seed, initial_membership, membership,
+                    modularity_host, n_communities_host, workspace, workspace_bytes, stream);
+}
+
+static int leiden_run(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n, int64_t nnz,
+                      double resolution, int n_iterations, double beta, uint64_t seed, const int32_t* initial_membership,
+                      int32_t* membership, double* modularity_host, int32_t* n_communities_host, void* workspace,
+                      size_t workspace_bytes, scamd_stream_t stream) {
   SCAMD_REQUIRE(indptr && membership && (nnz == 0 || (indices && weights)), SCAMD_EINVAL, "leiden: null pointer");
   SCAMD_REQUIRE(n >= 1 && n < ((int64_t)1 << 31) && nnz >= 0, SCAMD_EINVAL, "leiden: bad shape n=%lld nnz=%lld",
                 (long long)n, (long long)nnz);
@@ -3077,6 +3125,8 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
   if (const char* e = getenv("SCAMD_LEIDEN_SMALL_SEQ")) cx.small_seq_n = atoi(e);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_WAVE_MAX")) cx.agg_wave_max = std::min(atoi(e), (int)WH_MAX_DEG);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_MAX")) cx.agg_mid_max = std::min(atoi(e), (int)AGG_MID_MAX);
+  if (const char* e = getenv("SCAMD_LEIDEN_AGG_WAVE_WORK")) cx.agg_wave_work = std::max(1, atoi(e));
+  if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_WORK")) cx.agg_mid_work = std::max(1, atoi(e));
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_GRID")) cx.agg_mid_grid = std::max(1, atoi(e));
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_BIG_GRID")) cx.agg_big_grid = std::max(1, atoi(e));
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_PASS_KEYS"))
@@ -3095,8 +3145,18 @@ extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indice
   int rc = setup_level0(cx, indptr, indices, weights, n, nnz, &g0);
   if (rc != SCAMD_OK) return rc;
   LeidenBuffers& b = cx.b;
-  hipLaunchKernelGGL(ld_iota_kernel, GRID1(n), 0, cx.s, b.memb, (int)n);
-  SCAMD_LAUNCH_CHECK();
+  if (initial_membership) {
+    SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
+    hipLaunchKernelGGL(ld_copy_membership_kernel, GRID1(n), 0, cx.s, (int)n, initial_membership, b.memb, b.counters + 7);
+    SCAMD_LAUNCH_CHECK();
+    int bad = 0;
+    SCAMD_HIP_CHECK(hipMemcpyAsync(&bad, b.counters + 7, sizeof(int), hipMemcpyDeviceToHost, cx.s));
+    LD_SYNC(cx.s);
+    SCAMD_REQUIRE(bad == 0, SCAMD_EINVAL, "leiden: initial membership ids must lie in [0, n)");
+  } else {
+    hipLaunchKernelGGL(ld_iota_kernel, GRID1(n), 0, cx.s, b.memb, (int)n);
+    SCAMD_LAUNCH_CHECK();
+  }
   double q_best = 0.0;
   if (cx.m2 > 0.0) {
     rc = compute_totals(cx, g0, b.memb);

@@ -66,8 +66,10 @@ def rename_groups(adata, restrict_key, *, key_added, restrict_categories, restri
     return all_groups
 
 
-def leiden_partition(adjacency, *, resolution=1.0, n_iterations=-1, seed=0, use_weights=True, beta=0.01):
-    """Symmetric adjacency (scipy sparse) -> (membership int32 [n], modularity)."""
+def leiden_partition(adjacency, *, resolution=1.0, n_iterations=-1, seed=0, use_weights=True, beta=0.01,
+                     initial_membership=None):
+    """Symmetric adjacency (scipy sparse) -> (membership int32 [n], modularity).  `initial_membership`: a partition to
+    start from (any non-negative integer labels, one per vertex), as leidenalg / igraph take it."""
     import torch
 
     from .. import _kernels
@@ -85,8 +87,15 @@ def leiden_partition(adjacency, *, resolution=1.0, n_iterations=-1, seed=0, use_
     indices = pinned_uploader.upload(np.ascontiguousarray(adj.indices, dtype=np.int32), dev)
     w = adj.data if use_weights else np.ones_like(adj.data)
     weights = pinned_uploader.upload(np.ascontiguousarray(w, dtype=np.float32), dev)
+    init = None
+    if initial_membership is not None:
+        labels = np.asarray(initial_membership)
+        if labels.shape != (n,) or not np.issubdtype(labels.dtype, np.integer) or (n and labels.min() < 0):
+            raise ValueError(f"initial_membership must hold one non-negative integer per vertex ({n})")
+        # (the kernel wants ids below n: any labelling is renamed to consecutive ids first)
+        init = torch.from_numpy(np.unique(labels, return_inverse=True)[1].astype(np.int32)).to(dev)
     memb, q, _ = _kernels.leiden(indptr, indices, weights, n, resolution=float(resolution),
-                                 n_iterations=int(n_iterations), beta=beta, seed=int(seed))
+                                 n_iterations=int(n_iterations), beta=beta, seed=int(seed), initial_membership=init)
     return memb.cpu().numpy(), q
 
 
@@ -124,8 +133,11 @@ def leiden(  # noqa: PLR0913
         raise TypeError(f"leiden() got unexpected clustering arguments {sorted(unknown)}")
     if clustering_args.get("objective_function", "modularity").lower() != "modularity":
         raise NotImplementedError("only objective_function='modularity' is built on the MI355X path")
-    if clustering_args.get("initial_membership") is not None or clustering_args.get("node_weights") is not None:
-        raise NotImplementedError("initial_membership / node_weights are not supported on the MI355X path")
+    if clustering_args.get("node_weights") is not None:
+        raise NotImplementedError("node_weights are not supported on the MI355X path")
+    initial_membership = clustering_args.get("initial_membership")
+    if initial_membership is not None and restrict_to is not None:
+        raise NotImplementedError("initial_membership together with restrict_to is not supported on the MI355X path")
     if resolution is None:
         raise NotImplementedError("resolution=None (partition types without a resolution) is not supported")
     adata = adata.copy() if copy else adata
@@ -136,7 +148,8 @@ def leiden(  # noqa: PLR0913
         adjacency, restrict_indices = restrict_adjacency(
             adata, restrict_key, restrict_categories=restrict_categories, adjacency=adjacency)
     groups, modularity = leiden_partition(adjacency, resolution=resolution, n_iterations=n_iterations, seed=seed,
-                                          use_weights=use_weights, beta=clustering_args.get("beta", 0.01))
+                                          use_weights=use_weights, beta=clustering_args.get("beta", 0.01),
+                                          initial_membership=initial_membership)
     if restrict_to is not None:
         if key_added == "leiden":
             key_added += "_R"

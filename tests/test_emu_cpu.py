@@ -389,6 +389,7 @@ def test_front_ends_and_widening_kernels_on_the_emulator(emu):
     import subprocess
 
     keep = ("pca_transform_golden or pca_no_zero_center_golden or pca_shapes_and_errors or neighbors_key_added or leiden_errors or "
+            "leiden_initial_membership or "
             "neighbors_precomputed_distances or neighbors_fixture_vs_oracle or gauss_and_jaccard or neighbors_cosine_metric or "
             "transformer_plugin_route or leiden_restrict_to or leiden_basic_and_params or normalize_total or rep_mutation or "
             "test_scale or test_filters or chain_goldens or random_against_oracle or col_stats_clip or hvg_ or global-atomics or "
@@ -400,4 +401,4 @@ def test_front_ends_and_widening_kernels_on_the_emulator(emu):
     tail = out.stdout[-1500:]
     assert out.returncode == 0, tail
     m = re.search(r"(\d+) passed", tail)
-    assert m and int(m.group(1)) >= 40, tail
+    assert m and int(m.group(1)) >= 41, tail

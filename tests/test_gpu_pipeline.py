@@ -256,6 +256,31 @@ def test_leiden_errors(sc, pbmc68k):
         sc.tl.leiden(sc.AnnData(pbmc68k["X"]), flavor="igraph")
 
 
+def test_leiden_initial_membership(sc, pbmc68k):
+    """`initial_membership` through `**clustering_args` (src/scanpy/tools/_leiden.py:66, 174-196 hand it to leidenalg /
+    igraph): zero iterations return the given partition (renumbered by size) with its modularity; a stable partition stays
+    what it is; a coarse start is refined to a partition of the quality of a run from singletons; bad input raises"""
+    from sklearn.metrics import adjusted_rand_score
+
+    adata = _graph_adata(sc, pbmc68k)
+    sc.tl.leiden(adata, flavor="igraph", n_iterations=-1)
+    base, q_base = adata.obs["leiden"].cat.codes.to_numpy(), adata.uns["leiden"]["modularity"]
+    given = pbmc68k["bulk_labels_codes"].astype(np.int64) * 7 + 3  # (any non-negative integer labels)
+    sc.tl.leiden(adata, flavor="igraph", n_iterations=0, key_added="given", initial_membership=given)
+    assert adjusted_rand_score(adata.obs["given"].cat.codes, given) == 1.0
+    assert abs(adata.uns["given"]["modularity"] - sc.metrics.modularity(adata.obsp["connectivities"], given, is_directed=False)) < 1e-9
+    sizes = adata.obs["given"].cat.codes.value_counts().sort_index().to_numpy()
+    assert (np.diff(sizes) <= 0).all()  # ids by decreasing community size, as every result
+    sc.tl.leiden(adata, flavor="igraph", n_iterations=-1, key_added="again", initial_membership=base)
+    assert adjusted_rand_score(adata.obs["again"].cat.codes, base) == 1.0 and adata.uns["again"]["modularity"] == q_base
+    sc.tl.leiden(adata, flavor="leidenalg", n_iterations=-1, key_added="coarse", initial_membership=np.arange(700) % 2)
+    assert adata.uns["coarse"]["modularity"] > q_base - 5e-3
+    with pytest.raises(ValueError, match="one non-negative integer per vertex"):
+        sc.tl.leiden(adata, flavor="igraph", initial_membership=np.arange(10))
+    with pytest.raises(ValueError, match="one non-negative integer per vertex"):
+        sc.tl.leiden(adata, flavor="igraph", initial_membership=-np.ones(700, dtype=np.int64))
+
+
 def test_leiden_restrict_to_and_keys(sc, pbmc68k):
     """tests/test_clustering.py:177-242."""
     adata = _graph_adata(sc, pbmc68k)
