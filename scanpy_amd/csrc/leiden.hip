@@ -1509,10 +1509,8 @@ __global__ __launch_bounds__(THREADS) void ld_agg_block_kernel(
           nb = indptr[vn];
           ne = indptr[vn + 1];
         }
-        for (int64_t e = rb + lane; e < re; e += 64) {
-          const long long we = wq[e];
-          const int key = cid[indices[e]];
-          if (n_pass > 1 && (hash32((unsigned int)key * 0x9E3779B1u + 0x7F4A7C15u) >> 8) % n_pass != pass) continue;
+        auto add_entry = [&](int key, long long we) {
+          if (n_pass > 1 && (hash32((unsigned int)key * 0x9E3779B1u + 0x7F4A7C15u) >> 8) % n_pass != pass) return;
           unsigned int slot = hash32((unsigned int)key) & (nslots - 1);
           int tries = 0;
           for (;;) {
@@ -1527,7 +1525,21 @@ __global__ __launch_bounds__(THREADS) void ld_agg_block_kernel(
               break;
             }
           }
+        };
+        // Long member rows (the coarse levels of a graph without clear clusters: thousands of entries per row, a million
+        // per coarse vertex) were walked 64 entries per dependent round trip (indices -> cid): four steps' loads are
+        // requested before the first is used (round 5)
+        int64_t e = rb + lane;
+        for (; e + 192 < re; e += 256) {
+          const int x0 = indices[e], x1 = indices[e + 64], x2 = indices[e + 128], x3 = indices[e + 192];
+          const long long w0 = wq[e], w1 = wq[e + 64], w2 = wq[e + 128], w3 = wq[e + 192];
+          const int k0 = cid[x0], k1 = cid[x1], k2 = cid[x2], k3 = cid[x3];
+          add_entry(k0, w0);
+          add_entry(k1, w1);
+          add_entry(k2, w2);
+          add_entry(k3, w3);
         }
+        for (; e < re; e += 64) add_entry(cid[indices[e]], wq[e]);
       }
       __syncthreads();
       for (int s0 = 0; s0 < nslots; s0 += THREADS) {
