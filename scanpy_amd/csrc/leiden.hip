@@ -274,6 +274,12 @@ __device__ __forceinline__ int bhub_passes(int deg) { return deg <= BHUB_MAX_DEG
 __device__ __forceinline__ int bhub_class(int c, int n_pass) {
   return (int)((hash32((unsigned int)c * 0x9E3779B1u + 0x7F4A7C15u) >> 7) % (unsigned int)n_pass);
 }
+// The pass count of a long row is set by its LENGTH (the only bound on its distinct neighbour groups known in advance), but
+// on the coarse levels where such rows live the groups are few: a row of 19 000 entries pointing at a few hundred
+// communities was swept seven times (round 5 profile of the structure-less graph: ld_move_hub_kernel 20 % of the Leiden time, a
+// launch lasting as long as its longest row).  So a multi-pass row first tries ONE pass into the whole table with bounded
+// probing; only if some key finds no slot within HUB_TRY_PROBES steps is the table cleared and the row swept class by class.
+constexpr int HUB_TRY_PROBES = 64;
 
 struct BlockHash {
   int* keys;
@@ -298,6 +304,19 @@ struct BlockHash {
       slot = (slot + 1) & (nslots - 1);
     }
     atomicAdd(&vals[slot], (unsigned long long)w);
+  }
+  // optimistic single pass over a long row (see hub_try_single_pass): gives up after max_probes occupied slots
+  __device__ __forceinline__ bool add_limited(int c, long long w, int max_probes) {
+    unsigned int slot = hash32((unsigned int)c) & (nslots - 1);
+    for (int probes = 0; probes < max_probes; ++probes) {
+      const int prev = atomicCAS(&keys[slot], WH_EMPTY, c);
+      if (prev == WH_EMPTY || prev == c) {
+        atomicAdd(&vals[slot], (unsigned long long)w);
+        return true;
+      }
+      slot = (slot + 1) & (nslots - 1);
+    }
+    return false;
   }
   // multi-pass rows: the number of distinct keys of a pass is bounded only in expectation -> bounded probing;
   // false = table full (the caller raises the error flag, the host turns it into SCAMD_EINTERNAL)
@@ -548,11 +567,12 @@ __global__ __launch_bounds__(HUB_THREADS) void ld_move_hub_kernel(
     const int64_t* __restrict__ indptr, const int* __restrict__ indices, const long long* __restrict__ wq,
     const long long* __restrict__ k, const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot,
     const int* __restrict__ csize, double g, int round, unsigned int seed, int* __restrict__ decision,
-    int* __restrict__ err) {
+    int* __restrict__ err, int try_probes) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long hub_smem[];
   BlockHash bh{reinterpret_cast<int*>(hub_smem + BHUB_SLOTS), hub_smem, BHUB_SLOTS};
   __shared__ Cand sh_c[HUB_THREADS / 64];
   __shared__ long long sh_w[HUB_THREADS / 64];
+  __shared__ int sh_fail;
   const int n_hub = counters[4];
   for (int i = blockIdx.x; i < n_hub; i += gridDim.x) {
     const int w = hub_list[i];
@@ -569,17 +589,35 @@ __global__ __launch_bounds__(HUB_THREADS) void ld_move_hub_kernel(
     best.c = -1;
     best.pr = 0;
     long long w_own = 0;
-    for (int pass = 0; pass < n_pass; ++pass) {
+    bool filled = false;  // the table already holds the whole row (a successful optimistic pass)
+    if (n_pass > 1 && try_probes > 0) {
+      if (threadIdx.x == 0) sh_fail = 0;
       bh.clear();
       __syncthreads();
       for (int e = threadIdx.x; e < deg; e += blockDim.x) {
+        if (__hip_atomic_load(&sh_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
         const int u = indices[beg + e];
         if (u == v) continue;
-        const int c = comm[u];
-        if (n_pass == 1) bh.add(c, wq[beg + e]);
-        else if (bhub_class(c, n_pass) == pass && !bh.add_bounded(c, wq[beg + e])) *err = 1;
+        if (!bh.add_limited(comm[u], wq[beg + e], try_probes)) __hip_atomic_store(&sh_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       __syncthreads();
+      filled = sh_fail == 0;
+      __syncthreads();  // (sh_fail is rewritten for the next row)
+    }
+    const int n_sweep = filled ? 1 : n_pass;
+    for (int pass = 0; pass < n_sweep; ++pass) {
+      if (!filled) {
+        bh.clear();
+        __syncthreads();
+        for (int e = threadIdx.x; e < deg; e += blockDim.x) {
+          const int u = indices[beg + e];
+          if (u == v) continue;
+          const int c = comm[u];
+          if (n_pass == 1) bh.add(c, wq[beg + e]);
+          else if (bhub_class(c, n_pass) == pass && !bh.add_bounded(c, wq[beg + e])) *err = 1;
+        }
+        __syncthreads();
+      }
       for (int sl = threadIdx.x; sl < bh.nslots; sl += blockDim.x) {
         const int c = bh.keys[sl];
         if (c != WH_EMPTY) {
@@ -1205,11 +1243,12 @@ __global__ __launch_bounds__(HUB_THREADS) void ld_refine_propose_hub_kernel(
     const int* __restrict__ refsize, const unsigned long long* __restrict__ Kref,
     const unsigned long long* __restrict__ Eref, double g, double inv_beta, int round, int n_cls, unsigned int salt,
     unsigned int seed, int* __restrict__ target, int* __restrict__ err, const VertRec* __restrict__ vr,
-    const TargRec* __restrict__ tr) {
+    const TargRec* __restrict__ tr, int try_probes) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long hub_smem[];
   BlockHash bh{reinterpret_cast<int*>(hub_smem + BHUB_SLOTS), hub_smem, BHUB_SLOTS};
   __shared__ Cand sh_c[HUB_THREADS / 64];
   __shared__ long long sh_w[HUB_THREADS / 64];
+  __shared__ int sh_fail;
   const int n_hub = counters[4];
   for (int i = blockIdx.x; i < n_hub; i += gridDim.x) {
     const int v = hub_list[i];
@@ -1225,18 +1264,37 @@ __global__ __launch_bounds__(HUB_THREADS) void ld_refine_propose_hub_kernel(
     best.c = -1;
     best.pr = 0;
     long long dummy = 0;
-    for (int pass = 0; pass < n_pass; ++pass) {
+    bool filled = false;  // (hub_try_single_pass: the comment at HUB_TRY_PROBES)
+    if (n_pass > 1 && try_probes > 0) {
+      if (threadIdx.x == 0) sh_fail = 0;
       bh.clear();
       __syncthreads();
       for (int e = threadIdx.x; e < deg; e += blockDim.x) {
+        if (__hip_atomic_load(&sh_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
         const int u = indices[beg + e];
         const VertRec r = vr[u];
         if (u == v || r.comm != a) continue;
-        const int c = r.ref;
-        if (n_pass == 1) bh.add(c, wq[beg + e]);
-        else if (bhub_class(c, n_pass) == pass && !bh.add_bounded(c, wq[beg + e])) *err = 1;
+        if (!bh.add_limited(r.ref, wq[beg + e], try_probes)) __hip_atomic_store(&sh_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       __syncthreads();
+      filled = sh_fail == 0;
+      __syncthreads();
+    }
+    const int n_sweep = filled ? 1 : n_pass;
+    for (int pass = 0; pass < n_sweep; ++pass) {
+      if (!filled) {
+        bh.clear();
+        __syncthreads();
+        for (int e = threadIdx.x; e < deg; e += blockDim.x) {
+          const int u = indices[beg + e];
+          const VertRec r = vr[u];
+          if (u == v || r.comm != a) continue;
+          const int c = r.ref;
+          if (n_pass == 1) bh.add(c, wq[beg + e]);
+          else if (bhub_class(c, n_pass) == pass && !bh.add_bounded(c, wq[beg + e])) *err = 1;
+        }
+        __syncthreads();
+      }
       for (int sl = threadIdx.x; sl < bh.nslots; sl += blockDim.x) {
         const int c = bh.keys[sl];
         if (c != WH_EMPTY && c != v) {
@@ -1469,11 +1527,11 @@ __global__ __launch_bounds__(THREADS) void ld_agg_block_kernel(
     const int64_t* __restrict__ eoff, const int* __restrict__ members, const int64_t* __restrict__ indptr,
     const int* __restrict__ indices, const long long* __restrict__ wq, const int* __restrict__ cid,
     int* __restrict__ s_col, long long* __restrict__ s_w, int* __restrict__ rowcnt, int* __restrict__ err,
-    int pass_keys) {
+    int pass_keys, int try_probes) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long agg_smem[];
   unsigned long long* vals = agg_smem;
   int* keys = reinterpret_cast<int*>(agg_smem + SLOTS);
-  __shared__ int sh_cnt;
+  __shared__ int sh_cnt, sh_fail;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int n_list = *list_len;
   for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
@@ -1488,8 +1546,14 @@ __global__ __launch_bounds__(THREADS) void ld_agg_block_kernel(
       while (nslots < 2 * per_pass && nslots < SLOTS) nslots <<= 1;
       if (n_pass > 1) nslots = SLOTS;
     }
-    if (threadIdx.x == 0) sh_cnt = 0;
-    for (unsigned int pass = 0; pass < n_pass; ++pass) {
+    if (threadIdx.x == 0) {
+      sh_cnt = 0;
+      sh_fail = 0;
+    }
+    // pass -1 (rows that would need several passes): ONE optimistic pass over all keys with bounded probing -- the bound
+    // `need` is the members' entry count or the coarse vertex count, the distinct neighbours are usually far fewer (the
+    // comment at HUB_TRY_PROBES); if a key finds no slot the class-by-class passes 0 .. n_pass - 1 follow as before
+    for (int pass = ((n_pass > 1 && try_probes > 0) ? -1 : 0); pass < (int)n_pass; ++pass) {
       for (int i = threadIdx.x; i < nslots; i += THREADS) {
         keys[i] = WH_EMPTY;
         vals[i] = 0ull;
@@ -1503,6 +1567,7 @@ __global__ __launch_bounds__(THREADS) void ld_agg_block_kernel(
         ne = indptr[v + 1];
       }
       for (int64_t i = m0 + wv; i < m1; i += THREADS / 64) {
+        if (pass < 0 && __hip_atomic_load(&sh_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;  // (trial lost)
         const int64_t rb = nb, re = ne;
         if (i + THREADS / 64 < m1) {
           const int vn = members[i + THREADS / 64];
@@ -1510,8 +1575,9 @@ __global__ __launch_bounds__(THREADS) void ld_agg_block_kernel(
           ne = indptr[vn + 1];
         }
         auto add_entry = [&](int key, long long we) {
-          if (n_pass > 1 && (hash32((unsigned int)key * 0x9E3779B1u + 0x7F4A7C15u) >> 8) % n_pass != pass) return;
+          if (pass >= 0 && n_pass > 1 && (hash32((unsigned int)key * 0x9E3779B1u + 0x7F4A7C15u) >> 8) % n_pass != (unsigned int)pass) return;
           unsigned int slot = hash32((unsigned int)key) & (nslots - 1);
+          const int max_tries = pass < 0 ? try_probes : nslots;
           int tries = 0;
           for (;;) {
             const int prev = atomicCAS(&keys[slot], WH_EMPTY, key);
@@ -1520,8 +1586,11 @@ __global__ __launch_bounds__(THREADS) void ld_agg_block_kernel(
               break;
             }
             slot = (slot + 1) & (nslots - 1);
-            if (++tries > nslots) {  // table full: cannot happen for uniformly hashed classes; reported, not hidden
-              *err = 1;
+            if (++tries > max_tries) {
+              // trial pass: fall back to the class passes; class pass: table full -- cannot happen for uniformly
+              // hashed classes; reported, not hidden
+              if (pass < 0) __hip_atomic_store(&sh_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              else *err = 1;
               break;
             }
           }
@@ -1542,6 +1611,7 @@ __global__ __launch_bounds__(THREADS) void ld_agg_block_kernel(
         for (; e < re; e += 64) add_entry(cid[indices[e]], wq[e]);
       }
       __syncthreads();
+      if (pass < 0 && sh_fail) continue;  // (read by every thread after the barrier: uniform)
       for (int s0 = 0; s0 < nslots; s0 += THREADS) {
         const int sl = s0 + threadIdx.x;
         const int key = sl < nslots ? keys[sl] : WH_EMPTY;  // the table in use may be shorter than the workgroup
@@ -1557,6 +1627,7 @@ __global__ __launch_bounds__(THREADS) void ld_agg_block_kernel(
         }
       }
       __syncthreads();
+      if (pass < 0) break;  // the one pass held every key
     }
     if (threadIdx.x == 0) rowcnt[c] = sh_cnt;
     __syncthreads();
@@ -2343,6 +2414,7 @@ struct LeidenCtx {
   // (SCAMD_LEIDEN_AGG_WAVE_WORK / _MID_WORK)
   int agg_wave_work = 2048;
   int agg_mid_work = 65536;
+  int hub_try_probes = HUB_TRY_PROBES;  // 0: no optimistic single pass over multi-pass rows (SCAMD_LEIDEN_HUB_TRY_PROBES; tests)
 };
 
 static bool g_leiden_debug = false;  // SCAMD_LEIDEN_DEBUG=1, read at every entry (tools switch it inside one process)
@@ -2530,7 +2602,7 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
       if (n_hub > 0) {
         hipLaunchKernelGGL(ld_move_hub_kernel, dim3((unsigned)std::min(HUB_GRID, n_hub)), dim3(HUB_THREADS), HUB_LDS, cx.s, b.hub_list,
                            ctr, list, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg, dir_round, cx.seed,
-                           tg, b.counters + 7);
+                           tg, b.counters + 7, cx.hub_try_probes);
         SCAMD_LAUNCH_CHECK();
       }
       hipLaunchKernelGGL(ld_apply_kernel, GRID1(cnt), 0, cx.s, cnt, list, tg, g.k, b.comm, b.Ktot, b.csize, b.flag,
@@ -2700,7 +2772,7 @@ static int polish_level0(LeidenCtx& cx, const LevelGraph& g, int* stats) {
     if (n_hub > 0) {
       hipLaunchKernelGGL(ld_move_hub_kernel, dim3((unsigned)std::min(HUB_GRID, n_hub)), dim3(HUB_THREADS), HUB_LDS, cx.s, b.hub_list,
                          ctr, list, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.csize, gg, -1, cx.seed, b.target,
-                         b.counters + 7);
+                         b.counters + 7, cx.hub_try_probes);
       SCAMD_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(ld_polish_lock_kernel, GRID1(cnt), 0, cx.s, cnt, list, (const int*)b.target, (const int*)b.comm, lock, round);
@@ -2784,7 +2856,7 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
     if (n_hub > 0) {
       hipLaunchKernelGGL(ld_refine_propose_hub_kernel, dim3((unsigned)std::min(HUB_GRID, n_hub)), dim3(HUB_THREADS), HUB_LDS, cx.s,
                          b.hub_list, ctr, g.indptr, g.indices, g.wq, g.k, b.comm, b.Ktot, b.ref, b.refsize, b.Kref, b.Eref,
-                         gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.counters + 7, b.vrec, b.trec);
+                         gg, cx.inv_beta, c, n_cls, salt, rseed, b.target, b.counters + 7, b.vrec, b.trec, cx.hub_try_probes);
       SCAMD_LAUNCH_CHECK();
       LD_DBG_SYNC(cx, "rf propose hub n=%d class=%d", g.n, c);
     }
@@ -2865,13 +2937,13 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   if (htier[0] > 0) {
     hipLaunchKernelGGL((ld_agg_block_kernel<AGG_MID_SLOTS, 512>), dim3((unsigned)std::min(cx.agg_mid_grid, htier[0])), dim3(512),
                        (size_t)AGG_MID_SLOTS * 12, cx.s, b.mid_list, b.counters + 4, inn, b.moff, b.eoff, b.members, g.indptr,
-                       g.indices, g.wq, b.cid, b.agg_col, b.agg_w, b.rowcnt, b.counters + 7, AGG_MID_MAX);
+                       g.indices, g.wq, b.cid, b.agg_col, b.agg_w, b.rowcnt, b.counters + 7, AGG_MID_MAX, cx.hub_try_probes);
     SCAMD_LAUNCH_CHECK();
   }
   if (htier[1] > 0) {
     hipLaunchKernelGGL((ld_agg_block_kernel<BHUB_SLOTS, 1024>), dim3((unsigned)std::min(cx.agg_big_grid, htier[1])), dim3(1024),
                        HUB_LDS, cx.s, b.big_list, b.counters + 5, inn, b.moff, b.eoff, b.members, g.indptr, g.indices, g.wq,
-                       b.cid, b.agg_col, b.agg_w, b.rowcnt, b.counters + 7, cx.agg_pass_keys);
+                       b.cid, b.agg_col, b.agg_w, b.rowcnt, b.counters + 7, cx.agg_pass_keys, cx.hub_try_probes);
     SCAMD_LAUNCH_CHECK();
   }
   CoarseBuf& cb = b.cb[dst];
@@ -3137,6 +3209,7 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
   if (const char* e = getenv("SCAMD_LEIDEN_SMALL_SEQ")) cx.small_seq_n = atoi(e);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_WAVE_MAX")) cx.agg_wave_max = std::min(atoi(e), (int)WH_MAX_DEG);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_MAX")) cx.agg_mid_max = std::min(atoi(e), (int)AGG_MID_MAX);
+  if (const char* e = getenv("SCAMD_LEIDEN_HUB_TRY_PROBES")) cx.hub_try_probes = std::max(0, atoi(e));
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_WAVE_WORK")) cx.agg_wave_work = std::max(1, atoi(e));
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_WORK")) cx.agg_mid_work = std::max(1, atoi(e));
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_GRID")) cx.agg_mid_grid = std::max(1, atoi(e));

@@ -127,8 +127,15 @@ def test_leiden_disconnected_and_isolated(K):
         {"SCAMD_LEIDEN_AGG_WAVE_MAX": "0"},  # every coarse row through the workgroup tier
         {"SCAMD_LEIDEN_AGG_WAVE_MAX": "0", "SCAMD_LEIDEN_AGG_MID_MAX": "0"},  # ... through the 8192-slot tier
         {"SCAMD_LEIDEN_AGG_WAVE_MAX": "0", "SCAMD_LEIDEN_AGG_MID_MAX": "0", "SCAMD_LEIDEN_AGG_PASS_KEYS": "16"},
+        # (round 5: a multi-pass row first tries one optimistic pass with bounded probing; 0 = straight to the class passes,
+        #  1 = a trial that fails on the first collision and falls back)
+        {"SCAMD_LEIDEN_AGG_WAVE_MAX": "0", "SCAMD_LEIDEN_AGG_MID_MAX": "0", "SCAMD_LEIDEN_AGG_PASS_KEYS": "16",
+         "SCAMD_LEIDEN_HUB_TRY_PROBES": "0"},
+        {"SCAMD_LEIDEN_AGG_WAVE_MAX": "0", "SCAMD_LEIDEN_AGG_MID_MAX": "0", "SCAMD_LEIDEN_AGG_PASS_KEYS": "16",
+         "SCAMD_LEIDEN_HUB_TRY_PROBES": "1"},
+        {"SCAMD_LEIDEN_AGG_WAVE_WORK": "64", "SCAMD_LEIDEN_AGG_MID_WORK": "512"},  # tiers by work: rows leave the wave tier early
     ],
-    ids=["mid", "big", "big-multipass"],
+    ids=["mid", "big", "big-multipass", "big-classpasses", "big-failed-trial", "work-tiers"],
 )
 def test_leiden_coarse_row_tiers_agree(K, monkeypatch, env):
     """the wave / workgroup / multi-pass builders of the coarse graph produce the same graph, so the partition
@@ -141,6 +148,32 @@ def test_leiden_coarse_row_tiers_agree(K, monkeypatch, env):
     m1, q1, nc1 = K.leiden(ip, ix, w, n, seed=5)
     assert nc0 == nc1 and q0 == q1
     assert np.array_equal(m0.cpu().numpy(), m1.cpu().numpy())
+
+
+def test_leiden_long_hub_rows_single_pass_equals_class_passes(K, monkeypatch):
+    """vertices with 6500 / 7000 neighbours (beyond the 6000-entry single-pass bound of the hub kernels): the optimistic
+    single pass (default), a trial that fails at once (2 probes) and the class passes alone (0) must give the same
+    partition -- the decision of a row does not depend on how its table was filled"""
+    rng = np.random.default_rng(2)
+    n, deg = 8000, 6
+    m = sparse.coo_matrix((rng.random(n * deg).astype(np.float32) * 0.9 + 0.1,
+                           (np.repeat(np.arange(n), deg), rng.integers(0, n, n * deg))), shape=(n, n)).tocsr()
+    for h, dh in ((0, 7000), (1, 6500)):
+        t = rng.choice(n, dh, replace=False)
+        m = m + sparse.coo_matrix((rng.random(dh).astype(np.float32) * 0.5 + 0.1, (np.full(dh, h), t)), shape=(n, n)).tocsr()
+    m.setdiag(0)
+    m.eliminate_zeros()
+    m = m.maximum(m.T).tocsr().astype(np.float32)
+    assert np.diff(m.indptr).max() >= 7000
+    ip, ix, w, n = _graph_dev(m)
+    out = {}
+    for probes in ("64", "0", "2"):
+        monkeypatch.setenv("SCAMD_LEIDEN_HUB_TRY_PROBES", probes)
+        memb, q, nc = K.leiden(ip, ix, w, n, seed=0)
+        out[probes] = (memb.cpu().numpy(), q, nc)
+    assert abs(out["0"][1] - ol.modularity(m, out["0"][0])) < 1e-8
+    for probes in ("64", "2"):
+        assert out[probes][1] == out["0"][1] and np.array_equal(out[probes][0], out["0"][0])
 
 
 def test_leiden_small_levels_in_one_workgroup_vs_separate_kernels(K, monkeypatch, pbmc68k):
