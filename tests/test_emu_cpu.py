@@ -287,6 +287,27 @@ def test_knn_wide_rows_and_long_lists(emu, n, d, k):
     assert n_scan <= n // 10  # the MFMA pass certifies (nearly) every query itself: the float64 scan is the exception
 
 
+def test_leiden_coarse_row_builders_agree(emu, monkeypatch):
+    """the coarse graph does not depend on which builder made a row: wave tier, workgroup tiers by table size or by work, member
+    rows per wave or walked by the whole workgroup, one optimistic pass or the class passes after a failed trial"""
+    H, lib = emu
+    n = 3000
+    x = np.random.default_rng(0).standard_normal((n, 10)).astype(np.float32)
+    idx, dist = oknn.knn_exact_f64(x, np.arange(n), 15)
+    conn, _, _ = oconn.fuzzy_simplicial_set(idx, dist, n, 15)
+    monkeypatch.setenv("SCAMD_LEIDEN_SMALL", "0")
+    base = H.leiden(lib, conn, seed=0)
+    for env in ({"SCAMD_LEIDEN_AGG_WAVE_WORK": "64", "SCAMD_LEIDEN_AGG_MID_WORK": "400"},
+                {"SCAMD_LEIDEN_AGG_WAVE_MAX": "0", "SCAMD_LEIDEN_AGG_WIDE_ROW": "1"},
+                {"SCAMD_LEIDEN_AGG_WAVE_MAX": "0", "SCAMD_LEIDEN_AGG_MID_MAX": "0", "SCAMD_LEIDEN_AGG_WIDE_ROW": "1",
+                 "SCAMD_LEIDEN_AGG_PASS_KEYS": "16", "SCAMD_LEIDEN_HUB_TRY_PROBES": "1"}):
+        with monkeypatch.context() as mp:
+            for k_, v_ in env.items():
+                mp.setenv(k_, v_)
+            got = H.leiden(lib, conn, seed=0)
+        assert got[1] == base[1] and np.array_equal(got[0], base[0]), env
+
+
 def test_leiden_hub_rows(emu):
     """a vertex with 2500 neighbours (multi-pass hub tables) and vertices of 150 .. 1200 (overflow list, hub list tiers)"""
     from scipy import sparse
