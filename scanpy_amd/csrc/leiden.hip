@@ -468,13 +468,7 @@ __device__ __forceinline__ void ld_move_body(int bid, int nblk, const MoveArgs& 
         keys[i] = WH_EMPTY;
         vals[i] = 0ull;
       }
-      // (the weight towards the vertex's OWN community is summed in registers: on a settled level most neighbours share
-      // it, and G lanes adding to one LDS slot serialise -- round 5; integer sums, the order does not matter)
       auto insert = [&](int c, long long wt) {
-        if (c == a) {
-          w_own += wt;
-          return;
-        }
         unsigned int slot = hash32((unsigned int)c) & (nslots - 1);
         for (;;) {
           const int prev = atomicCAS(&keys[slot], WH_EMPTY, c);
@@ -512,7 +506,9 @@ __device__ __forceinline__ void ld_move_body(int bid, int nblk, const MoveArgs& 
         if (c != WH_EMPTY) {
           const long long sum =
               (long long)__hip_atomic_load(&vals[sub + t * G], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          {  // (the own community never enters the table)
+          if (c == a) {
+            w_own = sum;
+          } else {
             Cand x;
             x.val = (double)sum - g * kv * (double)(long long)kt[t];
             x.c = c;
@@ -529,7 +525,7 @@ __device__ __forceinline__ void ld_move_body(int bid, int nblk, const MoveArgs& 
       y.c = __shfl_xor(best.c, o);
       y.pr = (unsigned int)__shfl_xor((int)best.pr, o);
       if (cand_better(y, best)) best = y;
-      w_own += __shfl_xor(w_own, o);  // the lanes' shares of the own-community weight
+      w_own = max(w_own, __shfl_xor(w_own, o));
     }
     const double stay = (double)w_own - g * kv * Ka_wo;
     int target = a;
@@ -1483,16 +1479,6 @@ __global__ __launch_bounds__(256) void ld_agg_wave_kernel(
   WaveHash wh{hkeys[threadIdx.x >> 6], hvals[threadIdx.x >> 6], WH_SLOTS};
   wh.size_for((int)need);
   wh.clear(lane);
-  long long own_w = 0;
-  bool own_any = false;
-  auto add = [&](int key, long long w) {
-    if (key == c) {
-      own_w += w;
-      own_any = true;
-    } else {
-      wh.add(key, w);
-    }
-  };
   // The members' row extents are fetched 64 at a time (one coalesced gather), then two rows are in flight at once:
   // walking the members one by one is a chain members -> indptr -> indices -> cid per 24-entry row with nothing else
   // in flight.
@@ -1512,17 +1498,11 @@ __global__ __launch_bounds__(256) void ld_agg_wave_kernel(
       const int x0 = h0 ? indices[b0 + lane] : 0, x1 = h1 ? indices[b1 + lane] : 0;
       const long long w0 = h0 ? wq[b0 + lane] : 0ll, w1 = h1 ? wq[b1 + lane] : 0ll;
       const int c0 = cid[x0], c1 = cid[x1];
-      if (h0) add(c0, w0);
-      if (h1) add(c1, w1);
-      for (int64_t e = b0 + 64 + lane; e < e0; e += 64) add(cid[indices[e]], wq[e]);
-      for (int64_t e = b1 + 64 + lane; e < e1; e += 64) add(cid[indices[e]], wq[e]);
+      if (h0) wh.add(c0, w0);
+      if (h1) wh.add(c1, w1);
+      for (int64_t e = b0 + 64 + lane; e < e0; e += 64) wh.add(cid[indices[e]], wq[e]);
+      for (int64_t e = b1 + 64 + lane; e < e1; e += 64) wh.add(cid[indices[e]], wq[e]);
     }
-  }
-  {  // the weight towards the coarse vertex itself: summed in registers, one insertion per wave (see ld_agg_block_kernel)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) own_w += __shfl_xor(own_w, o);
-    const bool any = __ballot(own_any) != 0ull;
-    if (lane == 0 && any) wh.add(c, own_w);
   }
   int base = 0;
   for (int s0 = 0; s0 < wh.nslots; s0 += 64) {
@@ -1578,8 +1558,6 @@ __global__ __launch_bounds__(THREADS) void ld_agg_block_kernel(
         keys[i] = WH_EMPTY;
         vals[i] = 0ull;
       }
-      long long own_w = 0;    // this thread's share of the weight towards the coarse vertex itself (this pass)
-      bool own_any = false;
       __syncthreads();
       // Member rows are dealt to the waves one row per wave -- or, when the rows are long on average (coarse levels: a few
       // members with tens of thousands of entries each), walked one after the other by the WHOLE workgroup: a wave per row
@@ -1604,11 +1582,6 @@ __global__ __launch_bounds__(THREADS) void ld_agg_block_kernel(
         }
         auto add_entry = [&](int key, long long we) {
           if (pass >= 0 && n_pass > 1 && (hash32((unsigned int)key * 0x9E3779B1u + 0x7F4A7C15u) >> 8) % n_pass != (unsigned int)pass) return;
-          if (key == c) {  // the coarse vertex's own id: most entries of a coarse row are internal edges -> a register, not a slot
-            own_w += we;
-            own_any = true;
-            return;
-          }
           unsigned int slot = hash32((unsigned int)key) & (nslots - 1);
           const int max_tries = pass < 0 ? try_probes : nslots;
           int tries = 0;
@@ -1642,30 +1615,6 @@ __global__ __launch_bounds__(THREADS) void ld_agg_block_kernel(
           add_entry(k3, w3);
         }
         for (; e < re; e += e_step) add_entry(cid[indices[e]], wq[e]);
-      }
-      // the own-id weight of the wave: one table insertion per wave instead of one LDS atomic pair per entry on ONE slot
-      // (every lane of a wave hitting the same address serialises; integer sums: the order does not matter)
-      {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) own_w += __shfl_xor(own_w, o);
-        const bool any = __ballot(own_any) != 0ull;
-        if (lane == 0 && any) {
-          unsigned int slot = hash32((unsigned int)c) & (nslots - 1);
-          const int max_tries = pass < 0 ? try_probes : nslots;
-          for (int tries = 0;; ++tries) {
-            const int prev = atomicCAS(&keys[slot], WH_EMPTY, c);
-            if (prev == WH_EMPTY || prev == c) {
-              atomicAdd(&vals[slot], (unsigned long long)own_w);
-              break;
-            }
-            slot = (slot + 1) & (nslots - 1);
-            if (tries >= max_tries) {
-              if (pass < 0) __hip_atomic_store(&sh_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              else *err = 1;
-              break;
-            }
-          }
-        }
       }
       __syncthreads();
       if (pass < 0 && sh_fail) continue;  // (read by every thread after the barrier: uniform)
