@@ -1527,7 +1527,7 @@ __global__ __launch_bounds__(THREADS) void ld_agg_block_kernel(
     const int64_t* __restrict__ eoff, const int* __restrict__ members, const int64_t* __restrict__ indptr,
     const int* __restrict__ indices, const long long* __restrict__ wq, const int* __restrict__ cid,
     int* __restrict__ s_col, long long* __restrict__ s_w, int* __restrict__ rowcnt, int* __restrict__ err,
-    int pass_keys, int try_probes, int wide_row) {
+    int pass_keys, int try_probes) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long agg_smem[];
   unsigned long long* vals = agg_smem;
   int* keys = reinterpret_cast<int*>(agg_smem + SLOTS);
@@ -1559,24 +1559,18 @@ __global__ __launch_bounds__(THREADS) void ld_agg_block_kernel(
         vals[i] = 0ull;
       }
       __syncthreads();
-      // Member rows are dealt to the waves one row per wave -- or, when the rows are long on average (coarse levels: a few
-      // members with tens of thousands of entries each), walked one after the other by the WHOLE workgroup: a wave per row
-      // left the waves without a row idle and the launch waiting for the longest one (round 5)
-      const bool wide = (eoff[m1] - u0) >= (int64_t)wide_row * (m1 - m0);
-      const int64_t i_step = wide ? 1 : THREADS / 64, i_first = wide ? m0 : m0 + wv;
-      const int e_first = wide ? (int)threadIdx.x : lane, e_step = wide ? THREADS : 64;
       // the extent of a wave's next member row is requested while the current row is walked
       int64_t nb = 0, ne = 0;
-      if (i_first < m1) {
-        const int v = members[i_first];
+      if (m0 + wv < m1) {
+        const int v = members[m0 + wv];
         nb = indptr[v];
         ne = indptr[v + 1];
       }
-      for (int64_t i = i_first; i < m1; i += i_step) {
+      for (int64_t i = m0 + wv; i < m1; i += THREADS / 64) {
         if (pass < 0 && __hip_atomic_load(&sh_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;  // (trial lost)
         const int64_t rb = nb, re = ne;
-        if (i + i_step < m1) {
-          const int vn = members[i + i_step];
+        if (i + THREADS / 64 < m1) {
+          const int vn = members[i + THREADS / 64];
           nb = indptr[vn];
           ne = indptr[vn + 1];
         }
@@ -1604,17 +1598,17 @@ __global__ __launch_bounds__(THREADS) void ld_agg_block_kernel(
         // Long member rows (the coarse levels of a graph without clear clusters: thousands of entries per row, a million
         // per coarse vertex) were walked 64 entries per dependent round trip (indices -> cid): four steps' loads are
         // requested before the first is used (round 5)
-        int64_t e = rb + e_first;
-        for (; e + 3 * e_step < re; e += 4 * e_step) {
-          const int x0 = indices[e], x1 = indices[e + e_step], x2 = indices[e + 2 * e_step], x3 = indices[e + 3 * e_step];
-          const long long w0 = wq[e], w1 = wq[e + e_step], w2 = wq[e + 2 * e_step], w3 = wq[e + 3 * e_step];
+        int64_t e = rb + lane;
+        for (; e + 192 < re; e += 256) {
+          const int x0 = indices[e], x1 = indices[e + 64], x2 = indices[e + 128], x3 = indices[e + 192];
+          const long long w0 = wq[e], w1 = wq[e + 64], w2 = wq[e + 128], w3 = wq[e + 192];
           const int k0 = cid[x0], k1 = cid[x1], k2 = cid[x2], k3 = cid[x3];
           add_entry(k0, w0);
           add_entry(k1, w1);
           add_entry(k2, w2);
           add_entry(k3, w3);
         }
-        for (; e < re; e += e_step) add_entry(cid[indices[e]], wq[e]);
+        for (; e < re; e += 64) add_entry(cid[indices[e]], wq[e]);
       }
       __syncthreads();
       if (pass < 0 && sh_fail) continue;  // (read by every thread after the barrier: uniform)
@@ -2420,7 +2414,6 @@ struct LeidenCtx {
   // (SCAMD_LEIDEN_AGG_WAVE_WORK / _MID_WORK)
   int agg_wave_work = 2048;
   int agg_mid_work = 65536;
-  int agg_wide_row = 2048;  // mean member-row length from which a workgroup walks the rows together (SCAMD_LEIDEN_AGG_WIDE_ROW)
   int hub_try_probes = HUB_TRY_PROBES;  // 0: no optimistic single pass over multi-pass rows (SCAMD_LEIDEN_HUB_TRY_PROBES; tests)
 };
 
@@ -2944,13 +2937,13 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   if (htier[0] > 0) {
     hipLaunchKernelGGL((ld_agg_block_kernel<AGG_MID_SLOTS, 512>), dim3((unsigned)std::min(cx.agg_mid_grid, htier[0])), dim3(512),
                        (size_t)AGG_MID_SLOTS * 12, cx.s, b.mid_list, b.counters + 4, inn, b.moff, b.eoff, b.members, g.indptr,
-                       g.indices, g.wq, b.cid, b.agg_col, b.agg_w, b.rowcnt, b.counters + 7, AGG_MID_MAX, cx.hub_try_probes, cx.agg_wide_row);
+                       g.indices, g.wq, b.cid, b.agg_col, b.agg_w, b.rowcnt, b.counters + 7, AGG_MID_MAX, cx.hub_try_probes);
     SCAMD_LAUNCH_CHECK();
   }
   if (htier[1] > 0) {
     hipLaunchKernelGGL((ld_agg_block_kernel<BHUB_SLOTS, 1024>), dim3((unsigned)std::min(cx.agg_big_grid, htier[1])), dim3(1024),
                        HUB_LDS, cx.s, b.big_list, b.counters + 5, inn, b.moff, b.eoff, b.members, g.indptr, g.indices, g.wq,
-                       b.cid, b.agg_col, b.agg_w, b.rowcnt, b.counters + 7, cx.agg_pass_keys, cx.hub_try_probes, cx.agg_wide_row);
+                       b.cid, b.agg_col, b.agg_w, b.rowcnt, b.counters + 7, cx.agg_pass_keys, cx.hub_try_probes);
     SCAMD_LAUNCH_CHECK();
   }
   CoarseBuf& cb = b.cb[dst];
@@ -3217,7 +3210,6 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_WAVE_MAX")) cx.agg_wave_max = std::min(atoi(e), (int)WH_MAX_DEG);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_MAX")) cx.agg_mid_max = std::min(atoi(e), (int)AGG_MID_MAX);
   if (const char* e = getenv("SCAMD_LEIDEN_HUB_TRY_PROBES")) cx.hub_try_probes = std::max(0, atoi(e));
-  if (const char* e = getenv("SCAMD_LEIDEN_AGG_WIDE_ROW")) cx.agg_wide_row = std::max(1, atoi(e));
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_WAVE_WORK")) cx.agg_wave_work = std::max(1, atoi(e));
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_WORK")) cx.agg_mid_work = std::max(1, atoi(e));
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_GRID")) cx.agg_mid_grid = std::max(1, atoi(e));

@@ -288,8 +288,8 @@ def test_knn_wide_rows_and_long_lists(emu, n, d, k):
 
 
 def test_leiden_coarse_row_builders_agree(emu, monkeypatch):
-    """the coarse graph does not depend on which builder made a row: wave tier, workgroup tiers by table size or by work, member
-    rows per wave or walked by the whole workgroup, one optimistic pass or the class passes after a failed trial"""
+    """the coarse graph does not depend on which builder made a row: wave tier, workgroup tiers by table size or by work,
+    one optimistic pass or the class passes after a failed trial"""
     H, lib = emu
     n = 3000
     x = np.random.default_rng(0).standard_normal((n, 10)).astype(np.float32)
@@ -298,9 +298,9 @@ def test_leiden_coarse_row_builders_agree(emu, monkeypatch):
     monkeypatch.setenv("SCAMD_LEIDEN_SMALL", "0")
     base = H.leiden(lib, conn, seed=0)
     for env in ({"SCAMD_LEIDEN_AGG_WAVE_WORK": "64", "SCAMD_LEIDEN_AGG_MID_WORK": "400"},
-                {"SCAMD_LEIDEN_AGG_WAVE_MAX": "0", "SCAMD_LEIDEN_AGG_WIDE_ROW": "1"},
-                {"SCAMD_LEIDEN_AGG_WAVE_MAX": "0", "SCAMD_LEIDEN_AGG_MID_MAX": "0", "SCAMD_LEIDEN_AGG_WIDE_ROW": "1",
-                 "SCAMD_LEIDEN_AGG_PASS_KEYS": "16", "SCAMD_LEIDEN_HUB_TRY_PROBES": "1"}):
+                {"SCAMD_LEIDEN_AGG_WAVE_MAX": "0"},
+                {"SCAMD_LEIDEN_AGG_WAVE_MAX": "0", "SCAMD_LEIDEN_AGG_MID_MAX": "0", "SCAMD_LEIDEN_AGG_PASS_KEYS": "16",
+                 "SCAMD_LEIDEN_HUB_TRY_PROBES": "1"}):
         with monkeypatch.context() as mp:
             for k_, v_ in env.items():
                 mp.setenv(k_, v_)

@@ -134,12 +134,8 @@ def test_leiden_disconnected_and_isolated(K):
         {"SCAMD_LEIDEN_AGG_WAVE_MAX": "0", "SCAMD_LEIDEN_AGG_MID_MAX": "0", "SCAMD_LEIDEN_AGG_PASS_KEYS": "16",
          "SCAMD_LEIDEN_HUB_TRY_PROBES": "1"},
         {"SCAMD_LEIDEN_AGG_WAVE_WORK": "64", "SCAMD_LEIDEN_AGG_MID_WORK": "512"},  # tiers by work: rows leave the wave tier early
-        # every member row walked by the whole workgroup (the layout of long coarse rows), both workgroup tiers
-        {"SCAMD_LEIDEN_AGG_WAVE_MAX": "0", "SCAMD_LEIDEN_AGG_WIDE_ROW": "1"},
-        {"SCAMD_LEIDEN_AGG_WAVE_MAX": "0", "SCAMD_LEIDEN_AGG_MID_MAX": "0", "SCAMD_LEIDEN_AGG_WIDE_ROW": "1",
-         "SCAMD_LEIDEN_AGG_PASS_KEYS": "16", "SCAMD_LEIDEN_HUB_TRY_PROBES": "1"},
     ],
-    ids=["mid", "big", "big-multipass", "big-classpasses", "big-failed-trial", "work-tiers", "mid-wide", "big-wide-failed-trial"],
+    ids=["mid", "big", "big-multipass", "big-classpasses", "big-failed-trial", "work-tiers"],
 )
 def test_leiden_coarse_row_tiers_agree(K, monkeypatch, env):
     """the wave / workgroup / multi-pass builders of the coarse graph produce the same graph, so the partition

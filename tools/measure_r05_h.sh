@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 cd "$R"
 python -c "import __graft_entry__ as g; g.build()" > "$OUT/build.log" 2>&1; echo "build rc=$?"
 for ST in planted weak none; do
-  for K in "" "SCAMD_LEIDEN_AGG_WIDE_ROW=100000000"; do
+  for K in "" "SCAMD_LEIDEN_HUB_TRY_PROBES=0"; do
     echo "[$ST $K] $(env $K timeout -k 5 300 python tools/leiden_only.py 1000000 $ST 3 2>&1 | grep 'leiden n=' | tail -1 | cut -c1-110)" | tee -a "$OUT/leiden_ab.log"
   done
 done
