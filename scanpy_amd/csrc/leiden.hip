@@ -1447,6 +1447,8 @@ __global__ void ld_agg_scatter_kernel(int n, const int* __restrict__ cid, const 
 
 // distinct neighbours of a coarse node are bounded by both its degree sum and the coarse node count
 __device__ __forceinline__ int64_t agg_need(int64_t dsum, int nn) { return dsum < nn ? dsum : (int64_t)nn; }
+// a split row's parts are merged through ONE 8192-slot table: every key of the level must fit it (load <= 0.69)
+constexpr int AGG_SPLIT_NN_MAX = 5600;
 
 // one wave per coarse node; nodes needing more than the wave table go to the mid / big lists
 // (counters[4] / counters[5])
@@ -1455,7 +1457,7 @@ __global__ __launch_bounds__(256) void ld_agg_wave_kernel(
     const int64_t* __restrict__ indptr, const int* __restrict__ indices, const long long* __restrict__ wq,
     const int* __restrict__ cid, int* __restrict__ s_col, long long* __restrict__ s_w, int* __restrict__ rowcnt,
     int* __restrict__ mid_list, int* __restrict__ big_list, int* __restrict__ counters, int wave_max, int mid_max,
-    int wave_work, int mid_work) {
+    int wave_work, int mid_work, int* __restrict__ split_list, int64_t split_work) {
   __shared__ int hkeys[4][WH_SLOTS];
   __shared__ unsigned long long hvals[4][WH_SLOTS];
   const int lane = threadIdx.x & 63;
@@ -1471,7 +1473,10 @@ __global__ __launch_bounds__(256) void ld_agg_wave_kernel(
   // single launches of up to 7.9 ms); rows beyond wave_work entries go to a workgroup, beyond mid_work to the 1024-thread one
   if (need > wave_max || dsum > wave_work) {
     if (lane == 0) {
-      if (need <= mid_max && dsum <= mid_work) mid_list[atomicAdd(&counters[4], 1)] = c;
+      // (the very largest rows of a coarse level -- ~1e6 member entries behind a few hundred distinct neighbours -- are cut
+      // into parts for several workgroups and merged: ld_agg_parts_kernel; only where one table holds every key of the level)
+      if (dsum > split_work && nn <= AGG_SPLIT_NN_MAX) split_list[atomicAdd(&counters[6], 1)] = c;
+      else if (need <= mid_max && dsum <= mid_work) mid_list[atomicAdd(&counters[4], 1)] = c;
       else big_list[atomicAdd(&counters[5], 1)] = c;
     }
     return;
@@ -1539,7 +1544,8 @@ __global__ __launch_bounds__(THREADS) void ld_agg_block_kernel(
     const int64_t m0 = moff[c], m1 = moff[c + 1];
     const int64_t u0 = eoff[m0];
     const int64_t need = agg_need(eoff[m1] - u0, nn);
-    const unsigned int n_pass = (unsigned int)((need + pass_keys - 1) / pass_keys);
+    // (a part of a split row may be empty -- a member row longer than the part size spans several cuts: need = 0)
+    const unsigned int n_pass = (unsigned int)std::max<int64_t>(1, (need + pass_keys - 1) / pass_keys);
     int nslots = 256;
     {
       const int64_t per_pass = (need + n_pass - 1) / n_pass;
@@ -1629,6 +1635,106 @@ __global__ __launch_bounds__(THREADS) void ld_agg_block_kernel(
       __syncthreads();
       if (pass < 0) break;  // the one pass held every key
     }
+    if (threadIdx.x == 0) rowcnt[c] = sh_cnt;
+    __syncthreads();
+  }
+}
+
+// Split rows (round 5).  A launch of the workgroup builders lasts as long as its longest row, and on the coarse levels of a
+// graph without clear clusters a few coarse vertices hold ~1e6 member entries each (ld_agg_block_kernel<8192, 1024>: launches
+// of 1-3.5 ms, 10-13 % of the Leiden time on the weak / structure-less 1M graphs).  Such a row is cut into PARTS of ~chunk
+// member entries (whole member rows: the cut points are found by bisection in the members' entry offsets); every part is
+// built like a row of its own by ld_agg_block_kernel -- the parts are given pseudo-row ids whose member ranges live in
+// `pmoff` (one extra slot per row closes its last part), their lists land at their own members' scratch offsets -- and one
+// workgroup per split row merges the parts' lists through a table and writes the row.  Integer sums: the row is the same.
+__global__ void ld_agg_parts_kernel(const int* __restrict__ split_list, int* __restrict__ counters, const int64_t* __restrict__ moff,
+                                    const int64_t* __restrict__ eoff, int64_t chunk, int64_t* __restrict__ pmoff,
+                                    int* __restrict__ part_list, int* __restrict__ split_first, int* __restrict__ split_np) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= counters[6]) return;
+  const int c = split_list[s];
+  const int64_t m0 = moff[c], m1 = moff[c + 1];
+  const int64_t u0 = eoff[m0], dsum = eoff[m1] - u0;
+  const int np = (int)((dsum + chunk - 1) / chunk);
+  const int base = atomicAdd(&counters[2], np + 1);
+  split_first[s] = base;
+  split_np[s] = np;
+  for (int j = 0; j < np; ++j) {
+    int64_t lo = m0;
+    if (j > 0) {  // first member whose entries start at or after the j-th cut
+      const int64_t target = u0 + (int64_t)j * chunk;
+      int64_t hi = m1;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (eoff[mid] < target) lo = mid + 1;
+        else hi = mid;
+      }
+    }
+    pmoff[base + j] = lo;
+    part_list[atomicAdd(&counters[3], 1)] = base + j;
+  }
+  pmoff[base + np] = m1;
+}
+
+__global__ __launch_bounds__(1024) void ld_agg_merge_kernel(const int* __restrict__ split_list, const int* __restrict__ counters,
+                                                            const int64_t* __restrict__ moff, const int64_t* __restrict__ eoff,
+                                                            const int64_t* __restrict__ pmoff, const int* __restrict__ part_cnt,
+                                                            const int* __restrict__ split_first, const int* __restrict__ split_np,
+                                                            int* __restrict__ s_col, long long* __restrict__ s_w,
+                                                            int* __restrict__ rowcnt, int* __restrict__ err) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long agg_smem[];
+  unsigned long long* vals = agg_smem;
+  int* keys = reinterpret_cast<int*>(agg_smem + BHUB_SLOTS);
+  __shared__ int sh_cnt;
+  const int lane = threadIdx.x & 63;
+  const int n_split = counters[6];
+  for (int s = blockIdx.x; s < n_split; s += gridDim.x) {
+    const int c = split_list[s];
+    const int64_t u0 = eoff[moff[c]];
+    const int first = split_first[s], np = split_np[s];
+    for (int i = threadIdx.x; i < BHUB_SLOTS; i += 1024) {
+      keys[i] = WH_EMPTY;
+      vals[i] = 0ull;
+    }
+    if (threadIdx.x == 0) sh_cnt = 0;
+    __syncthreads();
+    for (int j = 0; j < np; ++j) {
+      const int64_t up = eoff[pmoff[first + j]];
+      const int cnt = part_cnt[first + j];
+      for (int t = threadIdx.x; t < cnt; t += 1024) {
+        const int key = s_col[up + t];
+        const long long w = s_w[up + t];
+        unsigned int slot = hash32((unsigned int)key) & (BHUB_SLOTS - 1);
+        for (int tries = 0;; ++tries) {
+          const int prev = atomicCAS(&keys[slot], WH_EMPTY, key);
+          if (prev == WH_EMPTY || prev == key) {
+            atomicAdd(&vals[slot], (unsigned long long)w);
+            break;
+          }
+          slot = (slot + 1) & (BHUB_SLOTS - 1);
+          if (tries > BHUB_SLOTS) {  // (cannot happen: at most AGG_SPLIT_NN_MAX distinct keys; reported, not hidden)
+            *err = 1;
+            break;
+          }
+        }
+      }
+    }
+    __syncthreads();  // every partial list has been read: the row is written over them
+    for (int s0 = 0; s0 < BHUB_SLOTS; s0 += 1024) {
+      const int sl = s0 + threadIdx.x;
+      const int key = keys[sl];
+      const bool has = key != WH_EMPTY;
+      const unsigned long long m = __ballot(has);
+      int wbase = 0;
+      if (lane == 0 && m) wbase = atomicAdd(&sh_cnt, __popcll(m));
+      wbase = __shfl(wbase, 0);
+      if (has) {
+        const int64_t p = u0 + wbase + __popcll(m & ((1ull << lane) - 1ull));
+        s_col[p] = key;
+        s_w[p] = (long long)vals[sl];
+      }
+    }
+    __syncthreads();
     if (threadIdx.x == 0) rowcnt[c] = sh_cnt;
     __syncthreads();
   }
@@ -2304,6 +2410,7 @@ struct LeidenBuffers {
   int* node_of; int* memb; int* memb_best;
   int* agg_col; long long* agg_w;  // scratch CSR of the coarse-graph build (rows at upper-bound offsets)
   int* mcount; int64_t* moff; int64_t* eoff; int* members; int* mdeg; int* mid_list; int* big_list;
+  int64_t* pmoff; int* part_list; int* part_cnt;  // split rows of the coarse-graph build (ld_agg_parts_kernel)
   int* rowcnt; int* cursor;
   int* counters; int* rcounters; unsigned long long* total; double* dscratch;
   unsigned long long* ckeys; int* cids; int* newlabel; int* minmember;
@@ -2317,6 +2424,16 @@ static int classes_env(const char* name) {
 }
 static int carve_classes() {
   return std::max((int)DEF_CLASSES, std::max(classes_env("SCAMD_LEIDEN_LM_CLASSES"), classes_env("SCAMD_LEIDEN_RF_CLASSES")));
+}
+// member entries per part of a split coarse row / entries from which a row is split (SCAMD_LEIDEN_AGG_SPLIT_CHUNK / _WORK:
+// tests push small graphs through the split path; resolved here so that the workspace query and the run agree)
+static int64_t agg_split_chunk() {
+  const char* e = getenv("SCAMD_LEIDEN_AGG_SPLIT_CHUNK");
+  return e ? std::max<int64_t>(64, atoll(e)) : 131072;
+}
+static int64_t agg_split_work() {
+  const char* e = getenv("SCAMD_LEIDEN_AGG_SPLIT_WORK");
+  return std::max<int64_t>(agg_split_chunk(), e ? atoll(e) : 262144);
 }
 static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b) {
   const size_t N = (size_t)n, E = (size_t)std::max<int64_t>(nnz, 1);
@@ -2366,6 +2483,12 @@ static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b
   b->mdeg = ws.take<int>(N);
   b->mid_list = ws.take<int>(N);
   b->big_list = ws.take<int>(N);
+  {
+    const size_t slots = 3 * E / (size_t)agg_split_chunk() + 16;  // parts + one closing slot per split row
+    b->pmoff = ws.take<int64_t>(slots);
+    b->part_list = ws.take<int>(slots);
+    b->part_cnt = ws.take<int>(slots);
+  }
   b->rowcnt = ws.take<int>(N);
   b->cursor = ws.take<int>(N);
   b->counters = ws.take<int>(16);  // [0..7] phase counters, [8..11] row-length statistics of the level being built
@@ -2923,13 +3046,13 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   const int inn = (int)nn;
   hipLaunchKernelGGL(ld_agg_wave_kernel, GRIDW(inn), 0, cx.s, inn, b.moff, b.eoff, b.members, g.indptr, g.indices, g.wq,
                      b.cid, b.agg_col, b.agg_w, b.rowcnt, b.mid_list, b.big_list, b.counters, cx.agg_wave_max,
-                     cx.agg_mid_max, cx.agg_wave_work, cx.agg_mid_work);
+                     cx.agg_mid_max, cx.agg_wave_work, cx.agg_mid_work, b.hub_list, agg_split_work());
   SCAMD_LAUNCH_CHECK();
   // workgroup tiers: 512 threads on the 48 KB tables (3 per CU), 1024 threads on the 96 KB table (1 per CU).  Their list
   // lengths are read back first: an empty launch of these shapes costs 40 / 140 us (768 x 512 / 512 x 1024 threads with
   // 48 / 96 KB of LDS each), a host round trip 15 -- and most levels of a clustered graph have no such rows at all.
-  int htier[2] = {0, 0};
-  SCAMD_HIP_CHECK(hipMemcpyAsync(htier, b.counters + 4, sizeof(int) * 2, hipMemcpyDeviceToHost, cx.s));
+  int htier[3] = {0, 0, 0};  // rows of the 512-thread tier, of the 1024-thread tier, split rows
+  SCAMD_HIP_CHECK(hipMemcpyAsync(htier, b.counters + 4, sizeof(int) * 3, hipMemcpyDeviceToHost, cx.s));
   LD_SYNC(cx.s);
   if (leiden_debug() && (htier[0] || htier[1]))
     fprintf(stderr, "[leiden] aggregate n=%d -> %d: %d rows through the workgroup tier, %d through the 8192-slot tier\n", g.n, inn,
@@ -2944,6 +3067,25 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
     hipLaunchKernelGGL((ld_agg_block_kernel<BHUB_SLOTS, 1024>), dim3((unsigned)std::min(cx.agg_big_grid, htier[1])), dim3(1024),
                        HUB_LDS, cx.s, b.big_list, b.counters + 5, inn, b.moff, b.eoff, b.members, g.indptr, g.indices, g.wq,
                        b.cid, b.agg_col, b.agg_w, b.rowcnt, b.counters + 7, cx.agg_pass_keys, cx.hub_try_probes);
+    SCAMD_LAUNCH_CHECK();
+  }
+  if (htier[2] > 0) {
+    // split rows: parts -> built as pseudo rows by the 1024-thread builder -> merged (ld_agg_parts_kernel).  The list of
+    // split rows borrows b.hub_list, their first part / part count b.rlist / b.touched (refinement scratch, idle here)
+    const int64_t chunk = agg_split_chunk();
+    if (leiden_debug()) fprintf(stderr, "[leiden] aggregate n=%d -> %d: %d rows split into parts of %lld entries\n", g.n, inn, htier[2], (long long)chunk);
+    hipLaunchKernelGGL(ld_agg_parts_kernel, GRID1(htier[2]), 0, cx.s, (const int*)b.hub_list, b.counters, b.moff, b.eoff, chunk,
+                       b.pmoff, b.part_list, b.rlist, b.touched);
+    SCAMD_LAUNCH_CHECK();
+    const int64_t parts_bound = (int64_t)htier[2] + g.nnz / chunk + 1;
+    hipLaunchKernelGGL((ld_agg_block_kernel<BHUB_SLOTS, 1024>), dim3((unsigned)std::min<int64_t>(cx.agg_big_grid, parts_bound)), dim3(1024),
+                       HUB_LDS, cx.s, (const int*)b.part_list, (const int*)(b.counters + 3), inn, (const int64_t*)b.pmoff, b.eoff,
+                       b.members, g.indptr, g.indices, g.wq, b.cid, b.agg_col, b.agg_w, b.part_cnt, b.counters + 7,
+                       cx.agg_pass_keys, cx.hub_try_probes);
+    SCAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ld_agg_merge_kernel, dim3((unsigned)std::min(HUB_GRID, htier[2])), dim3(1024), HUB_LDS, cx.s,
+                       (const int*)b.hub_list, (const int*)b.counters, b.moff, b.eoff, (const int64_t*)b.pmoff, (const int*)b.part_cnt,
+                       (const int*)b.rlist, (const int*)b.touched, b.agg_col, b.agg_w, b.rowcnt, b.counters + 7);
     SCAMD_LAUNCH_CHECK();
   }
   CoarseBuf& cb = b.cb[dst];
@@ -3223,6 +3365,10 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
   SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ld_move_hub_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)HUB_LDS));
   SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ld_refine_propose_hub_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)HUB_LDS));
+  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ld_agg_merge_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)HUB_LDS));
+  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ld_agg_block_kernel<BHUB_SLOTS, 1024>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)HUB_LDS));
   SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ld_small_levels_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmallLds)));

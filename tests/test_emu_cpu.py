@@ -289,7 +289,7 @@ def test_knn_wide_rows_and_long_lists(emu, n, d, k):
 
 def test_leiden_coarse_row_builders_agree(emu, monkeypatch):
     """the coarse graph does not depend on which builder made a row: wave tier, workgroup tiers by table size or by work,
-    one optimistic pass or the class passes after a failed trial"""
+    one optimistic pass or the class passes after a failed trial, whole rows or rows cut into parts and merged"""
     H, lib = emu
     n = 3000
     x = np.random.default_rng(0).standard_normal((n, 10)).astype(np.float32)
@@ -300,7 +300,9 @@ def test_leiden_coarse_row_builders_agree(emu, monkeypatch):
     for env in ({"SCAMD_LEIDEN_AGG_WAVE_WORK": "64", "SCAMD_LEIDEN_AGG_MID_WORK": "400"},
                 {"SCAMD_LEIDEN_AGG_WAVE_MAX": "0"},
                 {"SCAMD_LEIDEN_AGG_WAVE_MAX": "0", "SCAMD_LEIDEN_AGG_MID_MAX": "0", "SCAMD_LEIDEN_AGG_PASS_KEYS": "16",
-                 "SCAMD_LEIDEN_HUB_TRY_PROBES": "1"}):
+                 "SCAMD_LEIDEN_HUB_TRY_PROBES": "1"},
+                # ~200 coarse rows per level cut into parts of 64 member entries, built as pseudo rows and merged
+                {"SCAMD_LEIDEN_AGG_WAVE_WORK": "32", "SCAMD_LEIDEN_AGG_SPLIT_CHUNK": "64", "SCAMD_LEIDEN_AGG_SPLIT_WORK": "64"}):
         with monkeypatch.context() as mp:
             for k_, v_ in env.items():
                 mp.setenv(k_, v_)

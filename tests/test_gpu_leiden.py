@@ -134,8 +134,11 @@ def test_leiden_disconnected_and_isolated(K):
         {"SCAMD_LEIDEN_AGG_WAVE_MAX": "0", "SCAMD_LEIDEN_AGG_MID_MAX": "0", "SCAMD_LEIDEN_AGG_PASS_KEYS": "16",
          "SCAMD_LEIDEN_HUB_TRY_PROBES": "1"},
         {"SCAMD_LEIDEN_AGG_WAVE_WORK": "64", "SCAMD_LEIDEN_AGG_MID_WORK": "512"},  # tiers by work: rows leave the wave tier early
+        # coarse rows cut into parts of 64 / 1024 member entries, built as pseudo rows by several workgroups and merged
+        {"SCAMD_LEIDEN_AGG_WAVE_WORK": "32", "SCAMD_LEIDEN_AGG_SPLIT_CHUNK": "64", "SCAMD_LEIDEN_AGG_SPLIT_WORK": "64"},
+        {"SCAMD_LEIDEN_AGG_SPLIT_CHUNK": "1024", "SCAMD_LEIDEN_AGG_SPLIT_WORK": "4096"},
     ],
-    ids=["mid", "big", "big-multipass", "big-classpasses", "big-failed-trial", "work-tiers"],
+    ids=["mid", "big", "big-multipass", "big-classpasses", "big-failed-trial", "work-tiers", "split-64", "split-1024"],
 )
 def test_leiden_coarse_row_tiers_agree(K, monkeypatch, env):
     """the wave / workgroup / multi-pass builders of the coarse graph produce the same graph, so the partition
