@@ -643,6 +643,17 @@ def structure_variant(args, backend, kw, structure: str, probes=(8, 32, 128)) ->
            "pca_info": {k: v for k, v in res.info.items() if k not in ("knn_fallback_queries", "leiden_stats")},
            "leiden": leiden_block(res.info.get("leiden_stats", {}), res.stage_ms.get("leiden"))}
     out["leiden_guarantees"] = leiden_guarantees(res, args.n_obs)
+    # the same graph under the setting the reference recommends for its igraph flavor and announces as its future default
+    # (`n_iterations=2`, src/scanpy/tools/_leiden.py:247-256 warning text): what the stage costs when it is not run to stability
+    from scanpy_amd import _kernels as K
+
+    K.leiden(res.conn_indptr, res.conn_indices, res.conn_data, args.n_obs, n_iterations=2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, q2, nc2 = K.leiden(res.conn_indptr, res.conn_indices, res.conn_data, args.n_obs, n_iterations=2)
+    torch.cuda.synchronize()
+    out["leiden_n_iterations_2"] = {"ms": (time.perf_counter() - t0) * 1e3, "modularity": q2, "n_communities": nc2,
+                                    "note": "tl.leiden(flavor='igraph', n_iterations=2) on the same graph; `stage_ms.leiden` is n_iterations=-1"}
     if probes:
         out["knn_approx"] = approx_knn_curve(res.x_pca, res.knn_indices, args.n_neighbors, probes)
     return out

@@ -33,6 +33,12 @@ timeout -k 5 1200 python -m pytest tests -m gpu -q -p no:faulthandler > "$OUT/py
 echo "pytest rc=$?"; tail -2 "$OUT/pytest_gpu.log" | cut -c1-200
 timeout -k 5 120 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1 < /dev/null
 echo "smoke rc=$?"; tail -1 "$OUT/smoke.log"
+# the realistic case as the timed workload (overlapping programmes: the exact search evaluates every pair), and the driver's own
+# invocation (no flags) under `time`
+timeout -k 5 600 python bench.py --structure weak --steps 5 --warmup 1 --cpu-sizes 0 --no-noise-variant --h2h-reps 0 --no-side > "$OUT/bench_weak.json" 2> "$OUT/bench_weak.err" < /dev/null
+echo "bench weak rc=$? $(python -c "import json,sys; d=json.loads([l for l in open('$OUT/bench_weak.json') if l.startswith('{')][-1]); print(round(d['ms_per_step'],1), {k: round(v,1) for k,v in d['stage_ms_per_step'].items()}, 'roofline', round(d['roofline']['frac'],3), d['full_size_properties']['failed_gates'])" 2>&1 | tail -1)"
+( time timeout -k 5 900 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" < /dev/null ) 2> "$OUT/bench_default.time"
+echo "bench default rc=$? $(grep real "$OUT/bench_default.time")"
 python - "$OUT" <<'PY'
 import json, sys
 out = sys.argv[1]
