@@ -271,6 +271,16 @@ int scamd_leiden_csr_init_f32(const int64_t* indptr, const int32_t* indices, con
                               double beta, uint64_t seed, const int32_t* initial_membership,
                               int32_t* membership, double* modularity_host, int32_t* n_communities_host,
                               void* workspace, size_t workspace_bytes, scamd_stream_t stream);
+/* ... with the objective named: 0 = modularity (the two entry points above), 1 = CPM -- igraph's
+ * community_leiden(objective_function='CPM') as reached from sc.tl.leiden(flavor='igraph', objective_function='CPM')
+ * (src/scanpy/tools/_leiden.py:188-196): every vertex weighs 1, the resolution is not divided by 2m.
+ * initial_membership may be NULL.  With objective 1 *modularity_host is the resolution-1 modularity of the returned
+ * partition (the reference stores part.modularity, :219), not the CPM quality the run maximised. */
+int scamd_leiden_csr_ex_f32(const int64_t* indptr, const int32_t* indices, const float* weights,
+                            int64_t n, int64_t nnz, double resolution, int n_iterations,
+                            double beta, uint64_t seed, int objective, const int32_t* initial_membership,
+                            int32_t* membership, double* modularity_host, int32_t* n_communities_host,
+                            void* workspace, size_t workspace_bytes, scamd_stream_t stream);
 /* Statistics of the last scamd_leiden_csr_f32 call on this thread, out[0 .. min(n, 12)):
  *   [0] outer iterations run, [1] kernel launches, [2] blocking host round trips,
  *   [3] full sweeps / [4] rounds / [5] vertices moved by the final polish (n_iterations < 0: strictly monotone

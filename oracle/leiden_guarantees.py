@@ -25,7 +25,9 @@ import numpy as np
 from scipy import sparse
 
 
-def _prep(adj, labels):
+def _prep(adj, labels, objective: str = "modularity"):
+    """-> (a, lab, nu, norm, onehot, ntot, two_m): vertex weights nu and the divisor of the penalty term -- strengths and 2m for
+    modularity, ones and 1 for CPM (igraph `objective_function='CPM'`: gain of joining D = k_v(D) - g n_v N_D)"""
     a = sparse.csr_matrix(adj).astype(np.float64)
     a.setdiag(0)  # (the reference's graphs have no self loops; the optimisers ignore them)
     a.eliminate_zeros()
@@ -34,16 +36,29 @@ def _prep(adj, labels):
     n, nc = a.shape[0], int(lab.max()) + 1
     k = np.asarray(a.sum(axis=1)).ravel()
     two_m = float(k.sum())
+    if objective.lower() == "cpm":
+        nu, norm = np.ones(n), 1.0
+    elif objective.lower() == "modularity":
+        nu, norm = k, two_m
+    else:
+        raise ValueError(f"objective {objective!r}")
     onehot = sparse.csr_matrix((np.ones(n), (np.arange(n), lab)), shape=(n, nc))
-    ktot = np.asarray(onehot.T @ k).ravel()
-    return a, lab, k, two_m, onehot, ktot
+    ntot = np.asarray(onehot.T @ nu).ravel()
+    return a, lab, nu, norm, onehot, ntot, two_m
 
 
-def improving_moves(adj, labels, *, resolution: float = 1.0, tol: float = 1e-12):
+def quality(adj, labels, *, resolution: float = 1.0, objective: str = "modularity") -> float:
+    """(1 / 2m) sum_C [ e_C - g N_C^2 / norm ]: the modularity, or igraph's CPM quality, of a partition"""
+    a, lab, nu, norm, onehot, ntot, two_m = _prep(adj, labels, objective)
+    e = np.asarray((onehot.T @ a @ onehot).diagonal()).ravel()
+    return float((e - resolution * ntot * ntot / norm).sum() / two_m)
+
+
+def improving_moves(adj, labels, *, resolution: float = 1.0, tol: float = 1e-12, objective: str = "modularity"):
     """vertices that a single move to a neighbouring community (or to a community of their own) would improve.
 
     -> dict(count, fraction, max_gain (in units of Q), worst_vertex)"""
-    a, lab, k, two_m, onehot, ktot = _prep(adj, labels)
+    a, lab, k, norm, onehot, ktot, two_m = _prep(adj, labels, objective)
     n = a.shape[0]
     g = resolution
     w = (a @ onehot).tocsr()  # w[v, D] = k_v(D), stored for the communities v has an edge to
@@ -53,8 +68,8 @@ def improving_moves(adj, labels, *, resolution: float = 1.0, tol: float = 1e-12)
     own = cols == lab[rows]
     k_own = np.zeros(n)
     k_own[rows[own]] = w.data[own]  # k_v(C \ v): no self loops
-    stay = k_own - g * k * (ktot[lab] - k) / two_m
-    gain = w.data - g * k[rows] * ktot[cols] / two_m - stay[rows]
+    stay = k_own - g * k * (ktot[lab] - k) / norm
+    gain = w.data - g * k[rows] * ktot[cols] / norm - stay[rows]
     gain[own] = -np.inf
     best = np.full(n, -np.inf)
     np.maximum.at(best, rows, gain)
@@ -66,13 +81,13 @@ def improving_moves(adj, labels, *, resolution: float = 1.0, tol: float = 1e-12)
             "worst_vertex": worst}
 
 
-def mergeable_pairs(adj, labels, *, resolution: float = 1.0, tol: float = 1e-12):
+def mergeable_pairs(adj, labels, *, resolution: float = 1.0, tol: float = 1e-12, objective: str = "modularity"):
     """pairs of communities whose merge would improve the quality (g-separation violated).
 
     -> dict(count, max_gain (in units of Q), n_communities)"""
-    a, lab, k, two_m, onehot, ktot = _prep(adj, labels)
+    a, lab, k, norm, onehot, ktot, two_m = _prep(adj, labels, objective)
     e = (onehot.T @ a @ onehot).tocoo()  # E(C, D) for C != D (each unordered pair twice)
     off = e.row < e.col
-    gain = (e.data[off] - resolution * ktot[e.row[off]] * ktot[e.col[off]] / two_m) / (two_m / 2.0)
+    gain = (e.data[off] - resolution * ktot[e.row[off]] * ktot[e.col[off]] / norm) / (two_m / 2.0)
     return {"count": int((gain > tol).sum()), "max_gain": float(gain.max()) if gain.size else 0.0,
             "n_communities": int(ktot.size)}

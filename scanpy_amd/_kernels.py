@@ -396,9 +396,12 @@ def colsum(y: torch.Tensor) -> torch.Tensor:
 
 
 def leiden(indptr: torch.Tensor, indices: torch.Tensor, weights: torch.Tensor, n: int, *, resolution: float = 1.0,
-           n_iterations: int = -1, beta: float = 0.01, seed: int = 0, initial_membership: torch.Tensor | None = None):
+           n_iterations: int = -1, beta: float = 0.01, seed: int = 0, initial_membership: torch.Tensor | None = None,
+           objective: str = "modularity"):
     """Symmetric CSR graph on device -> (membership int32 [n] on device, modularity, n_communities).
-    `initial_membership` (int32 [n] on the device, ids in [0, n)): start from that partition instead of singletons."""
+    `initial_membership` (int32 [n] on the device, ids in [0, n)): start from that partition instead of singletons.
+    `objective`: 'modularity' (resolution normalised by 2m, vertex weight = strength) or 'cpm' (igraph's CPM: vertex weight
+    1, resolution as given; the returned float is then the resolution-1 modularity of the partition)."""
     dev = require_gpu()
     lib = _lib.load()
     indptr = indptr.to(torch.int64).contiguous()
@@ -409,10 +412,20 @@ def leiden(indptr: torch.Tensor, indices: torch.Tensor, weights: torch.Tensor, n
     ws, wsz = _ws(lib.scamd_leiden_workspace_bytes(n, nnz), dev)
     q = C.c_double(0.0)
     nc = C.c_int32(0)
+    init = None
     if initial_membership is not None:
         init = initial_membership.to(device=dev, dtype=torch.int32).contiguous()
         if init.numel() != n:
             raise ValueError(f"initial_membership has {init.numel()} entries for {n} vertices")
+    if objective.lower() not in ("modularity", "cpm"):
+        raise ValueError(f"objective={objective!r}: 'modularity' or 'cpm'")
+    if objective.lower() == "cpm":
+        rc = lib.scamd_leiden_csr_ex_f32(ptr(indptr), ptr(indices), ptr(weights), n, nnz, float(resolution),
+                                         int(n_iterations), float(beta), int(seed) & (2**64 - 1), 1, ptr(init), ptr(memb),
+                                         C.byref(q), C.byref(nc), ptr(ws), wsz, stream_ptr())
+        _check(rc, "scamd_leiden_csr_ex_f32")
+        return memb, float(q.value), int(nc.value)
+    if init is not None:
         rc = lib.scamd_leiden_csr_init_f32(ptr(indptr), ptr(indices), ptr(weights), n, nnz, float(resolution),
                                            int(n_iterations), float(beta), int(seed) & (2**64 - 1), ptr(init), ptr(memb),
                                            C.byref(q), C.byref(nc), ptr(ws), wsz, stream_ptr())

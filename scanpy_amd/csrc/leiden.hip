@@ -141,6 +141,17 @@ __global__ void ld_iota_kernel(int* __restrict__ a, int n) {
   if (i < n) a[i] = i;
 }
 
+__global__ void ld_fill_i64_kernel(long long* __restrict__ a, int n, long long v) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = v;
+}
+// coarse vertex weights of CPM: kout[cid[v]] += k[v]  (kout zeroed by the caller; integer: order free)
+__global__ void ld_agg_nodeweight_kernel(int n, const int* __restrict__ cid, const long long* __restrict__ k,
+                                         long long* __restrict__ kout) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n) atomicAdd(reinterpret_cast<unsigned long long*>(&kout[cid[v]]), (unsigned long long)k[v]);
+}
+
 __global__ void ld_fill_u8_kernel(unsigned char* __restrict__ a, int n, unsigned char v) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] = v;
@@ -2512,6 +2523,12 @@ struct LeidenCtx {
   LeidenBuffers b;
   double gamma;
   double m2;  // total (quantised) weight = sum of strengths
+  // Objective.  Modularity (default): vertex weight = strength, the gain of joining C is w(v, C) - (gamma / 2m) k_v K_C.
+  // CPM (igraph `objective_function='CPM'`, src/scanpy/tools/_leiden.py:188-196): vertex weight = 1 (sums on the coarse
+  // levels), resolution not normalised: w(v, C) - gamma n_v N_C.  Every kernel takes "the vertex weights" and "g": the two
+  // objectives differ only in what the host hands them (weights are 2^32 fixed point: g carries the scale).
+  bool cpm = false;
+  double gscale() const { return cpm ? gamma * WSCALE : gamma / m2; }
   double inv_beta = 0.0;  // 1 / (beta * 2^32): randomness of the refinement's merge rule (0 = greedy)
   int iter = 0;           // outer iteration: part of the refinement's noise seed
   unsigned int seed;
@@ -2570,7 +2587,7 @@ static int compute_totals(LeidenCtx& cx, const LevelGraph& g, const int* comm) {
   return SCAMD_OK;
 }
 
-// modularity of `comm` on level graph g (needs Ktot up to date)
+// quality of `comm` on level graph g (needs Ktot up to date): modularity, or the CPM objective in the same units
 static int quality(LeidenCtx& cx, const LevelGraph& g, const int* comm, double* q) {
   SCAMD_HIP_CHECK(hipMemsetAsync(cx.b.total + 1, 0, sizeof(unsigned long long), cx.s));
   if (g.nnz <= (int64_t)48 * g.n)
@@ -2580,7 +2597,8 @@ static int quality(LeidenCtx& cx, const LevelGraph& g, const int* comm, double* 
     hipLaunchKernelGGL(ld_internal_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(g.n, 4))), dim3(256), 0, cx.s, g.n,
                        g.indptr, g.indices, g.wq, comm, cx.b.total + 1);
   SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ld_sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(1024), 0, cx.s, g.n, cx.b.Ktot, cx.m2, cx.b.dscratch + 4);
+  // (CPM: sum of squared community SIZES, unnormalised)
+  hipLaunchKernelGGL(ld_sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(1024), 0, cx.s, g.n, cx.b.Ktot, cx.cpm ? 1.0 : cx.m2, cx.b.dscratch + 4);
   SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(ld_sumsq_final_kernel, dim3(1), dim3(1024), 0, cx.s, cx.b.dscratch + 4, cx.b.dscratch);
   SCAMD_LAUNCH_CHECK();
@@ -2589,7 +2607,8 @@ static int quality(LeidenCtx& cx, const LevelGraph& g, const int* comm, double* 
   SCAMD_HIP_CHECK(hipMemcpyAsync(&internal, cx.b.total + 1, sizeof(internal), hipMemcpyDeviceToHost, cx.s));
   SCAMD_HIP_CHECK(hipMemcpyAsync(&sumsq, cx.b.dscratch, sizeof(double), hipMemcpyDeviceToHost, cx.s));
   LD_SYNC(cx.s);
-  *q = (double)(long long)internal / cx.m2 - cx.gamma * sumsq;
+  *q = cx.cpm ? ((double)(long long)internal - cx.gamma * WSCALE * sumsq) / cx.m2
+              : (double)(long long)internal / cx.m2 - cx.gamma * sumsq;
   return SCAMD_OK;
 }
 
@@ -2626,7 +2645,7 @@ static int rf_classes(const LeidenCtx& cx, int n) {
 
 static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
   LeidenBuffers& b = cx.b;
-  const double gg = cx.gamma / cx.m2;
+  const double gg = cx.gscale();
   *total_moves = 0;
   int rc = compute_totals(cx, g, b.comm);
   if (rc != SCAMD_OK) return rc;
@@ -2813,7 +2832,7 @@ constexpr int MAX_POLISH_ROUNDS = 1 << 16;
 constexpr int MAX_POLISH_PASSES = 6;  // polish -> verifying iteration -> polish ... (each accepted pass raises Q)
 static int polish_level0(LeidenCtx& cx, const LevelGraph& g, int* stats) {
   LeidenBuffers& b = cx.b;
-  const double gg = cx.gamma / cx.m2;
+  const double gg = cx.gscale();
   const size_t n = (size_t)g.n;
   stats[0] = stats[1] = stats[2] = stats[3] = 0;
   SCAMD_HIP_CHECK(hipMemcpyAsync(b.comm, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
@@ -2913,7 +2932,7 @@ static int polish_level0(LeidenCtx& cx, const LevelGraph& g, int* stats) {
 
 static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
   LeidenBuffers& b = cx.b;
-  const double gg = cx.gamma / cx.m2;
+  const double gg = cx.gscale();
   // fresh merge noise and fresh classes every outer iteration
   const unsigned int rseed = cx.seed + 0x9E3779B9u * (unsigned int)cx.iter;
   const unsigned int salt = hash32(rseed ^ 0x5bd1e995u);
@@ -3105,7 +3124,12 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   SCAMD_LAUNCH_CHECK();
   SCAMD_HIP_CHECK(hipMemcpyAsync(dstat, b.counters + 8, sizeof(int) * 4, hipMemcpyDeviceToHost, cx.s));
   SCAMD_HIP_CHECK(hipMemcpyAsync(&nnz_new, cb.indptr + nn, sizeof(int64_t), hipMemcpyDeviceToHost, cx.s));
-  hipLaunchKernelGGL(ld_strength_kernel, GRIDW(nn), 0, cx.s, cb.indptr, cb.wq, (int)nn, cb.k);
+  if (cx.cpm) {  // sizes add up over the members; strengths are the row sums of the coarse graph
+    SCAMD_HIP_CHECK(hipMemsetAsync(cb.k, 0, sizeof(long long) * nn, cx.s));
+    hipLaunchKernelGGL(ld_agg_nodeweight_kernel, GRID1(g.n), 0, cx.s, g.n, (const int*)b.cid, g.k, cb.k);
+  } else {
+    hipLaunchKernelGGL(ld_strength_kernel, GRIDW(nn), 0, cx.s, cb.indptr, cb.wq, (int)nn, cb.k);
+  }
   SCAMD_LAUNCH_CHECK();
   SCAMD_HIP_CHECK(hipMemcpyAsync(b.comm, b.comm_tmp, sizeof(int) * nn, hipMemcpyDeviceToDevice, cx.s));
   LD_SYNC(cx.s);
@@ -3146,7 +3170,7 @@ static int small_levels(LeidenCtx& cx, const LevelGraph& g, int level) {
   }
   a.first_dst = level & 1;  // level L >= 1 lives in cb[(L - 1) & 1]
   a.comm = b.comm;
-  a.gg = cx.gamma / cx.m2;
+  a.gg = cx.gscale();
   a.inv_beta = cx.inv_beta;
   a.seed = cx.seed;
   a.iter = cx.iter;
@@ -3268,6 +3292,10 @@ static int setup_level0(LeidenCtx& cx, const int64_t* indptr, const int32_t* ind
   g0->indices = indices;
   g0->wq = b.wq0;
   g0->k = b.k0;
+  if (cx.cpm) {  // the vertex weights of CPM are counts; the strengths above were only needed for 2m
+    hipLaunchKernelGGL(ld_fill_i64_kernel, GRID1(n), 0, cx.s, b.k0, (int)n, 1ll);
+    SCAMD_LAUNCH_CHECK();
+  }
   return SCAMD_OK;
 }
 
@@ -3299,14 +3327,14 @@ __global__ void ld_copy_membership_kernel(int n, const int* __restrict__ init, i
 static int leiden_run(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n, int64_t nnz,
                       double resolution, int n_iterations, double beta, uint64_t seed, const int32_t* initial_membership,
                       int32_t* membership, double* modularity_host, int32_t* n_communities_host, void* workspace,
-                      size_t workspace_bytes, scamd_stream_t stream);
+                      size_t workspace_bytes, scamd_stream_t stream, int objective);
 
 extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n,
                                     int64_t nnz, double resolution, int n_iterations, double beta, uint64_t seed,
                                     int32_t* membership, double* modularity_host, int32_t* n_communities_host,
                                     void* workspace, size_t workspace_bytes, scamd_stream_t stream) {
   return leiden_run(indptr, indices, weights, n, nnz, resolution, n_iterations, beta, seed, nullptr, membership,
-                    modularity_host, n_communities_host, workspace, workspace_bytes, stream);
+                    modularity_host, n_communities_host, workspace, workspace_bytes, stream, 0);
 }
 
 // ... starting from a given partition instead of singletons (`initial_membership` of leidenalg.find_partition /
@@ -3319,13 +3347,28 @@ extern "C" int scamd_leiden_csr_init_f32(const int64_t* indptr, const int32_t* i
                                          size_t workspace_bytes, scamd_stream_t stream) {
   SCAMD_REQUIRE(initial_membership, SCAMD_EINVAL, "leiden: null initial membership");
   return leiden_run(indptr, indices, weights, n, nnz, resolution, n_iterations, beta, seed, initial_membership, membership,
-                    modularity_host, n_communities_host, workspace, workspace_bytes, stream);
+                    modularity_host, n_communities_host, workspace, workspace_bytes, stream, 0);
+}
+
+// ... with the objective named: 0 = modularity (the two entry points above), 1 = CPM -- igraph's
+// `community_leiden(objective_function='CPM')`, reachable through `sc.tl.leiden(flavor='igraph', objective_function='CPM')`
+// (src/scanpy/tools/_leiden.py:188-196): every vertex weighs 1, the resolution is NOT divided by 2m, a community pays
+// gamma n_C^2.  initial_membership may be NULL.  *modularity_host is the (resolution 1) modularity of the returned partition
+// either way -- what the reference stores (`part.modularity`, :219) -- for objective 0 at the given resolution, as before.
+extern "C" int scamd_leiden_csr_ex_f32(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n,
+                                       int64_t nnz, double resolution, int n_iterations, double beta, uint64_t seed,
+                                       int objective, const int32_t* initial_membership, int32_t* membership,
+                                       double* modularity_host, int32_t* n_communities_host, void* workspace,
+                                       size_t workspace_bytes, scamd_stream_t stream) {
+  SCAMD_REQUIRE(objective == 0 || objective == 1, SCAMD_EINVAL, "leiden: objective %d (0 = modularity, 1 = CPM)", objective);
+  return leiden_run(indptr, indices, weights, n, nnz, resolution, n_iterations, beta, seed, initial_membership, membership,
+                    modularity_host, n_communities_host, workspace, workspace_bytes, stream, objective);
 }
 
 static int leiden_run(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n, int64_t nnz,
                       double resolution, int n_iterations, double beta, uint64_t seed, const int32_t* initial_membership,
                       int32_t* membership, double* modularity_host, int32_t* n_communities_host, void* workspace,
-                      size_t workspace_bytes, scamd_stream_t stream) {
+                      size_t workspace_bytes, scamd_stream_t stream, int objective) {
   SCAMD_REQUIRE(indptr && membership && (nnz == 0 || (indices && weights)), SCAMD_EINVAL, "leiden: null pointer");
   SCAMD_REQUIRE(n >= 1 && n < ((int64_t)1 << 31) && nnz >= 0, SCAMD_EINVAL, "leiden: bad shape n=%lld nnz=%lld",
                 (long long)n, (long long)nnz);
@@ -3346,6 +3389,8 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
   if (const char* e = getenv("SCAMD_LEIDEN_SMALL")) cx.small_levels = e[0] != '0';
   if (const char* e = getenv("SCAMD_LEIDEN_FUSE")) cx.no_fuse = e[0] == '0';
   if (const char* e = getenv("SCAMD_LEIDEN_POLISH")) cx.polish = e[0] != '0';
+  cx.cpm = objective == 1;
+  if (cx.cpm) cx.small_levels = false;  // (ld_small_levels_kernel derives its coarse vertex weights from row sums: strengths)
   for (int i = 0; i < 12; ++i) g_ld_stats[i] = 0;
   g_ld_sweep_bytes = 0.0;
   if (const char* e = getenv("SCAMD_LEIDEN_SMALL_SEQ")) cx.small_seq_n = atoi(e);
@@ -3489,6 +3534,17 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
         break;  // stable: the polished partition stands
       }
     }
+  }
+  if (cx.cpm && cx.m2 > 0.0) {
+    // what is reported is the modularity of the partition (the reference stores `part.modularity`), not the CPM quality the
+    // run maximised: strengths back into k0, totals, resolution 1
+    hipLaunchKernelGGL(ld_strength_kernel, GRIDW(n), 0, cx.s, indptr, b.wq0, (int)n, b.k0);
+    SCAMD_LAUNCH_CHECK();
+    cx.cpm = false;
+    cx.gamma = 1.0;
+    rc = compute_totals(cx, g0, b.memb);
+    if (rc == SCAMD_OK) rc = quality(cx, g0, b.memb, &q_best);
+    if (rc != SCAMD_OK) return rc;
   }
   int nc = 0;
   rc = renumber(cx, (int)n, &nc);

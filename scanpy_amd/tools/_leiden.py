@@ -67,7 +67,7 @@ def rename_groups(adata, restrict_key, *, key_added, restrict_categories, restri
 
 
 def leiden_partition(adjacency, *, resolution=1.0, n_iterations=-1, seed=0, use_weights=True, beta=0.01,
-                     initial_membership=None):
+                     initial_membership=None, objective="modularity"):
     """Symmetric adjacency (scipy sparse) -> (membership int32 [n], modularity).  `initial_membership`: a partition to
     start from (any non-negative integer labels, one per vertex), as leidenalg / igraph take it."""
     import torch
@@ -95,7 +95,8 @@ def leiden_partition(adjacency, *, resolution=1.0, n_iterations=-1, seed=0, use_
         # (the kernel wants ids below n: any labelling is renamed to consecutive ids first)
         init = torch.from_numpy(np.unique(labels, return_inverse=True)[1].astype(np.int32)).to(dev)
     memb, q, _ = _kernels.leiden(indptr, indices, weights, n, resolution=float(resolution),
-                                 n_iterations=int(n_iterations), beta=beta, seed=int(seed), initial_membership=init)
+                                 n_iterations=int(n_iterations), beta=beta, seed=int(seed), initial_membership=init,
+                                 objective=objective)
     return memb.cpu().numpy(), q
 
 
@@ -131,8 +132,13 @@ def leiden(  # noqa: PLR0913
     unknown = set(clustering_args) - {"objective_function", "weights", "beta", "initial_membership", "node_weights"}
     if unknown:
         raise TypeError(f"leiden() got unexpected clustering arguments {sorted(unknown)}")
-    if clustering_args.get("objective_function", "modularity").lower() != "modularity":
-        raise NotImplementedError("only objective_function='modularity' is built on the MI355X path")
+    objective = str(clustering_args.get("objective_function", "modularity")).lower()
+    if objective not in ("modularity", "cpm"):  # (igraph's own message, Graph.community_leiden)
+        raise ValueError('objective_function must be "CPM" or "modularity".')
+    if objective == "cpm" and flavor != "igraph":
+        # (the reference hands `objective_function` to igraph only, _leiden.py:188-196; leidenalg takes a partition class)
+        raise NotImplementedError("objective_function='CPM' is igraph's: pass flavor='igraph' (leidenalg partition types are "
+                                  "not built on the MI355X path)")
     if clustering_args.get("node_weights") is not None:
         raise NotImplementedError("node_weights are not supported on the MI355X path")
     initial_membership = clustering_args.get("initial_membership")
@@ -149,7 +155,7 @@ def leiden(  # noqa: PLR0913
             adata, restrict_key, restrict_categories=restrict_categories, adjacency=adjacency)
     groups, modularity = leiden_partition(adjacency, resolution=resolution, n_iterations=n_iterations, seed=seed,
                                           use_weights=use_weights, beta=clustering_args.get("beta", 0.01),
-                                          initial_membership=initial_membership)
+                                          initial_membership=initial_membership, objective=objective)
     if restrict_to is not None:
         if key_added == "leiden":
             key_added += "_R"

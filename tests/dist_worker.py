@@ -40,10 +40,10 @@ def _patch_kernels():
         return (torch.from_numpy(conn.indptr.astype(np.int64)), torch.from_numpy(conn.indices.astype(np.int32)),
                 torch.from_numpy(conn.data.astype(np.float32)), torch.from_numpy(sig), torch.from_numpy(rho))
 
-    def leiden(indptr, indices, weights, n, *, resolution=1.0, n_iterations=-1, beta=0.01, seed=0, initial_membership=None):
+    def leiden(indptr, indices, weights, n, *, resolution=1.0, n_iterations=-1, beta=0.01, seed=0, initial_membership=None, objective="modularity"):
         from scipy import sparse
 
-        assert initial_membership is None, "the CPU stand-in starts from singletons"
+        assert objective == "modularity" and initial_membership is None, "the CPU stand-in starts from singletons"
 
         adj = sparse.csr_matrix((weights.numpy(), indices.numpy(), indptr.numpy()), shape=(n, n))
         memb, q = ol.leiden(adj, resolution=resolution, n_iterations=n_iterations, seed=seed)

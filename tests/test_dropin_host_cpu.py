@@ -262,8 +262,11 @@ def test_clustering_custom_key_and_objective(sc, pbmc68k):
     for res in (0.9, 1.1):
         assert adata.uns[f"leiden_{res}"]["params"]["resolution"] == res
     sc.tl.leiden(adata, objective_function="modularity", flavor="igraph", directed=False)
-    with pytest.raises(NotImplementedError, match="objective_function"):
-        sc.tl.leiden(adata, objective_function="CPM", flavor="igraph")
+    with pytest.raises(ValueError, match='must be "CPM" or "modularity"'):  # (igraph's message)
+        sc.tl.leiden(adata, objective_function="surprise", flavor="igraph")
+    with pytest.raises(NotImplementedError, match="objective_function='CPM' is igraph's"):
+        with pytest.warns(FutureWarning):
+            sc.tl.leiden(adata, objective_function="CPM")  # default flavor leidenalg: partition classes are not built
 
 
 # ---- tests/test_neighbors_key_added.py semantics ------------------------------------------------------------------------

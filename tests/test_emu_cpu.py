@@ -310,6 +310,42 @@ def test_leiden_coarse_row_builders_agree(emu, monkeypatch):
         assert got[1] == base[1] and np.array_equal(got[0], base[0]), env
 
 
+def test_leiden_cpm_objective(emu):
+    """igraph's `objective_function='CPM'` (src/scanpy/tools/_leiden.py:188-196): vertex weights 1, resolution not normalised.
+    At a resolution between the planted clusters' internal and external densities the clusters are recovered; at every
+    resolution the partition's CPM quality is at least the planted one's, no vertex move and no merge improves it UNDER THE CPM
+    OBJECTIVE (oracle/leiden_guarantees.py, objective='cpm'), and what is reported is the partition's modularity"""
+    from sklearn.metrics import adjusted_rand_score
+
+    from oracle import leiden as ol
+    from oracle import leiden_guarantees as lg
+
+    H, lib = emu
+    rng = np.random.default_rng(0)
+    n = 1500
+    cent = rng.standard_normal((12, 10)) * 4
+    truth = rng.integers(0, 12, n)
+    x = (cent[truth] + rng.standard_normal((n, 10))).astype(np.float32)
+    idx, dist = oknn.knn_exact_f64(x, np.arange(n), 15)
+    conn, _, _ = oconn.fuzzy_simplicial_set(idx, dist, n, 15)
+    for gamma, recovered in ((0.01, True), (0.05, False)):
+        memb, q, nc = H.leiden(lib, conn, seed=0, resolution=gamma, objective=1)
+        assert abs(q - ol.modularity(conn, memb)) < 1e-9 and nc == int(memb.max()) + 1
+        q_cpm = lg.quality(conn, memb, resolution=gamma, objective="cpm")
+        assert q_cpm >= lg.quality(conn, truth, resolution=gamma, objective="cpm") - 1e-12
+        assert q_cpm > max(lg.quality(conn, np.arange(n), resolution=gamma, objective="cpm"),
+                           lg.quality(conn, np.zeros(n, dtype=int), resolution=gamma, objective="cpm"))
+        assert lg.improving_moves(conn, memb, resolution=gamma, objective="cpm")["count"] == 0
+        assert lg.mergeable_pairs(conn, memb, resolution=gamma, objective="cpm")["count"] == 0
+        assert (adjusted_rand_score(memb, truth) == 1.0) == recovered and (nc == 12) == recovered
+    again = H.leiden(lib, conn, seed=0, resolution=0.05, objective=1)
+    assert np.array_equal(again[0], memb)  # reproducible
+    # the modularity objective is untouched by the switch
+    m0 = H.leiden(lib, conn, seed=0)
+    m1 = H.leiden(lib, conn, seed=0, objective=0)
+    assert m0[1] == m1[1] and np.array_equal(m0[0], m1[0])
+
+
 def test_leiden_hub_rows(emu):
     """a vertex with 2500 neighbours (multi-pass hub tables) and vertices of 150 .. 1200 (overflow list, hub list tiers)"""
     from scipy import sparse
@@ -412,7 +448,7 @@ def test_front_ends_and_widening_kernels_on_the_emulator(emu):
     import subprocess
 
     keep = ("pca_transform_golden or pca_no_zero_center_golden or pca_shapes_and_errors or neighbors_key_added or leiden_errors or "
-            "leiden_initial_membership or "
+            "leiden_initial_membership or leiden_cpm_objective or "
             "neighbors_precomputed_distances or neighbors_fixture_vs_oracle or gauss_and_jaccard or neighbors_cosine_metric or "
             "transformer_plugin_route or leiden_restrict_to or leiden_basic_and_params or normalize_total or rep_mutation or "
             "test_scale or test_filters or chain_goldens or random_against_oracle or col_stats_clip or hvg_ or global-atomics or "
@@ -424,4 +460,4 @@ def test_front_ends_and_widening_kernels_on_the_emulator(emu):
     tail = out.stdout[-1500:]
     assert out.returncode == 0, tail
     m = re.search(r"(\d+) passed", tail)
-    assert m and int(m.group(1)) >= 41, tail
+    assert m and int(m.group(1)) >= 42, tail

@@ -281,6 +281,31 @@ def test_leiden_initial_membership(sc, pbmc68k):
         sc.tl.leiden(adata, flavor="igraph", initial_membership=-np.ones(700, dtype=np.int64))
 
 
+def test_leiden_cpm_objective(sc, pbmc68k):
+    """`sc.tl.leiden(flavor='igraph', objective_function='CPM')` (src/scanpy/tools/_leiden.py:188-196 hands it to igraph's
+    community_leiden): node optimal and separated under the CPM objective, quality above the trivial partitions', the
+    stored `modularity` is the partition's modularity; the leidenalg flavor has no such argument"""
+    from oracle import leiden_guarantees as lg
+
+    adata = _graph_adata(sc, pbmc68k)
+    conn = adata.obsp["connectivities"]
+    for gamma in (0.005, 0.05):
+        sc.tl.leiden(adata, flavor="igraph", objective_function="CPM", resolution=gamma, key_added=f"cpm_{gamma}")
+        lab = adata.obs[f"cpm_{gamma}"].cat.codes.to_numpy()
+        q_cpm = lg.quality(conn, lab, resolution=gamma, objective="cpm")
+        assert q_cpm > max(lg.quality(conn, np.arange(700), resolution=gamma, objective="cpm"),
+                           lg.quality(conn, np.zeros(700, dtype=int), resolution=gamma, objective="cpm"))
+        assert lg.improving_moves(conn, lab, resolution=gamma, objective="cpm")["count"] == 0
+        assert lg.mergeable_pairs(conn, lab, resolution=gamma, objective="cpm")["count"] == 0
+        assert abs(adata.uns[f"cpm_{gamma}"]["modularity"] - sc.metrics.modularity(conn, lab, is_directed=False)) < 1e-9
+        assert adata.uns[f"cpm_{gamma}"]["params"]["resolution"] == gamma
+    assert adata.obs["cpm_0.05"].nunique() > adata.obs["cpm_0.005"].nunique()  # a higher resolution: smaller communities
+    with pytest.raises(ValueError, match='must be "CPM" or "modularity"'):
+        sc.tl.leiden(adata, flavor="igraph", objective_function="surprise")
+    with pytest.raises(NotImplementedError, match="objective_function='CPM' is igraph's"):
+        sc.tl.leiden(adata, flavor="leidenalg", objective_function="CPM")
+
+
 def test_leiden_restrict_to_and_keys(sc, pbmc68k):
     """tests/test_clustering.py:177-242."""
     adata = _graph_adata(sc, pbmc68k)
