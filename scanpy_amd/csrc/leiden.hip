@@ -837,21 +837,30 @@ __global__ __launch_bounds__(256) void ld_polish_apply_kernel(int n_act, const i
 // anything: connected components INSIDE the communities by min-label propagation (comp[v] -> the smallest vertex id of
 // its component; in place, monotone, with one pointer jump per visit), and every component becomes a community of its
 // own (splitting a community along a cut without edges raises Q by 2 g K1 K2 / (2m)^2 > 0).
-__global__ void ld_cc_prop_kernel(int n, const int64_t* __restrict__ indptr, const int* __restrict__ indices,
-                                  const int* __restrict__ comm, int* __restrict__ comp, int* __restrict__ changed) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= n) return;
-  const int c = comm[v];
-  const int old = __hip_atomic_load(&comp[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__global__ __launch_bounds__(256) void ld_cc_prop_kernel(int n, const int64_t* __restrict__ indptr, const int* __restrict__ indices,
+                                                         const int* __restrict__ comm, int* __restrict__ comp, int* __restrict__ changed) {
+  // 16 lanes per vertex: the row is read coalesced, the neighbours' labels gathered 16 at a time (a thread per vertex walked
+  // its row one dependent gather after the other: 1.0 ms per pass at 1M vertices)
+  const int v = (blockIdx.x * 256 + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+  const bool live = v < n;
+  const int vv = live ? v : 0;
+  const int c = comm[vv];
+  const int old = __hip_atomic_load(&comp[vv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int m = old;
-  for (int64_t e = indptr[v]; e < indptr[v + 1]; ++e) {
-    const int u = indices[e];
-    if (comm[u] == c) m = min(m, __hip_atomic_load(&comp[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  if (live) {
+    for (int64_t e = indptr[v] + sub; e < indptr[v + 1]; e += 16) {
+      const int u = indices[e];
+      if (comm[u] == c) m = min(m, __hip_atomic_load(&comp[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
   }
-  m = min(m, __hip_atomic_load(&comp[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));  // (comp[m] <= m, same component)
-  if (m < old) {
-    atomicMin(&comp[v], m);
-    *changed = 1;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));  // (every lane of the wave takes part)
+  if (live && sub == 0) {
+    m = min(m, __hip_atomic_load(&comp[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));  // (comp[m] <= m, same component)
+    if (m < old) {
+      atomicMin(&comp[v], m);
+      *changed = 1;
+    }
   }
 }
 // out[0] += components (roots), out[1] += non-empty communities
@@ -2806,7 +2815,8 @@ static int split_disconnected(LeidenCtx& cx, const LevelGraph& g, int* n_split) 
     SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 2, 0, sizeof(int) * 3, cx.s));
     // (several propagation steps per host round trip: the flag only says whether any of them changed something)
     for (int rep = 0; rep < 4; ++rep) {
-      hipLaunchKernelGGL(ld_cc_prop_kernel, GRID1(g.n), 0, cx.s, g.n, g.indptr, g.indices, (const int*)b.comm, b.cid, b.counters + 2);
+      hipLaunchKernelGGL(ld_cc_prop_kernel, dim3((unsigned)ceil_div(g.n, 16)), dim3(256), 0, cx.s, g.n, g.indptr, g.indices,
+                         (const int*)b.comm, b.cid, b.counters + 2);
       SCAMD_LAUNCH_CHECK();
     }
     int changed = 0;
