@@ -27,9 +27,6 @@ def _validate_flavor(flavor, *, partition_type, directed):
             msg = "Do not pass in partition_type argument when using igraph."
             raise ValueError(msg)
     elif flavor == "leidenalg":
-        if partition_type is not None:
-            msg = "partition_type is a leidenalg class; the MI355X kernel optimises RBConfiguration modularity only."
-            raise NotImplementedError(msg)
         if was_default:
             msg = ("In the future, the default backend for leiden will be igraph instead of leidenalg. "
                    "To achieve the future defaults please pass: `flavor='igraph'` and `n_iterations=2`. "
@@ -39,6 +36,33 @@ def _validate_flavor(flavor, *, partition_type, directed):
         msg = f"flavor must be either 'igraph' or 'leidenalg', but {flavor!r} was passed."
         raise ValueError(msg)
     return flavor
+
+
+# leidenalg partition classes the device optimiser covers, by class name (leidenalg is absent from this image; on a user's
+# machine `partition_type=leidenalg.CPMVertexPartition` arrives as the class): -> (objective, takes a resolution_parameter)
+_PARTITION_TYPES = {
+    "RBConfigurationVertexPartition": ("modularity", True),  # the reference's default, _leiden.py:174-175
+    "ModularityVertexPartition": ("modularity", False),  # RBConfiguration at resolution 1, no resolution_parameter
+    "CPMVertexPartition": ("cpm", True),  # node sizes 1: igraph's objective_function='CPM'
+}
+
+
+def _resolve_partition_type(partition_type, resolution):
+    """`partition_type` of the leidenalg flavor (src/scanpy/tools/_leiden.py:107-110, 174-186) -> (objective, resolution).
+    `leidenalg.find_partition` hands `resolution_parameter` to the class's constructor, so a class without one fails with a
+    TypeError unless `resolution=None` (the reference's docstring: "Set to `None` if overriding `partition_type`")."""
+    if partition_type is None:
+        return "modularity", 1.0 if resolution is None else resolution
+    name = partition_type if isinstance(partition_type, str) else getattr(partition_type, "__name__", type(partition_type).__name__)
+    if name not in _PARTITION_TYPES:
+        raise NotImplementedError(f"partition_type {name!r} is not built on the MI355X path (have: {sorted(_PARTITION_TYPES)})")
+    objective, takes_resolution = _PARTITION_TYPES[name]
+    if not takes_resolution:
+        if resolution is not None:
+            raise TypeError(f"{name}.__init__() got an unexpected keyword argument 'resolution_parameter' "
+                            "(pass resolution=None with this partition_type)")
+        return objective, 1.0
+    return objective, 1.0 if resolution is None else resolution
 
 
 def restrict_adjacency(adata, restrict_key, *, restrict_categories, adjacency):
@@ -123,7 +147,8 @@ def leiden(  # noqa: PLR0913
 
     Both reference flavors optimise the same objective on the symmetric connectivities
     (RBConfiguration modularity with `resolution`) and are served by the same GPU
-    optimiser.  Writes `.obs[key_added]` (categorical of str, naturally sorted categories, ids by
+    optimiser.  `objective_function='CPM'` (igraph) and `partition_type=` RBConfiguration / Modularity / CPM
+    VertexPartition (leidenalg; matched by class name, `_PARTITION_TYPES`) select the objective of that optimiser.  Writes `.obs[key_added]` (categorical of str, naturally sorted categories, ids by
     decreasing community size) and `.uns[key_added] = {params, modularity}`."""
     if not is_anndata(adata):
         raise TypeError("leiden() expects an AnnData-like object")
@@ -135,17 +160,20 @@ def leiden(  # noqa: PLR0913
     objective = str(clustering_args.get("objective_function", "modularity")).lower()
     if objective not in ("modularity", "cpm"):  # (igraph's own message, Graph.community_leiden)
         raise ValueError('objective_function must be "CPM" or "modularity".')
-    if objective == "cpm" and flavor != "igraph":
-        # (the reference hands `objective_function` to igraph only, _leiden.py:188-196; leidenalg takes a partition class)
-        raise NotImplementedError("objective_function='CPM' is igraph's: pass flavor='igraph' (leidenalg partition types are "
-                                  "not built on the MI355X path)")
+    if flavor == "leidenalg":
+        if "objective_function" in clustering_args:
+            # (the reference hands `objective_function` to igraph only, _leiden.py:188-196; leidenalg's find_partition would
+            # pass it on to the partition class, which does not take it)
+            raise TypeError("objective_function is igraph's argument: pass flavor='igraph', or "
+                            "partition_type=leidenalg.CPMVertexPartition with flavor='leidenalg'")
+        objective, gamma = _resolve_partition_type(partition_type, resolution)
+    else:
+        gamma = 1.0 if resolution is None else resolution  # (igraph's default when `resolution` is left out, _leiden.py:193-194)
     if clustering_args.get("node_weights") is not None:
         raise NotImplementedError("node_weights are not supported on the MI355X path")
     initial_membership = clustering_args.get("initial_membership")
     if initial_membership is not None and restrict_to is not None:
         raise NotImplementedError("initial_membership together with restrict_to is not supported on the MI355X path")
-    if resolution is None:
-        raise NotImplementedError("resolution=None (partition types without a resolution) is not supported")
     adata = adata.copy() if copy else adata
     if adjacency is None:
         adjacency = choose_graph(adata, obsp, neighbors_key)
@@ -153,7 +181,7 @@ def leiden(  # noqa: PLR0913
         restrict_key, restrict_categories = restrict_to
         adjacency, restrict_indices = restrict_adjacency(
             adata, restrict_key, restrict_categories=restrict_categories, adjacency=adjacency)
-    groups, modularity = leiden_partition(adjacency, resolution=resolution, n_iterations=n_iterations, seed=seed,
+    groups, modularity = leiden_partition(adjacency, resolution=gamma, n_iterations=n_iterations, seed=seed,
                                           use_weights=use_weights, beta=clustering_args.get("beta", 0.01),
                                           initial_membership=initial_membership, objective=objective)
     if restrict_to is not None:

@@ -264,9 +264,9 @@ def test_clustering_custom_key_and_objective(sc, pbmc68k):
     sc.tl.leiden(adata, objective_function="modularity", flavor="igraph", directed=False)
     with pytest.raises(ValueError, match='must be "CPM" or "modularity"'):  # (igraph's message)
         sc.tl.leiden(adata, objective_function="surprise", flavor="igraph")
-    with pytest.raises(NotImplementedError, match="objective_function='CPM' is igraph's"):
+    with pytest.raises(TypeError, match="objective_function is igraph's argument"):
         with pytest.warns(FutureWarning):
-            sc.tl.leiden(adata, objective_function="CPM")  # default flavor leidenalg: partition classes are not built
+            sc.tl.leiden(adata, objective_function="CPM")  # default flavor leidenalg: takes a partition class instead
 
 
 # ---- tests/test_neighbors_key_added.py semantics ------------------------------------------------------------------------

@@ -302,8 +302,31 @@ def test_leiden_cpm_objective(sc, pbmc68k):
     assert adata.obs["cpm_0.05"].nunique() > adata.obs["cpm_0.005"].nunique()  # a higher resolution: smaller communities
     with pytest.raises(ValueError, match='must be "CPM" or "modularity"'):
         sc.tl.leiden(adata, flavor="igraph", objective_function="surprise")
-    with pytest.raises(NotImplementedError, match="objective_function='CPM' is igraph's"):
+    with pytest.raises(TypeError, match="objective_function is igraph's argument"):
         sc.tl.leiden(adata, flavor="leidenalg", objective_function="CPM")
+
+
+def test_leiden_partition_type_of_the_leidenalg_flavor(sc, pbmc68k):
+    """`partition_type=` (src/scanpy/tools/_leiden.py:107-110, 174-186: the class `leidenalg.find_partition` optimises, with
+    `resolution_parameter=resolution` unless `resolution=None`): the classes are matched by name -- RBConfiguration is the
+    default, Modularity is RBConfiguration at 1 and takes no resolution, CPM is the igraph flavor's objective_function='CPM'"""
+    adata = _graph_adata(sc, pbmc68k)
+    rb = type("RBConfigurationVertexPartition", (), {})
+    mod = type("ModularityVertexPartition", (), {})
+    cpm = type("CPMVertexPartition", (), {})
+    sc.tl.leiden(adata, flavor="leidenalg", resolution=0.7, key_added="default")
+    sc.tl.leiden(adata, flavor="leidenalg", resolution=0.7, partition_type=rb, key_added="rb")
+    assert (adata.obs["default"] == adata.obs["rb"]).all()
+    sc.tl.leiden(adata, flavor="leidenalg", resolution=None, partition_type=mod, key_added="mod")
+    sc.tl.leiden(adata, flavor="leidenalg", resolution=1.0, key_added="one")
+    assert (adata.obs["mod"] == adata.obs["one"]).all() and adata.uns["mod"]["params"]["resolution"] is None
+    sc.tl.leiden(adata, flavor="leidenalg", resolution=0.05, partition_type=cpm, key_added="cpm")
+    sc.tl.leiden(adata, flavor="igraph", resolution=0.05, objective_function="CPM", key_added="cpm_igraph")
+    assert (adata.obs["cpm"] == adata.obs["cpm_igraph"]).all()
+    with pytest.raises(TypeError, match="unexpected keyword argument 'resolution_parameter'"):
+        sc.tl.leiden(adata, flavor="leidenalg", resolution=1.0, partition_type=mod)
+    with pytest.raises(NotImplementedError, match="SurpriseVertexPartition"):
+        sc.tl.leiden(adata, flavor="leidenalg", partition_type=type("SurpriseVertexPartition", (), {}))
 
 
 def test_leiden_restrict_to_and_keys(sc, pbmc68k):
