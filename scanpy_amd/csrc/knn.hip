@@ -568,6 +568,8 @@ struct IvfArgs {
                              // end of the prologue, end of the pre-pass, ticks inside the sweeps of the cells, cells swept}
   int n_cells, dc;          // dc = stride of `centers` (>= d)
   int d;
+  int* queue_ctr;           // persistent launch (null: one workgroup per launch slot): [8] next position of the queue of XCD x --
+  int n_slots;              // launch slots x, x + 8, x + 16, ... of block_perm[0, n_slots); see knn_select_reg_kernel
 };
 
 // TC_ = candidates per LDS tile, WPS = resident blocks per CU (= waves per SIMD) the register budget is cut for
@@ -605,6 +607,23 @@ __device__ __forceinline__ void b3_query_operand(const float* __restrict__ xp, i
     qh[3][3] = 0x3F803F80;             // dims 54, 55: 1, 1
   }
 }
+// lane exchanges of the pre-pass's sorting network that stay in the VALU (DPP control words: quad_perm 0x00-0xFF,
+// row_ror:8 0x128, row_mirror 0x140, row_half_mirror 0x141) or cross a row of 16 lanes (ds_swizzle, bit mode: and 0x1F,
+// xor << 10)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// lane i ^ 4: lanes 0-3 / 8-11 of a row (banks 0, 2) read four lanes up (row_shl:4), lanes 4-7 / 12-15 four lanes down
+__device__ __forceinline__ float dpp_xor4_f32(float v) {
+  int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xf, 0x5, false);
+  t = __builtin_amdgcn_update_dpp(t, __float_as_int(v), 0x114, 0xf, 0xa, false);
+  return __int_as_float(t);
+}
+template <int PATTERN>
+__device__ __forceinline__ float swizzle_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), PATTERN));
+}
 // scores of one 32 x 32 sub-tile minus the thresholds: qh.ch, then qh.cl, then ql.ch, 4 k-steps of 16 dims each
 __device__ __forceinline__ f32x16 b3_chain(const i32x4 (&qh)[4], const i32x4 (&ql)[4], const BFragBf16& b) {
   f32x16 acc;
@@ -622,11 +641,12 @@ __device__ __forceinline__ f32x16 b3_chain(const i32x4 (&qh)[4], const i32x4 (&q
   return acc;
 }
 
-template <int H, int TC_, int WPS, bool IVF, bool B3 = false>
-__global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* __restrict__ xp, int n_tiles_all,
-                                                                  int64_t n_pad, int64_t q_begin,
-                                                                  int thr_rank, int* __restrict__ cand_idx,
-                                                                  float* __restrict__ cand_tau, IvfArgs iv) {
+// one block of the search: 128 queries (brute force: queries blk * 128 ..; pruned sweep: the query slots of block blk)
+template <int H, int TC_, int WPS, bool IVF, bool B3>
+__device__ __forceinline__ void knn_select_reg_block(const int blk, const float* __restrict__ xp, int n_tiles_all,
+                                                     int64_t n_pad, int64_t q_begin, int thr_rank,
+                                                     int* __restrict__ cand_idx, float* __restrict__ cand_tau,
+                                                     const IvfArgs& iv) {
   using C = RegCfg<H, TC_, B3>;
   constexpr int HP = C::HP, DPL = C::DPL, TC = C::TC, SUBS = C::SUBS;
   using BFrag = std::conditional_t<B3, BFragBf16, BFragF32<HP>>;
@@ -635,12 +655,6 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int thr_lane = thr_rank - 1;
-  // block id: the pruned sweep hands out its blocks longest-expected-sweep first (block_perm)
-  int blk = blockIdx.x;
-  if constexpr (IVF) {
-    blk = iv.block_perm[blockIdx.x];
-    if (blk < 0) return;  // launch slot without a block (XCD-aware order: ivf_block_order_kernel)
-  }
 
   // A operand: lane l holds query (l&31), dims [half*H, half*H+H), pre-scaled by -2
   // (B3: k-step s, lane half h: dims 16 s + 8 h .. + 8 as four bf16 pairs, hi part in qh, lo part in ql)
@@ -1054,32 +1068,48 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
       }
       minima = false;
       block_sync();
+      // compare-exchange constants: a lane whose bit b (of l31) is clear keeps the SMALLER value of its pair --
+      // v = med3(v, partner, lim[b]) with lim = -inf there and +inf on the partner's side (negated: the larger value)
+      float lim[5];
+#pragma unroll
+      for (int b = 0; b < 5; ++b) lim[b] = (l31 & (1 << b)) ? INFINITY : -INFINITY;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         // bitonic sort of the 64 values of each half's query: element e = 32 j + l31, j = 0 in x (smallest per lane), j = 1
-        // in y (second smallest).  Stages kk = 2 .. 32 sort both registers along the lanes -- x ascending, y descending at
-        // kk = 32 (bit 5 of e is j) -- then the kk = 64 merge: its first step compares x with y in the lane and leaves
-        // the 32 smallest of the 64 in x, which its remaining five steps put in ascending order (y is done with).
+        // in y (second smallest).  Stages 2 .. 32 sort both registers along the 32 lanes, x ascending and y descending, in
+        // the "mirror" form of the network (the first step of a merge of blocks of B pairs lane i with lane B - 1 - i, the
+        // rest with i ^ j: every block ascends, no direction flags); then the 64-merge: its first step compares x with y in
+        // the lane and leaves the 32 smallest of the 64 in x, which its remaining five steps put in ascending order.
+        // Round 5: the partners come through the VALU (DPP quad_perm / row_half_mirror / row_mirror / row_ror:8, two
+        // bank-masked row shifts for i ^ 4) except the three that cross a row of 16 (ds_swizzle): 3 LDS-pipe exchanges per
+        // register instead of 35 `ds_bpermute`, each of which the compiler had put a full `s_waitcnt lgkmcnt(0)` behind.
         float x = key[r], y = iv.prepass_min2 ? __int_as_float(idx[r]) : KEY_BIG;  // (SCAMD_KNN_PREPASS_MIN2=0: lane minima only, rounds 1-3)
         idx[r] = -1;
-#pragma unroll
-        for (int kk = 2; kk <= 32; kk <<= 1) {
-#pragma unroll
-          for (int j = kk >> 1; j > 0; j >>= 1) {
-            const float xo = __shfl_xor(x, j), yo = __shfl_xor(y, j);
-            const bool lower = (l31 & j) == 0;
-            const bool upx = kk == 32 ? true : (l31 & kk) == 0;
-            const bool upy = kk == 32 ? false : (l31 & kk) == 0;
-            x = (lower == upx) ? fminf(x, xo) : fmaxf(x, xo);
-            y = (lower == upy) ? fminf(y, yo) : fmaxf(y, yo);
-          }
-        }
-        x = fminf(x, y);
-#pragma unroll
-        for (int j = 16; j > 0; j >>= 1) {
-          const float xo = __shfl_xor(x, j);
-          x = ((l31 & j) == 0) ? fminf(x, xo) : fmaxf(x, xo);
-        }
+        auto cx2 = [&](float xp_, float yp_, int b) __attribute__((always_inline)) {
+          x = __builtin_amdgcn_fmed3f(x, xp_, lim[b]);
+          y = __builtin_amdgcn_fmed3f(y, yp_, -lim[b]);
+        };
+        cx2(dpp_f32<0xB1>(x), dpp_f32<0xB1>(y), 0);                    // blocks of 2
+        cx2(dpp_f32<0x1B>(x), dpp_f32<0x1B>(y), 1);                    // blocks of 4: mirror, then i ^ 1
+        cx2(dpp_f32<0xB1>(x), dpp_f32<0xB1>(y), 0);
+        cx2(dpp_f32<0x141>(x), dpp_f32<0x141>(y), 2);                  // blocks of 8: row_half_mirror, i ^ 2, i ^ 1
+        cx2(dpp_f32<0x4E>(x), dpp_f32<0x4E>(y), 1);
+        cx2(dpp_f32<0xB1>(x), dpp_f32<0xB1>(y), 0);
+        cx2(dpp_f32<0x140>(x), dpp_f32<0x140>(y), 3);                  // blocks of 16: row_mirror, i ^ 4, i ^ 2, i ^ 1
+        cx2(dpp_xor4_f32(x), dpp_xor4_f32(y), 2);
+        cx2(dpp_f32<0x4E>(x), dpp_f32<0x4E>(y), 1);
+        cx2(dpp_f32<0xB1>(x), dpp_f32<0xB1>(y), 0);
+        cx2(swizzle_f32<0x7C1F>(x), swizzle_f32<0x7C1F>(y), 4);        // blocks of 32: i ^ 31 (swizzle), row_ror:8, i ^ 4, ...
+        cx2(dpp_f32<0x128>(x), dpp_f32<0x128>(y), 3);
+        cx2(dpp_xor4_f32(x), dpp_xor4_f32(y), 2);
+        cx2(dpp_f32<0x4E>(x), dpp_f32<0x4E>(y), 1);
+        cx2(dpp_f32<0xB1>(x), dpp_f32<0xB1>(y), 0);
+        x = __builtin_amdgcn_fmed3f(x, y, -INFINITY);                  // min: the 32 smallest, a bitonic sequence along the lanes
+        x = __builtin_amdgcn_fmed3f(x, swizzle_f32<0x401F>(x), lim[4]);
+        x = __builtin_amdgcn_fmed3f(x, dpp_f32<0x128>(x), lim[3]);
+        x = __builtin_amdgcn_fmed3f(x, dpp_xor4_f32(x), lim[2]);
+        x = __builtin_amdgcn_fmed3f(x, dpp_f32<0x4E>(x), lim[1]);
+        x = __builtin_amdgcn_fmed3f(x, dpp_f32<0xB1>(x), lim[0]);
         const int i0 = (r & 3) + 8 * (r >> 2), i1 = i0 + 4;
         const float t0 = readlane_f32(x, thr_lane), t1 = readlane_f32(x, 32 + thr_lane);
         athr = (lane == i0) ? -t0 : ((lane == i1) ? -t1 : athr);
@@ -1159,6 +1189,52 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
         cand_idx[qi * C::KP + l31] = sid >= 0 ? iv.perm[sid] : -1;
         if (l31 == thr_lane) cand_tau[qi] = half ? tf1 : tf0;
       }
+    }
+  }
+}
+
+// The launch.  Brute force: workgroup b = block b.  Pruned sweep: launch slot s -> block block_perm[s] (longest expected
+// sweep first, the blocks of a cell on one XCD: slots x, x + 8, ... are the queue of XCD x, ivf_block_order_kernel), either
+// one workgroup per slot, or -- round 5, iv.queue_ctr -- PERSISTENT: as many workgroups as the chip holds, each taking the
+// next block off the queue of its XCD (workgroup b runs on XCD b mod 8, like slot b would) and, once that queue is empty,
+// off the other XCDs' queues.  The per-block timeline (profiles/r05p_knn_timeline.log) had the queues finish 0.9 ms apart
+// (12.30 .. 13.18 ms: the work estimates behind the static deal are a ranking, not a measurement) and 4 % of the block
+// slots empty in the steady state, waiting for the dispatcher.
+template <int H, int TC_, int WPS, bool IVF, bool B3 = false>
+__global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* __restrict__ xp, int n_tiles_all,
+                                                                  int64_t n_pad, int64_t q_begin,
+                                                                  int thr_rank, int* __restrict__ cand_idx,
+                                                                  float* __restrict__ cand_tau, IvfArgs iv) {
+  if constexpr (!IVF) {
+    knn_select_reg_block<H, TC_, WPS, IVF, B3>((int)blockIdx.x, xp, n_tiles_all, n_pad, q_begin, thr_rank, cand_idx, cand_tau, iv);
+  } else {
+    using C = RegCfg<H, TC_, B3>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int* s_next = reinterpret_cast<int*>(smem + C::NBUF * C::TC * C::DPL + 8);  // (wmax[4 .. 15] are unused)
+    for (int pass = 0;; ++pass) {
+      int blk = -1;
+      if (iv.queue_ctr == nullptr) {
+        if (pass == 0) blk = iv.block_perm[blockIdx.x];  // (-1: launch slot without a block)
+      } else {
+        __syncthreads();  // nobody reads the previous block's tiles / tables / s_next any more
+        if (threadIdx.x == 0) {
+          int got = -1;
+          const int x0 = (int)(blockIdx.x & 7);
+          for (int t = 0; t < 8 && got < 0; ++t) {
+            const int x = (x0 + t) & 7;
+            // (a queue's blocks sit at its positions 0 .. len - 1, -1 behind them: a queue that ran dry is not taken from again)
+            const int64_t peek = 8 * (int64_t)__hip_atomic_load(&iv.queue_ctr[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + x;
+            if (peek >= iv.n_slots || iv.block_perm[peek] < 0) continue;
+            const int64_t slot = 8 * (int64_t)atomicAdd(&iv.queue_ctr[x], 1) + x;
+            if (slot < iv.n_slots) got = iv.block_perm[slot];  // (-1: somebody else took the queue's last block in between)
+          }
+          *s_next = got;
+        }
+        __syncthreads();
+        blk = *s_next;
+      }
+      if (blk < 0) return;
+      knn_select_reg_block<H, TC_, WPS, IVF, B3>(blk, xp, n_tiles_all, n_pad, q_begin, thr_rank, cand_idx, cand_tau, iv);
     }
   }
 }
@@ -2225,7 +2301,7 @@ static void knn_carve(Workspace& ws, const KnnPlan& p, int64_t n_query, KnnBuffe
   b->cand_tau = ws.take<float>((size_t)p.nq_pad);
   b->kth_d2 = ws.take<double>((size_t)n_query);
   b->flag_list = ws.take<int>((size_t)n_query);
-  b->counters = ws.take<int>(8);  // [0] uncertified, [1] overflow, [2..3] swept pairs, [4..5] pre-pass pairs (u64), [6] launch-order error
+  b->counters = ws.take<int>(16);  // [0] uncertified, [1] overflow, [2..3] swept pairs, [4..5] pre-pass pairs (u64), [6] launch-order error, [8..15] XCD queue positions
   b->scratch_d = ws.take<double>((size_t)FALLBACK_CHUNK * FALLBACK_CAP);
   b->scratch_i = ws.take<int>((size_t)FALLBACK_CHUNK * FALLBACK_CAP);
   b->fb_counts = ws.take<int>((size_t)FALLBACK_CHUNK);
@@ -2587,8 +2663,22 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
     SCAMD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&iv.trace), sizeof(unsigned long long) * 8 * n_blocks));
     SCAMD_HIP_CHECK(hipMemsetAsync(iv.trace, 0, sizeof(unsigned long long) * 8 * n_blocks, s));
   }
+  // persistent launch (see knn_select_reg_kernel): 8 XCDs x 32 CUs x the resident blocks per CU; SCAMD_KNN_PERSISTENT=0 is the
+  // launch of one workgroup per slot, = N sets the number of workgroups (rounded up to a multiple of 8)
+  int n_groups = n_launch;
+  iv.queue_ctr = nullptr;
+  iv.n_slots = n_launch;
+  {
+    const char* e = getenv("SCAMD_KNN_PERSISTENT");
+    const int want = e ? atoi(e) : 256 * ((wps_env && atoi(wps_env) == 2) ? 2 : 3);
+    if (want > 0 && n_launch > want) {
+      n_groups = (want + 7) / 8 * 8;
+      iv.queue_ctr = b.counters + 8;
+      SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 8, 0, sizeof(int) * 8, s));
+    }
+  }
   SCAMD_HIP_CHECK(hipEventRecord(ev0, s));
-  hipLaunchKernelGGL(kern, dim3(n_launch), dim3(C::NT), lds, s, b.xp, (int)(rows / 64), rows, q_begin, p.thr_rank,
+  hipLaunchKernelGGL(kern, dim3(n_groups), dim3(C::NT), lds, s, b.xp, (int)(rows / 64), rows, q_begin, p.thr_rank,
                      b.cand_idx, b.cand_tau, iv);
   SCAMD_LAUNCH_CHECK();
   SCAMD_HIP_CHECK(hipEventRecord(ev1, s));
@@ -2708,6 +2798,8 @@ static int run_ivf_tier2(const KnnPlan& p, const KnnBuffers& b, const float* x, 
   iv.debug_no_insert = 0;
   iv.cell_preload = 1;
   iv.trace = nullptr;
+  iv.queue_ctr = nullptr;  // (a few hundred queries: one workgroup per block)
+  iv.n_slots = n_blocks;
   const int thr_rank = std::min(32, std::max(1, k + 6));
   hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(C::NT), lds, s, b.xp2, (int)(rows / 64), rows, q_begin, thr_rank, b.cand_idx,
                      b.cand_tau, iv);

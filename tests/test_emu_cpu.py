@@ -126,6 +126,32 @@ def test_knn_lds_dma_ring_with_late_landing(emu, monkeypatch, ivf):
         lib.emu_set_dma_late(0)
 
 
+def test_knn_persistent_launch_takes_every_block_once(emu, monkeypatch):
+    """the pruned sweep's persistent launch (knn_select_reg_kernel: a fixed number of workgroups take blocks off the eight
+    per-XCD queues and steal from the others once their own is dry): forced at test size with SCAMD_KNN_PERSISTENT=8 / 24
+    (workgroups) on a layout with >= 64 blocks (the XCD-aware queues) and on one below (block-id order) -- same lists, same
+    survivor / insertion counts as the launch of one workgroup per slot, every query answered"""
+    from oracle import compare as cmp
+
+    H, lib = emu
+    monkeypatch.setenv("SCAMD_KNN_IVF", "1")
+    monkeypatch.setenv("SCAMD_KNN_CELL_ROWS", "512")
+    for n, launches in ((8500, ("0", "8")), (2500, ("0", "24"))):
+        x = _blobs(n, 50, 6, 5, spread=3.0)
+        ei, ed = oknn.knn_exact_f64(x, np.arange(n), 15)
+        ref = None
+        for groups in launches:
+            monkeypatch.setenv("SCAMD_KNN_PERSISTENT", groups)
+            before = H.user_counters(lib, 2)
+            idx, dist, n_fallback = H.knn(lib, x, 15)
+            after = H.user_counters(lib, 2)
+            bad, _ = cmp.knn_rows_differing_beyond_ties(idx, dist, ei, ed)
+            assert bad == 0 and n_fallback == 0, (n, groups, bad, n_fallback)
+            got = (idx.tobytes(), dist.tobytes(), after[0] - before[0], after[1] - before[1])
+            ref = ref or got
+            assert got == ref, (n, groups)
+
+
 def test_knn_trace_dump_matches_its_parser(emu, monkeypatch, tmp_path):
     """SCAMD_KNN_TRACE: the per-block records the pruned sweep dumps and `tools/knn_trace.py` reads (the measurement behind
     DESIGN 3.1 "What binds it") -- record size, tiles swept == the launch's own count of evaluated pairs, cells per block"""
