@@ -128,7 +128,7 @@ def test_knn_lds_dma_ring_with_late_landing(emu, monkeypatch, ivf):
 
 def test_knn_persistent_launch_takes_every_block_once(emu, monkeypatch):
     """the pruned sweep's persistent launch (knn_select_reg_kernel: a fixed number of workgroups take blocks off the eight
-    per-XCD queues and steal from the others once their own is dry): forced at test size with SCAMD_KNN_PERSISTENT=8 / 24
+    per-XCD queues and steal from the others once their own is dry): forced at test size with SCAMD_KNN_PERSISTENT=8
     (workgroups) on a layout with >= 64 blocks (the XCD-aware queues) and on one below (block-id order) -- same lists, same
     survivor / insertion counts as the launch of one workgroup per slot, every query answered"""
     from oracle import compare as cmp
@@ -136,7 +136,7 @@ def test_knn_persistent_launch_takes_every_block_once(emu, monkeypatch):
     H, lib = emu
     monkeypatch.setenv("SCAMD_KNN_IVF", "1")
     monkeypatch.setenv("SCAMD_KNN_CELL_ROWS", "512")
-    for n, launches in ((8500, ("0", "8")), (2500, ("0", "24"))):
+    for n, launches in ((8500, ("0", "8")), (2500, ("0", "8"))):
         x = _blobs(n, 50, 6, 5, spread=3.0)
         ei, ed = oknn.knn_exact_f64(x, np.arange(n), 15)
         ref = None
