@@ -1119,6 +1119,12 @@ __device__ __forceinline__ void knn_select_reg_block(const int blk, const float*
         const int tb = __float_as_int(fminf(half ? t1 : t0, KEY_BIG));  // (never +inf: its mantissa holds the slot)
         key[r] = __int_as_float((tb & ~KEY_SLOT_MASK) | (tb < 0 ? 31 - l31 : l31));
       }
+      // Padding slots (the last block of a cell is half empty on average: 3 % of all slots) are "queries" at image row 0, a
+      // row of some far cell: the cells come in the order of THIS cell's bounds, which for that row is no order at all, so
+      // its list kept improving through the whole sweep -- the last block of a cell was the slowest of the cell in 390 of 484
+      // cells, by a factor 1.5 (profiles/r05r_knn_last_block_of_a_cell.log), and those blocks end their queues.  Their
+      // threshold becomes -1e30: no score is below it, nothing is inserted, nothing of theirs is read.
+      if (half == 0 && !qvalid) athr = 1e30f;
       sync_thr();
     }
     if (iv.trace && tid == 0) iv.trace[(size_t)blk * 8 + 5] = wall_clock64();
