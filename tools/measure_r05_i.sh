@@ -6,7 +6,7 @@ R="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT="$R/gpurun_out/$TAG"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-for ST in weak none planted; do
+for ST in ${STRUCTURES:-weak none planted}; do
   cd /tmp
   timeout -k 5 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_$ST -o leiden -- python "$R/tools/leiden_only.py" 1000000 $ST 1 > "$OUT/leiden_${ST}_prof.log" 2>&1 < /dev/null
   find /tmp/prof_${TAG}_$ST -name '*kernel_stats.csv' -exec cp {} "$OUT/leiden_${ST}_kernel_stats.csv" \;
