@@ -56,4 +56,46 @@ struct Workspace {
 
 inline int ceil_div(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / b); }
 
+// ---- small device -> host read-backs (counters, sizes) between the launches of a host-driven loop ------------------------
+// hipMemcpyAsync into PAGEABLE host memory is a blocking round trip of its own (the runtime stages it): a kernel + two such
+// copies + hipStreamSynchronize costs 39.6 us, one copy 25.9 us; into PINNED memory 17.8 / 15.3 us
+// (tools/probes/host_roundtrip_probe.hip, MI355X).  `fetch` queues a copy into a per-thread pinned page and remembers where
+// the caller wants the bytes; `sync` drains the stream once and hands them out.  The page is allocated on first use and kept
+// for the life of the thread (4 KiB).
+struct HostReadback {
+  static constexpr size_t CAP = 4096;
+  static constexpr int MAX_ITEMS = 8;
+  struct Item {
+    void* dst;
+    size_t off, bytes;
+  };
+  char* pin = nullptr;
+  size_t used = 0;
+  int n = 0;
+  Item items[MAX_ITEMS];
+  void reset() { used = 0, n = 0; }  // (an error path may leave queued items behind: every C entry point starts with this)
+  int fetch(void* dst, const void* src_device, size_t bytes, hipStream_t s) {
+    if (!pin) SCAMD_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&pin), CAP, 0));
+    const size_t off = align_up(used, 8);
+    SCAMD_REQUIRE(off + bytes <= CAP && n < MAX_ITEMS, SCAMD_EINTERNAL, "read-back staging page overflow (%zu + %zu bytes, %d items)",
+                  off, bytes, n);
+    SCAMD_HIP_CHECK(hipMemcpyAsync(pin + off, src_device, bytes, hipMemcpyDeviceToHost, s));
+    items[n++] = Item{dst, off, bytes};
+    used = off + bytes;
+    return SCAMD_OK;
+  }
+  int sync(hipStream_t s) {
+    const hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess)
+      for (int i = 0; i < n; ++i) memcpy(items[i].dst, pin + items[i].off, items[i].bytes);
+    reset();
+    SCAMD_HIP_CHECK(e);
+    return SCAMD_OK;
+  }
+};
+inline HostReadback& host_readback() {
+  static thread_local HostReadback rb;
+  return rb;
+}
+
 }  // namespace scamd

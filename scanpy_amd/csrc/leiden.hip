@@ -43,10 +43,18 @@ static thread_local double g_ld_sweep_bytes = 0.0;  // -> stats[9] (MB)
     ++g_ld_stats[1];                        \
     SCAMD_HIP_CHECK(hipGetLastError());     \
   } while (0)
-#define LD_SYNC(stream)                               \
-  do {                                                \
-    ++g_ld_stats[2];                                  \
-    SCAMD_HIP_CHECK(hipStreamSynchronize(stream));    \
+// host round trips: the values the host decides on are fetched into a pinned page (common.h: HostReadback -- a copy into
+// pageable memory is a blocking round trip of its own) and handed out by ONE synchronisation
+#define LD_FETCH(dst, src, bytes, stream)                                          \
+  do {                                                                             \
+    const int rc_fetch_ = host_readback().fetch((dst), (src), (bytes), (stream)); \
+    if (rc_fetch_ != SCAMD_OK) return rc_fetch_;                                   \
+  } while (0)
+#define LD_SYNC(stream)                                       \
+  do {                                                        \
+    ++g_ld_stats[2];                                          \
+    const int rc_sync_ = host_readback().sync(stream);        \
+    if (rc_sync_ != SCAMD_OK) return rc_sync_;                \
   } while (0)
 
 constexpr double WSCALE = 4294967296.0;  // 2^32
@@ -2529,6 +2537,7 @@ constexpr int HUB_GRID = 512;
 constexpr size_t HUB_LDS = (size_t)BHUB_SLOTS * 12;
 
 struct LeidenCtx {
+  LeidenCtx() { host_readback().reset(); }  // (read-backs an earlier call's error path left queued are dropped)
   hipStream_t s;
   LeidenBuffers b;
   double gamma;
@@ -2584,7 +2593,7 @@ static bool g_leiden_debug_sync = false;
   } while (0)
 
 static int read_counters(LeidenCtx& cx, int* h, int cnt) {
-  SCAMD_HIP_CHECK(hipMemcpyAsync(h, cx.b.counters, sizeof(int) * cnt, hipMemcpyDeviceToHost, cx.s));
+  LD_FETCH(h, cx.b.counters, sizeof(int) * cnt, cx.s);
   LD_SYNC(cx.s);
   return SCAMD_OK;
 }
@@ -2614,8 +2623,8 @@ static int quality(LeidenCtx& cx, const LevelGraph& g, const int* comm, double* 
   SCAMD_LAUNCH_CHECK();
   unsigned long long internal = 0;
   double sumsq = 0;
-  SCAMD_HIP_CHECK(hipMemcpyAsync(&internal, cx.b.total + 1, sizeof(internal), hipMemcpyDeviceToHost, cx.s));
-  SCAMD_HIP_CHECK(hipMemcpyAsync(&sumsq, cx.b.dscratch, sizeof(double), hipMemcpyDeviceToHost, cx.s));
+  LD_FETCH(&internal, cx.b.total + 1, sizeof(internal), cx.s);
+  LD_FETCH(&sumsq, cx.b.dscratch, sizeof(double), cx.s);
   LD_SYNC(cx.s);
   *q = cx.cpm ? ((double)(long long)internal - cx.gamma * WSCALE * sumsq) / cx.m2
               : (double)(long long)internal / cx.m2 - cx.gamma * sumsq;
@@ -2674,8 +2683,8 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
                        sweep == 0 ? (int*)nullptr : b.flag, b.cls_lists, sw, n_cls, salt, g.indptr, thr_mid, (int)WH_MAX_DEG);
     SCAMD_LAUNCH_CHECK();
     int hc[CTR_AREA], ht[8];  // class list lengths, then per sub-round [CTR_N_MID] / [CTR_N_HUB]: long rows of the class
-    SCAMD_HIP_CHECK(hipMemcpyAsync(hc, sw, sizeof(int) * (MAX_CLASSES + CTR_STRIDE * n_cls), hipMemcpyDeviceToHost, cx.s));
-    SCAMD_HIP_CHECK(hipMemcpyAsync(ht, b.counters, sizeof(int) * 8, hipMemcpyDeviceToHost, cx.s));
+    LD_FETCH(hc, sw, sizeof(int) * (MAX_CLASSES + CTR_STRIDE * n_cls), cx.s);
+    LD_FETCH(ht, b.counters, sizeof(int) * 8, cx.s);
     LD_SYNC(cx.s);
     SCAMD_REQUIRE(ht[7] == 0, SCAMD_EINTERNAL, "leiden: hub table overflow (local moving)");
     int n_act = 0;
@@ -2821,14 +2830,14 @@ static int split_disconnected(LeidenCtx& cx, const LevelGraph& g, int* n_split) 
       SCAMD_LAUNCH_CHECK();
     }
     int changed = 0;
-    SCAMD_HIP_CHECK(hipMemcpyAsync(&changed, b.counters + 2, sizeof(int), hipMemcpyDeviceToHost, cx.s));
+    LD_FETCH(&changed, b.counters + 2, sizeof(int), cx.s);
     LD_SYNC(cx.s);
     if (!changed) break;
   }
   hipLaunchKernelGGL(ld_cc_count_kernel, GRID1(g.n), 0, cx.s, g.n, (const int*)b.cid, (const int*)b.csize, b.counters + 3);
   SCAMD_LAUNCH_CHECK();
   int cnt[2] = {0, 0};
-  SCAMD_HIP_CHECK(hipMemcpyAsync(cnt, b.counters + 3, sizeof(cnt), hipMemcpyDeviceToHost, cx.s));
+  LD_FETCH(cnt, b.counters + 3, sizeof(cnt), cx.s);
   LD_SYNC(cx.s);
   *n_split = cnt[0] - cnt[1];
   if (leiden_debug()) fprintf(stderr, "[leiden] components %d, communities %d\n", cnt[0], cnt[1]);
@@ -2867,8 +2876,8 @@ static int polish_level0(LeidenCtx& cx, const LevelGraph& g, int* stats) {
                        full ? (int*)nullptr : b.flag, b.cls_lists, sw, 1, 0u, g.indptr, thr_mid, (int)WH_MAX_DEG);
     SCAMD_LAUNCH_CHECK();
     int hc[MAX_CLASSES + CTR_STRIDE], ht[8];
-    SCAMD_HIP_CHECK(hipMemcpyAsync(hc, sw, sizeof(hc), hipMemcpyDeviceToHost, cx.s));
-    SCAMD_HIP_CHECK(hipMemcpyAsync(ht, b.counters, sizeof(ht), hipMemcpyDeviceToHost, cx.s));
+    LD_FETCH(hc, sw, sizeof(hc), cx.s);
+    LD_FETCH(ht, b.counters, sizeof(ht), cx.s);
     LD_SYNC(cx.s);
     SCAMD_REQUIRE(ht[7] == 0, SCAMD_EINTERNAL, "leiden: hub table overflow (polish)");
     const int cnt = hc[0];
@@ -2969,7 +2978,7 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
   SCAMD_LAUNCH_CHECK();
   LD_DBG_SYNC(cx, "rf candidates n=%d classes=%d", g.n, n_cls);
   int hc[CTR_AREA];  // class list lengths, then per sub-round [CTR_N_MID] / [CTR_N_HUB] (ld_refine_candidates_kernel)
-  SCAMD_HIP_CHECK(hipMemcpyAsync(hc, rc0, sizeof(int) * (MAX_CLASSES + CTR_STRIDE * n_cls), hipMemcpyDeviceToHost, cx.s));
+  LD_FETCH(hc, rc0, sizeof(int) * (MAX_CLASSES + CTR_STRIDE * n_cls), cx.s);
   LD_SYNC(cx.s);
   *n_merged = 0;
   // ONE sweep of n_cls sub-rounds, no host round trip in between: every candidate is considered exactly once (see
@@ -3029,8 +3038,8 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
     LD_DBG_SYNC(cx, "rf cut update n=%d class=%d", g.n, c);
   }
   int hr[CTR_AREA], herr = 0;
-  SCAMD_HIP_CHECK(hipMemcpyAsync(hr, rc0, sizeof(int) * (MAX_CLASSES + CTR_STRIDE * n_cls), hipMemcpyDeviceToHost, cx.s));
-  SCAMD_HIP_CHECK(hipMemcpyAsync(&herr, b.counters + 7, sizeof(int), hipMemcpyDeviceToHost, cx.s));
+  LD_FETCH(hr, rc0, sizeof(int) * (MAX_CLASSES + CTR_STRIDE * n_cls), cx.s);
+  LD_FETCH(&herr, b.counters + 7, sizeof(int), cx.s);
   LD_SYNC(cx.s);
   SCAMD_REQUIRE(herr == 0, SCAMD_EINTERNAL, "leiden: hub table overflow (refinement)");
   for (int c = 0; c < n_cls; ++c) {
@@ -3050,7 +3059,7 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   int rc = exclusive_scan_i32_i64(b.flag, g.n, b.newid, b.scan_tmp, cx.s);
   if (rc != SCAMD_OK) return rc;
   int64_t nn = 0;
-  SCAMD_HIP_CHECK(hipMemcpyAsync(&nn, b.newid + g.n, sizeof(int64_t), hipMemcpyDeviceToHost, cx.s));
+  LD_FETCH(&nn, b.newid + g.n, sizeof(int64_t), cx.s);
   LD_SYNC(cx.s);
   *n_new = (int)nn;
   if (nn == g.n) return SCAMD_OK;
@@ -3082,7 +3091,7 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   // lengths are read back first: an empty launch of these shapes costs 40 / 140 us (768 x 512 / 512 x 1024 threads with
   // 48 / 96 KB of LDS each), a host round trip 15 -- and most levels of a clustered graph have no such rows at all.
   int htier[3] = {0, 0, 0};  // rows of the 512-thread tier, of the 1024-thread tier, split rows
-  SCAMD_HIP_CHECK(hipMemcpyAsync(htier, b.counters + 4, sizeof(int) * 3, hipMemcpyDeviceToHost, cx.s));
+  LD_FETCH(htier, b.counters + 4, sizeof(int) * 3, cx.s);
   LD_SYNC(cx.s);
   if (leiden_debug() && (htier[0] || htier[1]))
     fprintf(stderr, "[leiden] aggregate n=%d -> %d: %d rows through the workgroup tier, %d through the 8192-slot tier\n", g.n, inn,
@@ -3129,12 +3138,12 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   int64_t nnz_new = 0;
   int dstat[4] = {0, 0, 0, 0};
   int agg_err = 0;
-  SCAMD_HIP_CHECK(hipMemcpyAsync(&agg_err, b.counters + 7, sizeof(int), hipMemcpyDeviceToHost, cx.s));
+  LD_FETCH(&agg_err, b.counters + 7, sizeof(int), cx.s);
   SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 8, 0, sizeof(int) * 4, cx.s));
   hipLaunchKernelGGL(ld_degstats_kernel, GRIDK(nn), 0, cx.s, cb.indptr, (int)nn, b.counters + 8);
   SCAMD_LAUNCH_CHECK();
-  SCAMD_HIP_CHECK(hipMemcpyAsync(dstat, b.counters + 8, sizeof(int) * 4, hipMemcpyDeviceToHost, cx.s));
-  SCAMD_HIP_CHECK(hipMemcpyAsync(&nnz_new, cb.indptr + nn, sizeof(int64_t), hipMemcpyDeviceToHost, cx.s));
+  LD_FETCH(dstat, b.counters + 8, sizeof(int) * 4, cx.s);
+  LD_FETCH(&nnz_new, cb.indptr + nn, sizeof(int64_t), cx.s);
   if (cx.cpm) {  // sizes add up over the members; strengths are the row sums of the coarse graph
     SCAMD_HIP_CHECK(hipMemsetAsync(cb.k, 0, sizeof(long long) * nn, cx.s));
     hipLaunchKernelGGL(ld_agg_nodeweight_kernel, GRID1(g.n), 0, cx.s, g.n, (const int*)b.cid, g.k, cb.k);
@@ -3192,7 +3201,7 @@ static int small_levels(LeidenCtx& cx, const LevelGraph& g, int level) {
   SCAMD_LAUNCH_CHECK();
   if (leiden_debug()) {
     int h[4];
-    SCAMD_HIP_CHECK(hipMemcpyAsync(h, b.counters + 12, sizeof(h), hipMemcpyDeviceToHost, cx.s));
+    LD_FETCH(h, b.counters + 12, sizeof(h), cx.s);
     LD_SYNC(cx.s);
     fprintf(stderr, "[leiden] small levels from level %d (n=%d nnz=%lld): %d levels, %d moves, %d merges -> n=%d\n", level, g.n,
             (long long)g.nnz, h[0], h[1], h[2], h[3]);
@@ -3255,7 +3264,7 @@ static int renumber(LeidenCtx& cx, int n, int* n_comm) {
   int rc = exclusive_scan_i32_i64(b.flag, n, b.newid, b.scan_tmp, cx.s);
   if (rc != SCAMD_OK) return rc;
   int64_t nc = 0;
-  SCAMD_HIP_CHECK(hipMemcpyAsync(&nc, b.newid + n, sizeof(int64_t), hipMemcpyDeviceToHost, cx.s));
+  LD_FETCH(&nc, b.newid + n, sizeof(int64_t), cx.s);
   LD_SYNC(cx.s);
   hipLaunchKernelGGL(ld_commkeys_kernel, GRID1(n), 0, cx.s, n, b.csize, b.minmember, b.newid, b.ckeys, b.cids);
   SCAMD_LAUNCH_CHECK();
@@ -3289,8 +3298,8 @@ static int setup_level0(LeidenCtx& cx, const int64_t* indptr, const int32_t* ind
   SCAMD_LAUNCH_CHECK();
   unsigned long long tot = 0;
   int dstat[4] = {0, 0, 0, 0};
-  SCAMD_HIP_CHECK(hipMemcpyAsync(&tot, b.total, sizeof(tot), hipMemcpyDeviceToHost, cx.s));
-  SCAMD_HIP_CHECK(hipMemcpyAsync(dstat, b.counters + 8, sizeof(int) * 4, hipMemcpyDeviceToHost, cx.s));
+  LD_FETCH(&tot, b.total, sizeof(tot), cx.s);
+  LD_FETCH(dstat, b.counters + 8, sizeof(int) * 4, cx.s);
   LD_SYNC(cx.s);
   cx.m2 = (double)tot;
   g0->max_deg = dstat[0];
@@ -3437,7 +3446,7 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
     hipLaunchKernelGGL(ld_copy_membership_kernel, GRID1(n), 0, cx.s, (int)n, initial_membership, b.memb, b.counters + 7);
     SCAMD_LAUNCH_CHECK();
     int bad = 0;
-    SCAMD_HIP_CHECK(hipMemcpyAsync(&bad, b.counters + 7, sizeof(int), hipMemcpyDeviceToHost, cx.s));
+    LD_FETCH(&bad, b.counters + 7, sizeof(int), cx.s);
     LD_SYNC(cx.s);
     SCAMD_REQUIRE(bad == 0, SCAMD_EINVAL, "leiden: initial membership ids must lie in [0, n)");
   } else {
