@@ -61,9 +61,9 @@ inline int ceil_div(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) 
 // copies + hipStreamSynchronize costs 39.6 us, one copy 25.9 us; into PINNED memory 17.8 / 15.3 us
 // (tools/probes/host_roundtrip_probe.hip, MI355X).  `fetch` queues a copy into a per-thread pinned page and remembers where
 // the caller wants the bytes; `sync` drains the stream once and hands them out.  The page is allocated on first use and kept
-// for the life of the thread (4 KiB).
+// for the life of the thread (8 KiB).
 struct HostReadback {
-  static constexpr size_t CAP = 4096;
+  static constexpr size_t CAP = 8192;
   static constexpr int MAX_ITEMS = 8;
   struct Item {
     void* dst;
@@ -97,5 +97,32 @@ inline HostReadback& host_readback() {
   static thread_local HostReadback rb;
   return rb;
 }
+// declared by the host function (or its context) whose locals are the destinations of split fetches: nothing queued survives
+// the function, whichever way it returns -- a later hand-out would write to its dead stack
+struct HostReadbackScope {
+  HostReadbackScope() { host_readback().reset(); }
+  ~HostReadbackScope() { host_readback().reset(); }
+};
+
+// fetch + hand-out for code that returns SCAMD_* codes (every host function of the library).  SCAMD_READBACK_NOW = one value
+// read at once (it also drops whatever an earlier call's error path may have left queued -- the hand-out would write to
+// that call's dead stack); the split form is for values fetched at different points and handed out by one synchronisation.
+#define SCAMD_READBACK(dst, src, bytes, stream)                                               \
+  do {                                                                                        \
+    const int rc_rb_ = ::scamd::host_readback().fetch((dst), (src), (bytes), (stream));       \
+    if (rc_rb_ != SCAMD_OK) return rc_rb_;                                                    \
+  } while (0)
+#define SCAMD_READBACK_NOW(dst, src, bytes, stream)                                            \
+  do {                                                                                        \
+    ::scamd::host_readback().reset();                                                         \
+    int rc_rb_ = ::scamd::host_readback().fetch((dst), (src), (bytes), (stream));             \
+    if (rc_rb_ == SCAMD_OK) rc_rb_ = ::scamd::host_readback().sync(stream);                   \
+    if (rc_rb_ != SCAMD_OK) return rc_rb_;                                                    \
+  } while (0)
+#define SCAMD_READBACK_SYNC(stream)                                  \
+  do {                                                               \
+    const int rc_rb_ = ::scamd::host_readback().sync(stream);        \
+    if (rc_rb_ != SCAMD_OK) return rc_rb_;                           \
+  } while (0)
 
 }  // namespace scamd

@@ -574,8 +574,7 @@ static int cholqr2(DenseCtx& cx, double* zin, double* tmp, double* zout) {
       SCAMD_HIP_CHECK(hipMemsetAsync(cx.d.flags, 0, sizeof(int), cx.s));
       hipLaunchKernelGGL(chol_factor_kernel, dim3(1), dim3(1024), CHOL_LDS, cx.s, cx.d.gm, b, shift, cx.d.s, cx.d.flags);
       SCAMD_LAUNCH_CHECK();
-      SCAMD_HIP_CHECK(hipMemcpyAsync(&bad, cx.d.flags, sizeof(int), hipMemcpyDeviceToHost, cx.s));
-      SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+      SCAMD_READBACK_NOW(&bad, cx.d.flags, sizeof(int), cx.s);
       if (!bad) break;
       SCAMD_REQUIRE(attempt < 4 && shifted_rounds < 8, SCAMD_EUNSUPPORTED,
                     "dense eigensolver: CholeskyQR gave up on the block (%d shifted rounds, attempt %d)", shifted_rounds,
@@ -615,7 +614,7 @@ static int rayleigh_ritz(DenseCtx& cx, const double* z, double* az, double* v, d
   SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(panel_small_kernel, dim3((g + 7) / 8), dim3(256), 0, cx.s, az, cx.d.y, g, b, b, av);
   SCAMD_LAUNCH_CHECK();
-  SCAMD_HIP_CHECK(hipMemcpyAsync(h_theta, cx.d.theta, sizeof(double) * b, hipMemcpyDeviceToHost, cx.s));
+  SCAMD_READBACK(h_theta, cx.d.theta, sizeof(double) * b, cx.s);  // (handed out by the caller's next synchronisation)
   return SCAMD_OK;
 }
 
@@ -627,6 +626,7 @@ static int dense_topk(DenseCtx& cx, int k, unsigned int seed, double tol, int* n
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHOL_LDS));
   SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_eigh_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)JAC_LDS));
+  HostReadbackScope readback_scope;  // (h_theta below is the destination of a fetch handed out one synchronisation later)
   std::vector<double> h_theta(b);
   double h_resid = INFINITY;
   double *z = d.z[0], *tmp = d.z[1], *az = d.z[2], *v = d.z[3], *av = d.z[4], *y0 = d.z[5], *y1 = d.z[6];
@@ -639,7 +639,7 @@ static int dense_topk(DenseCtx& cx, int k, unsigned int seed, double tol, int* n
     if (rc != SCAMD_OK) return rc;
     rc = rayleigh_ritz(cx, y0, az, v, av, h_theta.data());
     if (rc != SCAMD_OK) return rc;
-    SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+    SCAMD_READBACK_SYNC(cx.s);
     *n_outer_out = 0;
     *resid_out = 0.0;
     return SCAMD_OK;
@@ -693,8 +693,7 @@ static int dense_topk(DenseCtx& cx, int k, unsigned int seed, double tol, int* n
   hipLaunchKernelGGL(rq_minmax_kernel, dim3(1), dim3(1024), 0, cx.s, v, av, g, b, d.resid);
   SCAMD_LAUNCH_CHECK();
   double h_rq[3] = {0.0, 0.0, 0.0};
-  SCAMD_HIP_CHECK(hipMemcpyAsync(h_rq, d.resid, sizeof(double) * 3, hipMemcpyDeviceToHost, cx.s));
-  SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
+  SCAMD_READBACK_NOW(h_rq, d.resid, sizeof(double) * 3, cx.s);
   if (h_rq[2] > h_rq[1] && h_rq[1] > 0.0) {
     rc = filter(v, av, h_rq[1], h_rq[2], 8);
     if (rc != SCAMD_OK) return rc;
@@ -713,8 +712,8 @@ static int dense_topk(DenseCtx& cx, int k, unsigned int seed, double tol, int* n
   for (outer = 1;; ++outer) {
     hipLaunchKernelGGL(residual_kernel, dim3(1), dim3(1024), 0, cx.s, v, av, d.theta, g, b, k, d.resid);
     SCAMD_LAUNCH_CHECK();
-    SCAMD_HIP_CHECK(hipMemcpyAsync(&h_resid, d.resid, sizeof(double), hipMemcpyDeviceToHost, cx.s));
-    SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));  // (also completes the copy of theta)
+    SCAMD_READBACK(&h_resid, d.resid, sizeof(double), cx.s);
+    SCAMD_READBACK_SYNC(cx.s);  // (also completes the copy of theta)
     if (dbg)
       fprintf(stderr, "[dense] outer %d: residual %.3e, theta[0] %.6e theta[k-1] %.6e theta[b-1] %.6e, gemms %d, chol retries %d\n",
               outer, h_resid, h_theta[0], h_theta[k - 1], h_theta[b - 1], cx.n_gemm, cx.n_chol_retry);

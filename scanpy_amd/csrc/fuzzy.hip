@@ -656,8 +656,7 @@ static int symmetrise(const FuzzyBuffers& b, const int32_t* knn_idx, int64_t n, 
                      out_indices, out_data);
   SCAMD_LAUNCH_CHECK();
   int64_t nnz = 0;
-  SCAMD_HIP_CHECK(hipMemcpyAsync(&nnz, out_indptr + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-  SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+  SCAMD_READBACK_NOW(&nnz, out_indptr + n, sizeof(int64_t), s);
   *nnz_host = nnz;
   return SCAMD_OK;
 }
@@ -818,8 +817,7 @@ extern "C" int scamd_fuzzy_merge_rows_f32(const int32_t* knn_idx, const float* w
   int rc = exclusive_scan_i32_i64(rowcnt, n_local, out_indptr, scan_tmp, s);
   if (rc != SCAMD_OK) return rc;
   int64_t nnz = 0;
-  SCAMD_HIP_CHECK(hipMemcpyAsync(&nnz, out_indptr + n_local, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-  SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+  SCAMD_READBACK_NOW(&nnz, out_indptr + n_local, sizeof(int64_t), s);
   SCAMD_REQUIRE(nnz <= cap, SCAMD_ECAPACITY, "fuzzy_merge: %lld entries exceed the capacity %lld", (long long)nnz,
                 (long long)cap);
   hipLaunchKernelGGL(fss_merge_fill_kernel, dim3(ceil_div(n_local, 128)), dim3(128), 0, s, knn_idx, w, n_local, k,

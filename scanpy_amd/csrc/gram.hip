@@ -366,8 +366,7 @@ extern "C" int scamd_csr_gram_f32(const int64_t* indptr, const int32_t* indices,
       SCAMD_LAUNCH_CHECK();
     }
     unsigned int bits = 0;
-    SCAMD_HIP_CHECK(hipMemcpyAsync(&bits, mx, 4, hipMemcpyDeviceToHost, s));
-    SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+    SCAMD_READBACK_NOW(&bits, mx, 4, s);
     memcpy(absmax_host, &bits, 4);
     if (!gram) return SCAMD_OK;
   }

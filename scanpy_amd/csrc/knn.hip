@@ -2748,8 +2748,7 @@ static int run_ivf_tier2(const KnnPlan& p, const KnnBuffers& b, const float* x, 
   SCAMD_LAUNCH_CHECK();
   T2_DBG(__LINE__);
   std::vector<int> h_cnt(nc), h_slot_off(nc), h_block_cell;
-  SCAMD_HIP_CHECK(hipMemcpyAsync(h_cnt.data(), cnt2, sizeof(int) * nc, hipMemcpyDeviceToHost, s));
-  SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+  SCAMD_READBACK_NOW(h_cnt.data(), cnt2, sizeof(int) * nc, s);
   int64_t slots = 0;
   for (int c = 0; c < nc; ++c) {
     h_slot_off[c] = (int)slots;
@@ -2821,8 +2820,7 @@ static int run_ivf_tier2(const KnnPlan& p, const KnnBuffers& b, const float* x, 
   }
   SCAMD_LAUNCH_CHECK();
   T2_DBG(__LINE__);
-  SCAMD_HIP_CHECK(hipMemcpyAsync(n_flag2_host, ctr2, sizeof(int), hipMemcpyDeviceToHost, s));
-  SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+  SCAMD_READBACK_NOW(n_flag2_host, ctr2, sizeof(int), s);
   return SCAMD_OK;
 }
 
@@ -2961,8 +2959,7 @@ static int knn_l2_impl(const float* x, int64_t n, int d, int64_t ld_x, int64_t q
     SCAMD_LAUNCH_CHECK();
   }
   int h_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  SCAMD_HIP_CHECK(hipMemcpyAsync(h_counters, b.counters, 32, hipMemcpyDeviceToHost, s));
-  SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+  SCAMD_READBACK_NOW(h_counters, b.counters, 32, s);
   {
     float ms = -1.f;
     if (hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) ms = -1.f;
@@ -3026,8 +3023,7 @@ static int knn_l2_impl(const float* x, int64_t n, int d, int64_t ld_x, int64_t q
                          b.scratch_i, b.fb_counts, out_idx, out_dist, b.kth_d2, retry, b.counters + 1);
       SCAMD_LAUNCH_CHECK();
     }
-    SCAMD_HIP_CHECK(hipMemcpyAsync(h_counters, b.counters, 16, hipMemcpyDeviceToHost, s));
-    SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+    SCAMD_READBACK_NOW(h_counters, b.counters, 16, s);
     n_todo = h_counters[1];
     todo = retry;
   }

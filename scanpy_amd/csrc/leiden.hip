@@ -2537,7 +2537,7 @@ constexpr int HUB_GRID = 512;
 constexpr size_t HUB_LDS = (size_t)BHUB_SLOTS * 12;
 
 struct LeidenCtx {
-  LeidenCtx() { host_readback().reset(); }  // (read-backs an earlier call's error path left queued are dropped)
+  HostReadbackScope readback_scope;  // (the read-backs' destinations are locals of the functions this context is passed to)
   hipStream_t s;
   LeidenBuffers b;
   double gamma;
