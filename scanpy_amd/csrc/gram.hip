@@ -380,6 +380,19 @@ extern "C" int scamd_csr_gram_f32(const int64_t* indptr, const int32_t* indices,
   const int npair = ntile * (ntile + 1) / 2;
   // ~8 items per CU: enough to balance, few enough that the 128 KB flushes stay negligible
   int n_chunks = std::max(1, std::min<int>((int)((n + 4095) / 4096), (256 * 8 + npair - 1) / npair));
+  {
+    // one workgroup per CU (the 128 KB tile), equal items: the launch runs in rounds of 256 workgroups, and a last round that
+    // is half empty costs half a round -- 136 pairs x 16 chunks = 8.5 rounds: 6.90 ms, x 15 = 7.97 rounds: 6.57 ms
+    // (profiles/r05v_gram_chunks.log; 17 chunks = 9.03 rounds: 7.15 ms).  The count near the default that wastes least:
+    const int hi = (int)std::min<int64_t>((n + 4095) / 4096, n_chunks + 4);
+    double best = 1e9;
+    for (int c = std::max(1, n_chunks - 4); c <= hi; ++c) {
+      const int64_t items = (int64_t)npair * c, rounds = (items + 255) / 256;
+      const double waste = (double)(rounds * 256) / (double)items;
+      if (waste < best - 1e-9) best = waste, n_chunks = c;
+    }
+  }
+  if (const char* e = getenv("SCAMD_GRAM_CHUNKS")) n_chunks = std::max(1, std::min<int>((int)((n + 255) / 256), atoi(e)));  // (A/B knob)
   const int rows_per_chunk = (int)((n + n_chunks - 1) / n_chunks);
   n_chunks = (int)((n + rows_per_chunk - 1) / rows_per_chunk);
   const size_t lds = (size_t)(GT * GT + GT) * sizeof(unsigned long long);
