@@ -2574,6 +2574,9 @@ struct LeidenCtx {
   int agg_wave_work = 2048;
   int agg_mid_work = 65536;
   int hub_try_probes = HUB_TRY_PROBES;  // 0: no optimistic single pass over multi-pass rows (SCAMD_LEIDEN_HUB_TRY_PROBES; tests)
+  // sweeps of the local moving that follow a sweep with at most `small_sweep_act` active vertices use `small_sweep_classes`
+  // class sub-rounds instead of the level's (0: off) -- see local_moving
+  int small_sweep_act = 0, small_sweep_classes = 2;
 };
 
 static bool g_leiden_debug = false;  // SCAMD_LEIDEN_DEBUG=1, read at every entry (tools switch it inside one process)
@@ -2673,10 +2676,12 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
   SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));  // [0] moved, [1] blocked (cumulative), [7] error
   const int lanes = level_lanes(g);
   const int thr_mid = lanes == 16 ? (int)(WH_SLOTS / 4 * 3 / 4) : (lanes == 32 ? (int)(WH_SLOTS / 2 * 3 / 4) : -1);
-  const int n_cls = lm_classes(cx, g.n);
+  const int n_cls_level = lm_classes(cx, g.n);
+  int n_act_prev = g.n;
   int* sw = b.rcounters;  // [0, MAX_CLASSES): class list lengths of the sweep; then one block per sub-round: hub / overflow counts
   int moved_before = 0, quiet = 0, moved_prev2 = 0;
   for (int sweep = 0; sweep < MAX_LM_SWEEPS; ++sweep) {
+    const int n_cls = (sweep > 0 && n_act_prev <= cx.small_sweep_act) ? std::min(n_cls_level, cx.small_sweep_classes) : n_cls_level;
     SCAMD_HIP_CHECK(hipMemsetAsync(sw, 0, sizeof(int) * (MAX_CLASSES + CTR_STRIDE * n_cls), cx.s));
     const unsigned int salt = hash32(cx.seed + 0x85EBCA77u * (unsigned int)(sweep + 1) + 0xC2B2AE3Du * (unsigned int)cx.iter);
     hipLaunchKernelGGL(ld_compact_cls_kernel, dim3((unsigned)ceil_div(g.n, 1024)), dim3(1024), 0, cx.s, g.n,
@@ -2689,6 +2694,7 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
     SCAMD_REQUIRE(ht[7] == 0, SCAMD_EINTERNAL, "leiden: hub table overflow (local moving)");
     int n_act = 0;
     for (int c = 0; c < n_cls; ++c) n_act += hc[c];
+    n_act_prev = n_act;
     const int moved_last = ht[0] - moved_before;  // moves of the previous sweep
     moved_before = ht[0];
     *total_moves = ht[0];
@@ -3417,6 +3423,8 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_WAVE_MAX")) cx.agg_wave_max = std::min(atoi(e), (int)WH_MAX_DEG);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_MAX")) cx.agg_mid_max = std::min(atoi(e), (int)AGG_MID_MAX);
   if (const char* e = getenv("SCAMD_LEIDEN_HUB_TRY_PROBES")) cx.hub_try_probes = std::max(0, atoi(e));
+  if (const char* e = getenv("SCAMD_LEIDEN_SMALL_SWEEP_ACT")) cx.small_sweep_act = std::max(0, atoi(e));
+  if (const char* e = getenv("SCAMD_LEIDEN_SMALL_SWEEP_CLASSES")) cx.small_sweep_classes = std::max(1, std::min(atoi(e), (int)MAX_CLASSES));
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_WAVE_WORK")) cx.agg_wave_work = std::max(1, atoi(e));
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_WORK")) cx.agg_mid_work = std::max(1, atoi(e));
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_MID_GRID")) cx.agg_mid_grid = std::max(1, atoi(e));
