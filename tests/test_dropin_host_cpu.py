@@ -269,6 +269,24 @@ def test_clustering_custom_key_and_objective(sc, pbmc68k):
             sc.tl.leiden(adata, objective_function="CPM")  # default flavor leidenalg: takes a partition class instead
 
 
+def test_partition_type_resolution():
+    """`partition_type` of the leidenalg flavor (src/scanpy/tools/_leiden.py:107-110, 174-186) -> (objective, resolution):
+    classes matched by name (leidenalg is absent here; a user's `leidenalg.CPMVertexPartition` arrives as the class),
+    `resolution=None` = the class's default, a class without a resolution parameter refuses one as its constructor would"""
+    from scanpy_amd.tools._leiden import _resolve_partition_type as r
+
+    cls = lambda name: type(name, (), {})  # noqa: E731
+    assert r(None, 0.7) == ("modularity", 0.7) and r(None, None) == ("modularity", 1.0)
+    assert r(cls("RBConfigurationVertexPartition"), 2.0) == ("modularity", 2.0)
+    assert r("CPMVertexPartition", 0.01) == ("cpm", 0.01) and r(cls("CPMVertexPartition"), None) == ("cpm", 1.0)
+    assert r(cls("ModularityVertexPartition"), None) == ("modularity", 1.0)
+    with pytest.raises(TypeError, match="resolution_parameter"):
+        r(cls("ModularityVertexPartition"), 1.0)
+    for name in ("SignificanceVertexPartition", "SurpriseVertexPartition", "RBERVertexPartition"):
+        with pytest.raises(NotImplementedError, match=name):
+            r(cls(name), 1.0)
+
+
 # ---- tests/test_neighbors_key_added.py semantics ------------------------------------------------------------------------
 @pytest.mark.parametrize("rng_arg", ["rng", "random_state"])
 def test_neighbors_key_added_and_downstream_keys(sc, pbmc68k, rng_arg):
