@@ -772,7 +772,7 @@ __device__ __forceinline__ void knn_select_reg_block(const int blk, const float*
       const int vb = __builtin_amdgcn_readlane(__float_as_int(sc), 32 * h + s);
       const int lastb = __builtin_amdgcn_readlane(__float_as_int(key[r]), 32 * h + 31);
       // (a survivor of a threshold one sub-tile old may no longer beat the list's largest entry)
-      if (key_order(vb) < key_order(lastb)) {
+      if (__builtin_expect(key_order(vb) < key_order(lastb), 1)) {  // (the likely path laid out in line: a taken branch costs as much as four of these instructions)
         if (lane == 0) SCAMD_EMU_COUNT(1, 1);            // [1] insertions
         const int slot = lastb & KEY_SLOT_MASK;          // the evicted entry's slot is reused
         const float kv = __int_as_float((vb & ~KEY_SLOT_MASK) | slot);
