@@ -906,6 +906,10 @@ def main() -> None:
                 # lists out (32 ids + threshold per query)
                 "algorithmic_bytes_per_launch": float(n) * (272.0 if engine == 1 else 240.0) + float(n_query) * (32 * 4 + 4),
                 "launch_ms": sel,
+                # (`launch_ms` is the MEAN over the timed steps, as the contract asks; on a shared box one disturbed step
+                # moves it -- the spread of the same launches beside it)
+                "launch_ms_min_median_max": ([min(select_ms), sorted(select_ms)[len(select_ms) // 2], max(select_ms)]
+                                             if select_ms else None),
                 "algorithmic_flop_per_launch": flops,
                 "flop_per_pair": flop_per_pair,
                 # the same launch priced as rounds 1-2 priced the float32 engine: 2 * d flop per pair
