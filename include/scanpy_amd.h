@@ -281,6 +281,18 @@ int scamd_leiden_csr_ex_f32(const int64_t* indptr, const int32_t* indices, const
                             double beta, uint64_t seed, int objective, const int32_t* initial_membership,
                             int32_t* membership, double* modularity_host, int32_t* n_communities_host,
                             void* workspace, size_t workspace_bytes, scamd_stream_t stream);
+/* ... CPM with the caller's vertex weights -- igraph `community_leiden(objective_function='CPM', node_weights=...)`, which
+ * `sc.tl.leiden(flavor='igraph', objective_function='CPM', node_weights=...)` reaches through **clustering_args
+ * (src/scanpy/tools/_leiden.py:66, 188-196): a community pays resolution * (sum of its members' weights)^2.
+ * node_weights: device pointer, n floats in [0, 1e6] (SCAMD_EINVAL otherwise; held in fixed point, 16 fractional bits) or
+ * NULL (every vertex weighs 1: scamd_leiden_csr_ex_f32).  objective 0 (modularity: the vertex weights are the strengths)
+ * takes NULL only (SCAMD_EUNSUPPORTED). */
+int scamd_leiden_csr_nw_f32(const int64_t* indptr, const int32_t* indices, const float* weights,
+                            int64_t n, int64_t nnz, double resolution, int n_iterations,
+                            double beta, uint64_t seed, int objective, const float* node_weights,
+                            const int32_t* initial_membership, int32_t* membership, double* modularity_host,
+                            int32_t* n_communities_host, void* workspace, size_t workspace_bytes,
+                            scamd_stream_t stream);
 /* Statistics of the last scamd_leiden_csr_f32 call on this thread, out[0 .. min(n, 12)):
  *   [0] outer iterations run, [1] kernel launches, [2] blocking host round trips,
  *   [3] full sweeps / [4] rounds / [5] vertices moved by the final polish (n_iterations < 0: strictly monotone

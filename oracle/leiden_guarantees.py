@@ -25,9 +25,10 @@ import numpy as np
 from scipy import sparse
 
 
-def _prep(adj, labels, objective: str = "modularity"):
+def _prep(adj, labels, objective: str = "modularity", node_weights=None):
     """-> (a, lab, nu, norm, onehot, ntot, two_m): vertex weights nu and the divisor of the penalty term -- strengths and 2m for
-    modularity, ones and 1 for CPM (igraph `objective_function='CPM'`: gain of joining D = k_v(D) - g n_v N_D)"""
+    modularity, ones (or igraph's `node_weights`) and 1 for CPM (igraph `objective_function='CPM'`: gain of joining D =
+    k_v(D) - g n_v N_D)"""
     a = sparse.csr_matrix(adj).astype(np.float64)
     a.setdiag(0)  # (the reference's graphs have no self loops; the optimisers ignore them)
     a.eliminate_zeros()
@@ -37,7 +38,7 @@ def _prep(adj, labels, objective: str = "modularity"):
     k = np.asarray(a.sum(axis=1)).ravel()
     two_m = float(k.sum())
     if objective.lower() == "cpm":
-        nu, norm = np.ones(n), 1.0
+        nu, norm = (np.ones(n) if node_weights is None else np.asarray(node_weights, dtype=np.float64)), 1.0
     elif objective.lower() == "modularity":
         nu, norm = k, two_m
     else:
@@ -47,18 +48,18 @@ def _prep(adj, labels, objective: str = "modularity"):
     return a, lab, nu, norm, onehot, ntot, two_m
 
 
-def quality(adj, labels, *, resolution: float = 1.0, objective: str = "modularity") -> float:
+def quality(adj, labels, *, resolution: float = 1.0, objective: str = "modularity", node_weights=None) -> float:
     """(1 / 2m) sum_C [ e_C - g N_C^2 / norm ]: the modularity, or igraph's CPM quality, of a partition"""
-    a, lab, nu, norm, onehot, ntot, two_m = _prep(adj, labels, objective)
+    a, lab, nu, norm, onehot, ntot, two_m = _prep(adj, labels, objective, node_weights)
     e = np.asarray((onehot.T @ a @ onehot).diagonal()).ravel()
     return float((e - resolution * ntot * ntot / norm).sum() / two_m)
 
 
-def improving_moves(adj, labels, *, resolution: float = 1.0, tol: float = 1e-12, objective: str = "modularity"):
+def improving_moves(adj, labels, *, resolution: float = 1.0, tol: float = 1e-12, objective: str = "modularity", node_weights=None):
     """vertices that a single move to a neighbouring community (or to a community of their own) would improve.
 
     -> dict(count, fraction, max_gain (in units of Q), worst_vertex)"""
-    a, lab, k, norm, onehot, ktot, two_m = _prep(adj, labels, objective)
+    a, lab, k, norm, onehot, ktot, two_m = _prep(adj, labels, objective, node_weights)
     n = a.shape[0]
     g = resolution
     w = (a @ onehot).tocsr()  # w[v, D] = k_v(D), stored for the communities v has an edge to
@@ -81,11 +82,11 @@ def improving_moves(adj, labels, *, resolution: float = 1.0, tol: float = 1e-12,
             "worst_vertex": worst}
 
 
-def mergeable_pairs(adj, labels, *, resolution: float = 1.0, tol: float = 1e-12, objective: str = "modularity"):
+def mergeable_pairs(adj, labels, *, resolution: float = 1.0, tol: float = 1e-12, objective: str = "modularity", node_weights=None):
     """pairs of communities whose merge would improve the quality (g-separation violated).
 
     -> dict(count, max_gain (in units of Q), n_communities)"""
-    a, lab, k, norm, onehot, ktot, two_m = _prep(adj, labels, objective)
+    a, lab, k, norm, onehot, ktot, two_m = _prep(adj, labels, objective, node_weights)
     e = (onehot.T @ a @ onehot).tocoo()  # E(C, D) for C != D (each unordered pair twice)
     off = e.row < e.col
     gain = (e.data[off] - resolution * ktot[e.row[off]] * ktot[e.col[off]] / norm) / (two_m / 2.0)

@@ -397,11 +397,13 @@ def colsum(y: torch.Tensor) -> torch.Tensor:
 
 def leiden(indptr: torch.Tensor, indices: torch.Tensor, weights: torch.Tensor, n: int, *, resolution: float = 1.0,
            n_iterations: int = -1, beta: float = 0.01, seed: int = 0, initial_membership: torch.Tensor | None = None,
-           objective: str = "modularity"):
+           objective: str = "modularity", node_weights: torch.Tensor | None = None):
     """Symmetric CSR graph on device -> (membership int32 [n] on device, modularity, n_communities).
     `initial_membership` (int32 [n] on the device, ids in [0, n)): start from that partition instead of singletons.
     `objective`: 'modularity' (resolution normalised by 2m, vertex weight = strength) or 'cpm' (igraph's CPM: vertex weight
-    1, resolution as given; the returned float is then the resolution-1 modularity of the partition)."""
+    1, resolution as given; the returned float is then the resolution-1 modularity of the partition).
+    `node_weights` (float32 [n] in [0, 1e6], CPM only): igraph's `node_weights` -- a community pays resolution x (sum of its
+    members' weights)^2."""
     dev = require_gpu()
     lib = _lib.load()
     indptr = indptr.to(torch.int64).contiguous()
@@ -419,6 +421,17 @@ def leiden(indptr: torch.Tensor, indices: torch.Tensor, weights: torch.Tensor, n
             raise ValueError(f"initial_membership has {init.numel()} entries for {n} vertices")
     if objective.lower() not in ("modularity", "cpm"):
         raise ValueError(f"objective={objective!r}: 'modularity' or 'cpm'")
+    if node_weights is not None:
+        if objective.lower() != "cpm":
+            raise NotImplementedError("node_weights with the modularity objective (its vertex weights are the strengths)")
+        nw = node_weights.to(device=dev, dtype=torch.float32).contiguous()
+        if nw.numel() != n:
+            raise ValueError(f"node_weights has {nw.numel()} entries for {n} vertices")
+        rc = lib.scamd_leiden_csr_nw_f32(ptr(indptr), ptr(indices), ptr(weights), n, nnz, float(resolution),
+                                         int(n_iterations), float(beta), int(seed) & (2**64 - 1), 1, ptr(nw), ptr(init),
+                                         ptr(memb), C.byref(q), C.byref(nc), ptr(ws), wsz, stream_ptr())
+        _check(rc, "scamd_leiden_csr_nw_f32")
+        return memb, float(q.value), int(nc.value)
     if objective.lower() == "cpm":
         rc = lib.scamd_leiden_csr_ex_f32(ptr(indptr), ptr(indices), ptr(weights), n, nnz, float(resolution),
                                          int(n_iterations), float(beta), int(seed) & (2**64 - 1), 1, ptr(init), ptr(memb),

@@ -55,6 +55,7 @@ SIGNATURES = {
     "scamd_leiden_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _f64, _i32, _f64, _u64, _vp, C.POINTER(_f64), C.POINTER(_i32), _vp, _sz, _vp]),
     "scamd_leiden_csr_init_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _f64, _i32, _f64, _u64, _vp, _vp, C.POINTER(_f64), C.POINTER(_i32), _vp, _sz, _vp]),
     "scamd_leiden_csr_ex_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _f64, _i32, _f64, _u64, _i32, _vp, _vp, C.POINTER(_f64), C.POINTER(_i32), _vp, _sz, _vp]),
+    "scamd_leiden_csr_nw_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _f64, _i32, _f64, _u64, _i32, _vp, _vp, _vp, C.POINTER(_f64), C.POINTER(_i32), _vp, _sz, _vp]),
     "scamd_leiden_last_stats": (None, [C.POINTER(_i32), _i32]),
     "scamd_leiden_debug_split_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, C.POINTER(_i32), _vp, _sz, _vp]),
     "scamd_modularity_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _f64, C.POINTER(_f64), _vp, _sz, _vp]),

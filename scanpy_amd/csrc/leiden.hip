@@ -149,6 +149,20 @@ __global__ void ld_iota_kernel(int* __restrict__ a, int n) {
   if (i < n) a[i] = i;
 }
 
+// CPM with the caller's vertex weights (igraph `node_weights`): fixed point with 16 fractional bits; a negative or non-finite
+// weight raises the flag (the host turns it into SCAMD_EINVAL)
+constexpr double NODE_WEIGHT_SCALE = 65536.0;
+__global__ void ld_nodeweight_quantize_kernel(const float* __restrict__ w, int n, long long* __restrict__ k, int* __restrict__ err) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  const float x = w[v];
+  if (!(x >= 0.f) || !(x <= 1.0e6f)) {  // (the totals are int64 sums of 2^16 x: 1e6 x 1e8 vertices still fit)
+    atomicOr(err, 1);
+    k[v] = 0ll;
+    return;
+  }
+  k[v] = llrint((double)x * NODE_WEIGHT_SCALE);
+}
 __global__ void ld_fill_i64_kernel(long long* __restrict__ a, int n, long long v) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] = v;
@@ -2547,7 +2561,11 @@ struct LeidenCtx {
   // levels), resolution not normalised: w(v, C) - gamma n_v N_C.  Every kernel takes "the vertex weights" and "g": the two
   // objectives differ only in what the host hands them (weights are 2^32 fixed point: g carries the scale).
   bool cpm = false;
-  double gscale() const { return cpm ? gamma * WSCALE : gamma / m2; }
+  // CPM vertex weights: ones (nw_scale 1), or the caller's in fixed point (nw_scale = NODE_WEIGHT_SCALE: a power of two, so
+  // unit weights handed in as an array give bit-identical gains)
+  const float* node_weights = nullptr;
+  double nw_scale = 1.0;
+  double gscale() const { return cpm ? gamma * WSCALE / (nw_scale * nw_scale) : gamma / m2; }
   double inv_beta = 0.0;  // 1 / (beta * 2^32): randomness of the refinement's merge rule (0 = greedy)
   int iter = 0;           // outer iteration: part of the refinement's noise seed
   unsigned int seed;
@@ -2620,7 +2638,7 @@ static int quality(LeidenCtx& cx, const LevelGraph& g, const int* comm, double* 
                        g.indptr, g.indices, g.wq, comm, cx.b.total + 1);
   SCAMD_LAUNCH_CHECK();
   // (CPM: sum of squared community SIZES, unnormalised)
-  hipLaunchKernelGGL(ld_sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(1024), 0, cx.s, g.n, cx.b.Ktot, cx.cpm ? 1.0 : cx.m2, cx.b.dscratch + 4);
+  hipLaunchKernelGGL(ld_sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(1024), 0, cx.s, g.n, cx.b.Ktot, cx.cpm ? cx.nw_scale : cx.m2, cx.b.dscratch + 4);
   SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(ld_sumsq_final_kernel, dim3(1), dim3(1024), 0, cx.s, cx.b.dscratch + 4, cx.b.dscratch);
   SCAMD_LAUNCH_CHECK();
@@ -3318,7 +3336,16 @@ static int setup_level0(LeidenCtx& cx, const int64_t* indptr, const int32_t* ind
   g0->indices = indices;
   g0->wq = b.wq0;
   g0->k = b.k0;
-  if (cx.cpm) {  // the vertex weights of CPM are counts; the strengths above were only needed for 2m
+  if (cx.cpm && cx.node_weights) {
+    SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
+    hipLaunchKernelGGL(ld_nodeweight_quantize_kernel, GRID1(n), 0, cx.s, cx.node_weights, (int)n, b.k0, b.counters + 7);
+    SCAMD_LAUNCH_CHECK();
+    int bad = 0;
+    LD_FETCH(&bad, b.counters + 7, sizeof(int), cx.s);
+    LD_SYNC(cx.s);
+    SCAMD_REQUIRE(bad == 0, SCAMD_EINVAL, "leiden: node weights must lie in [0, 1e6]");
+    cx.nw_scale = NODE_WEIGHT_SCALE;
+  } else if (cx.cpm) {  // the vertex weights of CPM are counts; the strengths above were only needed for 2m
     hipLaunchKernelGGL(ld_fill_i64_kernel, GRID1(n), 0, cx.s, b.k0, (int)n, 1ll);
     SCAMD_LAUNCH_CHECK();
   }
@@ -3353,7 +3380,7 @@ __global__ void ld_copy_membership_kernel(int n, const int* __restrict__ init, i
 static int leiden_run(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n, int64_t nnz,
                       double resolution, int n_iterations, double beta, uint64_t seed, const int32_t* initial_membership,
                       int32_t* membership, double* modularity_host, int32_t* n_communities_host, void* workspace,
-                      size_t workspace_bytes, scamd_stream_t stream, int objective);
+                      size_t workspace_bytes, scamd_stream_t stream, int objective, const float* node_weights = nullptr);
 
 extern "C" int scamd_leiden_csr_f32(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n,
                                     int64_t nnz, double resolution, int n_iterations, double beta, uint64_t seed,
@@ -3391,10 +3418,27 @@ extern "C" int scamd_leiden_csr_ex_f32(const int64_t* indptr, const int32_t* ind
                     modularity_host, n_communities_host, workspace, workspace_bytes, stream, objective);
 }
 
+// ... CPM with the caller's vertex weights: igraph's `community_leiden(objective_function='CPM', node_weights=...)`, reachable
+// through `sc.tl.leiden(flavor='igraph', objective_function='CPM', node_weights=...)` (`**clustering_args`,
+// src/scanpy/tools/_leiden.py:66, 188-196): a community pays gamma (sum of its members' weights)^2.  node_weights: device
+// pointer, n floats in [0, 1e6] (held in fixed point with 16 fractional bits); NULL = every vertex weighs 1.  With the
+// modularity objective the vertex weights ARE the strengths: node_weights must be NULL there.
+extern "C" int scamd_leiden_csr_nw_f32(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n,
+                                       int64_t nnz, double resolution, int n_iterations, double beta, uint64_t seed,
+                                       int objective, const float* node_weights, const int32_t* initial_membership,
+                                       int32_t* membership, double* modularity_host, int32_t* n_communities_host,
+                                       void* workspace, size_t workspace_bytes, scamd_stream_t stream) {
+  SCAMD_REQUIRE(objective == 0 || objective == 1, SCAMD_EINVAL, "leiden: objective %d (0 = modularity, 1 = CPM)", objective);
+  SCAMD_REQUIRE(objective == 1 || node_weights == nullptr, SCAMD_EUNSUPPORTED,
+                "leiden: node weights with the modularity objective (its vertex weights are the strengths)");
+  return leiden_run(indptr, indices, weights, n, nnz, resolution, n_iterations, beta, seed, initial_membership, membership,
+                    modularity_host, n_communities_host, workspace, workspace_bytes, stream, objective, node_weights);
+}
+
 static int leiden_run(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n, int64_t nnz,
                       double resolution, int n_iterations, double beta, uint64_t seed, const int32_t* initial_membership,
                       int32_t* membership, double* modularity_host, int32_t* n_communities_host, void* workspace,
-                      size_t workspace_bytes, scamd_stream_t stream, int objective) {
+                      size_t workspace_bytes, scamd_stream_t stream, int objective, const float* node_weights) {
   SCAMD_REQUIRE(indptr && membership && (nnz == 0 || (indices && weights)), SCAMD_EINVAL, "leiden: null pointer");
   SCAMD_REQUIRE(n >= 1 && n < ((int64_t)1 << 31) && nnz >= 0, SCAMD_EINVAL, "leiden: bad shape n=%lld nnz=%lld",
                 (long long)n, (long long)nnz);
@@ -3416,6 +3460,7 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
   if (const char* e = getenv("SCAMD_LEIDEN_FUSE")) cx.no_fuse = e[0] == '0';
   if (const char* e = getenv("SCAMD_LEIDEN_POLISH")) cx.polish = e[0] != '0';
   cx.cpm = objective == 1;
+  cx.node_weights = node_weights;
   if (cx.cpm) cx.small_levels = false;  // (ld_small_levels_kernel derives its coarse vertex weights from row sums: strengths)
   for (int i = 0; i < 12; ++i) g_ld_stats[i] = 0;
   g_ld_sweep_bytes = 0.0;

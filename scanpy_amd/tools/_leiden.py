@@ -91,7 +91,7 @@ def rename_groups(adata, restrict_key, *, key_added, restrict_categories, restri
 
 
 def leiden_partition(adjacency, *, resolution=1.0, n_iterations=-1, seed=0, use_weights=True, beta=0.01,
-                     initial_membership=None, objective="modularity"):
+                     initial_membership=None, objective="modularity", node_weights=None):
     """Symmetric adjacency (scipy sparse) -> (membership int32 [n], modularity).  `initial_membership`: a partition to
     start from (any non-negative integer labels, one per vertex), as leidenalg / igraph take it."""
     import torch
@@ -118,9 +118,16 @@ def leiden_partition(adjacency, *, resolution=1.0, n_iterations=-1, seed=0, use_
             raise ValueError(f"initial_membership must hold one non-negative integer per vertex ({n})")
         # (the kernel wants ids below n: any labelling is renamed to consecutive ids first)
         init = torch.from_numpy(np.unique(labels, return_inverse=True)[1].astype(np.int32)).to(dev)
+    nw = None
+    if node_weights is not None:
+        # igraph's `node_weights` (a vertex attribute name or a list): one finite non-negative number per vertex
+        arr = np.asarray(node_weights, dtype=np.float64)
+        if arr.shape != (n,) or not np.isfinite(arr).all() or (n and (arr.min() < 0 or arr.max() > 1e6)):
+            raise ValueError(f"node_weights must hold one number in [0, 1e6] per vertex ({n})")
+        nw = torch.from_numpy(arr.astype(np.float32)).to(dev)
     memb, q, _ = _kernels.leiden(indptr, indices, weights, n, resolution=float(resolution),
                                  n_iterations=int(n_iterations), beta=beta, seed=int(seed), initial_membership=init,
-                                 objective=objective)
+                                 objective=objective, node_weights=nw)
     return memb.cpu().numpy(), q
 
 
@@ -154,7 +161,7 @@ def leiden(  # noqa: PLR0913
         raise TypeError("leiden() expects an AnnData-like object")
     flavor = _validate_flavor(flavor, partition_type=partition_type, directed=directed)
     seed, meta_random_state = resolve_seed(rng, random_state)
-    unknown = set(clustering_args) - {"objective_function", "weights", "beta", "initial_membership", "node_weights"}
+    unknown = set(clustering_args) - {"objective_function", "weights", "beta", "initial_membership", "node_weights", "node_sizes"}
     if unknown:
         raise TypeError(f"leiden() got unexpected clustering arguments {sorted(unknown)}")
     objective = str(clustering_args.get("objective_function", "modularity")).lower()
@@ -169,8 +176,20 @@ def leiden(  # noqa: PLR0913
         objective, gamma = _resolve_partition_type(partition_type, resolution)
     else:
         gamma = 1.0 if resolution is None else resolution  # (igraph's default when `resolution` is left out, _leiden.py:193-194)
-    if clustering_args.get("node_weights") is not None:
-        raise NotImplementedError("node_weights are not supported on the MI355X path")
+    # vertex weights of the quality function: igraph calls them `node_weights`, leidenalg's partition classes `node_sizes`
+    mine, other = ("node_sizes", "node_weights") if flavor == "leidenalg" else ("node_weights", "node_sizes")
+    if clustering_args.get(other) is not None:
+        raise TypeError(f"{other} is not an argument of the {flavor} flavor: it takes {mine}")
+    node_weights = clustering_args.get(mine)
+    if node_weights is not None:
+        # (igraph: with the modularity objective the vertex weights default to the strengths and the resolution is divided by
+        # 2m; what it does with OTHER weights there is not pinned by anything in the reference -- CPM's meaning is plain)
+        if objective != "cpm":
+            raise NotImplementedError(f"{mine} are taken with the CPM objective only on the MI355X path")
+        if restrict_to is not None:
+            raise NotImplementedError(f"{mine} together with restrict_to is not supported on the MI355X path")
+        if isinstance(node_weights, str):
+            raise NotImplementedError(f"{mine} as an igraph vertex attribute name: pass the numbers (one per cell)")
     initial_membership = clustering_args.get("initial_membership")
     if initial_membership is not None and restrict_to is not None:
         raise NotImplementedError("initial_membership together with restrict_to is not supported on the MI355X path")
@@ -183,7 +202,8 @@ def leiden(  # noqa: PLR0913
             adata, restrict_key, restrict_categories=restrict_categories, adjacency=adjacency)
     groups, modularity = leiden_partition(adjacency, resolution=gamma, n_iterations=n_iterations, seed=seed,
                                           use_weights=use_weights, beta=clustering_args.get("beta", 0.01),
-                                          initial_membership=initial_membership, objective=objective)
+                                          initial_membership=initial_membership, objective=objective,
+                                          node_weights=node_weights)
     if restrict_to is not None:
         if key_added == "leiden":
             key_added += "_R"

@@ -40,7 +40,7 @@ def _patch_kernels():
         return (torch.from_numpy(conn.indptr.astype(np.int64)), torch.from_numpy(conn.indices.astype(np.int32)),
                 torch.from_numpy(conn.data.astype(np.float32)), torch.from_numpy(sig), torch.from_numpy(rho))
 
-    def leiden(indptr, indices, weights, n, *, resolution=1.0, n_iterations=-1, beta=0.01, seed=0, initial_membership=None, objective="modularity"):
+    def leiden(indptr, indices, weights, n, *, resolution=1.0, n_iterations=-1, beta=0.01, seed=0, initial_membership=None, objective="modularity", node_weights=None):
         from scipy import sparse
 
         assert objective == "modularity" and initial_membership is None, "the CPU stand-in starts from singletons"

@@ -76,7 +76,7 @@ def fuzzy_simplicial_set(lib, idx, dist):
     return indptr, indices[:m].copy(), data[:m].copy(), sigma, rho
 
 
-def leiden(lib, adj, *, resolution=1.0, n_iterations=-1, beta=0.01, seed=0, initial_membership=None, objective=0):
+def leiden(lib, adj, *, resolution=1.0, n_iterations=-1, beta=0.01, seed=0, initial_membership=None, objective=0, node_weights=None):
     adj = adj.tocsr()
     adj.sort_indices()
     n = adj.shape[0]
@@ -87,7 +87,13 @@ def leiden(lib, adj, *, resolution=1.0, n_iterations=-1, beta=0.01, seed=0, init
     q = C.c_double(0)
     nc = C.c_int32(0)
     ws = _ws(lib.scamd_leiden_workspace_bytes(n, adj.nnz))
-    if objective:
+    if node_weights is not None:
+        init = None if initial_membership is None else np.ascontiguousarray(initial_membership, dtype=np.int32)
+        nw = np.ascontiguousarray(node_weights, dtype=np.float32)
+        rc = lib.scamd_leiden_csr_nw_f32(_p(indptr), _p(indices), _p(w), n, adj.nnz, float(resolution), int(n_iterations), float(beta),
+                                         int(seed), int(objective), _p(nw), None if init is None else _p(init), _p(memb),
+                                         C.byref(q), C.byref(nc), _p(ws), ws.size, None)
+    elif objective:
         init = None if initial_membership is None else np.ascontiguousarray(initial_membership, dtype=np.int32)
         rc = lib.scamd_leiden_csr_ex_f32(_p(indptr), _p(indices), _p(w), n, adj.nnz, float(resolution), int(n_iterations), float(beta),
                                          int(seed), int(objective), None if init is None else _p(init), _p(memb), C.byref(q),

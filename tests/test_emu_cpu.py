@@ -372,6 +372,42 @@ def test_leiden_cpm_objective(emu):
     assert m0[1] == m1[1] and np.array_equal(m0[0], m1[0])
 
 
+def test_leiden_cpm_node_weights(emu):
+    """igraph's `node_weights` under the CPM objective (`sc.tl.leiden(flavor='igraph', objective_function='CPM',
+    node_weights=...)`, `**clustering_args` at src/scanpy/tools/_leiden.py:66, 188-196): a community pays resolution x (sum of
+    its members' weights)^2.  Weights that are all 1 give the partition of the unweighted call bit for bit (the fixed-point
+    scale is a power of two); with weights in sixteenths (exact in the kernel's 16 fractional bits) no vertex move and no
+    merge improves the WEIGHTED quality, which is at least the planted partition's; heavy vertices end in smaller
+    communities; bad weights and the modularity objective are refused"""
+    from oracle import leiden_guarantees as lg
+
+    H, lib = emu
+    rng = np.random.default_rng(0)
+    n = 1500
+    cent = rng.standard_normal((12, 10)) * 4
+    truth = rng.integers(0, 12, n)
+    x = (cent[truth] + rng.standard_normal((n, 10))).astype(np.float32)
+    idx, dist = oknn.knn_exact_f64(x, np.arange(n), 15)
+    conn, _, _ = oconn.fuzzy_simplicial_set(idx, dist, n, 15)
+    gamma = 0.01
+    plain = H.leiden(lib, conn, seed=0, resolution=gamma, objective=1)
+    ones = H.leiden(lib, conn, seed=0, resolution=gamma, objective=1, node_weights=np.ones(n))
+    assert np.array_equal(plain[0], ones[0]) and plain[1] == ones[1]
+    nw = rng.integers(4, 65, n) / 16.0  # 0.25 .. 4 in sixteenths
+    nw[truth == 3] *= 4.0               # one planted cluster of heavy vertices
+    memb, q, nc = H.leiden(lib, conn, seed=0, resolution=gamma, objective=1, node_weights=nw)
+    kw = dict(resolution=gamma, objective="cpm", node_weights=nw)
+    assert lg.improving_moves(conn, memb, **kw)["count"] == 0 and lg.mergeable_pairs(conn, memb, **kw)["count"] == 0
+    assert lg.quality(conn, memb, **kw) >= lg.quality(conn, truth, **kw) - 1e-12
+    assert nc > plain[2]  # the heavy cluster cannot stay whole at this resolution
+    heavy = np.unique(memb[truth == 3]).size
+    assert heavy > 1 and all(np.unique(memb[truth == c]).size <= heavy for c in range(12))
+    with pytest.raises(RuntimeError, match=r"node weights must lie in \[0, 1e6\]"):
+        H.leiden(lib, conn, objective=1, node_weights=-np.ones(n))
+    with pytest.raises(RuntimeError, match="node weights with the modularity objective"):
+        H.leiden(lib, conn, objective=0, node_weights=np.ones(n))
+
+
 def test_leiden_hub_rows(emu):
     """a vertex with 2500 neighbours (multi-pass hub tables) and vertices of 150 .. 1200 (overflow list, hub list tiers)"""
     from scipy import sparse

@@ -306,6 +306,34 @@ def test_leiden_cpm_objective(sc, pbmc68k):
         sc.tl.leiden(adata, flavor="leidenalg", objective_function="CPM")
 
 
+def test_leiden_cpm_node_weights(sc, pbmc68k):
+    """`node_weights` (igraph) / `node_sizes` (leidenalg's CPMVertexPartition) through `**clustering_args`
+    (src/scanpy/tools/_leiden.py:66, 174-196): vertex weights of the CPM quality.  Ones = the unweighted call; weighted: node
+    optimal and separated under the WEIGHTED objective; each flavor refuses the other's name; modularity refuses both"""
+    from oracle import leiden_guarantees as lg
+
+    adata = _graph_adata(sc, pbmc68k)
+    conn = adata.obsp["connectivities"]
+    gamma = 0.02
+    sc.tl.leiden(adata, flavor="igraph", objective_function="CPM", resolution=gamma, key_added="plain")
+    sc.tl.leiden(adata, flavor="igraph", objective_function="CPM", resolution=gamma, node_weights=np.ones(700), key_added="ones")
+    assert (adata.obs["plain"] == adata.obs["ones"]).all()
+    nw = np.random.default_rng(2).integers(4, 49, 700) / 16.0
+    sc.tl.leiden(adata, flavor="igraph", objective_function="CPM", resolution=gamma, node_weights=list(nw), key_added="w")
+    lab = adata.obs["w"].cat.codes.to_numpy()
+    assert lg.improving_moves(conn, lab, resolution=gamma, objective="cpm", node_weights=nw)["count"] == 0
+    assert lg.mergeable_pairs(conn, lab, resolution=gamma, objective="cpm", node_weights=nw)["count"] == 0
+    sc.tl.leiden(adata, flavor="leidenalg", partition_type=type("CPMVertexPartition", (), {}), resolution=gamma, node_sizes=nw,
+                 key_added="w_leidenalg")
+    assert (adata.obs["w"] == adata.obs["w_leidenalg"]).all()
+    with pytest.raises(TypeError, match="node_sizes is not an argument of the igraph flavor"):
+        sc.tl.leiden(adata, flavor="igraph", objective_function="CPM", node_sizes=nw)
+    with pytest.raises(NotImplementedError, match="CPM objective only"):
+        sc.tl.leiden(adata, flavor="igraph", node_weights=nw)
+    with pytest.raises(ValueError, match=r"one number in \[0, 1e6\] per vertex"):
+        sc.tl.leiden(adata, flavor="igraph", objective_function="CPM", node_weights=nw[:10])
+
+
 def test_leiden_partition_type_of_the_leidenalg_flavor(sc, pbmc68k):
     """`partition_type=` (src/scanpy/tools/_leiden.py:107-110, 174-186: the class `leidenalg.find_partition` optimises, with
     `resolution_parameter=resolution` unless `resolution=None`): the classes are matched by name -- RBConfiguration is the
