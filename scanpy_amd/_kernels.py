@@ -453,10 +453,11 @@ def leiden(indptr: torch.Tensor, indices: torch.Tensor, weights: torch.Tensor, n
 
 def leiden_last_stats() -> dict:
     """Diagnostics of this thread's last `leiden` call (scamd_leiden_last_stats)."""
-    out = (C.c_int32 * 12)()
-    _lib.load().scamd_leiden_last_stats(out, 12)
+    out = (C.c_int32 * 16)()
+    _lib.load().scamd_leiden_last_stats(out, 16)
     keys = ("iterations", "launches", "host_round_trips", "polish_full_sweeps", "polish_rounds", "polish_moves",
-            "polish_skipped_proven", "levels_first_iteration", "lm_sweeps", "lm_sweep_algorithmic_MB", "polish_splits", "ended_by_iteration_cap")
+            "polish_skipped_proven", "levels_first_iteration", "lm_sweeps", "lm_sweep_algorithmic_MB", "polish_splits",
+            "ended_by_iteration_cap", "polish_ended_by_round_cap", "iteration_cap", "device_copies", "device_fills")
     return dict(zip(keys, (int(v) for v in out)))
 
 

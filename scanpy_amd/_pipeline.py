@@ -222,7 +222,10 @@ def run_path(a_handle, n_total: int, *, comm=None, backend=None, n_comps: int = 
     tm.mark("connectivities")
     if rank == 0:
         labels, q, nc = _kernels.leiden(ci, cx, cd, n_total, resolution=resolution, n_iterations=n_iterations, seed=seed)
-        leiden_stats = _kernels.leiden_last_stats()
+        try:  # (diagnostics only: a backend that replaces `_kernels.leiden` need not have the library loaded)
+            leiden_stats = _kernels.leiden_last_stats()
+        except Exception:  # noqa: BLE001
+            leiden_stats = {}
         tm.mark("leiden")
     if world > 1:
         import torch.distributed as tdist

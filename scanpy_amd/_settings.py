@@ -15,6 +15,11 @@ class Settings:
     # cells every query block probes when `pp.neighbors(transformer='ivf')` asks for the approximate search
     # (scamd_knn_l2_ivf_f32; ~2048 rows per cell).  The recall / work curve is data dependent: DESIGN.md 3.1.
     knn_nprobe: int = 32
+    # `sc.settings.preset` (src/scanpy/_settings/presets.py:179-188), as far as the path reads it: 'ScanpyV1' (default) or
+    # 'ScanpyV2Preview'.  It decides how the igraph flavor of `tl.leiden` builds its graph (src/scanpy/_utils/__init__.py:
+    # 285-298): V1 adds every stored entry of the symmetric matrix as an undirected edge (every pair twice), V2 every
+    # pair once -- which matters for the CPM objective only (tools/_leiden.py).
+    preset: str = "ScanpyV1"
 
 
 settings = Settings()

@@ -62,29 +62,71 @@ inline int ceil_div(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) 
 // (tools/probes/host_roundtrip_probe.hip, MI355X).  `fetch` queues a copy into a per-thread pinned page and remembers where
 // the caller wants the bytes; `sync` drains the stream once and hands them out.  The page is allocated on first use and kept
 // for the life of the thread (8 KiB).
+// Round 6: the copies themselves were blit kernels of the runtime (`__amd_rocclr_copyBuffer`, one per fetch: 182 per pass of the
+// path, 3.5 ms of device time); now ONE small kernel of ours per synchronisation writes every queued item into the page
+// (mapped pinned memory: the probe's 12.4 us variant).  Contract: the bytes handed out are the source's AT THE SYNCHRONISATION,
+// so a source must not be overwritten between its `fetch` and the `sync` (no call site does).
+struct HostReadbackItems {
+  static constexpr int MAX_ITEMS = 8;
+  const void* src[MAX_ITEMS];
+  unsigned int off[MAX_ITEMS], bytes[MAX_ITEMS];
+  int n;
+};
+static __global__ void host_readback_publish_kernel(HostReadbackItems it, char* page) {
+  for (int i = 0; i < it.n; ++i) {
+    const unsigned int nb = it.bytes[i];
+    const char* s = static_cast<const char*>(it.src[i]);
+    char* d = page + it.off[i];
+    if ((reinterpret_cast<uintptr_t>(s) & 3u) == 0) {
+      const unsigned int words = nb >> 2;
+      for (unsigned int w = threadIdx.x; w < words; w += blockDim.x)
+        reinterpret_cast<unsigned int*>(d)[w] = reinterpret_cast<const unsigned int*>(s)[w];
+      for (unsigned int b = (words << 2) + threadIdx.x; b < nb; b += blockDim.x) d[b] = s[b];
+    } else {
+      for (unsigned int b = threadIdx.x; b < nb; b += blockDim.x) d[b] = s[b];
+    }
+  }
+}
 struct HostReadback {
   static constexpr size_t CAP = 8192;
-  static constexpr int MAX_ITEMS = 8;
+  static constexpr int MAX_ITEMS = HostReadbackItems::MAX_ITEMS;
   struct Item {
     void* dst;
     size_t off, bytes;
   };
-  char* pin = nullptr;
+  char* pin = nullptr;      // host address of the page
+  char* pin_dev = nullptr;  // the same page as the device sees it
   size_t used = 0;
   int n = 0;
   Item items[MAX_ITEMS];
+  HostReadbackItems queued;
   void reset() { used = 0, n = 0; }  // (an error path may leave queued items behind: every C entry point starts with this)
   int fetch(void* dst, const void* src_device, size_t bytes, hipStream_t s) {
-    if (!pin) SCAMD_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&pin), CAP, 0));
+    (void)s;
+    if (!pin) {
+      SCAMD_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&pin), CAP, 0));
+      SCAMD_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&pin_dev), pin, 0));
+    }
     const size_t off = align_up(used, 8);
     SCAMD_REQUIRE(off + bytes <= CAP && n < MAX_ITEMS, SCAMD_EINTERNAL, "read-back staging page overflow (%zu + %zu bytes, %d items)",
                   off, bytes, n);
-    SCAMD_HIP_CHECK(hipMemcpyAsync(pin + off, src_device, bytes, hipMemcpyDeviceToHost, s));
+    queued.src[n] = src_device;
+    queued.off[n] = (unsigned int)off;
+    queued.bytes[n] = (unsigned int)bytes;
     items[n++] = Item{dst, off, bytes};
     used = off + bytes;
     return SCAMD_OK;
   }
   int sync(hipStream_t s) {
+    if (n > 0) {
+      queued.n = n;
+      hipLaunchKernelGGL(host_readback_publish_kernel, dim3(1), dim3(256), 0, s, queued, pin_dev);
+      const hipError_t le = hipGetLastError();
+      if (le != hipSuccess) {
+        reset();
+        SCAMD_HIP_CHECK(le);
+      }
+    }
     const hipError_t e = hipStreamSynchronize(s);
     if (e == hipSuccess)
       for (int i = 0; i < n; ++i) memcpy(items[i].dst, pin + items[i].off, items[i].bytes);

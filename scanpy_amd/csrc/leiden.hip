@@ -34,8 +34,10 @@ namespace scamd {
 // [6] 1 if the polish was skipped because the last iteration had already proven node optimality, [7] levels of iteration 0,
 // [8] local-moving sweeps of the levels that run as separate kernels (all iterations), [9] their algorithmic traffic in MB:
 //     active rows x (12 B per entry + 16 B per vertex), SURVEY.md 8(d)'s per-sweep figure restricted to the rows a sweep visits,
-// [10] communities the polish split off because a departure had cut them in two, [11] 1 if the iteration cap ended the run
-static thread_local int g_ld_stats[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+// [10] communities the polish split off because a departure had cut them in two, [11] 1 if the iteration cap ended the run,
+// [12] 1 if a polish pass stopped at MAX_POLISH_ROUNDS (node optimality then NOT proven), [13] the iteration cap in force
+constexpr int LD_NSTATS = 16;
+static thread_local int g_ld_stats[LD_NSTATS] = {0};
 static thread_local double g_ld_sweep_bytes = 0.0;  // -> stats[9] (MB)
 #undef SCAMD_LAUNCH_CHECK
 #define SCAMD_LAUNCH_CHECK()                \
@@ -66,6 +68,11 @@ constexpr int CTR_STRIDE = 16;    // ints per sub-round counter block
 // counter area of a sweep / a refinement: MAX_CLASSES class-list lengths, then one CTR_STRIDE block per sub-round
 constexpr int CTR_AREA = MAX_CLASSES + CTR_STRIDE * MAX_CLASSES;
 constexpr int MAX_LEVELS = 64;
+// Outer iterations of an `n_iterations < 0` run ("until an iteration does not improve", src/scanpy/tools/_leiden.py:65, 166).
+// On graphs without clear communities that takes dozens of iterations in the sequential algorithm as well: oracle/leiden.c
+// needs 44 on the 1M-cell `weak` graph of bench.py (gains of 1e-7 .. 1e-5 Q per iteration from the 6th on; round-6 probe,
+// profiles/r06a_oracle_iters_weak.log), 18 on a 100k sample.  The loop is bounded (SCAMD_LEIDEN_ITER_CAP overrides); a run the
+// bound ends sets stats[11] and `tl.leiden` warns.
 constexpr int MAX_OUTER_ITERS = 32;
 
 __host__ __device__ __forceinline__ unsigned int hash32(unsigned int x) {
@@ -2911,7 +2918,10 @@ static int polish_level0(LeidenCtx& cx, const LevelGraph& g, int* stats) {
     if (leiden_debug())
       fprintf(stderr, "[leiden] polish round=%u %s act=%d moved_prev=%d lost_total=%d\n", round, full ? "full" : "flagged", cnt,
               moved_last, ht[1]);
-    if (round >= MAX_POLISH_ROUNDS) break;  // (every round moves at least one vertex and raises Q: a cap, not a rule)
+    if (round >= MAX_POLISH_ROUNDS) {  // (every round moves at least one vertex and raises Q: a cap, not a rule)
+      g_ld_stats[12] = 1;  // ... but one that leaves node optimality unproven: reported (scamd_leiden_last_stats, tl.leiden warns)
+      break;
+    }
     if (cnt == 0) {
       // nobody is flagged any more.  If nothing moved since the last sweep over ALL vertices, that sweep was the proof
       // of node optimality; otherwise another full sweep has to give it.
@@ -3462,7 +3472,7 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
   cx.cpm = objective == 1;
   cx.node_weights = node_weights;
   if (cx.cpm) cx.small_levels = false;  // (ld_small_levels_kernel derives its coarse vertex weights from row sums: strengths)
-  for (int i = 0; i < 12; ++i) g_ld_stats[i] = 0;
+  for (int i = 0; i < LD_NSTATS; ++i) g_ld_stats[i] = 0;
   g_ld_sweep_bytes = 0.0;
   if (const char* e = getenv("SCAMD_LEIDEN_SMALL_SEQ")) cx.small_seq_n = atoi(e);
   if (const char* e = getenv("SCAMD_LEIDEN_AGG_WAVE_MAX")) cx.agg_wave_max = std::min(atoi(e), (int)WH_MAX_DEG);
@@ -3512,7 +3522,11 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
     if (rc == SCAMD_OK) rc = quality(cx, g0, b.memb, &q_best);
     if (rc != SCAMD_OK) return rc;
     SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb_best, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
-    int max_iter = n_iterations < 0 ? MAX_OUTER_ITERS : n_iterations;
+    int iter_cap = MAX_OUTER_ITERS;
+    if (const char* e = getenv("SCAMD_LEIDEN_ITER_CAP"))
+      if (atoi(e) > 0) iter_cap = atoi(e);
+    g_ld_stats[13] = iter_cap;
+    int max_iter = n_iterations < 0 ? iter_cap : n_iterations;
     // (test knob: caps the outer loop of an n_iterations < 0 run, so that the polish meets an unfinished partition)
     if (const char* e = getenv("SCAMD_LEIDEN_MAX_ITERS"))
       if (n_iterations < 0 && atoi(e) > 0) max_iter = std::min(max_iter, atoi(e));
@@ -3562,7 +3576,7 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
     // ordinary iteration from the polished partition: its level-0 moving finds nothing, its refinement and coarse levels
     // re-examine everything else.  No gain: stable, done.  A gain: accepted, and the polish runs again.
     int n_iter_total = g_ld_stats[0];
-    ended_by_cap = ended_by_cap && max_iter == MAX_OUTER_ITERS;  // (not the test knob's cap: that one is followed up)
+    ended_by_cap = ended_by_cap && max_iter == iter_cap;  // (not the test knob's cap: that one is followed up)
     g_ld_stats[11] = (n_iterations < 0 && ended_by_cap) ? 1 : 0;
     for (int pr = 0; n_iterations < 0 && cx.polish && pr <= MAX_POLISH_PASSES; ++pr) {
       if (best_is_clean) {
@@ -3661,7 +3675,7 @@ extern "C" int scamd_leiden_debug_split_f32(const int64_t* indptr, const int32_t
 
 extern "C" void scamd_leiden_last_stats(int32_t* out, int n) {
   g_ld_stats[9] = (int)std::min(2.0e9, g_ld_sweep_bytes / 1.0e6);
-  for (int i = 0; i < n && i < 12; ++i) out[i] = g_ld_stats[i];
+  for (int i = 0; i < n && i < LD_NSTATS; ++i) out[i] = g_ld_stats[i];
 }
 
 extern "C" int scamd_modularity_csr_f32(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n,

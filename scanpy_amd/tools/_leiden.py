@@ -90,10 +90,35 @@ def rename_groups(adata, restrict_key, *, key_added, restrict_categories, restri
     return all_groups
 
 
+def _warn_unfinished(stats: dict, n_iterations: int) -> None:
+    """`n_iterations < 0` promises a run "until it reaches an iteration that does not improve the clustering"
+    (src/scanpy/tools/_leiden.py:65, 166).  The device optimiser bounds that loop (csrc/leiden.hip: MAX_OUTER_ITERS) and its
+    final polish (MAX_POLISH_ROUNDS); when either bound ends a run the caller is told -- the partition returned is still
+    the best one seen, connected, and (unless the polish itself was cut short) node optimal."""
+    if n_iterations >= 0:
+        return
+    if stats.get("ended_by_iteration_cap"):
+        warnings.warn(
+            f"leiden(n_iterations={n_iterations}): every one of the {stats['iterations']} iterations still improved the "
+            "quality; the run was stopped at the iteration cap of the MI355X optimiser (SCAMD_LEIDEN_ITER_CAP) and the best "
+            "partition, polished to node optimality, is returned.  Graphs without clear community structure behave like "
+            "this in the reference as well (dozens of iterations with gains of 1e-5 and less); pass n_iterations=2, the "
+            "reference's recommendation for flavor='igraph', for a bounded run.",
+            UserWarning, stacklevel=4)
+    if stats.get("polish_ended_by_round_cap"):
+        warnings.warn(
+            "leiden: the final single-vertex polish stopped at its round cap; the partition may hold vertices that a "
+            "move would still improve.", UserWarning, stacklevel=4)
+
+
 def leiden_partition(adjacency, *, resolution=1.0, n_iterations=-1, seed=0, use_weights=True, beta=0.01,
-                     initial_membership=None, objective="modularity", node_weights=None):
+                     initial_membership=None, objective="modularity", node_weights=None, report="objective"):
     """Symmetric adjacency (scipy sparse) -> (membership int32 [n], modularity).  `initial_membership`: a partition to
-    start from (any non-negative integer labels, one per vertex), as leidenalg / igraph take it."""
+    start from (any non-negative integer labels, one per vertex), as leidenalg / igraph take it.
+    `report`: which number comes back beside the labels -- 'objective': the optimiser's own (modularity at `resolution`;
+    for CPM the weighted resolution-1 modularity); 'weighted' / 'unweighted': the plain resolution-1 modularity of the
+    partition with / without the edge weights, what `part.modularity` is in the reference for the igraph / leidenalg
+    flavor (see `leiden`)."""
     import torch
 
     from .. import _kernels
@@ -128,6 +153,11 @@ def leiden_partition(adjacency, *, resolution=1.0, n_iterations=-1, seed=0, use_
     memb, q, _ = _kernels.leiden(indptr, indices, weights, n, resolution=float(resolution),
                                  n_iterations=int(n_iterations), beta=beta, seed=int(seed), initial_membership=init,
                                  objective=objective, node_weights=nw)
+    _warn_unfinished(_kernels.leiden_last_stats(), int(n_iterations))
+    if report == "unweighted" and use_weights:
+        q = _kernels.modularity(indptr, indices, torch.ones_like(weights), n, memb, resolution=1.0)
+    elif report in ("weighted", "unweighted") and objective == "modularity" and float(resolution) != 1.0:
+        q = _kernels.modularity(indptr, indices, weights, n, memb, resolution=1.0)
     return memb.cpu().numpy(), q
 
 
@@ -155,8 +185,21 @@ def leiden(  # noqa: PLR0913
     Both reference flavors optimise the same objective on the symmetric connectivities
     (RBConfiguration modularity with `resolution`) and are served by the same GPU
     optimiser.  `objective_function='CPM'` (igraph) and `partition_type=` RBConfiguration / Modularity / CPM
-    VertexPartition (leidenalg; matched by class name, `_PARTITION_TYPES`) select the objective of that optimiser.  Writes `.obs[key_added]` (categorical of str, naturally sorted categories, ids by
-    decreasing community size) and `.uns[key_added] = {params, modularity}`."""
+    VertexPartition (leidenalg; matched by class name, `_PARTITION_TYPES`) select the objective of that optimiser.
+
+    The two flavors do NOT see the same graph in the reference, and CPM -- unlike modularity -- is not scale invariant:
+    under the default preset `get_igraph_from_adjacency` adds every STORED entry of the symmetric matrix as an undirected
+    edge (src/scanpy/_utils/__init__.py:292-298), so igraph's optimiser sees every pair twice, `A_ij = 2 w_ij`, and
+    `flavor='igraph', objective_function='CPM'` maximises `sum (2 w_ij - resolution n_i n_j)` -- `resolution / 2` on the
+    matrix itself; the V2 preset builds the graph with `Weighted_Adjacency(mode=undirected)` (:285-290: every pair once).
+    The leidenalg flavor gets a directed graph with both directions (`_leiden.py:172-173`): `CPMVertexPartition` maximises
+    `sum (w_ij - resolution n_i n_j)` over the ordered pairs -- `resolution` as given.  `settings.preset` selects V1 / V2.
+
+    Writes `.obs[key_added]` (categorical of str, naturally sorted categories, ids by decreasing community size) and
+    `.uns[key_added] = {params, modularity}`; `modularity` is what the reference stores, `part.modularity` (:219): igraph's
+    `VertexClustering.modularity` recomputed from the membership at resolution 1 -- with the edge weights for the igraph
+    flavor (`community_leiden` hands `modularity_params=dict(weights=...)` to the clustering), WITHOUT them for the
+    leidenalg flavor (`MutableVertexPartition` constructs the clustering with no modularity parameters)."""
     if not is_anndata(adata):
         raise TypeError("leiden() expects an AnnData-like object")
     flavor = _validate_flavor(flavor, partition_type=partition_type, directed=directed)
@@ -176,6 +219,8 @@ def leiden(  # noqa: PLR0913
         objective, gamma = _resolve_partition_type(partition_type, resolution)
     else:
         gamma = 1.0 if resolution is None else resolution  # (igraph's default when `resolution` is left out, _leiden.py:193-194)
+        if objective == "cpm" and settings.preset == "ScanpyV1":
+            gamma = gamma / 2.0  # every symmetric pair is an edge TWICE in the V1 graph (_utils/__init__.py:292-298)
     # vertex weights of the quality function: igraph calls them `node_weights`, leidenalg's partition classes `node_sizes`
     mine, other = ("node_sizes", "node_weights") if flavor == "leidenalg" else ("node_weights", "node_sizes")
     if clustering_args.get(other) is not None:
@@ -203,7 +248,8 @@ def leiden(  # noqa: PLR0913
     groups, modularity = leiden_partition(adjacency, resolution=gamma, n_iterations=n_iterations, seed=seed,
                                           use_weights=use_weights, beta=clustering_args.get("beta", 0.01),
                                           initial_membership=initial_membership, objective=objective,
-                                          node_weights=node_weights)
+                                          node_weights=node_weights,
+                                          report="weighted" if flavor == "igraph" else "unweighted")
     if restrict_to is not None:
         if key_added == "leiden":
             key_added += "_R"

@@ -86,6 +86,7 @@ def _patch_kernels():
     _kernels.fuzzy_weights = fuzzy_weights
     _kernels.fuzzy_merge_rows = fuzzy_merge_rows
     _kernels.leiden = leiden
+    _kernels.leiden_last_stats = lambda: {}  # (the library's thread-local stats say nothing about a stand-in run)
 
 
 def run(rank: int, world: int, init_file: str, out_dir: str, n: int, g: int, n_comps: int, mode: str):

@@ -69,6 +69,7 @@ template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { retu
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned = 0) { *d = h; return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }

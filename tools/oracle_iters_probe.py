@@ -1,0 +1,61 @@
+"""How many iterations does the SEQUENTIAL oracle (oracle/leiden.c, n_iterations=-1) need on the SAME 1M-cell graph the GPU
+optimiser is timed on?  ("Next round" 1a: is the cap of the GPU's outer loop the algorithm's behaviour or
+an artefact of the synchronous sub-rounds?)
+
+The graph is built by the GPU path (pca -> exact kNN -> fuzzy set), copied to the host, and handed to the oracle; the GPU
+optimiser runs on the same CSR.  Prints both iteration traces (Q per iteration), times, and the ARI between the two.
+
+    python tools/oracle_iters_probe.py 1000000 weak [seed]
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+from scipy import sparse
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+    structure = sys.argv[2] if len(sys.argv) > 2 else "weak"
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    import torch
+
+    import bench
+    from oracle import compare as cmp
+    from oracle import leiden as ol
+    from scanpy_amd import _kernels as K
+    from scanpy_amd._pipeline import run_path
+    from scanpy_amd.preprocessing._pca_solver import GpuBackend
+
+    ol.build()
+    x, truth = bench.make_matrix(n, 2000, 0, structure)
+    backend = GpuBackend()
+    res = run_path(backend.upload(x), n, backend=backend)
+    ip, ix, w = res.conn_indptr, res.conn_indices, res.conn_data
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    labels, q, nc = K.leiden(ip, ix, w, n, seed=seed)
+    torch.cuda.synchronize()
+    t_gpu = time.perf_counter() - t0
+    stats = K.leiden_last_stats()
+    gl = labels.cpu().numpy()
+    print(f"gpu: {t_gpu * 1e3:.1f} ms, Q {q!r}, {nc} communities, {stats}", flush=True)
+    conn = sparse.csr_matrix((w.cpu().numpy().astype(np.float64), ix.cpu().numpy(), ip.cpu().numpy()), shape=(n, n))
+    del res
+    os.environ["ORACLE_LEIDEN_DEBUG"] = "1"
+    t0 = time.perf_counter()
+    om, oq = ol.leiden(conn, resolution=1.0, n_iterations=-1, seed=seed)
+    t_cpu = time.perf_counter() - t0
+    print(f"oracle: {t_cpu:.1f} s, Q {oq!r}, {int(om.max()) + 1} communities", flush=True)
+    print(f"ARI gpu vs oracle {cmp.ari(gl, om):.4f}; vs truth: gpu {cmp.ari(gl, truth):.4f} oracle {cmp.ari(om, truth):.4f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
