@@ -68,10 +68,10 @@ def parse_args():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N > 1: strong = --n-obs cells split over the ranks (BASELINE configs[3]); weak = --n-obs cells PER "
                          "rank (e.g. --n-obs 1250000 --n-vars 4000 --gpus 8 is the configs[4] shape, 10M x 4k)")
-    ap.add_argument("--cpu-sizes", type=str, default="100000,250000,500000",
+    ap.add_argument("--cpu-sizes", type=str, default="100000,250000,1000000",
                     help="cell counts of the CPU-baseline samples (n^2 fit of the brute kNN); '' or 0 = skip")
     ap.add_argument("--cpu-sample", type=int, default=None, help="(old flag) one CPU-baseline sample size; 0 = skip")
-    ap.add_argument("--cpu-budget-s", type=float, default=150.0,
+    ap.add_argument("--cpu-budget-s", type=float, default=270.0,
                     help="stop adding CPU samples once the next one is predicted to exceed this many seconds in total")
     ap.add_argument("--structure", choices=("planted", "weak", "none"), default="planted",
                     help="planted: 64 separated cell types (BASELINE.md section 3); weak: overlapping types; "
@@ -150,28 +150,38 @@ def cpu_baseline(x_full, truth, sizes, n_full: int, n_comps: int, k: int, budget
         runs.append({"n": n_s, **sec, "total": sum(sec.values())})
         spent += runs[-1]["total"]
         last = c
-    # fits through the origin: kNN = a n^2 (least squares over the samples), every other stage = b n
-    ns = np.array([r["n"] for r in runs], dtype=np.float64)
-    a_knn = float((np.array([r["knn"] for r in runs]) * ns ** 2).sum() / (ns ** 4).sum())
-    lin = {st: float((np.array([r[st] for r in runs]) * ns).sum() / (ns ** 2).sum()) for st in ("pca", "connectivities", "leiden")}
+    # fits through the origin over the samples BELOW the full size: kNN = a n^2 (least squares), every other stage = b n
+    big = runs[-1]
+    full = big if big["n"] == n_full else None  # the whole workload was RUN (round 6: the default sizes end with it)
+    fit_runs = [r for r in runs if r["n"] < n_full] or runs
+    ns = np.array([r["n"] for r in fit_runs], dtype=np.float64)
+    a_knn = float((np.array([r["knn"] for r in fit_runs]) * ns ** 2).sum() / (ns ** 4).sum())
+    lin = {st: float((np.array([r[st] for r in fit_runs]) * ns).sum() / (ns ** 2).sum()) for st in ("pca", "connectivities", "leiden")}
     est = {"knn": a_knn * n_full ** 2, **{st: b * n_full for st, b in lin.items()}}
     est_total = sum(est.values())
-    big = runs[-1]
     obj = {
-        "value": n_full / est_total,
+        "value": n_full / (full["total"] if full else est_total),
         "unit": "cells/s",
         "cores": os.cpu_count(),
         "kind": "port",
+        "measured_at_full_size": full is not None,
         "sample": (f"first n cells x {x_full.shape[1]} genes of the same synthetic CSR for n in {[r['n'] for r in runs]}: "
                    "sklearn PCA(arpack) + sklearn brute kNN(n_jobs=-1) (the reference's own calls) + oracle "
-                   "fuzzy_simplicial_set + oracle Leiden (igraph / umap-learn absent); `value` = the full "
-                   f"{n_full} cells / the seconds extrapolated from these samples (brute kNN = a*n^2 least squares, "
-                   "the other stages linear in n; BASELINE.md section 3); `measured` holds what was timed"),
+                   "fuzzy_simplicial_set + oracle Leiden (igraph / umap-learn absent); "
+                   + (f"`value` = {n_full} cells / the seconds MEASURED on all {n_full} cells (the last entry of `measured`); "
+                      "`extrapolated_seconds_at_full_size` = what the smaller samples predicted for it "
+                      if full else
+                      f"`value` = the full {n_full} cells / the seconds EXTRAPOLATED from these samples (the full size did not fit "
+                      "`--cpu-budget-s` on this box) ")
+                   + "(fit: brute kNN = a*n^2 least squares, the other stages linear in n; BASELINE.md section 3)"),
         "measured": runs,
-        "extrapolated_seconds_at_full_size": {**est, "total": est_total},
+        "extrapolated_seconds_at_full_size": {**est, "total": est_total, "fitted_on": [r["n"] for r in fit_runs]},
         "largest_sample_cells_per_s": big["n"] / big["total"],
         "seconds": spent,
     }
+    if full:
+        obj["measured_seconds_at_full_size"] = {k_: full[k_] for k_ in ("pca", "knn", "connectivities", "leiden", "total")}
+        obj["fit_over_measured"] = est_total / full["total"]
     return obj, last
 
 
@@ -961,6 +971,9 @@ def main() -> None:
             if args.h2h_reps > 0:
                 h2h = host_to_host(x, args.n_comps, args.n_neighbors, args.h2h_reps)
                 out["value_host_to_host"] = h2h["value"]
+                out["value_h2h"] = h2h["value"]  # (same number under the short name; also inside `config`, which the driver's record keeps whole)
+                out["config"]["value_h2h_cells_per_s"] = h2h["value"]
+                out["config"]["h2h_ms_per_pass"] = h2h["best"]["total_ms"] if isinstance(h2h.get("best"), dict) and "total_ms" in h2h["best"] else None
                 out["host_to_host"] = h2h
             variant_fails = []
             for st in ("none", "weak"):

@@ -240,6 +240,22 @@ int scamd_pca_csr_f32(const int64_t* indptr, const int32_t* indices, const float
                       int n_comps, int zero_center, uint64_t seed, double tol, float* scores, double* components,
                       double* variance, double* variance_ratio, double* mean, int32_t* info_host, void* workspace,
                       size_t workspace_bytes, scamd_stream_t stream);
+/* The dense half of the above on its own -- what a ROW-SHARDED run calls after the all-reduce of the int64 sums (and what
+ * scamd_pca_csr_f32 itself calls), so that the model is bitwise the same for any number of ranks and no library computes
+ * any part of it (replaces the covariance-eigh arithmetic of src/scanpy/preprocessing/_pca/_kernels.py:14-58 and
+ * _pca/_dask.py:28-132, sklearn's svd_flip and explained-variance bookkeeping, sklearn/decomposition/_pca.py:704-793):
+ *   gram [g x g] int64 fixed point (2^scale_bits X^T X summed over ALL n_total rows, row stride ld_gram; only the upper
+ *   triangle is read), colsum [g] int64 (2^scale_bits column sums)  ->  components [n_comps x g] float64 (sign convention
+ *   applied), loadings_f32 [g x n_comps] float32 (= the B operand of scamd_spmm_csr_f32 for the scores), shift [n_comps]
+ *   float32 (mu^T V: its `shift` operand), variance / variance_ratio [n_comps], mean [g], eigenvalues [n_comps] (of
+ *   X^T X - n mu mu^T, clamped at 0: singular values squared; may be NULL).  info_host (optional, 8 ints) as scamd_pca_csr_f32.
+ * Same range as scamd_eigh_topk_f64 (SCAMD_EUNSUPPORTED outside). */
+size_t scamd_pca_solve_gram_workspace_bytes(int64_t g, int n_comps);
+int scamd_pca_solve_gram_f64(const int64_t* gram, int64_t ld_gram, const int64_t* colsum, int64_t n_total, int64_t g,
+                             int scale_bits, int n_comps, int zero_center, uint64_t seed, double tol, double* components,
+                             float* loadings_f32, float* shift, double* variance, double* variance_ratio, double* mean,
+                             double* eigenvalues, int32_t* info_host, void* workspace, size_t workspace_bytes,
+                             scamd_stream_t stream);
 /* colsum[l] (float64) = 1^T Y for Y [n, l] float32, fixed summation order. */
 size_t scamd_colsum_workspace_bytes(int l);
 int scamd_colsum_f32_f64(const float* y, int64_t n, int l, double* colsum,
@@ -293,7 +309,7 @@ int scamd_leiden_csr_nw_f32(const int64_t* indptr, const int32_t* indices, const
                             const int32_t* initial_membership, int32_t* membership, double* modularity_host,
                             int32_t* n_communities_host, void* workspace, size_t workspace_bytes,
                             scamd_stream_t stream);
-/* Statistics of the last scamd_leiden_csr_f32 call on this thread, out[0 .. min(n, 12)):
+/* Statistics of the last scamd_leiden_csr_f32 call on this thread:
  *   [0] outer iterations run, [1] kernel launches, [2] blocking host round trips,
  *   [3] full sweeps / [4] rounds / [5] vertices moved by the final polish (n_iterations < 0: strictly monotone
  *       single-vertex moves until a sweep over ALL vertices finds no improving one -- the node optimality a stable
@@ -303,8 +319,11 @@ int scamd_leiden_csr_nw_f32(const int64_t* indptr, const int32_t* indices, const
  *   [8] local-moving sweeps of the levels that run as separate kernels, [9] their algorithmic traffic in MB (active rows
  *       x (12 B per entry + 16 B per vertex): SURVEY.md 8(d)'s per-sweep figure over the rows a sweep visits),
  *   [10] communities the polish split off (a departing vertex had cut them in two), [11] 1 if the cap on the outer iterations
- *        (32) ended an n_iterations < 0 run instead of convergence.
- * Diagnostics only (bench.py, tools/). */
+ *        ([13]; 32 unless SCAMD_LEIDEN_ITER_CAP says otherwise) ended an n_iterations < 0 run instead of convergence --
+ *        `tl.leiden` turns it into a UserWarning, [12] 1 if a polish pass stopped at its round cap (node optimality then
+ *        unproven; warned about as well), [14] device-to-device copies (0 since round 6: partitions change buffers by
+ *        pointer), [15] launches of the multi-region clear kernel (all that is left of the hipMemsetAsync calls).
+ * out[0 .. min(n, 16)).  Diagnostics only (bench.py, tools/, the two warnings). */
 void scamd_leiden_last_stats(int32_t* out, int n);
 /* Test entry: the component split the polish applies after its moves -- every connected component (over the stored
  * entries) of a community of `membership` (ids in [0, n), device, rewritten in place) becomes a community of its own, id =

@@ -384,6 +384,33 @@ def pca_csr(indptr, indices, data, n: int, g: int, n_comps: int, *, zero_center:
                                              "chol_retries": info[3], "residual": resid, "scale_bits": info[6]}
 
 
+def pca_solve_gram(gram_q: torch.Tensor, colsum_q: torch.Tensor, n_total: int, g: int, scale_bits: int, n_comps: int, *,
+                   zero_center: bool = True, seed: int = 0, tol: float = 2e-8):
+    """`scamd_pca_solve_gram_f64`: the dense half of the Gram route in one C call (no torch arithmetic): int64 Gram matrix
+    [gp, gp] + column sums -> (components f64 [k, g], loadings f32 [g, k], shift f32 [k], variance [k], ratio [k],
+    mean f64 [g], eigenvalues f64 [k], info)."""
+    dev = require_gpu()
+    lib = _lib.load()
+    k = int(n_comps)
+    assert gram_q.dtype == torch.int64 and gram_q.is_contiguous() and colsum_q.dtype == torch.int64
+    comps = _empty((k, g), dtype=torch.float64, device=dev)
+    v32 = _empty((g, k), dtype=torch.float32, device=dev)
+    shift = _empty(k, dtype=torch.float32, device=dev)
+    var = _empty(k, dtype=torch.float64, device=dev)
+    ratio = _empty(k, dtype=torch.float64, device=dev)
+    mean = _empty(g, dtype=torch.float64, device=dev)
+    lam = _empty(k, dtype=torch.float64, device=dev)
+    info = (C.c_int32 * 12)()
+    ws, wsz = _ws(lib.scamd_pca_solve_gram_workspace_bytes(g, k), dev)
+    rc = lib.scamd_pca_solve_gram_f64(ptr(gram_q), gram_q.shape[1], ptr(colsum_q), int(n_total), g, int(scale_bits), k,
+                                      1 if zero_center else 0, int(seed) & (2**64 - 1), float(tol), ptr(comps), ptr(v32),
+                                      ptr(shift), ptr(var), ptr(ratio), ptr(mean), ptr(lam), info, ptr(ws), wsz, stream_ptr())
+    _check(rc, "scamd_pca_solve_gram_f64")
+    resid = C.cast(C.byref(info, 16), C.POINTER(C.c_double))[0]
+    return comps, v32, shift, var, ratio, mean, lam, {"n_outer": info[0], "n_gemm": info[1], "block_size": info[2],
+                                                       "chol_retries": info[3], "residual": resid}
+
+
 def colsum(y: torch.Tensor) -> torch.Tensor:
     dev = require_gpu()
     lib = _lib.load()

@@ -49,6 +49,8 @@ SIGNATURES = {
     "scamd_dense_debug_f64": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, C.POINTER(_i32), _vp]),
     "scamd_pca_csr_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "scamd_pca_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _u64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "scamd_pca_solve_gram_workspace_bytes": (_sz, [_i64, _i32]),
+    "scamd_pca_solve_gram_f64": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _u64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "scamd_colsum_workspace_bytes": (_sz, [_i32]),
     "scamd_colsum_f32_f64": (_i32, [_vp, _i64, _i32, _vp, _vp, _sz, _vp]),
     "scamd_leiden_workspace_bytes": (_sz, [_i64, _i64]),

@@ -850,24 +850,9 @@ extern "C" int scamd_dense_debug_f64(int op, const double* in0, const double* in
 // ---------------------------------------------------------------------------------------------------------------------
 namespace scamd {
 struct PcaBuffers {
-  long long* gram; long long* colsum; double* a; double* var; float* v32; float* shift; double* varsum; double* proj;
-  void* gram_ws; size_t gram_ws_bytes; void* dense_ws; size_t dense_ws_bytes;
+  long long* gram; long long* colsum; float* v32; float* shift;
+  void* gram_ws; size_t gram_ws_bytes; void* solve_ws; size_t solve_ws_bytes;
 };
-static void pca_carve(Workspace& ws, int64_t n, int64_t g, int k, PcaBuffers* b) {
-  const int64_t gp = (g + 127) / 128 * 128;
-  b->gram = ws.take<long long>((size_t)gp * gp);
-  b->colsum = ws.take<long long>((size_t)gp);
-  b->a = ws.take<double>((size_t)g * g);
-  b->var = ws.take<double>((size_t)g);
-  b->v32 = ws.take<float>((size_t)g * k);
-  b->shift = ws.take<float>((size_t)k + 8);
-  b->varsum = ws.take<double>(8);
-  b->proj = ws.take<double>((size_t)k + 8);
-  b->gram_ws_bytes = scamd_csr_gram_workspace_bytes(n, g);
-  b->gram_ws = ws.take<char>(b->gram_ws_bytes);
-  b->dense_ws_bytes = scamd_eigh_topk_workspace_bytes(g, k);
-  b->dense_ws = ws.take<char>(b->dense_ws_bytes);
-}
 // out[0] = sum of var[0..g) in index order (one thread: g <= 65535)
 __global__ void sum_kernel(const double* __restrict__ x, int g, double* __restrict__ out) {
   double s = 0.0;
@@ -886,6 +871,132 @@ __global__ void variance_kernel(const double* __restrict__ theta, int k, double 
   variance[c] = ev;
   const double tot = varsum[0] * total_scale;
   ratio[c] = tot > 0.0 ? ev / tot : 0.0;
+}
+}  // namespace scamd
+
+// ---- the dense half of the Gram route on its own: (fixed-point Gram matrix, column sums) -> model ------------------------
+// What a row-sharded run calls after the all-reduce of the int64 sums, and what scamd_pca_csr_f32 calls on one device: the
+// model is therefore bitwise the same for any number of ranks, and no library (torch / rocBLAS) computes any part of it.
+namespace scamd {
+struct PcaSolveBuffers {
+  double* a; double* var; double* varsum; double* proj; void* dense_ws; size_t dense_ws_bytes;
+};
+static void pca_solve_carve(Workspace& ws, int64_t g, int k, PcaSolveBuffers* b) {
+  b->a = ws.take<double>((size_t)g * g);
+  b->var = ws.take<double>((size_t)g);
+  b->varsum = ws.take<double>(8);
+  b->proj = ws.take<double>((size_t)k + 8);
+  b->dense_ws_bytes = scamd_eigh_topk_workspace_bytes(g, k);
+  b->dense_ws = ws.take<char>(b->dense_ws_bytes);
+}
+__global__ void copy_theta_kernel(const double* __restrict__ theta, int k, double* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < k) out[c] = fmax(theta[c], 0.0);
+}
+// steps 3-5 and 7 of the route; `dseed` is handed to the eigensolver as it is.  No synchronisation: the caller drains.
+static int pca_solve_gram(const long long* gram, int64_t ld_gram, const long long* colsum, int64_t n, int64_t g, int scale_bits,
+                          int k, int zero_center, unsigned int dseed, double tol, double* components, float* v32, float* shift,
+                          double* variance, double* variance_ratio, double* mean, double* theta_out, PcaSolveBuffers& b,
+                          hipStream_t s, int* n_outer, double* resid, int* n_gemm, int* bsz_out, int* n_chol_retry) {
+  // 3. A = G - n mu mu^T, means, column variances
+  const double inv = std::ldexp(1.0, -scale_bits);
+  hipLaunchKernelGGL(cov_from_gram_kernel, dim3((unsigned)(((int64_t)g * g + 255) / 256)), dim3(256), 0, s, gram, ld_gram,
+                     colsum, (int)g, inv, (double)n, zero_center ? 1 : 0, b.a, mean, b.var);
+  SCAMD_LAUNCH_CHECK();
+  // 4. top-k eigenpairs
+  const int bsz = dense_block_size(g, k);
+  SCAMD_REQUIRE((bsz == g || k + 32 <= bsz) && (bsz == g || g >= 2 * bsz), SCAMD_EUNSUPPORTED,
+                "pca: n_comps=%d / g=%lld outside the device eigensolver's range", k, (long long)g);
+  DenseCtx cx;
+  cx.s = s;
+  cx.a = b.a;
+  cx.lda = g;
+  cx.g = (int)g;
+  cx.b = bsz;
+  Workspace dws(b.dense_ws, b.dense_ws_bytes);
+  dense_carve(dws, g, bsz, &cx.d);
+  int rc = dense_topk(cx, k, dseed, tol, n_outer, resid);
+  if (rc != SCAMD_OK) return rc;
+  // 5. sign convention, float32 loadings, projected means
+  hipLaunchKernelGGL(finalize_components_kernel, dim3(k), dim3(256), 0, s, cx.d.z[3], (int)g, bsz, k, components, v32);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mean_shift_kernel, dim3(k), dim3(256), 0, s, mean, v32, (int)g, k, shift, b.proj);
+  SCAMD_LAUNCH_CHECK();
+  // 7. explained variance (sklearn: S^2 / (n - 1); ratio against the total variance with the same n / (n - 1) factor;
+  //    zero_center = False is TruncatedSVD: the variance of the scores of the uncentred decomposition, lam / n - (mu^T v)^2)
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1), 0, s, b.var, (int)g, b.varsum);
+  SCAMD_LAUNCH_CHECK();
+  const double denom = zero_center ? (double)(n - 1) : (double)n;
+  const double total_scale = zero_center ? (double)n / (double)(n - 1) : 1.0;
+  hipLaunchKernelGGL(variance_kernel, dim3(1), dim3(256), 0, s, cx.d.theta, k, denom,
+                     zero_center ? (const double*)nullptr : (const double*)b.proj, b.varsum, total_scale, variance,
+                     variance_ratio);
+  SCAMD_LAUNCH_CHECK();
+  if (theta_out) {
+    hipLaunchKernelGGL(copy_theta_kernel, dim3((k + 255) / 256), dim3(256), 0, s, cx.d.theta, k, theta_out);
+    SCAMD_LAUNCH_CHECK();
+  }
+  *n_gemm = cx.n_gemm;
+  *bsz_out = bsz;
+  *n_chol_retry = cx.n_chol_retry;
+  return SCAMD_OK;
+}
+}  // namespace scamd
+
+extern "C" size_t scamd_pca_solve_gram_workspace_bytes(int64_t g, int n_comps) {
+  if (g < 1 || n_comps < 1) return 0;
+  Workspace ws(nullptr, 0);
+  PcaSolveBuffers b;
+  pca_solve_carve(ws, g, n_comps, &b);
+  return ws.used();
+}
+
+extern "C" int scamd_pca_solve_gram_f64(const int64_t* gram, int64_t ld_gram, const int64_t* colsum, int64_t n_total, int64_t g,
+                                        int scale_bits, int n_comps, int zero_center, uint64_t seed, double tol,
+                                        double* components, float* loadings_f32, float* shift, double* variance,
+                                        double* variance_ratio, double* mean, double* eigenvalues, int32_t* info_host,
+                                        void* workspace, size_t workspace_bytes, scamd_stream_t stream) {
+  SCAMD_REQUIRE(gram && colsum && components && loadings_f32 && shift && variance && variance_ratio && mean, SCAMD_EINVAL,
+                "pca solve: null pointer");
+  const int k = n_comps;
+  SCAMD_REQUIRE(n_total >= 2 && g >= 1 && ld_gram >= g && k >= 1 && k <= g && scale_bits >= 0 && scale_bits <= 60, SCAMD_EINVAL,
+                "pca solve: bad shape n=%lld g=%lld ld=%lld k=%d S=%d", (long long)n_total, (long long)g, (long long)ld_gram, k, scale_bits);
+  SCAMD_REQUIRE(g <= 8192, SCAMD_EUNSUPPORTED, "pca solve: the Gram route takes up to 8192 genes (g=%lld)", (long long)g);
+  Workspace ws(workspace, workspace_bytes);
+  PcaSolveBuffers b;
+  pca_solve_carve(ws, g, k, &b);
+  SCAMD_REQUIRE(workspace && ws.ok, SCAMD_EWORKSPACE, "pca solve: workspace %zu < required %zu", workspace_bytes, ws.used());
+  int n_outer = 0, n_gemm = 0, bsz = 0, n_chol = 0;
+  double resid = 0.0;
+  int rc = pca_solve_gram(reinterpret_cast<const long long*>(gram), ld_gram, reinterpret_cast<const long long*>(colsum), n_total, g,
+                          scale_bits, k, zero_center, (unsigned int)(seed ^ (seed >> 32)) * 0x9E3779B1u + 12345u, tol, components,
+                          loadings_f32, shift, variance, variance_ratio, mean, eigenvalues, b, stream, &n_outer, &resid, &n_gemm,
+                          &bsz, &n_chol);
+  if (rc != SCAMD_OK) return rc;
+  SCAMD_HIP_CHECK(hipStreamSynchronize(stream));
+  if (info_host) {
+    info_host[0] = n_outer;
+    info_host[1] = n_gemm;
+    info_host[2] = bsz;
+    info_host[3] = n_chol;
+    memcpy(info_host + 4, &resid, sizeof(double));
+    info_host[6] = scale_bits;
+    info_host[7] = 0;
+  }
+  return SCAMD_OK;
+}
+
+namespace scamd {
+static void pca_carve(Workspace& ws, int64_t n, int64_t g, int k, PcaBuffers* b) {
+  const int64_t gp = (g + 127) / 128 * 128;
+  b->gram = ws.take<long long>((size_t)gp * gp);
+  b->colsum = ws.take<long long>((size_t)gp);
+  b->v32 = ws.take<float>((size_t)g * k);
+  b->shift = ws.take<float>((size_t)k + 8);
+  b->gram_ws_bytes = scamd_csr_gram_workspace_bytes(n, g);
+  b->gram_ws = ws.take<char>(b->gram_ws_bytes);
+  b->solve_ws_bytes = scamd_pca_solve_gram_workspace_bytes(g, k);
+  b->solve_ws = ws.take<char>(b->solve_ws_bytes);
 }
 }  // namespace scamd
 
@@ -929,55 +1040,28 @@ extern "C" int scamd_pca_csr_f32(const int64_t* indptr, const int32_t* indices, 
   rc = scamd_csr_gram_f32(indptr, indices, data, n, g, nnz, scale_bits, reinterpret_cast<int64_t*>(b.gram), gp,
                           reinterpret_cast<int64_t*>(b.colsum), nullptr, b.gram_ws, b.gram_ws_bytes, s);
   if (rc != SCAMD_OK) return rc;
-  // 3. A = G - n mu mu^T, means, column variances
-  const double inv = std::ldexp(1.0, -scale_bits);
-  hipLaunchKernelGGL(cov_from_gram_kernel, dim3((unsigned)(((int64_t)g * g + 255) / 256)), dim3(256), 0, s, b.gram, gp,
-                     b.colsum, (int)g, inv, (double)n, zero_center ? 1 : 0, b.a, mean, b.var);
-  SCAMD_LAUNCH_CHECK();
-  // 4. top-k eigenpairs
-  const int bsz = dense_block_size(g, k);
-  SCAMD_REQUIRE((bsz == g || k + 32 <= bsz) && (bsz == g || g >= 2 * bsz), SCAMD_EUNSUPPORTED,
-                "pca: n_comps=%d / g=%lld outside the device eigensolver's range", k, (long long)g);
-  DenseCtx cx;
-  cx.s = s;
-  cx.a = b.a;
-  cx.lda = g;
-  cx.g = (int)g;
-  cx.b = bsz;
-  Workspace dws(b.dense_ws, b.dense_ws_bytes);
-  dense_carve(dws, g, bsz, &cx.d);
-  int n_outer = 0;
+  // 3-5, 7. the dense half (shared with the row-sharded route)
+  Workspace sws(b.solve_ws, b.solve_ws_bytes);
+  PcaSolveBuffers sb;
+  pca_solve_carve(sws, g, k, &sb);
+  int n_outer = 0, n_gemm = 0, bsz = 0, n_chol = 0;
   double resid = 0.0;
-  rc = dense_topk(cx, k, (unsigned int)(seed ^ (seed >> 32)) * 0x9E3779B1u + 12345u, tol, &n_outer, &resid);
+  rc = pca_solve_gram(b.gram, gp, b.colsum, n, g, scale_bits, k, zero_center, (unsigned int)(seed ^ (seed >> 32)) * 0x9E3779B1u + 12345u,
+                      tol, components, b.v32, b.shift, variance, variance_ratio, mean, nullptr, sb, s, &n_outer, &resid, &n_gemm, &bsz,
+                      &n_chol);
   if (rc != SCAMD_OK) return rc;
-  // 5. sign convention, float32 loadings, projected means
-  hipLaunchKernelGGL(finalize_components_kernel, dim3(k), dim3(256), 0, s, cx.d.z[3], (int)g, bsz, k, components, b.v32);
-  SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(mean_shift_kernel, dim3(k), dim3(256), 0, s, mean, b.v32, (int)g, k, b.shift, b.proj);
-  SCAMD_LAUNCH_CHECK();
   // 6. scores = X V - 1 shift^T
   rc = scamd_spmm_csr_f32(indptr, indices, data, n, g, b.v32, k, zero_center ? b.shift : nullptr, scores, s);
   if (rc != SCAMD_OK) return rc;
-  // 7. explained variance (sklearn: S^2 / (n - 1); ratio against the total variance with the same n / (n - 1) factor;
-  //    zero_center = False is TruncatedSVD: variance of the scores is not what this entry returns -- lam / n there)
-  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1), 0, s, b.var, (int)g, b.varsum);
-  SCAMD_LAUNCH_CHECK();
-  const double denom = zero_center ? (double)(n - 1) : (double)n;
-  const double total_scale = zero_center ? (double)n / (double)(n - 1) : 1.0;
-  hipLaunchKernelGGL(variance_kernel, dim3(1), dim3(256), 0, s, cx.d.theta, k, denom,
-                     zero_center ? (const double*)nullptr : (const double*)b.proj, b.varsum, total_scale, variance,
-                     variance_ratio);
-  SCAMD_LAUNCH_CHECK();
   SCAMD_HIP_CHECK(hipStreamSynchronize(s));
   if (info_host) {
     info_host[0] = n_outer;
-    info_host[1] = cx.n_gemm;
+    info_host[1] = n_gemm;
     info_host[2] = bsz;
-    info_host[3] = cx.n_chol_retry;
+    info_host[3] = n_chol;
     memcpy(info_host + 4, &resid, sizeof(double));
     info_host[6] = scale_bits;
     info_host[7] = 0;
   }
   return SCAMD_OK;
 }
-

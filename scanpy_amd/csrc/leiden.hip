@@ -186,6 +186,48 @@ __global__ void ld_fill_u8_kernel(unsigned char* __restrict__ a, int n, unsigned
   if (i < n) a[i] = v;
 }
 
+// Clears of the orchestration (round 6).  Every hipMemsetAsync / device-to-device hipMemcpyAsync is a blit kernel of the
+// runtime (`__amd_rocclr_fillBufferAligned` / `__amd_rocclr_copyBuffer`: 365 launches and 4.35 ms per pass of the path in the
+// round-5 profile).  What could not be folded into a kernel that is launched anyway (per-vertex initialisations, the counter
+// blocks of the next sweep) goes through ONE launch of this kernel per phase: up to six regions, each filled with its own
+// 32-bit pattern (0, 0x7f7f7f7f = the `memset 0x7f` sentinel of the atomicMin targets, 0xffffffff).
+struct FillArgs {
+  static constexpr int MAX_REGIONS = 6;
+  unsigned int* p[MAX_REGIONS];
+  unsigned long long words[MAX_REGIONS];
+  unsigned int pat[MAX_REGIONS];
+  int n;
+};
+__global__ __launch_bounds__(256) void ld_fill_kernel(FillArgs a) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * 256ull + threadIdx.x, stride = (unsigned long long)gridDim.x * 256ull;
+  for (int r = 0; r < a.n; ++r) {
+    const unsigned long long words = a.words[r];
+    const unsigned int pat = a.pat[r];
+    unsigned int* __restrict__ p = a.p[r];
+    // (regions are carved on 256-byte boundaries: whole 16-byte stores, then the tail)
+    if ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+      const unsigned long long quads = words >> 2;
+      uint4* __restrict__ q = reinterpret_cast<uint4*>(p);
+      for (unsigned long long i = t; i < quads; i += stride) q[i] = make_uint4(pat, pat, pat, pat);
+      for (unsigned long long i = (quads << 2) + t; i < words; i += stride) p[i] = pat;
+    } else {
+      for (unsigned long long i = t; i < words; i += stride) p[i] = pat;
+    }
+  }
+}
+// start of an outer iteration: comm = the partition it starts from, node_of = identity
+__global__ void ld_iter_init_kernel(int n, const int* __restrict__ memb, int* __restrict__ comm, int* __restrict__ node_of) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n) {
+    comm[v] = memb[v];
+    node_of[v] = v;
+  }
+}
+__global__ void ld_copy_i32_kernel(int n, const int* __restrict__ src, int* __restrict__ dst) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n) dst[v] = src[v];
+}
+
 // ---- block-local pre-aggregation of per-community reductions ---------------------------------------
 // Late in the optimisation a million vertices reduce into a few dozen communities: a global atomic per vertex
 // serialises on those few L2 lines (~12 ns each).  Every 1024-thread block first combines its vertices in an LDS
@@ -207,8 +249,10 @@ __device__ __forceinline__ int bh_find_slot(int* keys, int c) {
 
 // Ktot[c] = sum k[v], csize[c] = #members   (both zeroed by the caller)
 __global__ __launch_bounds__(1024) void ld_totals_kernel(const int* __restrict__ comm, const long long* __restrict__ k, int n,
-                                                         unsigned long long* __restrict__ Ktot, int* __restrict__ csize) {
+                                                         unsigned long long* __restrict__ Ktot, int* __restrict__ csize,
+                                                         unsigned long long* __restrict__ zero_me) {
   __shared__ int keys[BH_SLOTS];
+  if (zero_me && blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0ull;  // (the internal-weight accumulator of `quality`)
   __shared__ unsigned long long ksum[BH_SLOTS];
   __shared__ int cnt[BH_SLOTS];
   for (int i = threadIdx.x; i < BH_SLOTS; i += 1024) {
@@ -938,9 +982,13 @@ __device__ __forceinline__ void count_long_rows(int c, int cls, int tier, int la
 
 __global__ __launch_bounds__(1024) void ld_compact_cls_kernel(int n, int* __restrict__ flag, int* __restrict__ lists,
                                                               int* __restrict__ cls_count, int n_cls, unsigned int salt,
-                                                              const int64_t* __restrict__ indptr, int thr_mid, int thr_hub) {
+                                                              const int64_t* __restrict__ indptr, int thr_mid, int thr_hub,
+                                                              int* __restrict__ clear_next, int clear_words) {
   __shared__ int wcnt[16][MAX_CLASSES];
   __shared__ int base[MAX_CLASSES];
+  // (the counter block the NEXT sweep will count into: its last users were the sub-rounds of the sweep before this one)
+  if (clear_next && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < clear_words; i += 1024) clear_next[i] = 0;
   const int v = blockIdx.x * 1024 + threadIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int cls = -1;
@@ -1416,9 +1464,15 @@ __global__ void ld_refine_apply_kernel(int n_cand, const int* __restrict__ list,
 __global__ void ld_refine_init_kernel(int n, const long long* __restrict__ k, const long long* __restrict__ a_in,
                                       const int* __restrict__ comm, int* __restrict__ ref, int* __restrict__ refsize,
                                       unsigned long long* __restrict__ Kref, unsigned long long* __restrict__ Eref,
-                                      VertRec* __restrict__ vr, TargRec* __restrict__ tr) {
+                                      VertRec* __restrict__ vr, TargRec* __restrict__ tr, int* __restrict__ touched,
+                                      int* __restrict__ rc0, int rc0_words, int* __restrict__ counters) {
   int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0) {  // class list lengths + per-sub-round counters of this refinement, phase counters
+    for (int i = threadIdx.x; i < rc0_words; i += blockDim.x) rc0[i] = 0;
+    if (threadIdx.x < 8) counters[threadIdx.x] = 0;
+  }
   if (v < n) {
+    touched[v] = -1;  // join sub-round stamps: -1 = never
     ref[v] = v;
     refsize[v] = 1;
     Kref[v] = (unsigned long long)k[v];
@@ -1429,9 +1483,12 @@ __global__ void ld_refine_init_kernel(int n, const long long* __restrict__ k, co
 }
 
 // ---- phase 3: aggregation --------------------------------------------------------------------------
-__global__ void ld_flag_kernel(int n, const int* __restrict__ size, int* __restrict__ flag) {
+__global__ void ld_flag_kernel(int n, const int* __restrict__ size, int* __restrict__ flag, int* __restrict__ fill_max) {
   int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v < n) flag[v] = size[v] > 0 ? 1 : 0;
+  if (v < n) {
+    flag[v] = size[v] > 0 ? 1 : 0;
+    if (fill_max) fill_max[v] = 0x7f7f7f7f;  // (`rep`: the atomicMin target of ld_coarse_ids_kernel)
+  }
 }
 
 // coarse id of every node + representative coarse id of its phase-1 community (min over its members)
@@ -1460,9 +1517,12 @@ __global__ __launch_bounds__(1024) void ld_coarse_ids_kernel(int n, const int* _
     if (keys[i] != BH_EMPTY) atomicMin(&rep[keys[i]], mn[i]);
 }
 __global__ void ld_coarse_comm_kernel(int n, const int* __restrict__ cid, const int* __restrict__ comm,
-                                      const int* __restrict__ rep, int* __restrict__ comm_new) {
+                                      const int* __restrict__ rep, int* __restrict__ comm_new, int nn,
+                                      int* __restrict__ cursor, int* __restrict__ counters) {
   int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v < n) comm_new[cid[v]] = rep[comm[v]];
+  if (v < nn) cursor[v] = 0;  // (nn <= n: fill cursors of the member scatter)
+  if (v < 8) counters[v] = 0;
 }
 __global__ void ld_remap_kernel(int n_orig, const int* __restrict__ cid, int* __restrict__ node_of) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1797,9 +1857,11 @@ __global__ __launch_bounds__(256) void ld_agg_compact_kernel(int nn, const int64
                                                              const int64_t* __restrict__ indptr_new,
                                                              const int* __restrict__ s_col,
                                                              const long long* __restrict__ s_w,
-                                                             int* __restrict__ out_col, long long* __restrict__ out_w) {
+                                                             int* __restrict__ out_col, long long* __restrict__ out_w,
+                                                             int* __restrict__ dstat) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blockIdx.x == 0 && threadIdx.x < 4) dstat[threadIdx.x] = 0;  // (row-length statistics of the level being built: ld_degstats_kernel follows)
   if (c >= nn) return;
   const int64_t u0 = eoff[moff[c]];
   const int64_t p0 = indptr_new[c];
@@ -2423,9 +2485,9 @@ __global__ void ld_compact_label_kernel(int nc, const int* __restrict__ ids, int
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nc) newlabel[ids[i]] = i;
 }
-__global__ void ld_relabel_kernel(int n, const int* __restrict__ newlabel, int* __restrict__ memb) {
+__global__ void ld_relabel_kernel(int n, const int* __restrict__ newlabel, const int* memb, int* out) {
   int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v < n) memb[v] = newlabel[memb[v]];
+  if (v < n) out[v] = newlabel[memb[v]];  // (out may be memb itself)
 }
 __global__ void ld_gather_kernel(int n, const int* __restrict__ comm, const int* __restrict__ node_of,
                                  int* __restrict__ out) {
@@ -2457,7 +2519,7 @@ struct LeidenBuffers {
   int* ref; int* target; int* target2; int* refsize; unsigned long long* Kref; unsigned long long* Eref; long long* a_in;
   VertRec* vrec; TargRec* trec;  // packed mirrors of {comm, ref, stamp} and {Kref, Eref, refsize} for the refinement's gathers
   int* flag; int64_t* newid; int64_t* scan_tmp; int* cid; int* rep; int* comm_tmp;
-  int* node_of; int* memb; int* memb_best;
+  int* node_of; int* memb; int* memb_work;  // memb: the best partition so far = the input of the next iteration; memb_work: its output
   int* agg_col; long long* agg_w;  // scratch CSR of the coarse-graph build (rows at upper-bound offsets)
   int* mcount; int64_t* moff; int64_t* eoff; int* members; int* mdeg; int* mid_list; int* big_list;
   int64_t* pmoff; int* part_list; int* part_cnt;  // split rows of the coarse-graph build (ld_agg_parts_kernel)
@@ -2523,7 +2585,7 @@ static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b
   b->comm_tmp = ws.take<int>(N);
   b->node_of = ws.take<int>(N);
   b->memb = ws.take<int>(N);
-  b->memb_best = ws.take<int>(N);
+  b->memb_work = ws.take<int>(N);
   b->agg_col = ws.take<int>(E);
   b->agg_w = ws.take<long long>(E);
   b->mcount = ws.take<int>(N);
@@ -2542,7 +2604,7 @@ static void leiden_carve(Workspace& ws, int64_t n, int64_t nnz, LeidenBuffers* b
   b->rowcnt = ws.take<int>(N);
   b->cursor = ws.take<int>(N);
   b->counters = ws.take<int>(16);  // [0..7] phase counters, [8..11] row-length statistics of the level being built
-  b->rcounters = ws.take<int>(CTR_AREA);
+  b->rcounters = ws.take<int>(2 * CTR_AREA);  // two counter areas: the sweeps of the local moving alternate between them
   b->total = ws.take<unsigned long long>(4);
   b->dscratch = ws.take<double>(4 + SUMSQ_BLOCKS);
   b->ckeys = ws.take<unsigned long long>(N);
@@ -2620,23 +2682,50 @@ static bool g_leiden_debug_sync = false;
     }                                                         \
   } while (0)
 
+// one launch of ld_fill_kernel for up to FillArgs::MAX_REGIONS regions (byte counts are multiples of 4)
+struct Filler {
+  FillArgs a;
+  unsigned long long max_words = 0;
+  Filler() { a.n = 0; }
+  Filler& add(void* p, size_t bytes, unsigned int pat = 0u) {
+    if (bytes == 0) return *this;
+    a.p[a.n] = static_cast<unsigned int*>(p);
+    a.words[a.n] = bytes / 4;
+    a.pat[a.n] = pat;
+    max_words = std::max<unsigned long long>(max_words, a.words[a.n]);
+    ++a.n;
+    return *this;
+  }
+};
+static int run_fill(LeidenCtx& cx, const Filler& f) {
+  if (f.a.n == 0) return SCAMD_OK;
+  const unsigned grid = (unsigned)std::min<unsigned long long>(2048ull, std::max<unsigned long long>(1ull, (f.max_words / 4 + 255) / 256));
+  hipLaunchKernelGGL(ld_fill_kernel, dim3(grid), dim3(256), 0, cx.s, f.a);
+  SCAMD_LAUNCH_CHECK();
+  ++g_ld_stats[15];
+  return SCAMD_OK;
+}
+
 static int read_counters(LeidenCtx& cx, int* h, int cnt) {
   LD_FETCH(h, cx.b.counters, sizeof(int) * cnt, cx.s);
   LD_SYNC(cx.s);
   return SCAMD_OK;
 }
 
-static int compute_totals(LeidenCtx& cx, const LevelGraph& g, const int* comm) {
-  SCAMD_HIP_CHECK(hipMemsetAsync(cx.b.Ktot, 0, sizeof(unsigned long long) * g.n, cx.s));
-  SCAMD_HIP_CHECK(hipMemsetAsync(cx.b.csize, 0, sizeof(int) * g.n, cx.s));
-  hipLaunchKernelGGL(ld_totals_kernel, dim3((unsigned)std::min(REDUCE_GRID, ceil_div(g.n, 1024))), dim3(1024), 0, cx.s, comm, g.k, g.n, cx.b.Ktot, cx.b.csize);
+// Ktot / csize of `comm`; `extra`: further regions the caller wants cleared by the same launch
+static int compute_totals(LeidenCtx& cx, const LevelGraph& g, const int* comm, Filler extra = Filler()) {
+  extra.add(cx.b.Ktot, sizeof(unsigned long long) * g.n).add(cx.b.csize, sizeof(int) * g.n);
+  const int rcf = run_fill(cx, extra);
+  if (rcf != SCAMD_OK) return rcf;
+  hipLaunchKernelGGL(ld_totals_kernel, dim3((unsigned)std::min(REDUCE_GRID, ceil_div(g.n, 1024))), dim3(1024), 0, cx.s, comm, g.k, g.n, cx.b.Ktot, cx.b.csize,
+                     cx.b.total + 1);
   SCAMD_LAUNCH_CHECK();
   return SCAMD_OK;
 }
 
 // quality of `comm` on level graph g (needs Ktot up to date): modularity, or the CPM objective in the same units
+// (b.total[1], the accumulator of the internal weight, was zeroed by the ld_totals_kernel launch of compute_totals)
 static int quality(LeidenCtx& cx, const LevelGraph& g, const int* comm, double* q) {
-  SCAMD_HIP_CHECK(hipMemsetAsync(cx.b.total + 1, 0, sizeof(unsigned long long), cx.s));
   if (g.nnz <= (int64_t)48 * g.n)
     hipLaunchKernelGGL(ld_internal_kernel<16>, dim3((unsigned)std::min(2048, ceil_div(g.n, 16))), dim3(256), 0, cx.s, g.n,
                        g.indptr, g.indices, g.wq, comm, cx.b.total + 1);
@@ -2694,23 +2783,24 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
   LeidenBuffers& b = cx.b;
   const double gg = cx.gscale();
   *total_moves = 0;
-  int rc = compute_totals(cx, g, b.comm);
-  if (rc != SCAMD_OK) return rc;
   const size_t n = (size_t)g.n;
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.flag, 0, sizeof(int) * n, cx.s));
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));  // [0] moved, [1] blocked (cumulative), [7] error
+  // (one clear launch: totals, re-queue flags, phase counters ([0] moved, [1] blocked (cumulative), [7] error), the counter
+  // area of sweep 0 -- every later sweep's area is cleared by the ld_compact_cls_kernel launch of the sweep before it)
+  int rc = compute_totals(cx, g, b.comm, Filler().add(b.flag, sizeof(int) * n).add(b.counters, sizeof(int) * 8).add(b.rcounters, sizeof(int) * CTR_AREA));
+  if (rc != SCAMD_OK) return rc;
   const int lanes = level_lanes(g);
   const int thr_mid = lanes == 16 ? (int)(WH_SLOTS / 4 * 3 / 4) : (lanes == 32 ? (int)(WH_SLOTS / 2 * 3 / 4) : -1);
   const int n_cls_level = lm_classes(cx, g.n);
   int n_act_prev = g.n;
-  int* sw = b.rcounters;  // [0, MAX_CLASSES): class list lengths of the sweep; then one block per sub-round: hub / overflow counts
   int moved_before = 0, quiet = 0, moved_prev2 = 0;
   for (int sweep = 0; sweep < MAX_LM_SWEEPS; ++sweep) {
     const int n_cls = (sweep > 0 && n_act_prev <= cx.small_sweep_act) ? std::min(n_cls_level, cx.small_sweep_classes) : n_cls_level;
-    SCAMD_HIP_CHECK(hipMemsetAsync(sw, 0, sizeof(int) * (MAX_CLASSES + CTR_STRIDE * n_cls), cx.s));
+    // [0, MAX_CLASSES): class list lengths of the sweep; then one block per sub-round: hub / overflow counts
+    int* sw = b.rcounters + (sweep & 1) * CTR_AREA;
     const unsigned int salt = hash32(cx.seed + 0x85EBCA77u * (unsigned int)(sweep + 1) + 0xC2B2AE3Du * (unsigned int)cx.iter);
     hipLaunchKernelGGL(ld_compact_cls_kernel, dim3((unsigned)ceil_div(g.n, 1024)), dim3(1024), 0, cx.s, g.n,
-                       sweep == 0 ? (int*)nullptr : b.flag, b.cls_lists, sw, n_cls, salt, g.indptr, thr_mid, (int)WH_MAX_DEG);
+                       sweep == 0 ? (int*)nullptr : b.flag, b.cls_lists, sw, n_cls, salt, g.indptr, thr_mid, (int)WH_MAX_DEG,
+                       b.rcounters + ((sweep + 1) & 1) * CTR_AREA, (int)CTR_AREA);
     SCAMD_LAUNCH_CHECK();
     int hc[CTR_AREA], ht[8];  // class list lengths, then per sub-round [CTR_N_MID] / [CTR_N_HUB]: long rows of the class
     LD_FETCH(hc, sw, sizeof(int) * (MAX_CLASSES + CTR_STRIDE * n_cls), cx.s);
@@ -2853,7 +2943,10 @@ static int split_disconnected(LeidenCtx& cx, const LevelGraph& g, int* n_split) 
   hipLaunchKernelGGL(ld_iota_kernel, GRID1(g.n), 0, cx.s, b.cid, g.n);
   SCAMD_LAUNCH_CHECK();
   for (int it = 0; it < g.n; ++it) {
-    SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 2, 0, sizeof(int) * 3, cx.s));
+    {
+      const int rcf = run_fill(cx, Filler().add(b.counters + 2, sizeof(int) * 3));
+      if (rcf != SCAMD_OK) return rcf;
+    }
     // (several propagation steps per host round trip: the flag only says whether any of them changed something)
     for (int rep = 0; rep < 4; ++rep) {
       hipLaunchKernelGGL(ld_cc_prop_kernel, dim3((unsigned)ceil_div(g.n, 16)), dim3(256), 0, cx.s, g.n, g.indptr, g.indices,
@@ -2873,7 +2966,7 @@ static int split_disconnected(LeidenCtx& cx, const LevelGraph& g, int* n_split) 
   *n_split = cnt[0] - cnt[1];
   if (leiden_debug()) fprintf(stderr, "[leiden] components %d, communities %d\n", cnt[0], cnt[1]);
   if (*n_split > 0) {
-    SCAMD_HIP_CHECK(hipMemcpyAsync(b.comm, b.cid, sizeof(int) * g.n, hipMemcpyDeviceToDevice, cx.s));
+    std::swap(b.comm, b.cid);  // (the component labels ARE the new partition; b.cid is scratch)
     return compute_totals(cx, g, b.comm);
   }
   return SCAMD_OK;
@@ -2886,26 +2979,27 @@ static int polish_level0(LeidenCtx& cx, const LevelGraph& g, int* stats) {
   const double gg = cx.gscale();
   const size_t n = (size_t)g.n;
   stats[0] = stats[1] = stats[2] = stats[3] = 0;
-  SCAMD_HIP_CHECK(hipMemcpyAsync(b.comm, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
-  int rc = compute_totals(cx, g, b.comm);
-  if (rc != SCAMD_OK) return rc;
+  // the polish works on b.comm in place: the partition changes buffers instead of being copied (b.comm <-> b.memb now and
+  // back at the end; what b.comm held is scratch between iterations)
+  std::swap(b.comm, b.memb);
   unsigned long long* lock = b.Kref;
-  SCAMD_HIP_CHECK(hipMemsetAsync(lock, 0, sizeof(unsigned long long) * n, cx.s));
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.flag, 0, sizeof(int) * n, cx.s));
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
+  int rc = compute_totals(cx, g, b.comm, Filler().add(lock, sizeof(unsigned long long) * n).add(b.flag, sizeof(int) * n).add(b.counters, sizeof(int) * 8)
+                                              .add(b.rcounters, sizeof(int) * CTR_AREA));
+  if (rc != SCAMD_OK) return rc;  // (cx.b lives for this call only: an error return need not swap back)
   const int lanes = level_lanes(g);
   const int thr_mid = lanes == 16 ? (int)(WH_SLOTS / 4 * 3 / 4) : (lanes == 32 ? (int)(WH_SLOTS / 2 * 3 / 4) : -1);
-  int* sw = b.rcounters;
-  int* ctr = sw + MAX_CLASSES;  // counter block of the one class
-  unsigned int round = 0;
+  unsigned int round = 0, area = 0;  // (the rounds alternate between the two counter areas, as the sweeps of the local moving do)
   int moved_before = 0, moved_at_full = 0;
   int checked_at = 0;  // moves + splits when the communities were last known to be connected (the input is: an iteration's result)
   bool full = true;  // the next round decides for every vertex (else: for the flagged ones)
   for (;;) {
-    SCAMD_HIP_CHECK(hipMemsetAsync(sw, 0, sizeof(int) * (MAX_CLASSES + CTR_STRIDE), cx.s));
+    int* sw = b.rcounters + (area & 1u) * CTR_AREA;
+    int* ctr = sw + MAX_CLASSES;  // counter block of the one class
     hipLaunchKernelGGL(ld_compact_cls_kernel, dim3((unsigned)ceil_div(g.n, 1024)), dim3(1024), 0, cx.s, g.n,
-                       full ? (int*)nullptr : b.flag, b.cls_lists, sw, 1, 0u, g.indptr, thr_mid, (int)WH_MAX_DEG);
+                       full ? (int*)nullptr : b.flag, b.cls_lists, sw, 1, 0u, g.indptr, thr_mid, (int)WH_MAX_DEG,
+                       b.rcounters + ((area + 1u) & 1u) * CTR_AREA, (int)(MAX_CLASSES + CTR_STRIDE));
     SCAMD_LAUNCH_CHECK();
+    ++area;
     int hc[MAX_CLASSES + CTR_STRIDE], ht[8];
     LD_FETCH(hc, sw, sizeof(hc), cx.s);
     LD_FETCH(ht, b.counters, sizeof(ht), cx.s);
@@ -2980,7 +3074,7 @@ static int polish_level0(LeidenCtx& cx, const LevelGraph& g, int* stats) {
                        (const int*)b.comm, b.flag);
     SCAMD_LAUNCH_CHECK();
   }
-  if (stats[2] + stats[3] > 0) SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb, b.comm, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+  std::swap(b.comm, b.memb);  // the polished partition (or, when nothing moved, the one that came in) is b.memb again
   return SCAMD_OK;
 }
 
@@ -2998,14 +3092,12 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
   else
     hipLaunchKernelGGL(ld_within_kernel<64>, GRIDW(g.n), 0, cx.s, g.n, g.indptr, g.indices, g.wq, b.comm, b.a_in);
   SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ld_refine_init_kernel, GRID1(g.n), 0, cx.s, g.n, g.k, b.a_in, b.comm, b.ref, b.refsize, b.Kref,
-                     b.Eref, b.vrec, b.trec);
-  SCAMD_LAUNCH_CHECK();
   const int n_cls = rf_classes(cx, g.n);
   int* rc0 = b.rcounters;  // [0, MAX_CLASSES): class list lengths; then per sub-round c: [0] joiners, [4] hubs, [5] overflow
-  SCAMD_HIP_CHECK(hipMemsetAsync(rc0, 0, sizeof(int) * (MAX_CLASSES + CTR_STRIDE * n_cls), cx.s));
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.touched, 0xff, sizeof(int) * n, cx.s));  // join sub-round stamps: -1 = never
+  // (also clears rc0, the phase counters and the join stamps b.touched: three memsets until round 6)
+  hipLaunchKernelGGL(ld_refine_init_kernel, GRID1(g.n), 0, cx.s, g.n, g.k, b.a_in, b.comm, b.ref, b.refsize, b.Kref,
+                     b.Eref, b.vrec, b.trec, b.touched, rc0, (int)(MAX_CLASSES + CTR_STRIDE * n_cls), b.counters);
+  SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(ld_refine_candidates_kernel, dim3((unsigned)ceil_div(g.n, 1024)), dim3(1024), 0, cx.s, g.n, g.k,
                      b.comm, b.Ktot, b.a_in, gg, b.cls_lists, rc0, n_cls, salt, g.indptr,
                      quad ? (int)(WH_SLOTS / 4 * 3 / 4) : -1, (int)WH_MAX_DEG);
@@ -3088,7 +3180,7 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
 // and b.node_of.  Returns the new node count in *n_new (== g.n means nothing merged: no graph built).
 static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, LevelGraph* out, int* n_new) {
   LeidenBuffers& b = cx.b;
-  hipLaunchKernelGGL(ld_flag_kernel, GRID1(g.n), 0, cx.s, g.n, b.refsize, b.flag);
+  hipLaunchKernelGGL(ld_flag_kernel, GRID1(g.n), 0, cx.s, g.n, b.refsize, b.flag, b.rep);  // (+ b.rep = the atomicMin sentinel)
   SCAMD_LAUNCH_CHECK();
   int rc = exclusive_scan_i32_i64(b.flag, g.n, b.newid, b.scan_tmp, cx.s);
   if (rc != SCAMD_OK) return rc;
@@ -3097,16 +3189,14 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   LD_SYNC(cx.s);
   *n_new = (int)nn;
   if (nn == g.n) return SCAMD_OK;
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.rep, 0x7f, sizeof(int) * g.n, cx.s));
   hipLaunchKernelGGL(ld_coarse_ids_kernel, GRIDK(g.n), 0, cx.s, g.n, b.ref, b.newid, b.comm, b.cid, b.rep);
   SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ld_coarse_comm_kernel, GRID1(g.n), 0, cx.s, g.n, b.cid, b.comm, b.rep, b.comm_tmp);
+  // (+ the cursors of the member scatter and the phase counters cleared: two memsets until round 6)
+  hipLaunchKernelGGL(ld_coarse_comm_kernel, GRID1(g.n), 0, cx.s, g.n, b.cid, b.comm, b.rep, b.comm_tmp, (int)nn, b.cursor, b.counters);
   SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(ld_remap_kernel, GRID1(n_orig), 0, cx.s, n_orig, b.cid, b.node_of);
   SCAMD_LAUNCH_CHECK();
   // group the members of every coarse node, then combine their rows per coarse node in LDS
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.cursor, 0, sizeof(int) * nn, cx.s));
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
   hipLaunchKernelGGL(ld_agg_mcount_kernel, GRID1(g.n), 0, cx.s, g.n, b.refsize, b.newid, b.mcount);
   SCAMD_LAUNCH_CHECK();
   rc = exclusive_scan_i32_i64(b.mcount, nn, b.moff, b.scan_tmp, cx.s);
@@ -3167,25 +3257,25 @@ static int aggregate(LeidenCtx& cx, const LevelGraph& g, int n_orig, int dst, Le
   // the order of a row's entries is arbitrary: nothing downstream depends on it (all sums are integer, every
   // choice is an argmax under a total order)
   hipLaunchKernelGGL(ld_agg_compact_kernel, GRIDW(inn), 0, cx.s, inn, b.moff, b.eoff, cb.indptr, b.agg_col, b.agg_w,
-                     cb.indices, cb.wq);
+                     cb.indices, cb.wq, b.counters + 8);  // (+ clears the row-length statistics ld_degstats_kernel adds to)
   SCAMD_LAUNCH_CHECK();
   int64_t nnz_new = 0;
   int dstat[4] = {0, 0, 0, 0};
   int agg_err = 0;
   LD_FETCH(&agg_err, b.counters + 7, sizeof(int), cx.s);
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 8, 0, sizeof(int) * 4, cx.s));
   hipLaunchKernelGGL(ld_degstats_kernel, GRIDK(nn), 0, cx.s, cb.indptr, (int)nn, b.counters + 8);
   SCAMD_LAUNCH_CHECK();
   LD_FETCH(dstat, b.counters + 8, sizeof(int) * 4, cx.s);
   LD_FETCH(&nnz_new, cb.indptr + nn, sizeof(int64_t), cx.s);
   if (cx.cpm) {  // sizes add up over the members; strengths are the row sums of the coarse graph
-    SCAMD_HIP_CHECK(hipMemsetAsync(cb.k, 0, sizeof(long long) * nn, cx.s));
+    rc = run_fill(cx, Filler().add(cb.k, sizeof(long long) * nn));
+    if (rc != SCAMD_OK) return rc;
     hipLaunchKernelGGL(ld_agg_nodeweight_kernel, GRID1(g.n), 0, cx.s, g.n, (const int*)b.cid, g.k, cb.k);
   } else {
     hipLaunchKernelGGL(ld_strength_kernel, GRIDW(nn), 0, cx.s, cb.indptr, cb.wq, (int)nn, cb.k);
   }
   SCAMD_LAUNCH_CHECK();
-  SCAMD_HIP_CHECK(hipMemcpyAsync(b.comm, b.comm_tmp, sizeof(int) * nn, hipMemcpyDeviceToDevice, cx.s));
+  std::swap(b.comm, b.comm_tmp);  // (the coarse phase-1 partition ld_coarse_comm_kernel wrote is b.comm from here on)
   LD_SYNC(cx.s);
   SCAMD_REQUIRE(agg_err == 0, SCAMD_EINTERNAL, "leiden: coarse-row table overflow");
   out->n = (int)nn;
@@ -3243,10 +3333,10 @@ static int small_levels(LeidenCtx& cx, const LevelGraph& g, int level) {
   return SCAMD_OK;
 }
 
+// (from the partition in b.memb; the result goes to b.memb_work)
 static int leiden_iteration(LeidenCtx& cx, const LevelGraph& g0) {
   LeidenBuffers& b = cx.b;
-  SCAMD_HIP_CHECK(hipMemcpyAsync(b.comm, b.memb, sizeof(int) * g0.n, hipMemcpyDeviceToDevice, cx.s));
-  hipLaunchKernelGGL(ld_iota_kernel, GRID1(g0.n), 0, cx.s, b.node_of, g0.n);
+  hipLaunchKernelGGL(ld_iter_init_kernel, GRID1(g0.n), 0, cx.s, g0.n, (const int*)b.memb, b.comm, b.node_of);
   SCAMD_LAUNCH_CHECK();
   LevelGraph g = g0;
   cx.l0_moves = -1;  // (a graph small enough to start in the one-workgroup kernel reports no level-0 count)
@@ -3281,19 +3371,21 @@ static int leiden_iteration(LeidenCtx& cx, const LevelGraph& g0) {
     if (n_new == g.n) break;
     g = gn;
   }
-  hipLaunchKernelGGL(ld_gather_kernel, GRID1(g0.n), 0, cx.s, g0.n, b.comm, b.node_of, b.memb);
+  hipLaunchKernelGGL(ld_gather_kernel, GRID1(g0.n), 0, cx.s, g0.n, b.comm, b.node_of, b.memb_work);
   SCAMD_LAUNCH_CHECK();
   return SCAMD_OK;
 }
 
-// relabel b.memb (values < n) to consecutive ids ordered by (size desc, first member asc)
-static int renumber(LeidenCtx& cx, int n, int* n_comm) {
+// b.memb (values < n) relabelled to consecutive ids ordered by (size desc, first member asc) -> out (the caller's buffer)
+static int renumber(LeidenCtx& cx, int n, int* n_comm, int* out) {
   LeidenBuffers& b = cx.b;
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.minmember, 0x7f, sizeof(int) * n, cx.s));
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.csize, 0, sizeof(int) * n, cx.s));
+  {
+    const int rcf = run_fill(cx, Filler().add(b.minmember, sizeof(int) * n, 0x7f7f7f7fu).add(b.csize, sizeof(int) * n));
+    if (rcf != SCAMD_OK) return rcf;
+  }
   hipLaunchKernelGGL(ld_minmember_kernel, dim3((unsigned)std::min(REDUCE_GRID, ceil_div(n, 1024))), dim3(1024), 0, cx.s, n, b.memb, b.minmember, b.csize);
   SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ld_flag_kernel, GRID1(n), 0, cx.s, n, b.csize, b.flag);
+  hipLaunchKernelGGL(ld_flag_kernel, GRID1(n), 0, cx.s, n, b.csize, b.flag, (int*)nullptr);
   SCAMD_LAUNCH_CHECK();
   int rc = exclusive_scan_i32_i64(b.flag, n, b.newid, b.scan_tmp, cx.s);
   if (rc != SCAMD_OK) return rc;
@@ -3309,7 +3401,7 @@ static int renumber(LeidenCtx& cx, int n, int* n_comm) {
     hipLaunchKernelGGL(ld_compact_label_kernel, GRID1(nc), 0, cx.s, (int)nc, b.cids, b.newlabel);
   }
   SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ld_relabel_kernel, GRID1(n), 0, cx.s, n, b.newlabel, b.memb);
+  hipLaunchKernelGGL(ld_relabel_kernel, GRID1(n), 0, cx.s, n, b.newlabel, (const int*)b.memb, out);
   SCAMD_LAUNCH_CHECK();
   *n_comm = (int)nc;
   return SCAMD_OK;
@@ -3322,12 +3414,14 @@ static int setup_level0(LeidenCtx& cx, const int64_t* indptr, const int32_t* ind
     hipLaunchKernelGGL(ld_quantize_kernel, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, cx.s, weights, nnz, b.wq0);
     SCAMD_LAUNCH_CHECK();
   }
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.total, 0, sizeof(unsigned long long) * 4, cx.s));
+  {
+    const int rcf = run_fill(cx, Filler().add(b.total, sizeof(unsigned long long) * 4).add(b.counters, sizeof(int) * 16));
+    if (rcf != SCAMD_OK) return rcf;
+  }
   hipLaunchKernelGGL(ld_strength_kernel, GRIDW(n), 0, cx.s, indptr, b.wq0, (int)n, b.k0);
   SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(ld_sum_kernel, dim3(256), dim3(256), 0, cx.s, b.k0, (int)n, b.total);
   SCAMD_LAUNCH_CHECK();
-  SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 8, 0, sizeof(int) * 4, cx.s));
   hipLaunchKernelGGL(ld_degstats_kernel, GRIDK(n), 0, cx.s, indptr, (int)n, b.counters + 8);
   SCAMD_LAUNCH_CHECK();
   unsigned long long tot = 0;
@@ -3347,7 +3441,7 @@ static int setup_level0(LeidenCtx& cx, const int64_t* indptr, const int32_t* ind
   g0->wq = b.wq0;
   g0->k = b.k0;
   if (cx.cpm && cx.node_weights) {
-    SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
+    // (b.counters[7] is zero: cleared above, nothing has raised it since)
     hipLaunchKernelGGL(ld_nodeweight_quantize_kernel, GRID1(n), 0, cx.s, cx.node_weights, (int)n, b.k0, b.counters + 7);
     SCAMD_LAUNCH_CHECK();
     int bad = 0;
@@ -3505,7 +3599,7 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
   if (rc != SCAMD_OK) return rc;
   LeidenBuffers& b = cx.b;
   if (initial_membership) {
-    SCAMD_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(int) * 8, cx.s));
+    // (b.counters[7] is zero: setup_level0 cleared the counters and checked whatever it raised)
     hipLaunchKernelGGL(ld_copy_membership_kernel, GRID1(n), 0, cx.s, (int)n, initial_membership, b.memb, b.counters + 7);
     SCAMD_LAUNCH_CHECK();
     int bad = 0;
@@ -3521,7 +3615,8 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
     rc = compute_totals(cx, g0, b.memb);
     if (rc == SCAMD_OK) rc = quality(cx, g0, b.memb, &q_best);
     if (rc != SCAMD_OK) return rc;
-    SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb_best, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+    // b.memb is ALWAYS the best partition seen (the input of the next iteration); an iteration writes into b.memb_work and
+    // the two change places when it improved -- no copies (round 5: two 4-byte-per-vertex blits per iteration)
     int iter_cap = MAX_OUTER_ITERS;
     if (const char* e = getenv("SCAMD_LEIDEN_ITER_CAP"))
       if (atoi(e) > 0) iter_cap = atoi(e);
@@ -3531,7 +3626,7 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
     if (const char* e = getenv("SCAMD_LEIDEN_MAX_ITERS"))
       if (n_iterations < 0 && atoi(e) > 0) max_iter = std::min(max_iter, atoi(e));
     int bad_iters = 0;
-    // true once b.memb_best has been the INPUT of an iteration whose level-0 local moving found nothing to move: its
+    // true once b.memb has been the INPUT of an iteration whose level-0 local moving found nothing to move: its
     // first sweep decides for every vertex on the final state, so that is a proof of node optimality
     bool best_is_clean = false;
     bool ended_by_cap = true;  // the loop below ran out of iterations (n_iterations < 0: MAX_OUTER_ITERS) instead of converging
@@ -3542,8 +3637,8 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
       if (rc != SCAMD_OK) return rc;
       if (it == 0) g_ld_stats[7] = cx.n_levels;
       double q = 0.0;
-      rc = compute_totals(cx, g0, b.memb);
-      if (rc == SCAMD_OK) rc = quality(cx, g0, b.memb, &q);
+      rc = compute_totals(cx, g0, b.memb_work);
+      if (rc == SCAMD_OK) rc = quality(cx, g0, b.memb_work, &q);
       if (rc != SCAMD_OK) return rc;
       const bool improved = q > q_best + 1e-12;
       const bool worse = q < q_best - 1e-12;
@@ -3552,11 +3647,10 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
         q_best = q;
         bad_iters = 0;
         best_is_clean = false;
-        SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb_best, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+        std::swap(b.memb, b.memb_work);
       } else {
         if (cx.l0_moves == 0) best_is_clean = true;
-        // synchronous moves and the randomised refinement are not monotone: keep the best partition seen
-        SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb, b.memb_best, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+        // synchronous moves and the randomised refinement are not monotone: the best partition seen stays in b.memb
       }
       // n_iterations < 0: until an iteration changes nothing (leidenalg: `while diff_inc > 0`).  An iteration that
       // reproduces the best quality exactly found nothing to move -> done.  One that came out WORSE was unlucky in its
@@ -3583,7 +3677,6 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
         if (pr == 0) g_ld_stats[6] = 1;
         break;
       }
-      // (b.memb == b.memb_best here: every iteration ends with one copied onto the other)
       int ps[4] = {0, 0, 0, 0};
       rc = polish_level0(cx, g0, ps);
       if (rc != SCAMD_OK) return rc;
@@ -3600,7 +3693,6 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
         fprintf(stderr, "[leiden] polish %d: %d full sweeps, %d rounds, %d moves: Q %.10f -> %.10f\n", pr, ps[0], ps[1], ps[2], q_best, q);
       SCAMD_REQUIRE(q >= q_best - 1e-12, SCAMD_EINTERNAL, "leiden: the monotone polish lowered the quality (%.12f -> %.12f)", q_best, q);
       q_best = q;
-      SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb_best, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
       // (the last pass only polishes what the last accepted iteration left.  A run that the iteration cap ended was still
       // gaining a little with every iteration -- structure-less graphs do that for dozens of iterations: there is no stable
       // partition to verify, the polished one is node optimal and connected, and that is what is returned)
@@ -3609,16 +3701,15 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
       g_ld_stats[0] = n_iter_total;
       rc = leiden_iteration(cx, g0);
       if (rc != SCAMD_OK) return rc;
-      rc = compute_totals(cx, g0, b.memb);
-      if (rc == SCAMD_OK) rc = quality(cx, g0, b.memb, &q);
+      rc = compute_totals(cx, g0, b.memb_work);
+      if (rc == SCAMD_OK) rc = quality(cx, g0, b.memb_work, &q);
       if (rc != SCAMD_OK) return rc;
       if (leiden_debug()) fprintf(stderr, "[leiden] iteration after polish %d: Q = %.10f (polished %.10f), level-0 moves %d\n", pr, q, q_best, cx.l0_moves);
       if (q > q_best + 1e-12) {
         q_best = q;
-        SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb_best, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+        std::swap(b.memb, b.memb_work);
       } else {
-        SCAMD_HIP_CHECK(hipMemcpyAsync(b.memb, b.memb_best, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
-        break;  // stable: the polished partition stands
+        break;  // stable: the polished partition (b.memb) stands
       }
     }
   }
@@ -3634,9 +3725,8 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
     if (rc != SCAMD_OK) return rc;
   }
   int nc = 0;
-  rc = renumber(cx, (int)n, &nc);
+  rc = renumber(cx, (int)n, &nc, membership);  // (writes the caller's buffer directly)
   if (rc != SCAMD_OK) return rc;
-  SCAMD_HIP_CHECK(hipMemcpyAsync(membership, b.memb, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
   LD_SYNC(cx.s);
   if (modularity_host) *modularity_host = q_best;
   if (n_communities_host) *n_communities_host = nc;
@@ -3661,13 +3751,17 @@ extern "C" int scamd_leiden_debug_split_f32(const int64_t* indptr, const int32_t
   LevelGraph g0;
   int rc = setup_level0(cx, indptr, indices, weights, n, nnz, &g0);
   if (rc != SCAMD_OK) return rc;
-  SCAMD_HIP_CHECK(hipMemcpyAsync(cx.b.comm, membership, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+  hipLaunchKernelGGL(ld_copy_i32_kernel, GRID1(n), 0, cx.s, (int)n, (const int*)membership, cx.b.comm);
+  SCAMD_LAUNCH_CHECK();
   rc = compute_totals(cx, g0, cx.b.comm);
   if (rc != SCAMD_OK) return rc;
   int n_split = 0;
   rc = split_disconnected(cx, g0, &n_split);
   if (rc != SCAMD_OK) return rc;
-  if (n_split > 0) SCAMD_HIP_CHECK(hipMemcpyAsync(membership, cx.b.comm, sizeof(int) * n, hipMemcpyDeviceToDevice, cx.s));
+  if (n_split > 0) {
+    hipLaunchKernelGGL(ld_copy_i32_kernel, GRID1(n), 0, cx.s, (int)n, (const int*)cx.b.comm, membership);
+    SCAMD_LAUNCH_CHECK();
+  }
   SCAMD_HIP_CHECK(hipStreamSynchronize(cx.s));
   *n_split_host = n_split;
   return SCAMD_OK;

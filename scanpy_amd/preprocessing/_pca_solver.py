@@ -168,6 +168,18 @@ class GpuBackend:
         # contiguous: the row shards all-reduce these tensors in place
         return gram[:g, :g].contiguous(), cs[:g].contiguous()
 
+    def gram_padded(self, a, scale_bits: int):
+        """-> (G int64 [gp, gp], colsum int64 [gp]), gp = ceil128(g): the kernel's own output, no slicing copy (the padding is
+        zero, so the padded tensors add up / all-reduce like the sliced ones)."""
+        ip, ix, dv, n, g = a
+        return self.K.csr_gram(ip, ix, dv, n, g, scale_bits)
+
+    def pca_solve_gram(self, gram_q, colsum_q, n_total: int, g: int, scale_bits: int, n_comps: int, *, zero_center: bool,
+                       seed: int, tol: float):
+        """The dense half of the Gram route as ONE C call (`scamd_pca_solve_gram_f64`)."""
+        return self.K.pca_solve_gram(gram_q, colsum_q, n_total, g, scale_bits, n_comps, zero_center=zero_center, seed=seed,
+                                     tol=tol)
+
 
 @dataclass
 class PCAResult:
@@ -465,13 +477,16 @@ def _pca_fit_gram(a, n_comps: int, backend, comm, zero_center: bool, seed: int, 
         absmax_local = 0.0
         for h in chunks.handles(backend):
             absmax_local = max(absmax_local, backend.absmax(h))
-    meta = torch.tensor([float(n_local), absmax_local], dtype=torch.float64, device=dev)
-    nt = meta[:1].clone()
-    mx = meta[1:].clone()
-    comm.allreduce_(nt)
-    comm.allreduce_max_(mx)
-    n = int(round(float(nt.item())))
-    absmax = float(mx.item())
+    if isinstance(comm, NoComm):  # one rank: nothing to reduce, no device round trip for two host numbers
+        n, absmax = int(n_local), float(absmax_local)
+    else:
+        meta = torch.tensor([float(n_local), absmax_local], dtype=torch.float64, device=dev)
+        nt = meta[:1].clone()
+        mx = meta[1:].clone()
+        comm.allreduce_(nt)
+        comm.allreduce_max_(mx)
+        n = int(round(float(nt.item())))
+        absmax = float(mx.item())
     if not 1 <= n_comps <= min(n, g):
         raise ValueError(f"n_components={n_comps!r} must be between 1 and min(n_samples, n_features)={min(n, g)!r} "
                          "with svd_solver='arpack'")
@@ -488,12 +503,65 @@ def _pca_fit_gram(a, n_comps: int, backend, comm, zero_center: bool, seed: int, 
     # (a negative S means even 2^0 overflows the int64 sums -- n * absmax^2 > 2^62 -- and is outside the C entry's range)
     if scale_bits < 0 or (absmax > 0.0 and scale_bits + 2.0 * np.log2(absmax) < 24.0):
         return None
-    gq = cq = None
-    for h in chunks.handles(backend):
-        gh, ch = backend.gram(h, scale_bits)
-        gq, cq = (gh, ch) if gq is None else (gq + gh, cq + ch)  # int64: exact, order independent
-    comm.allreduce_(gq)
-    comm.allreduce_(cq)
+    rng = np.random.default_rng(seed)
+    # Round 6: the dense half is ONE C call (`scamd_pca_solve_gram_f64`: covariance from the fixed-point sums, device
+    # eigensolver, sign convention, float32 loadings, projected means, variances) on the kernel's own padded Gram matrix --
+    # the same call for one rank and for row shards (after the all-reduce), so the model stays bitwise identical for any
+    # world size and no torch / rocBLAS kernel computes any part of it (round 5's profile: a Tensile GEMM and ~33
+    # at::native launches per pass came from the torch formulation below, which the CPU stand-in of the tests still runs).
+    b_dev = min(g, (n_comps + 32 + 15) // 16 * 16)
+    device_solver_ok = g <= 128 or (n_comps + 32 <= 128 and g >= 2 * b_dev)
+    gq = cq = solved = None
+    if hasattr(backend, "pca_solve_gram") and device_solver_ok:
+        for h in chunks.handles(backend):
+            gh, ch = backend.gram_padded(h, scale_bits)
+            gq, cq = (gh, ch) if gq is None else (gq + gh, cq + ch)  # int64: exact, order independent
+        comm.allreduce_(gq)
+        comm.allreduce_(cq)
+        import os
+
+        from .._lib import ScamdError
+
+        solved = None
+        try:
+            solved = backend.pca_solve_gram(gq, cq, n, g, scale_bits, n_comps, zero_center=zero_center,
+                                            seed=int(rng.integers(0, 2**31 - 1)), tol=tol)
+        except ScamdError as e:
+            # a block the device solver gives up on (numerically rank deficient: fewer cells than block columns; not
+            # converged).  Small matrices (g <= 384) then take the full decomposition below, as they always did; for larger
+            # ones that is an ERROR unless SCAMD_ALLOW_TORCH_FALLBACK=1 (round 5's rule for the eigensolver)
+            if g > 384 and os.environ.get("SCAMD_ALLOW_TORCH_FALLBACK") != "1":
+                raise ScamdError(f"{e} -- the device eigensolver gave up on this matrix; SCAMD_ALLOW_TORCH_FALLBACK=1 lets the "
+                                 "torch.linalg (rocSOLVER) formulation take over") from e
+            rng = np.random.default_rng(seed)
+    if hasattr(backend, "pca_solve_gram") and device_solver_ok and solved is not None:
+        comps, vf, shift_dev, ev, ratio, mean_dev, lam, dinfo = solved
+        info = {"solver": "gram", "scale_bits": scale_bits, "dense_solver": "chebyshev_subspace" if g > 128 else "jacobi", **dinfo}
+        parts = [backend.spmm(h, vf, shift_dev if zero_center else None) for h in chunks.handles(backend)]
+        scores = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+        info["n_operator_applications"] = 1
+        if chunks.n_chunks > 1:
+            info["row_chunks"] = chunks.n_chunks
+            info["chunks_resident"] = chunks.resident
+        # (one download of the small model pieces: 5 arrays of k or g numbers, k x g loadings)
+        return PCAResult(
+            scores=scores,
+            components=comps.cpu().numpy(),
+            explained_variance=ev.cpu().numpy(),
+            explained_variance_ratio=ratio.cpu().numpy(),
+            singular_values=np.sqrt(lam.cpu().numpy()),
+            mean=mean_dev.cpu().numpy() if zero_center else None,
+            n_samples=n,
+            info=info,
+        )
+    if gq is not None:  # (the padded sums of the attempt above)
+        gq, cq = gq[:g, :g].contiguous(), cq[:g].contiguous()
+    else:
+        for h in chunks.handles(backend):
+            gh, ch = backend.gram(h, scale_bits)
+            gq, cq = (gh, ch) if gq is None else (gq + gh, cq + ch)  # int64: exact, order independent
+        comm.allreduce_(gq)
+        comm.allreduce_(cq)
     inv = 2.0 ** -scale_bits
     gmat = gq.to(torch.float64) * inv
     colsum = cq.to(torch.float64) * inv
@@ -502,7 +570,6 @@ def _pca_fit_gram(a, n_comps: int, backend, comm, zero_center: bool, seed: int, 
     amat = gmat - n * torch.outer(mean, mean) if zero_center else gmat
     amat = 0.5 * (amat + amat.T)
     info = {"solver": "gram", "scale_bits": scale_bits}
-    rng = np.random.default_rng(seed)
     lam, v = _dense_topk_eigh(amat, n_comps, rng, tol, info)
     lam = torch.clamp(lam, min=0.0)
     v = _sign_flip(v)
