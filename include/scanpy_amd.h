@@ -103,6 +103,9 @@ int scamd_knn_last_select_engine(void);
  * pruned search; 0 when the count stayed below SCAMD_KNN_TIER2_MIN, default 256, or the float32 engine ran anyway).
  * `n_fallback_host` of scamd_knn_l2_f32 counts what went to the float64 scan after that. */
 int scamd_knn_last_second_tier_queries(void);
+/* cells probed by this thread's last search: 0 = it was answered EXACTLY -- also when scamd_knn_l2_ivf_f32 was asked for a
+ * shape its register-list kernel does not take (k > 24, d > 64, n < 4096); the Python layer tells the user. */
+int scamd_knn_last_nprobe(void);
 /* The certificate's error-bound factors of an engine (0 = float32, 1 = 3 x bf16), in units of u = 2^-24:
  *   |score_engine - score_exact| <= u * (cert_k * (||c||^2 + 2 ||q|| ||c||) + cert_k2 * 2 ||q|| ||c||) (+ key_slack * u * |tau|
  * for the slot bits of the list keys).  Read by the test that measures the bound (tests/test_gpu_knn_certificate.py). */
@@ -181,7 +184,7 @@ int scamd_csr_transpose_f32(const int64_t* indptr, const int32_t* indices, const
                             int64_t* t_indptr, int32_t* t_indices, float* t_data,
                             void* workspace, size_t workspace_bytes, scamd_stream_t stream);
 /* Y[n, l] (float32) = A[n, g] * B[g, l] - 1 * shift[l]^T   (shift may be NULL).
- * A is CSR; B row-major float32 with leading dimension l; 1 <= l <= 128. */
+ * A is CSR; B row-major float32 with leading dimension l; 1 <= l <= 256 (scamd_spmm_csr_f32; the float64-accumulating variant takes l <= 128). */
 int scamd_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, const float* data,
                        int64_t n, int64_t g, const float* b, int l, const float* shift,
                        float* y, scamd_stream_t stream);

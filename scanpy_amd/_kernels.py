@@ -111,6 +111,11 @@ def knn(x: torch.Tensor, k: int, *, q_begin: int = 0, n_query: int | None = None
         rc = lib.scamd_knn_l2_ivf_f32(ptr(x), n, d, x.stride(0), q_begin, nq, k, int(nprobe), ptr(idx), ptr(dist),
                                       C.byref(nfb), ptr(ws), wsz, stream_ptr())
         _check(rc, "scamd_knn_l2_ivf_f32")
+        if lib.scamd_knn_last_nprobe() == 0:
+            import warnings
+
+            warnings.warn(f"knn: the approximate mode (nprobe={int(nprobe)}) does not take this shape (n={n}, d={d}, k={k}: it "
+                          "needs n >= 4096, d <= 64, k <= 24); the search was answered EXACTLY.", UserWarning, stacklevel=3)
     else:
         rc = lib.scamd_knn_l2_f32(ptr(x), n, d, x.stride(0), q_begin, nq, k, ptr(idx), ptr(dist),
                                   float(cert_scale), C.byref(nfb), ptr(ws), wsz, stream_ptr())

@@ -30,6 +30,7 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 
 constexpr int DB_MAX = 128;      // largest block size / Jacobi dimension
 constexpr int DB_LD = DB_MAX + 2;  // LDS column stride (doubles): 1040 B, not a multiple of the 256-B bank period
+constexpr int DENSE_BATCH_HOST = DB_MAX - 32;  // eigenpairs per batch of the deflated solve (dense_topk_batched)
 
 __device__ __forceinline__ unsigned int dhash32(unsigned int x) {
   x ^= x >> 16;
@@ -455,6 +456,7 @@ __global__ void cov_from_gram_kernel(const long long* __restrict__ gram, int64_t
 
 // sign convention of sklearn's svd_flip(u_based_decision=False): the largest-|.| loading of a component is positive.
 // V [g x b] (first k columns used) -> comp64 [k x g] (row = component), v32 [g x k] float32 for the scores SpMM.
+// (k = row stride of v32 = components in all; comp64 / v32 are already offset to this batch's first component)
 __global__ __launch_bounds__(256) void finalize_components_kernel(const double* __restrict__ V, int g, int b, int k,
                                                                   double* __restrict__ comp64, float* __restrict__ v32) {
   __shared__ double bv[256];
@@ -671,7 +673,10 @@ static int dense_topk(DenseCtx& cx, int k, unsigned int seed, double tol, int* n
       ynew = old;
       sigma = sigma2;
     }
-    if (ycur != z) SCAMD_HIP_CHECK(hipMemcpyAsync(z, ycur, sizeof(double) * cnt, hipMemcpyDeviceToDevice, cx.s));
+    if (ycur != z) {  // (a copy by a kernel of ours, not a blit of the runtime)
+      hipLaunchKernelGGL(axpby_kernel, dim3(egrid), dim3(256), 0, cx.s, cnt, 1.0, ycur, 0.0, ycur, z);
+      SCAMD_LAUNCH_CHECK();
+    }
     return SCAMD_OK;
   };
   // two power steps (A (A z): the condition number of the block grows by (lambda_1 / lambda_b)^2, well within
@@ -701,7 +706,8 @@ static int dense_topk(DenseCtx& cx, int k, unsigned int seed, double tol, int* n
     if (rc != SCAMD_OK) return rc;
     rc = rayleigh_ritz(cx, y0, az, v, av, h_theta.data());
   } else {
-    SCAMD_HIP_CHECK(hipMemcpyAsync(y0, v, sizeof(double) * cnt, hipMemcpyDeviceToDevice, cx.s));
+    hipLaunchKernelGGL(axpby_kernel, dim3(egrid), dim3(256), 0, cx.s, cnt, 1.0, v, 0.0, v, y0);
+    SCAMD_LAUNCH_CHECK();
     rc = rayleigh_ritz(cx, y0, az, v, av, h_theta.data());
   }
   if (rc != SCAMD_OK) return rc;
@@ -879,19 +885,80 @@ __global__ void variance_kernel(const double* __restrict__ theta, int k, double 
 // model is therefore bitwise the same for any number of ranks, and no library (torch / rocBLAS) computes any part of it.
 namespace scamd {
 struct PcaSolveBuffers {
-  double* a; double* var; double* varsum; double* proj; void* dense_ws; size_t dense_ws_bytes;
+  double* a; double* var; double* varsum; double* proj; double* theta_all; double* deflate; void* dense_ws; size_t dense_ws_bytes;
 };
 static void pca_solve_carve(Workspace& ws, int64_t g, int k, PcaSolveBuffers* b) {
   b->a = ws.take<double>((size_t)g * g);
   b->var = ws.take<double>((size_t)g);
   b->varsum = ws.take<double>(8);
   b->proj = ws.take<double>((size_t)k + 8);
-  b->dense_ws_bytes = scamd_eigh_topk_workspace_bytes(g, k);
+  b->theta_all = ws.take<double>((size_t)k + 8);
+  b->deflate = ws.take<double>(k > DENSE_BATCH_HOST ? (size_t)DENSE_BATCH_HOST * g : 8);
+  b->dense_ws_bytes = scamd_eigh_topk_workspace_bytes(g, std::min(k, DENSE_BATCH_HOST));
   b->dense_ws = ws.take<char>(b->dense_ws_bytes);
 }
 __global__ void copy_theta_kernel(const double* __restrict__ theta, int k, double* __restrict__ out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < k) out[c] = fmax(theta[c], 0.0);
+}
+// q[c][m] = theta[c] * p[c][m]  (rows = components of a finished batch: A -= P^T Q deflates them)
+__global__ void scale_rows_kernel(const double* __restrict__ p, const double* __restrict__ theta, int kb, int g,
+                                  double* __restrict__ q) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < (int64_t)kb * g) q[e] = theta[e / g] * p[e];
+}
+// More components than one block of the subspace iteration holds (k + 32 > DB_MAX): batches of at most DB_MAX - 32, each on
+// the matrix DEFLATED by the finished ones, A <- A - V diag(theta) V^T (one rank-kb update on the f64 MFMA): the leading
+// eigenpairs of the deflated matrix are the next ones of A, orthogonal to the finished ones to the accuracy they were
+// converged to.  Round 6: until then n_comps > 96 ran the same iteration on torch.linalg (rocSOLVER / rocBLAS).
+constexpr int DENSE_BATCH = DB_MAX - 32;
+static bool dense_in_range(int64_t g, int k) {
+  if (g <= DB_MAX) return true;                       // the whole space: one Rayleigh-Ritz
+  if (k <= 0 || k > g) return false;
+  const int kb = std::min(k, DENSE_BATCH);
+  const int bsz = dense_block_size(g, kb);
+  return kb + 32 <= bsz && g >= 2 * bsz && (k <= DENSE_BATCH || g >= 2 * k);  // (deflating more than half the space is a full eigh's job)
+}
+// top-k eigenpairs of cx.a (DESTROYED when k needs more than one batch) -> comp64 [k x g] (sign convention applied),
+// v32 [g x k] (may be NULL), theta_all [k] (descending, raw).  `scratch` = kb_max x g doubles for the deflation.
+static int dense_topk_batched(DenseCtx& cx, double* a_mut, int k, unsigned int dseed, double tol, double* comp64, float* v32,
+                              double* theta_all, double* scratch, void* dense_ws, size_t dense_ws_bytes, int* n_outer, double* resid,
+                              int* bsz_out) {
+  const int g = cx.g;
+  *n_outer = 0;
+  *resid = 0.0;
+  for (int k0 = 0; k0 < k;) {
+    const int kb = g <= DB_MAX ? k : std::min(k - k0, DENSE_BATCH);
+    const int bsz = dense_block_size(g, kb);
+    cx.b = bsz;
+    Workspace dws(dense_ws, dense_ws_bytes);
+    dense_carve(dws, g, bsz, &cx.d);
+    SCAMD_REQUIRE(dws.ok, SCAMD_EWORKSPACE, "dense eigensolver: workspace");
+    int outer = 0;
+    double rs = 0.0;
+    int rc = dense_topk(cx, kb, dseed + 0x9E3779B9u * (unsigned int)k0, tol, &outer, &rs);
+    if (rc != SCAMD_OK) return rc;
+    *n_outer += outer;
+    *resid = std::max(*resid, rs);
+    *bsz_out = bsz;
+    hipLaunchKernelGGL(finalize_components_kernel, dim3(kb), dim3(256), 0, cx.s, cx.d.z[3], g, bsz, k, comp64 + (int64_t)k0 * g,
+                       v32 ? v32 + k0 : (float*)nullptr);
+    SCAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(axpby_kernel, dim3((kb + 255) / 256), dim3(256), 0, cx.s, (int64_t)kb, 1.0, cx.d.theta, 0.0, cx.d.theta,
+                       theta_all + k0);
+    SCAMD_LAUNCH_CHECK();
+    k0 += kb;
+    if (k0 < k) {  // deflate: A -= P^T (diag(theta) P), P = this batch's components [kb x g]
+      const double* pb = comp64 + (int64_t)(k0 - kb) * g;
+      hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)(((int64_t)kb * g + 255) / 256)), dim3(256), 0, cx.s, pb,
+                         theta_all + (k0 - kb), kb, g, scratch);
+      SCAMD_LAUNCH_CHECK();
+      rc = dgemm_tn(cx.s, pb, g, scratch, g, g, g, kb, -1.0, a_mut, cx.lda, 1.0, nullptr, 0, 0.0, a_mut, cx.lda);
+      if (rc != SCAMD_OK) return rc;
+      ++cx.n_gemm;
+    }
+  }
+  return SCAMD_OK;
 }
 // steps 3-5 and 7 of the route; `dseed` is handed to the eigensolver as it is.  No synchronisation: the caller drains.
 static int pca_solve_gram(const long long* gram, int64_t ld_gram, const long long* colsum, int64_t n, int64_t g, int scale_bits,
@@ -903,23 +970,19 @@ static int pca_solve_gram(const long long* gram, int64_t ld_gram, const long lon
   hipLaunchKernelGGL(cov_from_gram_kernel, dim3((unsigned)(((int64_t)g * g + 255) / 256)), dim3(256), 0, s, gram, ld_gram,
                      colsum, (int)g, inv, (double)n, zero_center ? 1 : 0, b.a, mean, b.var);
   SCAMD_LAUNCH_CHECK();
-  // 4. top-k eigenpairs
-  const int bsz = dense_block_size(g, k);
-  SCAMD_REQUIRE((bsz == g || k + 32 <= bsz) && (bsz == g || g >= 2 * bsz), SCAMD_EUNSUPPORTED,
-                "pca: n_comps=%d / g=%lld outside the device eigensolver's range", k, (long long)g);
+  // 4. top-k eigenpairs (batches of DENSE_BATCH with deflation when k needs more than one block)
+  SCAMD_REQUIRE(dense_in_range(g, k), SCAMD_EUNSUPPORTED, "pca: n_comps=%d / g=%lld outside the device eigensolver's range", k,
+                (long long)g);
   DenseCtx cx;
   cx.s = s;
   cx.a = b.a;
   cx.lda = g;
   cx.g = (int)g;
-  cx.b = bsz;
-  Workspace dws(b.dense_ws, b.dense_ws_bytes);
-  dense_carve(dws, g, bsz, &cx.d);
-  int rc = dense_topk(cx, k, dseed, tol, n_outer, resid);
+  int bsz = 0;
+  // 5. (inside the batches) sign convention, float32 loadings; then the projected means
+  int rc = dense_topk_batched(cx, b.a, k, dseed, tol, components, v32, b.theta_all, b.deflate, b.dense_ws, b.dense_ws_bytes, n_outer,
+                              resid, &bsz);
   if (rc != SCAMD_OK) return rc;
-  // 5. sign convention, float32 loadings, projected means
-  hipLaunchKernelGGL(finalize_components_kernel, dim3(k), dim3(256), 0, s, cx.d.z[3], (int)g, bsz, k, components, v32);
-  SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(mean_shift_kernel, dim3(k), dim3(256), 0, s, mean, v32, (int)g, k, shift, b.proj);
   SCAMD_LAUNCH_CHECK();
   // 7. explained variance (sklearn: S^2 / (n - 1); ratio against the total variance with the same n / (n - 1) factor;
@@ -928,12 +991,12 @@ static int pca_solve_gram(const long long* gram, int64_t ld_gram, const long lon
   SCAMD_LAUNCH_CHECK();
   const double denom = zero_center ? (double)(n - 1) : (double)n;
   const double total_scale = zero_center ? (double)n / (double)(n - 1) : 1.0;
-  hipLaunchKernelGGL(variance_kernel, dim3(1), dim3(256), 0, s, cx.d.theta, k, denom,
+  hipLaunchKernelGGL(variance_kernel, dim3((k + 255) / 256), dim3(256), 0, s, b.theta_all, k, denom,
                      zero_center ? (const double*)nullptr : (const double*)b.proj, b.varsum, total_scale, variance,
                      variance_ratio);
   SCAMD_LAUNCH_CHECK();
   if (theta_out) {
-    hipLaunchKernelGGL(copy_theta_kernel, dim3((k + 255) / 256), dim3(256), 0, s, cx.d.theta, k, theta_out);
+    hipLaunchKernelGGL(copy_theta_kernel, dim3((k + 255) / 256), dim3(256), 0, s, b.theta_all, k, theta_out);
     SCAMD_LAUNCH_CHECK();
   }
   *n_gemm = cx.n_gemm;

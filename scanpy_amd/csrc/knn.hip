@@ -30,6 +30,7 @@ static thread_local double g_last_select_pairs = -1.0;
 static thread_local double g_last_select_prepass_pairs = -1.0;
 static thread_local int g_last_select_engine = -1;
 static thread_local int g_last_second_tier = 0;
+static thread_local int g_last_nprobe = 0;  // cells probed by the last search on this thread (0: it was answered exactly)
 
 namespace scamd {
 
@@ -2833,6 +2834,7 @@ extern "C" double scamd_knn_last_select_pairs(void) { return g_last_select_pairs
 extern "C" double scamd_knn_last_select_prepass_pairs(void) { return g_last_select_prepass_pairs; }
 extern "C" int scamd_knn_last_select_engine(void) { return g_last_select_engine; }
 extern "C" int scamd_knn_last_second_tier_queries(void) { return g_last_second_tier; }
+extern "C" int scamd_knn_last_nprobe(void) { return g_last_nprobe; }
 
 extern "C" size_t scamd_knn_workspace_bytes(int64_t n, int d, int64_t n_query, int k) {
   // one figure for the exact and the approximate entry point: the approximate plan goes through the cell tables at
@@ -2889,6 +2891,7 @@ static int knn_l2_impl(const float* x, int64_t n, int d, int64_t ld_x, int64_t q
   KnnPlan p;
   SCAMD_REQUIRE(knn_plan(n, d, n_query, k, &p, nprobe), SCAMD_EUNSUPPORTED,
                 "knn: unsupported d=%d (max 256) or k=%d (max 256)", d, k);
+  g_last_nprobe = p.nprobe;
   if (n_fallback_host) *n_fallback_host = 0;
   if (n_query == 0) return SCAMD_OK;
   Workspace ws(workspace, workspace_bytes);

@@ -440,15 +440,21 @@ extern "C" int scamd_spmm_csr_f32(const int64_t* indptr, const int32_t* indices,
                                   int64_t g, const float* b, int l, const float* shift, float* y,
                                   scamd_stream_t stream) {
   SCAMD_REQUIRE(indptr && indices && data && b && y, SCAMD_EINVAL, "spmm: null pointer");
-  SCAMD_REQUIRE(n >= 0 && g >= 1 && l >= 1 && l <= 128, SCAMD_EINVAL, "spmm: bad shape n=%lld g=%lld l=%d",
+  SCAMD_REQUIRE(n >= 0 && g >= 1 && l >= 1 && l <= 256, SCAMD_EINVAL, "spmm: bad shape n=%lld g=%lld l=%d (at most 256 columns)",
                 (long long)n, (long long)g, l);
   if (n == 0) return SCAMD_OK;
   const int blocks = (int)std::min<int64_t>((n + 3) / 4, 256 * 32);
   if (l <= 64)
     hipLaunchKernelGGL(spmm_rows_f32_kernel<1>, dim3(blocks), dim3(256), 0, stream, indptr, indices, data, n, b, l,
                        shift, y);
-  else
+  else if (l <= 128)
     hipLaunchKernelGGL(spmm_rows_f32_kernel<2>, dim3(blocks), dim3(256), 0, stream, indptr, indices, data, n, b, l,
+                       shift, y);
+  else if (l <= 192)  // (round 6: n_comps beyond 128 -- the deflated eigensolver of csrc/dense.hip delivers them)
+    hipLaunchKernelGGL(spmm_rows_f32_kernel<3>, dim3(blocks), dim3(256), 0, stream, indptr, indices, data, n, b, l,
+                       shift, y);
+  else
+    hipLaunchKernelGGL(spmm_rows_f32_kernel<4>, dim3(blocks), dim3(256), 0, stream, indptr, indices, data, n, b, l,
                        shift, y);
   SCAMD_LAUNCH_CHECK();
   return SCAMD_OK;

@@ -14,7 +14,10 @@ import numpy as np
 from scipy import sparse
 
 
-METRICS = ("euclidean", "l2", "cosine")
+# metrics the Euclidean kernel serves exactly (the reference takes any sklearn / scipy metric name, neighbors/_types.py:23-50):
+# 'sqeuclidean' = the same lists with squared distances; 'cosine' / 'correlation' = the Euclidean search on unit-length
+# (/ row-centred unit-length) rows, 1 - cos = |x^ - y^|^2 / 2
+METRICS = ("euclidean", "l2", "sqeuclidean", "cosine", "correlation")
 
 
 def knn_search_device(x, k: int, *, q_begin: int = 0, n_query: int | None = None, metric: str = "euclidean",
@@ -36,14 +39,19 @@ def knn_search_device(x, k: int, *, q_begin: int = 0, n_query: int | None = None
     if sparse.issparse(x):
         x = x.toarray()
     xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
-    if metric == "cosine":
-        norm = torch.linalg.norm(xd.to(torch.float64), dim=1, keepdim=True)
+    if metric in ("cosine", "correlation"):
+        x64 = xd.to(torch.float64)
+        if metric == "correlation":  # scipy: 1 - (x - mean x) . (y - mean y) / (|x - mean x| |y - mean y|)
+            x64 = x64 - x64.mean(dim=1, keepdim=True)
+        norm = torch.linalg.norm(x64, dim=1, keepdim=True)
         if bool((norm == 0).any()):
-            raise ValueError("metric='cosine' is undefined for all-zero rows")
-        xd = (xd.to(torch.float64) / norm).to(torch.float32).contiguous()
+            raise ValueError(f"metric={metric!r} is undefined for " + ("all-zero rows" if metric == "cosine" else "constant rows"))
+        xd = (x64 / norm).to(torch.float32).contiguous()
     idx, dist, _ = _kernels.knn(xd, k, q_begin=q_begin, n_query=n_query, nprobe=nprobe)
-    if metric == "cosine":
+    if metric in ("cosine", "correlation"):
         dist = 0.5 * dist * dist
+    elif metric == "sqeuclidean":
+        dist = dist * dist
     return idx, dist
 
 
@@ -67,10 +75,18 @@ class MI355XKNNTransformer:
         self.n_neighbors = n_neighbors
         self.metric = metric
         self.include_self = include_self
-        if nprobe is not None and int(nprobe) < 0:
-            raise ValueError(f"nprobe={nprobe!r}: expected None (exact) or a positive number of cells")
-        self.nprobe = nprobe
+        self.nprobe = self._check_nprobe(nprobe)
         self._fit_x = None
+
+    @staticmethod
+    def _check_nprobe(nprobe):
+        """None / 0 = exact; a positive integer = cells probed.  Checked wherever the value can arrive (`__init__`,
+        `set_params` -- sklearn's `clone` / grid searches go through that --, and again at `transform`)."""
+        if nprobe is None:
+            return None
+        if isinstance(nprobe, bool) or int(nprobe) != nprobe or int(nprobe) < 0:
+            raise ValueError(f"nprobe={nprobe!r}: expected None (exact) or a positive number of cells")
+        return int(nprobe)
 
     def get_params(self, deep: bool = True) -> dict:
         return dict(n_neighbors=self.n_neighbors, metric=self.metric, include_self=self.include_self, nprobe=self.nprobe)
@@ -79,6 +95,10 @@ class MI355XKNNTransformer:
         for k, v in params.items():
             if k not in ("n_neighbors", "metric", "include_self", "nprobe"):
                 raise ValueError(f"Invalid parameter {k!r}")
+            if k == "nprobe":
+                v = self._check_nprobe(v)
+            if k == "metric" and v not in METRICS:
+                raise ValueError(f"metric={v!r}: the MI355X kNN kernel offers {METRICS}")
             setattr(self, k, v)
         return self
 
@@ -93,6 +113,7 @@ class MI355XKNNTransformer:
             msg = "MI355XKNNTransformer only answers queries for the fitted data (fit_transform semantics)"
             raise NotImplementedError(msg)
         n = x.shape[0]
+        self.nprobe = self._check_nprobe(self.nprobe)
         if self.include_self:  # sklearn style: self + n_neighbors others
             k = min(self.n_neighbors + 1, n)
             idx, dist = knn_search(x, k, metric=self.metric, nprobe=self.nprobe)

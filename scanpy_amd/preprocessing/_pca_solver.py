@@ -509,8 +509,10 @@ def _pca_fit_gram(a, n_comps: int, backend, comm, zero_center: bool, seed: int, 
     # the same call for one rank and for row shards (after the all-reduce), so the model stays bitwise identical for any
     # world size and no torch / rocBLAS kernel computes any part of it (round 5's profile: a Tensile GEMM and ~33
     # at::native launches per pass came from the torch formulation below, which the CPU stand-in of the tests still runs).
-    b_dev = min(g, (n_comps + 32 + 15) // 16 * 16)
-    device_solver_ok = g <= 128 or (n_comps + 32 <= 128 and g >= 2 * b_dev)
+    # (csrc/dense.hip: dense_in_range -- blocks of <= 128 columns; more than 96 components in batches on the deflated matrix)
+    kb_dev = min(n_comps, 96)
+    b_dev = min((kb_dev + 32 + 15) // 16 * 16, 128)
+    device_solver_ok = g <= 128 or (g >= 2 * b_dev and (n_comps <= 96 or g >= 2 * n_comps))
     gq = cq = solved = None
     if hasattr(backend, "pca_solve_gram") and device_solver_ok:
         for h in chunks.handles(backend):

@@ -44,6 +44,9 @@ _PARTITION_TYPES = {
     "RBConfigurationVertexPartition": ("modularity", True),  # the reference's default, _leiden.py:174-175
     "ModularityVertexPartition": ("modularity", False),  # RBConfiguration at resolution 1, no resolution_parameter
     "CPMVertexPartition": ("cpm", True),  # node sizes 1: igraph's objective_function='CPM'
+    # Reichardt-Bornholdt with the Erdos-Renyi null model: sum_ij (A_ij - gamma p n_i n_j) delta, p = the graph's density
+    # (total weight / n (n - 1) on the directed graph the leidenalg flavor builds): CPM at the resolution gamma * p
+    "RBERVertexPartition": ("cpm_density", True),
 }
 
 
@@ -229,7 +232,7 @@ def leiden(  # noqa: PLR0913
     if node_weights is not None:
         # (igraph: with the modularity objective the vertex weights default to the strengths and the resolution is divided by
         # 2m; what it does with OTHER weights there is not pinned by anything in the reference -- CPM's meaning is plain)
-        if objective != "cpm":
+        if objective not in ("cpm", "cpm_density"):
             raise NotImplementedError(f"{mine} are taken with the CPM objective only on the MI355X path")
         if restrict_to is not None:
             raise NotImplementedError(f"{mine} together with restrict_to is not supported on the MI355X path")
@@ -245,6 +248,12 @@ def leiden(  # noqa: PLR0913
         restrict_key, restrict_categories = restrict_to
         adjacency, restrict_indices = restrict_adjacency(
             adata, restrict_key, restrict_categories=restrict_categories, adjacency=adjacency)
+    if objective == "cpm_density":  # RBERVertexPartition: the density of the graph that is clustered (after restrict_to)
+        # (leidenalg's Graph::density: total edge weight / (N (N - 1)) on a directed graph, N = the total node size)
+        n_v = float(adjacency.shape[0]) if node_weights is None else float(np.sum(np.asarray(node_weights, dtype=np.float64)))
+        total = float(adjacency.sum()) if use_weights else float(adjacency.nnz)
+        gamma = gamma * total / max(n_v * (n_v - 1.0), 1.0)
+        objective = "cpm"
     groups, modularity = leiden_partition(adjacency, resolution=gamma, n_iterations=n_iterations, seed=seed,
                                           use_weights=use_weights, beta=clustering_args.get("beta", 0.01),
                                           initial_membership=initial_membership, objective=objective,

@@ -216,7 +216,21 @@ def umap_embedding(connectivities, *, n_components=2, n_epochs=None, a, b, gamma
     if isinstance(init, str) and init == "random":
         emb = rs.uniform(low=-10.0, high=10.0, size=(n, n_components)).astype(np.float32)
     elif isinstance(init, str) and init == "spectral":
-        ini = _spectral_init(indptr, indices, weights, n, n_components, seed)
+        sp_info: dict = {}
+        ini = None
+        if n > n_components + 6:
+            ini = _spectral_init(indptr, indices, weights, n, n_components, seed, info=sp_info)
+        if ini is None or not sp_info.get("converged", False) or not np.isfinite(ini).all():
+            # umap-learn's spectral_layout falls back to a random layout with a warning when ARPACK does not converge
+            # (umap/spectral.py); a graph too small for the block (n <= dim + 6) takes the same way out
+            import warnings
+
+            why = (f"the graph has only {n} vertices" if ini is None else
+                   f"the Chebyshev-filtered subspace iteration stopped at residual {sp_info.get('residual', float('nan')):.2e} after "
+                   f"{sp_info.get('outer_iterations')} outer iterations / {sp_info.get('operator_applications')} operator applications")
+            warnings.warn(f"tl.umap: spectral initialisation failed ({why}); falling back to a random initialisation, as "
+                          "umap-learn does when its eigensolver fails.", UserWarning, stacklevel=3)
+            ini = rs.uniform(low=-10.0, high=10.0, size=(n, n_components))
         expansion = 10.0 / np.abs(ini).max()
         emb = (ini * expansion).astype(np.float32) + rs.normal(scale=0.0001, size=[n, n_components]).astype(np.float32)
     else:

@@ -282,7 +282,8 @@ def test_partition_type_resolution():
     assert r(cls("ModularityVertexPartition"), None) == ("modularity", 1.0)
     with pytest.raises(TypeError, match="resolution_parameter"):
         r(cls("ModularityVertexPartition"), 1.0)
-    for name in ("SignificanceVertexPartition", "SurpriseVertexPartition", "RBERVertexPartition"):
+    assert r(cls("RBERVertexPartition"), 0.5) == ("cpm_density", 0.5)  # (CPM at resolution x the graph's density: tl.leiden)
+    for name in ("SignificanceVertexPartition", "SurpriseVertexPartition"):
         with pytest.raises(NotImplementedError, match=name):
             r(cls(name), 1.0)
 

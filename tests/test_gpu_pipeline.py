@@ -377,6 +377,12 @@ def test_leiden_partition_type_of_the_leidenalg_flavor(sc, pbmc68k):
     finally:
         settings.preset = "ScanpyV1"
     assert (adata.obs["cpm"] == adata.obs["cpm_igraph_v2"]).all()
+    # RBERVertexPartition: sum_ij (A_ij - resolution p) delta with p = the density of the (directed) graph = CPM at resolution x p
+    conn = adata.obsp["connectivities"]
+    dens = conn.sum() / (700 * 699)
+    sc.tl.leiden(adata, flavor="leidenalg", resolution=1.5, partition_type=type("RBERVertexPartition", (), {}), key_added="rber")
+    sc.tl.leiden(adata, flavor="leidenalg", resolution=1.5 * dens, partition_type=cpm, key_added="cpm_at_density")
+    assert (adata.obs["rber"] == adata.obs["cpm_at_density"]).all() and 1 < adata.obs["rber"].nunique() < 700
     with pytest.raises(TypeError, match="unexpected keyword argument 'resolution_parameter'"):
         sc.tl.leiden(adata, flavor="leidenalg", resolution=1.0, partition_type=mod)
     with pytest.raises(NotImplementedError, match="SurpriseVertexPartition"):
@@ -480,14 +486,17 @@ def test_counts_to_clusters_to_umap_with_the_dropin_calls():
     assert (truth[nb] == truth[:, None]).mean() > 0.95
 
 
-def test_neighbors_cosine_metric(sc, pbmc68k):
-    """metric='cosine' (the reference hands it to sklearn, neighbors/__init__.py:761-768): same neighbour sets and
-    distances as sklearn's brute-force cosine search, through the Euclidean kernel on unit-length rows"""
+@pytest.mark.parametrize("metric", ["cosine", "correlation", "sqeuclidean", "l2"])
+def test_neighbors_metrics_served_by_the_euclidean_kernel(sc, pbmc68k, metric):
+    """metric= 'cosine' / 'correlation' / 'sqeuclidean' / 'l2' (the reference hands the name to sklearn,
+    neighbors/__init__.py:761-768; the accepted names: neighbors/_types.py:23-50): same neighbour sets and distances as
+    sklearn's brute-force search with that metric -- cosine / correlation through the Euclidean kernel on unit-length
+    (row-centred) rows, sqeuclidean = squared distances of the same lists"""
     adata = sc.AnnData(pbmc68k["X"].copy())
     adata.obsm["X_pca"] = pbmc68k["X_pca"]
-    sc.pp.neighbors(adata, n_neighbors=12, metric="cosine")
-    assert adata.uns["neighbors"]["params"]["metric"] == "cosine"
-    oi, od, _ = oknn.knn_sklearn(pbmc68k["X_pca"], 12, metric="cosine")
+    sc.pp.neighbors(adata, n_neighbors=12, metric=metric)
+    assert adata.uns["neighbors"]["params"]["metric"] == metric
+    oi, od, _ = oknn.knn_sklearn(pbmc68k["X_pca"], 12, metric=metric)
     d = adata.obsp["distances"]
     assert (np.diff(d.indptr) == 11).all()
     got_i, got_d = d.indices.reshape(-1, 11), d.data.reshape(-1, 11)
@@ -496,11 +505,17 @@ def test_neighbors_cosine_metric(sc, pbmc68k):
     bad, _ = knn_sets_equal_mod_ties(got_i, got_d, oi[:, 1:], od[:, 1:], rtol=1e-5, atol=1e-7)
     assert bad == 0
     np.testing.assert_allclose(got_d, od[:, 1:], rtol=2e-5, atol=2e-7)
-    tr = sc.MI355XKNNTransformer(n_neighbors=12, metric="cosine")
+    tr = sc.MI355XKNNTransformer(n_neighbors=12, metric=metric)
     g = tr.fit_transform(pbmc68k["X_pca"])
     assert abs(g - d).max() < 1e-12
-    with pytest.raises(ValueError, match="all-zero"):
-        sc.MI355XKNNTransformer(metric="cosine").fit_transform(np.zeros((50, 4), dtype=np.float32))
+    if metric == "cosine":
+        with pytest.raises(ValueError, match="all-zero"):
+            sc.MI355XKNNTransformer(metric="cosine").fit_transform(np.zeros((50, 4), dtype=np.float32))
+    if metric == "correlation":
+        with pytest.raises(ValueError, match="constant rows"):
+            sc.MI355XKNNTransformer(metric="correlation").fit_transform(np.ones((50, 4), dtype=np.float32))
+    with pytest.raises(NotImplementedError, match="manhattan"):
+        sc.pp.neighbors(adata, n_neighbors=12, metric="manhattan")
 
 
 @pytest.mark.parametrize("resident", ["1", "0"], ids=["resident", "streamed"])
