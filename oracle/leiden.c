@@ -405,6 +405,9 @@ int oracle_leiden(int64_t n, const int64_t* indptr, const int32_t* indices, cons
         free(ref);
         break;
       }
+      if (getenv("ORACLE_LEIDEN_DEBUG") && getenv("ORACLE_LEIDEN_DEBUG")[0] == '2')
+        fprintf(stderr, "[oracle leiden] iteration %d level %d: n = %lld, nnz = %lld, communities %lld -> %lld refined\n", iter + 1, level,
+                (long long)g.n, (long long)g.indptr[g.n], (long long)ncomm, (long long)nref);
       graph_t a = aggregate(&g, ref, nref);
       int32_t* comm2 = (int32_t*)malloc(sizeof(int32_t) * (size_t)nref);
       for (int64_t v = 0; v < g.n; ++v) comm2[ref[v]] = comm[v];
