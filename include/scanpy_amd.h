@@ -259,6 +259,22 @@ int scamd_pca_solve_gram_f64(const int64_t* gram, int64_t ld_gram, const int64_t
                              float* loadings_f32, float* shift, double* variance, double* variance_ratio, double* mean,
                              double* eigenvalues, int32_t* info_host, void* workspace, size_t workspace_bytes,
                              scamd_stream_t stream);
+/* Spectral initialisation of the UMAP layout: the `dim` eigenvectors of the symmetric normalised adjacency
+ * S = D^-1/2 A D^-1/2 that follow the trivial one (= the smallest non-trivial ones of the normalised Laplacian) -- what
+ * `sc.tl.umap(init_pos='spectral')` gets from umap-learn's `spectral_layout` (src/scanpy/tools/_umap.py:165-215; ARPACK
+ * there, Chebyshev-filtered subspace iteration on (S + I) / 2 here, float32 SpMM operand, float64 everywhere else).
+ *   indptr / indices / weights: the symmetric fuzzy graph (device CSR, n x n); dim <= 10; n > dim + 6
+ *   out [n x dim] float64 (device): unit-norm, mutually orthogonal, orthogonal to sqrt(deg)
+ *   info_host (optional, 8 doubles): outer iterations, operator applications, residual of the wanted Ritz pairs,
+ *             1 if it is below `tol` (2e-6 is what the float32 operand allows), then up to four eigenvalues of S
+ *   max_outer / max_degree: bounds of the iteration (60 / 64 in the Python layer)
+ * SCAMD_EUNSUPPORTED when the block cannot be orthonormalised (the caller falls back to a random layout, as umap-learn does
+ * when its eigensolver fails). */
+size_t scamd_spectral_embedding_workspace_bytes(int64_t n, int64_t nnz, int dim);
+int scamd_spectral_embedding_f32(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n,
+                                 int64_t nnz, int dim, uint64_t seed, double tol, int max_outer, int max_degree,
+                                 double* out, double* info_host, void* workspace, size_t workspace_bytes,
+                                 scamd_stream_t stream);
 /* colsum[l] (float64) = 1^T Y for Y [n, l] float32, fixed summation order. */
 size_t scamd_colsum_workspace_bytes(int l);
 int scamd_colsum_f32_f64(const float* y, int64_t n, int l, double* colsum,

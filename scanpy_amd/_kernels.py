@@ -416,6 +416,29 @@ def pca_solve_gram(gram_q: torch.Tensor, colsum_q: torch.Tensor, n_total: int, g
                                                        "chol_retries": info[3], "residual": resid}
 
 
+def spectral_embedding(indptr: torch.Tensor, indices: torch.Tensor, weights: torch.Tensor, n: int, dim: int, *, seed: int = 0,
+                       tol: float = 2e-6, max_outer: int = 60, max_degree: int = 64):
+    """`scamd_spectral_embedding_f32`: the `dim` eigenvectors of D^-1/2 A D^-1/2 below the trivial one, float64 [n, dim] on the
+    device, + info (outer_iterations, operator_applications, residual, converged, ritz_values)."""
+    dev = require_gpu()
+    lib = _lib.load()
+    indptr = indptr.to(torch.int64).contiguous()
+    indices = indices.to(torch.int32).contiguous()
+    weights = weights.to(torch.float32).contiguous()
+    nnz = weights.numel()
+    out = _empty((n, dim), dtype=torch.float64, device=dev)
+    need = lib.scamd_spectral_embedding_workspace_bytes(n, nnz, int(dim))
+    if need == 0:
+        raise _lib.ScamdError(f"spectral_embedding: unsupported shape n={n} dim={dim} (at most 10 components)")
+    ws, wsz = _ws(need, dev)
+    info = (C.c_double * 8)()
+    rc = lib.scamd_spectral_embedding_f32(ptr(indptr), ptr(indices), ptr(weights), n, nnz, int(dim), int(seed) & (2**64 - 1),
+                                          float(tol), int(max_outer), int(max_degree), ptr(out), info, ptr(ws), wsz, stream_ptr())
+    _check(rc, "scamd_spectral_embedding_f32")
+    return out, {"outer_iterations": int(info[0]), "operator_applications": int(info[1]), "residual": float(info[2]),
+                 "converged": bool(info[3] > 0.5), "ritz_values": [float(info[4 + j]) for j in range(min(dim, 4))]}
+
+
 def colsum(y: torch.Tensor) -> torch.Tensor:
     dev = require_gpu()
     lib = _lib.load()

@@ -52,6 +52,8 @@ SIGNATURES = {
     "scamd_pca_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _u64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "scamd_pca_solve_gram_workspace_bytes": (_sz, [_i64, _i32]),
     "scamd_pca_solve_gram_f64": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _u64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "scamd_spectral_embedding_workspace_bytes": (_sz, [_i64, _i64, _i32]),
+    "scamd_spectral_embedding_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _u64, _f64, _i32, _i32, _vp, C.POINTER(_f64), _vp, _sz, _vp]),
     "scamd_colsum_workspace_bytes": (_sz, [_i32]),
     "scamd_colsum_f32_f64": (_i32, [_vp, _i64, _i32, _vp, _vp, _sz, _vp]),
     "scamd_leiden_workspace_bytes": (_sz, [_i64, _i64]),

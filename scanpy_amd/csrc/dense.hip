@@ -1128,3 +1128,383 @@ extern "C" int scamd_pca_csr_f32(const int64_t* indptr, const int32_t* indices, 
   }
   return SCAMD_OK;
 }
+
+// =====================================================================================================================
+// Spectral initialisation of the UMAP layout on the device (round 6).  `sc.tl.umap(init_pos='spectral')`
+// (src/scanpy/tools/_umap.py:165-215 -> umap-learn `spectral_layout`: the eigenvectors of the normalised Laplacian that
+// follow the trivial one, by ARPACK) as ONE call: Chebyshev-filtered subspace iteration on M = (S + I) / 2,
+// S = D^-1/2 A D^-1/2, with the known trivial eigenvector sqrt(deg) projected out -- the algorithm of
+// scanpy_amd/tools/_umap.py:_top_eigenvectors_below_trivial (which ran on torch.linalg QR / Cholesky / eigh + torch.bmm
+// until this round and remains the CPU stand-in of the tests), on the kernels of this file: the block is n x b with
+// b = dim + 6 <= 16 columns, S y is the float32 SpMM of pca.hip, every reduction over the n rows is a two-stage sum in a
+// fixed order (bitwise reproducible).
+// =====================================================================================================================
+namespace scamd {
+constexpr int SP_MAXB = 16;
+constexpr int SP_GRID = 1024;
+
+// deg[v] = sum of the row (float64), one wave per row
+__global__ __launch_bounds__(256) void sp_degree_kernel(const int64_t* __restrict__ indptr, const float* __restrict__ w, int64_t n,
+                                                        double* __restrict__ deg) {
+  const int lane = threadIdx.x & 63;
+  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= n) return;
+  double s = 0.0;
+  for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) s += (double)w[e];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) deg[v] = s;
+}
+// s[e] = w[e] / sqrt(deg[row] deg[col]) (float32: the SpMM's operand), t0[v] = sqrt(deg[v]) (the trivial eigenvector, unnormalised)
+__global__ __launch_bounds__(256) void sp_scale_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                       const float* __restrict__ w, int64_t n, const double* __restrict__ deg,
+                                                       float* __restrict__ s, double* __restrict__ t0) {
+  const int lane = threadIdx.x & 63;
+  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= n) return;
+  const double dv = deg[v];
+  const double dis_v = dv > 0.0 ? 1.0 / sqrt(dv) : 0.0;
+  if (lane == 0) t0[v] = sqrt(fmax(dv, 0.0));
+  for (int64_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) {
+    const double du = deg[indices[e]];
+    const double dis_u = du > 0.0 ? 1.0 / sqrt(du) : 0.0;
+    s[e] = (float)((double)w[e] * dis_v * dis_u);
+  }
+}
+// part[blk][i * bq + j] = sum over the block's rows of p[row][i] q[row][j]   (p: n x bp, q: n x bq, both <= 16 columns).
+// 256 threads = the 16 x 16 output entries; 64 rows at a time staged through LDS.
+__global__ __launch_bounds__(256) void sp_tall_gram_kernel(const double* __restrict__ p, int bp, const double* __restrict__ q,
+                                                           int bq, int64_t n, double* __restrict__ part) {
+  __shared__ double sp[64][SP_MAXB + 1], sq[64][SP_MAXB + 1];
+  const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+  const int64_t rows_per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per, r1 = r0 + rows_per < n ? r0 + rows_per : n;
+  double acc = 0.0;
+  for (int64_t base = r0; base < r1; base += 64) {
+    const int cnt = (int)(r1 - base < 64 ? r1 - base : 64);
+    for (int e = threadIdx.x; e < 64 * SP_MAXB; e += 256) {
+      const int r = e >> 4, c = e & 15;
+      sp[r][c] = (r < cnt && c < bp) ? p[(base + r) * bp + c] : 0.0;
+      sq[r][c] = (r < cnt && c < bq) ? q[(base + r) * bq + c] : 0.0;
+    }
+    __syncthreads();
+    for (int r = 0; r < 64; ++r) acc = fma(sp[r][i], sq[r][j], acc);
+    __syncthreads();
+  }
+  if (i < bp && j < bq) part[(int64_t)blockIdx.x * (bp * bq) + i * bq + j] = acc;
+}
+// out[e] = sum over the blocks in index order
+__global__ void sp_reduce_kernel(const double* __restrict__ part, int nblk, int cnt, double* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= cnt) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += part[(int64_t)b * cnt + e];
+  out[e] = s;
+}
+// y[row][j] -= t0[row] * c[j] / |t0|^2   (c = t0^T y, nrm2[0] = t0^T t0)
+__global__ void sp_deflate_kernel(double* __restrict__ y, const double* __restrict__ t0, const double* __restrict__ c,
+                                  const double* __restrict__ nrm2, int64_t n, int b) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * b) return;
+  const int64_t row = e / b;
+  const int j = (int)(e - row * b);
+  const double d = nrm2[0];
+  if (d > 0.0) y[e] -= t0[row] * (c[j] / d);
+}
+__global__ void sp_to_f32_kernel(const double* __restrict__ y, int64_t count, float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < count) out[e] = (float)y[e];
+}
+// out = a * (M y - center y) - bcoef * yprev with M y = (S y + y) / 2; a = 1, center = 0, bcoef = 0: out = M y
+__global__ void sp_cheb_kernel(int64_t count, const float* __restrict__ sy, const double* __restrict__ y,
+                               const double* __restrict__ yprev, double a, double center, double bcoef, double* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= count) return;
+  const double yy = y[e];
+  const double my = 0.5 * ((double)sy[e] + yy);
+  double r = a * (my - center * yy);
+  if (bcoef != 0.0) r -= bcoef * yprev[e];
+  out[e] = r;
+}
+// part[blk][j] = sum over the block's rows of (mv[row][j] - theta[j] v[row][j])^2, j < dim
+__global__ __launch_bounds__(256) void sp_resid_kernel(const double* __restrict__ v, const double* __restrict__ mv,
+                                                       const double* __restrict__ theta, int64_t n, int b, int dim,
+                                                       double* __restrict__ part) {
+  __shared__ double red[256];
+  const int j = threadIdx.x & 15, rl = threadIdx.x >> 4;  // 16 row lanes x 16 columns
+  const int64_t rows_per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per, r1 = r0 + rows_per < n ? r0 + rows_per : n;
+  double acc = 0.0;
+  if (j < dim) {
+    const double th = theta[j];
+    for (int64_t r = r0 + rl; r < r1; r += 16) {
+      const double d = mv[r * b + j] - th * v[r * b + j];
+      acc = fma(d, d, acc);
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (rl == 0) {
+    double s = 0.0;
+    for (int k = 0; k < 16; ++k) s += red[k * 16 + j];
+    if (j < dim) part[(int64_t)blockIdx.x * dim + j] = s;
+  }
+}
+__global__ void sp_zero_i32_kernel(int* __restrict__ p, int n) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = 0;
+}
+// out[row][j] = v[row][j], j < dim (row stride b -> dim)
+__global__ void sp_take_kernel(const double* __restrict__ v, int64_t n, int b, int dim, double* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * dim) return;
+  const int64_t row = e / dim;
+  out[e] = v[row * b + (e - row * dim)];
+}
+
+struct SpectralBuffers {
+  double* deg; double* t0; float* s; double* pan[7]; float* y32; float* sy32; double* part;
+  double* gm; double* smat; double* tmat; double* ymat; double* theta; double* cvec; double* nrm2; double* rnorm; int* flags;
+};
+static void spectral_carve(Workspace& ws, int64_t n, int64_t nnz, int b, SpectralBuffers* sb) {
+  sb->deg = ws.take<double>((size_t)n);
+  sb->t0 = ws.take<double>((size_t)n);
+  sb->s = ws.take<float>((size_t)std::max<int64_t>(nnz, 1));
+  for (int i = 0; i < 7; ++i) sb->pan[i] = ws.take<double>((size_t)n * b);
+  sb->y32 = ws.take<float>((size_t)n * b);
+  sb->sy32 = ws.take<float>((size_t)n * b);
+  sb->part = ws.take<double>((size_t)SP_GRID * SP_MAXB * SP_MAXB);
+  sb->gm = ws.take<double>(SP_MAXB * SP_MAXB);
+  sb->smat = ws.take<double>(SP_MAXB * SP_MAXB);
+  sb->tmat = ws.take<double>(SP_MAXB * SP_MAXB);
+  sb->ymat = ws.take<double>(SP_MAXB * SP_MAXB);
+  sb->theta = ws.take<double>(SP_MAXB);
+  sb->cvec = ws.take<double>(SP_MAXB);
+  sb->nrm2 = ws.take<double>(8);
+  sb->rnorm = ws.take<double>(SP_MAXB);
+  sb->flags = ws.take<int>(8);
+}
+
+struct SpectralCtx {
+  hipStream_t s;
+  const int64_t* indptr;
+  const int32_t* indices;
+  int64_t n;
+  int b, dim;
+  SpectralBuffers sb;
+  int n_apply = 0;
+  int grid_rows() const { return (int)std::min<int64_t>(SP_GRID, (n + 63) / 64); }
+  unsigned egrid() const { return (unsigned)((n * b + 255) / 256); }
+};
+// out[bp x bq] = p^T q over the n rows
+static int sp_gram(SpectralCtx& cx, const double* p, int bp, const double* q, int bq, double* out) {
+  const int g = cx.grid_rows();
+  hipLaunchKernelGGL(sp_tall_gram_kernel, dim3(g), dim3(256), 0, cx.s, p, bp, q, bq, cx.n, cx.sb.part);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sp_reduce_kernel, dim3(1), dim3(256), 0, cx.s, cx.sb.part, g, bp * bq, out);
+  SCAMD_LAUNCH_CHECK();
+  return SCAMD_OK;
+}
+// y <- y - t0 (t0^T y) / |t0|^2
+static int sp_deflate(SpectralCtx& cx, double* y) {
+  int rc = sp_gram(cx, cx.sb.t0, 1, y, cx.b, cx.sb.cvec);
+  if (rc != SCAMD_OK) return rc;
+  hipLaunchKernelGGL(sp_deflate_kernel, dim3(cx.egrid()), dim3(256), 0, cx.s, y, cx.sb.t0, cx.sb.cvec, cx.sb.nrm2, cx.n, cx.b);
+  SCAMD_LAUNCH_CHECK();
+  return SCAMD_OK;
+}
+// out = a (M y - center y) - bcoef yprev
+static int sp_apply(SpectralCtx& cx, const double* y, const double* yprev, double a, double center, double bcoef, double* out) {
+  const int64_t cnt = cx.n * cx.b;
+  hipLaunchKernelGGL(sp_to_f32_kernel, dim3(cx.egrid()), dim3(256), 0, cx.s, y, cnt, cx.sb.y32);
+  SCAMD_LAUNCH_CHECK();
+  int rc = scamd_spmm_csr_f32(cx.indptr, cx.indices, cx.sb.s, cx.n, cx.n, cx.sb.y32, cx.b, nullptr, cx.sb.sy32, cx.s);
+  if (rc != SCAMD_OK) return rc;
+  hipLaunchKernelGGL(sp_cheb_kernel, dim3(cx.egrid()), dim3(256), 0, cx.s, cnt, (const float*)cx.sb.sy32, y, yprev, a, center, bcoef, out);
+  SCAMD_LAUNCH_CHECK();
+  ++cx.n_apply;
+  return SCAMD_OK;
+}
+// CholeskyQR2 of the n x b block `cur` (overwritten) with scratch `other`; the orthonormal block ends in *result (one of the two)
+static int sp_cholqr2(SpectralCtx& cx, double* cur, double* other, double** result) {
+  const int b = cx.b;
+  int plain_ok = 0, shifted_rounds = 0;
+  const double s0 = 11.0 * ((double)cx.n * b + (double)b * (b + 1)) * 2.220446049250313e-16 * b;
+  while (plain_ok < 2) {
+    int rc = sp_gram(cx, cur, b, cur, b, cx.sb.gm);
+    if (rc != SCAMD_OK) return rc;
+    double shift = 0.0;
+    for (int attempt = 0;; ++attempt) {
+      int bad = 0;
+      hipLaunchKernelGGL(chol_factor_kernel, dim3(1), dim3(1024), CHOL_LDS, cx.s, cx.sb.gm, b, shift, cx.sb.smat, cx.sb.flags);
+      SCAMD_LAUNCH_CHECK();
+      SCAMD_READBACK_NOW(&bad, cx.sb.flags, sizeof(int), cx.s);
+      if (!bad) break;
+      SCAMD_REQUIRE(attempt < 4 && shifted_rounds < 8, SCAMD_EUNSUPPORTED,
+                    "spectral init: CholeskyQR gave up on the block (%d shifted rounds, attempt %d)", shifted_rounds, attempt);
+      shift = attempt == 0 ? s0 : shift * 1e3;
+      hipLaunchKernelGGL(sp_zero_i32_kernel, dim3(1), dim3(64), 0, cx.s, cx.sb.flags, 1);  // (chol_factor_kernel only RAISES the flag)
+      SCAMD_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(panel_small_kernel, dim3((unsigned)((cx.n + 7) / 8)), dim3(256), 0, cx.s, cur, cx.sb.smat, (int)cx.n, b, b, other);
+    SCAMD_LAUNCH_CHECK();
+    std::swap(cur, other);
+    if (shift > 0.0) {
+      plain_ok = 0;
+      ++shifted_rounds;
+    } else {
+      ++plain_ok;
+    }
+  }
+  *result = cur;
+  return SCAMD_OK;
+}
+// Rayleigh-Ritz on the orthonormal block z: mz = M z, T = z^T mz = Y diag(theta) Y^T, v = z Y, mv = mz Y; theta -> host
+static int sp_rayleigh_ritz(SpectralCtx& cx, const double* z, double* mz, double* v, double* mv, double* h_theta) {
+  const int b = cx.b;
+  int rc = sp_apply(cx, z, nullptr, 1.0, 0.0, 0.0, mz);
+  if (rc != SCAMD_OK) return rc;
+  rc = sp_gram(cx, z, b, mz, b, cx.sb.tmat);
+  if (rc != SCAMD_OK) return rc;
+  hipLaunchKernelGGL(symmetrize_kernel, dim3(1), dim3(256), 0, cx.s, cx.sb.tmat, b);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(jacobi_eigh_kernel, dim3(1), dim3(512), JAC_LDS, cx.s, cx.sb.tmat, b, cx.sb.theta, cx.sb.ymat, cx.sb.flags + 1);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(panel_small_kernel, dim3((unsigned)((cx.n + 7) / 8)), dim3(256), 0, cx.s, z, cx.sb.ymat, (int)cx.n, b, b, v);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(panel_small_kernel, dim3((unsigned)((cx.n + 7) / 8)), dim3(256), 0, cx.s, mz, cx.sb.ymat, (int)cx.n, b, b, mv);
+  SCAMD_LAUNCH_CHECK();
+  SCAMD_READBACK_NOW(h_theta, cx.sb.theta, sizeof(double) * b, cx.s);
+  return SCAMD_OK;
+}
+}  // namespace scamd
+
+extern "C" size_t scamd_spectral_embedding_workspace_bytes(int64_t n, int64_t nnz, int dim) {
+  if (n < 1 || nnz < 0 || dim < 1 || dim + 6 > SP_MAXB) return 0;
+  Workspace ws(nullptr, 0);
+  SpectralBuffers sb;
+  spectral_carve(ws, n, nnz, dim + 6, &sb);
+  return ws.used();
+}
+
+extern "C" int scamd_spectral_embedding_f32(const int64_t* indptr, const int32_t* indices, const float* weights, int64_t n,
+                                            int64_t nnz, int dim, uint64_t seed, double tol, int max_outer, int max_degree,
+                                            double* out, double* info_host, void* workspace, size_t workspace_bytes,
+                                            scamd_stream_t stream) {
+  SCAMD_REQUIRE(indptr && indices && weights && out, SCAMD_EINVAL, "spectral init: null pointer");
+  SCAMD_REQUIRE(dim >= 1 && dim + 6 <= SP_MAXB, SCAMD_EUNSUPPORTED, "spectral init: %d components (at most %d)", dim, SP_MAXB - 6);
+  SCAMD_REQUIRE(n > dim + 6 && n < ((int64_t)1 << 31) && nnz >= 1, SCAMD_EINVAL, "spectral init: bad shape n=%lld nnz=%lld",
+                (long long)n, (long long)nnz);
+  SpectralCtx cx;
+  cx.s = stream;
+  cx.indptr = indptr;
+  cx.indices = indices;
+  cx.n = n;
+  cx.dim = dim;
+  cx.b = dim + 6;
+  const int b = cx.b;
+  Workspace ws(workspace, workspace_bytes);
+  spectral_carve(ws, n, nnz, b, &cx.sb);
+  SCAMD_REQUIRE(workspace && ws.ok, SCAMD_EWORKSPACE, "spectral init: workspace %zu < required %zu", workspace_bytes, ws.used());
+  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_factor_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHOL_LDS));
+  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_eigh_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)JAC_LDS));
+  SpectralBuffers& sb = cx.sb;
+  hipStream_t s = stream;
+  // the flag words, then the operator: degrees, S = D^-1/2 A D^-1/2 in float32, the trivial eigenvector sqrt(deg)
+  hipLaunchKernelGGL(sp_zero_i32_kernel, dim3(1), dim3(64), 0, s, sb.flags, 8);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sp_degree_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, indptr, weights, n, sb.deg);
+  SCAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sp_scale_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, indptr, indices, weights, n,
+                     (const double*)sb.deg, sb.s, sb.t0);
+  SCAMD_LAUNCH_CHECK();
+  int rc = sp_gram(cx, sb.t0, 1, sb.t0, 1, sb.nrm2);
+  if (rc != SCAMD_OK) return rc;
+  double *z = sb.pan[0], *tmp = sb.pan[1], *mz = sb.pan[2], *v = sb.pan[3], *mv = sb.pan[4], *y0 = sb.pan[5], *y1 = sb.pan[6];
+  const int64_t cnt = n * b;
+  hipLaunchKernelGGL(randn_kernel, dim3(cx.egrid()), dim3(256), 0, s, z, cnt,
+                     (unsigned int)(seed ^ (seed >> 32)) * 0x9E3779B1u + 0x5bd1e995u);
+  SCAMD_LAUNCH_CHECK();
+  rc = sp_deflate(cx, z);
+  if (rc != SCAMD_OK) return rc;
+  double* zq = nullptr;
+  rc = sp_cholqr2(cx, z, tmp, &zq);
+  if (rc != SCAMD_OK) return rc;
+  double h_theta[SP_MAXB];
+  rc = sp_rayleigh_ritz(cx, zq, mz, v, mv, h_theta);
+  if (rc != SCAMD_OK) return rc;
+  double resid = INFINITY;
+  int outer = 0;
+  for (outer = 1; outer <= max_outer; ++outer) {
+    // residual of the wanted Ritz pairs (|M| = 1: absolute = relative)
+    const int g = cx.grid_rows();
+    hipLaunchKernelGGL(sp_resid_kernel, dim3(g), dim3(256), 0, s, (const double*)v, (const double*)mv, (const double*)sb.theta, n, b, dim, sb.part);
+    SCAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sp_reduce_kernel, dim3(1), dim3(256), 0, s, (const double*)sb.part, g, dim, sb.rnorm);
+    SCAMD_LAUNCH_CHECK();
+    double h_r[SP_MAXB];
+    SCAMD_READBACK_NOW(h_r, sb.rnorm, sizeof(double) * dim, s);
+    resid = 0.0;
+    for (int j = 0; j < dim; ++j) resid = std::max(resid, std::sqrt(std::max(h_r[j], 0.0)));
+    if (resid < tol) break;
+    const double c = h_theta[b - 1];
+    double* blk = nullptr;  // the block that is deflated and orthonormalised next
+    if (!(c > 0.0 && c < 1.0)) {  // a degenerate block: one plain step keeps it simple
+      blk = mv;
+    } else {
+      const double e = 0.5 * c, center = 0.5 * c;
+      // the degree: as high as the amplification SPREAD inside the wanted set allows (beyond ~1e9 every column is the
+      // leading wanted vector plus rounding noise); the spectrum's upper end is 1
+      const double x1 = (1.0 - center) / e, xk = std::max((h_theta[dim - 1] - center) / e, 1.0);
+      const double spread = std::acosh(x1) - std::acosh(xk);
+      const int m = spread <= 0.0 ? max_degree : std::max(4, std::min(max_degree, (int)std::floor(20.7 / spread)));
+      double sigma = e / (1.0 - center);
+      const double sigma1 = sigma;
+      // y = (mv - center v) sigma1 / e = (sigma1 / e) mv - (center sigma1 / e) v
+      hipLaunchKernelGGL(axpby_kernel, dim3(cx.egrid()), dim3(256), 0, s, cnt, sigma1 / e, (const double*)mv, -center * sigma1 / e,
+                         (const double*)v, y0);
+      SCAMD_LAUNCH_CHECK();
+      const double* yprev = v;
+      double* ycur = y0;
+      double* ynew = y1;
+      for (int it = 2; it <= m; ++it) {
+        const double sigma2 = 1.0 / (2.0 / sigma1 - sigma);
+        rc = sp_apply(cx, ycur, yprev, 2.0 * sigma2 / e, center, sigma * sigma2, ynew);
+        if (rc != SCAMD_OK) return rc;
+        double* old = (yprev == v) ? z : const_cast<double*>(yprev);  // v is never written: z joins the rotation
+        yprev = ycur;
+        ycur = ynew;
+        ynew = old;
+        sigma = sigma2;
+      }
+      blk = ycur;
+    }
+    rc = sp_deflate(cx, blk);
+    if (rc != SCAMD_OK) return rc;
+    // scratch for the orthonormalisation: any panel that is neither the block nor v / mv / mz (those are rewritten below)
+    double* scratch = (blk == tmp) ? z : tmp;
+    if (scratch == blk) scratch = y1;
+    if (blk == mv) {  // (the plain step orthonormalises a COPY: mv is an output of the Rayleigh-Ritz that follows)
+      hipLaunchKernelGGL(axpby_kernel, dim3(cx.egrid()), dim3(256), 0, s, cnt, 1.0, (const double*)mv, 0.0, (const double*)mv, y0);
+      SCAMD_LAUNCH_CHECK();
+      blk = y0;
+      scratch = y1;
+    }
+    rc = sp_cholqr2(cx, blk, scratch, &zq);
+    if (rc != SCAMD_OK) return rc;
+    rc = sp_rayleigh_ritz(cx, zq, mz, v, mv, h_theta);
+    if (rc != SCAMD_OK) return rc;
+  }
+  hipLaunchKernelGGL(sp_take_kernel, dim3((unsigned)((n * dim + 255) / 256)), dim3(256), 0, s, (const double*)v, n, b, dim, out);
+  SCAMD_LAUNCH_CHECK();
+  SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+  if (info_host) {
+    info_host[0] = (double)std::min(outer, max_outer);
+    info_host[1] = (double)cx.n_apply;
+    info_host[2] = resid;
+    info_host[3] = resid < tol ? 1.0 : 0.0;
+    for (int j = 0; j < dim && j < 4; ++j) info_host[4 + j] = 2.0 * h_theta[j] - 1.0;  // eigenvalues of S
+  }
+  return SCAMD_OK;
+}

@@ -177,6 +177,20 @@ def _spectral_init(indptr, indices, weights, n: int, dim: int, seed: int, *, inf
     from .. import _kernels as K
 
     dev = weights.device
+    if dev.type == "cuda" and dim <= 10:
+        # the product path: ONE C call on the kernels of csrc/dense.hip (round 6; until then the block iteration below ran
+        # on torch.linalg QR / Cholesky / eigh -- rocSOLVER -- and torch.bmm; it remains what the CPU tests run)
+        from .._lib import ScamdError
+
+        try:
+            vec, dinfo = K.spectral_embedding(indptr, indices, weights, n, dim, seed=seed)
+            if info is not None:
+                info.update(dinfo)
+            return vec.cpu().numpy()
+        except ScamdError as exc:  # (the block could not be orthonormalised: the caller falls back to a random layout)
+            if info is not None:
+                info.update(converged=False, residual=float("nan"), outer_iterations=0, operator_applications=0, error=str(exc))
+            return np.full((n, dim), np.nan)
     rows = torch.repeat_interleave(torch.arange(n, device=dev), (indptr[1:] - indptr[:-1]))
     deg = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, rows, weights.to(torch.float64))
     dis = torch.where(deg > 0, deg.rsqrt(), torch.zeros_like(deg))

@@ -178,3 +178,54 @@ def test_device_pruning_equals_host_pruning(pbmc68k, n_epochs):
     assert np.array_equal(ip.cpu().numpy(), csr.indptr) and np.array_equal(ix.cpu().numpy(), csr.indices)
     np.testing.assert_allclose(eps_d.cpu().numpy(), eps, rtol=1e-6)
     np.testing.assert_array_equal(w.cpu().numpy(), csr.data)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_spectral_init_on_the_device_equals_arpack(dim, monkeypatch):
+    """`init_pos='spectral'` (src/scanpy/tools/_umap.py:165-215 -> umap-learn's spectral_layout, ARPACK on the normalised
+    Laplacian): `scamd_spectral_embedding_f32` -- Chebyshev-filtered subspace iteration on the kernels of csrc/dense.hip --
+    returns the same eigen-SPACE as scipy's ARPACK on a graph WITHOUT clusters (a 30k-vertex sheet: eigenvalues 1 - O(1e-4), the
+    case a block power iteration cannot do), orthonormal and orthogonal to the trivial eigenvector; and `tl.umap` reaches no
+    torch.linalg routine on the way (round 5: QR / Cholesky / eigh of rocSOLVER)."""
+    import torch
+    from scipy.sparse.linalg import eigsh
+    from sklearn.neighbors import kneighbors_graph
+
+    from scanpy_amd import _kernels as K
+
+    rng = np.random.default_rng(0)
+    n = 30000
+    pts = rng.uniform(size=(n, 2)) * [3.0, 1.0]
+    g = kneighbors_graph(pts, 12, mode="distance")
+    g.data = np.exp(-g.data / g.data.mean())
+    a = (g + g.T).tocsr().astype(np.float32)
+    a.sort_indices()
+    dev = torch.device("cuda")
+    out, info = K.spectral_embedding(torch.from_numpy(a.indptr.astype(np.int64)).to(dev), torch.from_numpy(a.indices.astype(np.int32)).to(dev),
+                                     torch.from_numpy(a.data).to(dev), n, dim, seed=0)
+    v = out.cpu().numpy()
+    print(info)
+    assert info["converged"] and info["residual"] < 2e-6
+    deg = np.asarray(a.sum(1)).ravel().astype(np.float64)
+    dis = 1.0 / np.sqrt(deg)
+    s_mat = sparse.diags(dis) @ a.astype(np.float64) @ sparse.diags(dis)
+    lam, vec = eigsh(s_mat, k=dim + 1, which="LA", tol=1e-10)
+    order = np.argsort(-lam)
+    ref = vec[:, order][:, 1:dim + 1]
+    cosines = np.linalg.svd(ref.T @ v, compute_uv=False)
+    print("principal cosines", cosines, "eigenvalues", lam[order], info["ritz_values"])
+    assert cosines.min() > 1 - 1e-6
+    assert np.abs(v.T @ v - np.eye(dim)).max() < 1e-10
+    assert np.abs(v.T @ (np.sqrt(deg) / np.linalg.norm(np.sqrt(deg)))).max() < 1e-6
+    np.testing.assert_allclose(info["ritz_values"][:dim], lam[order][1:dim + 1], atol=2e-6)
+
+    def refuse(*args, **kwargs):
+        raise AssertionError("a torch.linalg routine was reached from tl.umap")
+
+    for name in ("eigh", "qr", "cholesky_ex", "cholesky", "solve_triangular", "svd"):
+        monkeypatch.setattr(torch.linalg, name, refuse)
+    adata = sc.AnnData(sparse.csr_matrix((n, 1), dtype=np.float32))
+    adata.obsp["connectivities"] = a
+    adata.uns["neighbors"] = dict(connectivities_key="connectivities", distances_key="distances", params=dict(n_neighbors=12, method="umap"))
+    sc.tl.umap(adata, n_components=dim, maxiter=20)
+    assert adata.obsm["X_umap"].shape == (n, dim) and np.isfinite(adata.obsm["X_umap"]).all()
