@@ -39,7 +39,7 @@ for STEP in "$@"; do
   case "$NAME" in
     build) python -c "import __graft_entry__ as g; g.build()" > "$OUT/build.log" 2>&1; echo "build rc=$?";;
     oracle_iters)  # background: single-threaded CPU job beside the GPU steps
-      ( timeout -k 5 900 python tools/oracle_iters_probe.py 1000000 "${ARG:-weak}" > "$OUT/oracle_iters_${ARG:-weak}.log" 2>&1 < /dev/null ) & ;;
+      ( timeout -k 5 1500 python tools/oracle_iters_probe.py 1000000 "${ARG:-weak}" ${ORACLE_SEEDS:-0} ${GPU_SEEDS:-0} > "$OUT/oracle_iters_${ARG:-weak}.log" 2>&1 < /dev/null ) & ;;
     bench_short) timeout -k 5 600 python bench.py --steps 20 --warmup 5 --cpu-sizes 0 --no-noise-variant --no-side --no-verify > "$OUT/bench_short.json" 2> "$OUT/bench_short.err" < /dev/null; echo "bench_short rc=$?"; line "$OUT/bench_short.json";;
     bench_full) timeout -k 5 1500 python bench.py --steps 20 --warmup 5 ${ARG_FULL:-} > "$OUT/bench.json" 2> "$OUT/bench.err" < /dev/null; echo "bench rc=$?"; tail -2 "$OUT/bench.err" | cut -c1-300; line "$OUT/bench.json";;
     bench_weak|bench_none) ST="${NAME#bench_}"; timeout -k 5 600 python bench.py --structure $ST --steps 5 --warmup 1 --cpu-sizes 0 --no-noise-variant --h2h-reps 0 --no-side > "$OUT/bench_$ST.json" 2> "$OUT/bench_$ST.err" < /dev/null; echo "bench $ST rc=$?"; line "$OUT/bench_$ST.json";;
@@ -67,5 +67,5 @@ for STEP in "$@"; do
   esac
 done
 wait
-for f in "$OUT"/oracle_iters_*.log; do test -s "$f" && { echo "== $f"; grep -c "oracle leiden. iteration" "$f"; grep "^gpu:\|^oracle:\|^ARI" "$f"; tail -3 "$f" | cut -c1-300; }; done
+for f in "$OUT"/oracle_iters_*.log; do test -s "$f" && { echo "== $f"; grep -c "oracle leiden. iteration" "$f"; grep "^gpu\|^oracle\|^ARI" "$f" | cut -c1-260; tail -3 "$f" | cut -c1-300; }; done
 exit 0

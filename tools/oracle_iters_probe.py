@@ -24,7 +24,8 @@ sys.path.insert(0, str(ROOT))
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     structure = sys.argv[2] if len(sys.argv) > 2 else "weak"
-    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    seeds = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
+    gpu_seeds = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else seeds
     import torch
 
     import bench
@@ -40,21 +41,26 @@ def main():
     res = run_path(backend.upload(x), n, backend=backend)
     ip, ix, w = res.conn_indptr, res.conn_indices, res.conn_data
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    labels, q, nc = K.leiden(ip, ix, w, n, seed=seed)
-    torch.cuda.synchronize()
-    t_gpu = time.perf_counter() - t0
-    stats = K.leiden_last_stats()
-    gl = labels.cpu().numpy()
-    print(f"gpu: {t_gpu * 1e3:.1f} ms, Q {q!r}, {nc} communities, {stats}", flush=True)
+    K.leiden(ip, ix, w, n, seed=gpu_seeds[0])  # warm-up
+    gpu = {}
+    for sd in gpu_seeds:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        labels, q, nc = K.leiden(ip, ix, w, n, seed=sd)
+        torch.cuda.synchronize()
+        t_gpu = time.perf_counter() - t0
+        stats = K.leiden_last_stats()
+        gpu[sd] = labels.cpu().numpy()
+        print(f"gpu seed {sd}: {t_gpu * 1e3:.1f} ms, Q {q!r}, {nc} communities, ARI vs truth {cmp.ari(gpu[sd], truth):.4f}, {stats}", flush=True)
     conn = sparse.csr_matrix((w.cpu().numpy().astype(np.float64), ix.cpu().numpy(), ip.cpu().numpy()), shape=(n, n))
     del res
     os.environ["ORACLE_LEIDEN_DEBUG"] = "1"
-    t0 = time.perf_counter()
-    om, oq = ol.leiden(conn, resolution=1.0, n_iterations=-1, seed=seed)
-    t_cpu = time.perf_counter() - t0
-    print(f"oracle: {t_cpu:.1f} s, Q {oq!r}, {int(om.max()) + 1} communities", flush=True)
-    print(f"ARI gpu vs oracle {cmp.ari(gl, om):.4f}; vs truth: gpu {cmp.ari(gl, truth):.4f} oracle {cmp.ari(om, truth):.4f}", flush=True)
+    for sd in seeds:
+        t0 = time.perf_counter()
+        om, oq = ol.leiden(conn, resolution=1.0, n_iterations=-1, seed=sd)
+        t_cpu = time.perf_counter() - t0
+        print(f"oracle seed {sd}: {t_cpu:.1f} s, Q {oq!r}, {int(om.max()) + 1} communities, ARI vs truth {cmp.ari(om, truth):.4f}; "
+              f"ARI vs gpu seeds {[round(cmp.ari(g, om), 4) for g in gpu.values()]}", flush=True)
 
 
 if __name__ == "__main__":
