@@ -214,7 +214,8 @@ def test_spectral_init_on_the_device_equals_arpack(dim, monkeypatch):
     ref = vec[:, order][:, 1:dim + 1]
     cosines = np.linalg.svd(ref.T @ v, compute_uv=False)
     print("principal cosines", cosines, "eigenvalues", lam[order], info["ritz_values"])
-    assert cosines.min() > 1 - 1e-6
+    # (an angle of residual / eigenvalue gap: 2e-6 / 1e-4 on this sheet -- 1 - cos ~ 1e-5 measured; a power iteration gives 0.87)
+    assert cosines.min() > 1 - 1e-4
     assert np.abs(v.T @ v - np.eye(dim)).max() < 1e-10
     assert np.abs(v.T @ (np.sqrt(deg) / np.linalg.norm(np.sqrt(deg)))).max() < 1e-6
     np.testing.assert_allclose(info["ritz_values"][:dim], lam[order][1:dim + 1], atol=2e-6)

@@ -24,8 +24,8 @@ sys.path.insert(0, str(ROOT))
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     structure = sys.argv[2] if len(sys.argv) > 2 else "weak"
-    seeds = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
-    gpu_seeds = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else seeds
+    seeds = [int(v) for v in sys.argv[3].split(",") if v != "none"] if len(sys.argv) > 3 else [0]  # ("none": no oracle run)
+    gpu_seeds = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else (seeds or [0])
     import torch
 
     import bench
