@@ -135,6 +135,38 @@ class _PinnedTransfer:
             out.record_stream(stream)  # written on the copy stream, allocated (and later freed) on the current one
             return out
 
+    def upload_into(self, arr, out: torch.Tensor) -> None:
+        """`upload` into a device tensor the caller allocated (same dtype and element count): the pieces are ordered behind
+        the CURRENT stream's work and that stream waits for them -- call it under `torch.cuda.stream(side)` to keep the
+        compute stream free (the caller then records an event on `side` and makes the compute stream wait for it)."""
+        import numpy as np
+
+        arr = np.ascontiguousarray(arr)
+        src = torch.from_numpy(arr)
+        nbytes = arr.nbytes
+        assert out.is_contiguous() and out.numel() * out.element_size() == nbytes
+        if nbytes < (8 << 20) or os.environ.get("SCAMD_PINNED_UPLOAD") == "0" or src.is_pinned():
+            out.copy_(src.view(out.dtype) if src.dtype != out.dtype else src, non_blocking=False)
+            return
+        with self._lock:
+            stages, events, stream = self._state(out.device)
+            out_b = out.view(torch.uint8).reshape(-1)
+            src_b = arr.view(np.uint8).reshape(-1)
+            cur = torch.cuda.current_stream(out.device)
+            stream.wait_stream(cur)
+            n_piece = (nbytes + self.PIECE - 1) // self.PIECE
+            for i in range(n_piece):
+                lo, hi = i * self.PIECE, min(nbytes, (i + 1) * self.PIECE)
+                slot = i & 1
+                stage = stages[slot]
+                events[slot].synchronize()
+                self._host_copy(stage.numpy()[:hi - lo], src_b[lo:hi])
+                with torch.cuda.stream(stream):
+                    out_b[lo:hi].copy_(stage[:hi - lo], non_blocking=True)
+                    events[slot].record(stream)
+            cur.wait_stream(stream)
+            out.record_stream(stream)
+
     def download(self, t: torch.Tensor):
         """device tensor -> numpy array in pageable memory: DMA of piece i + 1 into one staging buffer while the thread
         pool copies piece i out of the other"""

@@ -163,8 +163,20 @@ def pca(  # noqa: PLR0912, PLR0913, PLR0915
         rows = _ChunkedRows(host_chunks, n_vars, resident_budget_bytes=budget)
         res = pca_fit(rows, n_comps, backend=backend, zero_center=zero_center, svd_solver=svd_solver, seed=seed)
     else:
-        res = pca_fit(backend.upload(as_csr_f32(x)), n_comps, backend=backend, zero_center=zero_center,
-                      svd_solver=svd_solver, seed=seed)
+        xc = as_csr_f32(x)
+        import os
+
+        # (SCAMD_PCA_OVERLAP_MIN_NNZ: stored entries from which the overlapped upload is used -- default 16M, below that the
+        # whole matrix is on the device in a millisecond; the tests set 0; SCAMD_PCA_OVERLAP_UPLOAD=0 switches it off)
+        if xc.nnz >= int(os.environ.get("SCAMD_PCA_OVERLAP_MIN_NNZ", 16 << 20)) and os.environ.get("SCAMD_PCA_OVERLAP_UPLOAD") != "0":
+            # a large host matrix: the value array goes up first (max|x| fixes the fixed-point scale), the column indices follow
+            # in row chunks UNDER the Gram kernel of the chunk before (same bits as the one-shot fit: integer sums)
+            from ._pca_solver import _HostCsrOverlapped
+
+            handle = _HostCsrOverlapped(xc)
+        else:
+            handle = backend.upload(xc)
+        res = pca_fit(handle, n_comps, backend=backend, zero_center=zero_center, svd_solver=svd_solver, seed=seed)
     from .._device import to_host
 
     x_pca = to_host(res.scores)

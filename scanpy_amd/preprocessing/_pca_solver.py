@@ -461,13 +461,86 @@ class _ChunkedRows:
             self._cached = keep
 
 
+class _HostCsrOverlapped:
+    """A HOST CSR matrix as the row source of the Gram route, with half of its upload hidden under the Gram kernel
+    (host-to-host metric of SURVEY 8(d); round 6).  Same interface as `_ChunkedRows`.
+
+    The scale of the fixed-point sums needs max|x| over ALL rows before the first product -- so the VALUE array goes up first,
+    whole (`host_absmax`: upload + the device's absmax kernel); the column INDICES follow in row chunks on a side stream, and
+    the Gram kernel of chunk c (rows addressed through a view of the full row pointers: the kernels index `indices` / `data`
+    by absolute entry offsets) runs while chunk c + 1 is on the link.  Integer sums: the result is the one-shot result bit
+    for bit.  After the first pass `handles` yields ONE handle of the whole matrix (the scores SpMM)."""
+
+    def __init__(self, x_csr, n_chunks: int = 6):
+        self.x = x_csr
+        self.n_rows, self.n_cols = int(x_csr.shape[0]), int(x_csr.shape[1])
+        self.resident = True
+        self._full = None
+        ip = np.ascontiguousarray(x_csr.indptr, dtype=np.int64)
+        nnz = int(ip[-1])
+        # row chunks of ~equal entry counts
+        cuts = np.searchsorted(ip, np.linspace(0, nnz, max(1, int(n_chunks)) + 1)[1:-1], side="left")
+        self._bounds = sorted({0, self.n_rows, *(int(c) for c in cuts if 0 < c < self.n_rows)})
+        self.n_chunks = len(self._bounds) - 1
+        self._ip_host = ip
+        self._dev = None
+
+    def host_absmax(self):
+        from .._device import pinned_uploader, require_gpu
+        from .. import _kernels as K
+
+        dev = require_gpu()
+        self._ip = torch.from_numpy(self._ip_host).to(dev)
+        self._dv = pinned_uploader.upload(np.ascontiguousarray(self.x.data, dtype=np.float32), dev)
+        self._ix = torch.empty(self._dv.numel(), dtype=torch.int32, device=dev)
+        self._dev = dev
+        # (phase 1 of scamd_csr_gram_f32 reads the value array only: the index pointer is a placeholder)
+        return K.csr_absmax(self._ip, self._ix, self._dv, self.n_rows, self.n_cols)
+
+    def handles(self, backend):
+        if self._full is not None:
+            yield self._full
+            return
+        from .._device import pinned_uploader
+
+        if self._dev is None:
+            self.host_absmax()
+        dev = self._dev
+        side = getattr(backend, "_copy_stream", None)
+        if side is None:
+            side = backend._copy_stream = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)  # (`_ix` was allocated on the compute stream)
+        indices = np.ascontiguousarray(self.x.indices, dtype=np.int32)
+
+        def send(c):
+            r0, r1 = self._bounds[c], self._bounds[c + 1]
+            e0, e1 = int(self._ip_host[r0]), int(self._ip_host[r1])
+            ev = torch.cuda.Event()
+            with torch.cuda.stream(side):
+                if e1 > e0:
+                    pinned_uploader.upload_into(indices[e0:e1], self._ix[e0:e1])
+                ev.record(side)
+            return ev
+
+        ev = send(0)
+        for c in range(self.n_chunks):
+            r0, r1 = self._bounds[c], self._bounds[c + 1]
+            main.wait_event(ev)
+            yield (self._ip[r0:r1 + 1], self._ix, self._dv, r1 - r0, self.n_cols)  # the caller enqueues this chunk's Gram kernel ...
+            if c + 1 < self.n_chunks:
+                ev = send(c + 1)  # ... and the next chunk's indices cross the link under it
+        self._ix.record_stream(side)
+        self._full = (self._ip, self._ix, self._dv, self.n_rows, self.n_cols)
+
+
 def _pca_fit_gram(a, n_comps: int, backend, comm, zero_center: bool, seed: int, tol: float) -> "PCAResult | None":
     """Covariance route: exact fixed-point Gram matrix (one pass over the CSR, `scamd_csr_gram_f32`), all-reduced
     over the row shards as int64 (so the model is bitwise identical for any number of ranks), then a dense
     float64 eigen-solve.  Returns None when the route does not apply (too many genes / overflow risk)."""
     # `a` is one device CSR handle, or a _ChunkedRows (row chunks of a host matrix streamed through the device): the
     # Gram matrix, the column sums and max|x| are additive / max-able over row chunks exactly as over row shards
-    chunks = a if isinstance(a, _ChunkedRows) else _ChunkedRows.single(a)
+    chunks = a if isinstance(a, (_ChunkedRows, _HostCsrOverlapped)) else _ChunkedRows.single(a)
     n_local, g = chunks.n_rows, chunks.n_cols
     if g > GRAM_MAX_GENES or not hasattr(backend, "gram"):
         return None
@@ -607,6 +680,11 @@ def pca_fit(a, n_comps: int, *, backend=None, comm=None, zero_center: bool = Tru
     """`a` = backend handle of this rank's CSR rows (from `backend.upload`)."""
     backend = backend or GpuBackend()
     comm = comm or NoComm()
+    if isinstance(a, _HostCsrOverlapped):  # (a host matrix whose upload overlaps the Gram kernel; any other route: plain upload)
+        res = _pca_fit_gram(a, n_comps, backend, comm, zero_center, seed, tol) if svd_solver in ("arpack", "auto", "covariance_eigh") else None
+        if res is not None:
+            return res
+        a = a._full if a._full is not None else backend.upload(a.x)
     if isinstance(a, _ChunkedRows):  # streamed row chunks: only the (additive) Gram route applies
         res = _pca_fit_gram(a, n_comps, backend, comm, zero_center, seed, tol)
         if res is None:

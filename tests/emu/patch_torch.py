@@ -31,6 +31,9 @@ def activate() -> None:
         def wait_stream(self, other):
             pass
 
+        def wait_event(self, event):
+            pass
+
     cpu = torch.device("cpu")
     torch.cuda.is_available = lambda: True
     torch.cuda.synchronize = lambda *a, **k: None

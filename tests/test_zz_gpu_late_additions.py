@@ -121,3 +121,39 @@ def test_counts_on_disk_to_clusters(sc, tmp_path, pbmc68k):
     np.testing.assert_array_equal(b.obsm["X_pca"], a.obsm["X_pca"])
     np.testing.assert_array_equal(b.varm["PCs"], a.varm["PCs"])
     assert (b.X.to_memory() != a.X).nnz == 0
+
+
+def test_pca_overlapped_upload_equals_plain_upload(monkeypatch):
+    """`pp.pca` of a large HOST matrix uploads the value array first (max|x| fixes the fixed-point scale) and the column indices in
+    row chunks under the Gram kernel of the chunk before (`_pca_solver._HostCsrOverlapped`: the host-to-host metric of SURVEY
+    8(d)).  Integer sums: every output equals the plain upload's bit for bit -- also with empty rows, one chunk, many chunks."""
+    import scanpy_amd as sc
+    from scanpy_amd.datasets import synthetic_planted
+    from scanpy_amd.preprocessing import _pca_solver
+
+    x, _ = synthetic_planted(30000, 900, n_types=20, seed=11)
+    x = x.tolil()
+    x[5, :] = 0  # an empty row, and an empty stretch at the end
+    x[29990:, :] = 0
+    x = x.tocsr().astype(np.float32)
+    x.eliminate_zeros()
+    monkeypatch.setenv("SCAMD_PCA_OVERLAP_UPLOAD", "0")
+    ref = sc.AnnData(x.copy())
+    sc.pp.pca(ref, n_comps=30)
+    monkeypatch.delenv("SCAMD_PCA_OVERLAP_UPLOAD")
+    monkeypatch.setenv("SCAMD_PCA_OVERLAP_MIN_NNZ", "0")
+    seen = []
+    orig = _pca_solver._HostCsrOverlapped.__init__
+
+    for n_chunks in (1, 6, 37):
+        def init(self, x_csr, n_chunks_=6, _n=n_chunks):
+            orig(self, x_csr, _n)
+            seen.append(self.n_chunks)
+
+        monkeypatch.setattr(_pca_solver._HostCsrOverlapped, "__init__", init)
+        a = sc.AnnData(x.copy())
+        sc.pp.pca(a, n_comps=30)
+        np.testing.assert_array_equal(a.obsm["X_pca"], ref.obsm["X_pca"])
+        np.testing.assert_array_equal(a.varm["PCs"], ref.varm["PCs"])
+        np.testing.assert_array_equal(a.uns["pca"]["variance"], ref.uns["pca"]["variance"])
+    assert seen == [1, 6, 37]
