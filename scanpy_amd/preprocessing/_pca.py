@@ -173,7 +173,7 @@ def pca(  # noqa: PLR0912, PLR0913, PLR0915
             # in row chunks UNDER the Gram kernel of the chunk before (same bits as the one-shot fit: integer sums)
             from ._pca_solver import _HostCsrOverlapped
 
-            handle = _HostCsrOverlapped(xc)
+            handle = _HostCsrOverlapped(xc, int(os.environ.get("SCAMD_PCA_OVERLAP_CHUNKS", 6)))
         else:
             handle = backend.upload(xc)
         res = pca_fit(handle, n_comps, backend=backend, zero_center=zero_center, svd_solver=svd_solver, seed=seed)
