@@ -170,15 +170,21 @@ class Neighbors:
 
                 nprobe = int(settings.knn_nprobe)
             knn_indices, knn_distances = knn_search_device(x, k, metric=metric, nprobe=nprobe)
-            self._distances = sparse_distances_from_device(knn_indices, knn_distances)
+            # (the download of the distances runs on a side stream under the connectivity kernels below)
+            pending_distances = sparse_distances_from_device(knn_indices, knn_distances, deferred=True)
         else:  # user-supplied estimator instance: the reference's plug-in route, used as-is (:788, :638)
             self._distances = transformer.fit_transform(x)
             knn_indices, knn_distances = get_indices_distances_from_sparse_matrix(self._distances, n_neighbors)
+            pending_distances = None
         self._connectivities = None
-        if conn_method == "umap":
-            self._connectivities = _connectivities_umap(knn_indices, knn_distances, self._adata.n_obs)
-        elif conn_method in {"gauss", "jaccard"}:  # neighbors/__init__.py:694-708
-            self._connectivities = _connectivities_kernel(conn_method, knn_indices, knn_distances, self._adata.n_obs)
+        try:
+            if conn_method == "umap":
+                self._connectivities = _connectivities_umap(knn_indices, knn_distances, self._adata.n_obs)
+            elif conn_method in {"gauss", "jaccard"}:  # neighbors/__init__.py:694-708
+                self._connectivities = _connectivities_kernel(conn_method, knn_indices, knn_distances, self._adata.n_obs)
+        finally:
+            if pending_distances is not None:
+                self._distances = pending_distances()
         self._cc = None  # connected components (neighbors/__init__.py:666-671) are computed on first use
 
 

@@ -39,7 +39,7 @@ def csr_from_trusted_arrays(data, indices, indptr, shape) -> sparse.csr_matrix:
     return m
 
 
-def sparse_distances_from_device(idx, dist) -> sparse.csr_matrix:
+def sparse_distances_from_device(idx, dist, deferred: bool = False):
     """`get_sparse_matrix_from_indices_distances(..., keep_self=False)` (_common.py:35-61) for the (n, k) lists of the
     built-in search while they are still torch tensors: the self column is dropped on the device and the two arrays
     arrive on the host in their final layout (no host-side slicing copies)."""
@@ -53,10 +53,44 @@ def sparse_distances_from_device(idx, dist) -> sparse.csr_matrix:
     itype = torch.int32 if max(nnz, n) < 2**31 else torch.int64
     from .._device import to_host
 
-    indices = to_host(idx[:, 1:].to(itype).contiguous().reshape(-1))
-    data = to_host(dist[:, 1:].contiguous().reshape(-1))
-    indptr = np.arange(0, nnz + 1, k - 1, dtype=indices.dtype) if k > 1 else np.zeros(n + 1, dtype=indices.dtype)
-    return csr_from_trusted_arrays(data, indices, indptr, (n, n))
+    indices_d = idx[:, 1:].to(itype).contiguous().reshape(-1)
+    data_d = dist[:, 1:].contiguous().reshape(-1)
+
+    def finish(indices, data):
+        indptr = np.arange(0, nnz + 1, k - 1, dtype=indices.dtype) if k > 1 else np.zeros(n + 1, dtype=indices.dtype)
+        return csr_from_trusted_arrays(data, indices, indptr, (n, n))
+
+    if not deferred:
+        return finish(to_host(indices_d), to_host(data_d))
+    # deferred: the two arrays cross the link on a side stream while the caller's next kernels (the connectivities) run on the
+    # compute stream; the returned callable waits for them and builds the matrix (host-to-host metric)
+    from .._device import _PINNED_RESULT_MAX
+
+    nbytes = max(indices_d.numel() * indices_d.element_size(), data_d.numel() * data_d.element_size())
+    if not indices_d.is_cuda or nbytes < (8 << 20) or nbytes > _PINNED_RESULT_MAX:
+        out = finish(to_host(indices_d), to_host(data_d))
+        return lambda: out
+    dev = indices_d.device
+    main = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(device=dev)
+    ready = torch.cuda.Event()
+    ready.record(main)
+    hosts = []
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        for t in (indices_d, data_d):
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            t.record_stream(side)
+            hosts.append(h)
+    done = torch.cuda.Event()
+    done.record(side)
+
+    def wait():
+        done.synchronize()
+        return finish(hosts[0].numpy(), hosts[1].numpy())
+
+    return wait
 
 
 def graph_from_device(indptr, indices, data, n_obs: int) -> sparse.csr_matrix:

@@ -157,3 +157,31 @@ def test_pca_overlapped_upload_equals_plain_upload(monkeypatch):
         np.testing.assert_array_equal(a.varm["PCs"], ref.varm["PCs"])
         np.testing.assert_array_equal(a.uns["pca"]["variance"], ref.uns["pca"]["variance"])
     assert seen == [1, 6, 37]
+
+
+def test_deferred_distances_download_equals_direct():
+    """`pp.neighbors` downloads `distances` on a side stream while the connectivity kernels run (neighbors/_common.py:
+    sparse_distances_from_device(deferred=True)); at a size that takes the page-locked route (>= 8 MB per array) the matrix
+    equals the one the blocking download builds, and the connectivities are those of the same lists"""
+    import torch
+
+    import scanpy_amd as sc
+    from scanpy_amd.neighbors._common import sparse_distances_from_device
+    from scanpy_amd.neighbors._transformer import knn_search_device
+
+    rng = np.random.default_rng(3)
+    n = 120_000
+    emb = rng.normal(size=(n, 12)).astype(np.float32)
+    adata = sc.AnnData(sparse.csr_matrix((n, 1), dtype=np.float32))
+    adata.obsm["X_pca"] = emb
+    sc.pp.neighbors(adata, n_neighbors=15)
+    idx, dist = knn_search_device(emb, 15)
+    direct = sparse_distances_from_device(idx, dist)
+    d = adata.obsp["distances"]
+    assert d.nnz == direct.nnz == n * 14
+    np.testing.assert_array_equal(d.indices, direct.indices)
+    np.testing.assert_array_equal(d.data, direct.data)
+    np.testing.assert_array_equal(d.indptr, direct.indptr)
+    c = adata.obsp["connectivities"]
+    assert c.shape == (n, n) and abs(c - c.T).max() < 1e-7 and c.nnz >= d.nnz
+    torch.cuda.synchronize()
