@@ -174,7 +174,7 @@ def test_deferred_distances_download_equals_direct():
     emb = rng.normal(size=(n, 12)).astype(np.float32)
     adata = sc.AnnData(sparse.csr_matrix((n, 1), dtype=np.float32))
     adata.obsm["X_pca"] = emb
-    sc.pp.neighbors(adata, n_neighbors=15)
+    sc.pp.neighbors(adata, n_neighbors=15, use_rep="X_pca")  # (one variable in X: the default representation would be X itself)
     idx, dist = knn_search_device(emb, 15)
     direct = sparse_distances_from_device(idx, dist)
     d = adata.obsp["distances"]
