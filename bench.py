@@ -20,7 +20,8 @@ Extra objects in the line:
                 duration (scamd_knn_last_select_ms), peak = 2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md).  Beside it
                 `f32_equivalent_tflops` = 2 * 50 flop per pair (what the float32 engine of rounds 1-2 was priced on;
                 its peak was the 157.3 TFLOP/s of the f32-input MFMA).  SCAMD_KNN_B3=0 runs the float32 engine.
-  value_host_to_host   the BASELINE metric at the drop-in boundary: AnnData with a host CSR in -> sc.pp.pca /
+  value_h2h (= value_host_to_host; also config.value_h2h_cells_per_s / config.h2h_ms_per_pass, which the driver's record keeps)
+                the BASELINE metric at the drop-in boundary: AnnData with a host CSR in -> sc.pp.pca /
                 sc.pp.neighbors / sc.tl.leiden -> slots written on the host (H2D, kernels, D2H, scipy / pandas slot
                 construction), warm process, best of `--h2h-reps`; `value` is the device-resident figure.
   structure_none       the same path on the pure-noise variant of the matrix: nothing can be pruned, the
@@ -36,8 +37,10 @@ Extra objects in the line:
                 lists of the timed step, stage and select-kernel time, fraction of the pairs evaluated, per nprobe.
   cpu_baseline  the reference's CPU call chain (sklearn PCA arpack + sklearn brute kNN = reference calls; oracle
                 fuzzy set + oracle Leiden) on the first n cells of the same matrix for n in `--cpu-sizes`, on this box's
-                host cores; kNN fitted with the n^2 law, the other stages linearly, and extrapolated to the full size
-                (BASELINE.md section 3).
+                host cores.  The default sizes END WITH THE FULL 1M CELLS (round 6): `value` is then the measured run
+                (`measured_at_full_size`, ~170 s on the GPU box's 256 cores), `extrapolated_seconds_at_full_size` what
+                the two small samples predicted (kNN fitted with the n^2 law, the other stages linearly; BASELINE.md
+                section 3); a box on which the full size does not fit `--cpu-budget-s` reports the fit and says so.
   parity        (`--verify`, default at N=1) the GPU path against that CPU chain on the largest CPU sample, stage by
                 stage (every stage fed the CPU chain's previous output, so a gate isolates one stage) and end to end;
                 the process exits non-zero when a north_star gate breaks.
