@@ -49,6 +49,13 @@ def _patch_kernels():
         memb, q = ol.leiden(adj, resolution=resolution, n_iterations=n_iterations, seed=seed)
         return torch.from_numpy(memb.astype(np.int32)), q, int(memb.max()) + 1
 
+    def modularity(indptr, indices, weights, n, membership, *, resolution=1.0):
+        """CPU stand-in of scamd_modularity_csr_f32 (what `tl.leiden` stores when the run's resolution is not 1)"""
+        from scipy import sparse
+
+        adj = sparse.csr_matrix((weights.numpy(), indices.numpy(), indptr.numpy()), shape=(n, n))
+        return ol.modularity(adj, membership.numpy(), resolution=resolution)
+
     def fuzzy_weights(knn_idx, knn_dist, row_begin, n_total, sum_all):
         """membership strengths of a row shard (CPU stand-in of scamd_fuzzy_weights_f32)"""
         idx = knn_idx.numpy()
@@ -86,6 +93,7 @@ def _patch_kernels():
     _kernels.fuzzy_weights = fuzzy_weights
     _kernels.fuzzy_merge_rows = fuzzy_merge_rows
     _kernels.leiden = leiden
+    _kernels.modularity = modularity
     _kernels.leiden_last_stats = lambda: {}  # (the library's thread-local stats say nothing about a stand-in run)
 
 
