@@ -741,19 +741,6 @@ __device__ __forceinline__ void knn_select_reg_block(const int blk, const float*
   auto chain = [&](const BFrag& b, float athr_op) -> f32x16 {
     if constexpr (B3) {
       (void)athr_op;
-      if constexpr (IVF) {
-        // probe (SCAMD_KNN_DEBUG_NO_INSERT=2, WRONG results): the hi.hi product alone -- what a coarse first stage of the
-        // sweep would cost
-        if (iv.debug_no_insert == 2) {
-          f32x16 acc;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qh[s]), __builtin_bit_cast(bf16x8, b.h[s]), acc, 0, 0, 0);
-          return acc;
-        }
-      }
       return b3_chain(qh, ql, b);
     } else {
       f32x16 acc;
@@ -2671,7 +2658,7 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   }
   {
     const char* e = getenv("SCAMD_KNN_DEBUG_NO_INSERT");
-    iv.debug_no_insert = (e && e[0] == '1') ? 1 : ((e && e[0] == '2') ? 2 : 0);
+    iv.debug_no_insert = (e && e[0] == '1') ? 1 : 0;
   }
   {
     const char* e = getenv("SCAMD_KNN_CELL_PRELOAD");  // A/B switch: 0 = every cell's sweep requests its first tile itself
