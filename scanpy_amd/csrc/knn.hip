@@ -741,7 +741,20 @@ __device__ __forceinline__ void knn_select_reg_block(const int blk, const float*
   auto chain = [&](const BFrag& b, float athr_op) -> f32x16 {
     if constexpr (B3) {
       (void)athr_op;
+#ifdef SCAMD_KNN_PROBE_HH
+      // PROBE BUILD ONLY (tools/knn_coarse_probe.sh compiles a second library with this macro; WRONG results): the hi.hi product
+      // alone -- what a coarse first stage of the sweep would cost.  (As a RUN-TIME switch on `iv` this branch made the
+      // production kernel 4.3 x slower -- 50.1 instead of 11.7 ms: DESIGN.md section 8, round 6.)
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qh[s]), __builtin_bit_cast(bf16x8, b.h[s]), acc, 0, 0, 0);
+      return acc;
+#else
       return b3_chain(qh, ql, b);
+#endif
     } else {
       f32x16 acc;
 #pragma unroll
