@@ -106,6 +106,9 @@ int scamd_knn_last_second_tier_queries(void);
 /* cells probed by this thread's last search: 0 = it was answered EXACTLY -- also when scamd_knn_l2_ivf_f32 was asked for a
  * shape its register-list kernel does not take (k > 24, d > 64, n < 4096); the Python layer tells the user. */
 int scamd_knn_last_nprobe(void);
+/* 1 if this thread's last pruned sweep ran with the coarse first stage (hi.hi product first, the other two products only for
+ * sub-tiles with a coarse survivor: chosen when the cell bounds prune little; same lists either way). */
+int scamd_knn_last_coarse(void);
 /* The certificate's error-bound factors of an engine (0 = float32, 1 = 3 x bf16), in units of u = 2^-24:
  *   |score_engine - score_exact| <= u * (cert_k * (||c||^2 + 2 ||q|| ||c||) + cert_k2 * 2 ||q|| ||c||) (+ key_slack * u * |tau|
  * for the slot bits of the list keys).  Read by the test that measures the bound (tests/test_gpu_knn_certificate.py). */

@@ -27,6 +27,7 @@ SIGNATURES = {
     "scamd_knn_last_select_engine": (_i32, []),
     "scamd_knn_last_second_tier_queries": (_i32, []),
     "scamd_knn_last_nprobe": (_i32, []),
+    "scamd_knn_last_coarse": (_i32, []),
     "scamd_knn_cert_factors": (None, [_i32, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64)]),
     "scamd_knn_debug_b3_scores_workspace_bytes": (_sz, [_i64]),
     "scamd_knn_debug_b3_scores_f32": (_i32, [_vp, _i64, _i32, _i64, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),

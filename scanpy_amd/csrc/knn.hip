@@ -30,6 +30,7 @@ static thread_local double g_last_select_pairs = -1.0;
 static thread_local double g_last_select_prepass_pairs = -1.0;
 static thread_local int g_last_select_engine = -1;
 static thread_local int g_last_second_tier = 0;
+static thread_local int g_last_coarse = 0;  // 1: the last pruned sweep ran with the coarse first stage
 static thread_local int g_last_nprobe = 0;  // cells probed by the last search on this thread (0: it was answered exactly)
 
 namespace scamd {
@@ -562,6 +563,7 @@ struct IvfArgs {
   int prepass_tiles;         // tiles of the own cell the threshold pre-pass scores (SCAMD_KNN_PREPASS_TILES, default 32 bf16 / 16 float32)
   int prepass_cells;         // cells (own cell first, then by ascending lower bound) the pre-pass covers (SCAMD_KNN_PREPASS_CELLS, default 1)
   int prepass_min2;          // 1: the starting threshold is taken from the two smallest scores per lane (SCAMD_KNN_PREPASS_MIN2, default 1)
+  const unsigned int* cmax_bits;  // float bits of the largest ||c||^2 of the image (the COARSE sweep's slack, see knn_select_reg_block)
   int debug_no_insert;       // debug (SCAMD_KNN_DEBUG_NO_INSERT=1): survivors are dropped -- WRONG results, MFMA-side ceiling
   int cell_preload;          // 1: (bf16 engine) the tile requests run on into the next cell of the block's order while the
                              // current cell's last tiles are scored (SCAMD_KNN_CELL_PRELOAD, default 1; 0: every cell starts cold)
@@ -642,12 +644,41 @@ __device__ __forceinline__ f32x16 b3_chain(const i32x4 (&qh)[4], const i32x4 (&q
   return acc;
 }
 
+// the two stages of the COARSE sweep (round 6): hi.hi first, then -- only for sub-tiles in which some coarse score passed the
+// widened threshold -- hi.lo and lo.hi on top of it: the same twelve instructions in the same order as b3_chain
+__device__ __forceinline__ f32x16 b3_chain_hh(const i32x4 (&qh)[4], const BFragBf16& b) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qh[s]), __builtin_bit_cast(bf16x8, b.h[s]), acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ f32x16 b3_chain_rest(const i32x4 (&qh)[4], const i32x4 (&ql)[4], const BFragBf16& b, f32x16 acc) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qh[s]), __builtin_bit_cast(bf16x8, b.l[s]), acc, 0, 0, 0);
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ql[s]), __builtin_bit_cast(bf16x8, b.h[s]), acc, 0, 0, 0);
+  return acc;
+}
+
 // one block of the search: 128 queries (brute force: queries blk * 128 ..; pruned sweep: the query slots of block blk)
-template <int H, int TC_, int WPS, bool IVF, bool B3>
+// COARSE (bf16 engine, pruned-sweep kernel; chosen by the host when the cell bounds prune little, i.e. a query meets >= 1e5
+// candidates): a sub-tile is first scored with the hi.hi product alone -- 4 of the 12 MFMAs -- against the threshold WIDENED
+// by `slack` >= |hi.lo + lo.hi| (bf16 round-to-nearest: |x_lo| <= 2^-8 |x| per coordinate, the query operand is -2 q, so the two
+// dropped products are bounded by 2 * 2 * 2^-8 (1 + 2^-8) ||q|| ||c|| <= 2^-6 * 1.02 ||q||_max(wave) ||c||_max(image)); only a
+// sub-tile with a coarse survivor gets the other 8 MFMAs, the slack is taken off again and the exact sign test / insertion
+// follow as in the plain kernel.  A candidate whose full score is below the threshold has a coarse score below threshold +
+// slack: the lists are the plain kernel's lists.  With 1M candidates per query ~10 % of the sub-tiles are refined.
+template <int H, int TC_, int WPS, bool IVF, bool B3, bool COARSE = false>
 __device__ __forceinline__ void knn_select_reg_block(const int blk, const float* __restrict__ xp, int n_tiles_all,
                                                      int64_t n_pad, int64_t q_begin, int thr_rank,
                                                      int* __restrict__ cand_idx, float* __restrict__ cand_tau,
                                                      const IvfArgs& iv) {
+  static_assert(!COARSE || (B3 && IVF), "the coarse first stage belongs to the bf16 engine's pruned sweep");
   using C = RegCfg<H, TC_, B3>;
   constexpr int HP = C::HP, DPL = C::DPL, TC = C::TC, SUBS = C::SUBS;
   using BFrag = std::conditional_t<B3, BFragBf16, BFragF32<HP>>;
@@ -682,12 +713,13 @@ __device__ __forceinline__ void knn_select_reg_block(const int blk, const float*
   // A operand of the extra k-pair: lanes 0..31 hold -thr of query (l&31), lanes 32..63 hold 1.0.
   // Until the lists are filled (sub-tile 0) the "threshold" is 0, i.e. the accumulator is the plain score.
   float athr = half ? 1.0f : 0.0f;
+  float slack = 0.f;  // COARSE: what the operand's threshold is widened by (0 during the pre-pass: plain scores)
   // B3: the threshold lives in dims 50..52 of the query operand as three bf16 pieces (their sum is -thr exactly); `athr`
   // stays the float32 master copy, this re-derives the pieces of all 32 queries of the wave after it changed
   auto sync_thr = [&]() {
     if constexpr (B3) {
       unsigned int t1, t2, t3;
-      split3_bf16(athr, t1, t2, t3);
+      split3_bf16(COARSE ? athr - slack : athr, t1, t2, t3);
       if (half == 0) {
         qh[3][1] = (int)(t1 | (t2 << 16));
         qh[3][2] = (int)(t3 | 0x3F800000u);
@@ -822,6 +854,32 @@ __device__ __forceinline__ void knn_select_reg_block(const int blk, const float*
                   float athr_prev, BFrag& b_nxt) {
     load_b(min(g + 1, n_sub - 1), b_nxt);  // (the clamp re-reads the last sub-tile: no branch in the region)
     athr_cur = athr;
+    if constexpr (COARSE) {
+      if (!minima) {
+        // no deferral here: the coarse chain is short, the other two waves of the SIMD fill its latency.  The step works IN
+        // acc_cur (no second accumulator: the kernel's register budget has none to spare); the deferred tests of the plain
+        // pipeline are skipped in this mode (here, and at the end of the sweep)
+        acc_cur = b3_chain_hh(qh, b_cur);
+        const int c0 = __float_as_int(acc_cur[0]) | __float_as_int(acc_cur[1]) | __float_as_int(acc_cur[2]);
+        const int c1 = __float_as_int(acc_cur[3]) | __float_as_int(acc_cur[4]) | __float_as_int(acc_cur[5]);
+        const int c2 = __float_as_int(acc_cur[6]) | __float_as_int(acc_cur[7]) | __float_as_int(acc_cur[8]);
+        const int c3 = __float_as_int(acc_cur[9]) | __float_as_int(acc_cur[10]) | __float_as_int(acc_cur[11]);
+        const int c4 = __float_as_int(acc_cur[12]) | __float_as_int(acc_cur[13]) | __float_as_int(acc_cur[14]);
+        const int c5 = (c0 | c1 | c2) | (c3 | c4 | __float_as_int(acc_cur[15]));
+        if (__any(c5 < 0)) {
+          if (iv.debug_no_insert) return;
+          acc_cur = b3_chain_rest(qh, ql, b_cur, acc_cur);
+          bool neg = false;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            acc_cur[r] += slack;  // score - thr again (the threshold the chain used was thr + slack)
+            neg |= acc_cur[r] < 0.f;
+          }
+          if (__any(neg)) insert(acc_cur, athr_cur, row0 + g * 32, false);
+        }
+        return;
+      }
+    }
     acc_cur = chain(b_cur, athr_cur);
     // sign test: OR of the 16 accumulators of the previous sub-tile (3-input ORs)
     const int o0 = __float_as_int(acc_prev[0]) | __float_as_int(acc_prev[1]) | __float_as_int(acc_prev[2]);
@@ -977,7 +1035,7 @@ __device__ __forceinline__ void knn_select_reg_block(const int blk, const float*
       }
       step(g + 1, bB, accB, athrB, accA, athrA, bA);
     }
-    {
+    if (!(COARSE && !minima)) {  // (the coarse sweep tests and inserts inside its steps)
       bool neg = false;
 #pragma unroll
       for (int r = 0; r < 16; ++r) neg |= accB[r] < 0.f;
@@ -1139,6 +1197,12 @@ __device__ __forceinline__ void knn_select_reg_block(const int blk, const float*
       // cells, by a factor 1.5 (profiles/r05r_knn_last_block_of_a_cell.log), and those blocks end their queues.  Their
       // threshold becomes -1e30: no score is below it, nothing is inserted, nothing of theirs is read.
       if (half == 0 && !qvalid) athr = 1e30f;
+      if constexpr (COARSE) {
+        float qmax2 = qvalid ? qn : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) qmax2 = fmaxf(qmax2, __shfl_xor(qmax2, o));
+        slack = 0.015625f * 1.02f * sqrtf(qmax2 * __uint_as_float(iv.cmax_bits[0]));
+      }
       sync_thr();
     }
     if (iv.trace && tid == 0) iv.trace[(size_t)blk * 8 + 5] = wall_clock64();
@@ -1220,13 +1284,13 @@ __device__ __forceinline__ void knn_select_reg_block(const int blk, const float*
 // off the other XCDs' queues.  The per-block timeline (profiles/r05p_knn_timeline.log) had the queues finish 0.9 ms apart
 // (12.30 .. 13.18 ms: the work estimates behind the static deal are a ranking, not a measurement) and 4 % of the block
 // slots empty in the steady state, waiting for the dispatcher.
-template <int H, int TC_, int WPS, bool IVF, bool B3 = false>
+template <int H, int TC_, int WPS, bool IVF, bool B3 = false, bool COARSE = false>
 __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* __restrict__ xp, int n_tiles_all,
                                                                   int64_t n_pad, int64_t q_begin,
                                                                   int thr_rank, int* __restrict__ cand_idx,
                                                                   float* __restrict__ cand_tau, IvfArgs iv) {
   if constexpr (!IVF) {
-    knn_select_reg_block<H, TC_, WPS, IVF, B3>((int)blockIdx.x, xp, n_tiles_all, n_pad, q_begin, thr_rank, cand_idx, cand_tau, iv);
+    knn_select_reg_block<H, TC_, WPS, IVF, B3, COARSE>((int)blockIdx.x, xp, n_tiles_all, n_pad, q_begin, thr_rank, cand_idx, cand_tau, iv);
   } else {
     using C = RegCfg<H, TC_, B3>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1254,7 +1318,7 @@ __global__ __launch_bounds__(256, WPS) void knn_select_reg_kernel(const float* _
         blk = *s_next;
       }
       if (blk < 0) return;
-      knn_select_reg_block<H, TC_, WPS, IVF, B3>(blk, xp, n_tiles_all, n_pad, q_begin, thr_rank, cand_idx, cand_tau, iv);
+      knn_select_reg_block<H, TC_, WPS, IVF, B3, COARSE>(blk, xp, n_tiles_all, n_pad, q_begin, thr_rank, cand_idx, cand_tau, iv);
     }
   }
 }
@@ -2640,6 +2704,30 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   auto kern = B3 ? ((wps_env && atoi(wps_env) == 2) ? knn_select_reg_kernel<H, 64, 2, true, B3> : knn_select_reg_kernel<H, 64, 3, true, B3>)
                  : ((wps_env && atoi(wps_env) == 2) ? knn_select_reg_kernel<H, 64, 2, true, false>
                                                      : knn_select_reg_kernel<H, 64, 3, true, false>);
+  // COARSE first stage (bf16 engine; knn_select_reg_block): pays when a query meets so many candidates that few 32 x 32
+  // sub-tiles hold one below its threshold -- the sweeps in which the cell bounds prune little.  Decided from the device's own
+  // work estimates (tiles within a cell's radius, ivf_cell_order_kernel), weighted by the cells' query blocks: expected
+  // candidates per query >= 1e5 (1M cells: the planted matrix ~3e4 -> plain kernel, the weak / structure-less ones 1e6 -> coarse;
+  // 10M x 4k ~2.5e5 -> coarse).  SCAMD_KNN_COARSE=0 / 1 forces the choice (A/B, tests).
+  bool coarse = false;
+  if constexpr (B3) {
+    const char* ce = getenv("SCAMD_KNN_COARSE");
+    if (ce && (ce[0] == '0' || ce[0] == '1')) {
+      coarse = ce[0] == '1';
+    } else {
+      std::vector<int> h_work(nc);
+      SCAMD_HIP_CHECK(hipMemcpyAsync(h_work.data(), b.cell_aux, sizeof(int) * nc, hipMemcpyDeviceToHost, s));
+      SCAMD_HIP_CHECK(hipStreamSynchronize(s));
+      double num = 0.0, den = 0.0;
+      for (int c = 0; c < nc; ++c) {
+        num += (double)h_blk[nc + c] * (double)h_work[c] * 64.0;
+        den += (double)h_blk[nc + c];
+      }
+      coarse = den > 0.0 && num / den >= 1.0e5;
+    }
+    if (coarse) kern = knn_select_reg_kernel<H, 64, 3, true, B3, B3>;  // (COARSE = B3: the float32 engine has no such instantiation)
+  }
+  g_last_coarse = coarse ? 1 : 0;
   const size_t lds = C::LDS_BYTES + 64 + IVF_META_BYTES;
   SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
@@ -2653,6 +2741,7 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   iv.order = b.cell_order;
   iv.order_lb2 = b.cell_lb2;
   iv.perm = b.perm;
+  iv.cmax_bits = b.cmax;
   iv.pairs = reinterpret_cast<unsigned long long*>(b.counters + 2);
   iv.n_cells = nc;
   iv.dc = d;
@@ -2805,6 +2894,7 @@ static int run_ivf_tier2(const KnnPlan& p, const KnnBuffers& b, const float* x, 
   iv.order = b.cell_order;
   iv.order_lb2 = b.cell_lb2;
   iv.perm = b.perm;
+  iv.cmax_bits = b.cmax;
   iv.pairs = reinterpret_cast<unsigned long long*>(ctr2 + 2);
   iv.n_cells = nc;
   iv.dc = d;
@@ -2848,6 +2938,7 @@ extern "C" double scamd_knn_last_select_prepass_pairs(void) { return g_last_sele
 extern "C" int scamd_knn_last_select_engine(void) { return g_last_select_engine; }
 extern "C" int scamd_knn_last_second_tier_queries(void) { return g_last_second_tier; }
 extern "C" int scamd_knn_last_nprobe(void) { return g_last_nprobe; }
+extern "C" int scamd_knn_last_coarse(void) { return g_last_coarse; }
 
 extern "C" size_t scamd_knn_workspace_bytes(int64_t n, int d, int64_t n_query, int k) {
   // one figure for the exact and the approximate entry point: the approximate plan goes through the cell tables at

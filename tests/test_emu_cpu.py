@@ -101,6 +101,43 @@ def test_knn_both_engines_brute_and_pruned(emu, monkeypatch, n, d, env):
     assert st["partial_collectives"] == st["mixed_collectives"] == st["reads_of_inactive_lanes"] == 0, st
 
 
+@pytest.mark.parametrize("kind", ["blobs", "noise", "offset"])
+def test_knn_coarse_first_stage_gives_the_same_lists(emu, monkeypatch, kind):
+    """the COARSE sweep of the bf16 engine (round 6: hi.hi product first against a threshold widened by a bound on the two
+    dropped products, the other eight MFMAs only for sub-tiles with a coarse survivor -- chosen by the host when the cell
+    bounds prune little): the float64 brute force's lists, no query in the fallback, on clustered data, on data without
+    structure (every cell swept: the regime it is for) and far from the origin (large norms = a large slack); both landing
+    modes of the LDS-DMA ring; and the SAME lists as the plain kernel"""
+    from oracle import compare as cmp
+
+    H, lib = emu
+    monkeypatch.setenv("SCAMD_KNN_IVF", "1")
+    monkeypatch.setenv("SCAMD_KNN_CELL_ROWS", "512")
+    n = 4300
+    rng = np.random.default_rng(5)
+    x = _blobs(n, 50, 8, 91, spread=3.0) if kind != "noise" else rng.standard_normal((n, 50)).astype(np.float32)
+    if kind == "offset":
+        x = (x + 40.0).astype(np.float32)
+    ei, ed = oknn.knn_exact_f64(x, np.arange(n), 15)
+    monkeypatch.setenv("SCAMD_KNN_COARSE", "0")
+    idx0, dist0, _ = H.knn(lib, x, 15)
+    assert lib.scamd_knn_last_coarse() == 0
+    monkeypatch.setenv("SCAMD_KNN_COARSE", "1")
+    try:
+        for late in (1, 0):
+            lib.emu_set_dma_late(late)
+            lib.emu_reset_stats()
+            idx, dist, n_fallback = H.knn(lib, x, 15)
+            assert lib.scamd_knn_last_coarse() == 1 and lib.scamd_knn_last_select_engine() == 1
+            bad, _ = cmp.knn_rows_differing_beyond_ties(idx, dist, ei, ed)
+            assert bad == 0 and n_fallback == 0, (kind, late, bad, n_fallback)
+            assert np.array_equal(np.sort(idx, axis=1), np.sort(idx0, axis=1)) and np.array_equal(np.sort(dist, axis=1), np.sort(dist0, axis=1))
+            st = H.stats(lib)
+            assert st["partial_collectives"] == st["mixed_collectives"] == st["reads_of_inactive_lanes"] == 0, st
+    finally:
+        lib.emu_set_dma_late(0)
+
+
 @pytest.mark.parametrize("ivf", ["1", "0"])
 def test_knn_lds_dma_ring_with_late_landing(emu, monkeypatch, ivf):
     """the bf16 engine's tile ring (three LDS buffers filled by LDS-DMA, two requests in flight across the barrier): the
