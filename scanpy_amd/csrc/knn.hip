@@ -644,6 +644,9 @@ __device__ __forceinline__ f32x16 b3_chain(const i32x4 (&qh)[4], const i32x4 (&q
   return acc;
 }
 
+#ifndef SCAMD_KNN_COARSE_PIPELINED
+#define SCAMD_KNN_COARSE_PIPELINED 1  // 0: test + refine inside the step that scored the sub-tile (A/B build)
+#endif
 // the two stages of the COARSE sweep (round 6): hi.hi first, then -- only for sub-tiles in which some coarse score passed the
 // widened threshold -- hi.lo and lo.hi on top of it: the same twelve instructions in the same order as b3_chain
 __device__ __forceinline__ f32x16 b3_chain_hh(const i32x4 (&qh)[4], const BFragBf16& b) {
@@ -850,8 +853,44 @@ __device__ __forceinline__ void knn_select_reg_block(const int blk, const float*
   int row0 = 0;  // image row of the current sweep's first candidate
   // One pipeline step = ONE scheduling region: chain of sub-tile g into acc_cur (with the thresholds in athr),
   // fragment reads of sub-tile g+1, sign test of the previous sub-tile's accumulator.
-  auto step = [&](int g, BFrag& b_cur, f32x16& acc_cur, float& athr_cur, const f32x16& acc_prev,
+  // COARSE: the second stage of a sub-tile whose coarse scores (in `acc`, taken against thr + slack) hold a survivor: the other
+  // eight MFMAs on its fragments `bf`, the slack off again, the exact sign test and the insertions
+  auto refine = [&](f32x16& acc, const BFrag& bf, float athr_used, int cbase) {
+    if constexpr (COARSE) {
+      acc = b3_chain_rest(qh, ql, bf, acc);
+      bool neg = false;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[r] += slack;  // score - thr again
+        neg |= acc[r] < 0.f;
+      }
+      if (__any(neg)) insert(acc, athr_used, cbase, false);
+    }
+  };
+  auto coarse_hit = [&](const f32x16& acc) -> bool {
+    const int c0 = __float_as_int(acc[0]) | __float_as_int(acc[1]) | __float_as_int(acc[2]);
+    const int c1 = __float_as_int(acc[3]) | __float_as_int(acc[4]) | __float_as_int(acc[5]);
+    const int c2 = __float_as_int(acc[6]) | __float_as_int(acc[7]) | __float_as_int(acc[8]);
+    const int c3 = __float_as_int(acc[9]) | __float_as_int(acc[10]) | __float_as_int(acc[11]);
+    const int c4 = __float_as_int(acc[12]) | __float_as_int(acc[13]) | __float_as_int(acc[14]);
+    const int c5 = (c0 | c1 | c2) | (c3 | c4 | __float_as_int(acc[15]));
+    return __any(c5 < 0);
+  };
+  auto step = [&](int g, BFrag& b_cur, f32x16& acc_cur, float& athr_cur, f32x16& acc_prev,
                   float athr_prev, BFrag& b_nxt) {
+    if constexpr (COARSE) {
+      if (!minima) {
+        if (SCAMD_KNN_COARSE_PIPELINED) {
+          // pipelined: the coarse chain of sub-tile g is issued, then the coarse scores of sub-tile g - 1 are tested -- and refined
+          // from ITS fragments, which b_nxt still holds -- and only then b_nxt takes sub-tile g + 1
+          athr_cur = athr;
+          acc_cur = b3_chain_hh(qh, b_cur);
+          if (coarse_hit(acc_prev) && !iv.debug_no_insert) refine(acc_prev, b_nxt, athr_prev, row0 + (g - 1) * 32);
+          load_b(min(g + 1, n_sub - 1), b_nxt);
+          return;
+        }
+      }
+    }
     load_b(min(g + 1, n_sub - 1), b_nxt);  // (the clamp re-reads the last sub-tile: no branch in the region)
     athr_cur = athr;
     if constexpr (COARSE) {
@@ -868,14 +907,7 @@ __device__ __forceinline__ void knn_select_reg_block(const int blk, const float*
         const int c5 = (c0 | c1 | c2) | (c3 | c4 | __float_as_int(acc_cur[15]));
         if (__any(c5 < 0)) {
           if (iv.debug_no_insert) return;
-          acc_cur = b3_chain_rest(qh, ql, b_cur, acc_cur);
-          bool neg = false;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            acc_cur[r] += slack;  // score - thr again (the threshold the chain used was thr + slack)
-            neg |= acc_cur[r] < 0.f;
-          }
-          if (__any(neg)) insert(acc_cur, athr_cur, row0 + g * 32, false);
+          refine(acc_cur, b_cur, athr_cur, row0 + g * 32);
         }
         return;
       }
@@ -1035,7 +1067,11 @@ __device__ __forceinline__ void knn_select_reg_block(const int blk, const float*
       }
       step(g + 1, bB, accB, athrB, accA, athrA, bA);
     }
-    if (!(COARSE && !minima)) {  // (the coarse sweep tests and inserts inside its steps)
+    if (COARSE && !minima) {
+      // (pipelined form: the last sub-tile's coarse scores are in accB, its fragments in bB; the step-local form has tested
+      // and inserted inside its steps)
+      if (SCAMD_KNN_COARSE_PIPELINED && coarse_hit(accB) && !iv.debug_no_insert) refine(accB, bB, athrB, row0 + (n_sub - 1) * 32);
+    } else {
       bool neg = false;
 #pragma unroll
       for (int r = 0; r < 16; ++r) neg |= accB[r] < 0.f;
