@@ -315,6 +315,376 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the PACKED kernel.  The disassembly of gram_tile_kernel above has ~150 instructions of per-step overhead in
+// front of ~120 that make products, its a-loop runs to the longest of the step's eight rows (11 against a mean of 6.4
+// entries) and once more for the rows with more than eight entries in tile b (83 % of the steps have one): 20 broadcast
+// rounds per step for 328 products; and every visit of a (row, tile) gathers its ~26 bytes of indices and of values out of
+// two 128-byte lines.  A first rewrite that only sorted the rows (same CSR gathers, three dependent load levels) issued a
+// quarter fewer instructions and took 9.5 ms instead of 6.7: it waited for memory 2.8 x as long.  Here
+//   * gram_pack_kernel rewrites the matrix once per call as records: per gene tile t a slab [n_pad][16] of 8-byte records
+//     {(column - t * GT) << 3 | count << 16, value}, absent entries zero: ONE aligned 128-byte line per (row, tile), read
+//     with a base in scalar registers and a 32-bit offset, no position table, no masks -- a zero value adds nothing;
+//   * the same kernel ranks the rows of every block of RB = 1024 by their number of entries per tile (counting sort in LDS):
+//     the eight rows of a step have the SAME number of entries in tile a, the broadcast loop over them wastes nothing;
+//   * the entries 8 .. 15 of tile b are not a second pass of that loop: the roles are exchanged for them (the lane keeps its
+//     tile-a entry, the overflow entries of tile b are broadcast: 2-3 rounds instead of another 6-11);
+//   * workgroups are dealt to the XCDs by tile neighbourhood (the pairs of a 4 x 4 block of the pair triangle share eight
+//     slabs), chunk by chunk: what one workgroup pulled into the XCD's L2 the others find there.
+// Rows with more than 16 entries in a tile finish from the CSR arrays.  The products and their rounding are those of
+// gram_tile_kernel: the sums are the same integers.
+constexpr int RB = 1024;                 // rows per sorting block
+constexpr int STEPS_PER_BLOCK = RB / 8;  // eight rows per wave step
+constexpr int SORT_BINS = 64;            // entry counts 0 .. 62, 63+ share the last bin
+constexpr int SORT_TILES = 16;           // tiles ranked per pass (one wave scans one tile's bins)
+constexpr int REC = 16;                  // records per (row, tile): 128 bytes
+constexpr int PACK_MAX_TILES = 64;       // (the per-block count table: 64 KB of LDS; wider matrices take the round-2 kernel)
+
+// ent[t][row][k] (row < n_pad = blocks * RB; k < REC): the row's k-th entry in tile t, see above (rows >= n: all zero);
+// cnt8[row][t] = min(entries of the row in tile t, 255).  One row per wave, every record slot written (whole 128-byte lines).
+constexpr int PACK_WAVES = 4;
+__global__ __launch_bounds__(PACK_WAVES * 64) void gram_pack_kernel(const int64_t* __restrict__ indptr,
+                                                                   const int32_t* __restrict__ indices,
+                                                                   const float* __restrict__ data, int64_t n, int ntile,
+                                                                   uint2* __restrict__ ent, unsigned char* __restrict__ cnt8,
+                                                                   int64_t n_pad) {
+  __shared__ unsigned short pos[PACK_WAVES][PACK_MAX_TILES + 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned short* wpos = pos[wave];
+  const int64_t row = (int64_t)blockIdx.x * PACK_WAVES + wave;
+  if (row >= n_pad) return;
+  int64_t rb = 0;
+  int len = 0;
+  if (row < n) {
+    rb = indptr[row];
+    len = (int)(indptr[row + 1] - rb);
+  }
+  // wpos[t] = position in the row of its first entry with column >= t * GT (t = 0 .. ntile)
+  int prev_tile = -1;  // tile of the entry before this chunk
+  for (int e0 = 0; e0 < len; e0 += 64) {
+    const int e = e0 + lane;
+    const int t = (e < len) ? indices[rb + e] / GT : ntile;
+    int tp = __shfl_up(t, 1);
+    if (lane == 0) tp = prev_tile;
+    if (e < len)
+      for (int u = tp + 1; u <= t; ++u) wpos[u] = (unsigned short)e;
+    prev_tile = __shfl(t, 63);
+  }
+  const int last_tile = (len > 0) ? indices[rb + len - 1] / GT : -1;
+  for (int u = last_tile + 1 + lane; u <= ntile; u += 64) wpos[u] = (unsigned short)len;
+  __builtin_amdgcn_wave_barrier();  // (the wave's LDS writes above are read by other lanes below)
+  // the row's REC x ntile record slots, 64 at a time: lane -> (tile, k)
+  for (int sl = lane; sl < ntile * REC; sl += 64) {
+    const int t = sl / REC, k = sl % REC;
+    const int p0 = wpos[t], c = wpos[t + 1] - p0;
+    const bool have = k < c;
+    unsigned int col = 0u, vbits = 0u;
+    if (have) {
+      col = (unsigned int)(indices[rb + p0 + k] - t * GT);
+      vbits = __float_as_uint(data[rb + p0 + k]);
+    }
+    ent[((int64_t)t * n_pad + row) * REC + k] = make_uint2((col << 3) | ((unsigned int)min(c, 255) << 16), vbits);
+    if (k == 0) cnt8[row * ntile + t] = (unsigned char)min(c, 255);
+  }
+}
+
+// perm[t][blk * RB + i]: block-local number of the row with the i-th fewest entries in tile t (counting sort of a block's
+// rows, sixteen tiles per pass)
+__global__ __launch_bounds__(RB) void gram_rank_kernel(const unsigned char* __restrict__ cnt8, int ntile,
+                                                      unsigned short* __restrict__ perm, int64_t n_pad) {
+  __shared__ int hist[SORT_TILES * SORT_BINS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * RB;
+  const int r = threadIdx.x;
+  const unsigned char* cr = cnt8 + (row0 + r) * ntile;
+  for (int t0 = 0; t0 < ntile; t0 += SORT_TILES) {
+    const int nt = min(SORT_TILES, ntile - t0);
+    for (int i = threadIdx.x; i < SORT_TILES * SORT_BINS; i += RB) hist[i] = 0;
+    __syncthreads();
+    int bin[SORT_TILES], rank[SORT_TILES];
+#pragma unroll
+    for (int j = 0; j < SORT_TILES; ++j) {
+      bin[j] = 0, rank[j] = 0;
+      if (j < nt) {
+        bin[j] = min((int)cr[t0 + j], SORT_BINS - 1);
+        rank[j] = atomicAdd(&hist[j * SORT_BINS + bin[j]], 1);
+      }
+    }
+    __syncthreads();
+    {  // exclusive scan of every tile's bins: wave j owns tile j
+      const int v = hist[wave * SORT_BINS + lane];
+      int incl = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+      }
+      hist[wave * SORT_BINS + lane] = incl - v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SORT_TILES; ++j)
+      if (j < nt) perm[(int64_t)(t0 + j) * n_pad + row0 + hist[j * SORT_BINS + bin[j]] + rank[j]] = (unsigned short)r;
+    __syncthreads();
+  }
+}
+
+// maximum of a non-negative per-group value (the same in the eight lanes of a group) over the wave: one DPP step folds the
+// two groups of a row of sixteen lanes, the four rows meet in scalar registers
+__device__ __forceinline__ int wave_max_groups(int v) {
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true));  // row_shr:8: lanes 8 .. 15 see the row's other group
+  return max(max(__builtin_amdgcn_readlane(v, 15), __builtin_amdgcn_readlane(v, 31)),
+             max(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
+}
+
+// the k-th tile pair (a <= b) in blocked order: the triangle cut into 4 x 4 blocks, blocks row by row, pairs row by row inside
+__device__ inline void gram_blocked_pair(int k, int ntile, int* a_out, int* b_out) {
+  const int nb4 = (ntile + 3) / 4;
+  for (int ba = 0; ba < nb4; ++ba)
+    for (int bb = ba; bb < nb4; ++bb)
+      for (int a = 4 * ba; a < min(4 * ba + 4, ntile); ++a)
+        for (int b = max(a, 4 * bb); b < min(4 * bb + 4, ntile); ++b)
+          if (k-- == 0) {
+            *a_out = a, *b_out = b;
+            return;
+          }
+  *a_out = -1, *b_out = -1;
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(GRAM_THREADS) void gram_packed_kernel(
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ data, int ntile,
+    const uint2* __restrict__ ent, const unsigned short* __restrict__ perm, int64_t n_pad, int blocks_per_chunk, int nblk,
+    int n_chunks, double scale, unsigned long long* __restrict__ gram, int64_t ld, unsigned long long* __restrict__ colsum,
+    unsigned int* __restrict__ flag) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long tile[];  // [GT][GT] + [GT] column sums + the item
+  unsigned long long* csum = tile + GT * GT;
+  int* s_item = reinterpret_cast<int*>(csum + GT);
+  if constexpr (!FAST) {
+    if (*flag == 0u) return;
+  }
+  // launch slot -> (XCD, slot of the XCD) -> (chunk, pair): XCD x owns the pairs [x * npair / 8, (x + 1) * npair / 8) of the
+  // blocked order and runs them chunk after chunk (workgroup i is dispatched to XCD i mod 8)
+  if (threadIdx.x == 0) {
+    const int npair = ntile * (ntile + 1) / 2;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int p_lo = (int)((int64_t)xcd * npair / 8), p_hi = (int)((int64_t)(xcd + 1) * npair / 8);
+    const int px = p_hi - p_lo;
+    int a = -1, b = -1, chunk = -1;
+    if (px > 0 && slot < px * n_chunks) {
+      chunk = slot / px;
+      gram_blocked_pair(p_lo + slot % px, ntile, &a, &b);
+    }
+    s_item[0] = a, s_item[1] = b, s_item[2] = chunk;
+  }
+  __syncthreads();
+  const int a = s_item[0], b = s_item[1], chunk = s_item[2];
+  if (a < 0) return;
+  const bool diag = (a == b);
+  for (int i = threadIdx.x; i < GT * GT + GT; i += GRAM_THREADS) tile[i] = 0ull;
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rs = lane >> 3, q = lane & 7;
+  const int blk0 = chunk * blocks_per_chunk;
+  const int blk1 = min(nblk, blk0 + blocks_per_chunk);
+  const int steps = (blk1 - blk0) * STEPS_PER_BLOCK;
+  const int a0 = a * GT, b0 = b * GT;
+  const unsigned short* perm_a = perm + (int64_t)a * n_pad + (int64_t)blk0 * RB;
+  // slabs of the two tiles from the chunk's first row on, addressed in bytes by a 32-bit offset
+  const char* ent_a = reinterpret_cast<const char*>(ent + ((int64_t)a * n_pad + (int64_t)blk0 * RB) * REC);
+  const char* ent_b = reinterpret_cast<const char*>(ent + ((int64_t)b * n_pad + (int64_t)blk0 * RB) * REC);
+  char* tile_b = reinterpret_cast<char*>(tile);
+  float amax = 0.f, bmax = 0.f;
+  auto round_product = [&](double x) -> unsigned long long {
+    if constexpr (FAST) {
+      return (unsigned long long)(__double_as_longlong(x + 6755399441055744.0) - 0x4338000000000000ll);
+    } else {
+      return (unsigned long long)fixed_round(x);
+    }
+  };
+  auto add_at = [&](int byte_off, unsigned long long v) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(tile_b + byte_off), v);
+  };
+
+  // two levels of loads, each requested ahead of the level that needs its result (RAW values are kept until then: section
+  // 3.0 of DESIGN.md): the sorted rows of the steps s + 2 WS .. and the records of step s + WS are in flight while step s
+  // is computed
+  struct Ent {  // lane q: records q and q + 8 of either tile
+    uint2 a1, a2, b1, b2;
+  };
+  auto clamp_step = [&](int s) -> int { return min(s, steps - 1); };
+  auto load_perm = [&](int s) -> unsigned short { return perm_a[(unsigned int)(clamp_step(s) * 8 + rs)]; };
+  auto row_offset = [&](int s, unsigned short prow) -> unsigned int {  // byte offset of the row's records within a slab
+    return ((unsigned int)(clamp_step(s) >> 7) * RB + prow) * (REC * 8u) + (unsigned int)q * 8u;
+  };
+  auto load_ent = [&](unsigned int off) -> Ent {
+    Ent e;
+    e.a1 = *reinterpret_cast<const uint2*>(ent_a + off);
+    e.a2 = *reinterpret_cast<const uint2*>(ent_a + off + 64);
+    e.b1 = *reinterpret_cast<const uint2*>(ent_b + off);
+    e.b2 = *reinterpret_cast<const uint2*>(ent_b + off + 64);
+    return e;
+  };
+
+  auto compute = [&](const Ent& e, int s, unsigned short prow) __attribute__((always_inline)) {
+    const int na = (int)(e.a1.x >> 16), nb = (int)(e.b1.x >> 16);
+    // sorted ascending: the last group of the step has the most entries in tile a (bin 63 holds every count >= 63)
+    int namax = __builtin_amdgcn_readlane(na, 63);
+    if (namax >= SORT_BINS - 1) namax = wave_max_groups(na);
+    const int nbmax = wave_max_groups(nb);
+    if (namax == 0 || nbmax == 0) return;
+    const int jb_o = (int)(e.b1.x & 0x3f8u), jb2_o = (int)(e.b2.x & 0x3f8u);
+    const int ja_o = (int)(e.a1.x & 0x3f8u) << 7, ja2_o = (int)(e.a2.x & 0x3f8u) << 7;
+    const float va = __uint_as_float(e.a1.y), va2 = __uint_as_float(e.a2.y);
+    const float vb = __uint_as_float(e.b1.y), vb2 = __uint_as_float(e.b2.y);
+    if constexpr (FAST) {
+      amax = fmaxf(amax, fmaxf(fabsf(va), fabsf(va2)));
+      bmax = fmaxf(bmax, fmaxf(fabsf(vb), fabsf(vb2)));
+    }
+    if (diag) {  // column sums ride along on the diagonal items
+      if (q < na) atomicAdd(&csum[ja_o >> 10], (unsigned long long)fixed_round((double)va * scale));
+      if (q + 8 < na) atomicAdd(&csum[ja2_o >> 10], (unsigned long long)fixed_round((double)va2 * scale));
+    }
+    int j8[8];
+    float v8[8];
+#define SCAMD_GRAM_BCAST(JSRC, VSRC)                                                                     \
+  j8[0] = bcast8<0>(JSRC); v8[0] = __int_as_float(bcast8<0>(__float_as_int(VSRC)));                      \
+  j8[1] = bcast8<1>(JSRC); v8[1] = __int_as_float(bcast8<1>(__float_as_int(VSRC)));                      \
+  j8[2] = bcast8<2>(JSRC); v8[2] = __int_as_float(bcast8<2>(__float_as_int(VSRC)));                      \
+  j8[3] = bcast8<3>(JSRC); v8[3] = __int_as_float(bcast8<3>(__float_as_int(VSRC)));                      \
+  j8[4] = bcast8<4>(JSRC); v8[4] = __int_as_float(bcast8<4>(__float_as_int(VSRC)));                      \
+  j8[5] = bcast8<5>(JSRC); v8[5] = __int_as_float(bcast8<5>(__float_as_int(VSRC)));                      \
+  j8[6] = bcast8<6>(JSRC); v8[6] = __int_as_float(bcast8<6>(__float_as_int(VSRC)));                      \
+  j8[7] = bcast8<7>(JSRC); v8[7] = __int_as_float(bcast8<7>(__float_as_int(VSRC)))
+    // `cnt` of the eight broadcast entries are real (wave-uniform): nested so that the first missing entry leaves the chain with
+    // ONE forward branch, the likely side laid out in line (a taken branch costs as much as the product it guards)
+#define SCAMD_GRAM_P(K, OFF, VS) add_at(j8[K] + (OFF), round_product((double)v8[K] * (VS)))
+#define SCAMD_GRAM_CHAIN(CNT, OFF, VS)                                   \
+  do {                                                                   \
+    const int cnt_ = (CNT);                                              \
+    if (__builtin_expect(cnt_ > 0, 1)) { SCAMD_GRAM_P(0, OFF, VS);       \
+    if (__builtin_expect(cnt_ > 1, 1)) { SCAMD_GRAM_P(1, OFF, VS);       \
+    if (__builtin_expect(cnt_ > 2, 1)) { SCAMD_GRAM_P(2, OFF, VS);       \
+    if (__builtin_expect(cnt_ > 3, 1)) { SCAMD_GRAM_P(3, OFF, VS);       \
+    if (__builtin_expect(cnt_ > 4, 1)) { SCAMD_GRAM_P(4, OFF, VS);       \
+    if (__builtin_expect(cnt_ > 5, 1)) { SCAMD_GRAM_P(5, OFF, VS);       \
+    if (__builtin_expect(cnt_ > 6, 1)) { SCAMD_GRAM_P(6, OFF, VS);       \
+    if (__builtin_expect(cnt_ > 7, 1)) { SCAMD_GRAM_P(7, OFF, VS); } } } } } } } } \
+  } while (0)
+    // (1) the first eight entries of tile b stay in their lanes, the entries of tile a are broadcast one after the other
+    SCAMD_GRAM_BCAST(ja_o, va);
+    if (q < nb) {
+      const double vbs = (double)vb * scale;
+      SCAMD_GRAM_CHAIN(namax, jb_o, vbs);
+    }
+    if (namax > 8) {
+      SCAMD_GRAM_BCAST(ja2_o, va2);
+      if (q < nb) {
+        const double vbs = (double)vb * scale;
+        SCAMD_GRAM_CHAIN(namax - 8, jb_o, vbs);
+      }
+    }
+    // (2) entries 8 .. 15 of tile b: the roles exchanged -- the lane keeps its tile-a entries, these are broadcast
+    if (nbmax > 8) {
+      SCAMD_GRAM_BCAST(jb2_o, vb2);
+      const int nb2max = min(nbmax, 16) - 8;
+      if (q < na && nb > 8) {
+        const double vas = (double)va * scale;
+        SCAMD_GRAM_CHAIN(nb2max, ja_o, vas);
+      }
+      if (namax > 8) {
+        if (q + 8 < na && nb > 8) {
+          const double vas2 = (double)va2 * scale;
+          SCAMD_GRAM_CHAIN(nb2max, ja2_o, vas2);
+        }
+      }
+    }
+#undef SCAMD_GRAM_CHAIN
+#undef SCAMD_GRAM_P
+#undef SCAMD_GRAM_BCAST
+    // (3) rows with more than sixteen entries in either tile: the remaining products from the CSR arrays (every lane of a
+    // group finds the row's two tile ranges by bisection -- a rare path)
+    if (namax > REC || nbmax > REC) {
+      const int64_t row = ((int64_t)(blk0 + (s >> 7))) * RB + prow;
+      int64_t rb = 0;
+      int len = 0;
+      if (na > REC || nb > REC) {  // (padding rows behind the matrix have no indptr entry)
+        rb = indptr[row];
+        len = (int)(indptr[row + 1] - rb);
+      }
+      auto lower = [&](int col) -> int {  // first position of the row with column >= col
+        int lo = 0, hi = len;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (indices[rb + mid] < col) lo = mid + 1;
+          else hi = mid;
+        }
+        return lo;
+      };
+      const int pa_rel = lower(a0), pb_rel = lower(b0);
+      const int na_f = lower(a0 + GT) - pa_rel, nb_f = lower(b0 + GT) - pb_rel;  // the full counts (the records cap them at 255)
+      const int64_t pa = rb + pa_rel, pb = rb + pb_rel;
+      const int na_fmax = wave_max_groups(na_f), nb_fmax = wave_max_groups(nb_f);
+      if (diag)
+        for (int ia = REC + q; ia < na_fmax; ia += 8)
+          if (ia < na_f) atomicAdd(&csum[indices[pa + ia] - a0], (unsigned long long)fixed_round((double)data[pa + ia] * scale));
+      for (int cb = 0; cb < nb_fmax; cb += 8) {
+        const int ib = cb + q;
+        const bool hb = ib < nb_f;
+        int jbo = 0;
+        double vs = 0.0;
+        if (hb) {
+          jbo = (indices[pb + ib] - b0) << 3;
+          const float v = data[pb + ib];
+          if constexpr (FAST) bmax = fmaxf(bmax, fabsf(v));
+          vs = (double)v * scale;
+        }
+        for (int ia = (cb < REC ? REC : 0); ia < na_fmax; ++ia) {
+          if (hb && ia < na_f) {
+            const float v = data[pa + ia];
+            if constexpr (FAST) amax = fmaxf(amax, fabsf(v));
+            add_at(((indices[pa + ia] - a0) << 10) + jbo, round_product((double)v * vs));
+          }
+        }
+      }
+    }
+  };
+
+  if (steps > 0) {
+    constexpr int WS = GRAM_THREADS / 64;  // the wave's stride over the steps
+    unsigned short pr_cur = load_perm(wave), pr_nxt = load_perm(wave + WS), pr_nn = load_perm(wave + 2 * WS);
+    Ent en_cur = load_ent(row_offset(wave, pr_cur));
+    for (int s = wave; s < steps; s += WS) {
+      const unsigned short pr_3 = load_perm(s + 3 * WS);
+      const Ent en_nxt = load_ent(row_offset(s + WS, pr_nxt));
+      compute(en_cur, s, pr_cur);
+      en_cur = en_nxt;
+      pr_cur = pr_nxt;
+      pr_nxt = pr_nn;
+      pr_nn = pr_3;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < GT * GT; i += GRAM_THREADS) {
+    const unsigned long long v = tile[i];
+    if (v) atomicAdd(&gram[(int64_t)(a0 + i / GT) * ld + b0 + (i % GT)], v);
+  }
+  if (diag)
+    for (int i = threadIdx.x; i < GT; i += GRAM_THREADS)
+      if (csum[i]) atomicAdd(&colsum[a0 + i], csum[i]);
+  if constexpr (FAST) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      amax = fmaxf(amax, __shfl_xor(amax, o));
+      bmax = fmaxf(bmax, __shfl_xor(bmax, o));
+    }
+    if (!((double)amax * ((double)bmax * scale) < 2251799813685248.0) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+  }
+}
+
 // the fast pass met a product outside the range of its rounding: clear what it accumulated
 __global__ void gram_clear_if_flagged_kernel(unsigned long long* __restrict__ gram, int64_t n_gram,
                                              unsigned long long* __restrict__ colsum, int64_t n_col,
@@ -335,12 +705,42 @@ __global__ void gram_mirror_kernel(long long* __restrict__ gram, int64_t gp, int
 
 using namespace scamd;
 
+// what either kernel family needs: the packed records + per-tile row orders (g <= 64 tiles), or the round-2 tile pointers
+struct GramCarve {
+  uint2* ent = nullptr;
+  unsigned short* perm = nullptr;
+  unsigned char* cnt8 = nullptr;
+  unsigned short* ptr = nullptr;
+  unsigned int* mx = nullptr;
+  bool packed = false;
+};
+static bool gram_use_packed(int64_t n, int64_t ntile) {
+  static const bool legacy = [] {
+    const char* e = getenv("SCAMD_GRAM_LEGACY");
+    return e && e[0] == '1';
+  }();
+  const int64_t n_pad = (n + RB - 1) / RB * RB;
+  return !legacy && ntile <= PACK_MAX_TILES && n_pad * REC * 8 < ((int64_t)1 << 32);
+}
+static GramCarve gram_carve(Workspace& ws, int64_t n, int64_t ntile) {
+  GramCarve c;
+  c.packed = gram_use_packed(n, ntile);
+  const int64_t n_pad = (n + RB - 1) / RB * RB;
+  if (c.packed) {
+    c.ent = ws.take<uint2>((size_t)ntile * n_pad * REC);
+    c.perm = ws.take<unsigned short>((size_t)ntile * n_pad);
+    c.cnt8 = ws.take<unsigned char>((size_t)ntile * n_pad);
+  } else {
+    c.ptr = ws.take<unsigned short>((size_t)n * (ntile + 1));
+  }
+  c.mx = ws.take<unsigned int>(4);
+  return c;
+}
+
 extern "C" size_t scamd_csr_gram_workspace_bytes(int64_t n, int64_t g) {
   if (n <= 0 || g <= 0) return 0;
-  const int64_t ntile = (g + GT - 1) / GT;
   Workspace ws(nullptr, 0);
-  (void)ws.take<unsigned short>((size_t)n * (ntile + 1));
-  (void)ws.take<unsigned int>(4);
+  (void)gram_carve(ws, n, (g + GT - 1) / GT);
   return ws.used();
 }
 
@@ -354,9 +754,11 @@ extern "C" int scamd_csr_gram_f32(const int64_t* indptr, const int32_t* indices,
                 (long long)g);
   const int ntile = (int)((g + GT - 1) / GT);
   const int64_t gp = (int64_t)ntile * GT;
+  const int nblk = (int)((n + RB - 1) / RB);
+  const int64_t n_pad = (int64_t)nblk * RB;
   Workspace ws(workspace, workspace_bytes);
-  unsigned short* ptr = ws.take<unsigned short>((size_t)n * (ntile + 1));
-  unsigned int* mx = ws.take<unsigned int>(4);
+  const GramCarve cv = gram_carve(ws, n, ntile);
+  unsigned int* mx = cv.mx;
   SCAMD_REQUIRE(workspace && ws.ok, SCAMD_EWORKSPACE, "gram: workspace %zu < required %zu", workspace_bytes, ws.used());
   hipStream_t s = stream;
   if (absmax_host) {  // phase 1: max |x| (the caller derives scale_bits from it, possibly after a max all-reduce)
@@ -375,52 +777,84 @@ extern "C" int scamd_csr_gram_f32(const int64_t* indptr, const int32_t* indices,
   SCAMD_REQUIRE(scale_bits >= 0 && scale_bits <= 60, SCAMD_EINVAL, "gram: scale_bits=%d", scale_bits);
   SCAMD_HIP_CHECK(hipMemsetAsync(gram, 0, sizeof(int64_t) * gp * ld_gram, s));
   SCAMD_HIP_CHECK(hipMemsetAsync(colsum, 0, sizeof(int64_t) * gp, s));
-  hipLaunchKernelGGL(gram_tileptr_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, s, indptr, indices, n, ntile, ptr);
-  SCAMD_LAUNCH_CHECK();
   const int npair = ntile * (ntile + 1) / 2;
-  // ~8 items per CU: enough to balance, few enough that the 128 KB flushes stay negligible
-  int n_chunks = std::max(1, std::min<int>((int)((n + 4095) / 4096), (256 * 8 + npair - 1) / npair));
-  {
-    // one workgroup per CU (the 128 KB tile), equal items: the launch runs in rounds of 256 workgroups, and a last round that
-    // is half empty costs half a round -- 136 pairs x 16 chunks = 8.5 rounds: 6.90 ms, x 15 = 7.97 rounds: 6.57 ms
-    // (profiles/r05v_gram_chunks.log; 17 chunks = 9.03 rounds: 7.15 ms).  The count near the default that wastes least:
-    const int hi = (int)std::min<int64_t>((n + 4095) / 4096, n_chunks + 4);
-    double best = 1e9;
-    for (int c = std::max(1, n_chunks - 4); c <= hi; ++c) {
-      const int64_t items = (int64_t)npair * c, rounds = (items + 255) / 256;
-      const double waste = (double)(rounds * 256) / (double)items;
-      if (waste < best - 1e-9) best = waste, n_chunks = c;
-    }
-  }
-  if (const char* e = getenv("SCAMD_GRAM_CHUNKS")) n_chunks = std::max(1, std::min<int>((int)((n + 255) / 256), atoi(e)));  // (A/B knob)
-  const int rows_per_chunk = (int)((n + n_chunks - 1) / n_chunks);
-  n_chunks = (int)((n + rows_per_chunk - 1) / rows_per_chunk);
   const size_t lds = (size_t)(GT * GT + GT) * sizeof(unsigned long long);
-  static const bool a_from_mem = [] {
-    const char* e = getenv("SCAMD_GRAM_A_FROM_MEM");
-    return e && e[0] == '1';
-  }();
-  auto gram_kernel = a_from_mem ? gram_tile_kernel<true, true> : gram_tile_kernel<false, true>;
-  auto gram_exact = gram_tile_kernel<false, false>;
-  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_exact),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // column sums are scaled by 2^scale_bits as well (x * 2^S), products by 2^S: x_a * (x_b * 2^S)
   const double scale = std::ldexp(1.0, scale_bits);
   unsigned int* flag = mx + 1;  // products outside the fast rounding's range (see gram_tile_kernel)
   SCAMD_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(unsigned int), s));
   unsigned long long* gram_u = reinterpret_cast<unsigned long long*>(gram);
   unsigned long long* colsum_u = reinterpret_cast<unsigned long long*>(colsum);
-  hipLaunchKernelGGL(gram_kernel, dim3((unsigned)npair, (unsigned)n_chunks), dim3(GRAM_THREADS), lds, s, indptr,
-                     indices, data, n, ntile, ptr, rows_per_chunk, scale, gram_u, ld_gram, colsum_u, flag);
-  SCAMD_LAUNCH_CHECK();
-  // no-ops unless the flag went up (no host round trip: the entry stays stream-ordered)
-  hipLaunchKernelGGL(gram_clear_if_flagged_kernel, dim3(1024), dim3(256), 0, s, gram_u, gp * ld_gram, colsum_u, gp, flag);
-  SCAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gram_exact, dim3((unsigned)npair, (unsigned)n_chunks), dim3(GRAM_THREADS), lds, s, indptr,
-                     indices, data, n, ntile, ptr, rows_per_chunk, scale, gram_u, ld_gram, colsum_u, flag);
-  SCAMD_LAUNCH_CHECK();
+  // one workgroup per CU (the 128 KB tile), equal items: the launch runs in rounds of 256 workgroups, and a last round that
+  // is half empty costs half a round -- 136 pairs x 16 chunks = 8.5 rounds: 6.90 ms, x 15 = 7.97 rounds: 6.57 ms
+  // (profiles/r05v_gram_chunks.log; 17 chunks = 9.03 rounds: 7.15 ms).  The count near ~8 items per CU that wastes least:
+  auto pick_chunks = [&](int64_t most) -> int {  // most: the largest count that leaves a chunk ~4096 rows
+    int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(most, (256 * 8 + npair - 1) / npair));
+    const int hi = (int)std::min<int64_t>(most, n_chunks + 4);
+    double best = 1e9;
+    for (int c = std::max(1, n_chunks - 4); c <= hi; ++c) {
+      const int64_t items = (int64_t)npair * c, rounds = (items + 255) / 256;
+      const double waste = (double)(rounds * 256) / (double)items;
+      if (waste < best - 1e-9) best = waste, n_chunks = c;
+    }
+    return n_chunks;
+  };
+  if (nnz == 0) {
+    // nothing to add: the sums stay zero
+  } else if (cv.packed) {
+    hipLaunchKernelGGL(gram_pack_kernel, dim3((unsigned)ceil_div(n_pad, PACK_WAVES)), dim3(PACK_WAVES * 64), 0, s, indptr, indices,
+                       data, n, ntile, cv.ent, cv.cnt8, n_pad);
+    SCAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gram_rank_kernel, dim3((unsigned)nblk), dim3(RB), 0, s, cv.cnt8, ntile, cv.perm, n_pad);
+    SCAMD_LAUNCH_CHECK();
+    int n_chunks = pick_chunks(std::max(1, (nblk + 3) / 4));
+    if (const char* e = getenv("SCAMD_GRAM_CHUNKS")) n_chunks = std::max(1, std::min(nblk, atoi(e)));  // (A/B knob)
+    const int blocks_per_chunk = (nblk + n_chunks - 1) / n_chunks;
+    n_chunks = (nblk + blocks_per_chunk - 1) / blocks_per_chunk;
+    auto gram_kernel = gram_packed_kernel<true>;
+    auto gram_exact = gram_packed_kernel<false>;
+    const size_t lds_p = lds + 16;
+    SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+    SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_exact),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+    // launch slots: 8 XCD queues x (pairs of the XCD) x chunks (see gram_packed_kernel)
+    const unsigned grid = 8u * (unsigned)ceil_div(npair, 8) * (unsigned)n_chunks;
+    hipLaunchKernelGGL(gram_kernel, dim3(grid), dim3(GRAM_THREADS), lds_p, s, indptr, indices, data, ntile, cv.ent, cv.perm,
+                       n_pad, blocks_per_chunk, nblk, n_chunks, scale, gram_u, ld_gram, colsum_u, flag);
+    SCAMD_LAUNCH_CHECK();
+    // no-ops unless the flag went up (no host round trip: the entry stays stream-ordered)
+    hipLaunchKernelGGL(gram_clear_if_flagged_kernel, dim3(1024), dim3(256), 0, s, gram_u, gp * ld_gram, colsum_u, gp, flag);
+    SCAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gram_exact, dim3(grid), dim3(GRAM_THREADS), lds_p, s, indptr, indices, data, ntile, cv.ent, cv.perm,
+                       n_pad, blocks_per_chunk, nblk, n_chunks, scale, gram_u, ld_gram, colsum_u, flag);
+    SCAMD_LAUNCH_CHECK();
+  } else {
+    hipLaunchKernelGGL(gram_tileptr_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, s, indptr, indices, n, ntile, cv.ptr);
+    SCAMD_LAUNCH_CHECK();
+    int n_chunks = pick_chunks((n + 4095) / 4096);
+    if (const char* e = getenv("SCAMD_GRAM_CHUNKS")) n_chunks = std::max(1, std::min<int>((int)((n + 255) / 256), atoi(e)));  // (A/B knob)
+    const int rows_per_chunk = (int)((n + n_chunks - 1) / n_chunks);
+    n_chunks = (int)((n + rows_per_chunk - 1) / rows_per_chunk);
+    static const bool a_from_mem = [] {
+      const char* e = getenv("SCAMD_GRAM_A_FROM_MEM");
+      return e && e[0] == '1';
+    }();
+    auto gram_kernel = a_from_mem ? gram_tile_kernel<true, true> : gram_tile_kernel<false, true>;
+    auto gram_exact = gram_tile_kernel<false, false>;
+    SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_exact),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(gram_kernel, dim3((unsigned)npair, (unsigned)n_chunks), dim3(GRAM_THREADS), lds, s, indptr,
+                       indices, data, n, ntile, cv.ptr, rows_per_chunk, scale, gram_u, ld_gram, colsum_u, flag);
+    SCAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gram_clear_if_flagged_kernel, dim3(1024), dim3(256), 0, s, gram_u, gp * ld_gram, colsum_u, gp, flag);
+    SCAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gram_exact, dim3((unsigned)npair, (unsigned)n_chunks), dim3(GRAM_THREADS), lds, s, indptr,
+                       indices, data, n, ntile, cv.ptr, rows_per_chunk, scale, gram_u, ld_gram, colsum_u, flag);
+    SCAMD_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(gram_mirror_kernel, dim3((unsigned)ceil_div(gp, 256), (unsigned)gp), dim3(256), 0, s,
                      reinterpret_cast<long long*>(gram), gp, ld_gram);
   SCAMD_LAUNCH_CHECK();
