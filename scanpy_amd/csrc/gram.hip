@@ -374,18 +374,32 @@ __global__ __launch_bounds__(PACK_WAVES * 64) void gram_pack_kernel(const int64_
   const int last_tile = (len > 0) ? indices[rb + len - 1] / GT : -1;
   for (int u = last_tile + 1 + lane; u <= ntile; u += 64) wpos[u] = (unsigned short)len;
   __builtin_amdgcn_wave_barrier();  // (the wave's LDS writes above are read by other lanes below)
-  // the row's REC x ntile record slots, 64 at a time: lane -> (tile, k)
-  for (int sl = lane; sl < ntile * REC; sl += 64) {
-    const int t = sl / REC, k = sl % REC;
+  // the row's record slots, 64 at a time: lane -> (tile, k); first the entries 0 .. 7 of every tile (every slot written), then
+  // the entries 8 .. 15, where only the half lines of tiles with more than eight entries are written -- nobody uses the
+  // others' contents (gram_quad_kernel masks them by the count): 1.2 GB of stores instead of 2 at 1M x 2k.  (Two separate
+  // slabs of 64-byte half lines made the sweep 1.4 x slower: two 128-byte lines per visit instead of one.)
+  for (int sl = lane; sl < ntile * (REC / 2); sl += 64) {
+    const int t = sl / (REC / 2), k = sl % (REC / 2);
     const int p0 = wpos[t], c = wpos[t + 1] - p0;
-    const bool have = k < c;
     unsigned int col = 0u, vbits = 0u;
-    if (have) {
+    if (k < c) {
       col = (unsigned int)(indices[rb + p0 + k] - t * GT);
       vbits = __float_as_uint(data[rb + p0 + k]);
     }
     ent[((int64_t)t * n_pad + row) * REC + k] = make_uint2((col << 3) | ((unsigned int)min(c, 255) << 16), vbits);
     if (k == 0) cnt8[row * ntile + t] = (unsigned char)min(c, 255);
+  }
+  for (int sl = lane; sl < ntile * (REC / 2); sl += 64) {
+    const int t = sl / (REC / 2), k = sl % (REC / 2) + REC / 2;
+    const int p0 = wpos[t], c = wpos[t + 1] - p0;
+    if (c > REC / 2) {
+      unsigned int col = 0u, vbits = 0u;
+      if (k < c) {
+        col = (unsigned int)(indices[rb + p0 + k] - t * GT);
+        vbits = __float_as_uint(data[rb + p0 + k]);
+      }
+      ent[((int64_t)t * n_pad + row) * REC + k] = make_uint2((col << 3) | ((unsigned int)min(c, 255) << 16), vbits);
+    }
   }
 }
 
@@ -430,14 +444,6 @@ __global__ __launch_bounds__(RB) void gram_rank_kernel(const unsigned char* __re
   }
 }
 
-// maximum of a non-negative per-group value (the same in the eight lanes of a group) over the wave: one DPP step folds the
-// two groups of a row of sixteen lanes, the four rows meet in scalar registers
-__device__ __forceinline__ int wave_max_groups(int v) {
-  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true));  // row_shr:8: lanes 8 .. 15 see the row's other group
-  return max(max(__builtin_amdgcn_readlane(v, 15), __builtin_amdgcn_readlane(v, 31)),
-             max(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
-}
-
 // the k-th tile pair (a <= b) in blocked order: the triangle cut into 4 x 4 blocks, blocks row by row, pairs row by row inside
 __device__ inline void gram_blocked_pair(int k, int ntile, int* a_out, int* b_out) {
   const int nb4 = (ntile + 3) / 4;
@@ -453,7 +459,7 @@ __device__ inline void gram_blocked_pair(int k, int ntile, int* a_out, int* b_ou
 }
 
 template <bool FAST>
-__global__ __launch_bounds__(GRAM_THREADS) void gram_packed_kernel(
+__global__ __launch_bounds__(GRAM_THREADS) void gram_quad_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ data, int ntile,
     const uint2* __restrict__ ent, const unsigned short* __restrict__ perm, int64_t n_pad, int blocks_per_chunk, int nblk,
     int n_chunks, double scale, unsigned long long* __restrict__ gram, int64_t ld, unsigned long long* __restrict__ colsum,
@@ -487,10 +493,10 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_packed_kernel(
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int rs = lane >> 3, q = lane & 7;
+  const int rs = lane >> 2, q = lane & 3;  // sixteen rows per step, four lanes each
   const int blk0 = chunk * blocks_per_chunk;
   const int blk1 = min(nblk, blk0 + blocks_per_chunk);
-  const int steps = (blk1 - blk0) * STEPS_PER_BLOCK;
+  const int steps = (blk1 - blk0) * (RB / 16);
   const int a0 = a * GT, b0 = b * GT;
   const unsigned short* perm_a = perm + (int64_t)a * n_pad + (int64_t)blk0 * RB;
   // slabs of the two tiles from the chunk's first row on, addressed in bytes by a 32-bit offset
@@ -512,56 +518,79 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_packed_kernel(
   // two levels of loads, each requested ahead of the level that needs its result (RAW values are kept until then: section
   // 3.0 of DESIGN.md): the sorted rows of the steps s + 2 WS .. and the records of step s + WS are in flight while step s
   // is computed
-  struct Ent {  // lane q: records q and q + 8 of either tile
-    uint2 a1, a2, b1, b2;
+  struct Ent {  // lane q: records q, q + 4, q + 8, q + 12 of either tile
+    uint2 a[4], b[4];
   };
   auto clamp_step = [&](int s) -> int { return min(s, steps - 1); };
-  auto load_perm = [&](int s) -> unsigned short { return perm_a[(unsigned int)(clamp_step(s) * 8 + rs)]; };
+  auto load_perm = [&](int s) -> unsigned short { return perm_a[(unsigned int)(clamp_step(s) * 16 + rs)]; };
   auto row_offset = [&](int s, unsigned short prow) -> unsigned int {  // byte offset of the row's records within a slab
-    return ((unsigned int)(clamp_step(s) >> 7) * RB + prow) * (REC * 8u) + (unsigned int)q * 8u;
+    return ((unsigned int)(clamp_step(s) >> 6) * RB + prow) * (REC * 8u) + (unsigned int)q * 8u;
   };
   auto load_ent = [&](unsigned int off) -> Ent {
     Ent e;
-    e.a1 = *reinterpret_cast<const uint2*>(ent_a + off);
-    e.a2 = *reinterpret_cast<const uint2*>(ent_a + off + 64);
-    e.b1 = *reinterpret_cast<const uint2*>(ent_b + off);
-    e.b2 = *reinterpret_cast<const uint2*>(ent_b + off + 64);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      e.a[m] = *reinterpret_cast<const uint2*>(ent_a + off + 32 * m);
+      e.b[m] = *reinterpret_cast<const uint2*>(ent_b + off + 32 * m);
+    }
     return e;
   };
 
+  // broadcast of lane P of every quad: one VALU instruction (DPP quad_perm), nothing on the LDS pipe the atomics need
+#define SCAMD_QB(P, X) __builtin_amdgcn_update_dpp(0, (X), (P) * 0x55, 0xf, 0xf, true)
+  auto wave_max_quads = [&](int v) -> int {  // maximum of a non-negative per-quad value over the wave
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true));  // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true));  // row_shr:8: lanes 12 .. 15 hold the row's maximum
+    return max(max(__builtin_amdgcn_readlane(v, 15), __builtin_amdgcn_readlane(v, 31)),
+               max(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
+  };
   auto compute = [&](const Ent& e, int s, unsigned short prow) __attribute__((always_inline)) {
-    const int na = (int)(e.a1.x >> 16), nb = (int)(e.b1.x >> 16);
-    // sorted ascending: the last group of the step has the most entries in tile a (bin 63 holds every count >= 63)
+    const int na = (int)(e.a[0].x >> 16), nb = (int)(e.b[0].x >> 16);
+    // sorted ascending: the last quad of the step has the most entries in tile a (bin 63 holds every count >= 63)
     int namax = __builtin_amdgcn_readlane(na, 63);
-    if (namax >= SORT_BINS - 1) namax = wave_max_groups(na);
-    const int nbmax = wave_max_groups(nb);
+    if (namax >= SORT_BINS - 1) namax = wave_max_quads(na);
+    const int nbmax = wave_max_quads(nb);
     if (namax == 0 || nbmax == 0) return;
-    const int jb_o = (int)(e.b1.x & 0x3f8u), jb2_o = (int)(e.b2.x & 0x3f8u);
-    const int ja_o = (int)(e.a1.x & 0x3f8u) << 7, ja2_o = (int)(e.a2.x & 0x3f8u) << 7;
-    const float va = __uint_as_float(e.a1.y), va2 = __uint_as_float(e.a2.y);
-    const float vb = __uint_as_float(e.b1.y), vb2 = __uint_as_float(e.b2.y);
+    int ja_o[4], jb_o[4];
+    float va[4], vb[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      ja_o[m] = (int)(e.a[m].x & 0x3f8u) << 7;
+      jb_o[m] = (int)(e.b[m].x & 0x3f8u);
+      va[m] = __uint_as_float(e.a[m].y);
+      vb[m] = __uint_as_float(e.b[m].y);
+    }
+    // the upper half line of a (row, tile) with at most eight entries was never written.  Tile b: its contents only reach
+    // the lanes of their own quad, which are switched off (nb <= 8); tile a: masked where it is used (namax > 8, below)
+    if (na <= 8) va[2] = 0.f, va[3] = 0.f;
+    if (nb <= 8) vb[2] = 0.f, vb[3] = 0.f;
     if constexpr (FAST) {
-      amax = fmaxf(amax, fmaxf(fabsf(va), fabsf(va2)));
-      bmax = fmaxf(bmax, fmaxf(fabsf(vb), fabsf(vb2)));
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(va[0]), fabsf(va[1])), fmaxf(fabsf(va[2]), fabsf(va[3]))));
+      bmax = fmaxf(bmax, fmaxf(fmaxf(fabsf(vb[0]), fabsf(vb[1])), fmaxf(fabsf(vb[2]), fabsf(vb[3]))));
     }
     if (diag) {  // column sums ride along on the diagonal items
-      if (q < na) atomicAdd(&csum[ja_o >> 10], (unsigned long long)fixed_round((double)va * scale));
-      if (q + 8 < na) atomicAdd(&csum[ja2_o >> 10], (unsigned long long)fixed_round((double)va2 * scale));
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        if (q + 4 * m < na) atomicAdd(&csum[ja_o[m] >> 10], (unsigned long long)fixed_round((double)va[m] * scale));
     }
+    // eight broadcast entries at a time: byte offset j8[k] and value d8[k] of entry k (entry k sits in lane k & 3, register k >> 2)
     int j8[8];
-    float v8[8];
-#define SCAMD_GRAM_BCAST(JSRC, VSRC)                                                                     \
-  j8[0] = bcast8<0>(JSRC); v8[0] = __int_as_float(bcast8<0>(__float_as_int(VSRC)));                      \
-  j8[1] = bcast8<1>(JSRC); v8[1] = __int_as_float(bcast8<1>(__float_as_int(VSRC)));                      \
-  j8[2] = bcast8<2>(JSRC); v8[2] = __int_as_float(bcast8<2>(__float_as_int(VSRC)));                      \
-  j8[3] = bcast8<3>(JSRC); v8[3] = __int_as_float(bcast8<3>(__float_as_int(VSRC)));                      \
-  j8[4] = bcast8<4>(JSRC); v8[4] = __int_as_float(bcast8<4>(__float_as_int(VSRC)));                      \
-  j8[5] = bcast8<5>(JSRC); v8[5] = __int_as_float(bcast8<5>(__float_as_int(VSRC)));                      \
-  j8[6] = bcast8<6>(JSRC); v8[6] = __int_as_float(bcast8<6>(__float_as_int(VSRC)));                      \
-  j8[7] = bcast8<7>(JSRC); v8[7] = __int_as_float(bcast8<7>(__float_as_int(VSRC)))
+    double d8[8];
+#define SCAMD_GRAM_BCAST2(K0, JLO, VLO)                                                              \
+  j8[K0 + 0] = SCAMD_QB(0, JLO); d8[K0 + 0] = (double)__int_as_float(SCAMD_QB(0, __float_as_int(VLO))); \
+  j8[K0 + 1] = SCAMD_QB(1, JLO); d8[K0 + 1] = (double)__int_as_float(SCAMD_QB(1, __float_as_int(VLO)))
+#define SCAMD_GRAM_BCAST(CNT, JLO, VLO, JHI, VHI)                  \
+  do {                                                             \
+    SCAMD_GRAM_BCAST2(0, JLO, VLO);                                \
+    if ((CNT) > 2) { j8[2] = SCAMD_QB(2, JLO); d8[2] = (double)__int_as_float(SCAMD_QB(2, __float_as_int(VLO))); \
+                     j8[3] = SCAMD_QB(3, JLO); d8[3] = (double)__int_as_float(SCAMD_QB(3, __float_as_int(VLO))); } \
+    if ((CNT) > 4) { SCAMD_GRAM_BCAST2(4, JHI, VHI); }             \
+    if ((CNT) > 6) { j8[6] = SCAMD_QB(2, JHI); d8[6] = (double)__int_as_float(SCAMD_QB(2, __float_as_int(VHI))); \
+                     j8[7] = SCAMD_QB(3, JHI); d8[7] = (double)__int_as_float(SCAMD_QB(3, __float_as_int(VHI))); } \
+  } while (0)
     // `cnt` of the eight broadcast entries are real (wave-uniform): nested so that the first missing entry leaves the chain with
     // ONE forward branch, the likely side laid out in line (a taken branch costs as much as the product it guards)
-#define SCAMD_GRAM_P(K, OFF, VS) add_at(j8[K] + (OFF), round_product((double)v8[K] * (VS)))
+#define SCAMD_GRAM_P(K, OFF, VS) add_at(j8[K] + (OFF), round_product(d8[K] * (VS)))
 #define SCAMD_GRAM_CHAIN(CNT, OFF, VS)                                   \
   do {                                                                   \
     const int cnt_ = (CNT);                                              \
@@ -574,41 +603,50 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_packed_kernel(
     if (__builtin_expect(cnt_ > 6, 1)) { SCAMD_GRAM_P(6, OFF, VS);       \
     if (__builtin_expect(cnt_ > 7, 1)) { SCAMD_GRAM_P(7, OFF, VS); } } } } } } } } \
   } while (0)
-    // (1) the first eight entries of tile b stay in their lanes, the entries of tile a are broadcast one after the other
-    SCAMD_GRAM_BCAST(ja_o, va);
+    // (1) the first eight entries of tile b stay in their lanes (two per lane), the entries of tile a are broadcast
+    SCAMD_GRAM_BCAST(namax, ja_o[0], va[0], ja_o[1], va[1]);
     if (q < nb) {
-      const double vbs = (double)vb * scale;
-      SCAMD_GRAM_CHAIN(namax, jb_o, vbs);
+      const double vbs = (double)vb[0] * scale;
+      SCAMD_GRAM_CHAIN(namax, jb_o[0], vbs);
+    }
+    if (q + 4 < nb) {
+      const double vbs = (double)vb[1] * scale;
+      SCAMD_GRAM_CHAIN(namax, jb_o[1], vbs);
     }
     if (namax > 8) {
-      SCAMD_GRAM_BCAST(ja2_o, va2);
+      if (na <= 8) ja_o[2] = 0, ja_o[3] = 0;
+      SCAMD_GRAM_BCAST(namax - 8, ja_o[2], va[2], ja_o[3], va[3]);
       if (q < nb) {
-        const double vbs = (double)vb * scale;
-        SCAMD_GRAM_CHAIN(namax - 8, jb_o, vbs);
+        const double vbs = (double)vb[0] * scale;
+        SCAMD_GRAM_CHAIN(namax - 8, jb_o[0], vbs);
+      }
+      if (q + 4 < nb) {
+        const double vbs = (double)vb[1] * scale;
+        SCAMD_GRAM_CHAIN(namax - 8, jb_o[1], vbs);
       }
     }
     // (2) entries 8 .. 15 of tile b: the roles exchanged -- the lane keeps its tile-a entries, these are broadcast
     if (nbmax > 8) {
-      SCAMD_GRAM_BCAST(jb2_o, vb2);
       const int nb2max = min(nbmax, 16) - 8;
-      if (q < na && nb > 8) {
-        const double vas = (double)va * scale;
-        SCAMD_GRAM_CHAIN(nb2max, ja_o, vas);
-      }
-      if (namax > 8) {
-        if (q + 8 < na && nb > 8) {
-          const double vas2 = (double)va2 * scale;
-          SCAMD_GRAM_CHAIN(nb2max, ja2_o, vas2);
+      SCAMD_GRAM_BCAST(nb2max, jb_o[2], vb[2], jb_o[3], vb[3]);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if (m < 2 || namax > 8) {
+          if (q + 4 * m < na && nb > 8) {
+            const double vas = (double)va[m] * scale;
+            SCAMD_GRAM_CHAIN(nb2max, ja_o[m], vas);
+          }
         }
       }
     }
 #undef SCAMD_GRAM_CHAIN
 #undef SCAMD_GRAM_P
 #undef SCAMD_GRAM_BCAST
+#undef SCAMD_GRAM_BCAST2
     // (3) rows with more than sixteen entries in either tile: the remaining products from the CSR arrays (every lane of a
-    // group finds the row's two tile ranges by bisection -- a rare path)
+    // quad finds the row's two tile ranges by bisection -- a rare path)
     if (namax > REC || nbmax > REC) {
-      const int64_t row = ((int64_t)(blk0 + (s >> 7))) * RB + prow;
+      const int64_t row = ((int64_t)(blk0 + (s >> 6))) * RB + prow;
       int64_t rb = 0;
       int len = 0;
       if (na > REC || nb > REC) {  // (padding rows behind the matrix have no indptr entry)
@@ -627,11 +665,11 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_packed_kernel(
       const int pa_rel = lower(a0), pb_rel = lower(b0);
       const int na_f = lower(a0 + GT) - pa_rel, nb_f = lower(b0 + GT) - pb_rel;  // the full counts (the records cap them at 255)
       const int64_t pa = rb + pa_rel, pb = rb + pb_rel;
-      const int na_fmax = wave_max_groups(na_f), nb_fmax = wave_max_groups(nb_f);
+      const int na_fmax = wave_max_quads(na_f), nb_fmax = wave_max_quads(nb_f);
       if (diag)
-        for (int ia = REC + q; ia < na_fmax; ia += 8)
+        for (int ia = REC + q; ia < na_fmax; ia += 4)
           if (ia < na_f) atomicAdd(&csum[indices[pa + ia] - a0], (unsigned long long)fixed_round((double)data[pa + ia] * scale));
-      for (int cb = 0; cb < nb_fmax; cb += 8) {
+      for (int cb = 0; cb < nb_fmax; cb += 4) {
         const int ib = cb + q;
         const bool hb = ib < nb_f;
         int jbo = 0;
@@ -652,19 +690,25 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_packed_kernel(
       }
     }
   };
+#undef SCAMD_QB
 
   if (steps > 0) {
     constexpr int WS = GRAM_THREADS / 64;  // the wave's stride over the steps
-    unsigned short pr_cur = load_perm(wave), pr_nxt = load_perm(wave + WS), pr_nn = load_perm(wave + 2 * WS);
+    // (the records two steps ahead, the sorted rows four: with one step of lead a third of the wave cycles waited for memory)
+    unsigned short pr_cur = load_perm(wave), pr_1 = load_perm(wave + WS), pr_2 = load_perm(wave + 2 * WS),
+                   pr_3 = load_perm(wave + 3 * WS);
     Ent en_cur = load_ent(row_offset(wave, pr_cur));
+    Ent en_1 = load_ent(row_offset(wave + WS, pr_1));
     for (int s = wave; s < steps; s += WS) {
-      const unsigned short pr_3 = load_perm(s + 3 * WS);
-      const Ent en_nxt = load_ent(row_offset(s + WS, pr_nxt));
+      const unsigned short pr_4 = load_perm(s + 4 * WS);
+      const Ent en_2 = load_ent(row_offset(s + 2 * WS, pr_2));
       compute(en_cur, s, pr_cur);
-      en_cur = en_nxt;
-      pr_cur = pr_nxt;
-      pr_nxt = pr_nn;
-      pr_nn = pr_3;
+      en_cur = en_1;
+      en_1 = en_2;
+      pr_cur = pr_1;
+      pr_1 = pr_2;
+      pr_2 = pr_3;
+      pr_3 = pr_4;
     }
   }
   __syncthreads();
@@ -811,14 +855,14 @@ extern "C" int scamd_csr_gram_f32(const int64_t* indptr, const int32_t* indices,
     if (const char* e = getenv("SCAMD_GRAM_CHUNKS")) n_chunks = std::max(1, std::min(nblk, atoi(e)));  // (A/B knob)
     const int blocks_per_chunk = (nblk + n_chunks - 1) / n_chunks;
     n_chunks = (nblk + blocks_per_chunk - 1) / blocks_per_chunk;
-    auto gram_kernel = gram_packed_kernel<true>;
-    auto gram_exact = gram_packed_kernel<false>;
+    auto gram_kernel = gram_quad_kernel<true>;
+    auto gram_exact = gram_quad_kernel<false>;
     const size_t lds_p = lds + 16;
     SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
     SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_exact),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
-    // launch slots: 8 XCD queues x (pairs of the XCD) x chunks (see gram_packed_kernel)
+    // launch slots: 8 XCD queues x (pairs of the XCD) x chunks (see gram_quad_kernel)
     const unsigned grid = 8u * (unsigned)ceil_div(npair, 8) * (unsigned)n_chunks;
     hipLaunchKernelGGL(gram_kernel, dim3(grid), dim3(GRAM_THREADS), lds_p, s, indptr, indices, data, ntile, cv.ent, cv.perm,
                        n_pad, blocks_per_chunk, nblk, n_chunks, scale, gram_u, ld_gram, colsum_u, flag);

@@ -6,7 +6,7 @@ P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_AN
 P2="SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVES SQ_ACTIVE_INST_VMEM"
 i=0
 for P in "$P1" "$P2"; do i=$((i+1))
-  ( cd /tmp; env "$@" timeout -k 5 200 rocprofv3 --kernel-trace --output-format csv --kernel-include-regex 'gram_(packed|tile)_kernel' --pmc $P -d /tmp/gpmc_${TAG}_$i -o gram -- python "$R/tools/gram_only.py" > "$OUT/gram_pmc$i.log" 2>&1 < /dev/null; echo "pmc$i rc=$?" )
+  ( cd /tmp; env "$@" timeout -k 5 200 rocprofv3 --kernel-trace --output-format csv --kernel-include-regex 'gram_(packed|tile|quad)_kernel' --pmc $P -d /tmp/gpmc_${TAG}_$i -o gram -- python "$R/tools/gram_only.py" > "$OUT/gram_pmc$i.log" 2>&1 < /dev/null; echo "pmc$i rc=$?" )
   find /tmp/gpmc_${TAG}_$i -name '*counter_collection.csv' -exec cp {} "$OUT/gram_pmc$i.csv" \;
 done
 python - "$OUT" <<'PY'
