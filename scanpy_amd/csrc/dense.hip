@@ -188,10 +188,8 @@ __global__ __launch_bounds__(1024) void chol_factor_kernel(const double* __restr
     if (mine && part == 0) L[row * DB_LD + j] = (row == j) ? sqrt(piv) : v / sqrt(piv);
     __syncthreads();  // column j is final before the next column's dot products read it
   }
-  if (bad) {
-    if (tid == 0) *flag = 1;
-    return;
-  }
+  if (tid == 0) *flag = bad ? 1 : 0;  // (written either way: no clear in front of the launch)
+  if (bad) return;
   // X = L^-1 (lower triangular), row by row: X[j][c] = (delta_jc - sum_{c <= k < j} L[j][k] X[k][c]) / L[j][j] for all
   // columns c <= j at once (thread group `row` = c, eight lanes split k).  X[k][c] (k > c) lives in the unused UPPER
   // triangle at (c, k); X[c][c] = 1 / L[c][c].
@@ -391,8 +389,18 @@ __global__ __launch_bounds__(1024) void rq_minmax_kernel(const double* __restric
   __shared__ double part[8][DB_MAX];
   const int c = threadIdx.x & 127, rr = threadIdx.x >> 7;
   double s = 0.0;
-  if (c < b)
-    for (int m = rr; m < g; m += 8) s = fma(Z[(int64_t)m * b + c], AZ[(int64_t)m * b + c], s);
+  if (c < b) {  // (four independent chains: the loop is a walk of dependent loads otherwise, 76 us at g = 2000)
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int m = rr;
+    for (; m + 24 < g; m += 32) {
+      s = fma(Z[(int64_t)m * b + c], AZ[(int64_t)m * b + c], s);
+      s1 = fma(Z[(int64_t)(m + 8) * b + c], AZ[(int64_t)(m + 8) * b + c], s1);
+      s2 = fma(Z[(int64_t)(m + 16) * b + c], AZ[(int64_t)(m + 16) * b + c], s2);
+      s3 = fma(Z[(int64_t)(m + 24) * b + c], AZ[(int64_t)(m + 24) * b + c], s3);
+    }
+    for (; m < g; m += 8) s = fma(Z[(int64_t)m * b + c], AZ[(int64_t)m * b + c], s);
+    s = (s + s1) + (s2 + s3);
+  }
   part[rr][c] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -417,10 +425,23 @@ __global__ __launch_bounds__(1024) void residual_kernel(const double* __restrict
   double s = 0.0;
   if (c < k) {
     const double th = theta[c];
-    for (int m = rr; m < g; m += 8) {
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int m = rr;
+    for (; m + 24 < g; m += 32) {  // (four independent chains, see rq_minmax_kernel)
+      const double d0 = AV[(int64_t)m * b + c] - th * V[(int64_t)m * b + c];
+      const double d1 = AV[(int64_t)(m + 8) * b + c] - th * V[(int64_t)(m + 8) * b + c];
+      const double d2 = AV[(int64_t)(m + 16) * b + c] - th * V[(int64_t)(m + 16) * b + c];
+      const double d3 = AV[(int64_t)(m + 24) * b + c] - th * V[(int64_t)(m + 24) * b + c];
+      s = fma(d0, d0, s);
+      s1 = fma(d1, d1, s1);
+      s2 = fma(d2, d2, s2);
+      s3 = fma(d3, d3, s3);
+    }
+    for (; m < g; m += 8) {
       const double d = AV[(int64_t)m * b + c] - th * V[(int64_t)m * b + c];
       s = fma(d, d, s);
     }
+    s = (s + s1) + (s2 + s3);
   }
   part[rr][c] = s;
   __syncthreads();
@@ -573,7 +594,6 @@ static int cholqr2(DenseCtx& cx, double* zin, double* tmp, double* zout) {
     double shift = 0.0;
     for (int attempt = 0;; ++attempt) {
       int bad = 0;
-      SCAMD_HIP_CHECK(hipMemsetAsync(cx.d.flags, 0, sizeof(int), cx.s));
       hipLaunchKernelGGL(chol_factor_kernel, dim3(1), dim3(1024), CHOL_LDS, cx.s, cx.d.gm, b, shift, cx.d.s, cx.d.flags);
       SCAMD_LAUNCH_CHECK();
       SCAMD_READBACK_NOW(&bad, cx.d.flags, sizeof(int), cx.s);
@@ -859,11 +879,19 @@ struct PcaBuffers {
   long long* gram; long long* colsum; float* v32; float* shift;
   void* gram_ws; size_t gram_ws_bytes; void* solve_ws; size_t solve_ws_bytes;
 };
-// out[0] = sum of var[0..g) in index order (one thread: g <= 65535)
-__global__ void sum_kernel(const double* __restrict__ x, int g, double* __restrict__ out) {
+// out[0] = sum of var[0..g) in a fixed order (256 strided partial sums in index order, then a fixed tree: one thread walking
+// the array took 105 us of dependent loads at g = 2000)
+__global__ __launch_bounds__(256) void sum_kernel(const double* __restrict__ x, int g, double* __restrict__ out) {
+  __shared__ double part[256];
   double s = 0.0;
-  for (int i = 0; i < g; ++i) s += x[i];
-  out[0] = s;
+  for (int i = threadIdx.x; i < g; i += 256) s += x[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = part[0];
 }
 // zero_center: variance[c] = theta[c] / (n - 1) (sklearn PCA: S^2 / (n - 1)); otherwise the variance of the scores of
 // the uncentred decomposition, theta[c] / n - (mu^T v_c)^2 (TruncatedSVD); ratio[c] = variance[c] / total
@@ -987,7 +1015,7 @@ static int pca_solve_gram(const long long* gram, int64_t ld_gram, const long lon
   SCAMD_LAUNCH_CHECK();
   // 7. explained variance (sklearn: S^2 / (n - 1); ratio against the total variance with the same n / (n - 1) factor;
   //    zero_center = False is TruncatedSVD: the variance of the scores of the uncentred decomposition, lam / n - (mu^T v)^2)
-  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1), 0, s, b.var, (int)g, b.varsum);
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, s, b.var, (int)g, b.varsum);
   SCAMD_LAUNCH_CHECK();
   const double denom = zero_center ? (double)(n - 1) : (double)n;
   const double total_scale = zero_center ? (double)n / (double)(n - 1) : 1.0;
