@@ -572,6 +572,10 @@ struct DenseCtx {
   int g, b;
   DenseBuffers d;
   int n_gemm = 0, n_chol_retry = 0;
+  bool shift_first = [] {  // (A/B knob: SCAMD_DENSE_SHIFT_FIRST=0)
+    const char* e = getenv("SCAMD_DENSE_SHIFT_FIRST");
+    return !(e && e[0] == '0');
+  }();
 };
 
 static constexpr size_t CHOL_LDS = (size_t)(DB_MAX * DB_LD + DB_MAX) * sizeof(double);
@@ -582,7 +586,9 @@ static constexpr size_t JAC_LDS = (size_t)(DB_MAX * DB_LD + DB_MAX) * sizeof(dou
 // a SHIFTED round (Fukaya et al. 2020: factor G + s I, s ~ 11 (g b + b (b + 1)) u |Y|^2; every such round divides kappa by
 // ~1 / sqrt(s) ~ 3e3) and starts the count of plain rounds again; directions that were lost to rounding come back as
 // orthonormal noise, as they do from a Householder QR.  zin and tmp are overwritten; zin, tmp, zout are distinct panels.
-static int cholqr2(DenseCtx& cx, double* zin, double* tmp, double* zout) {
+// filtered = the block comes out of a Chebyshev filter: its plain first round fails (kappa 1e16 and beyond: the solve of the
+// bench spent two Cholesky launches and their read-backs on finding that out), so the first round is a shifted one at once
+static int cholqr2(DenseCtx& cx, double* zin, double* tmp, double* zout, bool filtered = false) {
   const int g = cx.g, b = cx.b;
   double* cur = zin;
   double* other = tmp;
@@ -591,8 +597,8 @@ static int cholqr2(DenseCtx& cx, double* zin, double* tmp, double* zout) {
   while (plain_ok < 2) {
     int rc = dgemm_tn(cx.s, cur, b, cur, b, b, b, g, 1.0, nullptr, 0, 0.0, nullptr, 0, 0.0, cx.d.gm, b);
     if (rc != SCAMD_OK) return rc;
-    double shift = 0.0;
-    for (int attempt = 0;; ++attempt) {
+    double shift = (filtered && plain_ok == 0 && shifted_rounds == 0 && cx.shift_first) ? s0 : 0.0;
+    for (int attempt = shift > 0.0 ? 1 : 0;; ++attempt) {
       int bad = 0;
       hipLaunchKernelGGL(chol_factor_kernel, dim3(1), dim3(1024), CHOL_LDS, cx.s, cx.d.gm, b, shift, cx.d.s, cx.d.flags);
       SCAMD_LAUNCH_CHECK();
@@ -601,7 +607,7 @@ static int cholqr2(DenseCtx& cx, double* zin, double* tmp, double* zout) {
       SCAMD_REQUIRE(attempt < 4 && shifted_rounds < 8, SCAMD_EUNSUPPORTED,
                     "dense eigensolver: CholeskyQR gave up on the block (%d shifted rounds, attempt %d)", shifted_rounds,
                     attempt);
-      shift = attempt == 0 ? s0 : shift * 1e3;
+      shift = shift == 0.0 ? s0 : shift * 1e3;
       ++cx.n_chol_retry;
     }
     const bool was_shifted = shift > 0.0;
@@ -722,7 +728,7 @@ static int dense_topk(DenseCtx& cx, int k, unsigned int seed, double tol, int* n
   if (h_rq[2] > h_rq[1] && h_rq[1] > 0.0) {
     rc = filter(v, av, h_rq[1], h_rq[2], 8);
     if (rc != SCAMD_OK) return rc;
-    rc = cholqr2(cx, z, tmp, y0);
+    rc = cholqr2(cx, z, tmp, y0, true);
     if (rc != SCAMD_OK) return rc;
     rc = rayleigh_ritz(cx, y0, az, v, av, h_theta.data());
   } else {
@@ -748,6 +754,7 @@ static int dense_topk(DenseCtx& cx, int k, unsigned int seed, double tol, int* n
                   "dense eigensolver: residual %.3e above the tolerance %.3e after %d filtered iterations", h_resid, tol,
                   MAX_OUTER);
     const double c = std::max(h_theta[b - 1], 0.0), top = h_theta[0];
+    bool filtered = false;
     if (!(top > c && c > 0.0)) {
       // rank-deficient block (c == 0): a plain power step on the Ritz block
       rc = dgemm_tn(cx.s, cx.a, cx.lda, av, b, g, b, g, 1.0, nullptr, 0, 0.0, nullptr, 0, 0.0, z, b);
@@ -765,8 +772,9 @@ static int dense_topk(DenseCtx& cx, int k, unsigned int seed, double tol, int* n
       if (spread > 0.0) m = std::max(4, std::min(m, (int)std::floor(20.7 / spread)));
       rc = filter(v, av, c, top, m);
       if (rc != SCAMD_OK) return rc;
+      filtered = m >= 8;
     }
-    rc = cholqr2(cx, z, tmp, y0);
+    rc = cholqr2(cx, z, tmp, y0, filtered);
     if (rc != SCAMD_OK) return rc;
     rc = rayleigh_ritz(cx, y0, az, v, av, h_theta.data());
     if (rc != SCAMD_OK) return rc;

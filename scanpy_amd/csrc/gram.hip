@@ -5,17 +5,20 @@
 // PCAEighDask.fit at _pca/_dask.py:28-132) and, through it, every CSR pass of the PCA solve: once G (g x g) and
 // the column sums are on the device, the eigen-solve is dense GEMM work on a 32 MB matrix.
 //
-// Design (deterministic; what bounds it: see the notes in front of bcast8 below):
+// Design (deterministic):
 //   * genes are cut into tiles of T = 128; a work item = (tile pair a <= b, row chunk); its T x T block of G lives
 //     in LDS as int64 (128 KB) and is accumulated with ds_add_u64 -- integer addition is associative, so the
 //     result does not depend on the order in which waves/lanes/blocks (or ranks) add: bitwise reproducible;
 //   * products are exact: (double)x_ia * (double)x_ib is exact for float32 inputs, scaled by 2^S and rounded
 //     once to int64 (S chosen by the host from max|x| and n so that no sum can overflow);
-//   * a per-row tile pointer table (uint16, built once) gives each item the entries of a row that fall into
-//     gene tiles a and b without searching; 8 lanes work on one row (lane = entry of tile b, loop over the
-//     entries of tile a), 8 rows per wave step;
 //   * each item flushes its block to global memory with 64-bit integer atomics (distinct addresses except
-//     between the row chunks of one tile pair).
+//     between the row chunks of one tile pair);
+//   * round 6 (g <= 8192): the matrix is first rewritten as per-tile record slabs, one 128-byte line per (row, tile),
+//     the rows of every block of 1024 ranked by their entry count per tile; four lanes work on one row, sixteen rows
+//     per wave step (gram_pack_kernel, gram_rank_kernel, gram_quad_kernel below: 3.7 + 0.8 ms at 1M x 2k);
+//   * wider matrices (and SCAMD_GRAM_LEGACY=1) take the round-2 kernel: a per-row tile pointer table (uint16) gives
+//     each item the entries of a row that fall into gene tiles a and b without searching; 8 lanes work on one row
+//     (lane = entry of tile b, loop over the entries of tile a), 8 rows per wave step (gram_tile_kernel: 6.7 ms).
 // Work: sum_i r_i^2 products (r_i = stored entries of row i) -- 5e9 at 1M x 2k, 5 % dense.
 #include "common.h"
 
@@ -317,25 +320,32 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_tile_kernel(
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Round 6: the PACKED kernel.  The disassembly of gram_tile_kernel above has ~150 instructions of per-step overhead in
+// Round 6: the PACKED kernels.  The disassembly of gram_tile_kernel above has ~150 instructions of per-step overhead in
 // front of ~120 that make products, its a-loop runs to the longest of the step's eight rows (11 against a mean of 6.4
 // entries) and once more for the rows with more than eight entries in tile b (83 % of the steps have one): 20 broadcast
 // rounds per step for 328 products; and every visit of a (row, tile) gathers its ~26 bytes of indices and of values out of
-// two 128-byte lines.  A first rewrite that only sorted the rows (same CSR gathers, three dependent load levels) issued a
-// quarter fewer instructions and took 9.5 ms instead of 6.7: it waited for memory 2.8 x as long.  Here
+// two 128-byte lines.  What was measured on the way (profiles/r06o .. r06w):
+//   - rows sorted by entry count, same CSR gathers through a position table (three dependent load levels): a quarter fewer
+//     instructions, 9.5 ms instead of 6.7 -- it waited for memory 2.8 x as long;
+//   - record slabs + eight lanes per row, broadcasts through ds_swizzle: 4.0 ms, bound by the LDS pipe (2.8 ms busy: the
+//     crossbar shares it with the atomics);
+//   - record slabs + FOUR lanes per row, broadcasts by DPP quad_perm (VALU): 3.66 ms, LDS 2.0 ms busy (64 % of it bank
+//     conflicts of the 64-bit atomics: 50 random addresses over 32 bank pairs), VALU 1.9 ms;
+//   - entries 0 .. 7 and 8 .. 15 in two separate slabs of 64-byte half lines: 5.1 ms -- two 128-byte lines per visit.
+// As built:
 //   * gram_pack_kernel rewrites the matrix once per call as records: per gene tile t a slab [n_pad][16] of 8-byte records
 //     {(column - t * GT) << 3 | count << 16, value}, absent entries zero: ONE aligned 128-byte line per (row, tile), read
-//     with a base in scalar registers and a 32-bit offset, no position table, no masks -- a zero value adds nothing;
-//   * the same kernel ranks the rows of every block of RB = 1024 by their number of entries per tile (counting sort in LDS):
-//     the eight rows of a step have the SAME number of entries in tile a, the broadcast loop over them wastes nothing;
+//     with a base in scalar registers and a 32-bit offset, no position table, no masks -- a zero value adds nothing; the
+//     upper half line is only written where a tile has more than eight entries (1.2 GB of stores instead of 2);
+//   * gram_rank_kernel ranks the rows of every block of RB = 1024 by their number of entries per tile (counting sort in
+//     LDS): the sixteen rows of a step have the SAME number of entries in tile a, the broadcast loop wastes nothing;
 //   * the entries 8 .. 15 of tile b are not a second pass of that loop: the roles are exchanged for them (the lane keeps its
-//     tile-a entry, the overflow entries of tile b are broadcast: 2-3 rounds instead of another 6-11);
+//     tile-a entries, the overflow entries of tile b are broadcast: 2-3 rounds instead of another 6-11);
 //   * workgroups are dealt to the XCDs by tile neighbourhood (the pairs of a 4 x 4 block of the pair triangle share eight
 //     slabs), chunk by chunk: what one workgroup pulled into the XCD's L2 the others find there.
 // Rows with more than 16 entries in a tile finish from the CSR arrays.  The products and their rounding are those of
 // gram_tile_kernel: the sums are the same integers.
 constexpr int RB = 1024;                 // rows per sorting block
-constexpr int STEPS_PER_BLOCK = RB / 8;  // eight rows per wave step
 constexpr int SORT_BINS = 64;            // entry counts 0 .. 62, 63+ share the last bin
 constexpr int SORT_TILES = 16;           // tiles ranked per pass (one wave scans one tile's bins)
 constexpr int REC = 16;                  // records per (row, tile): 128 bytes
@@ -496,7 +506,7 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_quad_kernel(
   const int rs = lane >> 2, q = lane & 3;  // sixteen rows per step, four lanes each
   const int blk0 = chunk * blocks_per_chunk;
   const int blk1 = min(nblk, blk0 + blocks_per_chunk);
-  const int steps = (blk1 - blk0) * (RB / 16);
+  const int steps = (blk1 - blk0) * (RB / 16);  // sixteen rows per wave step
   const int a0 = a * GT, b0 = b * GT;
   const unsigned short* perm_a = perm + (int64_t)a * n_pad + (int64_t)blk0 * RB;
   // slabs of the two tiles from the chunk's first row on, addressed in bytes by a 32-bit offset

@@ -2719,8 +2719,9 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   // COARSE first stage (bf16 engine; knn_select_reg_block): pays when a query meets so many candidates that few 32 x 32
   // sub-tiles hold one below its threshold -- the sweeps in which the cell bounds prune little.  Decided from the device's own
   // work estimates (tiles within a cell's radius, ivf_cell_order_kernel), weighted by the cells' query blocks: expected
-  // candidates per query >= 1e5 (1M cells: the planted matrix ~3e4 -> plain kernel, the weak / structure-less ones 1e6 -> coarse;
-  // 10M x 4k ~2.5e5 -> coarse).  SCAMD_KNN_COARSE=0 / 1 forces the choice (A/B, tests).
+  // candidates per query >= 5e5 (1M cells: the planted matrix ~3e4 -> plain kernel, the weak / structure-less ones 1e6 -> coarse,
+  // 317 -> 260 ms; 10M planted cells ~2.5e5 -> plain: 795 ms against 835 with the coarse stage, profiles/r06y2_ab.log).
+  // SCAMD_KNN_COARSE=0 / 1 forces the choice (A/B, tests).
   bool coarse = false;
   if constexpr (B3) {
     const char* ce = getenv("SCAMD_KNN_COARSE");
@@ -2735,7 +2736,7 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
         num += (double)h_blk[nc + c] * (double)h_work[c] * 64.0;
         den += (double)h_blk[nc + c];
       }
-      coarse = den > 0.0 && num / den >= 1.0e5;
+      coarse = den > 0.0 && num / den >= 5.0e5;
     }
     if (coarse) kern = knn_select_reg_kernel<H, 64, 3, true, B3, B3>;  // (COARSE = B3: the float32 engine has no such instantiation)
   }

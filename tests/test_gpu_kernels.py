@@ -290,7 +290,10 @@ def test_spmm_long_rows(K):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize(("n", "g", "density"), [(5000, 2000, 0.05), (1234, 77, 0.3), (3000, 300, 0.2), (3, 5, 0.9), (9000, 513, 0.02)])
+# (1234, 77, 0.3) / (3000, 300, 0.2): more than 16 entries per (row, tile), the CSR tail of the packed kernel; (2100, 300, 0.05):
+# three row blocks, the last one partial; (300, 8500, 0.01): more than 64 gene tiles, the round-2 kernel
+@pytest.mark.parametrize(("n", "g", "density"), [(5000, 2000, 0.05), (1234, 77, 0.3), (3000, 300, 0.2), (3, 5, 0.9), (9000, 513, 0.02),
+                                                 (2100, 300, 0.05), (300, 8500, 0.01)])
 def test_csr_gram_bit_exact(K, n, g, density):
     """scamd_csr_gram_f32: integer (fixed point) Gram matrix and column sums, bit-exact against numpy int64."""
     import torch
