@@ -10,6 +10,8 @@
 // instead of ARPACK's one-vector-at-a-time Lanczos.  All kernels are HBM/L2-bound streaming
 // kernels; all reductions have a fixed order (bitwise reproducible run to run).
 #include "common.h"
+
+#include <cstdlib>
 #include "scan.h"
 
 #include <algorithm>
@@ -436,6 +438,87 @@ extern "C" int scamd_csr_transpose_f32(const int64_t* indptr, const int32_t* ind
   return SCAMD_OK;
 }
 
+// Round 6, l <= 64 (the scores of sc.pp.pca): the kernel above issues ONE 200-byte load instruction per stored entry and
+// is bound by the rate of those instructions -- halving the bytes (32 columns) did not move its 1.9 ms (tools/spmm_probe.py).
+// Here a load instruction fetches the B rows of FOUR entries: lane = (entry slot 0..3, column quad 0..15), 16 bytes per lane;
+// the four slots' partial sums meet in a fixed shuffle tree at the end of the row (a different, still fixed, summation order).
+// The last quad of a row of B is shifted back to columns [l - 4, l) so that no lane reads past the row.
+__global__ __launch_bounds__(256) void spmm_rows_quad_f32_kernel(const int64_t* __restrict__ indptr,
+                                                                 const int32_t* __restrict__ indices,
+                                                                 const float* __restrict__ data, int64_t n,
+                                                                 const float* __restrict__ b, int l,
+                                                                 const float* __restrict__ shift, float* __restrict__ y) {
+  constexpr int GU = 4;  // loads in flight per lane: 16 entries of the row (8: 1.65 ms against 1.58)
+  const int lane = threadIdx.x & 63, slot = lane >> 4, cq = lane & 15;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int nquad = (l + 3) / 4;
+  const int col0 = min(4 * min(cq, nquad - 1), l - 4);  // first of the lane's four columns
+  const bool own_quad = cq < nquad;
+  float sh[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) sh[c] = shift ? shift[col0 + c] : 0.f;
+  if (wave >= n) return;
+  int64_t rb = indptr[wave], re = indptr[wave + 1];
+  for (int64_t row = wave; row < n; row += nwaves) {
+    const int64_t nrow = row + nwaves < n ? row + nwaves : row;
+    const int64_t nrb = indptr[nrow], nre = indptr[nrow + 1];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int ci = 0;
+    float cv = 0.f;
+    if (rb + lane < re) {
+      ci = indices[rb + lane];
+      cv = data[rb + lane];
+    }
+    for (int64_t p0 = rb; p0 < re; p0 += 64) {
+      int ci_n = 0;
+      float cv_n = 0.f;
+      if (p0 + 64 + lane < re) {
+        ci_n = indices[p0 + 64 + lane];
+        cv_n = data[p0 + 64 + lane];
+      }
+      const int cnt = (int)std::min<int64_t>(64, re - p0);
+      for (int u = 0; u < cnt; u += 4 * GU) {
+        float4 bv[GU];
+        float vv[GU];
+#pragma unroll
+        for (int t = 0; t < GU; ++t) {
+          // the slot's entry of this round; past the end of the row: the row's last entry with value 0
+          const int e = u + 4 * t + slot;
+          const int ec = min(e, cnt - 1);
+          const int j = __shfl(ci, ec);
+          const float v = __shfl(cv, ec);
+          vv[t] = e < cnt ? v : 0.f;
+          const float* bp = b + (int64_t)j * l + col0;
+          // (rows of B are l * 4 bytes apart: 8-byte alignment at best, so the 16 bytes come as four dwords the compiler may merge)
+          bv[t] = make_float4(bp[0], bp[1], bp[2], bp[3]);
+        }
+#pragma unroll
+        for (int t = 0; t < GU; ++t) {
+          acc[0] = fmaf(vv[t], bv[t].x, acc[0]);
+          acc[1] = fmaf(vv[t], bv[t].y, acc[1]);
+          acc[2] = fmaf(vv[t], bv[t].z, acc[2]);
+          acc[3] = fmaf(vv[t], bv[t].w, acc[3]);
+        }
+      }
+      ci = ci_n;
+      cv = cv_n;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      acc[c] += __shfl_xor(acc[c], 16);
+      acc[c] += __shfl_xor(acc[c], 32);
+    }
+    if (slot == 0 && own_quad) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (col0 + c >= 4 * cq) y[row * l + col0 + c] = acc[c] - sh[c];
+    }
+    rb = nrb;
+    re = nre;
+  }
+}
+
 extern "C" int scamd_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, const float* data, int64_t n,
                                   int64_t g, const float* b, int l, const float* shift, float* y,
                                   scamd_stream_t stream) {
@@ -444,7 +527,13 @@ extern "C" int scamd_spmm_csr_f32(const int64_t* indptr, const int32_t* indices,
                 (long long)n, (long long)g, l);
   if (n == 0) return SCAMD_OK;
   const int blocks = (int)std::min<int64_t>((n + 3) / 4, 256 * 32);
-  if (l <= 64)
+  static const bool quad = [] {  // (A/B knob: SCAMD_SPMM_QUAD=0 runs the one-entry-per-load kernel)
+    const char* e = getenv("SCAMD_SPMM_QUAD");
+    return !(e && e[0] == '0');
+  }();
+  if (l <= 64 && l >= 4 && quad)
+    hipLaunchKernelGGL(spmm_rows_quad_f32_kernel, dim3(blocks), dim3(256), 0, stream, indptr, indices, data, n, b, l, shift, y);
+  else if (l <= 64)
     hipLaunchKernelGGL(spmm_rows_f32_kernel<1>, dim3(blocks), dim3(256), 0, stream, indptr, indices, data, n, b, l,
                        shift, y);
   else if (l <= 128)
