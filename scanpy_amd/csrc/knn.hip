@@ -2125,8 +2125,10 @@ __global__ __launch_bounds__(256) void ivf_assign_mfma_kernel(const float* __res
       if (l31 == 0 && jj < count) {
         const int64_t row = start + jj * step;
         labels[jj] = id;
-        atomicAdd(&counts[id], 1);
-        if (qcounts && row >= q0 && row < q1) atomicAdd(&qcounts[id], 1);
+        if (counts) {  // (the sampled Lloyd iterations; the assignment of every row counts afterwards: ivf_count_kernel)
+          atomicAdd(&counts[id], 1);
+          if (qcounts && row >= q0 && row < q1) atomicAdd(&qcounts[id], 1);
+        }
       }
     }
   }
@@ -2153,18 +2155,70 @@ __global__ void ivf_update_kernel(const long long* __restrict__ sums, const int*
 
 // position of every row in the cell-sorted image (+ of the query rows in the query list); order inside a cell is
 // arbitrary
-__global__ void ivf_scatter_kernel(const int* __restrict__ labels, int64_t n, const int* __restrict__ cell_map,
-                                   const int* __restrict__ row_off, int* __restrict__ row_cur, int64_t q0, int64_t q1,
-                                   const int* __restrict__ slot_off, int* __restrict__ slot_cur, int* __restrict__ perm,
-                                   int* __restrict__ qpos, int* __restrict__ qrow) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int c = cell_map[labels[i]];
-  const int pos = row_off[c] + atomicAdd(&row_cur[c], 1);
-  perm[pos] = (int)i;
-  if (i >= q0 && i < q1) {
-    qpos[slot_off[c] + atomicAdd(&slot_cur[c], 1)] = pos;
-    if (qrow) qrow[i - q0] = pos;  // image row of the query (second tier of the bf16 engine)
+// rows (and query rows) per cell of the final assignment: per-workgroup counters in LDS, one flush per cell and workgroup
+// (the assignment kernel's own two atomics per row on ~500 words were most of its 0.69 ms at 1M rows)
+__global__ __launch_bounds__(1024) void ivf_count_kernel(const int* __restrict__ labels, int64_t n, int n_cells, int64_t q0, int64_t q1,
+                                                        int* __restrict__ counts, int* __restrict__ qcounts) {
+  __shared__ int l_row[IVF_MAX_CELLS], l_q[IVF_MAX_CELLS];
+  for (int c = threadIdx.x; c < n_cells; c += 1024) l_row[c] = 0, l_q[c] = 0;
+  __syncthreads();
+  const int64_t i0 = (int64_t)blockIdx.x * 4096 + threadIdx.x;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int64_t i = i0 + (int64_t)t * 1024;
+    if (i < n) {
+      const int c = labels[i];
+      atomicAdd(&l_row[c], 1);
+      if (i >= q0 && i < q1) atomicAdd(&l_q[c], 1);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < n_cells; c += 1024) {
+    if (l_row[c]) atomicAdd(&counts[c], l_row[c]);
+    if (l_q[c]) atomicAdd(&qcounts[c], l_q[c]);
+  }
+}
+// Round 6: positions through per-workgroup counters in LDS (a workgroup ranks 4096 rows per cell, then takes ONE range per cell
+// from the global cursors): 8 x fewer returning atomics on the ~500 cursor words every row used to hit (0.43 ms at 1M rows).
+// The order of the rows inside a cell is arbitrary either way (the search is exact for any order).
+constexpr int SCATTER_ROWS = 4;  // rows per thread
+__global__ __launch_bounds__(1024) void ivf_scatter_kernel(const int* __restrict__ labels, int64_t n, const int* __restrict__ cell_map,
+                                                          const int* __restrict__ row_off, int* __restrict__ row_cur, int64_t q0, int64_t q1,
+                                                          const int* __restrict__ slot_off, int* __restrict__ slot_cur, int* __restrict__ perm,
+                                                          int* __restrict__ qpos, int* __restrict__ qrow, int n_cells) {
+  __shared__ int l_row[IVF_MAX_CELLS], l_slot[IVF_MAX_CELLS];
+  for (int c = threadIdx.x; c < n_cells; c += 1024) l_row[c] = 0, l_slot[c] = 0;
+  __syncthreads();
+  const int64_t i0 = (int64_t)blockIdx.x * (1024 * SCATTER_ROWS) + threadIdx.x;
+  int cell[SCATTER_ROWS], rk[SCATTER_ROWS], qk[SCATTER_ROWS];
+#pragma unroll
+  for (int t = 0; t < SCATTER_ROWS; ++t) {
+    const int64_t i = i0 + (int64_t)t * 1024;
+    cell[t] = -1, rk[t] = 0, qk[t] = -1;
+    if (i < n) {
+      cell[t] = cell_map[labels[i]];
+      rk[t] = atomicAdd(&l_row[cell[t]], 1);
+      if (i >= q0 && i < q1) qk[t] = atomicAdd(&l_slot[cell[t]], 1);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < n_cells; c += 1024) {
+    const int nr = l_row[c], ns = l_slot[c];
+    l_row[c] = nr ? atomicAdd(&row_cur[c], nr) : 0;
+    l_slot[c] = ns ? atomicAdd(&slot_cur[c], ns) : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < SCATTER_ROWS; ++t) {
+    const int64_t i = i0 + (int64_t)t * 1024;
+    if (cell[t] < 0) continue;
+    const int c = cell[t];
+    const int pos = row_off[c] + l_row[c] + rk[t];
+    perm[pos] = (int)i;
+    if (qk[t] >= 0) {
+      qpos[slot_off[c] + l_slot[c] + qk[t]] = pos;
+      if (qrow) qrow[i - q0] = pos;  // image row of the query (second tier of the bf16 engine)
+    }
   }
 }
 
@@ -2205,8 +2259,21 @@ __global__ void ivf_pack_image_kernel(const float* __restrict__ x, const float* 
   const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
   float wmax = 0.f;
-  for (int64_t r = grp; r < n_img; r += ngrp) {
-    const int src = perm[r];
+  // a group of 16 lanes packs a CONTIGUOUS run of image rows (sorted by cell: one or two cells per run) and keeps the run's
+  // largest centre distance per cell in registers -- one atomic per (group, cell) instead of a read and often an atomic per
+  // row on the same word as every other group working in that cell (round 6: the kernel got SLOWER with more workgroups,
+  // 0.81 / 1.01 / 2.90 ms at 4096 / 16384 / 65536)
+  const int64_t rpg = (n_img + ngrp - 1) / ngrp;
+  const int64_t r_lo = grp * rpg, r_hi = r_lo + rpg < n_img ? r_lo + rpg : n_img;
+  int run_cell = -1;
+  unsigned int run_rb = 0u;
+  auto flush_radius = [&]() {
+    if (sub == 0 && run_cell >= 0 && run_rb > 0u) atomicMax(&radius_bits[run_cell], run_rb);
+  };
+  int src_next = r_lo < r_hi ? perm[r_lo] : -1;
+  for (int64_t r = r_lo; r < r_hi; ++r) {
+    const int src = src_next;
+    src_next = r + 1 < r_hi ? perm[r + 1] : -1;
     double s = 0.0;
     float dc2 = 0.f;
     int cell = 0;
@@ -2245,15 +2312,22 @@ __global__ void ivf_pack_image_kernel(const float* __restrict__ x, const float* 
     }
     if (src >= 0) {
       wmax = fmaxf(wmax, nf);
-      // rows arrive sorted by cell: read before the atomic, the maximum only grows (a stale read costs an atomic, never
-      // loses one)
       const unsigned int rb = __float_as_uint(sqrtf(dc2) * 1.0001f + 1e-6f);
-      if (sub == 0 && rb > radius_bits[cell]) atomicMax(&radius_bits[cell], rb);
+      if (cell != run_cell) {
+        flush_radius();
+        run_cell = cell;
+        run_rb = 0u;
+      }
+      run_rb = max(run_rb, rb);
     }
   }
+  flush_radius();
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
-  if (lane == 0 && wmax > 0.f) atomicMax(cmax_bits, __float_as_uint(wmax));
+  // (read before the atomic: the maximum only grows, a stale read costs an atomic and never loses one -- 16k same-word
+  // atomics, one per wave, were a third of this kernel)
+  if (lane == 0 && wmax > 0.f && __float_as_uint(wmax) > __hip_atomic_load(cmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(cmax_bits, __float_as_uint(wmax));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2553,13 +2627,13 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
     SCAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_assign_mfma_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
   auto run_assign = [&](int64_t a_start, int64_t a_step, int64_t a_count, int accumulate, int64_t aq0, int64_t aq1,
-                        int* a_qcounts) -> int {
+                        int* a_qcounts, bool count_in_kernel = true) -> int {
     if (mfma_assign) {
       hipLaunchKernelGGL(ivf_centpad_bf16_kernel, dim3((unsigned)ceil_div((int64_t)ncp * 32, 256)), dim3(256), 0, s, b.cent, nc, ncp, d,
                          centb);
       SCAMD_LAUNCH_CHECK();
       hipLaunchKernelGGL(ivf_assign_mfma_kernel, dim3((unsigned)ceil_div(a_count, ASSIGN_ROWS)), dim3(256), lds_a, s, x, d, ld, a_start,
-                         a_step, a_count, centb, ncp, nc, b.labels, counts, aq0, aq1, a_qcounts);
+                         a_step, a_count, centb, ncp, nc, b.labels, count_in_kernel ? counts : (int*)nullptr, aq0, aq1, a_qcounts);
       SCAMD_LAUNCH_CHECK();
       if (accumulate) {
         hipLaunchKernelGGL(ivf_sums_kernel, dim3((unsigned)ceil_div(a_count * d, 256)), dim3(256), 0, s, x, d, ld, a_start, a_step,
@@ -2593,8 +2667,13 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   // 2. every row to its cell
   SCAMD_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * 2 * nc, s));
   {
-    const int rca = run_assign(0, 1, n, 0, q_begin, q_begin + n_query, qcounts);
+    const int rca = run_assign(0, 1, n, 0, q_begin, q_begin + n_query, qcounts, !mfma_assign);
     if (rca != SCAMD_OK) return rca;
+    if (mfma_assign) {
+      hipLaunchKernelGGL(ivf_count_kernel, dim3((unsigned)ceil_div(n, 4096)), dim3(1024), 0, s, b.labels, n, nc, q_begin, q_begin + n_query,
+                         counts, qcounts);
+      SCAMD_LAUNCH_CHECK();
+    }
   }
   std::vector<int> h_cnt(2 * nc);
   std::vector<float> h_cent((size_t)nc * d);
@@ -2679,11 +2758,16 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   SCAMD_HIP_CHECK(hipMemsetAsync(b.counters + 2, 0, 16, s));
   SCAMD_HIP_CHECK(hipStreamSynchronize(s));  // the host vectors above must outlive their copies
   // 4. cell-sorted image
-  hipLaunchKernelGGL(ivf_scatter_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, b.labels, n, cell_map, row_off,
-                     row_cur, q_begin, q_begin + n_query, slot_off, slot_cur, b.perm, b.qpos, b.qrow);
+  hipLaunchKernelGGL(ivf_scatter_kernel, dim3((unsigned)ceil_div(n, 1024 * SCATTER_ROWS)), dim3(1024), 0, s, b.labels, n, cell_map, row_off,
+                     row_cur, q_begin, q_begin + n_query, slot_off, slot_cur, b.perm, b.qpos, b.qrow, nc);
   SCAMD_LAUNCH_CHECK();
   {
-    const int blocks = (int)std::min<int64_t>((rows + 3) / 4, 256 * 16);
+    // (a group of 16 lanes per image row, 16 groups per workgroup; SCAMD_KNN_PACK_BLOCKS: A/B of the grid)
+    static const int pack_blocks_env = [] {
+      const char* e = getenv("SCAMD_KNN_PACK_BLOCKS");
+      return e ? atoi(e) : 0;
+    }();
+    const int blocks = (int)std::min<int64_t>((rows + 15) / 16, pack_blocks_env > 0 ? pack_blocks_env : 256 * 16);
     hipLaunchKernelGGL(ivf_pack_image_kernel, dim3(blocks), dim3(256), 0, s, x, b.mu, d, ld, H, C::HP, C::DPL, rows, b.perm,
                        b.labels, cell_map, b.cent, b.xp, b.cmax, b.radius_bits, B3 ? 1 : 0);
     SCAMD_LAUNCH_CHECK();

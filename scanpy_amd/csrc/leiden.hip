@@ -2813,9 +2813,12 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
     const int moved_last = ht[0] - moved_before;  // moves of the previous sweep
     moved_before = ht[0];
     *total_moves = ht[0];
-    if (leiden_debug())
-      fprintf(stderr, "[leiden] lm n=%d sweep=%d classes=%d act=%d moved_prev=%d blocked_total=%d\n", g.n, sweep, n_cls, n_act,
-              moved_last, ht[1]);
+    if (leiden_debug()) {
+      int tot_mid = 0, tot_hub = 0;
+      for (int c = 0; c < n_cls; ++c) tot_mid += hc[MAX_CLASSES + CTR_STRIDE * c + CTR_N_MID], tot_hub += hc[MAX_CLASSES + CTR_STRIDE * c + CTR_N_HUB];
+      fprintf(stderr, "[leiden] lm n=%d sweep=%d classes=%d act=%d moved_prev=%d blocked_total=%d long rows: mid %d hub %d\n", g.n, sweep,
+              n_cls, n_act, moved_last, ht[1], tot_mid, tot_hub);
+    }
     if (n_act == 0) break;
     ++g_ld_stats[8];
     g_ld_sweep_bytes += (double)n_act * (12.0 * (double)g.nnz / (double)std::max(g.n, 1) + 16.0);
