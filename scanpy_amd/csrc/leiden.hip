@@ -36,6 +36,30 @@ namespace scamd {
 //     active rows x (12 B per entry + 16 B per vertex), SURVEY.md 8(d)'s per-sweep figure restricted to the rows a sweep visits,
 // [10] communities the polish split off because a departure had cut them in two, [11] 1 if the iteration cap ended the run,
 // [12] 1 if a polish pass stopped at MAX_POLISH_ROUNDS (node optimality then NOT proven), [13] the iteration cap in force
+// register budgets of the decision kernels (second launch bound = waves per SIMD the compiler must fit; A/B builds: -D...)
+#ifndef SCAMD_LD_PROPOSE_WAVES
+#define SCAMD_LD_PROPOSE_WAVES 0
+#endif
+#ifndef SCAMD_LD_MOVE_WAVES
+#define SCAMD_LD_MOVE_WAVES 0
+#endif
+#if SCAMD_LD_PROPOSE_WAVES > 0
+#define SCAMD_LD_PROPOSE_LB __launch_bounds__(256, SCAMD_LD_PROPOSE_WAVES)
+#else
+#define SCAMD_LD_PROPOSE_LB __launch_bounds__(256)
+#endif
+#if SCAMD_LD_MOVE_WAVES > 0
+#define SCAMD_LD_MOVE_LB __launch_bounds__(256, SCAMD_LD_MOVE_WAVES)
+#else
+#define SCAMD_LD_MOVE_LB __launch_bounds__(256)
+#endif
+// table slots of a vertex of the sixteen-lanes-per-vertex kernels (the kNN graph itself); rows longer than 3/4 of them go to
+// the wave-per-vertex tier
+#ifndef SCAMD_LD_G16_SLOTS
+#define SCAMD_LD_G16_SLOTS 128
+#endif
+constexpr int G16_SLOTS = SCAMD_LD_G16_SLOTS;
+constexpr int G16_MAX = G16_SLOTS * 3 / 4;
 constexpr int LD_NSTATS = 16;
 static thread_local int g_ld_stats[LD_NSTATS] = {0};
 static thread_local double g_ld_sweep_bytes = 0.0;  // -> stats[9] (MB)
@@ -133,7 +157,7 @@ __global__ __launch_bounds__(1024) void ld_degstats_kernel(const int64_t* __rest
   __syncthreads();
   int v = blockIdx.x * blockDim.x + threadIdx.x;
   int d = (v < n) ? (int)(indptr[v + 1] - indptr[v]) : 0;
-  const unsigned long long m1 = __ballot(d > 96), m2 = __ballot(d > 192), m3 = __ballot(d > 384);
+  const unsigned long long m1 = __ballot(d > G16_MAX), m2 = __ballot(d > 192), m3 = __ballot(d > 384);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) d = max(d, __shfl_xor(d, o));
   if ((threadIdx.x & 63) == 0 && d > 0) {
@@ -497,7 +521,7 @@ __device__ __forceinline__ void ld_move_body(int bid, int nblk, const MoveArgs& 
   int* __restrict__ hub_list = ma.hub_list;
   int* __restrict__ counters = ma.counters;
   constexpr int GROUPS = 256 / G;            // vertices per workgroup
-  constexpr int GSLOTS = WH_SLOTS * G / 64;  // table slots per vertex
+  constexpr int GSLOTS = G == 16 ? G16_SLOTS : WH_SLOTS * G / 64;  // table slots per vertex
   constexpr int GMAX = GSLOTS * 3 / 4;       // longest row the table takes
   __shared__ int hkeys[GROUPS][GSLOTS];
   __shared__ unsigned long long hvals[GROUPS][GSLOTS];
@@ -633,7 +657,7 @@ __device__ __forceinline__ void ld_move_body(int bid, int nblk, const MoveArgs& 
   }
 }
 template <int G>
-__global__ __launch_bounds__(256) void ld_move_kernel(
+__global__ SCAMD_LD_MOVE_LB void ld_move_kernel(
     int n_act, const int* __restrict__ list, const int* __restrict__ sub_list, const int* __restrict__ sub_count,
     const int64_t* __restrict__ indptr, const int* __restrict__ indices, const long long* __restrict__ wq,
     const long long* __restrict__ k, const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot,
@@ -835,7 +859,7 @@ __global__ __launch_bounds__(256) void ld_requeue_kernel(int n_act, const int* _
 // write their own buffer and lists.  The first nb_rq workgroups re-queue, the rest decide.  One launch of ~16 us less per
 // sub-round (152 per call at 1M cells).
 template <int G>
-__global__ __launch_bounds__(256) void ld_requeue_move_kernel(int nb_rq, int rq_n_act, const int* __restrict__ rq_list,
+__global__ SCAMD_LD_MOVE_LB void ld_requeue_move_kernel(int nb_rq, int rq_n_act, const int* __restrict__ rq_list,
                                                               const int* __restrict__ rq_decision,
                                                               const int64_t* __restrict__ indptr,
                                                               const int* __restrict__ indices, const int* __restrict__ comm,
@@ -1190,7 +1214,7 @@ __device__ __forceinline__ double refine_noise(int v, int c, int round, unsigned
 // `list` holds the candidates of class `round` (the sub-round's number).  target[v] = refined community to join,
 // -1 = no admissible target, -2 = no longer a singleton (somebody joined it) or "stay" was drawn.
 template <int G>
-__global__ __launch_bounds__(256) void ld_refine_propose_kernel(
+__global__ SCAMD_LD_PROPOSE_LB void ld_refine_propose_kernel(
     const int* __restrict__ list, const int* __restrict__ sub_list, const int* __restrict__ sub_count,
     const int64_t* __restrict__ indptr, const int* __restrict__ indices, const long long* __restrict__ wq,
     const long long* __restrict__ k, const int* __restrict__ comm, const unsigned long long* __restrict__ Ktot,
@@ -1200,7 +1224,7 @@ __global__ __launch_bounds__(256) void ld_refine_propose_kernel(
     int* __restrict__ ovf_list, int* __restrict__ hub_list, int* __restrict__ counters, int n_cand,
     const VertRec* __restrict__ vr, const TargRec* __restrict__ tr) {
   constexpr int GROUPS = 256 / G;
-  constexpr int GSLOTS = WH_SLOTS * G / 64;
+  constexpr int GSLOTS = G == 16 ? G16_SLOTS : WH_SLOTS * G / 64;
   constexpr int GMAX = GSLOTS * 3 / 4;
   __shared__ int hkeys[GROUPS][GSLOTS];
   __shared__ unsigned long long hvals[GROUPS][GSLOTS];
@@ -2749,7 +2773,7 @@ static int quality(LeidenCtx& cx, const LevelGraph& g, const int* comm, double* 
 }
 
 // levels whose rows are short on average (the kNN graph itself) take the four-vertices-per-wave kernels
-static_assert(WH_SLOTS / 4 * 3 / 4 == 96 && WH_SLOTS / 2 * 3 / 4 == 192 && WH_MAX_DEG == 384,
+static_assert(WH_SLOTS / 2 * 3 / 4 == 192 && WH_MAX_DEG == 384,
               "ld_degstats_kernel counts the rows beyond the 128- / 256- / 512-slot tables");
 // lanes per vertex of the decision kernels for this level: 16 (four vertices per wave, rows <= 96), 32 (two per wave,
 // rows <= 192: the first coarse levels, ~64 entries per row) or 64.  SCAMD_LEIDEN_QUAD = 0 / 1 / 2 forces 64 / 16 / 32.
@@ -2789,7 +2813,7 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
   int rc = compute_totals(cx, g, b.comm, Filler().add(b.flag, sizeof(int) * n).add(b.counters, sizeof(int) * 8).add(b.rcounters, sizeof(int) * CTR_AREA));
   if (rc != SCAMD_OK) return rc;
   const int lanes = level_lanes(g);
-  const int thr_mid = lanes == 16 ? (int)(WH_SLOTS / 4 * 3 / 4) : (lanes == 32 ? (int)(WH_SLOTS / 2 * 3 / 4) : -1);
+  const int thr_mid = lanes == 16 ? (int)G16_MAX : (lanes == 32 ? (int)(WH_SLOTS / 2 * 3 / 4) : -1);
   const int n_cls_level = lm_classes(cx, g.n);
   int n_act_prev = g.n;
   int moved_before = 0, quiet = 0, moved_prev2 = 0;
@@ -2990,7 +3014,7 @@ static int polish_level0(LeidenCtx& cx, const LevelGraph& g, int* stats) {
                                               .add(b.rcounters, sizeof(int) * CTR_AREA));
   if (rc != SCAMD_OK) return rc;  // (cx.b lives for this call only: an error return need not swap back)
   const int lanes = level_lanes(g);
-  const int thr_mid = lanes == 16 ? (int)(WH_SLOTS / 4 * 3 / 4) : (lanes == 32 ? (int)(WH_SLOTS / 2 * 3 / 4) : -1);
+  const int thr_mid = lanes == 16 ? (int)G16_MAX : (lanes == 32 ? (int)(WH_SLOTS / 2 * 3 / 4) : -1);
   unsigned int round = 0, area = 0;  // (the rounds alternate between the two counter areas, as the sweeps of the local moving do)
   int moved_before = 0, moved_at_full = 0;
   int checked_at = 0;  // moves + splits when the communities were last known to be connected (the input is: an iteration's result)
@@ -3103,7 +3127,7 @@ static int refinement(LeidenCtx& cx, const LevelGraph& g, int* n_merged) {
   SCAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(ld_refine_candidates_kernel, dim3((unsigned)ceil_div(g.n, 1024)), dim3(1024), 0, cx.s, g.n, g.k,
                      b.comm, b.Ktot, b.a_in, gg, b.cls_lists, rc0, n_cls, salt, g.indptr,
-                     quad ? (int)(WH_SLOTS / 4 * 3 / 4) : -1, (int)WH_MAX_DEG);
+                     quad ? (int)G16_MAX : -1, (int)WH_MAX_DEG);
   SCAMD_LAUNCH_CHECK();
   LD_DBG_SYNC(cx, "rf candidates n=%d classes=%d", g.n, n_cls);
   int hc[CTR_AREA];  // class list lengths, then per sub-round [CTR_N_MID] / [CTR_N_HUB] (ld_refine_candidates_kernel)
