@@ -790,6 +790,11 @@ static GramCarve gram_carve(Workspace& ws, int64_t n, int64_t ntile) {
   c.mx = ws.take<unsigned int>(4);
   return c;
 }
+// The packed kernels are built around <= 8 entries per (row, tile) with a tail up to 16: measured at 200k x 2k, 6.4 / 10.2 /
+// 15.4 / 25.6 entries per tile (5 / 8 / 12 / 20 % dense): 1.33 / 4.13 / 12.0 / 33.7 ms against 2.47 / 3.57 / 6.49 / 14.1 ms of
+// the round-2 kernel (tools/gram_density_probe.py) -- denser matrices keep the round-2 kernel (its uint16 tile pointers fit
+// the records' space).
+static bool gram_sparse_enough(int64_t n, int64_t ntile, int64_t nnz) { return (double)nnz <= 8.0 * (double)n * (double)ntile; }
 
 extern "C" size_t scamd_csr_gram_workspace_bytes(int64_t n, int64_t g) {
   if (n <= 0 || g <= 0) return 0;
@@ -811,8 +816,12 @@ extern "C" int scamd_csr_gram_f32(const int64_t* indptr, const int32_t* indices,
   const int nblk = (int)((n + RB - 1) / RB);
   const int64_t n_pad = (int64_t)nblk * RB;
   Workspace ws(workspace, workspace_bytes);
-  const GramCarve cv = gram_carve(ws, n, ntile);
+  GramCarve cv = gram_carve(ws, n, ntile);
   unsigned int* mx = cv.mx;
+  if (cv.packed && !gram_sparse_enough(n, ntile, nnz)) {
+    cv.packed = false;
+    cv.ptr = reinterpret_cast<unsigned short*>(cv.ent);  // n x (ntile + 1) uint16 <= the records' n_pad x ntile x 128 bytes
+  }
   SCAMD_REQUIRE(workspace && ws.ok, SCAMD_EWORKSPACE, "gram: workspace %zu < required %zu", workspace_bytes, ws.used());
   hipStream_t s = stream;
   if (absmax_host) {  // phase 1: max |x| (the caller derives scale_bits from it, possibly after a max all-reduce)

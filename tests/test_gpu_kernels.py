@@ -290,7 +290,7 @@ def test_spmm_long_rows(K):
 
 
 @pytest.mark.gpu
-# (1234, 77, 0.3) / (3000, 300, 0.2): more than 16 entries per (row, tile), the CSR tail of the packed kernel; (2100, 300, 0.05):
+# (1234, 77, 0.3) / (3000, 300, 0.2): more than 8 entries per (row, tile) on average, the round-2 kernel; (2100, 300, 0.05):
 # three row blocks, the last one partial; (300, 8500, 0.01): more than 64 gene tiles, the round-2 kernel
 @pytest.mark.parametrize(("n", "g", "density"), [(5000, 2000, 0.05), (1234, 77, 0.3), (3000, 300, 0.2), (3, 5, 0.9), (9000, 513, 0.02),
                                                  (2100, 300, 0.05), (300, 8500, 0.01)])
@@ -324,6 +324,42 @@ def test_csr_gram_bit_exact(K, n, g, density):
     # determinism: the accumulation order is arbitrary, the integers are not
     gq2, _ = K.csr_gram(ip, ix, dv, n, g, sb)
     np.testing.assert_array_equal(gq2.cpu().numpy(), gq)
+
+
+@pytest.mark.gpu
+def test_csr_gram_rows_with_crowded_tiles(K):
+    """A matrix that is sparse on average (the packed kernels take it) with rows that crowd a 128-gene tile: 17 .. 128 entries in
+    one tile finish from the CSR arrays, next to rows with 9 .. 16 (the exchanged-roles rounds) and empty rows."""
+    import torch
+    from scipy import sparse
+
+    rng = np.random.default_rng(11)
+    n, g, sb = 2500, 300, 30
+    x = sparse.random(n, g, density=0.03, random_state=rng, format="lil", dtype=np.float32)
+    for r in rng.choice(n, size=120, replace=False):
+        t0 = 128 * int(rng.integers(0, 3))
+        width = min(128, g - t0)
+        cnt = int(rng.integers(9, width + 1))
+        cols = t0 + rng.choice(width, size=cnt, replace=False)
+        x[r, cols] = 1.0
+    x = x.tocsr()
+    x[rng.choice(n, size=50, replace=False)] = 0  # empty rows
+    x.eliminate_zeros()
+    x.data = np.log1p(np.exp(rng.standard_normal(x.nnz))).astype(np.float32)
+    x.sort_indices()
+    assert x.nnz <= 8 * n * 3  # the packed kernels' side of the dispatch
+    ip = torch.from_numpy(x.indptr.astype(np.int64)).cuda()
+    ix = torch.from_numpy(x.indices.astype(np.int32)).cuda()
+    dv = torch.from_numpy(x.data).cuda()
+    gq, cq = K.csr_gram(ip, ix, dv, n, g, sb)
+    gq, cq = gq.cpu().numpy(), cq.cpu().numpy()
+    xd = x.astype(np.float64).toarray()
+    ref = np.zeros((g, g), dtype=np.int64)
+    for row in xd:
+        nz = np.flatnonzero(row)
+        ref[np.ix_(nz, nz)] += np.rint(np.outer(row[nz], row[nz] * 2.0**sb)).astype(np.int64)
+    np.testing.assert_array_equal(gq[:g, :g], ref)
+    np.testing.assert_array_equal(cq[:g], np.rint(xd * 2.0**sb).astype(np.int64).sum(axis=0))
 
 
 @pytest.mark.gpu
