@@ -2750,11 +2750,17 @@ static int compute_totals(LeidenCtx& cx, const LevelGraph& g, const int* comm, F
 // quality of `comm` on level graph g (needs Ktot up to date): modularity, or the CPM objective in the same units
 // (b.total[1], the accumulator of the internal weight, was zeroed by the ld_totals_kernel launch of compute_totals)
 static int quality(LeidenCtx& cx, const LevelGraph& g, const int* comm, double* q) {
+  // (a group walks its vertices one after the other, three dependent loads each: the more groups, the fewer steps of that
+  // walk -- and one same-word atomic per workgroup at the end; SCAMD_LEIDEN_QUALITY_GRID: A/B)
+  static const int qgrid = [] {
+    const char* e = getenv("SCAMD_LEIDEN_QUALITY_GRID");
+    return e ? std::max(64, atoi(e)) : 2048;
+  }();
   if (g.nnz <= (int64_t)48 * g.n)
-    hipLaunchKernelGGL(ld_internal_kernel<16>, dim3((unsigned)std::min(2048, ceil_div(g.n, 16))), dim3(256), 0, cx.s, g.n,
+    hipLaunchKernelGGL(ld_internal_kernel<16>, dim3((unsigned)std::min(qgrid, ceil_div(g.n, 16))), dim3(256), 0, cx.s, g.n,
                        g.indptr, g.indices, g.wq, comm, cx.b.total + 1);
   else
-    hipLaunchKernelGGL(ld_internal_kernel<64>, dim3((unsigned)std::min(2048, ceil_div(g.n, 4))), dim3(256), 0, cx.s, g.n,
+    hipLaunchKernelGGL(ld_internal_kernel<64>, dim3((unsigned)std::min(qgrid, ceil_div(g.n, 4))), dim3(256), 0, cx.s, g.n,
                        g.indptr, g.indices, g.wq, comm, cx.b.total + 1);
   SCAMD_LAUNCH_CHECK();
   // (CPM: sum of squared community SIZES, unnormalised)
