@@ -2797,9 +2797,20 @@ static bool level_is_short_rowed(const LevelGraph& g) { return level_lanes(g) ==
 // class sub-rounds per sweep: 8 everywhere.  (4 / 2 on levels below 16384 / 1024 vertices saved ~1 ms of launch latency
 // per call, but the fewer the classes the more neighbours move at once: on the 700-cell fixture one seed in ten then
 // ended in a worse optimum, Q 0.8101 against the oracle's minimum 0.8120.)
+// Round 6, large levels: FOUR.  At 1M cells (five seeds, profiles/r06zb_leiden_classes.log) 8 / 4 / 2 classes take 457 / 413 / 390 ms
+// on the weak graph at Q 0.83960 / 0.83969 / 0.84037 (means), 877 / 794 / 781 ms without structure at Q 0.3318 / 0.3327 / 0.3335,
+// 26.6 / 25.2 / 26.5 ms on the planted one (same partition): a vertex of a kNN graph with 10^5 and more vertices has two dozen
+// neighbours, half of which deciding on the same snapshot costs nothing the next sweep does not repair -- it is the SMALL levels
+// where fewer classes lose quality (see rf_classes; with four classes from 65536 vertices on, the 100k weak sample of the bench
+// fell below its agreement gate against the oracle: median ARI over seed pairs 0.02 under the oracle's own).  Four from 262144
+// vertices on; SCAMD_LEIDEN_LM_BIG_N moves that size (0: eight everywhere).
 static int lm_classes(const LeidenCtx& cx, int n) {
-  (void)n;
-  return cx.lm_classes > 0 ? cx.lm_classes : DEF_CLASSES;
+  static const int big_n = [] {
+    const char* e = getenv("SCAMD_LEIDEN_LM_BIG_N");
+    return e ? atoi(e) : 262144;
+  }();
+  if (cx.lm_classes > 0) return cx.lm_classes;
+  return (big_n > 0 && n >= big_n) ? 4 : DEF_CLASSES;
 }
 // (refinement: a singleton cannot join a singleton of its OWN class -- with 8 classes an eighth of the targets the
 // sequential algorithm would see are excluded, which on small graphs costs quality: 700-cell fixture over 30 seeds, runs
