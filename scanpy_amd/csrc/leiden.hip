@@ -2662,7 +2662,10 @@ struct LeidenCtx {
   double inv_beta = 0.0;  // 1 / (beta * 2^32): randomness of the refinement's merge rule (0 = greedy)
   int iter = 0;           // outer iteration: part of the refinement's noise seed
   unsigned int seed;
-  int lm_stop_permille = 20;  // local moving of a level stops once < 2 % of its vertices move in a sweep
+  int lm_stop_permille = 20;  // local moving of a level stops once < 2 % of its vertices move in a sweep (first iteration)
+  int lm_stop_permille_big = 40;  // ... < 4 % on the levels that run four classes per sweep (lm_classes): 0.9 ms / 11 ms faster on the
+                                  // planted / weak 1M graph at the same Q / inside the seeds' spread (profiles/r06ze_lm_stop_with_4_classes.log);
+                                  // everywhere, one seed of the 700-cell fixture fell out of the oracle's seed distribution
   int lm_classes = 0;         // class sub-rounds per local-moving sweep (0 = by level size; SCAMD_LEIDEN_LM_CLASSES)
   int rf_classes = 0;         // class sub-rounds of the refinement (0 = by level size; SCAMD_LEIDEN_RF_CLASSES)
   bool small_levels = true;   // levels of <= SMALL_N nodes in one workgroup (SCAMD_LEIDEN_SMALL=0: separate kernels)
@@ -2876,7 +2879,7 @@ static int local_moving(LeidenCtx& cx, const LevelGraph& g, int* total_moves) {
       // coalesce one boundary vertex at a time -- exactly the work that is cheaper one level up.  A sweep that does not
       // move at least a tenth fewer vertices than the one before it ends the level (first outer iteration only).
       if (cx.iter == 0 && sweep >= 2) {
-        if ((long long)moved_last * 1000 < (long long)g.n * cx.lm_stop_permille) break;
+        if ((long long)moved_last * 1000 < (long long)g.n * (n_cls_level < DEF_CLASSES ? cx.lm_stop_permille_big : cx.lm_stop_permille)) break;
         if (sweep >= 3 && (long long)moved_last * 10 > (long long)moved_prev2 * 9) break;
       }
       moved_prev2 = moved_last;
@@ -3601,7 +3604,7 @@ static int leiden_run(const int64_t* indptr, const int32_t* indices, const float
   cx.gamma = resolution;
   cx.inv_beta = beta > 0.0 ? 1.0 / (beta * WSCALE) : 0.0;  // beta <= 0: the greedy limit (largest gain, no "stay")
   cx.seed = (unsigned int)(seed ^ (seed >> 32)) * 0x9E3779B1u + 0x632BE5ABu;
-  if (const char* e = getenv("SCAMD_LEIDEN_LM_STOP_PERMILLE")) cx.lm_stop_permille = atoi(e);
+  if (const char* e = getenv("SCAMD_LEIDEN_LM_STOP_PERMILLE")) cx.lm_stop_permille = cx.lm_stop_permille_big = atoi(e);
   cx.lm_classes = classes_env("SCAMD_LEIDEN_LM_CLASSES");
   cx.rf_classes = classes_env("SCAMD_LEIDEN_RF_CLASSES");
   if (const char* e = getenv("SCAMD_LEIDEN_SMALL")) cx.small_levels = e[0] != '0';
