@@ -2813,7 +2813,13 @@ static int lm_classes(const LeidenCtx& cx, int n) {
     return e ? atoi(e) : 262144;
   }();
   if (cx.lm_classes > 0) return cx.lm_classes;
-  return (big_n > 0 && n >= big_n) ? 4 : DEF_CLASSES;
+  static const int later_cls = [] {  // (A/B knob: classes of the large levels in the iterations after the first)
+    const char* e = getenv("SCAMD_LEIDEN_LM_LATER_CLASSES");
+    const int v = e ? atoi(e) : 4;
+    return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 4;
+  }();
+  if (big_n > 0 && n >= big_n) return cx.iter >= 1 ? later_cls : 4;
+  return DEF_CLASSES;
 }
 // (refinement: a singleton cannot join a singleton of its OWN class -- with 8 classes an eighth of the targets the
 // sequential algorithm would see are excluded, which on small graphs costs quality: 700-cell fixture over 30 seeds, runs
