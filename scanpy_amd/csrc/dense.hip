@@ -729,7 +729,14 @@ static int dense_topk(DenseCtx& cx, int k, unsigned int seed, double tol, int* n
   double h_rq[3] = {0.0, 0.0, 0.0};
   SCAMD_READBACK_NOW(h_rq, d.resid, sizeof(double) * 3, cx.s);
   if (h_rq[2] > h_rq[1] && h_rq[1] > 0.0) {
-    rc = filter(v, av, h_rq[1], h_rq[2], 8);
+    // degree of the first filter: 7 (8 until round 6).  On the bench's matrix 8 / 7 / 6 / 5 leave the residual at 4.5e-11 / 4.6e-10 /
+    // 4.8e-9 / 5e-8 against the tolerance 2e-8: 8 buys nothing but a block so ill-conditioned that CholeskyQR needs a second
+    // shifted round (pca_fit 9.76 / 9.45 / 9.35 ms; 5: a second outer iteration).  SCAMD_DENSE_FIRST_DEGREE: A/B.
+    static const int first_degree = [] {
+      const char* e = getenv("SCAMD_DENSE_FIRST_DEGREE");
+      return e ? std::max(2, std::min(16, atoi(e))) : 7;
+    }();
+    rc = filter(v, av, h_rq[1], h_rq[2], first_degree);
     if (rc != SCAMD_OK) return rc;
     rc = cholqr2(cx, z, tmp, y0, true);
     if (rc != SCAMD_OK) return rc;
