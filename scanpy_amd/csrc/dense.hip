@@ -591,13 +591,13 @@ static constexpr size_t JAC_LDS = (size_t)(DB_MAX * DB_LD + DB_MAX) * sizeof(dou
 // orthonormal noise, as they do from a Householder QR.  zin and tmp are overwritten; zin, tmp, zout are distinct panels.
 // filtered = the block comes out of a Chebyshev filter: its plain first round fails (kappa 1e16 and beyond: the solve of the
 // bench spent two Cholesky launches and their read-backs on finding that out), so the first round is a shifted one at once
-static int cholqr2(DenseCtx& cx, double* zin, double* tmp, double* zout, bool filtered = false) {
+static int cholqr2(DenseCtx& cx, double* zin, double* tmp, double* zout, bool filtered = false, int plain_rounds = 2) {
   const int g = cx.g, b = cx.b;
   double* cur = zin;
   double* other = tmp;
   int plain_ok = 0, shifted_rounds = 0;
   const double s0 = 11.0 * ((double)g * b + (double)b * (b + 1)) * 2.220446049250313e-16 * b;
-  while (plain_ok < 2) {
+  while (plain_ok < plain_rounds) {
     int rc = dgemm_tn(cx.s, cur, b, cur, b, b, b, g, 1.0, nullptr, 0, 0.0, nullptr, 0, 0.0, cx.d.gm, b);
     if (rc != SCAMD_OK) return rc;
     double shift = (filtered && plain_ok == 0 && shifted_rounds == 0 && cx.shift_first) ? s0 : 0.0;
@@ -614,7 +614,7 @@ static int cholqr2(DenseCtx& cx, double* zin, double* tmp, double* zout, bool fi
       ++cx.n_chol_retry;
     }
     const bool was_shifted = shift > 0.0;
-    double* dst = (!was_shifted && plain_ok == 1) ? zout : other;
+    double* dst = (!was_shifted && plain_ok == plain_rounds - 1) ? zout : other;
     hipLaunchKernelGGL(panel_small_kernel, dim3((g + 7) / 8), dim3(256), 0, cx.s, cur, cx.d.s, g, b, b, dst);
     SCAMD_LAUNCH_CHECK();
     if (dst == other) std::swap(cur, other);
@@ -715,7 +715,14 @@ static int dense_topk(DenseCtx& cx, int k, unsigned int seed, double tol, int* n
   rc = dgemm_tn(cx.s, cx.a, cx.lda, y1, b, g, b, g, 1.0, nullptr, 0, 0.0, nullptr, 0, 0.0, z, b);
   if (rc != SCAMD_OK) return rc;
   cx.n_gemm += 2;
-  rc = cholqr2(cx, z, tmp, v);
+  // (ONE plain round here: the block has been through two power steps, kappa ~ (lambda_1 / lambda_b)^2, and serves for the
+  // Rayleigh quotients that bound the first filter and as that filter's start -- orthonormal to ~kappa^2 u is enough for both;
+  // the block is orthonormalised properly after the filter.  SCAMD_DENSE_FIRST_QR_ROUNDS=2: as until round 6)
+  static const int first_rounds = [] {
+    const char* e = getenv("SCAMD_DENSE_FIRST_QR_ROUNDS");
+    return (e && e[0] == '2') ? 2 : 1;
+  }();
+  rc = cholqr2(cx, z, tmp, v, false, first_rounds);
   if (rc != SCAMD_OK) return rc;
   // First filter straight on this basis, bounds from its Rayleigh quotients: a Rayleigh-Ritz here would only re-mix
   // the block (the filter does not care) at the price of one more 128 x 128 eigenproblem, the most expensive kernel of
