@@ -2655,7 +2655,11 @@ static int run_ivf_select(const KnnPlan& p, const KnnBuffers& b, const float* x,
   SCAMD_LAUNCH_CHECK();
   const int64_t n_sample = std::min<int64_t>(n, (int64_t)64 * nc);
   const int64_t step = n / n_sample;
-  for (int it = 0; it < 3; ++it) {
+  static const int lloyd_iters = [] {  // (A/B knob; 3 since round 1)
+    const char* e = getenv("SCAMD_KNN_LLOYD_ITERS");
+    return e ? std::max(0, std::min(16, atoi(e))) : 3;
+  }();
+  for (int it = 0; it < lloyd_iters; ++it) {
     SCAMD_HIP_CHECK(hipMemsetAsync(b.sums, 0, sizeof(long long) * nc * d, s));
     SCAMD_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * nc, s));
     const int rca = run_assign(0, step, n_sample, 1, 0, 0, nullptr);
