@@ -8,7 +8,7 @@ for B in ${@:-4096 16384 65536}; do
   [ -n "$f" ] && python - "$f" <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if any(k in r["Name"] for k in ("ivf_pack_image", "ivf_scatter", "ivf_assign_mfma", "knn_select", "rerank_rows")):
+    if any(k in r["Name"] for k in ("ivf_pack_image", "ivf_scatter", "ivf_assign_mfma", "knn_select", "rerank_rows", "fallback")):
         print(f"{float(r['AverageNs']) / 1e3:9.1f} us x {r['Calls']:>3}  {r['Name'][:60]}")
 PY
 done
