@@ -1720,11 +1720,16 @@ __global__ __launch_bounds__(256) void knn_rerank_rows_kernel(
   __builtin_amdgcn_wave_barrier();
 
   const float* myq = qrows + half * RS;
-  double qn = 0.0;  // ||fl(q - mu)||^2: the norm of the query's image row (the thresholds live in that frame)
-  for (int c = 0; c < d; ++c) {
+  // ||fl(q - mu)||^2: the norm of the query's image row (the thresholds live in that frame).  The 32 lanes of the query's half
+  // share the coordinates and meet in a fixed butterfly (every lane used to walk all d of them: a quarter of the kernel's
+  // instructions for one number per query)
+  double qn = 0.0;
+  for (int c = l31; c < d; c += 32) {
     const double qc = (double)__fsub_rn(myq[c], mu[c]);
     qn += qc * qc;
   }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
   double myd = INFINITY;
   int myi = -1;
   if (ci >= 0) {
