@@ -438,6 +438,7 @@ extern "C" int scamd_csr_transpose_f32(const int64_t* indptr, const int32_t* ind
   return SCAMD_OK;
 }
 
+namespace scamd {
 // Round 6, l <= 64 (the scores of sc.pp.pca): the kernel above issues ONE 200-byte load instruction per stored entry and
 // is bound by the rate of those instructions -- halving the bytes (32 columns) did not move its 1.9 ms (tools/spmm_probe.py).
 // Here a load instruction fetches the B rows of FOUR entries: lane = (entry slot 0..3, column quad 0..15), 16 bytes per lane;
@@ -518,6 +519,8 @@ __global__ __launch_bounds__(256) void spmm_rows_quad_f32_kernel(const int64_t* 
     re = nre;
   }
 }
+
+}  // namespace scamd
 
 extern "C" int scamd_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, const float* data, int64_t n,
                                   int64_t g, const float* b, int l, const float* shift, float* y,
