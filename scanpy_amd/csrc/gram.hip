@@ -851,8 +851,8 @@ extern "C" int scamd_csr_gram_f32(const int64_t* indptr, const int32_t* indices,
   // one workgroup per CU (the 128 KB tile), equal items: the launch runs in rounds of 256 workgroups, and a last round that
   // is half empty costs half a round -- 136 pairs x 16 chunks = 8.5 rounds: 6.90 ms, x 15 = 7.97 rounds: 6.57 ms
   // (profiles/r05v_gram_chunks.log; 17 chunks = 9.03 rounds: 7.15 ms).  The count near ~8 items per CU that wastes least:
-  auto pick_chunks = [&](int64_t most) -> int {  // most: the largest count that leaves a chunk ~4096 rows
-    int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(most, (256 * 8 + npair - 1) / npair));
+  auto pick_chunks = [&](int64_t most, int per_cu = 8) -> int {  // most: the largest count that leaves a chunk ~4096 rows
+    int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(most, (256 * per_cu + npair - 1) / npair));
     const int hi = (int)std::min<int64_t>(most, n_chunks + 4);
     double best = 1e9;
     for (int c = std::max(1, n_chunks - 4); c <= hi; ++c) {
@@ -870,7 +870,10 @@ extern "C" int scamd_csr_gram_f32(const int64_t* indptr, const int32_t* indices,
     SCAMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(gram_rank_kernel, dim3((unsigned)nblk), dim3(RB), 0, s, cv.cnt8, ntile, cv.perm, n_pad);
     SCAMD_LAUNCH_CHECK();
-    int n_chunks = pick_chunks(std::max(1, (nblk + 3) / 4));
+    // (the packed sweep likes ~24 items per CU, three times the round-2 kernel's: 8 / 15 / 30 / 45 / 60 / 98 / 163 chunks at 1M x 2k
+    // take 4.86 / 4.44 / 4.36 / 4.20-4.26 / 4.24 / 4.56 / 5.30 ms for the entry -- shorter items even out the XCD queues' tails,
+    // until the 128 KB flush per item shows)
+    int n_chunks = pick_chunks(std::max(1, (nblk + 3) / 4), 24);
     if (const char* e = getenv("SCAMD_GRAM_CHUNKS")) n_chunks = std::max(1, std::min(nblk, atoi(e)));  // (A/B knob)
     const int blocks_per_chunk = (nblk + n_chunks - 1) / n_chunks;
     n_chunks = (nblk + blocks_per_chunk - 1) / blocks_per_chunk;
